@@ -1,0 +1,262 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  extern "C" surface of the CPU restatement (see sdvl_oracle.h).
+// PARITY UNPINNED (see ref_math.h).
+#include "sdvl_oracle.h"
+
+#include <cstring>
+#include <vector>
+
+#include "ref_align.h"
+#include "ref_detect.h"
+#include "ref_math.h"
+#include "ref_orb.h"
+#include "ref_tracker.h"
+
+using namespace sdvlref;
+
+namespace {
+
+Params ToParams(const sdvl_ref_params *p) {
+  Params q;
+  q.pyramid_levels = p->pyramid_levels; q.cell_size = p->cell_size; q.max_fast_levels = p->max_fast_levels;
+  q.fast_threshold = p->fast_threshold; q.num_features = p->num_features; q.use_orb = p->use_orb;
+  q.orb_size = p->orb_size; q.patch_size = p->patch_size; q.max_align_its = p->max_align_its;
+  q.search_size = p->search_size; q.align_patch_size = p->align_patch_size; q.max_align_level = p->max_align_level;
+  q.min_align_level = p->min_align_level; q.max_img_align_its = p->max_img_align_its;
+  q.min_feature_score = p->min_feature_score; q.max_matches = p->max_matches; q.min_matches = p->min_matches;
+  q.max_failed = p->max_failed; q.max_optim_pose_its = p->max_optim_pose_its; q.max_ransac_points = p->max_ransac_points;
+  q.max_ransac_its = p->max_ransac_its; q.min_keyframe_its = p->min_keyframe_its;
+  q.inlier_error_threshold = p->inlier_error_threshold; q.lost_ratio = p->lost_ratio;
+  return q;
+}
+
+struct Pyramid {
+  std::vector<std::vector<uint8_t>> data;
+  std::vector<Image> lv;
+  Pyramid(const uint8_t *img, int w, int h, int stride, int levels) {
+    data.resize(levels);
+    lv.resize(levels);
+    data[0].resize(static_cast<size_t>(w) * h);
+    for (int y = 0; y < h; y++) std::memcpy(&data[0][static_cast<size_t>(y) * w], img + static_cast<size_t>(y) * stride, w);
+    lv[0] = Image{data[0].data(), w, h, w};
+    for (int i = 1; i < levels; i++) {
+      const int cw = lv[i - 1].cols / 2, ch = lv[i - 1].rows / 2;
+      data[i].resize(static_cast<size_t>(cw) * ch);
+      PyrDown(lv[i - 1], data[i].data(), cw);
+      lv[i] = Image{data[i].data(), cw, ch, cw};
+    }
+  }
+};
+
+SE3 ToSE3(const double *T) {
+  SE3 s;
+  s.q0 = T[0]; s.q1 = T[1]; s.q2 = T[2]; s.q3 = T[3];
+  s.t = Vec3{T[4], T[5], T[6]};
+  return s;
+}
+void FromSE3(const SE3 &s, double *T) {
+  T[0] = s.q0; T[1] = s.q1; T[2] = s.q2; T[3] = s.q3; T[4] = s.t.x; T[5] = s.t.y; T[6] = s.t.z;
+}
+Camera ToCam(const double *cam, int w, int h) {
+  Camera c;
+  c.width = w; c.height = h; c.fx = cam[0]; c.fy = cam[1]; c.u0 = cam[2]; c.v0 = cam[3];
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sdvl_ref_default_params(sdvl_ref_params *p) {
+  Params q;
+  p->pyramid_levels = q.pyramid_levels; p->cell_size = q.cell_size; p->max_fast_levels = q.max_fast_levels;
+  p->fast_threshold = q.fast_threshold; p->num_features = q.num_features; p->use_orb = q.use_orb;
+  p->orb_size = q.orb_size; p->patch_size = q.patch_size; p->max_align_its = q.max_align_its;
+  p->search_size = q.search_size; p->align_patch_size = q.align_patch_size; p->max_align_level = q.max_align_level;
+  p->min_align_level = q.min_align_level; p->max_img_align_its = q.max_img_align_its;
+  p->min_feature_score = q.min_feature_score; p->max_matches = q.max_matches; p->min_matches = q.min_matches;
+  p->max_failed = q.max_failed; p->max_optim_pose_its = q.max_optim_pose_its; p->max_ransac_points = q.max_ransac_points;
+  p->max_ransac_its = q.max_ransac_its; p->min_keyframe_its = q.min_keyframe_its;
+  p->inlier_error_threshold = q.inlier_error_threshold; p->lost_ratio = q.lost_ratio;
+}
+
+int sdvl_ref_pyr_down(const uint8_t *src, int w, int h, int stride, uint8_t *dst, int dst_stride) {
+  PyrDown(Image{src, w, h, stride}, dst, dst_stride);
+  return 0;
+}
+
+int sdvl_ref_fast(const uint8_t *img, int w, int h, int stride, int thr, int nonmax, int cap, int32_t *out_xys) {
+  std::vector<KeyPoint> kps;
+  Fast9_16(Image{img, w, h, stride}, &kps, thr, nonmax != 0);
+  for (size_t i = 0; i < kps.size() && static_cast<int>(i) < cap; i++) {
+    out_xys[3 * i] = static_cast<int>(kps[i].x);
+    out_xys[3 * i + 1] = static_cast<int>(kps[i].y);
+    out_xys[3 * i + 2] = static_cast<int>(kps[i].response);
+  }
+  return static_cast<int>(kps.size());
+}
+
+int sdvl_ref_fast_cells(const uint8_t *img, int w, int h, int stride, const sdvl_ref_params *p, int cap,
+                        int32_t *out_xys, int32_t *cell_offsets, uint8_t *ran_out) {
+  std::vector<std::vector<KeyPoint>> cells;
+  std::vector<uint8_t> ran;
+  int wc, hc;
+  FastCells(Image{img, w, h, stride}, ToParams(p), &cells, &ran, &wc, &hc);
+  int n = 0;
+  for (int c = 0; c < wc * hc; c++) {
+    cell_offsets[c] = n;
+    ran_out[c] = ran[c];
+    for (const auto &k : cells[c]) {
+      if (n < cap) {
+        out_xys[3 * n] = static_cast<int>(k.x);
+        out_xys[3 * n + 1] = static_cast<int>(k.y);
+        out_xys[3 * n + 2] = static_cast<int>(k.response);
+      }
+      n++;
+    }
+  }
+  cell_offsets[wc * hc] = n;
+  return n;
+}
+
+int sdvl_ref_detect_pyramid(const uint8_t *img, int w, int h, int stride, const sdvl_ref_params *p, int nfeatures,
+                            int cap, int32_t *corners) {
+  const Params q = ToParams(p);
+  Pyramid pyr(img, w, h, stride, q.pyramid_levels);
+  std::vector<Corner> cs;
+  DetectPyramid(pyr.lv, q, nfeatures, &cs);
+  for (size_t i = 0; i < cs.size() && static_cast<int>(i) < cap; i++) {
+    corners[3 * i] = cs[i].x; corners[3 * i + 1] = cs[i].y; corners[3 * i + 2] = cs[i].level;
+  }
+  return static_cast<int>(cs.size());
+}
+
+double sdvl_ref_shi_tomasi(const uint8_t *img, int w, int h, int stride, int x, int y) {
+  return ShiTomasiScore(Image{img, w, h, stride}, x, y);
+}
+
+int sdvl_ref_filter_corners(const uint8_t *img, int w, int h, int stride, const sdvl_ref_params *p, int n,
+                            const int32_t *corners, int n_locked, const double *locked, int cap, int32_t *indices) {
+  const Params q = ToParams(p);
+  Pyramid pyr(img, w, h, stride, q.pyramid_levels);
+  std::vector<Corner> cs(n);
+  for (int i = 0; i < n; i++) cs[i] = Corner{corners[3 * i], corners[3 * i + 1], corners[3 * i + 2]};
+  CornerGrid g(w, h, q);
+  for (int i = 0; i < n_locked; i++) g.LockCell(locked[2 * i], locked[2 * i + 1]);
+  std::vector<int> idx;
+  g.FilterCorners(pyr.lv, cs, q, &idx);
+  for (size_t i = 0; i < idx.size() && static_cast<int>(i) < cap; i++) indices[i] = idx[i];
+  return static_cast<int>(idx.size());
+}
+
+void sdvl_ref_orb_describe(const uint8_t *img, int w, int h, int stride, int n, const int32_t *xy, uint8_t *desc,
+                           float *angles_deg) {
+  OrbDetector orb(31);
+  const Image im{img, w, h, stride};
+  for (int i = 0; i < n; i++) {
+    orb.GetDescriptor(im, xy[2 * i], xy[2 * i + 1], desc + 32 * i);
+    if (angles_deg) angles_deg[i] = orb.GetOrientation(im, xy[2 * i], xy[2 * i + 1]);
+  }
+}
+
+int sdvl_ref_orb_distance(const uint8_t *a, const uint8_t *b) { return OrbDetector::Distance(a, b); }
+
+int sdvl_ref_image_align(const uint8_t *img1, const uint8_t *img2, int w, int h, const sdvl_ref_params *p,
+                         const double *cam, int n, const double *px, const double *bearing, const double *depth,
+                         const uint8_t *valid, double *T_io, int fast, double *error, double *chi2, int *its) {
+  const Params q = ToParams(p);
+  Pyramid p1(img1, w, h, w, q.pyramid_levels), p2(img2, w, h, w, q.pyramid_levels);
+  std::vector<AlignFeature> feats(n);
+  for (int i = 0; i < n; i++) {
+    feats[i].px = px[2 * i]; feats[i].py = px[2 * i + 1];
+    feats[i].f = Vec3{bearing[3 * i], bearing[3 * i + 1], bearing[3 * i + 2]};
+    feats[i].depth = depth[i];
+    feats[i].valid = valid[i];
+  }
+  ImageAlign ia;
+  SE3 T = ToSE3(T_io);
+  const int r = ia.ComputePose(p1.lv, p2.lv, feats, ToCam(cam, w, h), q, &T, fast != 0);
+  FromSE3(T, T_io);
+  if (error) *error = ia.error;
+  if (chi2) *chi2 = ia.chi2;
+  if (its) for (int i = 0; i < 8; i++) its[i] = ia.its_per_level[i];
+  return r;
+}
+
+int sdvl_ref_search_point(const uint8_t *ref_img, const uint8_t *cur_img, int w, int h, const sdvl_ref_params *p,
+                          const double *cam, const double *ref_pose, const double *cur_pose, const double *feat_px,
+                          const double *feat_bearing, int feat_level, const uint8_t *feat_desc, double idepth,
+                          double idepth_std, int fixed, int n_corners, const int32_t *corners, double *px_io,
+                          int *out_level, uint8_t *out_border_patch, int *out_slevel) {
+  const Params q = ToParams(p);
+  Pyramid pr(ref_img, w, h, w, q.pyramid_levels), pc(cur_img, w, h, w, q.pyramid_levels);
+  std::vector<Corner> cs(n_corners);
+  for (int i = 0; i < n_corners; i++) cs[i] = Corner{corners[3 * i], corners[3 * i + 1], corners[3 * i + 2]};
+  std::vector<std::vector<uint8_t>> descs(n_corners);
+  const Camera c = ToCam(cam, w, h);
+  Matcher m(q.patch_size, q, c);
+  SearchCur cur{&pc.lv, ToSE3(cur_pose), &cs, &descs};
+  SearchRef ref;
+  ref.ref_pyr = &pr.lv;
+  ref.ref_pose = ToSE3(ref_pose);
+  ref.px = feat_px[0]; ref.py = feat_px[1];
+  ref.f = Vec3{feat_bearing[0], feat_bearing[1], feat_bearing[2]};
+  ref.level = feat_level;
+  std::memcpy(ref.desc, feat_desc, 32);
+  Vec2 px{px_io[0], px_io[1]};
+  int level = -1;
+  const bool found = m.SearchPoint(&cur, ref, idepth, idepth_std, fixed != 0, &px, &level);
+  px_io[0] = px.x; px_io[1] = px.y;
+  if (out_level) *out_level = level;
+  if (out_border_patch) std::memcpy(out_border_patch, m.border_patch.data(), m.border_patch.size());
+  if (out_slevel) {
+    Mat2 A;
+    m.WarpMatrixAffine(Vec2{ref.px, ref.py}, ref.f, 1.0 / idepth, ToSE3(cur_pose) * ToSE3(ref_pose).Inverse(), feat_level, &A);
+    *out_slevel = m.GetSearchLevel(A);
+  }
+  return found ? 1 : 0;
+}
+
+int sdvl_ref_align_patch(const uint8_t *img, int w, int h, int stride, const uint8_t *border_patch,
+                         const uint8_t *patch, double *px_io, int max_its) {
+  Params q;
+  q.max_align_its = max_its;
+  Camera c;
+  Matcher m(8, q, c);
+  Vec2 px{px_io[0], px_io[1]};
+  const bool ok = m.AlignPatch(Image{img, w, h, stride}, border_patch, patch, &px);
+  px_io[0] = px.x; px_io[1] = px.y;
+  return ok ? 1 : 0;
+}
+
+void sdvl_ref_se3_exp(const double *u6, double *T7) { FromSE3(SE3Exp(u6), T7); }
+void sdvl_ref_se3_log(const double *T7, double *u6) { SE3Log(ToSE3(T7), u6); }
+void sdvl_ref_se3_mul(const double *A7, const double *B7, double *C7) { FromSE3(ToSE3(A7) * ToSE3(B7), C7); }
+void sdvl_ref_se3_inv(const double *A7, double *B7) { FromSE3(ToSE3(A7).Inverse(), B7); }
+void sdvl_ref_ldlt_solve6(const double *A36, const double *b6, double *x6) {
+  double A[6][6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) A[i][j] = A36[6 * i + j];
+  LdltSolve6(A, b6, x6);
+}
+void sdvl_ref_rand_stream(unsigned seed, int n, int *out) {
+  GlibcRand r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.Next();
+}
+
+void *sdvl_ref_tracker_create(const sdvl_ref_params *p, int w, int h, const double *cam, const double *plane4,
+                              const double *first_pose7) {
+  ScenePlane pl;
+  pl.n = Vec3{plane4[0], plane4[1], plane4[2]};
+  pl.d = plane4[3];
+  return new Tracker(ToParams(p), ToCam(cam, w, h), pl, ToSE3(first_pose7));
+}
+void sdvl_ref_tracker_destroy(void *t) { delete static_cast<Tracker *>(t); }
+int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_ref_frame_stats *out) {
+  const FrameStats s = static_cast<Tracker *>(t)->HandleFrame(img, stride);
+  out->state = s.state; out->quality = s.quality; out->matches = s.matches; out->attempts = s.attempts;
+  out->inliers = s.inliers; out->outliers = s.outliers; out->n_corners = s.n_corners; out->align_meas = s.align_meas;
+  out->keyframe = s.keyframe; out->relocalized = s.relocalized;
+  for (int i = 0; i < 7; i++) out->pose[i] = s.pose[i];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+"""Independent re-derivations (numpy / scipy / libc) that pin the CPU restatement where the reference has no
+golden vectors (the reference has no tests; OpenCV/Eigen are absent).  These check the ORACLE."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.linalg
+import scipy.ndimage
+
+from oraclelib import TUM_CAM, trajectory_pose, quat_to_R
+
+CIRCLE = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+          (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def rand_img(seed, h, w, smooth=0):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w)).astype(np.float64)
+    if smooth:
+        img = scipy.ndimage.gaussian_filter(img, smooth)
+        img = (img - img.min()) / (img.max() - img.min()) * 255
+    return img.astype(np.uint8)
+
+
+# ---------------------------------------------------------------- pyrDown (Appendix A.1)
+@pytest.mark.parametrize("shape", [(480, 640), (30, 40), (60, 94), (8, 8), (6, 10)])
+def test_pyrdown_matches_separable_integer_gaussian(orc, shape):
+    img = rand_img(1, *shape)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    full = scipy.ndimage.correlate1d(img.astype(np.int64), k, axis=1, mode="mirror")   # mirror == REFLECT_101
+    full = scipy.ndimage.correlate1d(full, k, axis=0, mode="mirror")
+    want = ((full[::2, ::2] + 128) >> 8)[: shape[0] // 2, : shape[1] // 2].astype(np.uint8)
+    got = orc.pyr_down(img)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_pyrdown_constant_image(orc):
+    assert np.all(orc.pyr_down(np.full((16, 24), 77, np.uint8)) == 77)
+
+
+# ---------------------------------------------------------------- FAST-9/16 (Appendix A.2)
+def fast_bruteforce(img, t):
+    """FAST by definition: corner iff >= 9 contiguous circle pixels all brighter than v+t or all darker than v-t;
+    score = largest threshold for which it is still a corner; 3x3 strict NMS; row-major output."""
+    h, w = img.shape
+    im = img.astype(np.int32)
+    ring = np.stack([im[3 + dy: h - 3 + dy, 3 + dx: w - 3 + dx] for dx, dy in CIRCLE])   # [16, h-6, w-6]
+    v = im[3:h - 3, 3:w - 3]
+
+    def is_corner(thr):
+        br = ring > v + thr
+        dk = ring < v - thr
+        out = np.zeros(v.shape, bool)
+        for m in (br, dk):
+            mm = np.concatenate([m, m[:8]])
+            run = np.ones_like(m)
+            for s in range(9):
+                run = run & mm[s:s + 16]
+            out |= run.any(axis=0)
+        return out
+
+    corner = is_corner(t)
+    score = np.zeros(v.shape, np.int32)
+    ys, xs = np.nonzero(corner)
+    d = v[None] - ring                          # [16, ...]
+    dd = np.concatenate([d, d[:8]])
+    amin = np.stack([dd[s:s + 9].min(axis=0) for s in range(16)]).max(axis=0)
+    bmin = np.stack([(-dd[s:s + 9]).min(axis=0) for s in range(16)]).max(axis=0)
+    sc = np.maximum(np.maximum(amin, bmin), t) - 1
+    score[corner] = sc[corner]
+    # cross-check the closed form against the literal definition on a sample
+    for y, x in list(zip(ys, xs))[:40]:
+        s = score[y, x]
+        assert is_corner_at(im, x + 3, y + 3, s) and not is_corner_at(im, x + 3, y + 3, s + 1)
+    full = np.zeros((h, w), np.int32)
+    full[3:h - 3, 3:w - 3] = score
+    out = []
+    for y, x in zip(ys + 3, xs + 3):
+        s = full[y, x]
+        nb = full[y - 1:y + 2, x - 1:x + 2].copy()
+        nb[1, 1] = -1
+        if (s > nb).all():
+            out.append((x, y, s))
+    return np.array(out, np.int32).reshape(-1, 3)
+
+
+def is_corner_at(im, x, y, thr):
+    v = im[y, x]
+    p = np.array([im[y + dy, x + dx] for dx, dy in CIRCLE])
+    for m in (p > v + thr, p < v - thr):
+        mm = np.concatenate([m, m[:8]])
+        if any(mm[s:s + 9].all() for s in range(16)):
+            return True
+    return False
+
+
+@pytest.mark.parametrize("seed,shape,smooth,thr", [(3, (40, 52), 0, 10), (4, (64, 64), 1.0, 10), (5, (33, 47), 1.5, 20),
+                                                   (6, (32, 32), 0, 40), (7, (90, 70), 2.0, 5)])
+def test_fast_matches_definition(orc, seed, shape, smooth, thr):
+    img = rand_img(seed, *shape, smooth=smooth)
+    want = fast_bruteforce(img, thr)
+    got = orc.fast(img, thr=thr)
+    assert len(want) > 0
+    assert np.array_equal(got, want)
+
+
+def test_fast_constant_and_tiny(orc):
+    assert len(orc.fast(np.full((32, 32), 100, np.uint8))) == 0
+    assert len(orc.fast(rand_img(1, 6, 6))) == 0          # ROI smaller than 7x7: loops do not execute
+    # a single bright dot on a dark ground is not a FAST-9 corner for its neighbours, but a dark dot centre is:
+    img = np.full((15, 15), 200, np.uint8); img[7, 7] = 10
+    got = orc.fast(img, thr=10)
+    assert got.tolist() == [[7, 7, 189]]                  # all 16 ring pixels brighter by 190 -> score 190-1
+
+
+def test_fast_cells_equal_per_roi_fast(orc, synth):
+    """SelectPixels runs cv::FAST on each cell ROI independently (fast_detector.cc:80-106)."""
+    img = synth.render(trajectory_pose(orc, 0), TUM_CAM, 640, 480)
+    kps, offs, ran = orc.fast_cells(img)
+    m, cs = 19, 32
+    wc = 20
+    for (i, j) in [(0, 0), (0, 19), (14, 0), (7, 9), (14, 19), (3, 3)]:
+        y0, y1 = max(m, i * cs), min(480 - m, i * cs + cs)
+        x0, x1 = max(m, j * cs), min(640 - m, j * cs + cs)
+        roi = np.ascontiguousarray(img[y0:y1, x0:x1])
+        want = fast_bruteforce(roi, 10) if min(roi.shape) >= 7 else np.zeros((0, 3), np.int32)
+        if len(want):
+            want = want + np.array([x0, y0, 0], np.int32)
+        c = i * wc + j
+        got = kps[offs[c]:offs[c + 1]]
+        assert ran[c] == 1
+        assert np.array_equal(got, want)
+
+
+def test_detect_pyramid_quota_and_margins(orc, synth):
+    img = synth.render(trajectory_pose(orc, 0), TUM_CAM, 640, 480)
+    c = orc.detect_pyramid(img)
+    # quotas 395/329/274 (fast_detector.cc:161-174); retainBest keeps boundary ties so counts may exceed
+    per = [int((c[:, 2] == l).sum()) for l in range(3)]
+    assert per[0] >= 395 and per[1] >= 329 and per[2] >= 274 and sum(per) < 1100
+    for l in range(3):
+        w, h = 640 >> l, 480 >> l
+        cl = c[c[:, 2] == l]
+        assert cl[:, 0].min() >= 22 and cl[:, 0].max() < w - 22      # margin 19 + FAST border 3
+        assert cl[:, 1].min() >= 22 and cl[:, 1].max() < h - 22
+
+
+# ---------------------------------------------------------------- Shi-Tomasi (extra/utils.cc:61-97)
+def test_shi_tomasi_matches_eigenvalue(orc):
+    img = rand_img(11, 64, 64, smooth=1.2)
+    im = img.astype(np.float64)
+    for (x, y) in [(20, 20), (31, 40), (10, 50), (50, 12)]:
+        dx = im[y - 4:y + 4, x - 4 + 1:x + 4 + 1] - im[y - 4:y + 4, x - 4 - 1:x + 4 - 1]
+        dy = im[y - 4 + 1:y + 4 + 1, x - 4:x + 4] - im[y - 4 - 1:y + 4 - 1, x - 4:x + 4]
+        M = np.array([[np.sum(dx * dx), np.sum(dx * dy)], [np.sum(dx * dy), np.sum(dy * dy)]]) / 128.0
+        want = np.linalg.eigvalsh(M)[0]
+        got = orc.shi_tomasi(img, x, y)
+        assert abs(got - want) <= 1e-3 * max(1.0, abs(want))
+    assert orc.shi_tomasi(img, 3, 30) == 0.0           # box touches the border
+
+
+# ---------------------------------------------------------------- ORB (extra/orb_detector.cc)
+def test_orb_orientation_and_rotation_consistency(orc):
+    img = rand_img(21, 96, 96, smooth=2.0)
+    desc, ang = orc.orb_describe(img, [[48, 48]])
+    # intensity-centroid by definition over the radius-15 disc used by ORB (umax table)
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    m10 = m01 = 0
+    for v in range(-15, 16):
+        for u in range(-umax[abs(v)], umax[abs(v)] + 1):
+            p = int(img[48 + v, 48 + u]); m10 += u * p; m01 += v * p
+    want = np.degrees(np.arctan2(m01, m10)) % 360
+    assert abs(((ang[0] - want + 180) % 360) - 180) < 0.02        # fastAtan2 is a <=0.01 deg polynomial
+    # descriptor of the 180-degree-rotated image at the mirrored point is identical (steering by the angle)
+    rot = np.ascontiguousarray(img[::-1, ::-1])
+    d2, a2 = orc.orb_describe(rot, [[95 - 48, 95 - 48]])
+    assert abs(((a2[0] - ang[0] - 180 + 180) % 360) - 180) < 0.02
+    assert orc.orb_distance(desc[0], d2[0]) <= 6                   # only rounding-tie samples may differ
+
+
+def test_orb_distance_is_hamming(orc):
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, 32).astype(np.uint8); b = rng.integers(0, 256, 32).astype(np.uint8)
+    assert orc.orb_distance(a, b) == int(np.unpackbits(a ^ b).sum())
+    assert orc.orb_distance(a, a) == 0
+
+
+# ---------------------------------------------------------------- SE3 / LDLT / rand
+def hat6(u):
+    w = u[3:]
+    M = np.zeros((4, 4))
+    M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+    M[:3, 3] = u[:3]
+    return M
+
+
+def T_to_mat(T):
+    M = np.eye(4); M[:3, :3] = quat_to_R(T[:4]); M[:3, 3] = T[4:]
+    return M
+
+
+def test_se3_exp_log_compose_against_expm(orc):
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        u = rng.normal(size=6) * [0.3, 0.3, 0.3, 0.4, 0.4, 0.4]
+        v = rng.normal(size=6) * 0.2
+        A, B = orc.se3_exp(u), orc.se3_exp(v)
+        assert np.allclose(T_to_mat(A), scipy.linalg.expm(hat6(u)), atol=1e-12)
+        assert np.allclose(orc.se3_log(A), u, atol=1e-10)
+        assert np.allclose(T_to_mat(orc.se3_mul(A, B)), T_to_mat(A) @ T_to_mat(B), atol=1e-12)
+        assert np.allclose(T_to_mat(orc.se3_inv(A)), np.linalg.inv(T_to_mat(A)), atol=1e-12)
+    assert np.allclose(orc.se3_exp(np.zeros(6)), [1, 0, 0, 0, 0, 0, 0])
+
+
+def test_ldlt_solve_against_numpy(orc):
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        J = rng.normal(size=(40, 6)) * rng.uniform(0.1, 100, size=6)
+        A = J.T @ J; b = rng.normal(size=6)
+        x = orc.ldlt_solve6(A, b)
+        assert np.allclose(A @ x, b, rtol=1e-8, atol=1e-8 * np.abs(b).max())
+    assert np.all(orc.ldlt_solve6(np.zeros((6, 6)), np.ones(6)) == 0.0)   # all-zero H -> x = 0, not NaN (App. C)
+
+
+def test_rand_stream_is_glibc_rand(orc):
+    libc = C.CDLL("libc.so.6")
+    libc.srand(1)
+    want = [libc.rand() for _ in range(2000)]
+    assert orc.rand_stream(2000, seed=1).tolist() == want
