@@ -1,0 +1,198 @@
+/* sdvl_hip.h — C-ABI of the MI355X-native SDVL tracking front-end (libsdvl_hip.so, gfx950).
+ *
+ * The reference (JdeRobot/slam-SDVL) has no FFI: its hot path is reached through C++ member calls.  Each entry
+ * point below names the reference call it replaces (file:line under the reference tree); INTEGRATION.md shows
+ * the glue a maintainer adds inside frame.cc / image_align.cc / matcher.cc.  Plain pointers and sizes only;
+ * every function returns 0 on success or a negative sdvl_status, never throws, never frees caller memory.
+ *
+ * Everything is batched: one call handles n frames / alignment jobs / search requests of any number of
+ * independent sequences, so that a single launch fills the 256 CUs.  Frames live in HBM behind opaque handles
+ * (pyramid + corner list + ORB descriptors); only small records cross PCIe.
+ *
+ * Poses are 7 doubles (qw,qx,qy,qz,tx,ty,tz) of Frame::pose_ (world -> camera), extra/se3.h:32-78.
+ * Threading: one sdvl_ctx per host thread (tracker / mapper); frames may be shared read-only across contexts
+ * of the same device once the creating context has been synchronised. */
+#ifndef SDVL_HIP_H_
+#define SDVL_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdvl_ctx sdvl_ctx;
+typedef struct sdvl_frame sdvl_frame; /* device-resident Frame: pyramid_, corners_, descriptors_ (frame.h:155-165) */
+
+enum sdvl_status {
+  SDVL_OK = 0,
+  SDVL_ERR_INVALID = -1,   /* bad argument (null pointer, size out of range) */
+  SDVL_ERR_HIP = -2,       /* a HIP runtime call failed; see sdvl_last_error */
+  SDVL_ERR_CAPACITY = -3,  /* an output or a per-frame capacity would overflow */
+  SDVL_ERR_NO_DEVICE = -4  /* no gfx950 device visible */
+};
+
+#define SDVL_MAX_LEVELS 8
+#define SDVL_MAX_CORNERS 4096        /* per frame; first frame detects 2*NumFeatures (sdvl.cc:135) */
+#define SDVL_MAX_ALIGN_FEATURES 2048 /* features per image-alignment job */
+#define SDVL_CELL_KP_CAP 176         /* a 32x32 ROI holds at most 13*13 = 169 NMS-surviving corners */
+
+typedef struct sdvl_camera { /* camera.h:34-135 pinhole part */
+  double width, height, fx, fy, u0, v0;
+} sdvl_camera;
+
+typedef struct sdvl_detect_params { /* Config getters used by FastDetector (config.cc:55-85) */
+  int cell_size;       /* CellSize, 32 */
+  int max_fast_levels; /* MaxFastLevels, 3 */
+  int fast_threshold;  /* FastThreshold, 10 */
+  int margin;          /* 4+ORBSize/2 (ORB) or 1+PatchSize/2, fast_detector.cc:63-66 */
+} sdvl_detect_params;
+
+typedef struct sdvl_keypoint { /* one cv::KeyPoint of a per-cell cv::FAST call, image coordinates of its level */
+  uint16_t x, y;
+  uint8_t score; /* response */
+  uint8_t level;
+  uint16_t cell; /* row-major cell index inside the level */
+} sdvl_keypoint;
+
+typedef struct sdvl_align_feature { /* what ImageAlign reads of one frame1 feature, image_align.cc:147-160,219-236 */
+  double px, py;      /* Feature::GetPosition() */
+  double fx, fy, fz;  /* Feature::GetVector() */
+  double depth;       /* |point->GetPosition() - frame1->GetWorldPosition()| */
+  int32_t valid;      /* feature->GetPoint() && !ToDelete() */
+  int32_t pad_;
+} sdvl_align_feature;
+
+typedef struct sdvl_align_job {
+  const sdvl_frame *ref; /* frame1 */
+  const sdvl_frame *cur; /* frame2 */
+  int32_t feat_begin, feat_end; /* range in the features array */
+  double T[7];           /* frame2.pose * frame1.pose^-1 (image_align.cc:66) */
+} sdvl_align_job;
+
+typedef struct sdvl_align_params { /* Config getters used by ImageAlign */
+  int max_level, min_level; /* MaxAlignLevel 4, MinAlignLevel 2 */
+  int max_its;              /* MaxImgAlignIts 30 */
+  int patch_size;           /* AlignPatchSize 4 (only 4 is supported) */
+  int fast;                 /* ComputePose(..., fast) relocalisation early-out */
+} sdvl_align_params;
+
+typedef struct sdvl_align_result {
+  double T[7];      /* refined frame2.pose * frame1.pose^-1 */
+  double error;     /* ImageAlign::GetError() */
+  double chi2;
+  int32_t n_meas;   /* n_meas_ / patch_area = ComputePose return value */
+  int32_t its[SDVL_MAX_LEVELS]; /* accepted Gauss-Newton steps per level */
+  int32_t stop;
+} sdvl_align_result;
+
+typedef struct sdvl_search_params { /* Config getters used by Matcher */
+  int patch_size;      /* PatchSize 8 (only 8 is supported: one wave64 per 8x8 patch) */
+  int max_align_its;   /* MaxAlignIts 10 */
+  int search_size;     /* SearchSize 6 */
+  int max_fast_levels; /* MaxFastLevels 3 */
+  int margin;          /* corner margin, matcher.cc:131-134 */
+  int use_orb;         /* UseORB (1: Hamming on ORB descriptors; 0: ZMSSD on 8x8 patches) */
+} sdvl_search_params;
+
+typedef struct sdvl_search_req { /* arguments of Matcher::SearchPoint, matcher.cc:45-46 */
+  const sdvl_frame *cur;  /* frame */
+  const sdvl_frame *ref;  /* feature->GetFrame() */
+  double cur_pose[7], ref_pose[7];
+  double px[2];           /* feature->GetPosition() */
+  double bearing[3];      /* feature->GetVector() */
+  double idepth, idepth_std;
+  double px0[2];          /* *px on entry (search centre for fixed points) */
+  int32_t level;          /* feature->GetLevel() */
+  int32_t fixed;
+  uint8_t desc[32];       /* feature->GetDescriptor() */
+} sdvl_search_req;
+
+typedef struct sdvl_search_res {
+  double px[2];     /* *px on return */
+  int32_t found;    /* return value */
+  int32_t level;    /* *flevel */
+  int32_t best_corner; /* index of the winning corner in the current frame, -1 if none */
+  int32_t stage;    /* 0 rejected before patch, 1 no corner matched, 2 LK not converged, 3 found */
+  int32_t lk_its;   /* AlignPatch iterations executed */
+  int32_t slevel;   /* GetSearchLevel() */
+} sdvl_search_res;
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+int sdvl_ctx_create(int device, sdvl_ctx **out);
+int sdvl_ctx_destroy(sdvl_ctx *ctx);
+const char *sdvl_last_error(const sdvl_ctx *ctx);
+int sdvl_ctx_synchronize(sdvl_ctx *ctx);
+void *sdvl_ctx_stream(sdvl_ctx *ctx); /* the hipStream_t every launch of this context goes to */
+/* per-kernel device time (HIP events on the context stream) accumulated since the last reset; names/ms/launches */
+int sdvl_ctx_timing_enable(sdvl_ctx *ctx, int on);
+int sdvl_ctx_timing_get(sdvl_ctx *ctx, int cap, char (*names)[32], double *ms, int64_t *launches, int *n);
+int sdvl_ctx_timing_reset(sdvl_ctx *ctx);
+
+/* ---- Frame: pyramid + corners (frame.cc:34-56) -------------------------------------------------------------- */
+int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_frame **out);
+int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f);
+/* pyramid_[0] = img (frame.cc:116): host image -> HBM (async on the context stream, staged through pinned memory) */
+int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stride);
+/* same, image already in HBM (device pointer) */
+int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride);
+/* Frame::CreatePyramid, frame.cc:114-120: levels 1..L-1 by cv::pyrDown for n frames */
+int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames);
+/* host mirror of GetPyramid()[level] (read by the mapper / UI) */
+int sdvl_frame_download_level(sdvl_ctx *ctx, const sdvl_frame *f, int level, uint8_t *out, int stride);
+
+/* The cv::FAST(roi, kps, thr, true) calls of FastDetector::SelectPixels, fast_detector.cc:79-106, for every cell
+ * of levels 0..max_fast_levels-1 of n frames.  out_kps[i*cap ..] holds frame i's keypoints grouped by
+ * (level, cell) in row-major cell order and cv::FAST scan order inside a cell; out_cell_offsets[i*(ncells+1) ..]
+ * are exclusive offsets over the frame's concatenated cells (ncells = sum over levels, see sdvl_fast_num_cells).
+ * The quota / retainBest selection (fast_detector.cc:108-151) stays on the host. */
+int sdvl_fast_num_cells(int width, int height, const sdvl_detect_params *p, int *cells_per_level, int *total);
+int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_detect_params *p, int cap,
+                    sdvl_keypoint *out_kps, int32_t *out_cell_offsets);
+
+/* corners_ of a frame (x, y in level coordinates, level), fast_detector.cc:151 -> HBM; descriptors are invalidated */
+int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *xyl);
+int sdvl_frame_num_corners(const sdvl_frame *f);
+
+/* FindShiTomasiScoreAtPoint for every corner of n frames (extra/utils.cc:61-97, called from
+ * FastDetector::FilterCorners fast_detector.cc:205); out_scores[i*cap + k]; the grid logic stays on the host */
+int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, double *out_scores);
+
+/* ORBDetector::GetDescriptor for every corner of n frames (orb_detector.cc:350-395; lazily called from
+ * matcher.cc:266-269 and frame.cc:148-161).  Descriptors stay in HBM; out_desc (may be NULL) = [n][cap][32] */
+int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *out_desc);
+/* ORBDetector::GetDescriptor at arbitrary (x,y,level) points of one frame; out_angle_deg may be NULL */
+int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const int32_t *xyl, uint8_t *out_desc,
+                             float *out_angle_deg);
+
+/* ---- ImageAlign::ComputePose, image_align.cc:46-84 (Optimize :86-125, ComputeResiduals :127-206,
+ * PrecomputePatches :208-267): n_jobs independent frame pairs, whole coarse-to-fine Gauss-Newton on device ------ */
+int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
+                     const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p,
+                     sdvl_align_result *out);
+
+/* ---- Matcher::SearchPoint, matcher.cc:45-121 (WarpMatrixAffine :293-312, GetSearchLevel :314-323,
+ * CreatePatch :325-357, GetCornersInRange :123-230, SearchFeatures :232-291, AlignPatch :359-445).
+ * The current frames need corners (sdvl_frame_set_corners) and, with use_orb, descriptors (sdvl_orb_describe). -- */
+int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
+                       const sdvl_search_params *p, sdvl_search_res *out);
+
+/* Matcher::AlignPatch alone, matcher.cc:359-445: n patches against level images of frames.
+ * border[n][100], patch[n][64], uv_io[n][2] (level coordinates), converged[n], its[n] (may be NULL) */
+int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const int32_t *levels,
+                       const uint8_t *border, const uint8_t *patch, int max_its, double *uv_io,
+                       uint8_t *converged, int32_t *its);
+
+/* ---- synthetic sequence generator (no dataset ships with the repo) ------------------------------- */
+struct sdvl_synth_view;
+/* renders n views of the textured plane straight into HBM: dev_out + i*frame_bytes, row stride = width */
+int sdvl_synth_render(sdvl_ctx *ctx, int n, const struct sdvl_synth_view *views, int width, int height,
+                      void *dev_out, int64_t frame_bytes);
+int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out);
+int sdvl_device_free(sdvl_ctx *ctx, void *p);
+int sdvl_device_download(sdvl_ctx *ctx, const void *dev, int64_t bytes, void *host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDVL_HIP_H_ */

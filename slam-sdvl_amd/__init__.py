@@ -1,0 +1,316 @@
+"""slam-sdvl_amd — MI355X-native SDVL tracking front-end (import with importlib.import_module("slam-sdvl_amd")).
+
+Thin ctypes view of the C-ABI in include/sdvl_hip.h (libsdvl_hip.so, hand-written gfx950 kernels).  There is NO
+CPU fallback: importing works anywhere the library loads (so that symbol checks run without a GPU), but every
+compute entry point needs an MI355X and raises SdvlError otherwise.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsdvl_hip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "host", "libsdvl_host.so")
+
+MAX_LEVELS = 8
+MAX_CORNERS = 4096
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+f32p = C.POINTER(C.c_float)
+
+
+class SdvlError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("width", "height", "fx", "fy", "u0", "v0")]
+
+
+class DetectParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("cell_size", "max_fast_levels", "fast_threshold", "margin")]
+
+
+class Keypoint(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("score", C.c_uint8), ("level", C.c_uint8), ("cell", C.c_uint16)]
+
+
+class AlignFeature(C.Structure):
+    _fields_ = [("px", C.c_double), ("py", C.c_double), ("fx", C.c_double), ("fy", C.c_double), ("fz", C.c_double),
+                ("depth", C.c_double), ("valid", C.c_int32), ("pad_", C.c_int32)]
+
+
+class AlignJob(C.Structure):
+    _fields_ = [("ref", C.c_void_p), ("cur", C.c_void_p), ("feat_begin", C.c_int32), ("feat_end", C.c_int32),
+                ("T", C.c_double * 7)]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("max_level", "min_level", "max_its", "patch_size", "fast")]
+
+
+class AlignResult(C.Structure):
+    _fields_ = [("T", C.c_double * 7), ("error", C.c_double), ("chi2", C.c_double), ("n_meas", C.c_int32),
+                ("its", C.c_int32 * MAX_LEVELS), ("stop", C.c_int32)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("patch_size", "max_align_its", "search_size", "max_fast_levels", "margin", "use_orb")]
+
+
+class SearchReq(C.Structure):
+    _fields_ = [("cur", C.c_void_p), ("ref", C.c_void_p), ("cur_pose", C.c_double * 7), ("ref_pose", C.c_double * 7),
+                ("px", C.c_double * 2), ("bearing", C.c_double * 3), ("idepth", C.c_double), ("idepth_std", C.c_double),
+                ("px0", C.c_double * 2), ("level", C.c_int32), ("fixed", C.c_int32), ("desc", C.c_uint8 * 32)]
+
+
+class SearchRes(C.Structure):
+    _fields_ = [("px", C.c_double * 2), ("found", C.c_int32), ("level", C.c_int32), ("best_corner", C.c_int32),
+                ("stage", C.c_int32), ("lk_its", C.c_int32), ("slevel", C.c_int32)]
+
+
+class SynthView(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("plane", C.c_double * 4),
+                ("seed", C.c_uint32), ("frame_id", C.c_uint32)]
+
+
+# every symbol include/sdvl_hip.h declares
+ABI_SYMBOLS = [
+    "sdvl_ctx_create", "sdvl_ctx_destroy", "sdvl_last_error", "sdvl_ctx_synchronize", "sdvl_ctx_stream",
+    "sdvl_ctx_timing_enable", "sdvl_ctx_timing_get", "sdvl_ctx_timing_reset",
+    "sdvl_frame_create", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frame_set_image_device",
+    "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
+    "sdvl_frame_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
+    "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches",
+    "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsdvl_hip.so; raises SdvlError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdvlError("libsdvl_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                            % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.sdvl_last_error.restype = C.c_char_p
+        lib.sdvl_last_error.argtypes = [C.c_void_p]
+        lib.sdvl_ctx_stream.restype = C.c_void_p
+        lib.sdvl_ctx_stream.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Frame:
+    """Device-resident Frame (pyramid + corners + descriptors) behind an sdvl_frame handle."""
+
+    def __init__(self, ctx, width, height, levels=5):
+        self.ctx = ctx
+        self.width, self.height, self.levels = width, height, levels
+        h = C.c_void_p()
+        ctx._check(ctx.lib.sdvl_frame_create(ctx.h, width, height, levels, C.byref(h)))
+        self.h = h
+
+    def upload(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.height, self.width)
+        self._keep = img
+        self.ctx._check(self.ctx.lib.sdvl_frame_upload(self.ctx.h, self.h, _ptr(img, u8p), self.width))
+        return self
+
+    def set_image_device(self, dev_ptr, stride=None):
+        self.ctx._check(self.ctx.lib.sdvl_frame_set_image_device(self.ctx.h, self.h, C.c_void_p(dev_ptr), stride or self.width))
+        return self
+
+    def level(self, l):
+        w, h = self.width >> l, self.height >> l
+        out = np.zeros((h, w), np.uint8)
+        self.ctx._check(self.ctx.lib.sdvl_frame_download_level(self.ctx.h, self.h, l, _ptr(out, u8p), w))
+        return out
+
+    def set_corners(self, xyl):
+        xyl = np.ascontiguousarray(xyl, np.int32).reshape(-1, 3)
+        self.ctx._check(self.ctx.lib.sdvl_frame_set_corners(self.ctx.h, self.h, len(xyl), _ptr(xyl, i32p)))
+        return self
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.sdvl_frame_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    """One sdvl_ctx = one HIP stream on one MI355X."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.sdvl_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise SdvlError("sdvl_ctx_create(device=%d) failed with %d: no MI355X visible; there is no CPU fallback" % (device, rc))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SdvlError("sdvl error %d: %s" % (rc, self.lib.sdvl_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.sdvl_ctx_destroy(self.h)
+            self.h = None
+
+    def stream(self):
+        return self.lib.sdvl_ctx_stream(self.h)
+
+    def synchronize(self):
+        self._check(self.lib.sdvl_ctx_synchronize(self.h))
+
+    # ---- timing
+    def timing_enable(self, on=True):
+        self._check(self.lib.sdvl_ctx_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._check(self.lib.sdvl_ctx_timing_reset(self.h))
+
+    def timing_get(self):
+        names = ((C.c_char * 32) * 32)()
+        ms = (C.c_double * 32)()
+        launches = (C.c_int64 * 32)()
+        n = C.c_int()
+        self._check(self.lib.sdvl_ctx_timing_get(self.h, 32, names, ms, launches, C.byref(n)))
+        return {names[i].value.decode(): (ms[i], launches[i]) for i in range(n.value)}
+
+    # ---- frames
+    def frame(self, img=None, width=None, height=None, levels=5, pyramid=True):
+        if img is not None:
+            height, width = img.shape
+        f = Frame(self, width, height, levels)
+        if img is not None:
+            f.upload(img)
+            if pyramid:
+                self.pyramid_build([f])
+        return f
+
+    def pyramid_build(self, frames):
+        arr = (C.c_void_p * len(frames))(*[f.h for f in frames])
+        self._check(self.lib.sdvl_pyramid_build(self.h, len(frames), arr))
+
+    def fast_cells(self, frames, dp, cap=16384):
+        """-> list of (keypoints[(x,y,score,level,cell)], cell_offsets) per frame"""
+        n = len(frames)
+        cpl = (C.c_int * 4)()
+        tot = C.c_int()
+        self._check(self.lib.sdvl_fast_num_cells(frames[0].width, frames[0].height, C.byref(dp), cpl, C.byref(tot)))
+        kps = (Keypoint * (n * cap))()
+        offs = np.zeros((n, tot.value + 1), np.int32)
+        arr = (C.c_void_p * n)(*[f.h for f in frames])
+        self._check(self.lib.sdvl_fast_cells(self.h, n, arr, C.byref(dp), cap, kps, _ptr(offs, i32p)))
+        raw = np.frombuffer(kps, dtype=np.dtype([("x", "<u2"), ("y", "<u2"), ("score", "u1"), ("level", "u1"), ("cell", "<u2")]))
+        out = []
+        for i in range(n):
+            k = raw[i * cap: i * cap + offs[i, -1]]
+            out.append((np.stack([k["x"], k["y"], k["score"], k["level"], k["cell"]], 1).astype(np.int32), offs[i].copy()))
+        return out, [cpl[i] for i in range(dp.max_fast_levels)]
+
+    def shi_tomasi(self, frames, cap=MAX_CORNERS):
+        n = len(frames)
+        out = np.zeros((n, cap), np.float64)
+        arr = (C.c_void_p * n)(*[f.h for f in frames])
+        self._check(self.lib.sdvl_shi_tomasi(self.h, n, arr, cap, _ptr(out, f64p)))
+        return [out[i, :self.lib.sdvl_frame_num_corners(frames[i].h)].copy() for i in range(n)]
+
+    def orb_describe(self, frames, want=True, cap=MAX_CORNERS):
+        n = len(frames)
+        arr = (C.c_void_p * n)(*[f.h for f in frames])
+        if not want:
+            self._check(self.lib.sdvl_orb_describe(self.h, n, arr, cap, None))
+            return None
+        out = np.zeros((n, cap, 32), np.uint8)
+        self._check(self.lib.sdvl_orb_describe(self.h, n, arr, cap, _ptr(out, u8p)))
+        return [out[i, :self.lib.sdvl_frame_num_corners(frames[i].h)].copy() for i in range(n)]
+
+    def orb_describe_points(self, frame, xyl):
+        xyl = np.ascontiguousarray(xyl, np.int32).reshape(-1, 3)
+        desc = np.zeros((len(xyl), 32), np.uint8)
+        ang = np.zeros(len(xyl), np.float32)
+        self._check(self.lib.sdvl_orb_describe_points(self.h, frame.h, len(xyl), _ptr(xyl, i32p), _ptr(desc, u8p), _ptr(ang, f32p)))
+        return desc, ang
+
+    def image_align(self, jobs, feats, cam, ap):
+        """jobs: list of (ref Frame, cur Frame, feat_begin, feat_end, T7); feats: AlignFeature array"""
+        n = len(jobs)
+        ja = (AlignJob * n)()
+        for i, (ref, cur, b, e, T) in enumerate(jobs):
+            ja[i].ref = ref.h.value
+            ja[i].cur = cur.h.value
+            ja[i].feat_begin, ja[i].feat_end = b, e
+            for k in range(7):
+                ja[i].T[k] = float(T[k])
+        res = (AlignResult * n)()
+        self._check(self.lib.sdvl_image_align(self.h, n, ja, len(feats), feats, C.byref(cam), C.byref(ap), res))
+        return res
+
+    def search_points(self, reqs, cam, sp):
+        n = len(reqs)
+        res = (SearchRes * n)()
+        self._check(self.lib.sdvl_search_points(self.h, n, reqs, C.byref(cam), C.byref(sp), res))
+        return res
+
+    def align_patches(self, frames, levels, border, patch, uv, max_its=10):
+        n = len(frames)
+        arr = (C.c_void_p * n)(*[f.h for f in frames])
+        levels = np.ascontiguousarray(levels, np.int32)
+        border = np.ascontiguousarray(border, np.uint8).reshape(n, 100)
+        patch = np.ascontiguousarray(patch, np.uint8).reshape(n, 64)
+        uv = np.array(uv, np.float64).reshape(n, 2)
+        conv = np.zeros(n, np.uint8)
+        its = np.zeros(n, np.int32)
+        self._check(self.lib.sdvl_align_patches(self.h, n, arr, _ptr(levels, i32p), _ptr(border, u8p), _ptr(patch, u8p), max_its,
+                                                _ptr(uv, f64p), _ptr(conv, u8p), _ptr(its, i32p)))
+        return uv, conv, its
+
+    # ---- synthetic frames in HBM
+    def device_malloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self.lib.sdvl_device_malloc(self.h, C.c_int64(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, p):
+        self._check(self.lib.sdvl_device_free(self.h, C.c_void_p(p)))
+
+    def device_download(self, p, nbytes):
+        out = np.zeros(nbytes, np.uint8)
+        self._check(self.lib.sdvl_device_download(self.h, C.c_void_p(p), C.c_int64(nbytes), _ptr(out, u8p)))
+        return out
+
+    def synth_render(self, views, width, height, dev_out, frame_bytes=None):
+        n = len(views)
+        arr = (SynthView * n)(*views)
+        self._check(self.lib.sdvl_synth_render(self.h, n, arr, width, height, C.c_void_p(dev_out), C.c_int64(frame_bytes or width * height)))
+
+
+def default_detect_params(use_orb=True, orb_size=31, patch_size=8):
+    """Config defaults (config.cc:55-85) with the TUM cfg overrides (config/config_tum_f1.cfg:34-42)."""
+    return DetectParams(cell_size=32, max_fast_levels=3, fast_threshold=10,
+                        margin=(4 + orb_size // 2) if use_orb else (1 + patch_size // 2))
+
+
+def default_align_params(fast=False):
+    return AlignParams(max_level=4, min_level=2, max_its=30, patch_size=4, fast=int(fast))
+
+
+def default_search_params(use_orb=True, orb_size=31, patch_size=8):
+    return SearchParams(patch_size=8, max_align_its=10, search_size=6, max_fast_levels=3,
+                        margin=(4 + orb_size // 2) if use_orb else (1 + patch_size // 2), use_orb=int(use_orb))

@@ -1,0 +1,285 @@
+// sdvl_ctx.hip — context, staging buffers, per-kernel HIP-event timing, frame allocation and transfers.
+#include "sdvl_internal.h"
+
+int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned) {
+  if (*cur >= need && *p) return SDVL_OK;
+  size_t want = need + need / 2 + 4096;
+  if (*p) {
+    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (pinned) SDVL_HIP_CHECK(ctx, hipHostFree(*p));
+    else SDVL_HIP_CHECK(ctx, hipFree(*p));
+    *p = nullptr;
+    *cur = 0;
+  }
+  if (pinned) SDVL_HIP_CHECK(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+  else SDVL_HIP_CHECK(ctx, hipMalloc(p, want));
+  *cur = want;
+  return SDVL_OK;
+}
+
+int sdvl_timer_begin(sdvl_ctx *ctx, const char *name) {
+  if (!ctx->timing) return -1;
+  int t = -1;
+  for (size_t i = 0; i < ctx->timers.size(); i++)
+    if (ctx->timers[i].name == name) { t = static_cast<int>(i); break; }
+  if (t < 0) {
+    KernelTimer kt;
+    kt.name = name;
+    ctx->timers.push_back(kt);
+    t = static_cast<int>(ctx->timers.size()) - 1;
+  }
+  sdvl_ctx::Pending p;
+  p.timer = t;
+  for (hipEvent_t *e : {&p.a, &p.b}) {
+    if (!ctx->free_events.empty()) {
+      *e = ctx->free_events.back();
+      ctx->free_events.pop_back();
+    } else if (hipEventCreate(e) != hipSuccess) {
+      return -1;
+    }
+  }
+  (void)hipEventRecord(p.a, ctx->stream);
+  ctx->pending.push_back(p);
+  return static_cast<int>(ctx->pending.size()) - 1;
+}
+
+void sdvl_timer_end(sdvl_ctx *ctx, int pending) {
+  if (pending < 0) return;
+  (void)hipEventRecord(ctx->pending[pending].b, ctx->stream);
+}
+
+static void sdvl_timer_collect(sdvl_ctx *ctx) {
+  for (auto &p : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->timers[p.timer].ms += ms;
+      ctx->timers[p.timer].launches += 1;
+    }
+    ctx->free_events.push_back(p.a);
+    ctx->free_events.push_back(p.b);
+  }
+  ctx->pending.clear();
+}
+
+extern "C" {
+
+int sdvl_ctx_create(int device, sdvl_ctx **out) {
+  if (!out) return SDVL_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SDVL_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return SDVL_ERR_INVALID;
+  sdvl_ctx *ctx = new sdvl_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return SDVL_ERR_HIP;
+  }
+  *out = ctx;
+  return SDVL_OK;
+}
+
+int sdvl_ctx_destroy(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  sdvl_timer_collect(ctx);
+  for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+  if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+  if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->d_work) (void)hipFree(ctx->d_work);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SDVL_OK;
+}
+
+const char *sdvl_last_error(const sdvl_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int sdvl_ctx_synchronize(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return SDVL_OK;
+}
+
+void *sdvl_ctx_stream(sdvl_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+int sdvl_ctx_timing_enable(sdvl_ctx *ctx, int on) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  ctx->timing = on;
+  return SDVL_OK;
+}
+
+int sdvl_ctx_timing_get(sdvl_ctx *ctx, int cap, char (*names)[32], double *ms, int64_t *launches, int *n) {
+  if (!ctx || !n) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  sdvl_timer_collect(ctx);
+  int k = 0;
+  for (const auto &t : ctx->timers) {
+    if (k >= cap) break;
+    if (names) { strncpy(names[k], t.name.c_str(), 31); names[k][31] = 0; }
+    if (ms) ms[k] = t.ms;
+    if (launches) launches[k] = t.launches;
+    k++;
+  }
+  *n = k;
+  return SDVL_OK;
+}
+
+int sdvl_ctx_timing_reset(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  sdvl_timer_collect(ctx);
+  for (auto &t : ctx->timers) { t.ms = 0.0; t.launches = 0; }
+  return SDVL_OK;
+}
+
+// ---- frames -------------------------------------------------------------------------------------------------
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_frame **out) {
+  if (!ctx || !out) return SDVL_ERR_INVALID;
+  *out = nullptr;
+  SDVL_REQUIRE(ctx, width >= 16 && height >= 16 && width <= 4095 && height <= 4095, "frame size out of range");
+  SDVL_REQUIRE(ctx, levels >= 1 && levels <= SDVL_MAX_LEVELS, "pyramid levels out of range");
+  SDVL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  sdvl_frame *f = new sdvl_frame();
+  memset(&f->v, 0, sizeof(f->v));
+  f->width = width;
+  f->height = height;
+  size_t off = 0, lo[SDVL_MAX_LEVELS];
+  int w = width, h = height;
+  for (int l = 0; l < levels; l++) {
+    f->v.lw[l] = w;
+    f->v.lh[l] = h;
+    lo[l] = off;
+    off = align_up(off + static_cast<size_t>(w) * h + 64, 256);  // +64: slack so that 16-byte tile loads may overrun a row end
+    w /= 2;
+    h /= 2;
+    if (w < 1 || h < 1) { delete f; SDVL_REQUIRE(ctx, false, "image too small for the pyramid depth"); }
+  }
+  const size_t corners_off = off;
+  off = align_up(off + sizeof(int32_t) * 4 * SDVL_MAX_CORNERS, 256);
+  const size_t desc_off = off;
+  off = align_up(off + 32 * SDVL_MAX_CORNERS, 256);
+  // per-cell FAST lists: worst case cell size 16 on the 3 finest levels
+  int max_cells = 0;
+  for (int l = 0; l < levels && l < 4; l++) max_cells += ((f->v.lw[l] + 15) / 16) * ((f->v.lh[l] + 15) / 16);
+  f->max_cells = max_cells / 4 + 64;  // capacity (in cells) of the per-cell lists below: cell_size >= 32
+  const size_t counts_off = off;
+  off = align_up(off + sizeof(int32_t) * (max_cells + 1), 256);
+  const size_t kps_off = off;
+  off = align_up(off + sizeof(uint32_t) * SDVL_CELL_KP_CAP * f->max_cells, 256);
+  f->bytes = off;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&f->base), off);
+  if (e != hipSuccess) {
+    ctx->err = std::string("hipMalloc(frame): ") + hipGetErrorString(e);
+    delete f;
+    return SDVL_ERR_HIP;
+  }
+  for (int l = 0; l < levels; l++) f->v.level[l] = f->base + lo[l];
+  f->v.levels = levels;
+  f->v.n_corners = 0;
+  f->v.corners = reinterpret_cast<int32_t *>(f->base + corners_off);
+  f->v.desc = f->base + desc_off;
+  f->cell_counts = reinterpret_cast<int32_t *>(f->base + counts_off);
+  f->cell_kps = reinterpret_cast<uint32_t *>(f->base + kps_off);
+  f->desc_valid = 0;
+  *out = f;
+  return SDVL_OK;
+}
+
+int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f) {
+  if (!ctx || !f) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipFree(f->base));
+  delete f;
+  return SDVL_OK;
+}
+
+int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stride) {
+  if (!ctx || !f || !img) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, stride >= f->width, "stride smaller than width");
+  // hipMemcpy2DAsync from pageable memory stages internally; it returns once the source has been consumed.
+  SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, img, stride, f->width, f->height, hipMemcpyHostToDevice,
+                                       ctx->stream));
+  f->v.n_corners = 0;
+  f->desc_valid = 0;
+  return SDVL_OK;
+}
+
+int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride) {
+  if (!ctx || !f || !dev_img) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, stride >= f->width, "stride smaller than width");
+  SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, dev_img, stride, f->width, f->height,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+  f->v.n_corners = 0;
+  f->desc_valid = 0;
+  return SDVL_OK;
+}
+
+int sdvl_frame_download_level(sdvl_ctx *ctx, const sdvl_frame *f, int level, uint8_t *out, int stride) {
+  if (!ctx || !f || !out) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, level >= 0 && level < f->v.levels, "level out of range");
+  SDVL_REQUIRE(ctx, stride >= f->v.lw[level], "stride smaller than level width");
+  SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(out, stride, f->v.level[level], f->v.lw[level], f->v.lw[level], f->v.lh[level],
+                                       hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return SDVL_OK;
+}
+
+int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *xyl) {
+  if (!ctx || !f || (n > 0 && !xyl)) return SDVL_ERR_INVALID;
+  if (n < 0 || n > SDVL_MAX_CORNERS) {
+    ctx->err = "too many corners for one frame (SDVL_MAX_CORNERS)";
+    return SDVL_ERR_CAPACITY;
+  }
+  // validate on the host: every corner must lie inside its level image (kernels index with it)
+  for (int i = 0; i < n; i++) {
+    const int x = xyl[3 * i], y = xyl[3 * i + 1], l = xyl[3 * i + 2];
+    SDVL_REQUIRE(ctx, l >= 0 && l < f->v.levels && x >= 0 && y >= 0 && x < f->v.lw[l] && y < f->v.lh[l],
+                 "corner outside its pyramid level");
+  }
+  if (n > 0) {
+    const size_t bytes = sizeof(int32_t) * 4 * n;
+    int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
+    if (rc) return rc;
+    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier copy
+    int32_t *st = static_cast<int32_t *>(ctx->h_stage);
+    for (int i = 0; i < n; i++) {
+      st[4 * i] = xyl[3 * i]; st[4 * i + 1] = xyl[3 * i + 1]; st[4 * i + 2] = xyl[3 * i + 2]; st[4 * i + 3] = 0;
+    }
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(f->v.corners, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  f->v.n_corners = n;
+  f->desc_valid = 0;
+  return SDVL_OK;
+}
+
+int sdvl_frame_num_corners(const sdvl_frame *f) { return f ? f->v.n_corners : SDVL_ERR_INVALID; }
+
+int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out) {
+  if (!ctx || !out || bytes <= 0) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  SDVL_HIP_CHECK(ctx, hipMalloc(out, static_cast<size_t>(bytes)));
+  return SDVL_OK;
+}
+
+int sdvl_device_free(sdvl_ctx *ctx, void *p) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipFree(p));
+  return SDVL_OK;
+}
+
+int sdvl_device_download(sdvl_ctx *ctx, const void *dev, int64_t bytes, void *host) {
+  if (!ctx || !dev || !host || bytes <= 0) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(host, dev, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return SDVL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+// sdvl_image_align.hip — K5/K6 sparse direct image alignment, ImageAlign::ComputePose (image_align.cc:46-84).
+// One 512-thread workgroup per frame pair runs the WHOLE coarse-to-fine Gauss-Newton on device (levels
+// max..min x <= max_its iterations) — no host round trip per iteration:
+//   PrecomputePatches (:208-267)  work item = (feature, pixel of the 4x4 patch): bilinear reference patch (float)
+//                                 and the 6-vector Jacobian (double) into an L2-resident cache in HBM;
+//   ComputeResiduals (:127-206)   phase A, thread = feature: project with the current SE3, bilinear weights -> LDS;
+//                                 phase B, thread = (feature, pixel): residual, upper triangle of J J^T (21), J res (6),
+//                                 chi2, count in FP64 registers; halving butterfly over the wave (32 DP shuffles for 32
+//                                 values instead of 6 per value), fixed-order sum over the 8 waves in LDS;
+//   Optimize (:86-125)            thread 0: pivoted LDLT 6x6, chi2 / NaN / stop_ tests, roll-back, T <- T * Exp(-x).
+// Float vs double follow the reference statement by statement; the only deviation is the reduction ORDER of H, Jres
+// (double) and chi2 (float in the reference, accumulated in double here), hence tolerance-class parity (1e-4).
+#include "sdvl_internal.h"
+#include "sdvl_math.h"
+
+namespace {
+
+using namespace sdvl;
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxF = SDVL_MAX_ALIGN_FEATURES;
+
+struct IaJob {
+  const uint8_t *ref_level[SDVL_MAX_LEVELS];
+  const uint8_t *cur_level[SDVL_MAX_LEVELS];
+  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
+  int feat_begin, n_feat;
+  double T[7];
+  float *patch_cache;  // [n_feat*16]
+  double *jac_cache;   // [n_feat*16][6]
+};
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask, 64);
+  hi = __shfl_xor(hi, mask, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// Halving butterfly: on return the even lane 2j (and its odd partner) holds the wave-wide sum of value index
+// idx(2j) = lane bits (5,4,3,2,1) read as a 5-bit number.  32 values in, 32 DP shuffles.
+__device__ __forceinline__ double wave_reduce32(double *v, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const bool up = lane & 32;
+    const double keep = up ? v[i + 16] : v[i], send = up ? v[i] : v[i + 16];
+    v[i] = keep + shfl_xor_f64(send, 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const bool up = lane & 16;
+    const double keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+    v[i] = keep + shfl_xor_f64(send, 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool up = lane & 8;
+    const double keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+    v[i] = keep + shfl_xor_f64(send, 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const bool up = lane & 4;
+    const double keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+    v[i] = keep + shfl_xor_f64(send, 4);
+  }
+  {
+    const bool up = lane & 2;
+    const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = keep + shfl_xor_f64(send, 2);
+  }
+  return v[0] + shfl_xor_f64(v[0], 1);
+}
+
+__global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__restrict__ jobs,
+                                                               const sdvl_align_feature *__restrict__ feats_all, Cam cam,
+                                                               sdvl_align_params prm, sdvl_align_result *__restrict__ out) {
+  __shared__ int s_ui[kMaxF], s_vi[kMaxF];
+  __shared__ float s_w[4][kMaxF];
+  __shared__ uint8_t s_ok[kMaxF], s_vis[kMaxF];
+  __shared__ double s_red[kWaves][32];
+  __shared__ double s_sum[32];
+  __shared__ double s_T[7], s_R[9];
+  __shared__ int s_break, s_abort;
+
+  const IaJob &job = jobs[blockIdx.x];
+  const int nf = job.n_feat;
+  const sdvl_align_feature *F = feats_all + job.feat_begin;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_items = nf * 16;
+
+  // thread-0 optimiser state (image_align.cc:33-39)
+  SE3 T = se3_identity(), T_bk = se3_identity();
+  double chi2 = 1e10, error = 1e10;
+  bool stop = false;
+  int n_meas = 0;
+  int its[SDVL_MAX_LEVELS];
+#pragma unroll
+  for (int i = 0; i < SDVL_MAX_LEVELS; i++) its[i] = 0;
+
+  for (int f = tid; f < nf; f += kThreads) s_vis[f] = 0;
+  if (tid == 0) {
+    T = se3_from7(job.T);
+    se3_to7(T, s_T);
+    const M3 R = se3_rot(T);
+    for (int i = 0; i < 9; i++) s_R[i] = R.m[i];
+    s_abort = 0;
+  }
+  __syncthreads();
+
+  for (int level = prm.max_level; level >= prm.min_level; level--) {
+    const int W = job.lw[level], H = job.lh[level];
+    const uint8_t *ref_img = job.ref_level[level];
+    const uint8_t *cur_img = job.cur_level[level];
+    const float scale = 1.0f / (1 << level);
+    // jacobian_cache_.setZero(), image_align.cc:69
+    for (int i = tid; i < n_items * 6; i += kThreads) job.jac_cache[i] = 0.0;
+    if (tid == 0) T_bk = T;
+    __syncthreads();
+
+    for (int it = 0; it < prm.max_its; it++) {
+      if (it == 0) {
+        // ---- PrecomputePatches(level), image_align.cc:208-267
+        const double fl = cam.fx / (1 << level);
+        for (int idx = tid; idx < n_items; idx += kThreads) {
+          const int f = idx >> 4, p = idx & 15;
+          const sdvl_align_feature ft = F[f];
+          const float u_ref = static_cast<float>(ft.px * scale);
+          const float v_ref = static_cast<float>(ft.py * scale);
+          const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
+          const int border = 3;
+          if (!ft.valid || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) continue;
+          if (p == 0) s_vis[f] = 1;
+          const V3 xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+          double fj[12];
+          jacobian_3d_to_plane(xyz, fj);
+          const float su = u_ref - ui, sv = v_ref - vi;
+          const float w_tl = static_cast<float>((1.0 - su) * (1.0 - sv));
+          const float w_tr = static_cast<float>(su * (1.0 - sv));
+          const float w_bl = static_cast<float>((1.0 - su) * sv);
+          const float w_br = su * sv;
+          const int y = p >> 2, x = p & 3;
+          const uint8_t *ip = ref_img + static_cast<size_t>(vi + y - 2) * W + (ui + x - 2);
+          const int st = W;
+          job.patch_cache[idx] = w_tl * ip[0] + w_tr * ip[1] + w_bl * ip[st] + w_br * ip[st + 1];
+          const float dx = 0.5f * ((w_tl * ip[1] + w_tr * ip[2] + w_bl * ip[st + 1] + w_br * ip[st + 2]) -
+                                   (w_tl * ip[-1] + w_tr * ip[0] + w_bl * ip[st - 1] + w_br * ip[st]));
+          const float dy = 0.5f * ((w_tl * ip[st] + w_tr * ip[1 + st] + w_bl * ip[st * 2] + w_br * ip[st * 2 + 1]) -
+                                   (w_tl * ip[-st] + w_tr * ip[1 - st] + w_bl * ip[0] + w_br * ip[1]));
+          double *J = job.jac_cache + static_cast<size_t>(idx) * 6;
+#pragma unroll
+          for (int c = 0; c < 6; c++) J[c] = (dx * fj[c] + dy * fj[6 + c]) * fl;
+        }
+        __syncthreads();
+      }
+      // ---- ComputeResiduals phase A: per-feature projection, image_align.cc:147-181
+      for (int f = tid; f < nf; f += kThreads) {
+        uint8_t ok = 0;
+        if (s_vis[f]) {
+          const sdvl_align_feature ft = F[f];
+          const V3 xr = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+          const V3 xc = {s_R[0] * xr.x + s_R[1] * xr.y + s_R[2] * xr.z + s_T[4], s_R[3] * xr.x + s_R[4] * xr.y + s_R[5] * xr.z + s_T[5],
+                         s_R[6] * xr.x + s_R[7] * xr.y + s_R[8] * xr.z + s_T[6]};
+          const V2 pr = cam_project(cam, xc);
+          const float u_cur = static_cast<float>(pr.x * scale);
+          const float v_cur = static_cast<float>(pr.y * scale);
+          const float fu = floorf(u_cur), fv = floorf(v_cur);
+          // (int)floorf of NaN / huge values is undefined on the CPU; treat anything outside the image as a miss
+          if (fu >= 3.f && fv >= 3.f && fu < static_cast<float>(W - 3) && fv < static_cast<float>(H - 3)) {
+            const int ui = static_cast<int>(fu), vi = static_cast<int>(fv);
+            const float su = u_cur - ui, sv = v_cur - vi;
+            s_ui[f] = ui;
+            s_vi[f] = vi;
+            s_w[0][f] = static_cast<float>((1.0 - su) * (1.0 - sv));
+            s_w[1][f] = static_cast<float>(su * (1.0 - sv));
+            s_w[2][f] = static_cast<float>((1.0 - su) * sv);
+            s_w[3][f] = su * sv;
+            ok = 1;
+          }
+        }
+        s_ok[f] = ok;
+      }
+      __syncthreads();
+      // ---- phase B: residuals + normal equations, image_align.cc:182-203
+      double acc[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) acc[i] = 0.0;
+      for (int idx = tid; idx < n_items; idx += kThreads) {
+        const int f = idx >> 4;
+        if (!s_ok[f]) continue;
+        const int p = idx & 15, y = p >> 2, x = p & 3;
+        const uint8_t *ip = cur_img + static_cast<size_t>(s_vi[f] + y - 2) * W + (s_ui[f] + x - 2);
+        const float intensity = s_w[0][f] * ip[0] + s_w[1][f] * ip[1] + s_w[2][f] * ip[W] + s_w[3][f] * ip[W + 1];
+        const float res = intensity - job.patch_cache[idx];
+        const double *Jp = job.jac_cache + static_cast<size_t>(idx) * 6;
+        double J[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) J[c] = Jp[c];
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = r; c < 6; c++) acc[k++] += J[r] * J[c];
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[21 + r] -= J[r] * res;
+        acc[27] += static_cast<double>(res * res);
+        acc[28] += 1.0;
+      }
+      const double tot = wave_reduce32(acc, lane);
+      if ((lane & 1) == 0) {
+        const int vidx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) |
+                         ((lane >> 1) & 1);
+        s_red[wave][vidx] = tot;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) s += s_red[w][tid];
+        s_sum[tid] = s;
+      }
+      __syncthreads();
+      // ---- Optimize body, image_align.cc:93-124
+      if (tid == 0) {
+        double Hm[36], Jres[6], x[6];
+        int k = 0;
+        for (int r = 0; r < 6; r++)
+          for (int c = r; c < 6; c++) {
+            Hm[6 * r + c] = s_sum[k];
+            Hm[6 * c + r] = s_sum[k];
+            k++;
+          }
+        for (int r = 0; r < 6; r++) Jres[r] = s_sum[21 + r];
+        n_meas = static_cast<int>(s_sum[28]);
+        const double new_chi2 = static_cast<double>(static_cast<float>(s_sum[27]) / static_cast<float>(n_meas));
+        if (n_meas == 0) stop = true;
+        ldlt_solve6(Hm, Jres, x);
+        if (x[0] != x[0]) stop = true;
+        int brk = 0;
+        if ((it > 0 && new_chi2 > chi2) || stop) {
+          T = T_bk;
+          brk = 1;
+        } else {
+          T_bk = T;
+          double mx[6];
+          for (int r = 0; r < 6; r++) mx[r] = -x[r];
+          T = se3_mul(T, se3_exp(mx));
+          chi2 = new_chi2;
+          its[level]++;
+          error = abs_max6(x);
+          if (error <= 1e-10) brk = 1;
+        }
+        se3_to7(T, s_T);
+        const M3 R = se3_rot(T);
+        for (int i = 0; i < 9; i++) s_R[i] = R.m[i];
+        s_break = brk;
+      }
+      __syncthreads();
+      if (s_break) break;
+    }
+    // image_align.cc:73-76
+    if (tid == 0 && prm.fast && error > 0.01) {
+      error = 1e10;
+      s_abort = 1;
+    }
+    __syncthreads();
+    if (s_abort) break;
+  }
+  if (tid == 0) {
+    sdvl_align_result r;
+    se3_to7(T, r.T);
+    r.error = error;
+    r.chi2 = chi2;
+    r.n_meas = n_meas / 16;
+    for (int i = 0; i < SDVL_MAX_LEVELS; i++) r.its[i] = its[i];
+    r.stop = stop ? 1 : 0;
+    out[blockIdx.x] = r;
+  }
+}
+
+}  // namespace
+
+extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
+                                const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p,
+                                sdvl_align_result *out) {
+  if (!ctx || !cam || !p || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out)) || n_features < 0 || (n_features > 0 && !features))
+    return SDVL_ERR_INVALID;
+  if (n_jobs == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, p->patch_size == 4, "only align_patch_size 4 is supported");
+  SDVL_REQUIRE(ctx, p->min_level >= 0 && p->max_level >= p->min_level && p->max_level < SDVL_MAX_LEVELS, "bad align levels");
+  SDVL_REQUIRE(ctx, p->max_its >= 0, "bad max_its");
+  size_t work = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    const sdvl_align_job &a = jobs[j];
+    SDVL_REQUIRE(ctx, a.ref && a.cur, "null frame in alignment job");
+    SDVL_REQUIRE(ctx, a.ref->width == a.cur->width && a.ref->height == a.cur->height && a.ref->v.levels == a.cur->v.levels,
+                 "frame pair with different geometry");
+    SDVL_REQUIRE(ctx, p->max_level < a.ref->v.levels, "max_align_level exceeds the pyramid depth");
+    SDVL_REQUIRE(ctx, a.feat_begin >= 0 && a.feat_end >= a.feat_begin && a.feat_end <= n_features, "feature range out of bounds");
+    if (a.feat_end - a.feat_begin > kMaxF) {
+      ctx->err = "too many features in one alignment job (SDVL_MAX_ALIGN_FEATURES)";
+      return SDVL_ERR_CAPACITY;
+    }
+    work += static_cast<size_t>(a.feat_end - a.feat_begin) * 16 * (sizeof(float) + 6 * sizeof(double));
+    work = (work + 255) / 256 * 256;
+  }
+  const size_t job_bytes = (sizeof(IaJob) * n_jobs + 255) / 256 * 256;
+  const size_t feat_bytes = sizeof(sdvl_align_feature) * static_cast<size_t>(n_features);
+  const size_t res_bytes = sizeof(sdvl_align_result) * n_jobs;
+  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, job_bytes + feat_bytes, true);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, job_bytes + feat_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, work + 256, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, res_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, res_bytes, true);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  IaJob *hj = static_cast<IaJob *>(ctx->h_stage);
+  uint8_t *wbase = static_cast<uint8_t *>(ctx->d_work);
+  size_t woff = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    const sdvl_align_job &a = jobs[j];
+    IaJob &d = hj[j];
+    memset(&d, 0, sizeof(IaJob));
+    for (int l = 0; l < a.ref->v.levels; l++) {
+      d.ref_level[l] = a.ref->v.level[l];
+      d.cur_level[l] = a.cur->v.level[l];
+      d.lw[l] = a.ref->v.lw[l];
+      d.lh[l] = a.ref->v.lh[l];
+    }
+    d.feat_begin = a.feat_begin;
+    d.n_feat = a.feat_end - a.feat_begin;
+    for (int k = 0; k < 7; k++) d.T[k] = a.T[k];
+    const size_t items = static_cast<size_t>(d.n_feat) * 16;
+    d.jac_cache = reinterpret_cast<double *>(wbase + woff);
+    d.patch_cache = reinterpret_cast<float *>(wbase + woff + items * 6 * sizeof(double));
+    woff += items * (sizeof(float) + 6 * sizeof(double));
+    woff = (woff + 255) / 256 * 256;
+  }
+  if (feat_bytes) memcpy(static_cast<uint8_t *>(ctx->h_stage) + job_bytes, features, feat_bytes);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, job_bytes + feat_bytes, hipMemcpyHostToDevice, ctx->stream));
+  Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  {
+    ScopedKernelTimer tm(ctx, "image_align");
+    hipLaunchKernelGGL(image_align_kernel, dim3(n_jobs), dim3(kThreads), 0, ctx->stream, static_cast<const IaJob *>(ctx->d_stage),
+                       reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(ctx->d_stage) + job_bytes), c, *p,
+                       static_cast<sdvl_align_result *>(ctx->d_out));
+  }
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, ctx->h_out, res_bytes);
+  return SDVL_OK;
+}

@@ -1,0 +1,296 @@
+// sdvl_orb.hip — K3 Shi-Tomasi score and K4 ORB (orientation + 256-bit steered BRIEF), one wave64 per corner.
+//   K4  orb_describe_kernel : ORBDetector::GetDescriptor / GetOrientation, extra/orb_detector.cc:350-437.
+//        Orientation: lanes stride the radius-15 disc (umax_ table of InitParameters :325-348), exact int32
+//        moments, wave butterfly; cv::fastAtan2 polynomial in float (all lanes redundantly -> no broadcast);
+//        cos/sin of the float angle in double, rounded to float (DESIGN.md "frozen interpretations");
+//        lane k evaluates tests 4k..4k+3 with cvRound = v_rndne_f32, nibbles are merged pairwise into bytes.
+//   K3  shi_tomasi_kernel   : FindShiTomasiScoreAtPoint, extra/utils.cc:61-97 — lane = pixel of the 8x8 box,
+//        exact int32 sums (every partial sum < 2^24 so the reference's float loop is exact too), float/double tail.
+// No FMA contraction (-ffp-contract=off): sample coordinates round exactly as on the CPU.
+#include "sdvl_internal.h"
+
+namespace {
+
+__constant__ int8_t c_orb_pattern[256 * 4] = {
+#include "orb_pattern_31.inc"
+};
+
+// umax_[v] for HALF_PATCH_SIZE = 15 (orb_detector.cc:325-348)
+__constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+struct OrbJob {
+  const uint8_t *level[SDVL_MAX_LEVELS];
+  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
+  const int32_t *corners;  // [n][4]
+  uint8_t *desc;           // [n][32] in HBM
+  uint8_t *out;            // optional second copy (host-bound buffer), may be null
+  float *out_angle;        // optional
+  double *out_score;       // shi-tomasi output
+  int n;
+  int levels;
+};
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// cv::fastAtan2 (degrees), OpenCV >= 2.4.9 scalar polynomial
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * static_cast<float>(180 / M_PI);
+  const float p3 = -0.3258083974640975f * static_cast<float>(180 / M_PI);
+  const float p5 = 0.1555786518463281f * static_cast<float>(180 / M_PI);
+  const float p7 = -0.04432655554792128f * static_cast<float>(180 / M_PI);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + static_cast<float>(2.2204460492503131e-16));
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + static_cast<float>(2.2204460492503131e-16));
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__device__ __forceinline__ int cv_round_f(float v) { return static_cast<int>(__builtin_rintf(v)); }
+
+// grid.x = ceil(max_n / 4) workgroups of 4 waves, grid.y = jobs (frames)
+__global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restrict__ jobs) {
+  const OrbJob &job = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ci >= job.n) return;  // wave-uniform
+  const int cx = job.corners[4 * ci], cy = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
+  if (cl < 0 || cl >= job.levels) return;
+  const int W = job.lw[cl], H = job.lh[cl];
+  uint8_t *dst = job.desc + static_cast<size_t>(ci) * 32;
+  // ORBDetector::IsInsideLimits (orb_detector.cc:439-445); the reference asserts it
+  if (!(cx >= 19 && cx < W - 19 && cy >= 19 && cy < H - 19)) {
+    if (lane < 32) {
+      dst[lane] = 0;
+      if (job.out) job.out[static_cast<size_t>(ci) * 32 + lane] = 0;
+    }
+    if (lane == 0 && job.out_angle) job.out_angle[ci] = -1.f;
+    return;
+  }
+  const uint8_t *center = job.level[cl] + static_cast<size_t>(cy) * W + cx;
+  // intensity centroid over the disc: 31 rows x 31 cols candidates, masked by umax
+  int m10 = 0, m01 = 0;
+  for (int idx = lane; idx < 31 * 31; idx += 64) {
+    const int v = idx / 31 - 15, u = idx - (v + 15) * 31 - 15;
+    const int av = v < 0 ? -v : v;
+    if ((u < 0 ? -u : u) <= c_umax[av]) {
+      const int p = center[v * W + u];
+      m10 += u * p;
+      m01 += v * p;
+    }
+  }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
+  const float angle_deg = fast_atan2_deg(static_cast<float>(m01), static_cast<float>(m10));
+  const float factorPI = static_cast<float>(M_PI / 180.f);
+  const float angle = static_cast<float>(static_cast<double>(angle_deg) * factorPI);
+  const float a = static_cast<float>(cos(static_cast<double>(angle)));
+  const float b = static_cast<float>(sin(static_cast<double>(angle)));
+  // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..)
+  uint32_t nib = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int8_t *pt = &c_orb_pattern[(4 * lane + q) * 4];
+    const int x0 = pt[0], y0 = pt[1], x1 = pt[2], y1 = pt[3];
+    const int t0 = center[cv_round_f(x0 * b + y0 * a) * W + cv_round_f(x0 * a - y0 * b)];
+    const int t1 = center[cv_round_f(x1 * b + y1 * a) * W + cv_round_f(x1 * a - y1 * b)];
+    nib |= (t0 < t1 ? 1u : 0u) << q;
+  }
+  const uint32_t hi = __shfl_down(nib, 1, 64);
+  if ((lane & 1) == 0) {
+    const uint8_t byte = static_cast<uint8_t>(nib | (hi << 4));
+    dst[lane >> 1] = byte;
+    if (job.out) job.out[static_cast<size_t>(ci) * 32 + (lane >> 1)] = byte;
+  }
+  if (lane == 0 && job.out_angle) job.out_angle[ci] = angle_deg;
+}
+
+__global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restrict__ jobs) {
+  const OrbJob &job = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ci >= job.n) return;
+  const int px = job.corners[4 * ci], py = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
+  if (cl < 0 || cl >= job.levels) return;
+  const int W = job.lw[cl], H = job.lh[cl];
+  const int x_min = px - 4, x_max = px + 4, y_min = py - 4, y_max = py + 4;
+  if (x_min < 1 || x_max >= W - 1 || y_min < 1 || y_max >= H - 1) {
+    if (lane == 0) job.out_score[ci] = 0.0;
+    return;
+  }
+  const uint8_t *img = job.level[cl];
+  const int y = y_min + (lane >> 3), x = x_min + (lane & 7);
+  const int dx = static_cast<int>(img[static_cast<size_t>(y) * W + x + 1]) - static_cast<int>(img[static_cast<size_t>(y) * W + x - 1]);
+  const int dy = static_cast<int>(img[static_cast<size_t>(y + 1) * W + x]) - static_cast<int>(img[static_cast<size_t>(y - 1) * W + x]);
+  const int sxx = wave_sum_i32(dx * dx), syy = wave_sum_i32(dy * dy), sxy = wave_sum_i32(dx * dy);
+  if (lane == 0) {
+    float dXX = static_cast<float>(sxx), dYY = static_cast<float>(syy), dXY = static_cast<float>(sxy);
+    dXX = static_cast<float>(dXX / (2.0 * 64));
+    dYY = static_cast<float>(dYY / (2.0 * 64));
+    dXY = static_cast<float>(dXY / (2.0 * 64));
+    const float disc = (dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY);
+    job.out_score[ci] = 0.5 * (dXX + dYY - sqrt(static_cast<double>(disc)));
+  }
+}
+
+int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *d_out_desc, double *d_out_score,
+              OrbJob **d_jobs, int *max_n) {
+  const size_t bytes = sizeof(OrbJob) * n;
+  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, bytes, false);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  OrbJob *hj = static_cast<OrbJob *>(ctx->h_stage);
+  *max_n = 0;
+  for (int i = 0; i < n; i++) {
+    const FrameView &v = frames[i]->v;
+    memset(&hj[i], 0, sizeof(OrbJob));
+    for (int l = 0; l < v.levels; l++) { hj[i].level[l] = v.level[l]; hj[i].lw[l] = v.lw[l]; hj[i].lh[l] = v.lh[l]; }
+    hj[i].corners = v.corners;
+    hj[i].desc = v.desc;
+    hj[i].out = d_out_desc ? d_out_desc + static_cast<size_t>(i) * cap * 32 : nullptr;
+    hj[i].out_angle = nullptr;
+    hj[i].out_score = d_out_score ? d_out_score + static_cast<size_t>(i) * cap : nullptr;
+    hj[i].n = v.n_corners;
+    hj[i].levels = v.levels;
+    if (v.n_corners > *max_n) *max_n = v.n_corners;
+  }
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *d_jobs = static_cast<OrbJob *>(ctx->d_stage);
+  return SDVL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *out_desc) {
+  if (!ctx || n < 0 || (n > 0 && !frames)) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    if (out_desc && frames[i]->v.n_corners > cap) {
+      ctx->err = "descriptor output capacity smaller than the corner count";
+      return SDVL_ERR_CAPACITY;
+    }
+  }
+  uint8_t *d_desc = nullptr;
+  const size_t out_bytes = out_desc ? static_cast<size_t>(n) * cap * 32 : 0;
+  if (out_desc) {
+    int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
+    if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
+    if (rc) return rc;
+    d_desc = static_cast<uint8_t *>(ctx->d_out);
+  }
+  OrbJob *d_jobs = nullptr;
+  int max_n = 0;
+  int rc = fill_jobs(ctx, n, frames, cap, d_desc, nullptr, &d_jobs, &max_n);
+  if (rc) return rc;
+  if (max_n > 0) {
+    ScopedKernelTimer tm(ctx, "orb_describe");
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_n + 3) / 4, n), dim3(256), 0, ctx->stream, d_jobs);
+    SDVL_HIP_CHECK(ctx, hipGetLastError());
+  }
+  for (int i = 0; i < n; i++) frames[i]->desc_valid = 1;
+  if (out_desc) {
+    if (max_n > 0) {
+      SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, static_cast<size_t>(cap) * 32, d_desc, static_cast<size_t>(cap) * 32,
+                                           static_cast<size_t>(max_n) * 32, n, hipMemcpyDeviceToHost, ctx->stream));
+      SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      for (int i = 0; i < n; i++)
+        memcpy(out_desc + static_cast<size_t>(i) * cap * 32, static_cast<uint8_t *>(ctx->h_out) + static_cast<size_t>(i) * cap * 32,
+               static_cast<size_t>(frames[i]->v.n_corners) * 32);
+    }
+  }
+  return SDVL_OK;
+}
+
+int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, double *out_scores) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !out_scores))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    if (frames[i]->v.n_corners > cap) {
+      ctx->err = "score output capacity smaller than the corner count";
+      return SDVL_ERR_CAPACITY;
+    }
+  }
+  const size_t out_bytes = sizeof(double) * static_cast<size_t>(n) * cap;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
+  if (rc) return rc;
+  OrbJob *d_jobs = nullptr;
+  int max_n = 0;
+  rc = fill_jobs(ctx, n, frames, cap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
+  if (rc) return rc;
+  if (max_n == 0) return SDVL_OK;
+  {
+    ScopedKernelTimer tm(ctx, "shi_tomasi");
+    hipLaunchKernelGGL(shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), 0, ctx->stream, d_jobs);
+  }
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, sizeof(double) * cap, ctx->d_out, sizeof(double) * cap, sizeof(double) * max_n, n,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n; i++)
+    memcpy(out_scores + static_cast<size_t>(i) * cap, static_cast<double *>(ctx->h_out) + static_cast<size_t>(i) * cap,
+           sizeof(double) * frames[i]->v.n_corners);
+  return SDVL_OK;
+}
+
+int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const int32_t *xyl, uint8_t *out_desc,
+                             float *out_angle_deg) {
+  if (!ctx || !f || n < 0 || (n > 0 && (!xyl || !out_desc))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  for (int i = 0; i < n; i++) {
+    const int x = xyl[3 * i], y = xyl[3 * i + 1], l = xyl[3 * i + 2];
+    SDVL_REQUIRE(ctx, l >= 0 && l < f->v.levels && x >= 0 && y >= 0 && x < f->v.lw[l] && y < f->v.lh[l], "point outside its pyramid level");
+  }
+  // device scratch: d_stage = corners[n][4] | OrbJob ; d_out = desc[n][32] | angle[n]
+  const size_t c_bytes = sizeof(int32_t) * 4 * n, d_bytes = 32 * static_cast<size_t>(n), a_bytes = sizeof(float) * n;
+  const size_t job_off = (c_bytes + 255) / 256 * 256;
+  const size_t a_off = (d_bytes + 255) / 256 * 256;
+  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, job_off + sizeof(OrbJob), true);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, job_off + sizeof(OrbJob), false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, a_off + a_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, a_off + a_bytes, true);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t *hc = static_cast<int32_t *>(ctx->h_stage);
+  for (int i = 0; i < n; i++) { hc[4 * i] = xyl[3 * i]; hc[4 * i + 1] = xyl[3 * i + 1]; hc[4 * i + 2] = xyl[3 * i + 2]; hc[4 * i + 3] = 0; }
+  OrbJob *hj = reinterpret_cast<OrbJob *>(static_cast<uint8_t *>(ctx->h_stage) + job_off);
+  memset(hj, 0, sizeof(OrbJob));
+  for (int l = 0; l < f->v.levels; l++) { hj->level[l] = f->v.level[l]; hj->lw[l] = f->v.lw[l]; hj->lh[l] = f->v.lh[l]; }
+  hj->corners = static_cast<int32_t *>(ctx->d_stage);
+  hj->desc = static_cast<uint8_t *>(ctx->d_out);
+  hj->out = nullptr;
+  hj->out_angle = reinterpret_cast<float *>(static_cast<uint8_t *>(ctx->d_out) + a_off);
+  hj->n = n;
+  hj->levels = f->v.levels;
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, job_off + sizeof(OrbJob), hipMemcpyHostToDevice, ctx->stream));
+  {
+    ScopedKernelTimer tm(ctx, "orb_describe");
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((n + 3) / 4, 1), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(ctx->d_stage) + job_off));
+  }
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, a_off + a_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out_desc, ctx->h_out, d_bytes);
+  if (out_angle_deg) memcpy(out_angle_deg, static_cast<uint8_t *>(ctx->h_out) + a_off, a_bytes);
+  return SDVL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,526 @@
+// sdvl_search.hip — K7 batched Matcher::SearchPoint (matcher.cc:45-121), ONE wave64 per request.
+//   phase 0  (all lanes redundantly, FP64): relative pose, depth-interval projection, margin test,
+//            WarpMatrixAffine (:293-312), GetSearchLevel (:314-323), search range;
+//   phase 1  CreatePatch (:325-357): the 100 samples of the 10x10 warped patch over 64 lanes (2 rounds),
+//            Interpolate8U (extra/utils.cc:44-59) in float, truncated to u8 -> LDS;
+//   phase 2  GetCornersInRange (:123-230) + SearchFeatures (:232-291): lanes stride the frame's corner list,
+//            range test in FP64, Hamming distance on the HBM-resident ORB descriptors (or integer ZMSSD),
+//            wave arg-min on the key (score << 20 | index) -> first index wins ties like the sequential loop;
+//   phase 3  AlignPatch (:359-445): lane = pixel of the 8x8 patch.  Template gradients and the 3x3 H from the LDS
+//            border patch (H entries are exact quarter-integers -> any summation order is exact), Eigen's cofactor
+//            inverse in float, then <= max_align_its iterations: bilinear sample per lane, residual products to LDS
+//            and three lanes accumulate them IN THE REFERENCE'S SEQUENTIAL ORDER so that update / convergence
+//            decisions are bit-identical to the CPU path.
+// Compiled with -ffp-contract=off.  sdvl_align_patches exposes phase 3 alone.
+#include "sdvl_internal.h"
+#include "sdvl_math.h"
+
+namespace {
+
+using namespace sdvl;
+
+constexpr int kWavesPerBlock = 4;
+
+struct SearchFrame {
+  const uint8_t *level[SDVL_MAX_LEVELS];
+  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
+  const int32_t *corners;
+  const uint8_t *desc;
+  int n_corners;
+  int levels;
+};
+
+struct SearchReqDev {
+  SearchFrame cur, ref;
+  double cur_pose[7], ref_pose[7];
+  double px[2], bearing[3];
+  double idepth, idepth_std;
+  double px0[2];
+  int level, fixed;
+  uint32_t desc[8];
+};
+
+struct PatchJob {  // sdvl_align_patches
+  const uint8_t *img;
+  int w, h;
+  double u, v;
+};
+
+struct WaveLds {
+  uint8_t border[104];
+  uint8_t patch[64];
+  float prod[3][64];
+};
+
+__device__ __forceinline__ float interpolate8u(const uint8_t *img, int stride, float u, float v) {
+  const int x = static_cast<int>(floorf(u));
+  const int y = static_cast<int>(floorf(v));
+  const float sx = u - x, sy = v - y;
+  const float w00 = (1.0f - sx) * (1.0f - sy);
+  const float w01 = (1.0f - sx) * sy;
+  const float w10 = sx * (1.0f - sy);
+  const float w11 = 1.0f - w00 - w01 - w10;
+  const uint8_t *p = img + static_cast<size_t>(y) * stride + x;
+  return w00 * p[0] + w01 * p[stride] + w10 * p[1] + w11 * p[stride + 1];
+}
+
+// LDS hand-off between the lanes of ONE wave: order the compiler's view of memory, no s_barrier needed
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    unsigned lo = static_cast<unsigned>(v), hi = static_cast<unsigned>(v >> 32);
+    lo = __shfl_xor(lo, off, 64);
+    hi = __shfl_xor(hi, off, 64);
+    const unsigned long long o = (static_cast<unsigned long long>(hi) << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// Matcher::AlignPatch, matcher.cc:359-445.  border/patch in this wave's LDS.  Returns converged; *u,*v updated.
+__device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, int max_its, int lane, float *u_io, float *v_io,
+                                 int *its_out) {
+  const int y = lane >> 3, x = lane & 7;
+  const uint8_t *it = &L.border[(y + 1) * 10 + 1 + x];
+  const int jx = static_cast<int>(it[1]) - static_cast<int>(it[-1]);
+  const int jy = static_cast<int>(it[10]) - static_cast<int>(it[-10]);
+  const float dx = static_cast<float>(0.5 * jx);
+  const float dy = static_cast<float>(0.5 * jy);
+  // H = sum J J^T with J = (dx, dy, 1): quarter-integers, exact in float in any order
+  const float h00 = 0.25f * static_cast<float>(wave_sum_i32(jx * jx));
+  const float h01 = 0.25f * static_cast<float>(wave_sum_i32(jx * jy));
+  const float h11 = 0.25f * static_cast<float>(wave_sum_i32(jy * jy));
+  const float h02 = 0.5f * static_cast<float>(wave_sum_i32(jx));
+  const float h12 = 0.5f * static_cast<float>(wave_sum_i32(jy));
+  const float m[3][3] = {{h00, h01, h02}, {h01, h11, h12}, {h02, h12, 64.f}};
+  // Eigen compute_inverse_size3 (cofactors of column 0, det, multiply by the reciprocal)
+  const float c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1];
+  const float c10 = m[2][1] * m[0][2] - m[2][2] * m[0][1];
+  const float c20 = m[0][1] * m[1][2] - m[0][2] * m[1][1];
+  const float det = (c00 * m[0][0] + c10 * m[1][0]) + c20 * m[2][0];
+  const float invdet = 1.0f / det;
+  float inv[3][3];
+  inv[0][0] = c00 * invdet;
+  inv[0][1] = c10 * invdet;
+  inv[0][2] = c20 * invdet;
+  inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * invdet;
+  inv[1][1] = (m[2][2] * m[0][0] - m[2][0] * m[0][2]) * invdet;
+  inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * invdet;
+  inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * invdet;
+  inv[2][1] = (m[2][0] * m[0][1] - m[2][1] * m[0][0]) * invdet;
+  inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * invdet;
+
+  const float ref = static_cast<float>(L.patch[lane]);
+  float mean_diff = 0.f;
+  float u = *u_io, v = *v_io;
+  const float min_update_squared = static_cast<float>(0.03 * 0.03);
+  bool converged = false;
+  int iters = 0;
+  for (int iter = 0; iter < max_its; iter++) {
+    const float fu = floorf(u), fv = floorf(v);
+    // u_r < half || v_r < half || u_r >= cols-half || v_r >= rows-half -> break   (NaN fails the >= tests -> break)
+    if (!(fu >= 4.f && fv >= 4.f && fu < static_cast<float>(W - 4) && fv < static_cast<float>(H - 4))) break;
+    const int u_r = static_cast<int>(fu), v_r = static_cast<int>(fv);
+    iters++;
+    const float sx = u - u_r, sy = v - v_r;
+    const float wTL = static_cast<float>((1.0 - sx) * (1.0 - sy));
+    const float wTR = static_cast<float>(sx * (1.0 - sy));
+    const float wBL = static_cast<float>((1.0 - sx) * sy);
+    const float wBR = sx * sy;
+    const uint8_t *ip = img + static_cast<size_t>(v_r + y - 4) * W + (u_r + x - 4);
+    const float search_pixel = wTL * ip[0] + wTR * ip[1] + wBL * ip[W] + wBR * ip[W + 1];
+    const float res = search_pixel - ref + mean_diff;
+    L.prod[0][lane] = res * dx;
+    L.prod[1][lane] = res * dy;
+    L.prod[2][lane] = res;
+    wave_sync();
+    // sequential accumulation (matcher.cc:427-429): lanes 0..2 own one component each
+    float acc = 0.f;
+    if (lane < 3) {
+#pragma unroll 8
+      for (int k = 0; k < 64; k++) acc -= L.prod[lane][k];
+    }
+    const float J0 = __shfl(acc, 0, 64), J1 = __shfl(acc, 1, 64), J2 = __shfl(acc, 2, 64);
+    wave_sync();
+    const float up0 = inv[0][0] * J0 + inv[0][1] * J1 + inv[0][2] * J2;
+    const float up1 = inv[1][0] * J0 + inv[1][1] * J1 + inv[1][2] * J2;
+    const float up2 = inv[2][0] * J0 + inv[2][1] * J1 + inv[2][2] * J2;
+    u += up0;
+    v += up1;
+    mean_diff += up2;
+    if (up0 * up0 + up1 * up1 < min_update_squared) {
+      converged = true;
+      break;
+    }
+  }
+  *u_io = u;
+  *v_io = v;
+  *its_out = iters;
+  return converged;
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(const SearchReqDev *__restrict__ reqs, int n, Cam cam,
+                                                                            sdvl_search_params prm,
+                                                                            sdvl_search_res *__restrict__ out) {
+  __shared__ WaveLds s_lds[kWavesPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ri = blockIdx.x * kWavesPerBlock + wv;
+  if (ri >= n) return;
+  WaveLds &L = s_lds[wv];
+  const SearchReqDev &rq = reqs[ri];
+  sdvl_search_res res;
+  res.px[0] = rq.px0[0];
+  res.px[1] = rq.px0[1];
+  res.found = 0;
+  res.level = -1;
+  res.best_corner = -1;
+  res.stage = 0;
+  res.lk_its = 0;
+  res.slevel = -1;
+
+  const int level = rq.level;
+  const SE3 cur_pose = se3_from7(rq.cur_pose), ref_pose = se3_from7(rq.ref_pose);
+  const SE3 ref_world = se3_inverse(ref_pose);
+  const SE3 pose = se3_mul(cur_pose, ref_world);
+  const V3 fvec = {rq.bearing[0], rq.bearing[1], rq.bearing[2]};
+  const double idepth = rq.idepth, istd = rq.idepth_std;
+  bool alive = true;
+  V2 pxa = {0, 0}, pxb = {0, 0};
+  {
+    const double zmin = 1.0 / (idepth + 2.0 * istd);
+    const V3 rel = se3_apply(cur_pose, se3_apply(ref_world, vscale_l(zmin, fvec)));
+    if (rel.z < 0.0) alive = false;
+    else pxa = cam_project(cam, rel);
+    if (alive && !rq.fixed) {
+      const double zmax = 1.0 / (fmax(idepth - 2.0 * istd, 0.00000001));
+      const V3 rel2 = se3_apply(cur_pose, se3_apply(ref_world, vscale_l(zmax, fvec)));
+      if (rel2.z < 0.0) alive = false;
+      else pxb = cam_project(cam, rel2);
+    }
+  }
+  if (alive) {
+    const int lx = static_cast<int>(rq.px[0] / (1 << level)), ly = static_cast<int>(rq.px[1] / (1 << level));
+    if (!cam_inside_level(cam, lx, ly, prm.patch_size / 2 + 2, level)) alive = false;
+  }
+  if (!alive) {
+    if (lane == 0) out[ri] = res;
+    return;
+  }
+  // ---- WarpMatrixAffine, matcher.cc:293-312
+  double A00, A01, A10, A11;
+  {
+    const int half_size = 5;
+    const double depth = 1.0 / idepth;
+    const V3 p3d = vscale(fvec, depth);
+    V3 xyz_du = cam_unproject(cam, {rq.px[0] + static_cast<double>(half_size) * (1 << level), rq.px[1] + 0.0 * (1 << level)});
+    V3 xyz_dv = cam_unproject(cam, {rq.px[0] + 0.0 * (1 << level), rq.px[1] + static_cast<double>(half_size) * (1 << level)});
+    const double su = p3d.z / xyz_du.z;
+    xyz_du = vscale(xyz_du, su);
+    const double sv = p3d.z / xyz_dv.z;
+    xyz_dv = vscale(xyz_dv, sv);
+    const V2 px_cur = cam_project(cam, se3_apply(pose, p3d));
+    const V2 px_du = cam_project(cam, se3_apply(pose, xyz_du));
+    const V2 px_dv = cam_project(cam, se3_apply(pose, xyz_dv));
+    A00 = (px_du.x - px_cur.x) / half_size;
+    A10 = (px_du.y - px_cur.y) / half_size;
+    A01 = (px_dv.x - px_cur.x) / half_size;
+    A11 = (px_dv.y - px_cur.y) / half_size;
+  }
+  // ---- GetSearchLevel, matcher.cc:314-323
+  int slevel = 0;
+  {
+    double det = A00 * A11 - A01 * A10;
+    const int mx = prm.max_fast_levels - 1;
+    while (det > 3.0 && slevel < mx) {
+      slevel += 1;
+      det *= 0.25;
+    }
+  }
+  res.slevel = slevel;
+  // ---- CreatePatch, matcher.cc:325-357
+  {
+    const double det = A00 * A11 - A01 * A10;
+    const double invdet = 1.0 / det;
+    const double I00 = A11 * invdet, I01 = -A01 * invdet, I10 = -A10 * invdet, I11 = A00 * invdet;
+    const uint8_t *img = rq.ref.level[level];
+    const int W = rq.ref.lw[level], H = rq.ref.lh[level];
+    const double pyrx = rq.px[0] / (1 << level), pyry = rq.px[1] / (1 << level);
+    const bool bad = (I00 != I00);  // std::isnan(matrix_inv(0,0)): the reference returns leaving stale patches
+    for (int s = lane; s < 100; s += 64) {
+      const int y = s / 10, x = s - y * 10;
+      double ppx = x - 5, ppy = y - 5;
+      ppx *= (1 << slevel);
+      ppy *= (1 << slevel);
+      const double p0 = (I00 * ppx + I01 * ppy) + pyrx;
+      const double p1 = (I10 * ppx + I11 * ppy) + pyry;
+      uint8_t val = 0;
+      if (!bad && !(p0 < 0 || p1 < 0 || p0 >= W - 1 || p1 >= H - 1) && p0 == p0 && p1 == p1)
+        val = static_cast<uint8_t>(interpolate8u(img, W, static_cast<float>(p0), static_cast<float>(p1)));
+      L.border[s] = val;
+      if (y >= 1 && y < 9 && x >= 1 && x < 9) L.patch[(y - 1) * 8 + (x - 1)] = val;
+    }
+  }
+  wave_sync();
+  double range = prm.search_size;
+  for (int i = 1; i <= slevel; i++) range *= 1.2;
+  const double range2 = range * range;
+
+  // ---- GetCornersInRange + SearchFeatures
+  const int threshold = prm.use_orb ? 100 : prm.patch_size * prm.patch_size * 500;
+  unsigned long long best = ~0ull;
+  {
+    const SearchFrame &cf = rq.cur;
+    // epipolar line constants (matcher.cc:139-148)
+    double ex = pxa.x - pxb.x, ey = pxa.y - pxb.y;
+    const double en = sqrt(ex * ex + ey * ey);
+    ex /= en;
+    ey /= en;
+    const double nx = ey, ny = -ex;
+    const double normdist = pxa.x * nx + pxa.y * ny;
+    const double xdiff = pxb.x - pxa.x, ydiff = pxb.y - pxa.y;
+    const double vline = (xdiff) * (xdiff) + (ydiff) * (ydiff);
+    int sumA = 0, sumAA = 0;
+    if (!prm.use_orb) {
+      const int pv = L.patch[lane];
+      sumA = wave_sum_i32(pv);
+      sumAA = wave_sum_i32(pv * pv);
+    }
+    for (int ci = lane; ci < cf.n_corners; ci += 64) {
+      const int cx = cf.corners[4 * ci], cy = cf.corners[4 * ci + 1], cl = cf.corners[4 * ci + 2];
+      int d = cl - level;
+      if (d < 0) d = -d;
+      if (d > 1) continue;
+      if (cx - prm.margin < 0 || cy - prm.margin < 0) continue;
+      if (cy + prm.margin >= cf.lh[cl] || cx + prm.margin >= cf.lw[cl]) continue;
+      const double posx = cx * (1 << cl), posy = cy * (1 << cl);
+      if (rq.fixed) {
+        const double ddx = rq.px0[0] - posx, ddy = rq.px0[1] - posy;
+        if (ddx * ddx + ddy * ddy > range2) continue;
+      } else {
+        const double dist = normdist - (posx * nx + posy * ny);
+        if (fabs(dist) > range) continue;
+        const double uu = ((posx - pxa.x) * xdiff + (posy - pxa.y) * ydiff) / vline;
+        if (uu > 1) {
+          const double ddx = posx - pxb.x, ddy = posy - pxb.y;
+          if ((ddx * ddx + ddy * ddy) > range2) continue;
+        }
+        if (uu < 0) {
+          const double ddx = posx - pxa.x, ddy = posy - pxa.y;
+          if ((ddx * ddx + ddy * ddy) > range2) continue;
+        }
+      }
+      int score;
+      if (prm.use_orb) {
+        const uint32_t *dd = reinterpret_cast<const uint32_t *>(cf.desc + static_cast<size_t>(ci) * 32);
+        score = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) score += __popc(dd[k] ^ rq.desc[k]);
+      } else {
+        // CompareZMSSDScore, matcher.cc:461-476 (integer arithmetic, integer division by 64)
+        const uint8_t *cp = cf.level[cl] + static_cast<size_t>(cy - 4) * cf.lw[cl] + (cx - 4);
+        unsigned sumB = 0, sumBB = 0, sumAB = 0;
+        for (int yy = 0, r = 0; yy < 8; yy++)
+          for (int xx = 0; xx < 8; xx++, r++) {
+            const unsigned pix = cp[yy * cf.lw[cl] + xx];
+            sumB += pix;
+            sumBB += pix * pix;
+            sumAB += pix * L.patch[r];
+          }
+        const int iB = static_cast<int>(sumB), iBB = static_cast<int>(sumBB), iAB = static_cast<int>(sumAB);
+        score = sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+      }
+      // score < best_score with first-index-wins == min over (score, index); scores may be negative for ZMSSD
+      const unsigned long long key =
+          (static_cast<unsigned long long>(static_cast<unsigned>(score + 0x40000000)) << 20) | static_cast<unsigned>(ci);
+      best = key < best ? key : best;
+    }
+    best = wave_min_u64(best);
+  }
+  res.stage = 1;
+  bool matched = false;
+  int best_ci = -1;
+  if (best != ~0ull) {
+    const int bscore = static_cast<int>(static_cast<unsigned>(best >> 20)) - 0x40000000;
+    // best_score starts at threshold+1; "best_score >= threshold -> false" (matcher.cc:247,286)
+    if (bscore < threshold + 1 && !(bscore >= threshold)) {
+      matched = true;
+      best_ci = static_cast<int>(best & 0xFFFFF);
+    }
+  }
+  if (!matched) {
+    if (lane == 0) out[ri] = res;
+    return;
+  }
+  res.best_corner = best_ci;
+  const int bx = rq.cur.corners[4 * best_ci], by = rq.cur.corners[4 * best_ci + 1], bl = rq.cur.corners[4 * best_ci + 2];
+  const double mpx = static_cast<double>(bx * (1 << bl)), mpy = static_cast<double>(by * (1 << bl));
+  res.px[0] = mpx;
+  res.px[1] = mpy;
+  // ---- AlignPatch at the search level
+  float u = static_cast<float>(mpx / (1 << slevel)), v = static_cast<float>(mpy / (1 << slevel));
+  int its = 0;
+  const bool conv = align_patch_wave(L, rq.cur.level[slevel], rq.cur.lw[slevel], rq.cur.lh[slevel], prm.max_align_its, lane, &u, &v, &its);
+  res.lk_its = its;
+  res.stage = 2;
+  if (conv) {
+    res.px[0] = static_cast<double>(u) * (1 << slevel);
+    res.px[1] = static_cast<double>(v) * (1 << slevel);
+    res.level = slevel;
+    res.found = 1;
+    res.stage = 3;
+  }
+  if (lane == 0) out[ri] = res;
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void align_patches_kernel(const PatchJob *__restrict__ jobs, const uint8_t *__restrict__ border,
+                                                                            const uint8_t *__restrict__ patch, int n, int max_its,
+                                                                            double *__restrict__ uv_out, uint8_t *__restrict__ conv_out,
+                                                                            int32_t *__restrict__ its_out) {
+  __shared__ WaveLds s_lds[kWavesPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * kWavesPerBlock + wv;
+  if (i >= n) return;
+  WaveLds &L = s_lds[wv];
+  for (int s = lane; s < 100; s += 64) L.border[s] = border[static_cast<size_t>(i) * 100 + s];
+  L.patch[lane] = patch[static_cast<size_t>(i) * 64 + lane];
+  wave_sync();
+  const PatchJob jb = jobs[i];
+  float u = static_cast<float>(jb.u), v = static_cast<float>(jb.v);
+  int its = 0;
+  const bool conv = align_patch_wave(L, jb.img, jb.w, jb.h, max_its, lane, &u, &v, &its);
+  if (lane == 0) {
+    uv_out[2 * i] = u;
+    uv_out[2 * i + 1] = v;
+    conv_out[i] = conv ? 1 : 0;
+    its_out[i] = its;
+  }
+}
+
+void fill_frame(SearchFrame *d, const sdvl_frame *f) {
+  memset(d, 0, sizeof(SearchFrame));
+  for (int l = 0; l < f->v.levels; l++) {
+    d->level[l] = f->v.level[l];
+    d->lw[l] = f->v.lw[l];
+    d->lh[l] = f->v.lh[l];
+  }
+  d->corners = f->v.corners;
+  d->desc = f->v.desc;
+  d->n_corners = f->v.n_corners;
+  d->levels = f->v.levels;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
+                       const sdvl_search_params *p, sdvl_search_res *out) {
+  if (!ctx || !cam || !p || n < 0 || (n > 0 && (!reqs || !out))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, p->patch_size == 8, "only patch_size 8 is supported (one wave64 per 8x8 patch)");
+  SDVL_REQUIRE(ctx, p->max_fast_levels >= 1 && p->max_fast_levels <= 4, "bad max_fast_levels");
+  SDVL_REQUIRE(ctx, p->max_align_its >= 0 && p->margin >= 4, "bad max_align_its / margin");
+  for (int i = 0; i < n; i++) {
+    const sdvl_search_req &r = reqs[i];
+    SDVL_REQUIRE(ctx, r.cur && r.ref, "null frame in search request");
+    SDVL_REQUIRE(ctx, r.level >= 0 && r.level < r.ref->v.levels, "feature level outside the reference pyramid");
+    SDVL_REQUIRE(ctx, p->max_fast_levels <= r.cur->v.levels, "max_fast_levels exceeds the pyramid depth");
+    SDVL_REQUIRE(ctx, r.cur->v.n_corners < (1 << 20), "too many corners");
+    if (p->use_orb) SDVL_REQUIRE(ctx, r.cur->v.n_corners == 0 || r.cur->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
+    SDVL_REQUIRE(ctx, r.idepth == r.idepth && r.idepth != 0.0, "inverse depth must be finite and non-zero");
+  }
+  const size_t in_bytes = sizeof(SearchReqDev) * static_cast<size_t>(n);
+  const size_t out_bytes = sizeof(sdvl_search_res) * static_cast<size_t>(n);
+  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, in_bytes, true);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, in_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SearchReqDev *hd = static_cast<SearchReqDev *>(ctx->h_stage);
+  for (int i = 0; i < n; i++) {
+    const sdvl_search_req &r = reqs[i];
+    SearchReqDev &d = hd[i];
+    fill_frame(&d.cur, r.cur);
+    fill_frame(&d.ref, r.ref);
+    memcpy(d.cur_pose, r.cur_pose, sizeof(d.cur_pose));
+    memcpy(d.ref_pose, r.ref_pose, sizeof(d.ref_pose));
+    d.px[0] = r.px[0]; d.px[1] = r.px[1];
+    d.bearing[0] = r.bearing[0]; d.bearing[1] = r.bearing[1]; d.bearing[2] = r.bearing[2];
+    d.idepth = r.idepth; d.idepth_std = r.idepth_std;
+    d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
+    d.level = r.level; d.fixed = r.fixed;
+    memcpy(d.desc, r.desc, 32);
+  }
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, hd, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  {
+    ScopedKernelTimer tm(ctx, "search_points");
+    hipLaunchKernelGGL(search_points_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, ctx->stream,
+                       static_cast<const SearchReqDev *>(ctx->d_stage), n, c, *p, static_cast<sdvl_search_res *>(ctx->d_out));
+  }
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, ctx->h_out, out_bytes);
+  return SDVL_OK;
+}
+
+int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const int32_t *levels, const uint8_t *border,
+                       const uint8_t *patch, int max_its, double *uv_io, uint8_t *converged, int32_t *its) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !levels || !border || !patch || !uv_io || !converged))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, max_its >= 0, "bad max_its");
+  const size_t jb = (sizeof(PatchJob) * n + 255) / 256 * 256, bb = (static_cast<size_t>(n) * 100 + 255) / 256 * 256;
+  const size_t pb = static_cast<size_t>(n) * 64;
+  const size_t ob_uv = (sizeof(double) * 2 * n + 255) / 256 * 256, ob_its = (sizeof(int32_t) * n + 255) / 256 * 256;
+  const size_t ob = ob_uv + ob_its + n;
+  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, jb + bb + pb, true);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, jb + bb + pb, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, ob, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, ob, true);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  PatchJob *hj = static_cast<PatchJob *>(ctx->h_stage);
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] && levels[i] >= 0 && levels[i] < frames[i]->v.levels, "bad frame / level");
+    hj[i].img = frames[i]->v.level[levels[i]];
+    hj[i].w = frames[i]->v.lw[levels[i]];
+    hj[i].h = frames[i]->v.lh[levels[i]];
+    hj[i].u = uv_io[2 * i];
+    hj[i].v = uv_io[2 * i + 1];
+  }
+  uint8_t *hs = static_cast<uint8_t *>(ctx->h_stage), *ds = static_cast<uint8_t *>(ctx->d_stage);
+  memcpy(hs + jb, border, static_cast<size_t>(n) * 100);
+  memcpy(hs + jb + bb, patch, pb);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, jb + bb + pb, hipMemcpyHostToDevice, ctx->stream));
+  uint8_t *dout = static_cast<uint8_t *>(ctx->d_out);
+  {
+    ScopedKernelTimer tm(ctx, "align_patches");
+    hipLaunchKernelGGL(align_patches_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, ctx->stream,
+                       reinterpret_cast<const PatchJob *>(ds), ds + jb, ds + jb + bb, n, max_its, reinterpret_cast<double *>(dout),
+                       dout + ob_uv + ob_its, reinterpret_cast<int32_t *>(dout + ob_uv));
+  }
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const uint8_t *ho = static_cast<const uint8_t *>(ctx->h_out);
+  memcpy(uv_io, ho, sizeof(double) * 2 * n);
+  if (its) memcpy(its, ho + ob_uv, sizeof(int32_t) * n);
+  memcpy(converged, ho + ob_uv + ob_its, n);
+  return SDVL_OK;
+}
+
+}  // extern "C"

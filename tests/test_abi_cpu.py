@@ -1,0 +1,58 @@
+"""CPU-side checks of the boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/sdvl_hip.h declares; compute entry points refuse to run (no CPU fallback)."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sdvl():
+    return importlib.import_module("slam-sdvl_amd")
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "sdvl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdvl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(sdvl):
+    lib = sdvl.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "libsdvl_hip.so does not export %s" % s
+    assert sorted(sdvl.ABI_SYMBOLS) == syms
+
+
+def test_struct_layouts_match_header(sdvl):
+    # sizes the C side static-asserts implicitly by use; a mismatch here would corrupt batched records
+    assert C.sizeof(sdvl.Keypoint) == 8
+    assert C.sizeof(sdvl.AlignFeature) == 56
+    assert C.sizeof(sdvl.AlignJob) == 8 + 8 + 8 + 56
+    assert C.sizeof(sdvl.SearchReq) == 8 + 8 + 56 + 56 + 16 + 24 + 16 + 16 + 8 + 32
+    assert C.sizeof(sdvl.SearchRes) == 16 + 6 * 4
+    assert C.sizeof(sdvl.AlignResult) == 56 + 16 + 4 + 32 + 4
+
+
+def test_no_cpu_fallback_without_gpu(sdvl):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sdvl.SdvlError):
+        sdvl.Context(0)
+
+
+def test_fast_num_cells_matches_survey(sdvl):
+    lib = sdvl.load_library()
+    dp = sdvl.default_detect_params()
+    cpl = (C.c_int * 4)()
+    tot = C.c_int()
+    for (w, h), want in {(640, 480): [300, 80, 20], (752, 480): [360, 96, 24], (1280, 960): [1200, 300, 80]}.items():
+        assert lib.sdvl_fast_num_cells(w, h, C.byref(dp), cpl, C.byref(tot)) == 0
+        assert [cpl[i] for i in range(3)] == want and tot.value == sum(want)      # SURVEY §8 header

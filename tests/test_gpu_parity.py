@@ -1,0 +1,276 @@
+"""GPU parity tests proper: every kernel behind the C-ABI (include/sdvl_hip.h) against the CPU oracle on the same
+seeded inputs.  Bit-exact for integer / byte / index work (pyramid, FAST lists incl. order, Shi-Tomasi, ORB bits,
+SearchPoint decisions, AlignPatch offsets); 1e-4 (BASELINE.json north_star) for the image-alignment pose, whose
+normal equations are reduced in a different order than the CPU's sequential loop."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from oraclelib import EUROC_CAM, TUM_CAM, trajectory_pose
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-4   # BASELINE.json: "pose and patch-offset deltas within 1e-4"
+
+
+@pytest.fixture(scope="module")
+def sdvl():
+    return importlib.import_module("slam-sdvl_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx(sdvl):
+    c = sdvl.Context(0)
+    yield c
+    c.close()
+
+
+def rand_img(seed, h, w):
+    return np.random.default_rng(seed).integers(0, 256, (h, w)).astype(np.uint8)
+
+
+def frames_of(synth, orc, cam, w, h, ks, seed=20260001):
+    return [synth.render(trajectory_pose(orc, k), cam, w, h, seed=seed, frame_id=k) for k in ks]
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("shape", [(480, 640), (480, 752), (960, 1280), (66, 130), (48, 80)])
+def test_pyramid_bit_exact(ctx, orc, shape):
+    h, w = shape
+    levels = 5 if min(shape) >= 64 * 4 else 3
+    imgs = [rand_img(s, h, w) for s in (1, 2)]
+    fr = [ctx.frame(im, levels=levels, pyramid=False) for im in imgs]
+    ctx.pyramid_build(fr)
+    for f, im in zip(fr, imgs):
+        want = orc.pyramid(im, levels)
+        for l in range(levels):
+            assert np.array_equal(f.level(l), want[l]), "level %d" % l
+        f.close()
+
+
+# ------------------------------------------------------------------------------------------------ K2
+def check_fast(ctx, sdvl, orc, imgs, margin=19, thr=10):
+    dp = sdvl.default_detect_params()
+    dp.margin, dp.fast_threshold = margin, thr
+    orc.params.fast_threshold = thr
+    orc.params.use_orb = 1 if margin == 19 else 0
+    try:
+        fr = [ctx.frame(im) for im in imgs]
+        got, cpl = ctx.fast_cells(fr, dp, cap=60000)
+        total = 0
+        for f, im, (kps, offs) in zip(fr, imgs, got):
+            pyr = orc.pyramid(im, 5)
+            base = 0
+            for l in range(3):
+                wk, woffs, _ = orc.fast_cells(pyr[l], cap=400000)
+                g = kps[kps[:, 3] == l]
+                assert np.array_equal(g[:, :3], wk), "level %d keypoints (x,y,score) incl. order" % l
+                assert np.array_equal(offs[base:base + cpl[l] + 1] - offs[base], woffs), "level %d cell offsets" % l
+                base += cpl[l]
+                total += len(wk)
+            f.close()
+        return total
+    finally:
+        orc.params.fast_threshold = 10
+        orc.params.use_orb = 1
+
+
+def test_fast_cells_bit_exact_synthetic(ctx, sdvl, orc, synth):
+    n = check_fast(ctx, sdvl, orc, frames_of(synth, orc, TUM_CAM, 640, 480, [0, 7]))
+    assert n > 5000
+
+
+def test_fast_cells_bit_exact_noise_and_thresholds(ctx, sdvl, orc):
+    img = rand_img(5, 480, 640)
+    assert check_fast(ctx, sdvl, orc, [img], thr=40) > 1000
+    assert check_fast(ctx, sdvl, orc, [img], margin=5, thr=25) > 1000      # non-ORB margin (1 + PatchSize/2)
+    flat = np.full((480, 640), 90, np.uint8)
+    assert check_fast(ctx, sdvl, orc, [flat]) == 0
+
+
+def test_fast_cells_euroc_size(ctx, sdvl, orc, synth):
+    assert check_fast(ctx, sdvl, orc, frames_of(synth, orc, EUROC_CAM, 752, 480, [3])) > 3000
+
+
+# ------------------------------------------------------------------------------------------------ K3 / K4
+def test_shi_tomasi_and_orb_bit_exact(ctx, sdvl, orc, synth):
+    img = frames_of(synth, orc, TUM_CAM, 640, 480, [2])[0]
+    corners = orc.detect_pyramid(img)
+    f = ctx.frame(img)
+    f.set_corners(corners)
+    pyr = orc.pyramid(img, 5)
+    got = ctx.shi_tomasi([f])[0]
+    want = np.array([orc.shi_tomasi(pyr[l], x, y) for x, y, l in corners])
+    assert np.array_equal(got, want)
+    desc = ctx.orb_describe([f])[0]
+    for l in range(3):
+        m = corners[:, 2] == l
+        wd, wa = orc.orb_describe(pyr[l], corners[m][:, :2])
+        assert np.array_equal(desc[m], wd), "ORB bits level %d" % l
+        gd, ga = ctx.orb_describe_points(f, corners[m])
+        assert np.array_equal(gd, wd) and np.array_equal(ga, wa)
+    f.close()
+
+
+# ------------------------------------------------------------------------------------------------ K5/K6
+def align_inputs(sdvl, orc, img0, cam, n_feat, seed):
+    """features of frame 0 on the scene plane z = 2 (camera 0 = world)."""
+    h, w = img0.shape
+    rng = np.random.default_rng(seed)
+    px = np.stack([rng.uniform(48, w - 48, n_feat), rng.uniform(48, h - 48, n_feat)], 1)
+    ray = np.stack([(px[:, 0] - cam[2]) / cam[0], (px[:, 1] - cam[3]) / cam[1], np.ones(n_feat)], 1)
+    bearing = ray / np.linalg.norm(ray, axis=1, keepdims=True)
+    depth = 2.0 / bearing[:, 2]
+    valid = np.ones(n_feat, np.uint8)
+    valid[::17] = 0
+    feats = (sdvl.AlignFeature * n_feat)()
+    for i in range(n_feat):
+        feats[i].px, feats[i].py = px[i]
+        feats[i].fx, feats[i].fy, feats[i].fz = bearing[i]
+        feats[i].depth = depth[i]
+        feats[i].valid = int(valid[i])
+    return px, bearing, depth, valid, feats
+
+
+@pytest.mark.parametrize("n_feat,k,fast", [(200, 3, False), (1000, 5, False), (200, 40, True), (7, 2, False)])
+def test_image_align_pose_within_tolerance(ctx, sdvl, orc, synth, n_feat, k, fast):
+    img0, imgk = frames_of(synth, orc, TUM_CAM, 640, 480, [0, k])
+    px, bearing, depth, valid, feats = align_inputs(sdvl, orc, img0, TUM_CAM, n_feat, 20260200)
+    T0 = np.array([1, 0, 0, 0, 0, 0, 0], np.float64)
+    want = orc.image_align(img0, imgk, TUM_CAM, px, bearing, depth, valid, T0, fast=fast)
+    f0, fk = ctx.frame(img0), ctx.frame(imgk)
+    cam = sdvl.Camera(640, 480, *TUM_CAM)
+    res = ctx.image_align([(f0, fk, 0, n_feat, T0)], feats, cam, sdvl.default_align_params(fast))[0]
+    got = np.array(res.T[:])
+    assert np.abs(got - want["T"]).max() <= POSE_TOL
+    assert res.n_meas == want["n"]
+    assert abs(res.error - want["error"]) <= 1e-4 * max(1.0, abs(want["error"])) or (res.error >= 1e9 and want["error"] >= 1e9)
+    assert np.abs(np.array(res.its[:]) - want["its"]).max() <= 1          # +-1 GN step near convergence is allowed
+    if not fast:
+        Tgt = trajectory_pose(orc, k)
+        assert np.abs(got - Tgt).max() < 5e-3                               # and it actually aligns the frames
+    f0.close(); fk.close()
+
+
+def test_image_align_batch_of_jobs_and_empty(ctx, sdvl, orc, synth):
+    imgs = frames_of(synth, orc, TUM_CAM, 640, 480, [0, 2, 4, 6])
+    px, bearing, depth, valid, feats = align_inputs(sdvl, orc, imgs[0], TUM_CAM, 300, 7)
+    fr = [ctx.frame(im) for im in imgs]
+    T0 = np.array([1, 0, 0, 0, 0, 0, 0], np.float64)
+    jobs = [(fr[0], fr[1], 0, 300, T0), (fr[0], fr[2], 0, 150, T0), (fr[0], fr[3], 150, 300, T0), (fr[0], fr[1], 10, 10, T0)]
+    cam = sdvl.Camera(640, 480, *TUM_CAM)
+    res = ctx.image_align(jobs, feats, cam, sdvl.default_align_params())
+    for (ref, cur, b, e, T), r, im in zip(jobs[:3], res, imgs[1:]):
+        want = orc.image_align(imgs[0], im, TUM_CAM, px[b:e], bearing[b:e], depth[b:e], valid[b:e], T0)
+        assert np.abs(np.array(r.T[:]) - want["T"]).max() <= POSE_TOL
+        assert r.n_meas == want["n"]
+    assert np.array_equal(np.array(res[3].T[:]), T0) and res[3].n_meas == 0      # no features: pose untouched
+    for f in fr:
+        f.close()
+
+
+# ------------------------------------------------------------------------------------------------ K7
+def search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, cam4, n_req, seed, fixed, noise=0.0):
+    """points seeded on the reference frame's corners (plane z=2 in world = camera 0), searched in the current frame"""
+    h, w = img_ref.shape
+    rng = np.random.default_rng(seed)
+    cref = orc.detect_pyramid(img_ref)
+    ccur = orc.detect_pyramid(img_cur)
+    pyr_ref = orc.pyramid(img_ref, 5)
+    sel = rng.choice(len(cref), size=min(n_req, len(cref)), replace=False)
+    f_ref, f_cur = ctx.frame(img_ref), ctx.frame(img_cur)
+    f_cur.set_corners(ccur)
+    ctx.orb_describe([f_cur], want=False)
+    Tw = orc.se3_inv(T_ref)
+    from oraclelib import quat_to_R
+    Rw, tw = quat_to_R(Tw[:4]), Tw[4:]
+    Rc, tc = quat_to_R(T_cur[:4]), T_cur[4:]
+    reqs = (sdvl.SearchReq * len(sel))()
+    meta = []
+    for i, ci in enumerate(sel):
+        x, y, l = cref[ci]
+        px = np.array([x * (1 << l), y * (1 << l)], np.float64)
+        ray = np.array([(px[0] - cam4[2]) / cam4[0], (px[1] - cam4[3]) / cam4[1], 1.0])
+        bearing = ray / np.linalg.norm(ray)
+        rw = Rw @ bearing
+        s = (2.0 - tw[2]) / rw[2]
+        desc, _ = orc.orb_describe(pyr_ref[l], [[x, y]])
+        idepth = 1.0 / s * (1.0 + noise * rng.normal())
+        istd = 0.05 * idepth if fixed else 0.1 * idepth
+        Pw = Rw @ (bearing * s) + tw
+        pc = Rc @ Pw + tc
+        px0 = np.array([cam4[2] + cam4[0] * pc[0] / pc[2], cam4[3] + cam4[1] * pc[1] / pc[2]]) + rng.normal(size=2) * 0.7
+        r = reqs[i]
+        r.cur, r.ref = f_cur.h.value, f_ref.h.value
+        for k in range(7):
+            r.cur_pose[k], r.ref_pose[k] = T_cur[k], T_ref[k]
+        r.px[0], r.px[1] = px
+        r.bearing[0], r.bearing[1], r.bearing[2] = bearing
+        r.idepth, r.idepth_std = idepth, istd
+        r.px0[0], r.px0[1] = px0
+        r.level, r.fixed = int(l), int(fixed)
+        for k in range(32):
+            r.desc[k] = int(desc[0, k])
+        meta.append(dict(px=px, bearing=bearing, level=int(l), desc=desc[0], idepth=idepth, istd=istd, px0=px0))
+    return reqs, meta, ccur, f_ref, f_cur
+
+
+@pytest.mark.parametrize("fixed,k_ref,k_cur,noise", [(True, 0, 4, 0.0), (False, 0, 6, 0.02), (True, 10, 3, 0.0), (False, 2, 30, 0.05)])
+def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur, noise):
+    img_ref, img_cur = frames_of(synth, orc, TUM_CAM, 640, 480, [k_ref, k_cur])
+    T_ref, T_cur = trajectory_pose(orc, k_ref), trajectory_pose(orc, k_cur)
+    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, 160, 11, fixed, noise)
+    cam = sdvl.Camera(640, 480, *TUM_CAM)
+    res = ctx.search_points(reqs, cam, sdvl.default_search_params())
+    n_found = 0
+    for r, m in zip(res, meta):
+        want = orc.search_point(img_ref, img_cur, TUM_CAM, T_ref, T_cur, m["px"], m["bearing"], m["level"], m["desc"],
+                                m["idepth"], m["istd"], fixed, ccur, m["px0"])
+        assert r.found == want["found"]
+        if r.slevel >= 0:
+            assert r.slevel == want["slevel"]
+        if want["found"]:
+            n_found += 1
+            assert r.level == want["level"]
+            assert np.abs(np.array(r.px[:]) - want["px"]).max() <= POSE_TOL
+            assert np.array_equal(np.array(r.px[:]), want["px"])      # same op order, no contraction: bit-identical
+    assert n_found >= (40 if fixed else 10)
+    f_ref.close(); f_cur.close()
+
+
+def test_align_patches_bit_exact_and_recovers_shift(ctx, sdvl, orc, synth):
+    img = frames_of(synth, orc, TUM_CAM, 640, 480, [0])[0]
+    corners = orc.detect_pyramid(img)
+    c0 = corners[corners[:, 2] == 0][:200]
+    rng = np.random.default_rng(20260300)
+    shift = rng.uniform(-2, 2, (len(c0), 2))
+    f = ctx.frame(img)
+    border = np.stack([img[y - 5:y + 5, x - 5:x + 5].reshape(-1) for x, y, _ in c0])      # identity warp, matcher.cc:338-341
+    patch = np.stack([img[y - 4:y + 4, x - 4:x + 4].reshape(-1) for x, y, _ in c0])
+    uv0 = c0[:, :2] + shift
+    uv, conv, its = ctx.align_patches([f] * len(c0), np.zeros(len(c0), np.int32), border, patch, uv0)
+    n_conv = 0
+    for i in range(len(c0)):
+        ok, px = orc.align_patch(img, border[i], patch[i], uv0[i])
+        assert bool(conv[i]) == bool(ok)
+        assert np.array_equal(uv[i], px)
+        if ok:
+            n_conv += 1
+            assert np.abs(px - c0[i, :2]).max() < 0.2      # LK pulls the shifted start back onto the corner
+    assert n_conv > 150
+    # window leaving the image -> break, not converged (Appendix B)
+    uv, conv, its = ctx.align_patches([f], [0], border[:1], patch[:1], [[2.5, 100.0]])
+    assert conv[0] == 0 and its[0] == 0
+    f.close()
+
+
+def test_errors_are_reported_not_swallowed(ctx, sdvl):
+    with pytest.raises(sdvl.SdvlError):
+        ctx.frame(width=8, height=8)                         # too small
+    f = ctx.frame(np.zeros((480, 640), np.uint8))
+    with pytest.raises(sdvl.SdvlError):
+        f.set_corners([[700, 10, 0]])                        # outside the level image
+    with pytest.raises(sdvl.SdvlError):
+        f.set_corners(np.zeros((5000, 3), np.int32))         # capacity
+    f.close()
