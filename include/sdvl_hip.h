@@ -152,6 +152,8 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
 
 /* corners_ of a frame (x, y in level coordinates, level), fast_detector.cc:151 -> HBM; descriptors are invalidated */
 int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *xyl);
+/* same for n frames in one transfer: counts[i] corners of frame i, concatenated in xyl */
+int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const int32_t *counts, const int32_t *xyl);
 int sdvl_frame_num_corners(const sdvl_frame *f);
 
 /* FindShiTomasiScoreAtPoint for every corner of n frames (extra/utils.cc:61-97, called from
@@ -161,6 +163,8 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
 /* ORBDetector::GetDescriptor for every corner of n frames (orb_detector.cc:350-395; lazily called from
  * matcher.cc:266-269 and frame.cc:148-161).  Descriptors stay in HBM; out_desc (may be NULL) = [n][cap][32] */
 int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *out_desc);
+/* host mirror of descriptors_ (GetDescriptors()): out = [n_corners][32]; needs a prior sdvl_orb_describe */
+int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap, uint8_t *out);
 /* ORBDetector::GetDescriptor at arbitrary (x,y,level) points of one frame; out_angle_deg may be NULL */
 int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const int32_t *xyl, uint8_t *out_desc,
                              float *out_angle_deg);

@@ -29,9 +29,7 @@ namespace sdvlref {
 
 // glibc rand(): random_r TYPE_3 (x^31 + x^3 + 1 additive feedback), srand(1) default state.
 struct GlibcRand {
-  int32_t r[34];
-  int f, b;  // front / rear indices into a 31-entry ring kept in r[3..33]
-  std::vector<int32_t> ring;
+  std::vector<int32_t> ring;  // 31-entry additive-feedback state
   int fi, ri;
   explicit GlibcRand(uint32_t seed = 1) { Seed(seed); }
   void Seed(uint32_t seed) {
@@ -152,6 +150,7 @@ struct Tracker {
   int quality = 0;
   double vel[6] = {0, 0, 0, 0, 0, 0};
   std::shared_ptr<RFrame> last_frame, last_kf, current;
+  std::shared_ptr<RFrame> map_last_kf;  // Map::last_kf_ (map.cc:157), distinct from SDVL::last_kf_ after a relocalisation
   std::vector<std::shared_ptr<RFrame>> keyframes;
   std::vector<std::shared_ptr<RPoint>> points_trash;
   int last_matches = 0;  // Map::last_matches_
@@ -260,6 +259,7 @@ struct Tracker {
       current->pose = init_pose;
       current->is_keyframe = true;
       keyframes.push_back(current);
+      map_last_kf = current;
       SeedPoints(current);
       last_frame = current;
       last_kf = current;
@@ -296,6 +296,7 @@ struct Tracker {
               if (ft->point) ft->point->features.insert(ft->point->features.begin(), ft);
             current->is_keyframe = true;
             keyframes.push_back(current);
+            map_last_kf = current;
             last_kf = current;
             SeedPoints(current);  // sequential-mode mapper work, outside the reference's timing window
             st.keyframe = 1;
@@ -319,7 +320,7 @@ struct Tracker {
   // Map::NeedKeyframe, map.cc:170-188
   bool NeedKeyframe(const std::shared_ptr<RFrame> &frame, int) {
     const int npoints = frame->NumPoints();
-    const bool enough_its = (frame->id - last_kf->id) >= prm.min_keyframe_its;
+    const bool enough_its = (frame->id - map_last_kf->id) >= prm.min_keyframe_its;
     const bool lost_many = npoints < last_matches * prm.lost_ratio;
     const bool lost_some = npoints < last_matches * 0.9;
     last_matches = std::max(last_matches, npoints);

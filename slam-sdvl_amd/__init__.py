@@ -9,6 +9,14 @@ import os
 
 import numpy as np
 
+# PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HIP runtimes in one process
+# fight over the GPU (whichever initialises second sees no device), so when torch is installed it is imported
+# FIRST: libsdvl_hip.so then binds to the already-loaded runtime by soname and shares devices and streams with it.
+try:
+    import torch  # noqa: F401  (plumbing only: runtime sharing, torch.distributed in bench.py)
+except ImportError:  # pure C-ABI use without torch: the system ROCm runtime is loaded instead
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsdvl_hip.so")
@@ -85,8 +93,8 @@ ABI_SYMBOLS = [
     "sdvl_ctx_timing_enable", "sdvl_ctx_timing_get", "sdvl_ctx_timing_reset",
     "sdvl_frame_create", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frame_set_image_device",
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
-    "sdvl_frame_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
-    "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches",
+    "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
+    "sdvl_frame_download_descriptors", "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
 ]
 

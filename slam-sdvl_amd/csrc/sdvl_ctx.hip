@@ -259,6 +259,55 @@ int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *x
   return SDVL_OK;
 }
 
+int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const int32_t *counts, const int32_t *xyl) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !counts))) return SDVL_ERR_INVALID;
+  size_t total = 0;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    if (counts[i] < 0 || counts[i] > SDVL_MAX_CORNERS) {
+      ctx->err = "too many corners for one frame (SDVL_MAX_CORNERS)";
+      return SDVL_ERR_CAPACITY;
+    }
+    total += counts[i];
+  }
+  if (total == 0) {
+    for (int i = 0; i < n; i++) { frames[i]->v.n_corners = 0; frames[i]->desc_valid = 0; }
+    return SDVL_OK;
+  }
+  if (!xyl) return SDVL_ERR_INVALID;
+  {
+    size_t k = 0;
+    for (int i = 0; i < n; i++) {
+      const sdvl_frame *f = frames[i];
+      for (int j = 0; j < counts[i]; j++, k++) {
+        const int x = xyl[3 * k], y = xyl[3 * k + 1], l = xyl[3 * k + 2];
+        SDVL_REQUIRE(ctx, l >= 0 && l < f->v.levels && x >= 0 && y >= 0 && x < f->v.lw[l] && y < f->v.lh[l],
+                     "corner outside its pyramid level");
+      }
+    }
+  }
+  const size_t bytes = sizeof(int32_t) * 4 * total;
+  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t *st = static_cast<int32_t *>(ctx->h_stage);
+  for (size_t k = 0; k < total; k++) {
+    st[4 * k] = xyl[3 * k]; st[4 * k + 1] = xyl[3 * k + 1]; st[4 * k + 2] = xyl[3 * k + 2]; st[4 * k + 3] = 0;
+  }
+  size_t k = 0;
+  for (int i = 0; i < n; i++) {
+    if (counts[i] > 0)
+      SDVL_HIP_CHECK(ctx, hipMemcpyAsync(frames[i]->v.corners, st + 4 * k, sizeof(int32_t) * 4 * counts[i], hipMemcpyHostToDevice,
+                                         ctx->stream));
+    frames[i]->v.n_corners = counts[i];
+    frames[i]->desc_valid = 0;
+    k += counts[i];
+  }
+  // no synchronisation: later launches on the same stream are ordered behind the copies; the pinned staging
+  // buffer is only rewritten after the next hipStreamSynchronize every entry point performs before reuse
+  return SDVL_OK;
+}
+
 int sdvl_frame_num_corners(const sdvl_frame *f) { return f ? f->v.n_corners : SDVL_ERR_INVALID; }
 
 int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out) {

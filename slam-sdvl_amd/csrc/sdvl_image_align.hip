@@ -3,7 +3,7 @@
 // max..min x <= max_its iterations) — no host round trip per iteration:
 //   PrecomputePatches (:208-267)  work item = (feature, pixel of the 4x4 patch): bilinear reference patch (float)
 //                                 and the 6-vector Jacobian (double) into an L2-resident cache in HBM;
-//   ComputeResiduals (:127-206)   phase A, thread = feature: project with the current SE3, bilinear weights -> LDS;
+//   ComputeResiduals (:127-206)   phase A, thread = feature: project with the current Rigid, bilinear weights -> LDS;
 //                                 phase B, thread = (feature, pixel): residual, upper triangle of J J^T (21), J res (6),
 //                                 chi2, count in FP64 registers; halving butterfly over the wave (32 DP shuffles for 32
 //                                 values instead of 6 per value), fixed-order sum over the 8 waves in LDS;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__re
   const int n_items = nf * 16;
 
   // thread-0 optimiser state (image_align.cc:33-39)
-  SE3 T = se3_identity(), T_bk = se3_identity();
+  Rigid T = se3_identity(), T_bk = se3_identity();
   double chi2 = 1e10, error = 1e10;
   bool stop = false;
   int n_meas = 0;

@@ -1,6 +1,6 @@
-// sdvl_math.h — SE3 / camera / small dense algebra shared by the host layer and the gfx950 kernels.
+// sdvl_math.h — Rigid / camera / small dense algebra shared by the host layer and the gfx950 kernels.
 // Mirrors the Eigen + extra/se3 operations the reference path uses:
-//   SE3 (quaternion + translation): extra/se3.h:32-78, extra/se3.cc:28-177
+//   Rigid (quaternion + translation): extra/se3.h:32-78, extra/se3.cc:28-177
 //   Camera::Project / Unproject / IsInsideImage: camera.cc:69-79, camera.h:93-98
 //   Jacobian3DToPlane, AbsMax: extra/utils.cc:28-42,99-118
 //   Matrix<double,6,6>::ldlt().solve: image_align.cc:102, feature_align.cc:402
@@ -56,21 +56,21 @@ SDVL_HD M3 quat_to_mat(double w, double x, double y, double z) {
   return R;
 }
 
-struct SE3 {
+struct Rigid {
   double q0, q1, q2, q3;
   V3 t;
 };
 
-SDVL_HD SE3 se3_identity() { return {1.0, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0}}; }
-SDVL_HD SE3 se3_from7(const double *p) { return {p[0], p[1], p[2], p[3], {p[4], p[5], p[6]}}; }
-SDVL_HD void se3_to7(const SE3 &s, double *p) {
+SDVL_HD Rigid se3_identity() { return {1.0, 0.0, 0.0, 0.0, {0.0, 0.0, 0.0}}; }
+SDVL_HD Rigid se3_from7(const double *p) { return {p[0], p[1], p[2], p[3], {p[4], p[5], p[6]}}; }
+SDVL_HD void se3_to7(const Rigid &s, double *p) {
   p[0] = s.q0; p[1] = s.q1; p[2] = s.q2; p[3] = s.q3; p[4] = s.t.x; p[5] = s.t.y; p[6] = s.t.z;
 }
-SDVL_HD M3 se3_rot(const SE3 &s) { return quat_to_mat(s.q0, s.q1, s.q2, s.q3); }
+SDVL_HD M3 se3_rot(const Rigid &s) { return quat_to_mat(s.q0, s.q1, s.q2, s.q3); }
 
-// SE3::Inverse, extra/se3.cc:59-70
-SDVL_HD SE3 se3_inverse(const SE3 &s) {
-  SE3 r;
+// Rigid::Inverse, extra/se3.cc:59-70
+SDVL_HD Rigid se3_inverse(const Rigid &s) {
+  Rigid r;
   const double n2 = s.q0 * s.q0 + s.q1 * s.q1 + s.q2 * s.q2 + s.q3 * s.q3;
   if (n2 > 0.0) {
     r.q0 = s.q0 / n2; r.q1 = -s.q1 / n2; r.q2 = -s.q2 / n2; r.q3 = -s.q3 / n2;
@@ -82,12 +82,12 @@ SDVL_HD SE3 se3_inverse(const SE3 &s) {
   return r;
 }
 
-// SE3 * Vector3d, extra/se3.h:68
-SDVL_HD V3 se3_apply(const SE3 &s, V3 p) { return vadd(mvec(se3_rot(s), p), s.t); }
+// Rigid * Vector3d, extra/se3.h:68
+SDVL_HD V3 se3_apply(const Rigid &s, V3 p) { return vadd(mvec(se3_rot(s), p), s.t); }
 
-// SE3::operator*, extra/se3.cc:166-177
-SDVL_HD SE3 se3_mul(const SE3 &a, const SE3 &b) {
-  SE3 r;
+// Rigid::operator*, extra/se3.cc:166-177
+SDVL_HD Rigid se3_mul(const Rigid &a, const Rigid &b) {
+  Rigid r;
   const double w = a.q0 * b.q0 - a.q1 * b.q1 - a.q2 * b.q2 - a.q3 * b.q3;
   const double x = a.q0 * b.q1 + a.q1 * b.q0 + a.q2 * b.q3 - a.q3 * b.q2;
   const double y = a.q0 * b.q2 + a.q2 * b.q0 + a.q3 * b.q1 - a.q1 * b.q3;
@@ -98,8 +98,8 @@ SDVL_HD SE3 se3_mul(const SE3 &a, const SE3 &b) {
   return r;
 }
 
-// SE3::Exp, extra/se3.cc:72-94,114-138
-SDVL_HD SE3 se3_exp(const double *u) {
+// Rigid::Exp, extra/se3.cc:72-94,114-138
+SDVL_HD Rigid se3_exp(const double *u) {
   const double kEps = 1e-10;
   const V3 ups = {u[0], u[1], u[2]};
   const V3 om = {u[3], u[4], u[5]};
@@ -114,7 +114,7 @@ SDVL_HD SE3 se3_exp(const double *u) {
   } else {
     imag = sin(half_theta) / theta;
   }
-  SE3 r;
+  Rigid r;
   r.q0 = real; r.q1 = imag * om.x; r.q2 = imag * om.y; r.q3 = imag * om.z;
   M3 Om;
   Om.m[0] = 0;     Om.m[1] = -om.z; Om.m[2] = om.y;
@@ -134,8 +134,8 @@ SDVL_HD SE3 se3_exp(const double *u) {
   return r;
 }
 
-// SE3::Log, extra/se3.cc:96-112,140-164
-SDVL_HD void se3_log(const SE3 &s, double *out) {
+// Rigid::Log, extra/se3.cc:96-112,140-164
+SDVL_HD void se3_log(const Rigid &s, double *out) {
   const double kEps = 1e-10;
   const double n = sqrt(s.q1 * s.q1 + s.q2 * s.q2 + s.q3 * s.q3);
   const double w = s.q0;

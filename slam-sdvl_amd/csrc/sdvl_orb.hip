@@ -250,6 +250,19 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   return SDVL_OK;
 }
 
+int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap, uint8_t *out) {
+  if (!ctx || !f || !out) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, f->desc_valid || f->v.n_corners == 0, "frame has no ORB descriptors (call sdvl_orb_describe)");
+  if (f->v.n_corners > cap) {
+    ctx->err = "descriptor output capacity smaller than the corner count";
+    return SDVL_ERR_CAPACITY;
+  }
+  if (f->v.n_corners == 0) return SDVL_OK;
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(out, f->v.desc, static_cast<size_t>(f->v.n_corners) * 32, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return SDVL_OK;
+}
+
 int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const int32_t *xyl, uint8_t *out_desc,
                              float *out_angle_deg) {
   if (!ctx || !f || n < 0 || (n > 0 && (!xyl || !out_desc))) return SDVL_ERR_INVALID;

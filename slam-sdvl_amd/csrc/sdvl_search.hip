@@ -191,9 +191,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
   res.slevel = -1;
 
   const int level = rq.level;
-  const SE3 cur_pose = se3_from7(rq.cur_pose), ref_pose = se3_from7(rq.ref_pose);
-  const SE3 ref_world = se3_inverse(ref_pose);
-  const SE3 pose = se3_mul(cur_pose, ref_world);
+  const Rigid cur_pose = se3_from7(rq.cur_pose), ref_pose = se3_from7(rq.ref_pose);
+  const Rigid ref_world = se3_inverse(ref_pose);
+  const Rigid pose = se3_mul(cur_pose, ref_world);
   const V3 fvec = {rq.bearing[0], rq.bearing[1], rq.bearing[2]};
   const double idepth = rq.idepth, istd = rq.idepth_std;
   bool alive = true;

@@ -1,0 +1,1363 @@
+// sdvl_host.cc — implementation of the host layer declared in sdvl_host.h.  Reference line numbers are cited at
+// each function; device work goes through the C-ABI (include/sdvl_hip.h) only.
+#include "sdvl_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+namespace sdvl {
+
+using std::shared_ptr;
+using std::vector;
+
+// ------------------------------------------------------------------------------------------------------ Device
+static thread_local Device *g_current_device = nullptr;
+
+Device::Device(int gpu) {
+  const int rc = sdvl_ctx_create(gpu, &ctx_);
+  if (rc != SDVL_OK) throw std::runtime_error("sdvl_ctx_create failed (" + std::to_string(rc) + "): no MI355X visible; there is no CPU fallback");
+  if (!g_current_device) g_current_device = this;
+}
+
+Device::~Device() {
+  for (auto &p : pool_) sdvl_frame_destroy(ctx_, p.f);
+  if (g_current_device == this) g_current_device = nullptr;
+  sdvl_ctx_destroy(ctx_);
+}
+
+Device *Device::Current() {
+  if (!g_current_device) throw std::runtime_error("no sdvl::Device bound to this thread (construct one, or Device::SetCurrent)");
+  return g_current_device;
+}
+void Device::SetCurrent(Device *d) { g_current_device = d; }
+
+void Device::Check(int rc, const char *what) const {
+  if (rc != SDVL_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + sdvl_last_error(ctx_));
+}
+
+sdvl_frame *Device::AcquireFrame(int w, int h, int levels) {
+  std::lock_guard<std::mutex> lk(pool_mutex_);
+  for (size_t i = 0; i < pool_.size(); i++) {
+    if (pool_[i].w == w && pool_[i].h == h && pool_[i].levels == levels) {
+      sdvl_frame *f = pool_[i].f;
+      pool_[i] = pool_.back();
+      pool_.pop_back();
+      return f;
+    }
+  }
+  sdvl_frame *f = nullptr;
+  Check(sdvl_frame_create(ctx_, w, h, levels, &f), "sdvl_frame_create");
+  return f;
+}
+
+// frames die wherever their last shared_ptr is dropped, including the host worker threads
+void Device::ReleaseFrame(sdvl_frame *f, int w, int h, int levels) {
+  std::lock_guard<std::mutex> lk(pool_mutex_);
+  pool_.push_back(Pooled{f, w, h, levels});
+}
+
+// ---------------------------------------------------------------------------------------------------- RandStream
+RandStream::RandStream(unsigned seed) {
+  if (seed == 0) seed = 1;
+  r_[0] = static_cast<int>(seed);
+  for (int i = 1; i < 31; i++) {
+    const long hi = r_[i - 1] / 127773, lo = r_[i - 1] % 127773;
+    long word = 16807 * lo - 2836 * hi;
+    if (word < 0) word += 2147483647;
+    r_[i] = static_cast<int>(word);
+  }
+  fi_ = 3;
+  ri_ = 0;
+  for (int i = 0; i < 310; i++) Next();
+}
+
+int RandStream::Next() {
+  const unsigned val = static_cast<unsigned>(r_[fi_]) + static_cast<unsigned>(r_[ri_]);
+  r_[fi_] = static_cast<int>(val);
+  if (++fi_ >= 31) fi_ = 0;
+  if (++ri_ >= 31) ri_ = 0;
+  return static_cast<int>(val >> 1);
+}
+
+// -------------------------------------------------------------------------------------------------------- Camera
+Camera::Camera() {
+  const CameraParameters &p = Config::GetCameraParameters();
+  width_ = p.width; height_ = p.height; fx_ = p.fx; fy_ = p.fy; u0_ = p.u0; v0_ = p.v0;
+}
+Camera::Camera(int width, int height, double fx, double fy, double u0, double v0)
+    : width_(width), height_(height), fx_(fx), fy_(fy), u0_(u0), v0_(v0) {}
+
+// camera.cc:69-79
+void Camera::Project(const Vector3d &p3D, Vector2d *p2D) const {
+  (*p2D)(0) = u0_ + fx_ * p3D(0) / p3D(2);
+  (*p2D)(1) = v0_ + fy_ * p3D(1) / p3D(2);
+}
+void Camera::Unproject(const Vector2d &p2D, Vector3d *p3D) const {
+  const double x = (p2D(0) - u0_) / fx_, y = (p2D(1) - v0_) / fy_, z = 1.0;
+  const double n = std::sqrt(x * x + y * y + z * z);
+  (*p3D)(0) = x / n; (*p3D)(1) = y / n; (*p3D)(2) = z / n;
+}
+
+// ------------------------------------------------------------------------------------------------------- detectors
+static int DetectMargin() { return Config::UseORB() ? 4 + Config::ORBSize() / 2 : 1 + Config::PatchSize() / 2; }
+
+static sdvl_detect_params DetectParams() {
+  sdvl_detect_params dp;
+  dp.cell_size = Config::CellSize();
+  dp.max_fast_levels = Config::MaxFastLevels();
+  dp.fast_threshold = Config::FastThreshold();
+  dp.margin = DetectMargin();
+  return dp;
+}
+
+bool ORBDetector::GetDescriptor(const Image &src, const Vector2i &pos, std::vector<uchar> *desc) {
+  if (!src.dev) {
+    std::cerr << "[ERROR] ORBDetector::GetDescriptor needs a pyramid level of a Frame (HBM-resident)" << std::endl;
+    return false;
+  }
+  Device *dev = Device::Current();
+  const int32_t xyl[3] = {pos(0), pos(1), src.level};
+  desc->resize(32);
+  dev->Check(sdvl_orb_describe_points(dev->ctx(), src.dev, 1, xyl, desc->data(), nullptr), "sdvl_orb_describe_points");
+  return true;
+}
+
+// orb_detector.cc:398-410
+int ORBDetector::Distance(const std::vector<uchar> &a, const std::vector<uchar> &b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t va, vb;
+    std::memcpy(&va, &a[4 * i], 4);
+    std::memcpy(&vb, &b[4 * i], 4);
+    uint32_t v = va ^ vb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+// fast_detector.cc:33-51
+FastDetector::FastDetector(int width, int height, bool grid) {
+  cell_size_ = Config::CellSize();
+  grid_width_ = static_cast<int>(std::ceil(static_cast<double>(width) / cell_size_));
+  grid_height_ = static_cast<int>(std::ceil(static_cast<double>(height) / cell_size_));
+  if (grid) {
+    cgrid_.resize(static_cast<size_t>(grid_width_) * grid_height_, std::make_pair(0, Config::MinFeatureScore()));
+    grid_mask_.resize(static_cast<size_t>(grid_width_) * grid_height_, false);
+  }
+}
+void FastDetector::LockCell(Vector2d p) {
+  const int index = static_cast<int>(p(1) / cell_size_) * grid_width_ + static_cast<int>(p(0) / cell_size_);
+  grid_mask_.at(index) = true;
+}
+void FastDetector::UnlockCell(Vector2d p) {
+  const int index = static_cast<int>(p(1) / cell_size_) * grid_width_ + static_cast<int>(p(0) / cell_size_);
+  grid_mask_.at(index) = false;
+}
+
+namespace {
+struct KP { float x, y, response; };
+
+// cv::KeyPointsFilter::retainBest: same libstdc++ calls on identically ordered input
+void RetainBest(vector<KP> *kps, int n_points) {
+  if (n_points >= 0 && kps->size() > static_cast<size_t>(n_points)) {
+    if (n_points == 0) { kps->clear(); return; }
+    std::nth_element(kps->begin(), kps->begin() + n_points, kps->end(), [](const KP &a, const KP &b) { return a.response > b.response; });
+    const float ambiguous = (*kps)[n_points - 1].response;
+    auto new_end = std::partition(kps->begin() + n_points, kps->end(), [ambiguous](const KP &k) { return k.response >= ambiguous; });
+    kps->resize(new_end - kps->begin());
+  }
+}
+}  // namespace
+
+// fast_detector.cc:108-151 over the per-cell lists the K2 kernel produced (fast_detector.cc:79-106)
+void FastDetector::SelectFromCells(const sdvl_keypoint *kps, const int32_t *cell_offsets, int level_cell_begin, int wcells, int hcells,
+                                   int level, int level_w, int level_h, int nfeatures, vector<Vector3i> *pixels) {
+  const int cell = Config::CellSize(), margin = DetectMargin();
+  const int ncells = wcells * hcells;
+  vector<vector<KP>> cell_fts(ncells);
+  vector<int> nleft(ncells, 0), nselected(ncells, 0);
+  int nempty = 0;
+  for (int i = 0; i < hcells; i++) {
+    const int inity = std::max(margin, i * cell), maxy = std::min(level_h - margin, i * cell + cell);
+    if (maxy <= inity) continue;
+    for (int j = 0; j < wcells; j++) {
+      const int initx = std::max(margin, j * cell), maxx = std::min(level_w - margin, j * cell + cell);
+      if (maxx <= initx) continue;
+      const int c = i * wcells + j;
+      const int b = cell_offsets[level_cell_begin + c], e = cell_offsets[level_cell_begin + c + 1];
+      vector<KP> &v = cell_fts[c];
+      v.reserve(e - b);
+      for (int k = b; k < e; k++) v.push_back(KP{static_cast<float>(kps[k].x), static_cast<float>(kps[k].y), static_cast<float>(kps[k].score)});
+      if (!v.empty()) nleft[c] = static_cast<int>(v.size());
+      else nempty++;
+    }
+  }
+  int selected = 0;
+  int cells_left = ncells - nempty;
+  while ((nfeatures - selected) > 0 && cells_left > 0) {
+    const int npercell = static_cast<int>(std::ceil(static_cast<double>(nfeatures - selected) / static_cast<double>(cells_left)));
+    cells_left = 0;
+    for (int c = 0; c < ncells; c++) {
+      if (nleft[c] > 0) {
+        if (nleft[c] > npercell) {
+          nselected[c] += npercell; selected += npercell; nleft[c] -= npercell; cells_left++;
+        } else {
+          nselected[c] += nleft[c]; selected += nleft[c]; nleft[c] = 0;
+        }
+      }
+    }
+  }
+  vector<KP> fts;
+  for (int c = 0; c < ncells; c++) {
+    RetainBest(&cell_fts[c], nselected[c]);
+    for (const KP &k : cell_fts[c]) fts.push_back(k);
+  }
+  if (static_cast<int>(fts.size()) > nfeatures) RetainBest(&fts, nfeatures);
+  for (const KP &k : fts) pixels->push_back(Vector3i(static_cast<int>(k.x), static_cast<int>(k.y), level));
+}
+
+// fast_detector.cc:154-175.  `pyramid` must be a Frame's pyramid (HBM binding).
+void FastDetector::DetectPyramid(const vector<Image> &pyramid, vector<Vector3i> *corners, int nfeatures) {
+  if (pyramid.empty() || !pyramid[0].dev) {
+    std::cerr << "[ERROR] FastDetector::DetectPyramid needs the pyramid of a Frame (HBM-resident)" << std::endl;
+    return;
+  }
+  Device *dev = Device::Current();
+  const sdvl_detect_params dp = DetectParams();
+  int cpl[4] = {0, 0, 0, 0}, total = 0;
+  dev->Check(sdvl_fast_num_cells(pyramid[0].cols, pyramid[0].rows, &dp, cpl, &total), "sdvl_fast_num_cells");
+  const int cap = 32768;
+  vector<sdvl_keypoint> kps(cap);
+  vector<int32_t> offs(total + 1);
+  sdvl_frame *fr = pyramid[0].dev;
+  dev->Check(sdvl_fast_cells(dev->ctx(), 1, &fr, &dp, cap, kps.data(), offs.data()), "sdvl_fast_cells");
+  const double scale = 1.2;
+  double factor = 1.0, val = 0.0;
+  for (int i = 0; i < Config::MaxFastLevels(); i++) { val += factor; factor /= scale; }
+  int levelfeatures = static_cast<int>(nfeatures / val);
+  int begin = 0;
+  for (int i = 0; i < Config::MaxFastLevels(); i++) {
+    const int wc = (pyramid[i].cols + dp.cell_size - 1) / dp.cell_size, hc = (pyramid[i].rows + dp.cell_size - 1) / dp.cell_size;
+    SelectFromCells(kps.data(), offs.data(), begin, wc, hc, i, pyramid[i].cols, pyramid[i].rows, levelfeatures, corners);
+    begin += cpl[i];
+    levelfeatures = static_cast<int>(levelfeatures / scale);
+  }
+}
+
+// fast_detector.cc:177-218 with the Shi-Tomasi scores supplied by the K3 kernel
+void FastDetector::FilterWithScores(const vector<Image> &pyramid, const vector<Vector3i> &corners, const double *scores,
+                                    vector<int> *indices) {
+  const int margin = DetectMargin();
+  int index = 0;
+  for (auto it = corners.begin(); it != corners.end(); it++, index++) {
+    const int px = (*it)(0), py = (*it)(1), level = (*it)(2);
+    const int scale = (1 << level);
+    if (px < margin || py < margin || px >= pyramid[level].cols - margin || py >= pyramid[level].rows - margin) continue;
+    const int pos = static_cast<int>((py * scale) / cell_size_) * grid_width_ + static_cast<int>((px * scale) / cell_size_);
+    if (grid_mask_[pos]) continue;
+    const double score = scores[index];
+    if (score > cgrid_.at(pos).second) cgrid_.at(pos) = std::make_pair(index, static_cast<int>(score));
+  }
+  for (auto it = cgrid_.begin(); it != cgrid_.end(); it++)
+    if ((*it).second > Config::MinFeatureScore()) indices->push_back((*it).first);
+}
+
+void FastDetector::FilterCorners(const vector<Image> &pyramid, const vector<Vector3i> &corners, vector<int> *indices) {
+  if (pyramid.empty() || !pyramid[0].dev) {
+    std::cerr << "[ERROR] FastDetector::FilterCorners needs the pyramid of a Frame (HBM-resident)" << std::endl;
+    return;
+  }
+  Device *dev = Device::Current();
+  sdvl_frame *fr = pyramid[0].dev;
+  if (sdvl_frame_num_corners(fr) != static_cast<int>(corners.size())) {
+    std::cerr << "[ERROR] FastDetector::FilterCorners: corners differ from the frame's HBM corner list" << std::endl;
+    return;
+  }
+  vector<double> scores(std::max<size_t>(corners.size(), 1));
+  dev->Check(sdvl_shi_tomasi(dev->ctx(), 1, &fr, static_cast<int>(scores.size()), scores.data()), "sdvl_shi_tomasi");
+  FilterWithScores(pyramid, corners, scores.data(), indices);
+}
+
+// ------------------------------------------------------------------------------------------------ Feature / Point
+// feature.cc:28-56
+Feature::Feature(const shared_ptr<Frame> &f, const Vector2d &p, int l) : frame_(f), point_(nullptr), p2d_(p), level_(l) {
+  v_ = f->GetCamera()->Unproject(p2d_);
+  descriptor_.resize(32);
+  has_descriptor_ = false;
+}
+Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, int l) : frame_(f), point_(ft), p2d_(p), level_(l) {
+  v_ = f->GetCamera()->Unproject(p2d_);
+  descriptor_.resize(32);
+  has_descriptor_ = false;
+}
+Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, const Vector3d &v, int l)
+    : frame_(f), point_(ft), p2d_(p), v_(v), level_(l) {
+  descriptor_.resize(32);
+  has_descriptor_ = false;
+}
+
+static std::atomic<int> g_point_counter{0};
+
+// point.cc:32-43
+Point::Point() {
+  id_ = g_point_counter++;
+  status_ = P_NOT_FOUND;
+  last_frame_ = -1;
+  n_failed_ = 0;
+  n_successful_ = 0;
+  delete_ = false;
+  fixed_ = false;
+  a_ = b_ = 10;
+  rho_ = 1.0;
+  sigma2_ = 1.0;
+  z_range_ = 6.0;
+}
+double Point::GetStd() { return std::sqrt(sigma2_); }
+
+// point.cc:48-62
+void Point::InitCandidate(const shared_ptr<Feature> &p, double depth) {
+  feature_ = p;
+  a_ = 10; b_ = 10;
+  rho_ = 1.0 / depth;
+  sigma2_ = 1.0;
+  z_range_ = std::sqrt(sigma2_ * 36);
+}
+void Point::InitFixed(const shared_ptr<Feature> &f, double depth, double sigma2, const Vector3d &p3d) {
+  InitCandidate(f, depth);
+  sigma2_ = sigma2;
+  fixed_ = true;
+  p3d_ = p3d;
+}
+
+// point.cc:128-142
+Vector3d Point::GetPosition() const {
+  if (fixed_) return p3d_;
+  shared_ptr<Frame> fr = feature_->GetFrame();
+  const SE3 se3 = fr->GetWorldPose();
+  const Vector3d &v = feature_->GetVector();
+  const double s = 1.0 / rho_;
+  return se3 * Vector3d(s * v(0), s * v(1), s * v(2));
+}
+
+// point.cc:105-118
+bool Point::Promote() { n_successful_++; n_failed_ = 0; return true; }
+bool Point::Unpromote() {
+  n_failed_++;
+  b_++;
+  return n_failed_ > Config::MaxFailed();
+}
+
+// ---------------------------------------------------------------------------------------------------------- Frame
+int Frame::counter_ = 0;
+static std::mutex g_frame_counter_mutex;
+
+void Frame::InitCommon(Camera *camera, ORBDetector *detector, int w, int h) {
+  {
+    std::lock_guard<std::mutex> lk(g_frame_counter_mutex);
+    id_ = counter_;
+    counter_ += 1;
+  }
+  camera_ = camera;
+  orb_detector_ = detector;
+  pyramid_levels_ = Config::PyramidLevels();
+  pose_ = SE3();
+  width_ = w;
+  height_ = h;
+  is_keyframe_ = false;
+  owner_ = Device::Current();
+  dev_ = owner_->AcquireFrame(w, h, pyramid_levels_);
+  pyramid_.resize(pyramid_levels_);
+  int lw = w, lh = h;
+  for (int l = 0; l < pyramid_levels_; l++) {
+    Image im;
+    im.cols = lw; im.rows = lh; im.step = lw; im.dev = dev_; im.level = l;
+    pyramid_[l] = im;
+    lw /= 2;
+    lh /= 2;
+  }
+}
+
+namespace {
+// pyramid + FAST + selection + ORB for a set of already-initialised frames (frame.cc:34-56 for each)
+void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs, const vector<Image> &imgs, bool corners, int nfeatures,
+                 vector<vector<Vector3i> *> corner_lists, const std::function<void(int, std::function<void(int)>)> *pfor) {
+  Device *dev = Device::Current();
+  const int n = static_cast<int>(frames.size());
+  if (n == 0) return;
+  for (int i = 0; i < n; i++) {
+    if (imgs[i].dev_src) dev->Check(sdvl_frame_set_image_device(dev->ctx(), devs[i], imgs[i].dev_src, imgs[i].step), "sdvl_frame_set_image_device");
+    else dev->Check(sdvl_frame_upload(dev->ctx(), devs[i], imgs[i].data, imgs[i].step), "sdvl_frame_upload");
+  }
+  dev->Check(sdvl_pyramid_build(dev->ctx(), n, devs.data()), "sdvl_pyramid_build");
+  if (!corners) return;
+  const sdvl_detect_params dp = DetectParams();
+  const int W = imgs[0].cols, H = imgs[0].rows;
+  int cpl[4] = {0, 0, 0, 0}, total = 0;
+  dev->Check(sdvl_fast_num_cells(W, H, &dp, cpl, &total), "sdvl_fast_num_cells");
+  const int cap = 32768;
+  static thread_local vector<sdvl_keypoint> kps;
+  static thread_local vector<int32_t> offs;
+  kps.resize(static_cast<size_t>(n) * cap);
+  offs.resize(static_cast<size_t>(n) * (total + 1));
+  dev->Check(sdvl_fast_cells(dev->ctx(), n, devs.data(), &dp, cap, kps.data(), offs.data()), "sdvl_fast_cells");
+  // quota per level, fast_detector.cc:161-174
+  const double scale = 1.2;
+  double factor = 1.0, val = 0.0;
+  for (int i = 0; i < Config::MaxFastLevels(); i++) { val += factor; factor /= scale; }
+  const int first_quota = static_cast<int>(nfeatures / val);
+  // plain pointers: a lambda body that names a thread_local variable reads the EXECUTING thread's instance
+  const sdvl_keypoint *kps_p = kps.data();
+  const int32_t *offs_p = offs.data();
+  auto select_one = [&, kps_p, offs_p](int i) {
+    int levelfeatures = first_quota, begin = 0, lw = W, lh = H;
+    for (int l = 0; l < Config::MaxFastLevels(); l++) {
+      const int wc = (lw + dp.cell_size - 1) / dp.cell_size, hc = (lh + dp.cell_size - 1) / dp.cell_size;
+      FastDetector::SelectFromCells(kps_p + static_cast<size_t>(i) * cap, offs_p + static_cast<size_t>(i) * (total + 1), begin, wc, hc,
+                                    l, lw, lh, levelfeatures, corner_lists[i]);
+      begin += cpl[l];
+      levelfeatures = static_cast<int>(levelfeatures / scale);
+      lw /= 2;
+      lh /= 2;
+    }
+  };
+  if (pfor) (*pfor)(n, select_one);
+  else for (int i = 0; i < n; i++) select_one(i);
+  vector<int32_t> counts(n), xyl;
+  for (int i = 0; i < n; i++) {
+    counts[i] = static_cast<int32_t>(corner_lists[i]->size());
+    for (const Vector3i &c : *corner_lists[i]) { xyl.push_back(c(0)); xyl.push_back(c(1)); xyl.push_back(c(2)); }
+  }
+  dev->Check(sdvl_frames_set_corners(dev->ctx(), n, devs.data(), counts.data(), xyl.data()), "sdvl_frames_set_corners");
+  if (Config::UseORB()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
+}
+}  // namespace
+
+// frame.cc:34-56
+Frame::Frame(Camera *camera, ORBDetector *detector, const Image &img, bool corners) {
+  InitCommon(camera, detector, img.cols, img.rows);
+  BuildFrames({this}, {dev_}, {img}, corners, Config::NumFeatures(), {&corners_}, nullptr);
+  if (corners && Config::UseORB()) descriptors_.resize(corners_.size());
+}
+
+void Frame::CreateBatch(Camera *camera, ORBDetector *detector, const vector<Image> &imgs, bool corners, int nfeatures,
+                        vector<shared_ptr<Frame>> *out, const std::function<void(int, std::function<void(int)>)> *pfor) {
+  const int n = static_cast<int>(imgs.size());
+  vector<Frame *> raw(n);
+  vector<sdvl_frame *> devs(n);
+  vector<vector<Vector3i> *> lists(n);
+  out->clear();
+  for (int i = 0; i < n; i++) {
+    shared_ptr<Frame> f(new Frame());
+    f->InitCommon(camera, detector, imgs[i].cols, imgs[i].rows);
+    raw[i] = f.get();
+    devs[i] = f->dev_;
+    lists[i] = &f->corners_;
+    out->push_back(f);
+  }
+  BuildFrames(raw, devs, imgs, corners, nfeatures, lists, pfor);
+  if (corners && Config::UseORB())
+    for (auto &f : *out) f->descriptors_.resize(f->corners_.size());
+}
+
+Frame::~Frame() {
+  features_.clear();
+  if (dev_ && owner_) {
+    sdvl_frame *f = dev_;  // hand the HBM frame back to the pool
+    dev_ = nullptr;
+    owner_->ReleaseFrame(f, width_, height_, pyramid_levels_);
+  }
+}
+
+// frame.cc:122-131
+void Frame::CreateCorners(int, int nfeatures) {
+  corners_.clear();
+  FastDetector detector(width_, height_, false);
+  detector.DetectPyramid(pyramid_, &corners_, nfeatures);
+  Device *dev = Device::Current();
+  vector<int32_t> xyl;
+  for (const Vector3i &c : corners_) { xyl.push_back(c(0)); xyl.push_back(c(1)); xyl.push_back(c(2)); }
+  dev->Check(sdvl_frame_set_corners(dev->ctx(), dev_, static_cast<int>(corners_.size()), xyl.data()), "sdvl_frame_set_corners");
+  descriptors_.clear();
+  descriptors_on_host_ = false;
+  if (Config::UseORB()) {
+    dev->Check(sdvl_orb_describe(dev->ctx(), 1, &dev_, SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
+    descriptors_.resize(corners_.size());
+  }
+}
+
+vector<Image> &Frame::GetPyramid() {
+  if (!pyramid_on_host_) {
+    Device *dev = Device::Current();
+    for (int l = 0; l < pyramid_levels_; l++) {
+      Image &im = pyramid_[l];
+      im.owner = std::make_shared<vector<uint8_t>>(static_cast<size_t>(im.cols) * im.rows);
+      dev->Check(sdvl_frame_download_level(dev->ctx(), dev_, l, im.owner->data(), im.cols), "sdvl_frame_download_level");
+      im.data = im.owner->data();
+    }
+    pyramid_on_host_ = true;
+  }
+  return pyramid_;
+}
+
+vector<vector<uchar>> &Frame::GetDescriptors() {
+  if (!descriptors_on_host_ && Config::UseORB() && !corners_.empty()) {
+    Device *dev = Device::Current();
+    vector<uint8_t> buf(corners_.size() * 32);
+    dev->Check(sdvl_frame_download_descriptors(dev->ctx(), dev_, static_cast<int>(corners_.size()), buf.data()), "sdvl_frame_download_descriptors");
+    descriptors_.resize(corners_.size());
+    for (size_t i = 0; i < corners_.size(); i++) descriptors_[i].assign(buf.begin() + 32 * i, buf.begin() + 32 * (i + 1));
+    descriptors_on_host_ = true;
+  }
+  return descriptors_;
+}
+
+// frame.cc:133-163
+void Frame::FilterCorners() { FilterCornersBatch({shared_from_this()}); }
+
+void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
+  const int n = static_cast<int>(frames.size());
+  if (n == 0) return;
+  Device *dev = Device::Current();
+  vector<sdvl_frame *> devs(n);
+  for (int i = 0; i < n; i++) devs[i] = frames[i]->dev_;
+  vector<double> scores(static_cast<size_t>(n) * SDVL_MAX_CORNERS);
+  dev->Check(sdvl_shi_tomasi(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, scores.data()), "sdvl_shi_tomasi");
+  for (int i = 0; i < n; i++) {
+    Frame &f = *frames[i];
+    FastDetector detector(f.width_, f.height_);
+    for (auto it = f.features_.begin(); it != f.features_.end(); it++) detector.LockCell((*it)->GetPosition());
+    detector.FilterWithScores(f.pyramid_, f.corners_, scores.data() + static_cast<size_t>(i) * SDVL_MAX_CORNERS, &f.filtered_corners_);
+    if (Config::UseORB()) f.GetDescriptors();  // frame.cc:145-161: descriptors of the filtered corners on the host
+  }
+}
+
+// frame.cc:165-179
+int Frame::GetNumPoints() const {
+  int count = 0;
+  for (auto it = features_.begin(); it != features_.end(); it++) {
+    if (!(*it)) continue;
+    if (!(*it)->GetPoint()) continue;
+    count++;
+  }
+  return count;
+}
+
+// frame.cc:94-103
+bool Frame::Project(const Vector3d &p3D, Vector2d *p2D) {
+  const Vector3d rel_p = GetRelativePos(p3D);
+  if (rel_p(2) < 0.0) return false;
+  camera_->Project(rel_p, p2D);
+  return true;
+}
+
+// ----------------------------------------------------------------------------------------------------- ImageAlign
+static sdvl_align_params AlignParams(bool fast) {
+  sdvl_align_params ap;
+  ap.max_level = Config::MaxAlignLevel();
+  ap.min_level = Config::MinAlignLevel();
+  ap.max_its = Config::MaxImgAlignIts();
+  ap.patch_size = Config::AlignPatchSize();
+  ap.fast = fast ? 1 : 0;
+  return ap;
+}
+
+// image_align.cc:46-84 for n pairs with one launch
+void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> &pairs, bool fast, vector<int> *n_meas,
+                                  vector<double> *errors) {
+  const int n = static_cast<int>(pairs.size());
+  n_meas->assign(n, 0);
+  errors->assign(n, 1e10);
+  vector<sdvl_align_job> jobs;
+  vector<int> job_of;
+  vector<sdvl_align_feature> feats;
+  for (int i = 0; i < n; i++) {
+    Frame &f1 = *pairs[i].first, &f2 = *pairs[i].second;
+    vector<shared_ptr<Feature>> &features = f1.GetFeatures();
+    if (features.empty()) {
+      std::cerr << "[ERROR] No points to track!" << std::endl;  // image_align.cc:55-58
+      continue;
+    }
+    const Vector3d first_pos = f1.GetWorldPosition();
+    sdvl_align_job job;
+    job.ref = f1.device();
+    job.cur = f2.device();
+    job.feat_begin = static_cast<int32_t>(feats.size());
+    for (auto &ft : features) {
+      sdvl_align_feature a;
+      a.px = ft->GetPosition()(0); a.py = ft->GetPosition()(1);
+      a.fx = ft->GetVector()(0); a.fy = ft->GetVector()(1); a.fz = ft->GetVector()(2);
+      shared_ptr<Point> pt = ft->GetPoint();
+      a.valid = (pt && !pt->ToDelete()) ? 1 : 0;
+      a.depth = 0.0;
+      if (a.valid) {
+        const Vector3d p = pt->GetPosition();
+        const double dx = p(0) - first_pos(0), dy = p(1) - first_pos(1), dz = p(2) - first_pos(2);
+        a.depth = std::sqrt(dx * dx + dy * dy + dz * dz);
+      }
+      a.pad_ = 0;
+      feats.push_back(a);
+    }
+    job.feat_end = static_cast<int32_t>(feats.size());
+    const SE3 T = f2.GetPose() * f1.GetPose().Inverse();  // image_align.cc:66
+    T.ToArray(job.T);
+    jobs.push_back(job);
+    job_of.push_back(i);
+  }
+  if (jobs.empty()) return;
+  Device *dev = Device::Current();
+  const sdvl_camera cam = pairs[job_of[0]].second->GetCamera()->abi();
+  const sdvl_align_params ap = AlignParams(fast);
+  vector<sdvl_align_result> res(jobs.size());
+  dev->Check(sdvl_image_align(dev->ctx(), static_cast<int>(jobs.size()), jobs.data(), static_cast<int>(feats.size()), feats.data(), &cam, &ap,
+                              res.data()), "sdvl_image_align");
+  for (size_t j = 0; j < jobs.size(); j++) {
+    const int i = job_of[j];
+    pairs[i].second->SetPose(SE3::FromArray(res[j].T) * pairs[i].first->GetPose());  // image_align.cc:79
+    (*n_meas)[i] = res[j].n_meas;
+    (*errors)[i] = res[j].error;
+  }
+}
+
+int ImageAlign::ComputePose(const shared_ptr<Frame> &frame1, const shared_ptr<Frame> &frame2, bool fast) {
+  vector<int> n;
+  vector<double> e;
+  ComputePoseBatch({{frame1, frame2}}, fast, &n, &e);
+  error_ = e[0];
+  return n[0];
+}
+
+// -------------------------------------------------------------------------------------------------------- Matcher
+static sdvl_search_params SearchParams() {
+  sdvl_search_params sp;
+  sp.patch_size = Config::PatchSize();
+  sp.max_align_its = Config::MaxAlignIts();
+  sp.search_size = Config::SearchSize();
+  sp.max_fast_levels = Config::MaxFastLevels();
+  sp.margin = DetectMargin();
+  sp.use_orb = Config::UseORB() ? 1 : 0;
+  return sp;
+}
+
+bool Matcher::MakeRequest(const shared_ptr<Frame> &frame, const shared_ptr<Feature> &feature, double idepth, double idepth_std, bool fixed,
+                          const Vector2d &px, sdvl_search_req *req) {
+  shared_ptr<Frame> ref_frame = feature->GetFrame();
+  if (!ref_frame) return false;
+  req->cur = frame->device();
+  req->ref = ref_frame->device();
+  frame->GetPose().ToArray(req->cur_pose);
+  ref_frame->GetPose().ToArray(req->ref_pose);
+  req->px[0] = feature->GetPosition()(0); req->px[1] = feature->GetPosition()(1);
+  req->bearing[0] = feature->GetVector()(0); req->bearing[1] = feature->GetVector()(1); req->bearing[2] = feature->GetVector()(2);
+  req->idepth = idepth;
+  req->idepth_std = idepth_std;
+  req->px0[0] = px(0); req->px0[1] = px(1);
+  req->level = feature->GetLevel();
+  req->fixed = fixed ? 1 : 0;
+  std::memcpy(req->desc, feature->GetDescriptor().data(), 32);
+  return true;
+}
+
+void Matcher::SearchPoints(Device *dev, const vector<sdvl_search_req> &reqs, const Camera &cam, vector<sdvl_search_res> *res) {
+  res->resize(reqs.size());
+  if (reqs.empty()) return;
+  const sdvl_camera c = cam.abi();
+  const sdvl_search_params sp = SearchParams();
+  dev->Check(sdvl_search_points(dev->ctx(), static_cast<int>(reqs.size()), reqs.data(), &c, &sp, res->data()), "sdvl_search_points");
+}
+
+// matcher.cc:45-121
+bool Matcher::SearchPoint(const shared_ptr<Frame> &frame, const shared_ptr<Feature> &feature, double idepth, double idepth_std, bool fixed,
+                          Vector2d *px, int *flevel) {
+  vector<sdvl_search_req> reqs(1);
+  if (!MakeRequest(frame, feature, idepth, idepth_std, fixed, *px, &reqs[0])) return false;
+  vector<sdvl_search_res> res;
+  SearchPoints(Device::Current(), reqs, *frame->GetCamera(), &res);
+  if (res[0].stage >= 2 || res[0].found) { (*px)(0) = res[0].px[0]; (*px)(1) = res[0].px[1]; }
+  if (!res[0].found) return false;
+  *flevel = res[0].level;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------ Map
+// map.cc:170-188
+bool Map::NeedKeyframe(const shared_ptr<Frame> &frame, int) {
+  const int npoints = frame->GetNumPoints();
+  const bool enough_its = (frame->GetID() - last_kf_->GetID()) >= Config::MinKeyframeIts();
+  const bool lost_many = npoints < last_matches_ * Config::LostRatio();
+  const bool lost_some = npoints < last_matches_ * 0.9;
+  last_matches_ = std::max(last_matches_, npoints);
+  if ((enough_its && lost_some) || lost_many) {
+    last_matches_ = npoints;
+    return true;
+  }
+  return false;
+}
+
+// map.cc:145-159
+void Map::AddKeyframe(const shared_ptr<Frame> &frame) {
+  keyframes_.push_back(frame);
+  last_kf_ = frame;
+}
+
+// map.cc:207-259 (points)
+void Map::EmptyTrash() {
+  for (auto &p : points_trash_) {
+    std::list<shared_ptr<Feature>> &features = p->GetFeatures();
+    for (auto it = features.begin(); it != features.end(); it++) (*it)->SetPoint(nullptr);
+    features.clear();
+    p->SetDelete();
+  }
+  points_trash_.clear();
+}
+
+void PlaneMap::InitCandidates(const shared_ptr<Frame> &kf) {
+  kf->FilterCorners();
+  SeedFromFiltered(kf);
+}
+
+void PlaneMap::SeedFromFiltered(const shared_ptr<Frame> &kf) {
+  const SE3 world = kf->GetWorldPose();
+  const M3 Rw = world.GetRotation();
+  const Vector3d tw = world.GetTranslation();
+  vector<Vector3i> &corners = kf->GetCorners();
+  vector<vector<uchar>> &descriptors = kf->GetDescriptors();
+  for (int index : kf->GetFilteredCorners()) {
+    const Vector3i corner = corners[index];
+    const int scale = (1 << corner(2));
+    shared_ptr<Feature> feature = std::make_shared<Feature>(kf, Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
+    if (Config::UseORB()) feature->SetDescriptor(descriptors[index]);
+    const Vector3d &v = feature->GetVector();
+    const V3 ray = mvec(Rw, {v(0), v(1), v(2)});
+    const double denom = n_(0) * ray.x + n_(1) * ray.y + n_(2) * ray.z;
+    if (!(std::fabs(denom) > 1e-9)) continue;
+    const double s = (d_ - (n_(0) * tw(0) + n_(1) * tw(1) + n_(2) * tw(2))) / denom;
+    if (!(s > 0.05)) continue;
+    shared_ptr<Point> pt = std::make_shared<Point>();
+    const double rho = 1.0 / s;
+    pt->InitFixed(feature, s, (0.05 * rho) * (0.05 * rho), world * Vector3d(s * v(0), s * v(1), s * v(2)));
+    feature->SetPoint(pt);
+    kf->AddFeature(feature);
+    pt->AddFeature(feature);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------- FeatureAlign
+// feature_align.cc:33-54
+FeatureAlign::FeatureAlign(Map *map, Camera *camera, int max_matches, RandStream *rng) {
+  map_ = map;
+  camera_ = camera;
+  rng_ = rng;
+  cell_size_ = Config::CellSize();
+  max_matches_ = max_matches;
+  matches_ = 0;
+  num_attempts_ = 0;
+  relocalizing_ = false;
+  grid_width_ = static_cast<int>(std::ceil(static_cast<double>(camera->GetWidth()) / cell_size_));
+  grid_height_ = static_cast<int>(std::ceil(static_cast<double>(camera->GetHeight()) / cell_size_));
+  const int size = grid_width_ * grid_height_;
+  grid_.resize(size);
+  for (auto &c : grid_) c = new GridCell;
+  for (int i = 0; i < size; ++i) cell_order_.push_back(i);
+  rng_->Shuffle(&cell_order_);
+}
+
+FeatureAlign::~FeatureAlign() {
+  for (auto c : grid_) delete c;
+}
+
+// feature_align.cc:285-294
+void FeatureAlign::ResetGrid() {
+  matches_ = 0;
+  num_attempts_ = 0;
+  for (auto c : grid_) c->clear();
+}
+
+// feature_align.cc:296-339
+void FeatureAlign::ProjectPoints(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame) {
+  ResetGrid();
+  vector<shared_ptr<Feature>> &features = last_frame->GetFeatures();
+  for (auto it = features.begin(); it != features.end(); it++) {
+    if (*it == nullptr) continue;
+    shared_ptr<Point> point = (*it)->GetPoint();
+    if (!point || point->ToDelete()) continue;
+    if (frame->GetID() == point->GetLastFrame()) continue;
+    ProjectPoint(frame, point);
+    if (!relocalizing_) point->SetLastFrame(frame->GetID());
+  }
+}
+
+bool FeatureAlign::ProjectPoint(const shared_ptr<Frame> &frame, const shared_ptr<Point> &point) {
+  Vector2d p;
+  if (!frame->Project(point->GetPosition(), &p)) {
+    point->SetStatus(Point::P_UNSEEN);
+    return false;
+  }
+  if (!frame->GetCamera()->IsInsideImage(Vector2i(static_cast<int>(p(0)), static_cast<int>(p(1))), Config::PatchSize())) {
+    point->SetStatus(Point::P_UNSEEN);
+    return false;
+  }
+  const int k = static_cast<int>(p(1) / cell_size_) * grid_width_ + static_cast<int>(p(0) / cell_size_);
+  grid_.at(k)->push_back(std::make_pair(point, p));
+  point->SetStatus(Point::P_SEEN);
+  return true;
+}
+
+// first half of SelectPoints (feature_align.cc:88-118): project, shuffle, sort every cell, emit ALL candidates
+void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame, bool reloc,
+                                    vector<sdvl_search_req> *reqs) {
+  inliers_.clear();
+  outliers_.clear();
+  relocalizing_ = reloc;
+  ProjectPoints(frame, last_frame);
+  matches_ = 0;
+  num_attempts_ = 0;
+  rng_->Shuffle(&cell_order_);
+  const int size = static_cast<int>(grid_.size());
+  plan_.assign(size, {});
+  for (int i = 0; i < size; i++) {
+    GridCell *cell = grid_.at(cell_order_[i]);
+    cell->sort([](const PointInfo &a, const PointInfo &b) { return a.first->Score() > b.first->Score(); });
+    for (auto it = cell->begin(); it != cell->end(); it++) {
+      shared_ptr<Point> point = it->first;
+      if (point->ToDelete()) continue;
+      shared_ptr<Feature> feature = point->GetInitFeature();
+      if (!feature) continue;
+      Candidate c;
+      c.point = point;
+      c.pos = it->second;
+      c.req = -1;
+      sdvl_search_req rq;
+      if (Matcher::MakeRequest(frame, feature, point->GetInverseDepth(), point->GetStd(), point->IsFixed(), it->second, &rq)) {
+        c.req = static_cast<int>(reqs->size());
+        reqs->push_back(rq);
+      }
+      plan_[i].push_back(c);
+    }
+  }
+}
+
+// second half of SelectPoints (feature_align.cc:105-149) replayed over the batch results, then SelectInliers
+void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
+  vector<shared_ptr<Feature>> selected_fs;
+  const int size = static_cast<int>(plan_.size());
+  for (int i = 0; i < size && matches_ < max_matches_; i++) {
+    bool found = false;
+    for (auto it = plan_[i].begin(); it != plan_[i].end() && !found; it++) {
+      shared_ptr<Point> point = it->point;
+      num_attempts_++;
+      found = it->req >= 0 && res[it->req].found != 0;
+      if (found) {
+        if (!relocalizing_) {
+          point->Promote();
+          shared_ptr<Feature> feature = std::make_shared<Feature>(frame, Vector2d(res[it->req].px[0], res[it->req].px[1]), res[it->req].level);
+          feature->SetPoint(point);
+          frame->AddFeature(feature);
+          point->SetStatus(Point::P_FOUND);
+          selected_fs.push_back(feature);
+        }
+        matches_++;
+      } else {
+        if (!relocalizing_) {
+          if (point->Unpromote()) map_->DeletePoint(point);
+          point->SetStatus(Point::P_NOT_FOUND);
+        }
+      }
+    }
+  }
+  plan_.clear();
+  SelectInliers(frame, selected_fs, &inliers_, &outliers_);
+}
+
+// feature_align.cc:59-71
+void FeatureAlign::Reproject(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame, const shared_ptr<Frame> &, bool reloc) {
+  vector<sdvl_search_req> reqs;
+  PrepareReproject(frame, last_frame, reloc, &reqs);
+  vector<sdvl_search_res> res;
+  Matcher::SearchPoints(Device::Current(), reqs, *camera_, &res);
+  FinishReproject(frame, res.data());
+}
+
+// feature_align.cc:73-82
+bool FeatureAlign::OptimizePose(const shared_ptr<Frame> &frame) {
+  OptimizePose(frame, &inliers_, &outliers_);
+  if (RescueOutliers(frame, &inliers_, &outliers_)) OptimizePose(frame, &inliers_, &outliers_);
+  RemoveOutliers(frame, &outliers_);
+  return true;
+}
+
+// feature_align.cc:152-216
+void FeatureAlign::SelectInliers(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> &fs_found, vector<shared_ptr<Feature>> *inliers,
+                                 vector<shared_ptr<Feature>> *outliers) {
+  inliers->clear();
+  outliers->clear();
+  if (fs_found.empty()) return;
+  const int size = static_cast<int>(fs_found.size());
+  const int npoints = std::min(Config::MaxRansacPoints(), size);
+  vector<shared_ptr<Feature>> selected;
+  SE3 se3, best_se3;
+  const double sprob = 0.99;
+  int nits = Config::MaxRansacIts();
+  int best_supporters = 0;
+  int it = 0;
+  const double thr = Config::InlierErrorThreshold() / frame->GetCamera()->GetFx();
+  while (it < nits) {
+    selected.clear();
+    const int index = rng_->Next() % size;
+    for (int i = 0; i < npoints; i++) selected.push_back(fs_found.at((index + i) % size));
+    if (!ConvergePose(frame, selected, &se3)) { it++; continue; }
+    const int supporters = CheckReprojectionError(fs_found, se3, thr);
+    if (supporters > best_supporters) {
+      best_supporters = supporters;
+      best_se3 = se3;
+      const double epsilon = 1.0 - (static_cast<double>(supporters) / static_cast<double>(size));
+      double tmp = 1.0 - epsilon;
+      for (int k = 1; k < npoints; k++) tmp *= tmp;
+      if (tmp < 1e-5) nits = Config::MaxRansacIts();
+      else nits = std::min(Config::MaxRansacIts(), static_cast<int>(std::log(1.0 - sprob) / std::log(1.0 - tmp)));
+    }
+    it++;
+  }
+  CheckReprojectionError(fs_found, best_se3, thr, inliers, outliers);
+}
+
+// feature_align.cc:218-230
+void FeatureAlign::OptimizePose(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> *features, vector<shared_ptr<Feature>> *outliers) {
+  SE3 se3 = frame->GetPose();
+  if (!ConvergePose(frame, *features, &se3)) return;
+  frame->SetPose(se3);
+  vector<shared_ptr<Feature>> cfeatures = *features;
+  features->clear();
+  CheckReprojectionError(cfeatures, frame->GetPose(), Config::InlierErrorThreshold() / frame->GetCamera()->GetFx(), features, outliers);
+}
+
+// feature_align.cc:232-243
+bool FeatureAlign::RescueOutliers(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> *inliers, vector<shared_ptr<Feature>> *outliers) {
+  const int init_inliers = static_cast<int>(inliers->size());
+  vector<shared_ptr<Feature>> cfeatures = *outliers;
+  outliers->clear();
+  CheckReprojectionError(cfeatures, frame->GetPose(), 2 * Config::InlierErrorThreshold() / frame->GetCamera()->GetFx(), inliers, outliers);
+  return static_cast<int>(inliers->size()) > init_inliers;
+}
+
+// feature_align.cc:245-256
+void FeatureAlign::RemoveOutliers(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> *outliers) {
+  for (auto it = outliers->begin(); it != outliers->end(); it++) {
+    shared_ptr<Point> p = (*it)->GetPoint();
+    if (!p) continue;
+    (*it)->SetPoint(nullptr);
+    p->SetStatus(Point::P_NOT_FOUND);
+    frame->AddOutlier((*it)->GetPosition());
+  }
+}
+
+// feature_align.cc:258-283
+int FeatureAlign::CheckReprojectionError(const vector<shared_ptr<Feature>> &features, const SE3 &se3, double threshold,
+                                         vector<shared_ptr<Feature>> *inliers, vector<shared_ptr<Feature>> *outliers) {
+  int valids = 0;
+  for (auto it = features.begin(); it != features.end(); it++) {
+    shared_ptr<Point> point = (*it)->GetPoint();
+    if (!point) continue;
+    const Vector3d pos = se3 * point->GetPosition();
+    const Vector2d a = Camera::SimpleProject((*it)->GetVector()), b = Camera::SimpleProject(pos);
+    double ex = a(0) - b(0), ey = a(1) - b(1);
+    const double sqrt_inv_cov = 1.0 / (1 << (*it)->GetLevel());
+    ex *= sqrt_inv_cov;
+    ey *= sqrt_inv_cov;
+    if (std::sqrt(ex * ex + ey * ey) <= threshold) {
+      valids++;
+      if (inliers != NULL) inliers->push_back(*it);
+    } else {
+      if (outliers != NULL) outliers->push_back(*it);
+    }
+  }
+  return valids;
+}
+
+// feature_align.cc:341-421
+bool FeatureAlign::ConvergePose(const shared_ptr<Frame> &frame, const vector<shared_ptr<Feature>> &features, SE3 *se3) {
+  SE3 last_se3 = frame->GetPose();
+  Camera *camera = frame->GetCamera();
+  *se3 = last_se3;
+  double chi2 = 0.0;
+  vector<double> errors;
+  for (auto it = features.begin(); it != features.end(); it++) {
+    shared_ptr<Point> point = (*it)->GetPoint();
+    if (!point) continue;
+    const Vector3d pos = (*se3) * point->GetPosition();
+    const Vector2d a = Camera::SimpleProject((*it)->GetVector()), b = Camera::SimpleProject(pos);
+    double ex = a(0) - b(0), ey = a(1) - b(1);
+    const double s = 1.0 / (1 << (*it)->GetLevel());
+    ex *= s;
+    ey *= s;
+    errors.push_back(std::sqrt(ex * ex + ey * ey));
+  }
+  if (errors.empty()) return false;
+  auto mid = errors.begin() + static_cast<long>(std::floor(errors.size() / 2));  // GetMedianVector, extra/utils.cc:215-220
+  std::nth_element(errors.begin(), mid, errors.end());
+  double scale = KMADNorm * (*mid);
+  for (int i = 0; i < Config::MaxOptimPoseIts(); i++) {
+    double A[36], b[6];
+    for (int r = 0; r < 6; r++) b[r] = 0.0;
+    for (int r = 0; r < 36; r++) A[r] = 0.0;
+    double new_chi2 = 0.0;
+    if (i == 5) scale = 0.85 / camera->GetFx();
+    for (auto it = features.begin(); it != features.end(); it++) {
+      shared_ptr<Point> point = (*it)->GetPoint();
+      if (!point) continue;
+      const Vector3d pos = (*se3) * point->GetPosition();
+      double J[12];
+      jacobian_3d_to_plane({pos(0), pos(1), pos(2)}, J);
+      const Vector2d pa = Camera::SimpleProject((*it)->GetVector()), pb = Camera::SimpleProject(pos);
+      double ex = pa(0) - pb(0), ey = pa(1) - pb(1);
+      const double sqrt_inv_cov = 1.0 / (1 << (*it)->GetLevel());
+      ex *= sqrt_inv_cov;
+      ey *= sqrt_inv_cov;
+      for (int c = 0; c < 12; c++) J[c] *= sqrt_inv_cov;
+      const double weight = GetTukeyValue(std::sqrt(ex * ex + ey * ey) / scale);
+      for (int r = 0; r < 6; r++) {
+        for (int c = 0; c < 6; c++) A[6 * r + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+        b[r] -= (J[r] * ex + J[6 + r] * ey) * weight;
+      }
+      new_chi2 += (ex * ex + ey * ey) * weight;
+    }
+    double dT[6];
+    ldlt_solve6(A, b, dT);
+    if ((i > 0 && new_chi2 > chi2) || std::isnan(dT[0])) {
+      *se3 = last_se3;
+      break;
+    }
+    Vector6d d;
+    for (int r = 0; r < 6; r++) d[r] = dT[r];
+    const SE3 T_new = SE3::Exp(d) * (*se3);
+    last_se3 = *se3;
+    *se3 = T_new;
+    chi2 = new_chi2;
+    if (abs_max6(dT) <= 1e-10) break;
+  }
+  return true;
+}
+
+// feature_align.cc:423-431
+double FeatureAlign::GetTukeyValue(double x) {
+  const double x_square = x * x;
+  if (x_square <= KTukeyC) {
+    const double tmp = 1.0 - x_square / KTukeyC;
+    return tmp * tmp;
+  }
+  return 0.0;
+}
+
+// ----------------------------------------------------------------------------------------------------------- SDVL
+SDVL::SDVL(Camera *camera, Map *map, const SE3 &first_pose)
+    : camera_(camera), map_(map), rng_(1), feature_align_(map, camera, Config::MaxMatches(), &rng_), first_pose_(first_pose) {
+  state_ = STATE_FIRST_FRAME;
+  tracking_quality_ = TRACKING_GOOD;
+  lost_frames_ = 0;
+  matches_ = attempts_ = 0;
+  frame_counter_ = 0;
+}
+
+SDVL::~SDVL() {}
+
+SE3 SDVL::GetPose() const {
+  if (last_frame_) return last_frame_->GetWorldPose();
+  return SE3();
+}
+
+// sdvl.cc:240-264
+void SDVL::CalcTrackingQuality(int matches, int attempts) {
+  const double ratio = (attempts == 0) ? 0.0 : static_cast<double>(matches) / static_cast<double>(attempts);
+  if (ratio > 0.2) {
+    tracking_quality_ = TRACKING_GOOD;
+    lost_frames_ = 0;
+    return;
+  }
+  if (matches < Config::MinMatches()) {
+    tracking_quality_ = TRACKING_BAD;
+    lost_frames_++;
+    return;
+  }
+  lost_frames_ = 0;
+  tracking_quality_ = TRACKING_INSUFFICIENT;
+}
+
+bool SDVL::HandleFrame(const Image &img) {
+  SDVLBatch one(Device::Current(), {this}, 1);
+  FrameStats st;
+  one.HandleFrames({img}, &st);
+  return true;
+}
+
+void SDVL::Mapping() {
+  if (pending_kf_) {
+    map_->InitCandidates(pending_kf_);
+    pending_kf_ = nullptr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ SDVLBatch
+namespace {
+// persistent worker pool for the per-sequence host stages
+class Pool {
+ public:
+  explicit Pool(int n) : stop_(false), gen_(0), pending_(0) {
+    for (int i = 0; i < n; i++) workers_.emplace_back([this] { Run(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  void For(int n, const std::function<void(int)> &fn) {
+    if (n <= 0) return;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      n_ = n;
+      next_.store(0);
+      pending_ = static_cast<int>(workers_.size());
+      gen_++;
+    }
+    cv_.notify_all();
+    Drain();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    if (err_) {
+      std::exception_ptr e = err_;
+      err_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+
+ private:
+  void Drain() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      try {
+        (*fn_)(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!err_) err_ = std::current_exception();
+      }
+    }
+  }
+  void Run() {
+    unsigned seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      Drain();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  bool stop_;
+  unsigned gen_;
+  int pending_;
+  const std::function<void(int)> *fn_ = nullptr;
+  int n_ = 0;
+  std::atomic<int> next_{0};
+  std::exception_ptr err_;
+};
+}  // namespace
+
+static Pool *g_pool_of(void *&slot, int threads) {
+  if (!slot && threads > 1) slot = new Pool(threads - 1);
+  return static_cast<Pool *>(slot);
+}
+
+SDVLBatch::SDVLBatch(Device *dev, const vector<SDVL *> &trackers, int host_threads) : dev_(dev), trk_(trackers), threads_(host_threads) {}
+SDVLBatch::~SDVLBatch() {}
+
+static thread_local void *g_pool_slot = nullptr;
+static thread_local int g_pool_threads = 0;
+
+void SDVLBatch::ParallelFor(int n, const std::function<void(int)> &fn) {
+  if (threads_ <= 1 || n <= 1) {
+    for (int i = 0; i < n; i++) fn(i);
+    return;
+  }
+  if (g_pool_slot && g_pool_threads != threads_) {
+    delete static_cast<Pool *>(g_pool_slot);
+    g_pool_slot = nullptr;
+  }
+  g_pool_threads = threads_;
+  g_pool_of(g_pool_slot, threads_)->For(n, fn);
+}
+
+// SDVL::HandleFrame (sdvl.cc:55-130) for B trackers, stage by stage
+void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
+  const int B = static_cast<int>(trk_.size());
+  if (static_cast<int>(imgs.size()) != B) throw std::runtime_error("SDVLBatch::HandleFrames: one image per tracker");
+  Device::SetCurrent(dev_);
+  const std::function<void(int, std::function<void(int)>)> pfor = [this](int n, std::function<void(int)> fn) { ParallelFor(n, fn); };
+
+  // ---- stage 0: Frame construction (pyramid + FAST + selection + ORB), sdvl.cc:59
+  vector<shared_ptr<Frame>> frames;
+  Frame::CreateBatch(trk_[0]->camera_, &trk_[0]->orb_detector_, imgs, true, Config::NumFeatures(), &frames, &pfor);
+  vector<int> run;  // trackers that execute ProcessFrame this step
+  for (int i = 0; i < B; i++) {
+    SDVL &t = *trk_[i];
+    FrameStats &st = stats[i];
+    st = FrameStats();
+    t.current_frame_ = frames[i];
+    t.current_frame_->SetID(t.frame_counter_++);
+    st.n_corners = static_cast<int>(frames[i]->GetCorners().size());
+    if (t.state_ != SDVL::STATE_RUNNING) {
+      // bootstrap replacement (SaveFirstFrame/SaveSecondFrame are out of scope): first frame = keyframe at first_pose
+      t.current_frame_->SetPose(t.first_pose_);
+      t.current_frame_->SetKeyframe();
+      t.map_->AddKeyframe(t.current_frame_);
+      t.pending_kf_ = t.current_frame_;
+      t.last_frame_ = t.current_frame_;
+      t.last_kf_ = t.current_frame_;
+      t.state_ = SDVL::STATE_RUNNING;
+      st.state = 0;
+      st.keyframe = 1;
+    } else {
+      st.state = 2;
+      bool relocalize = t.lost_frames_ >= 3;
+      if (relocalize) {
+        // sdvl.cc:73-89,205-238: sequential over keyframes with the single-object calls (rare path)
+        for (int k = 0; k < 6; k++) t.vel_[k] = 0.0;
+        vector<shared_ptr<Frame>> &kfs = t.map_->GetKeyframes();
+        for (auto it = kfs.rbegin(); it != kfs.rend(); it++) {
+          shared_ptr<Frame> cframe = *it;
+          t.current_frame_->SetPose(cframe->GetPose());
+          ImageAlign image_align;
+          image_align.ComputePose(cframe, t.current_frame_, true);
+          if (image_align.GetError() >= 0.001) continue;
+          t.feature_align_.Reproject(t.current_frame_, cframe, cframe, true);
+          t.matches_ = t.feature_align_.GetMatches();
+          t.attempts_ = t.feature_align_.GetAttempts();
+          if (t.matches_ >= Config::MinMatches()) {
+            t.last_kf_ = cframe;
+            t.last_frame_ = cframe;
+            relocalize = false;
+            st.relocalized = 1;
+            break;
+          }
+        }
+      }
+      if (!relocalize) {
+        t.current_frame_->SetPose(SE3::Exp(t.vel_) * t.last_frame_->GetPose());  // SetMotionModel, sdvl.cc:278-281
+        run.push_back(i);
+      }
+    }
+  }
+
+  // ---- stage 1: ImageAlign for every running tracker, sdvl.cc:185-190
+  const int R = static_cast<int>(run.size());
+  {
+    vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> pairs;
+    for (int i : run) pairs.push_back({trk_[i]->last_frame_, trk_[i]->current_frame_});
+    vector<int> n_meas;
+    vector<double> errors;
+    ImageAlign::ComputePoseBatch(pairs, false, &n_meas, &errors);
+    for (int k = 0; k < R; k++) stats[run[k]].align_meas = n_meas[k];
+  }
+
+  // ---- stage 2: FeatureAlign::Reproject, sdvl.cc:193 — all candidates of all trackers in one launch
+  {
+    vector<vector<sdvl_search_req>> per(R);
+    ParallelFor(R, [&](int k) {
+      SDVL &t = *trk_[run[k]];
+      t.feature_align_.PrepareReproject(t.current_frame_, t.last_frame_, false, &per[k]);
+    });
+    vector<sdvl_search_req> reqs;
+    vector<size_t> begin(R + 1, 0);
+    for (int k = 0; k < R; k++) {
+      begin[k] = reqs.size();
+      reqs.insert(reqs.end(), per[k].begin(), per[k].end());
+    }
+    begin[R] = reqs.size();
+    vector<sdvl_search_res> res;
+    if (R > 0) Matcher::SearchPoints(dev_, reqs, *trk_[run[0]]->camera_, &res);
+    // ---- stage 3: replay + RANSAC + pose refinement + bookkeeping, sdvl.cc:193-127
+    ParallelFor(R, [&](int k) {
+      const int i = run[k];
+      SDVL &t = *trk_[i];
+      FrameStats &st = stats[i];
+      t.feature_align_.FinishReproject(t.current_frame_, res.data() + begin[k]);
+      t.matches_ = t.feature_align_.GetMatches();
+      t.attempts_ = t.feature_align_.GetAttempts();
+      t.feature_align_.OptimizePose(t.current_frame_);
+      st.inliers = t.feature_align_.GetInliers();
+      st.outliers = t.feature_align_.GetOutliers();
+      {  // GetMotionModel, sdvl.cc:266-276
+        const SE3 mov = t.current_frame_->GetPose() * t.last_frame_->GetPose().Inverse();
+        const Vector6d vel = SE3::Log(mov);
+        for (int c = 0; c < 6; c++) t.vel_[c] = 0.9 * (0.5 * vel[c] + 0.5 * t.vel_[c]);
+      }
+      t.CalcTrackingQuality(t.matches_, t.attempts_);
+      if (t.tracking_quality_ != SDVL::TRACKING_BAD) {
+        if (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) {
+          vector<shared_ptr<Feature>> &features = t.current_frame_->GetFeatures();
+          for (auto it = features.begin(); it != features.end(); it++)
+            if ((*it)->GetPoint()) (*it)->GetPoint()->AddFeature(*it);
+          t.current_frame_->SetKeyframe();
+          t.map_->AddKeyframe(t.current_frame_);
+          t.last_kf_ = t.current_frame_;
+          t.pending_kf_ = t.current_frame_;
+          st.keyframe = 1;
+        } else {
+          t.map_->AddFrame(t.current_frame_);
+        }
+        t.last_frame_ = t.current_frame_;
+      }
+    });
+  }
+
+  // ---- stage 4: mapper stand-in for fresh keyframes (sequential mode, main.cc:148-149): one K3 launch for all
+  {
+    vector<shared_ptr<Frame>> kfs;
+    vector<int> owner;
+    for (int i = 0; i < B; i++)
+      if (trk_[i]->pending_kf_) { kfs.push_back(trk_[i]->pending_kf_); owner.push_back(i); }
+    if (!kfs.empty()) {
+      Frame::FilterCornersBatch(kfs);
+      ParallelFor(static_cast<int>(kfs.size()), [&](int k) {
+        SDVL &t = *trk_[owner[k]];
+        PlaneMap *pm = dynamic_cast<PlaneMap *>(t.map_);
+        if (pm) pm->SeedFromFiltered(kfs[k]);  // other Map implementations run their own mapper on AddKeyframe
+        t.pending_kf_ = nullptr;
+      });
+    }
+  }
+
+  for (int i = 0; i < B; i++) {
+    SDVL &t = *trk_[i];
+    FrameStats &st = stats[i];
+    st.quality = static_cast<int>(t.tracking_quality_);
+    st.matches = t.matches_;
+    st.attempts = t.attempts_;
+    t.current_frame_->GetPose().ToArray(st.pose);
+    t.stats_ = st;
+    t.current_frame_ = nullptr;
+    t.map_->EmptyTrash();  // sdvl.cc:127
+  }
+}
+
+}  // namespace sdvl

@@ -1,0 +1,437 @@
+// sdvl_host.h — host side of the MI355X-native SDVL front-end: the reference's C++ API surface
+// (Camera, Feature, Point, Frame, FastDetector, ORBDetector, ImageAlign, Matcher, FeatureAlign, SDVL) with the same
+// names, argument meaning and return conventions, implemented on top of the C-ABI in include/sdvl_hip.h.
+//
+// MI355X-first differences (none visible to a caller that uses the reference signatures):
+//   * a Frame's pyramid / corners / descriptors live in HBM; GetPyramid() / GetDescriptors() mirror to the host
+//     lazily (the mapper and the UI read them);
+//   * every stage has a batched form (Frame::CreateBatch, ImageAlign::ComputePoseBatch, Matcher::SearchPoints,
+//     FeatureAlign::PrepareReproject/FinishReproject, SDVLBatch::HandleFrames) so that B independent sequences
+//     advance one frame with ONE launch per kernel; the single-object calls are the B = 1 case;
+//   * FeatureAlign evaluates Matcher::SearchPoint for ALL grid candidates in one launch and then replays the
+//     reference's sequential cell-order / first-hit / max_matches logic over the results (SearchPoint is a pure
+//     function of its arguments, so the outcome is identical to the one-call-at-a-time loop).
+// Error convention: the reference returns bool/int and prints to cerr; so does this layer.  A failing device call
+// is fatal (std::runtime_error carrying sdvl_last_error) — there is no CPU fallback.
+#ifndef SDVL_HOST_H_
+#define SDVL_HOST_H_
+
+#include <functional>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sdvl_hip.h"
+#include "config.h"
+#include "se3.h"
+#include "types.h"
+
+namespace sdvl {
+
+class Frame;
+class Feature;
+class Point;
+class Map;
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device: one sdvl_ctx (= one HIP stream) + a pool of HBM frames.  One per host thread (tracker / mapper).
+class Device {
+ public:
+  explicit Device(int gpu = 0);
+  ~Device();
+  sdvl_ctx *ctx() const { return ctx_; }
+  sdvl_frame *AcquireFrame(int w, int h, int levels);
+  void ReleaseFrame(sdvl_frame *f, int w, int h, int levels);
+  void Check(int rc, const char *what) const;
+  static Device *Current();
+  static void SetCurrent(Device *d);
+
+ private:
+  sdvl_ctx *ctx_ = nullptr;
+  struct Pooled { sdvl_frame *f; int w, h, levels; };
+  std::vector<Pooled> pool_;
+  std::mutex pool_mutex_;
+};
+
+// glibc rand() (TYPE_3, seed 1) as a private stream: the reference draws from the process-global rand()
+// (feature_align.cc:53,103,180); B trackers in one process each own the stream a lone reference process would see.
+class RandStream {
+ public:
+  explicit RandStream(unsigned seed = 1);
+  int Next();
+  template <typename T>
+  void Shuffle(std::vector<T> *v) {  // libstdc++ std::random_shuffle(first, last)
+    for (size_t i = 1; i < v->size(); ++i) {
+      const size_t j = static_cast<size_t>(Next()) % (i + 1);
+      if (i != j) std::swap((*v)[i], (*v)[j]);
+    }
+  }
+
+ private:
+  int r_[31];
+  int fi_, ri_;
+};
+
+// camera.h:34-135 (pinhole part; UndistortImage is out of scope — SURVEY §8f #2)
+class Camera {
+ public:
+  Camera();  // from Config::GetCameraParameters(), camera.cc:28-38
+  Camera(int width, int height, double fx, double fy, double u0, double v0);
+  double GetWidth() const { return width_; }
+  double GetHeight() const { return height_; }
+  double GetFx() const { return fx_; }
+  double GetFy() const { return fy_; }
+  double GetU0() const { return u0_; }
+  double GetV0() const { return v0_; }
+  void Project(const Vector3d &p3D, Vector2d *p2D) const;
+  void Unproject(const Vector2d &p2D, Vector3d *p3D) const;
+  Vector2d Project(const Vector3d &p3D) const { Vector2d r; Project(p3D, &r); return r; }
+  Vector3d Unproject(const Vector2d &p2D) const { Vector3d r; Unproject(p2D, &r); return r; }
+  bool IsInsideImage(const Vector2i &p, int m = 0) const { return p(0) >= m && p(0) < width_ - m && p(1) >= m && p(1) < height_ - m; }
+  bool IsInsideImage(const Vector2i &p, int m, int l) const {
+    return p(0) >= m && p(0) < width_ / (1 << l) - m && p(1) >= m && p(1) < height_ / (1 << l) - m;
+  }
+  static Vector2d SimpleProject(const Vector3d &p) { return Vector2d(p(0) / p(2), p(1) / p(2)); }
+  sdvl_camera abi() const { return sdvl_camera{width_, height_, fx_, fy_, u0_, v0_}; }
+
+ private:
+  double width_, height_, fx_, fy_, u0_, v0_;
+};
+
+// extra/orb_detector.h:34-56.  Descriptors come from the K4 kernel; Distance is the reference's popcount.
+class ORBDetector {
+ public:
+  ORBDetector() {}
+  // src must be a pyramid level of a Frame (it carries the HBM binding)
+  bool GetDescriptor(const Image &src, const Vector2i &pos, std::vector<uchar> *desc);
+  int Distance(const std::vector<uchar> &a, const std::vector<uchar> &b);
+};
+
+// extra/fast_detector.h:34-64
+class FastDetector {
+ public:
+  FastDetector(int width, int height, bool grid = true);
+  void DetectPyramid(const std::vector<Image> &pyramid, std::vector<Vector3i> *corners, int nfeatures);
+  void FilterCorners(const std::vector<Image> &pyramid, const std::vector<Vector3i> &corners, std::vector<int> *indices);
+  void LockCell(Vector2d p);
+  void UnlockCell(Vector2d p);
+  // host half of SelectPixels (quota + retainBest, fast_detector.cc:108-151) over the device's per-cell lists
+  static void SelectFromCells(const sdvl_keypoint *kps, const int32_t *cell_offsets, int level_cell_begin, int wcells, int hcells,
+                              int level, int level_w, int level_h, int nfeatures, std::vector<Vector3i> *pixels);
+  // host half of FilterCorners given the K3 scores
+  void FilterWithScores(const std::vector<Image> &pyramid, const std::vector<Vector3i> &corners, const double *scores,
+                        std::vector<int> *indices);
+
+ private:
+  std::vector<std::pair<int, int>> cgrid_;
+  std::vector<bool> grid_mask_;
+  int grid_width_, grid_height_, cell_size_;
+};
+
+// feature.h:38-105
+class Feature {
+ public:
+  Feature(const std::shared_ptr<Frame> &f, const Vector2d &p, int l);
+  Feature(const std::shared_ptr<Frame> &f, const std::shared_ptr<Point> &ft, const Vector2d &p, int l);
+  Feature(const std::shared_ptr<Frame> &f, const std::shared_ptr<Point> &ft, const Vector2d &p, const Vector3d &v, int l);
+  std::shared_ptr<Frame> GetFrame() { return frame_.lock(); }
+  void SetFrame(const std::shared_ptr<Frame> &f) { frame_ = f; }
+  std::shared_ptr<Point> GetPoint() const { return point_; }
+  void SetPoint(const std::shared_ptr<Point> &p) { point_ = p; }
+  const Vector2d &GetPosition() const { return p2d_; }
+  const Vector3d &GetVector() const { return v_; }
+  void SetVector(Vector3d &v) { v_ = v; }
+  int GetLevel() const { return level_; }
+  const std::vector<uchar> &GetDescriptor() const { return descriptor_; }
+  void SetDescriptor(const std::vector<uchar> &d) { descriptor_ = d; descriptor_.resize(32); has_descriptor_ = true; }
+  bool HasDescriptor() const { return has_descriptor_; }
+  Vector2d GetLevelPosition() { return Vector2d(p2d_(0) / (1 << level_), p2d_(1) / (1 << level_)); }
+
+ private:
+  std::weak_ptr<Frame> frame_;  // the reference holds a shared_ptr (a frame<->feature cycle it never breaks)
+  std::shared_ptr<Point> point_;
+  Vector2d p2d_;
+  Vector3d v_;
+  int level_;
+  std::vector<uchar> descriptor_;
+  bool has_descriptor_;
+};
+
+// point.h:37-147 — the part the front-end reads or updates (the depth filter itself is map state, out of scope)
+class Point {
+ public:
+  enum PointStatus { P_FOUND, P_NOT_FOUND, P_SEEN, P_UNSEEN, P_OUTLIER };
+  Point();
+  double GetInverseDepth() { return rho_; }
+  double GetStd();
+  std::shared_ptr<Feature> GetInitFeature() { return feature_; }
+  void SetInitFeature(const std::shared_ptr<Feature> &f) { feature_ = f; }
+  int GetID() const { return id_; }
+  Vector3d GetPosition() const;
+  void InitFixed(const std::shared_ptr<Feature> &f, double depth, double sigma2, const Vector3d &p3d);
+  void InitCandidate(const std::shared_ptr<Feature> &f, double depth);
+  std::list<std::shared_ptr<Feature>> &GetFeatures() { return features_; }
+  int Score() const { return n_successful_; }
+  int GetLastFrame() const { return last_frame_; }
+  void SetLastFrame(int id) { last_frame_ = id; }
+  PointStatus GetStatus() const { return status_; }
+  void SetStatus(PointStatus s) { status_ = s; }
+  bool ToDelete() const { return delete_; }
+  void SetDelete() { delete_ = true; }
+  void SetFixed() { fixed_ = true; }
+  bool IsFixed() { return fixed_; }
+  void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_front(f); }
+  bool Promote();
+  bool Unpromote();
+
+ private:
+  int id_;
+  PointStatus status_;
+  bool delete_;
+  std::list<std::shared_ptr<Feature>> features_;
+  int last_frame_, n_successful_, n_failed_;
+  double a_, b_, rho_, sigma2_, z_range_;
+  std::shared_ptr<Feature> feature_;
+  bool fixed_;
+  Vector3d p3d_;
+};
+
+// frame.h:41-173
+class Frame : public std::enable_shared_from_this<Frame> {
+ public:
+  Frame(Camera *camera, ORBDetector *detector, const Image &img, bool corners);
+  ~Frame();
+  // B frames with one launch per kernel (pyramid, FAST, ORB); corners as in the ctor
+  static void CreateBatch(Camera *camera, ORBDetector *detector, const std::vector<Image> &imgs, bool corners, int nfeatures,
+                          std::vector<std::shared_ptr<Frame>> *out, const std::function<void(int, std::function<void(int)>)> *pfor = nullptr);
+
+  bool IsKeyframe() { return is_keyframe_; }
+  void SetKeyframe() { is_keyframe_ = true; }
+  void FilterCorners();
+  static void FilterCornersBatch(const std::vector<std::shared_ptr<Frame>> &frames);
+  SE3 &GetPose() { return pose_; }
+  const SE3 &GetPose() const { return pose_; }
+  void SetPose(const SE3 &se3) { pose_ = se3; }
+  std::vector<Image> &GetPyramid();  // host mirror is filled on first call
+  std::vector<std::shared_ptr<Feature>> &GetFeatures() { return features_; }
+  std::vector<Vector3i> &GetCorners() { return corners_; }
+  std::vector<int> &GetFilteredCorners() { return filtered_corners_; }
+  std::vector<Vector2d> &GetOutliers() { return outliers_; }
+  std::vector<std::vector<uchar>> &GetDescriptors();  // host mirror of the HBM descriptors
+  Camera *GetCamera() const { return camera_; }
+  int GetWidth() const { return width_; }
+  int GetHeight() const { return height_; }
+  int GetID() const { return id_; }
+  void SetID(int id) { id_ = id; }
+  SE3 GetWorldPose() const { return pose_.Inverse(); }
+  Vector3d GetWorldPosition() const { return pose_.Inverse().GetTranslation(); }
+  Vector3d GetRelativePos(const Vector3d &pos) const { return pose_ * pos; }
+  void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_back(f); }
+  void AddOutlier(const Vector2d &p) { outliers_.push_back(p); }
+  int GetNumFeatures() const { return static_cast<int>(features_.size()); }
+  int GetNumPoints() const;
+  bool Project(const Vector3d &p3D, Vector2d *p2D);
+  void CreateCorners(int levels, int nfeatures);
+  void RemoveFeatures() { features_.clear(); }
+  sdvl_frame *device() const { return dev_; }
+  Device *owner() const { return owner_; }
+
+ private:
+  Frame() {}
+  void InitCommon(Camera *camera, ORBDetector *detector, int w, int h);
+  int id_ = 0;
+  Camera *camera_ = nullptr;
+  ORBDetector *orb_detector_ = nullptr;
+  int pyramid_levels_ = 0;
+  bool is_keyframe_ = false;
+  std::vector<Image> pyramid_;
+  bool pyramid_on_host_ = false;
+  int width_ = 0, height_ = 0;
+  SE3 pose_;
+  std::vector<std::shared_ptr<Feature>> features_;
+  std::vector<Vector3i> corners_;
+  std::vector<int> filtered_corners_;
+  std::vector<Vector2d> outliers_;
+  std::vector<std::vector<uchar>> descriptors_;
+  bool descriptors_on_host_ = false;
+  sdvl_frame *dev_ = nullptr;
+  Device *owner_ = nullptr;
+  static int counter_;
+};
+
+// image_align.h:33-66
+class ImageAlign {
+ public:
+  ImageAlign() {}
+  int ComputePose(const std::shared_ptr<Frame> &frame1, const std::shared_ptr<Frame> &frame2, bool fast = false);
+  double GetError() { return error_; }
+  // n frame pairs, one launch; returns per-pair ComputePose results and errors
+  static void ComputePoseBatch(const std::vector<std::pair<std::shared_ptr<Frame>, std::shared_ptr<Frame>>> &pairs, bool fast,
+                               std::vector<int> *n_meas, std::vector<double> *errors);
+
+ private:
+  double error_ = 1e10;
+};
+
+// matcher.h:39-83
+class Matcher {
+ public:
+  explicit Matcher(int size) : patch_size_(size) {}
+  bool SearchPoint(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Feature> &feature, double idepth, double idepth_std,
+                   bool fixed, Vector2d *px, int *flevel);
+  // batched form: fills one sdvl_search_req per call site, evaluated together by SearchPoints
+  static bool MakeRequest(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Feature> &feature, double idepth,
+                          double idepth_std, bool fixed, const Vector2d &px, sdvl_search_req *req);
+  static void SearchPoints(Device *dev, const std::vector<sdvl_search_req> &reqs, const Camera &cam, std::vector<sdvl_search_res> *res);
+
+ private:
+  int patch_size_;
+};
+
+// The out-of-scope back-end (map.cc) as the tracker sees it: deletion queue + keyframe decision + keyframe list.
+class Map {
+ public:
+  virtual ~Map() {}
+  void DeletePoint(const std::shared_ptr<Point> &p) { points_trash_.push_back(p); }
+  bool NeedKeyframe(const std::shared_ptr<Frame> &frame, int matches);  // map.cc:170-188
+  void AddKeyframe(const std::shared_ptr<Frame> &frame);
+  void AddFrame(const std::shared_ptr<Frame> &) {}
+  void EmptyTrash();  // map.cc:207-259 (points part)
+  std::vector<std::shared_ptr<Frame>> &GetKeyframes() { return keyframes_; }
+  // mapper work for a fresh keyframe (Map::InitCandidates stand-in); called outside the tracking stages
+  virtual void InitCandidates(const std::shared_ptr<Frame> &) {}
+
+ protected:
+  std::vector<std::shared_ptr<Frame>> keyframes_;
+  std::vector<std::shared_ptr<Point>> points_trash_;
+  std::shared_ptr<Frame> last_kf_;
+  int last_matches_ = 0;
+};
+
+// Map stand-in for synthetic scenes: seeds one FIXED point per FilterCorners() corner of a keyframe, depth from a
+// known scene plane n.X = d (replaces homography_init + depth filter, both out of scope).
+class PlaneMap : public Map {
+ public:
+  PlaneMap(const Vector3d &n, double d) : n_(n), d_(d) {}
+  void InitCandidates(const std::shared_ptr<Frame> &kf) override;
+  void SeedFromFiltered(const std::shared_ptr<Frame> &kf);  // after Frame::FilterCorners()
+
+ private:
+  Vector3d n_;
+  double d_;
+};
+
+typedef std::pair<std::shared_ptr<Point>, Vector2d> PointInfo;
+typedef std::list<PointInfo> GridCell;
+
+// feature_align.h:42-116
+class FeatureAlign {
+ public:
+  FeatureAlign(Map *map, Camera *camera, int max_matches, RandStream *rng);
+  ~FeatureAlign();
+  void Reproject(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, const std::shared_ptr<Frame> &last_kf,
+                 bool reloc = false);
+  bool OptimizePose(const std::shared_ptr<Frame> &frame);
+  int GetMatches() { return matches_; }
+  int GetAttempts() { return num_attempts_; }
+  int GetInliers() const { return static_cast<int>(inliers_.size()); }
+  int GetOutliers() const { return static_cast<int>(outliers_.size()); }
+  // batched form of Reproject: project + shuffle + emit every candidate request; then replay over the results
+  void PrepareReproject(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, bool reloc,
+                        std::vector<sdvl_search_req> *reqs);
+  void FinishReproject(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res);
+
+ private:
+  struct Candidate { std::shared_ptr<Point> point; Vector2d pos; int req; };  // req < 0: SearchPoint not evaluated
+  void SelectInliers(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> &fs_found,
+                     std::vector<std::shared_ptr<Feature>> *inliers, std::vector<std::shared_ptr<Feature>> *outliers);
+  void OptimizePose(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> *features,
+                    std::vector<std::shared_ptr<Feature>> *outliers);
+  bool RescueOutliers(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> *inliers,
+                      std::vector<std::shared_ptr<Feature>> *outliers);
+  void RemoveOutliers(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> *outliers);
+  int CheckReprojectionError(const std::vector<std::shared_ptr<Feature>> &features, const SE3 &se3, double threshold,
+                             std::vector<std::shared_ptr<Feature>> *inliers = NULL, std::vector<std::shared_ptr<Feature>> *outliers = NULL);
+  void ResetGrid();
+  void ProjectPoints(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame);
+  bool ProjectPoint(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Point> &point);
+  bool ConvergePose(const std::shared_ptr<Frame> &frame, const std::vector<std::shared_ptr<Feature>> &features, SE3 *se3);
+  double GetTukeyValue(double x);
+
+  Map *map_;
+  Camera *camera_;
+  RandStream *rng_;
+  int cell_size_, max_matches_, grid_width_, grid_height_;
+  std::vector<GridCell *> grid_;
+  std::vector<int> cell_order_;
+  std::vector<std::vector<Candidate>> plan_;  // per visited cell (in cell_order_), candidates in Score order
+  int matches_, num_attempts_;
+  bool relocalizing_;
+  std::vector<std::shared_ptr<Feature>> inliers_, outliers_;
+  static constexpr double KMADNorm = 1.4826;
+  static constexpr double KTukeyC = 4.6851 * 4.6851;
+};
+
+struct FrameStats {
+  int state = 0, quality = 0, matches = 0, attempts = 0, inliers = 0, outliers = 0, n_corners = 0, align_meas = 0, keyframe = 0,
+      relocalized = 0;
+  double pose[7] = {1, 0, 0, 0, 0, 0, 0};
+};
+
+class SDVLBatch;
+
+// sdvl.h:36-108.  The two-frame homography bootstrap is out of scope: the first frame becomes a keyframe at
+// `first_pose` and the Map seeds its points (PlaneMap for synthetic scenes).
+class SDVL {
+ public:
+  enum State { STATE_FIRST_FRAME, STATE_SECOND_FRAME, STATE_RUNNING };
+  enum TrackingQuality { TRACKING_GOOD, TRACKING_INSUFFICIENT, TRACKING_BAD };
+  SDVL(Camera *camera, Map *map, const SE3 &first_pose = SE3());
+  ~SDVL();
+  bool HandleFrame(const Image &img);
+  SE3 GetPose() const;
+  TrackingQuality GetTrackingQuality() const { return tracking_quality_; }
+  bool HasMap() { return state_ == STATE_RUNNING; }
+  const FrameStats &LastStats() const { return stats_; }
+  void Mapping();  // sequential-mode mapper step (main.cc:148-149): seeds points on a fresh keyframe
+
+ private:
+  friend class SDVLBatch;
+  void CalcTrackingQuality(int matches, int attempts);
+  Camera *camera_;
+  Map *map_;
+  ORBDetector orb_detector_;
+  RandStream rng_;
+  State state_;
+  std::shared_ptr<Frame> current_frame_, last_frame_, last_kf_, pending_kf_;
+  TrackingQuality tracking_quality_;
+  Vector6d vel_;
+  FeatureAlign feature_align_;
+  int lost_frames_, matches_, attempts_;
+  int frame_counter_;
+  SE3 first_pose_;
+  FrameStats stats_;
+  bool relocalize_pending_ = false;
+};
+
+// B independent trackers stepping together, one launch per kernel per stage (MI355X-first driver)
+class SDVLBatch {
+ public:
+  SDVLBatch(Device *dev, const std::vector<SDVL *> &trackers, int host_threads);
+  ~SDVLBatch();
+  // imgs[i] feeds tracker i; stats[i] receives its FrameStats
+  void HandleFrames(const std::vector<Image> &imgs, FrameStats *stats);
+
+ private:
+  void ParallelFor(int n, const std::function<void(int)> &fn);
+  Device *dev_;
+  std::vector<SDVL *> trk_;
+  int threads_;
+};
+
+}  // namespace sdvl
+
+#endif  // SDVL_HOST_H_

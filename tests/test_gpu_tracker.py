@@ -1,0 +1,57 @@
+"""Closed-loop parity (BASELINE.json config 3: "full HIP front-end ... pose-delta tolerance check"): B synthetic
+sequences tracked on the MI355X through the host layer (sdvl::SDVLBatch) against the CPU oracle tracker run on
+the same frames.  Decisions (matches, attempts, inliers, keyframes) must be identical, poses within 1e-4."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oraclelib import TUM_CAM, XI, trajectory_pose
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def trk():
+    importlib.import_module("slam-sdvl_amd")
+    return importlib.import_module("slam-sdvl_amd.tracker")
+
+
+def run_case(trk, orc, synth, B, n_frames, threads, w=640, h=480, cam=TUM_CAM):
+    trk.configure()
+    dev = trk.HostDevice(0)
+    xis = [XI * (1.0 + 0.15 * i) * (1 if i % 2 == 0 else -1) for i in range(B)]
+    seeds = [20260001 + i for i in range(B)]
+    batch = trk.TrackerBatch(dev, B, w, h, cam, host_threads=threads)
+    oracles = [orc.tracker(w, h, cam) for _ in range(B)]
+    worst = 0.0
+    for k in range(n_frames):
+        imgs = [synth.render(trajectory_pose(orc, k, xis[i]), cam, w, h, seed=seeds[i], frame_id=k) for i in range(B)]
+        got = batch.step_host(imgs)
+        for i in range(B):
+            want = oracles[i].handle_frame(imgs[i])
+            g = got[i]
+            assert (g.state, g.quality, g.keyframe, g.n_corners) == (want.state, want.quality, want.keyframe, want.n_corners), (k, i)
+            assert (g.matches, g.attempts, g.inliers, g.outliers) == (want.matches, want.attempts, want.inliers, want.outliers), (k, i)
+            assert g.align_meas == want.align_meas, (k, i)
+            d = np.abs(np.array(g.pose[:]) - np.array(want.pose[:])).max()
+            worst = max(worst, d)
+            assert d <= POSE_TOL, (k, i, d)
+            if k > 0:
+                assert g.quality == 0 and g.matches >= 100       # the sequence is actually being tracked
+    batch.close()
+    for o in oracles:
+        o.close()
+    dev.close()
+    return worst
+
+
+def test_single_sequence_closed_loop(trk, orc, synth):
+    worst = run_case(trk, orc, synth, B=1, n_frames=14, threads=1)
+    assert worst <= POSE_TOL
+
+
+def test_batch_of_sequences_closed_loop_threaded(trk, orc, synth):
+    worst = run_case(trk, orc, synth, B=5, n_frames=9, threads=4)
+    assert worst <= POSE_TOL
