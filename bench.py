@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py — tracked frames/sec of the MI355X-native SDVL front-end (BASELINE.json metric).
+
+A "step" = one pass of the hot path (SDVL::HandleFrame in STATE_RUNNING: pyramid, FAST/ORB, sparse image alignment,
+grid reprojection with SearchPoint/AlignPatch, RANSAC + pose refinement) over one batch of B independent synthetic
+640x480 sequences per GPU (workload S-A of SURVEY §8d, TUM intrinsics / TUM cfg parameters, 5-level pyramid,
+max 200 matches).  All input frames are rendered into HBM before the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Sequences shard across ranks with no data-path collective ("weak" scaling: B sequences per GPU); RCCL is used only
+for the barrier and the throughput reduction.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events
+on the kernel's own stream over the timed region) and `cpu_baseline` (the CPU oracle on one host core, bounded sample).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+W_IMG, H_IMG = 640, 480
+TUM_CAM = np.array([517.3, 516.5, 318.6, 255.3])
+XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])
+
+
+def quat_to_R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def se3_exp(u):
+    """SE3::Exp (extra/se3.cc:72-94) in numpy, used only to lay out the synthetic trajectories."""
+    ups, om = u[:3], u[3:]
+    th = np.linalg.norm(om)
+    Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+    if th < 1e-10:
+        q = np.array([1.0, *(0.5 * om)])
+        V = np.eye(3)
+    else:
+        q = np.array([np.cos(th / 2), *(np.sin(th / 2) / th * om)])
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
+    return np.concatenate([q, V @ ups])
+
+
+def make_view(pkg, T, seed, frame_id):
+    v = pkg.SynthView()
+    v.fx, v.fy, v.u0, v.v0 = [float(c) for c in TUM_CAM]
+    R = quat_to_R(T[:4])
+    for i in range(9):
+        v.R[i] = float(R.flat[i])
+    for i in range(3):
+        v.t[i] = float(T[4 + i])
+    v.plane[0], v.plane[1], v.plane[2], v.plane[3] = 0.0, 0.0, 1.0, 2.0
+    v.seed, v.frame_id = seed, frame_id
+    return v
+
+
+def seq_twist(gidx):
+    """per-sequence camera twist per frame: the S-A twist scaled / mirrored so that sequences differ"""
+    s = 1.0 + 0.05 * (gidx % 7)
+    sign = 1.0 if (gidx // 7) % 2 == 0 else -1.0
+    return XI * s * np.array([sign, 1, 1, 1, sign, 1])
+
+
+class CtxView:
+    """minimal view of the sdvl_ctx owned by the host layer's Device (timing + synthetic rendering)"""
+
+    def __init__(self, pkg, handle):
+        self.lib = pkg.load_library()
+        self.h = C.c_void_p(handle)
+        self.pkg = pkg
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.sdvl_last_error(self.h).decode())
+
+    def malloc(self, n):
+        p = C.c_void_p()
+        self.check(self.lib.sdvl_device_malloc(self.h, C.c_int64(n), C.byref(p)))
+        return p.value
+
+    def render(self, views, dev_out):
+        arr = (self.pkg.SynthView * len(views))(*views)
+        self.check(self.lib.sdvl_synth_render(self.h, len(views), arr, W_IMG, H_IMG, C.c_void_p(dev_out), C.c_int64(W_IMG * H_IMG)))
+
+    def download(self, p, n):
+        out = np.zeros(n, np.uint8)
+        self.check(self.lib.sdvl_device_download(self.h, C.c_void_p(p), C.c_int64(n), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def timing(self, on):
+        self.check(self.lib.sdvl_ctx_timing_enable(self.h, int(on)))
+        self.check(self.lib.sdvl_ctx_timing_reset(self.h))
+
+    def timing_get(self):
+        names = ((C.c_char * 32) * 32)()
+        ms = (C.c_double * 32)()
+        launches = (C.c_int64 * 32)()
+        n = C.c_int()
+        self.check(self.lib.sdvl_ctx_timing_get(self.h, 32, names, ms, launches, C.byref(n)))
+        return {names[i].value.decode(): (ms[i], launches[i]) for i in range(n.value)}
+
+
+def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa):
+    """SURVEY §8(d) per-frame algorithmic bytes, split by kernel (640x480, 5 levels, 3 FAST levels)."""
+    P = [(W_IMG >> l) * (H_IMG >> l) for l in range(5)]
+    return {
+        "pyr_down": sum(P[:4]) + sum(P[1:]),                         # pyramid read + write (4 launches per frame batch)
+        "fast_cells": sum(P[:3]) + 16 * n_c,                         # FAST read + keypoint write
+        "orb_describe": n_c * (961 + 32),                            # 31x31 window + descriptor
+        "image_align": 3 * n_f * 49 + i_ia * n_f * 25,               # reference windows + current windows per GN iteration
+        "search_points": 12 * n_c + n_s * (121 + 164 + i_fa * 81),   # corner list + warp window + patches + LK windows
+    }.get(kernel)
+
+
+def cpu_baseline(frames):
+    """the CPU oracle (oracle/, kind "port") on ONE host core over a bounded sample of sequence 0"""
+    import oraclelib as ol
+    orc = ol.Oracle()
+    trk = orc.tracker(W_IMG, H_IMG, TUM_CAM)
+    tracked, t_total = 0, 0.0
+    for k, im in enumerate(frames):
+        t0 = time.perf_counter()
+        st = trk.handle_frame(im)
+        dt = time.perf_counter() - t0
+        if k > 0:                       # frame 0 is the bootstrap keyframe (STATE_FIRST_FRAME), not a tracked frame
+            t_total += dt
+            tracked += int(st.quality != 2)
+    trk.close()
+    return tracked / t_total, tracked, t_total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "512")), help="independent sequences per GPU")
+    ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
+    ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")
+    ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, "WORLD_SIZE must equal --gpus (launch with torch.distributed.run)"
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("slam-sdvl_amd")
+    trk = importlib.import_module("slam-sdvl_amd.tracker")
+    trk.configure()
+    ncpu = os.cpu_count() or 8
+    B, K, Wm = args.seqs, args.steps, args.warmup
+    G = args.groups or max(1, min(B // 8 if B >= 8 else 1, max(1, (ncpu // max(1, world)) // 2), 32))
+    while B % G:
+        G -= 1
+    Bg = B // G
+    threads = args.threads or 1
+    farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
+    ctxs = [CtxView(pkg, farm.ctx_handle(g)) for g in range(G)]
+    ctx = ctxs[0]
+
+    n_frames = 1 + Wm + K                     # bootstrap keyframe + warmup + timed
+    frame_bytes = W_IMG * H_IMG
+    buf = ctx.malloc(B * n_frames * frame_bytes)
+    for k in range(n_frames):                 # frame-major layout: step k reads B consecutive frames
+        views = [make_view(pkg, se3_exp(seq_twist(rank * B + i) * k), 20260001 + rank * B + i, k) for i in range(B)]
+        ctx.render(views, buf + k * B * frame_bytes)
+    ptrs = (buf + (np.arange(n_frames, dtype=np.uint64)[:, None] * B + np.arange(B, dtype=np.uint64)[None, :]) * frame_bytes).astype(np.uint64)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    farm.run(ptrs[:1 + Wm])                   # bootstrap + warmup (untimed)
+    farm.stage_times(reset=True)
+    for c in ctxs:
+        c.timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    stats = farm.run(ptrs[1 + Wm:])           # the K timed steps: every group free-runs through its K steps
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timers = {}
+    for c in ctxs:
+        for name, (ms, n) in c.timing_get().items():
+            a = timers.get(name, (0.0, 0))
+            timers[name] = (a[0] + ms, a[1] + n)
+        c.timing(False)
+    stage_s, stage_n = farm.stage_times()
+    tracked = 0
+    n_c = n_s = n_f = n_ia = n_lk = 0
+    for st in stats:
+        tracked += int(st.quality != 2)
+        n_c += st.n_corners
+        n_s += st.search_requests
+        n_f += st.align_features
+        n_ia += st.align_iters
+        n_lk += st.lk_iters
+
+    tot = torch.tensor([float(tracked), elapsed], dtype=torch.float64, device="cuda")
+    if distributed:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed_max, tracked_all = float(mx[1]), float(tot[0])
+    else:
+        elapsed_max, tracked_all = elapsed, float(tracked)
+
+    if rank == 0:
+        frames_rank = B * K
+        dom = max(timers.items(), key=lambda kv: kv[1][0]) if timers else None
+        roofline = None
+        if dom:
+            name, (ms, launches) = dom
+            avg_s = ms / max(1, launches) * 1e-3
+            # measured per-frame averages (corners, features, requests, GN evaluations, LK iterations) feed the §8(d) formula
+            per_frame = algorithmic_bytes_per_frame(name, n_c / frames_rank, n_f / frames_rank, n_s / frames_rank,
+                                                    n_ia / frames_rank, n_lk / max(1, n_s))
+            launches_per_step = launches / K          # all groups together
+            if per_frame is not None:
+                bytes_per_launch = per_frame * B / launches_per_step
+                achieved = bytes_per_launch / avg_s / 1e9
+                roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                            "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+        cpu = None
+        if args.cpu_frames > 0:
+            n_cpu = args.cpu_frames
+            cbuf = ctx.malloc(n_cpu * frame_bytes)
+            views = [make_view(pkg, se3_exp(seq_twist(0) * k), 20260001, k) for k in range(n_cpu)]
+            ctx.render(views, cbuf)
+            host = ctx.download(cbuf, n_cpu * frame_bytes).reshape(n_cpu, H_IMG, W_IMG)
+            fps, n_tracked, secs = cpu_baseline([host[k] for k in range(n_cpu)])
+            cpu = {"value": round(fps, 2), "unit": "tracked frames/s", "cores": 1, "kind": "port",
+                   "sample": "sequence 0 of the same workload, %d tracked frames, %.1f s on one host core (%d cores present)" % (n_tracked, secs, ncpu)}
+        value = tracked_all / elapsed_max
+        out = {
+            "metric": "tracked frames/sec (640x480, 5-lvl pyr, ~200 feats)", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed_max / K * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
+            "config": {"workload": "S-A: synthetic TUM fr1-like 640x480 mono, textured plane z=2m, %d independent sequences per GPU, "
+                                   "one tracked frame per sequence per step" % B,
+                       "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "parallelism": "sequences sharded over %d GPU(s)" % world,
+                       "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
+                       "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
+                       "lk_iterations_per_request": round(n_lk / max(1, n_s), 2)},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "kernel_ms_per_step": {k: round(v[0] / K, 4) for k, v in sorted(timers.items())},
+            "host_stage_ms_per_group_step": {k: round(v / max(1, stage_n) * 1e3, 3) for k, v in stage_s.items()},
+            "speedup_vs_cpu_1core": round(value / cpu["value"], 2) if cpu else None,
+        }
+        print(json.dumps(out))
+    farm.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,8 @@ typedef struct sdvl_align_result {
   int32_t n_meas;   /* n_meas_ / patch_area = ComputePose return value */
   int32_t its[SDVL_MAX_LEVELS]; /* accepted Gauss-Newton steps per level */
   int32_t stop;
+  int32_t iters_run; /* ComputeResiduals evaluations over all levels (accepted + rejected), for traffic accounting */
+  int32_t pad_;
 } sdvl_align_result;
 
 typedef struct sdvl_search_params { /* Config getters used by Matcher */
@@ -149,6 +151,17 @@ int sdvl_frame_download_level(sdvl_ctx *ctx, const sdvl_frame *f, int level, uin
 int sdvl_fast_num_cells(int width, int height, const sdvl_detect_params *p, int *cells_per_level, int *total);
 int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_detect_params *p, int cap,
                     sdvl_keypoint *out_kps, int32_t *out_cell_offsets);
+
+/* FastDetector::DetectPyramid (fast_detector.cc:154-175) entirely on the device for n frames: per-cell FAST, the
+ * quota loop and cv::KeyPointsFilter::retainBest in libstdc++'s nth_element/partition order, levels concatenated
+ * into corners_.  Asynchronous: nothing returns to the host, the corner count stays in HBM. */
+int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_detect_params *p, int nfeatures);
+/* corner counts of n frames (blocking, one round trip); SDVL_ERR_CAPACITY if a device capacity overflowed */
+int sdvl_frames_corner_counts(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int32_t *counts);
+/* host mirror of corners_ (GetCorners()): xyl = [n][3], *n_out = count */
+int sdvl_frame_download_corners(sdvl_ctx *ctx, sdvl_frame *f, int cap, int32_t *xyl, int *n_out);
+/* diagnostic: cv::KeyPointsFilter::retainBest on packed keypoints (response in the top byte) run by the device code */
+int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int *out_len);
 
 /* corners_ of a frame (x, y in level coordinates, level), fast_detector.cc:151 -> HBM; descriptors are invalidated */
 int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *xyl);

@@ -130,6 +130,16 @@ int sdvl_ref_detect_pyramid(const uint8_t *img, int w, int h, int stride, const 
   return static_cast<int>(cs.size());
 }
 
+int sdvl_ref_retain_best(uint32_t *packed, int len, int n_points) {
+  std::vector<KeyPoint> kps(len);
+  for (int i = 0; i < len; i++)
+    kps[i] = KeyPoint{static_cast<float>(packed[i] & 0xFFF), static_cast<float>((packed[i] >> 12) & 0xFFF), static_cast<float>(packed[i] >> 24)};
+  RetainBest(&kps, n_points);
+  for (size_t i = 0; i < kps.size(); i++)
+    packed[i] = static_cast<uint32_t>(kps[i].x) | (static_cast<uint32_t>(kps[i].y) << 12) | (static_cast<uint32_t>(kps[i].response) << 24);
+  return static_cast<int>(kps.size());
+}
+
 double sdvl_ref_shi_tomasi(const uint8_t *img, int w, int h, int stride, int x, int y) {
   return ShiTomasiScore(Image{img, w, h, stride}, x, y);
 }

@@ -37,6 +37,8 @@ int sdvl_ref_fast_cells(const uint8_t *img, int w, int h, int stride, const sdvl
 /* fast_detector.cc:154-175 on a pyramid built from img; corners = [cap][3] (x,y,level) */
 int sdvl_ref_detect_pyramid(const uint8_t *img, int w, int h, int stride, const sdvl_ref_params *p, int nfeatures,
                             int cap, int32_t *corners);
+/* cv::KeyPointsFilter::retainBest on packed keypoints (x | y<<12 | response<<24), in place; returns the new length */
+int sdvl_ref_retain_best(uint32_t *packed, int len, int n_points);
 /* extra/utils.cc:61-97 */
 double sdvl_ref_shi_tomasi(const uint8_t *img, int w, int h, int stride, int x, int y);
 /* frame.cc:133-163 / fast_detector.cc:177-218; locked = [n_locked][2] level-0 positions of existing features */

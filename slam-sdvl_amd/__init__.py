@@ -63,7 +63,7 @@ class AlignParams(C.Structure):
 
 class AlignResult(C.Structure):
     _fields_ = [("T", C.c_double * 7), ("error", C.c_double), ("chi2", C.c_double), ("n_meas", C.c_int32),
-                ("its", C.c_int32 * MAX_LEVELS), ("stop", C.c_int32)]
+                ("its", C.c_int32 * MAX_LEVELS), ("stop", C.c_int32), ("iters_run", C.c_int32), ("pad_", C.c_int32)]
 
 
 class SearchParams(C.Structure):
@@ -93,6 +93,7 @@ ABI_SYMBOLS = [
     "sdvl_ctx_timing_enable", "sdvl_ctx_timing_get", "sdvl_ctx_timing_reset",
     "sdvl_frame_create", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frame_set_image_device",
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
+    "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
     "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
     "sdvl_frame_download_descriptors", "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
@@ -231,6 +232,27 @@ class Context:
             k = raw[i * cap: i * cap + offs[i, -1]]
             out.append((np.stack([k["x"], k["y"], k["score"], k["level"], k["cell"]], 1).astype(np.int32), offs[i].copy()))
         return out, [cpl[i] for i in range(dp.max_fast_levels)]
+
+    def detect_corners(self, frames, dp, nfeatures=1000):
+        """DetectPyramid fully on device -> list of corners [(x, y, level)] per frame"""
+        n = len(frames)
+        arr = (C.c_void_p * n)(*[f.h for f in frames])
+        self._check(self.lib.sdvl_detect_corners(self.h, n, arr, C.byref(dp), nfeatures))
+        counts = np.zeros(n, np.int32)
+        self._check(self.lib.sdvl_frames_corner_counts(self.h, n, arr, _ptr(counts, i32p)))
+        out = []
+        for f, c in zip(frames, counts):
+            xyl = np.zeros((max(int(c), 1), 3), np.int32)
+            k = C.c_int()
+            self._check(self.lib.sdvl_frame_download_corners(self.h, f.h, len(xyl), _ptr(xyl, i32p), C.byref(k)))
+            out.append(xyl[:k.value].copy())
+        return out
+
+    def retain_best(self, packed, n_points):
+        packed = np.ascontiguousarray(packed, np.uint32).copy()
+        k = C.c_int()
+        self._check(self.lib.sdvl_retain_best(self.h, _ptr(packed, C.POINTER(C.c_uint32)), len(packed), int(n_points), C.byref(k)))
+        return packed[:k.value]
 
     def shi_tomasi(self, frames, cap=MAX_CORNERS):
         n = len(frames)

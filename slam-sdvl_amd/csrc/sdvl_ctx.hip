@@ -5,7 +5,7 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned) 
   if (*cur >= need && *p) return SDVL_OK;
   size_t want = need + need / 2 + 4096;
   if (*p) {
-    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
     if (pinned) SDVL_HIP_CHECK(ctx, hipHostFree(*p));
     else SDVL_HIP_CHECK(ctx, hipFree(*p));
     *p = nullptr;
@@ -14,6 +14,28 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned) 
   if (pinned) SDVL_HIP_CHECK(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
   else SDVL_HIP_CHECK(ctx, hipMalloc(p, want));
   *cur = want;
+  return SDVL_OK;
+}
+
+hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
+  if (!ctx->wait_event) {
+    hipError_t e = hipEventCreateWithFlags(&ctx->wait_event, hipEventBlockingSync | hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
+  if (e != hipSuccess) return e;
+  return hipEventSynchronize(ctx->wait_event);
+}
+
+int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n) {
+  if (f->v.n_corners < 0) {
+    int rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, 64, true);
+    if (rc) return rc;
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, f->v.corner_hdr, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+    f->v.n_corners = static_cast<const int32_t *>(ctx->h_out)[0];
+  }
+  *n = f->v.n_corners;
   return SDVL_OK;
 }
 
@@ -85,11 +107,13 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   sdvl_timer_collect(ctx);
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+  if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   if (ctx->d_stage) (void)hipFree(ctx->d_stage);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
+  if (ctx->d_counts) (void)hipFree(ctx->d_counts);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SDVL_OK;
@@ -99,7 +123,7 @@ const char *sdvl_last_error(const sdvl_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 int sdvl_ctx_synchronize(sdvl_ctx *ctx) {
   if (!ctx) return SDVL_ERR_INVALID;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   return SDVL_OK;
 }
 
@@ -113,7 +137,7 @@ int sdvl_ctx_timing_enable(sdvl_ctx *ctx, int on) {
 
 int sdvl_ctx_timing_get(sdvl_ctx *ctx, int cap, char (*names)[32], double *ms, int64_t *launches, int *n) {
   if (!ctx || !n) return SDVL_ERR_INVALID;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   sdvl_timer_collect(ctx);
   int k = 0;
   for (const auto &t : ctx->timers) {
@@ -129,7 +153,7 @@ int sdvl_ctx_timing_get(sdvl_ctx *ctx, int cap, char (*names)[32], double *ms, i
 
 int sdvl_ctx_timing_reset(sdvl_ctx *ctx) {
   if (!ctx) return SDVL_ERR_INVALID;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   sdvl_timer_collect(ctx);
   for (auto &t : ctx->timers) { t.ms = 0.0; t.launches = 0; }
   return SDVL_OK;
@@ -160,8 +184,10 @@ int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_fra
     h /= 2;
     if (w < 1 || h < 1) { delete f; SDVL_REQUIRE(ctx, false, "image too small for the pyramid depth"); }
   }
-  const size_t corners_off = off;
-  off = align_up(off + sizeof(int32_t) * 4 * SDVL_MAX_CORNERS, 256);
+  const size_t corners_off = off;  // 16-byte header {count,0,0,0} + corner records, written by ONE copy
+  off = align_up(off + sizeof(int32_t) * 4 * (SDVL_MAX_CORNERS + 1), 256);
+  const size_t lvl_off = off;      // selection-kernel scratch: per-level segments + counts
+  off = align_up(off + sizeof(int32_t) * 4 * SDVL_MAX_CORNERS * 4 + 64, 256);
   const size_t desc_off = off;
   off = align_up(off + 32 * SDVL_MAX_CORNERS, 256);
   // per-cell FAST lists: worst case cell size 16 on the 3 finest levels
@@ -182,18 +208,28 @@ int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_fra
   for (int l = 0; l < levels; l++) f->v.level[l] = f->base + lo[l];
   f->v.levels = levels;
   f->v.n_corners = 0;
-  f->v.corners = reinterpret_cast<int32_t *>(f->base + corners_off);
+  f->v.corner_hdr = reinterpret_cast<int32_t *>(f->base + corners_off);
+  f->v.corners = f->v.corner_hdr + 4;
+  f->level_corners = reinterpret_cast<int32_t *>(f->base + lvl_off);
+  f->level_counts = f->level_corners + static_cast<size_t>(4) * SDVL_MAX_CORNERS * 4;
   f->v.desc = f->base + desc_off;
   f->cell_counts = reinterpret_cast<int32_t *>(f->base + counts_off);
   f->cell_kps = reinterpret_cast<uint32_t *>(f->base + kps_off);
   f->desc_valid = 0;
+  hipError_t e2 = hipMemsetAsync(f->v.corner_hdr, 0, 16, ctx->stream);
+  if (e2 != hipSuccess) {
+    ctx->err = std::string("hipMemsetAsync(frame): ") + hipGetErrorString(e2);
+    (void)hipFree(f->base);
+    delete f;
+    return SDVL_ERR_HIP;
+  }
   *out = f;
   return SDVL_OK;
 }
 
 int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f) {
   if (!ctx || !f) return SDVL_ERR_INVALID;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   SDVL_HIP_CHECK(ctx, hipFree(f->base));
   delete f;
   return SDVL_OK;
@@ -205,6 +241,7 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
   // hipMemcpy2DAsync from pageable memory stages internally; it returns once the source has been consumed.
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, img, stride, f->width, f->height, hipMemcpyHostToDevice,
                                        ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipMemsetAsync(f->v.corner_hdr, 0, 16, ctx->stream));
   f->v.n_corners = 0;
   f->desc_valid = 0;
   return SDVL_OK;
@@ -215,6 +252,7 @@ int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_im
   SDVL_REQUIRE(ctx, stride >= f->width, "stride smaller than width");
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, dev_img, stride, f->width, f->height,
                                        hipMemcpyDeviceToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipMemsetAsync(f->v.corner_hdr, 0, 16, ctx->stream));
   f->v.n_corners = 0;
   f->desc_valid = 0;
   return SDVL_OK;
@@ -226,7 +264,7 @@ int sdvl_frame_download_level(sdvl_ctx *ctx, const sdvl_frame *f, int level, uin
   SDVL_REQUIRE(ctx, stride >= f->v.lw[level], "stride smaller than level width");
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(out, stride, f->v.level[level], f->v.lw[level], f->v.lw[level], f->v.lh[level],
                                        hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   return SDVL_OK;
 }
 
@@ -242,17 +280,18 @@ int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *x
     SDVL_REQUIRE(ctx, l >= 0 && l < f->v.levels && x >= 0 && y >= 0 && x < f->v.lw[l] && y < f->v.lh[l],
                  "corner outside its pyramid level");
   }
-  if (n > 0) {
-    const size_t bytes = sizeof(int32_t) * 4 * n;
+  {
+    const size_t bytes = sizeof(int32_t) * 4 * (n + 1);
     int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
     if (rc) return rc;
-    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier copy
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // the staging buffer may still feed an earlier copy
     int32_t *st = static_cast<int32_t *>(ctx->h_stage);
+    st[0] = n; st[1] = 0; st[2] = 0; st[3] = 0;
     for (int i = 0; i < n; i++) {
-      st[4 * i] = xyl[3 * i]; st[4 * i + 1] = xyl[3 * i + 1]; st[4 * i + 2] = xyl[3 * i + 2]; st[4 * i + 3] = 0;
+      st[4 * (i + 1)] = xyl[3 * i]; st[4 * (i + 1) + 1] = xyl[3 * i + 1]; st[4 * (i + 1) + 2] = xyl[3 * i + 2]; st[4 * (i + 1) + 3] = 0;
     }
-    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(f->v.corners, st, bytes, hipMemcpyHostToDevice, ctx->stream));
-    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(f->v.corner_hdr, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   }
   f->v.n_corners = n;
   f->desc_valid = 0;
@@ -270,11 +309,8 @@ int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, con
     }
     total += counts[i];
   }
-  if (total == 0) {
-    for (int i = 0; i < n; i++) { frames[i]->v.n_corners = 0; frames[i]->desc_valid = 0; }
-    return SDVL_OK;
-  }
-  if (!xyl) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  if (total > 0 && !xyl) return SDVL_ERR_INVALID;
   {
     size_t k = 0;
     for (int i = 0; i < n; i++) {
@@ -286,29 +322,51 @@ int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, con
       }
     }
   }
-  const size_t bytes = sizeof(int32_t) * 4 * total;
+  const size_t bytes = sizeof(int32_t) * 4 * (total + n);
   int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   int32_t *st = static_cast<int32_t *>(ctx->h_stage);
-  for (size_t k = 0; k < total; k++) {
-    st[4 * k] = xyl[3 * k]; st[4 * k + 1] = xyl[3 * k + 1]; st[4 * k + 2] = xyl[3 * k + 2]; st[4 * k + 3] = 0;
-  }
-  size_t k = 0;
+  size_t k = 0, w = 0;
   for (int i = 0; i < n; i++) {
-    if (counts[i] > 0)
-      SDVL_HIP_CHECK(ctx, hipMemcpyAsync(frames[i]->v.corners, st + 4 * k, sizeof(int32_t) * 4 * counts[i], hipMemcpyHostToDevice,
-                                         ctx->stream));
+    int32_t *rec = st + 4 * w;  // {count,0,0,0} header + records: one copy per frame
+    rec[0] = counts[i]; rec[1] = 0; rec[2] = 0; rec[3] = 0;
+    for (int j = 0; j < counts[i]; j++, k++) {
+      rec[4 * (j + 1)] = xyl[3 * k]; rec[4 * (j + 1) + 1] = xyl[3 * k + 1]; rec[4 * (j + 1) + 2] = xyl[3 * k + 2]; rec[4 * (j + 1) + 3] = 0;
+    }
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(frames[i]->v.corner_hdr, rec, sizeof(int32_t) * 4 * (counts[i] + 1), hipMemcpyHostToDevice, ctx->stream));
     frames[i]->v.n_corners = counts[i];
     frames[i]->desc_valid = 0;
-    k += counts[i];
+    w += counts[i] + 1;
   }
   // no synchronisation: later launches on the same stream are ordered behind the copies; the pinned staging
-  // buffer is only rewritten after the next hipStreamSynchronize every entry point performs before reuse
+  // buffer is only rewritten after the next wait every entry point performs before reuse
   return SDVL_OK;
 }
 
 int sdvl_frame_num_corners(const sdvl_frame *f) { return f ? f->v.n_corners : SDVL_ERR_INVALID; }
+
+int sdvl_frame_download_corners(sdvl_ctx *ctx, sdvl_frame *f, int cap, int32_t *xyl, int *n_out) {
+  if (!ctx || !f || !n_out) return SDVL_ERR_INVALID;
+  int n = 0;
+  int rc = sdvl_frame_count_host(ctx, f, &n);
+  if (rc) return rc;
+  *n_out = n;
+  if (n == 0) return SDVL_OK;
+  if (!xyl) return SDVL_ERR_INVALID;
+  if (n > cap) {
+    ctx->err = "corner output capacity smaller than the corner count";
+    return SDVL_ERR_CAPACITY;
+  }
+  const size_t bytes = sizeof(int32_t) * 4 * n;
+  rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, bytes, true);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, f->v.corners, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  const int32_t *src = static_cast<const int32_t *>(ctx->h_out);
+  for (int i = 0; i < n; i++) { xyl[3 * i] = src[4 * i]; xyl[3 * i + 1] = src[4 * i + 1]; xyl[3 * i + 2] = src[4 * i + 2]; }
+  return SDVL_OK;
+}
 
 int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out) {
   if (!ctx || !out || bytes <= 0) return SDVL_ERR_INVALID;
@@ -319,7 +377,7 @@ int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out) {
 
 int sdvl_device_free(sdvl_ctx *ctx, void *p) {
   if (!ctx) return SDVL_ERR_INVALID;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   SDVL_HIP_CHECK(ctx, hipFree(p));
   return SDVL_OK;
 }
@@ -327,7 +385,7 @@ int sdvl_device_free(sdvl_ctx *ctx, void *p) {
 int sdvl_device_download(sdvl_ctx *ctx, const void *dev, int64_t bytes, void *host) {
   if (!ctx || !dev || !host || bytes <= 0) return SDVL_ERR_INVALID;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(host, dev, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   return SDVL_OK;
 }
 

@@ -247,6 +247,315 @@ __global__ __launch_bounds__(256) void compact_cells_kernel(const FastJob *__res
   if (tid == 0) offs[total_cells] = s_carry;
 }
 
+
+// ------------------------------------------------------------------------------------ corner selection on device
+// The quota / retainBest half of FastDetector::SelectPixels (fast_detector.cc:108-151) without leaving the GPU.
+// cv::KeyPointsFilter::retainBest = std::nth_element + std::partition; the surviving ORDER is whatever libstdc++'s
+// introselect leaves, and that order matters downstream (first-wins ties in matcher.cc:280-283 and
+// fast_detector.cc:208).  The functions below restate libstdc++ (GCC 11 bits/stl_algo.h, bits/stl_heap.h)
+// __introselect / __unguarded_partition_pivot / __move_median_to_first / __insertion_sort / __heap_select and the
+// bidirectional std::__partition statement by statement on packed keypoints (score in the top byte), so the device
+// list is identical — element for element — to what the host calls produce on the same input order.
+__device__ __forceinline__ bool kp_gt(uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); }  // response greater
+__device__ __forceinline__ void kp_swap(uint32_t *v, int i, int j) { const uint32_t t = v[i]; v[i] = v[j]; v[j] = t; }
+
+__device__ void sel_move_median_to_first(uint32_t *v, int result, int a, int b, int c) {
+  if (kp_gt(v[a], v[b])) {
+    if (kp_gt(v[b], v[c])) kp_swap(v, result, b);
+    else if (kp_gt(v[a], v[c])) kp_swap(v, result, c);
+    else kp_swap(v, result, a);
+  } else if (kp_gt(v[a], v[c])) kp_swap(v, result, a);
+  else if (kp_gt(v[b], v[c])) kp_swap(v, result, c);
+  else kp_swap(v, result, b);
+}
+
+__device__ int sel_unguarded_partition(uint32_t *v, int first, int last, int pivot) {
+  while (true) {
+    while (kp_gt(v[first], v[pivot])) ++first;
+    --last;
+    while (kp_gt(v[pivot], v[last])) --last;
+    if (!(first < last)) return first;
+    kp_swap(v, first, last);
+    ++first;
+  }
+}
+
+__device__ void sel_push_heap(uint32_t *v, int first, int hole, int top, uint32_t value) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && kp_gt(v[first + parent], value)) {
+    v[first + hole] = v[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  v[first + hole] = value;
+}
+
+__device__ void sel_adjust_heap(uint32_t *v, int first, int hole, int len, uint32_t value) {
+  const int top = hole;
+  int second = hole;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (kp_gt(v[first + second], v[first + (second - 1)])) second--;
+    v[first + hole] = v[first + second];
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    v[first + hole] = v[first + (second - 1)];
+    hole = second - 1;
+  }
+  sel_push_heap(v, first, hole, top, value);
+}
+
+__device__ void sel_heap_select(uint32_t *v, int first, int middle, int last) {
+  const int len = middle - first;
+  if (len >= 2) {  // __make_heap
+    int parent = (len - 2) / 2;
+    while (true) {
+      const uint32_t value = v[first + parent];
+      sel_adjust_heap(v, first, parent, len, value);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  for (int i = middle; i < last; ++i)
+    if (kp_gt(v[i], v[first])) {  // __pop_heap(first, middle, i)
+      const uint32_t value = v[i];
+      v[i] = v[first];
+      sel_adjust_heap(v, first, 0, middle - first, value);
+    }
+}
+
+__device__ void sel_insertion_sort(uint32_t *v, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    const uint32_t val = v[i];
+    if (kp_gt(val, v[first])) {
+      for (int k = i; k > first; --k) v[k] = v[k - 1];  // move_backward(first, i, i + 1)
+      v[first] = val;
+    } else {  // __unguarded_linear_insert
+      int lastp = i, next = i - 1;
+      while (kp_gt(val, v[next])) {
+        v[lastp] = v[next];
+        lastp = next;
+        --next;
+      }
+      v[lastp] = val;
+    }
+  }
+}
+
+// std::nth_element(v+first, v+nth, v+last, response-greater)
+__device__ void sel_nth_element(uint32_t *v, int first, int nth, int last) {
+  if (first == last || nth == last) return;
+  int depth_limit = (31 - __clz(last - first)) * 2;  // std::__lg(n) * 2
+  while (last - first > 3) {
+    if (depth_limit == 0) {
+      sel_heap_select(v, first, nth + 1, last);
+      kp_swap(v, first, nth);
+      return;
+    }
+    --depth_limit;
+    const int mid = first + (last - first) / 2;
+    sel_move_median_to_first(v, first, first + 1, mid, last - 1);
+    const int cut = sel_unguarded_partition(v, first + 1, last, first);
+    if (cut <= nth) first = cut;
+    else last = cut;
+  }
+  sel_insertion_sort(v, first, last);
+}
+
+// cv::KeyPointsFilter::retainBest(kps, n_points) on v[0..len): returns the new length
+__device__ int sel_retain_best(uint32_t *v, int len, int n_points) {
+  if (n_points >= 0 && len > n_points) {
+    if (n_points == 0) return 0;
+    sel_nth_element(v, 0, n_points, len);
+    const uint32_t amb = v[n_points - 1] >> 24;
+    // std::partition(v+n_points, v+len, response >= amb)   (bidirectional __partition)
+    int first = n_points, last = len;
+    while (true) {
+      while (true) {
+        if (first == last) return first;
+        else if ((v[first] >> 24) >= amb) ++first;
+        else break;
+      }
+      --last;
+      while (true) {
+        if (first == last) return first;
+        else if (!((v[last] >> 24) >= amb)) --last;
+        else break;
+      }
+      kp_swap(v, first, last);
+      ++first;
+    }
+  }
+  return len;
+}
+
+constexpr int kSelMaxCells = 2048;  // cells of one level
+constexpr int kSelStage = 8192;     // keypoints staged in LDS per round
+constexpr int kSelFts = 4096;       // concatenated selection of one level before the final retainBest
+
+struct SelLevels {
+  int n_levels;
+  int cell_begin[5];
+  int wcells[4], hcells[4];
+  int quota[4];
+  int cell_size, margin;
+};
+
+struct SelJob {
+  const uint32_t *cell_kps;
+  const int32_t *cell_counts;
+  int32_t *level_corners;  // [4][SDVL_MAX_CORNERS][4]
+  int32_t *level_counts;   // [4]
+  int32_t *corner_hdr;     // {count,0,0,0} + corners
+  int lw[4], lh[4];
+};
+
+// one workgroup per (level, frame)
+__global__ __launch_bounds__(256) void select_corners_kernel(const SelJob *__restrict__ jobs, SelLevels lv) {
+  __shared__ uint32_t s_stage[kSelStage];
+  __shared__ uint32_t s_fts[kSelFts];
+  __shared__ uint8_t s_nleft[kSelMaxCells], s_nsel[kSelMaxCells], s_newlen[kSelMaxCells];
+  __shared__ int s_off[kSelMaxCells];  // offset of the cell inside s_stage for the current round
+  __shared__ int s_round[3];           // c0, c1, total staged
+  __shared__ int s_nfts, s_overflow;
+  const SelJob &job = jobs[blockIdx.y];
+  const int l = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int ncells = lv.wcells[l] * lv.hcells[l];
+  const int cbeg = lv.cell_begin[l];
+  const int nfeatures = lv.quota[l];
+  // ---- quota loop, fast_detector.cc:108-135 (thread 0; a handful of passes over <= 2048 bytes of LDS)
+  for (int c = tid; c < ncells; c += 256) {
+    s_nleft[c] = static_cast<uint8_t>(job.cell_counts[cbeg + c]);
+    s_nsel[c] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int nempty = 0;
+    for (int i = 0; i < lv.hcells[l]; i++) {
+      const int inity = max(lv.margin, i * lv.cell_size), maxy = min(job.lh[l] - lv.margin, i * lv.cell_size + lv.cell_size);
+      if (maxy <= inity) continue;
+      for (int j = 0; j < lv.wcells[l]; j++) {
+        const int initx = max(lv.margin, j * lv.cell_size), maxx = min(job.lw[l] - lv.margin, j * lv.cell_size + lv.cell_size);
+        if (maxx <= initx) continue;
+        if (s_nleft[i * lv.wcells[l] + j] == 0) nempty++;  // only cells where cv::FAST ran count as empty (Appendix B)
+      }
+    }
+    int selected = 0;
+    int cells_left = ncells - nempty;
+    while ((nfeatures - selected) > 0 && cells_left > 0) {
+      const int rem = nfeatures - selected;
+      const int npercell = (rem + cells_left - 1) / cells_left;  // ceil(double(rem) / double(cells_left)), exact for ints this small
+      cells_left = 0;
+      for (int c = 0; c < ncells; c++) {
+        const int nl = s_nleft[c];
+        if (nl > 0) {
+          if (nl > npercell) {
+            s_nsel[c] = static_cast<uint8_t>(s_nsel[c] + npercell);
+            selected += npercell;
+            s_nleft[c] = static_cast<uint8_t>(nl - npercell);
+            cells_left++;
+          } else {
+            s_nsel[c] = static_cast<uint8_t>(s_nsel[c] + nl);
+            selected += nl;
+            s_nleft[c] = 0;
+          }
+        }
+      }
+    }
+    s_nfts = 0;
+    s_overflow = 0;
+  }
+  __syncthreads();
+  // ---- per-cell retainBest (fast_detector.cc:138-145): cells are staged into LDS in rounds, one thread per cell
+  int c0 = 0;
+  while (c0 < ncells) {
+    if (tid == 0) {
+      int tot = 0, c = c0;
+      while (c < ncells) {
+        const int cnt = job.cell_counts[cbeg + c];
+        if (tot + cnt > kSelStage) break;
+        s_off[c] = tot;
+        tot += cnt;
+        c++;
+      }
+      s_round[0] = c0;
+      s_round[1] = c;
+      s_round[2] = tot;
+    }
+    __syncthreads();
+    const int c1 = s_round[1];
+    for (int c = c0 + (tid >> 2); c < c1; c += 64) {  // 4 lanes copy one cell
+      const int cnt = job.cell_counts[cbeg + c];
+      const uint32_t *src = job.cell_kps + static_cast<size_t>(cbeg + c) * SDVL_CELL_KP_CAP;
+      for (int k = (tid & 3); k < cnt; k += 4) s_stage[s_off[c] + k] = src[k];
+    }
+    __syncthreads();
+    for (int c = c0 + tid; c < c1; c += 256) {
+      const int cnt = job.cell_counts[cbeg + c];
+      s_newlen[c] = static_cast<uint8_t>(sel_retain_best(&s_stage[s_off[c]], cnt, s_nsel[c]));
+    }
+    __syncthreads();
+    if (tid == 0) {  // append the survivors in cell order (fast_detector.cc:141-143)
+      int n = s_nfts;
+      for (int c = c0; c < c1; c++) {
+        const int len = s_newlen[c];
+        if (n + len > kSelFts) { s_overflow = 1; break; }
+        for (int k = 0; k < len; k++) s_fts[n + k] = s_stage[s_off[c] + k];
+        n += len;
+      }
+      s_nfts = n;
+    }
+    __syncthreads();
+    c0 = c1;
+    if (s_overflow) break;
+  }
+  // ---- final retainBest over the level (fast_detector.cc:147-148)
+  if (tid == 0 && !s_overflow) {
+    if (s_nfts > nfeatures) s_nfts = sel_retain_best(s_fts, s_nfts, nfeatures);
+  }
+  __syncthreads();
+  int n = s_overflow ? -1 : min(s_nfts, SDVL_MAX_CORNERS);
+  int32_t *dst = job.level_corners + static_cast<size_t>(l) * SDVL_MAX_CORNERS * 4;
+  for (int k = tid; k < n; k += 256) {
+    const uint32_t v = s_fts[k];
+    dst[4 * k] = static_cast<int32_t>(v & 0xFFF);
+    dst[4 * k + 1] = static_cast<int32_t>((v >> 12) & 0xFFF);
+    dst[4 * k + 2] = l;
+    dst[4 * k + 3] = 0;
+  }
+  if (tid == 0) job.level_counts[l] = n;
+}
+
+// one workgroup per frame: level segments -> corners_ (fast_detector.cc:171-174 concatenates levels in order)
+__global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restrict__ jobs, int n_levels, int32_t *__restrict__ batch_counts) {
+  const SelJob &job = jobs[blockIdx.x];
+  int off = 0;
+  bool bad = false;
+  for (int l = 0; l < n_levels; l++) {
+    const int cnt = job.level_counts[l];
+    if (cnt < 0 || off + cnt > SDVL_MAX_CORNERS) { bad = true; break; }
+    const int4 *src = reinterpret_cast<const int4 *>(job.level_corners + static_cast<size_t>(l) * SDVL_MAX_CORNERS * 4);
+    int4 *dst = reinterpret_cast<int4 *>(job.corner_hdr + 4) + off;
+    for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
+    off += cnt;
+  }
+  if (threadIdx.x == 0) {
+    const int total = bad ? -1 : off;  // -1: a capacity overflowed; reported by sdvl_frames_corner_counts
+    job.corner_hdr[0] = total < 0 ? 0 : total;
+    job.corner_hdr[1] = total;
+    if (batch_counts) batch_counts[blockIdx.x] = total;
+  }
+}
+
+// diagnostic: retainBest of one list by one thread (tests the libstdc++ restatement against the host calls)
+__global__ void retain_best_kernel(uint32_t *v, int len, int n_points, int *out_len) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out_len = sel_retain_best(v, len, n_points);
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,7 +575,7 @@ int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
   if (rc) return rc;
   rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, bytes, false);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // staging reuse
   PyrJob *hj = static_cast<PyrJob *>(ctx->h_stage);
   for (int l = 1; l < levels; l++)
     for (int i = 0; i < n; i++) {
@@ -337,7 +646,7 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, offs_bytes + kps_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, offs_bytes + kps_bytes, true);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   FastJob *hj = static_cast<FastJob *>(ctx->h_stage);
   for (int i = 0; i < n; i++) {
     memset(&hj[i], 0, sizeof(FastJob));
@@ -366,7 +675,7 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   int32_t *h_offs = static_cast<int32_t *>(ctx->h_out);
   uint32_t *h_kps = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->h_out) + offs_bytes);
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h_offs, d_offs, offs_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   int max_total = 0;
   for (int i = 0; i < n; i++) {
     const int tot = h_offs[static_cast<size_t>(i) * (total_cells + 1) + total_cells];
@@ -379,7 +688,7 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   if (max_total > 0) {
     SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(h_kps, sizeof(uint32_t) * cap, d_kps, sizeof(uint32_t) * cap,
                                          sizeof(uint32_t) * max_total, n, hipMemcpyDeviceToHost, ctx->stream));
-    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   }
   memcpy(out_cell_offsets, h_offs, offs_bytes);
   for (int i = 0; i < n; i++) {
@@ -399,6 +708,176 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
       }
     }
   }
+  return SDVL_OK;
+}
+
+// FastDetector::DetectPyramid (fast_detector.cc:154-175) entirely on device: per-cell FAST, quota + retainBest in
+// libstdc++ order, level concatenation.  No host synchronisation; the corner count stays in HBM (frame header).
+int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_detect_params *p, int nfeatures) {
+  if (!ctx || !p || n < 0 || (n > 0 && !frames)) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, p->cell_size >= 8 && p->cell_size <= kTile, "cell_size must be in [8,32]");
+  SDVL_REQUIRE(ctx, p->max_fast_levels >= 1 && p->max_fast_levels <= 4, "max_fast_levels must be in [1,4]");
+  SDVL_REQUIRE(ctx, p->margin >= 0 && nfeatures >= 0, "bad margin / nfeatures");
+  const int W = frames[0]->width, H = frames[0]->height;
+  FastLevels lv;
+  SelLevels sl;
+  memset(&lv, 0, sizeof(lv));
+  memset(&sl, 0, sizeof(sl));
+  lv.n_levels = sl.n_levels = p->max_fast_levels;
+  lv.cell_size = sl.cell_size = p->cell_size;
+  lv.margin = sl.margin = p->margin;
+  lv.threshold = p->fast_threshold < 0 ? 0 : (p->fast_threshold > 255 ? 255 : p->fast_threshold);
+  // level quotas, fast_detector.cc:161-174
+  const double scale = 1.2;
+  double factor = 1.0, val = 0.0;
+  for (int i = 0; i < p->max_fast_levels; i++) { val += factor; factor /= scale; }
+  int levelfeatures = static_cast<int>(nfeatures / val);
+  int total_cells = 0;
+  for (int l = 0; l < lv.n_levels; l++) {
+    SDVL_REQUIRE(ctx, l < frames[0]->v.levels, "max_fast_levels exceeds the pyramid depth");
+    const int w = frames[0]->v.lw[l], h = frames[0]->v.lh[l];
+    lv.cell_begin[l] = sl.cell_begin[l] = total_cells;
+    lv.wcells[l] = sl.wcells[l] = (w + p->cell_size - 1) / p->cell_size;
+    sl.hcells[l] = (h + p->cell_size - 1) / p->cell_size;
+    SDVL_REQUIRE(ctx, sl.wcells[l] * sl.hcells[l] <= kSelMaxCells, "too many cells in one level for the selection kernel");
+    total_cells += sl.wcells[l] * sl.hcells[l];
+    sl.quota[l] = levelfeatures;
+    levelfeatures = static_cast<int>(levelfeatures / scale);
+  }
+  lv.cell_begin[lv.n_levels] = sl.cell_begin[sl.n_levels] = total_cells;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] && frames[i]->width == W && frames[i]->height == H && frames[i]->v.levels == frames[0]->v.levels,
+                 "frames of one batch must share size and pyramid depth");
+    if (total_cells > frames[i]->max_cells) {
+      ctx->err = "cell grid larger than the frame's per-cell list capacity";
+      return SDVL_ERR_CAPACITY;
+    }
+  }
+  const size_t fj_bytes = (sizeof(FastJob) * n + 255) / 256 * 256, sj_bytes = sizeof(SelJob) * n;
+  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, fj_bytes + sj_bytes, true);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, fj_bytes + sj_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_counts, &ctx->d_counts_bytes, sizeof(int32_t) * n, false);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  ctx->detect_frames.assign(frames, frames + n);
+  FastJob *hf = static_cast<FastJob *>(ctx->h_stage);
+  SelJob *hs = reinterpret_cast<SelJob *>(static_cast<uint8_t *>(ctx->h_stage) + fj_bytes);
+  for (int i = 0; i < n; i++) {
+    memset(&hf[i], 0, sizeof(FastJob));
+    memset(&hs[i], 0, sizeof(SelJob));
+    for (int l = 0; l < lv.n_levels; l++) {
+      hf[i].level[l] = frames[i]->v.level[l];
+      hf[i].lw[l] = hs[i].lw[l] = frames[i]->v.lw[l];
+      hf[i].lh[l] = hs[i].lh[l] = frames[i]->v.lh[l];
+    }
+    hf[i].cell_kps = frames[i]->cell_kps;
+    hf[i].cell_counts = frames[i]->cell_counts;
+    hs[i].cell_kps = frames[i]->cell_kps;
+    hs[i].cell_counts = frames[i]->cell_counts;
+    hs[i].level_corners = frames[i]->level_corners;
+    hs[i].level_counts = frames[i]->level_counts;
+    hs[i].corner_hdr = frames[i]->v.corner_hdr;
+    frames[i]->v.n_corners = -1;  // known on the device only
+    frames[i]->desc_valid = 0;
+  }
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, fj_bytes + sj_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const FastJob *df = static_cast<const FastJob *>(ctx->d_stage);
+  const SelJob *ds = reinterpret_cast<const SelJob *>(static_cast<uint8_t *>(ctx->d_stage) + fj_bytes);
+  {
+    ScopedKernelTimer tm(ctx, "fast_cells");
+    hipLaunchKernelGGL(fast_cells_kernel, dim3(total_cells, n), dim3(256), 0, ctx->stream, df, lv);
+  }
+  {
+    ScopedKernelTimer tm(ctx, "select_corners");
+    hipLaunchKernelGGL(select_corners_kernel, dim3(lv.n_levels, n), dim3(256), 0, ctx->stream, ds, sl);
+  }
+  {
+    ScopedKernelTimer tm(ctx, "pack_corners");
+    hipLaunchKernelGGL(pack_corners_kernel, dim3(n), dim3(256), 0, ctx->stream, ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts));
+  }
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  return SDVL_OK;
+}
+
+// corner counts of n frames in one transfer (blocking); refreshes the host copies
+int sdvl_frames_corner_counts(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int32_t *counts) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !counts))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  bool all_known = true;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    if (frames[i]->v.n_corners < 0) all_known = false;
+  }
+  if (!all_known) {
+    const size_t nd = ctx->detect_frames.size();
+    int rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, sizeof(int32_t) * (4 * static_cast<size_t>(n) + nd), true);
+    if (rc) return rc;
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+    int32_t *h = static_cast<int32_t *>(ctx->h_out);
+    // fast path: the pack kernel of the last detect batch left every count in one array
+    bool batch_ok = nd > 0;
+    std::vector<int> where(n, -1);
+    if (batch_ok) {
+      for (int i = 0; i < n && batch_ok; i++) {
+        if (frames[i]->v.n_corners >= 0) continue;
+        if (static_cast<size_t>(i) < nd && ctx->detect_frames[i] == frames[i]) where[i] = i;
+        else {
+          for (size_t k = 0; k < nd; k++)
+            if (ctx->detect_frames[k] == frames[i]) { where[i] = static_cast<int>(k); break; }
+          if (where[i] < 0) batch_ok = false;
+        }
+      }
+    }
+    if (batch_ok) {
+      SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_counts, sizeof(int32_t) * nd, hipMemcpyDeviceToHost, ctx->stream));
+      SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+      for (int i = 0; i < n; i++)
+        if (frames[i]->v.n_corners < 0) {
+          const int c = h[where[i]];
+          if (c < 0) {
+            ctx->err = "corner selection overflowed a device capacity (SDVL_MAX_CORNERS / level staging)";
+            return SDVL_ERR_CAPACITY;
+          }
+          frames[i]->v.n_corners = c;
+        }
+    } else {
+      for (int i = 0; i < n; i++)
+        if (frames[i]->v.n_corners < 0)
+          SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h + 4 * i, frames[i]->v.corner_hdr, 16, hipMemcpyDeviceToHost, ctx->stream));
+      SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+      for (int i = 0; i < n; i++)
+        if (frames[i]->v.n_corners < 0) {
+          if (h[4 * i + 1] < 0) {
+            ctx->err = "corner selection overflowed a device capacity (SDVL_MAX_CORNERS / level staging)";
+            return SDVL_ERR_CAPACITY;
+          }
+          frames[i]->v.n_corners = h[4 * i];
+        }
+    }
+  }
+  for (int i = 0; i < n; i++) counts[i] = frames[i]->v.n_corners;
+  return SDVL_OK;
+}
+
+// diagnostic: cv::KeyPointsFilter::retainBest on packed keypoints (score = top byte) by the device restatement
+int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int *out_len) {
+  if (!ctx || !packed || !out_len || len < 0 || len > (1 << 20)) return SDVL_ERR_INVALID;
+  if (len == 0) { *out_len = 0; return SDVL_OK; }
+  const size_t bytes = sizeof(uint32_t) * len + 64;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, bytes, true);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  memcpy(static_cast<uint8_t *>(ctx->h_out) + 64, packed, sizeof(uint32_t) * len);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_out, ctx->h_out, bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(retain_best_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->d_out) + 64), len,
+                     n_points, static_cast<int *>(ctx->d_out));
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  *out_len = *static_cast<int *>(ctx->h_out);
+  memcpy(packed, static_cast<uint8_t *>(ctx->h_out) + 64, sizeof(uint32_t) * len);
   return SDVL_OK;
 }
 

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__re
   Rigid T = se3_identity(), T_bk = se3_identity();
   double chi2 = 1e10, error = 1e10;
   bool stop = false;
-  int n_meas = 0;
+  int n_meas = 0, iters_run = 0;
   int its[SDVL_MAX_LEVELS];
 #pragma unroll
   for (int i = 0; i < SDVL_MAX_LEVELS; i++) its[i] = 0;
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__re
           }
         for (int r = 0; r < 6; r++) Jres[r] = s_sum[21 + r];
         n_meas = static_cast<int>(s_sum[28]);
+        iters_run++;
         const double new_chi2 = static_cast<double>(static_cast<float>(s_sum[27]) / static_cast<float>(n_meas));
         if (n_meas == 0) stop = true;
         ldlt_solve6(Hm, Jres, x);
@@ -275,6 +276,8 @@ __global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__re
     r.n_meas = n_meas / 16;
     for (int i = 0; i < SDVL_MAX_LEVELS; i++) r.its[i] = its[i];
     r.stop = stop ? 1 : 0;
+    r.iters_run = iters_run;
+    r.pad_ = 0;
     out[blockIdx.x] = r;
   }
 }
@@ -314,7 +317,7 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
   if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, res_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, res_bytes, true);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   IaJob *hj = static_cast<IaJob *>(ctx->h_stage);
   uint8_t *wbase = static_cast<uint8_t *>(ctx->d_work);
   size_t woff = 0;
@@ -348,7 +351,7 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(out, ctx->h_out, res_bytes);
   return SDVL_OK;
 }

@@ -17,9 +17,10 @@ struct FrameView {
   uint8_t *level[SDVL_MAX_LEVELS];  // level[l] row-major, row stride = lw[l]
   int32_t lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
   int32_t levels;
-  int32_t n_corners;
-  int32_t *corners;  // [SDVL_MAX_CORNERS][4]: x, y, level, pad
-  uint8_t *desc;     // [SDVL_MAX_CORNERS][32]
+  int32_t n_corners;    // host copy of the corner count, -1 = only known on the device (after sdvl_detect_corners)
+  int32_t *corner_hdr;  // device: [4] = {count, 0, 0, 0}, immediately followed by `corners`
+  int32_t *corners;     // device: [SDVL_MAX_CORNERS][4]: x, y, level, pad
+  uint8_t *desc;        // device: [SDVL_MAX_CORNERS][32]
 };
 
 struct sdvl_frame {
@@ -29,6 +30,8 @@ struct sdvl_frame {
   int width, height;
   uint32_t *cell_kps;    // [total_cells][SDVL_CELL_KP_CAP] packed (x | y<<12 | score<<24), level coordinates
   int32_t *cell_counts;  // [total_cells]
+  int32_t *level_corners;  // [4][SDVL_MAX_CORNERS][4] per-level output segments of the selection kernel
+  int32_t *level_counts;   // [4]
   int max_cells;
   int desc_valid;
 };
@@ -49,6 +52,10 @@ struct sdvl_ctx {
   void *h_out = nullptr;   size_t h_out_bytes = 0;
   void *d_out = nullptr;   size_t d_out_bytes = 0;
   void *d_work = nullptr;  size_t d_work_bytes = 0;
+  // corner counts of the last sdvl_detect_corners batch, written by the pack kernel: one D2H serves all frames
+  void *d_counts = nullptr; size_t d_counts_bytes = 0;
+  std::vector<sdvl_frame *> detect_frames;
+  hipEvent_t wait_event = nullptr;  // created with hipEventBlockingSync | hipEventDisableTiming
   // per-kernel timing (HIP events on `stream`)
   int timing = 0;
   std::vector<KernelTimer> timers;
@@ -75,6 +82,10 @@ struct sdvl_ctx {
   } while (0)
 
 int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);
+// wait for everything queued on ctx->stream WITHOUT spinning: hipEventBlockingSync event + hipEventSynchronize.
+hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
+// host copy of a frame's corner count; fetches it (blocking) when only the device knows it
+int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n);
 int sdvl_timer_begin(sdvl_ctx *ctx, const char *name);  // returns pending index or -1
 void sdvl_timer_end(sdvl_ctx *ctx, int pending);
 

@@ -26,6 +26,7 @@ struct OrbJob {
   uint8_t *out;            // optional second copy (host-bound buffer), may be null
   float *out_angle;        // optional
   double *out_score;       // shi-tomasi output
+  const int32_t *n_ptr;    // device-resident corner count (frame header); null -> use n
   int n;
   int levels;
 };
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
   const OrbJob &job = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ci >= job.n) return;  // wave-uniform
+  const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
+  if (ci >= n) return;  // wave-uniform
   const int cx = job.corners[4 * ci], cy = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
   if (cl < 0 || cl >= job.levels) return;
   const int W = job.lw[cl], H = job.lh[cl];
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restric
   const OrbJob &job = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ci >= job.n) return;
+  const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
+  if (ci >= n) return;
   const int px = job.corners[4 * ci], py = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
   if (cl < 0 || cl >= job.levels) return;
   const int W = job.lw[cl], H = job.lh[cl];
@@ -151,7 +154,7 @@ int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t 
   int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, bytes, false);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   OrbJob *hj = static_cast<OrbJob *>(ctx->h_stage);
   *max_n = 0;
   for (int i = 0; i < n; i++) {
@@ -163,9 +166,11 @@ int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t 
     hj[i].out = d_out_desc ? d_out_desc + static_cast<size_t>(i) * cap * 32 : nullptr;
     hj[i].out_angle = nullptr;
     hj[i].out_score = d_out_score ? d_out_score + static_cast<size_t>(i) * cap : nullptr;
+    hj[i].n_ptr = v.corner_hdr;
     hj[i].n = v.n_corners;
     hj[i].levels = v.levels;
-    if (v.n_corners > *max_n) *max_n = v.n_corners;
+    const int bound = v.n_corners >= 0 ? v.n_corners : SDVL_MAX_CORNERS / 2;  // device-only count: launch for the capacity
+    if (bound > *max_n) *max_n = bound;
   }
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
   *d_jobs = static_cast<OrbJob *>(ctx->d_stage);
@@ -181,6 +186,11 @@ int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, 
   if (n == 0) return SDVL_OK;
   for (int i = 0; i < n; i++) {
     SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    if (out_desc) {
+      int cnt = 0;
+      int rc0 = sdvl_frame_count_host(ctx, frames[i], &cnt);
+      if (rc0) return rc0;
+    }
     if (out_desc && frames[i]->v.n_corners > cap) {
       ctx->err = "descriptor output capacity smaller than the corner count";
       return SDVL_ERR_CAPACITY;
@@ -208,7 +218,7 @@ int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, 
     if (max_n > 0) {
       SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, static_cast<size_t>(cap) * 32, d_desc, static_cast<size_t>(cap) * 32,
                                            static_cast<size_t>(max_n) * 32, n, hipMemcpyDeviceToHost, ctx->stream));
-      SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
       for (int i = 0; i < n; i++)
         memcpy(out_desc + static_cast<size_t>(i) * cap * 32, static_cast<uint8_t *>(ctx->h_out) + static_cast<size_t>(i) * cap * 32,
                static_cast<size_t>(frames[i]->v.n_corners) * 32);
@@ -222,6 +232,9 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   if (n == 0) return SDVL_OK;
   for (int i = 0; i < n; i++) {
     SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    int cnt = 0;
+    int rc0 = sdvl_frame_count_host(ctx, frames[i], &cnt);
+    if (rc0) return rc0;
     if (frames[i]->v.n_corners > cap) {
       ctx->err = "score output capacity smaller than the corner count";
       return SDVL_ERR_CAPACITY;
@@ -243,7 +256,7 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, sizeof(double) * cap, ctx->d_out, sizeof(double) * cap, sizeof(double) * max_n, n,
                                        hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   for (int i = 0; i < n; i++)
     memcpy(out_scores + static_cast<size_t>(i) * cap, static_cast<double *>(ctx->h_out) + static_cast<size_t>(i) * cap,
            sizeof(double) * frames[i]->v.n_corners);
@@ -252,6 +265,11 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
 
 int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap, uint8_t *out) {
   if (!ctx || !f || !out) return SDVL_ERR_INVALID;
+  {
+    int cnt = 0;
+    int rc0 = sdvl_frame_count_host(ctx, const_cast<sdvl_frame *>(f), &cnt);
+    if (rc0) return rc0;
+  }
   SDVL_REQUIRE(ctx, f->desc_valid || f->v.n_corners == 0, "frame has no ORB descriptors (call sdvl_orb_describe)");
   if (f->v.n_corners > cap) {
     ctx->err = "descriptor output capacity smaller than the corner count";
@@ -259,7 +277,7 @@ int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap,
   }
   if (f->v.n_corners == 0) return SDVL_OK;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(out, f->v.desc, static_cast<size_t>(f->v.n_corners) * 32, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   return SDVL_OK;
 }
 
@@ -280,7 +298,7 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, a_off + a_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, a_off + a_bytes, true);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   int32_t *hc = static_cast<int32_t *>(ctx->h_stage);
   for (int i = 0; i < n; i++) { hc[4 * i] = xyl[3 * i]; hc[4 * i + 1] = xyl[3 * i + 1]; hc[4 * i + 2] = xyl[3 * i + 2]; hc[4 * i + 3] = 0; }
   OrbJob *hj = reinterpret_cast<OrbJob *>(static_cast<uint8_t *>(ctx->h_stage) + job_off);
@@ -290,6 +308,7 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   hj->desc = static_cast<uint8_t *>(ctx->d_out);
   hj->out = nullptr;
   hj->out_angle = reinterpret_cast<float *>(static_cast<uint8_t *>(ctx->d_out) + a_off);
+  hj->n_ptr = nullptr;
   hj->n = n;
   hj->levels = f->v.levels;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, job_off + sizeof(OrbJob), hipMemcpyHostToDevice, ctx->stream));
@@ -300,7 +319,7 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, a_off + a_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(out_desc, ctx->h_out, d_bytes);
   if (out_angle_deg) memcpy(out_angle_deg, static_cast<uint8_t *>(ctx->h_out) + a_off, a_bytes);
   return SDVL_OK;

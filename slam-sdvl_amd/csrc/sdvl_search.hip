@@ -26,8 +26,9 @@ struct SearchFrame {
   int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
   const int32_t *corners;
   const uint8_t *desc;
-  int n_corners;
+  const int32_t *n_ptr;  // device-resident corner count
   int levels;
+  int pad_;
 };
 
 struct SearchReqDev {
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
       sumA = wave_sum_i32(pv);
       sumAA = wave_sum_i32(pv * pv);
     }
-    for (int ci = lane; ci < cf.n_corners; ci += 64) {
+    const int n_corners = min(cf.n_ptr[0], SDVL_MAX_CORNERS);
+    for (int ci = lane; ci < n_corners; ci += 64) {
       const int cx = cf.corners[4 * ci], cy = cf.corners[4 * ci + 1], cl = cf.corners[4 * ci + 2];
       int d = cl - level;
       if (d < 0) d = -d;
@@ -417,7 +419,7 @@ void fill_frame(SearchFrame *d, const sdvl_frame *f) {
   }
   d->corners = f->v.corners;
   d->desc = f->v.desc;
-  d->n_corners = f->v.n_corners;
+  d->n_ptr = f->v.corner_hdr;
   d->levels = f->v.levels;
 }
 
@@ -437,7 +439,6 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     SDVL_REQUIRE(ctx, r.cur && r.ref, "null frame in search request");
     SDVL_REQUIRE(ctx, r.level >= 0 && r.level < r.ref->v.levels, "feature level outside the reference pyramid");
     SDVL_REQUIRE(ctx, p->max_fast_levels <= r.cur->v.levels, "max_fast_levels exceeds the pyramid depth");
-    SDVL_REQUIRE(ctx, r.cur->v.n_corners < (1 << 20), "too many corners");
     if (p->use_orb) SDVL_REQUIRE(ctx, r.cur->v.n_corners == 0 || r.cur->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
     SDVL_REQUIRE(ctx, r.idepth == r.idepth && r.idepth != 0.0, "inverse depth must be finite and non-zero");
   }
@@ -448,7 +449,7 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
   if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   SearchReqDev *hd = static_cast<SearchReqDev *>(ctx->h_stage);
   for (int i = 0; i < n; i++) {
     const sdvl_search_req &r = reqs[i];
@@ -473,7 +474,7 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(out, ctx->h_out, out_bytes);
   return SDVL_OK;
 }
@@ -492,7 +493,7 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
   if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, ob, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, ob, true);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   PatchJob *hj = static_cast<PatchJob *>(ctx->h_stage);
   for (int i = 0; i < n; i++) {
     SDVL_REQUIRE(ctx, frames[i] && levels[i] >= 0 && levels[i] < frames[i]->v.levels, "bad frame / level");
@@ -515,7 +516,7 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   const uint8_t *ho = static_cast<const uint8_t *>(ctx->h_out);
   memcpy(uv_io, ho, sizeof(double) * 2 * n);
   if (its) memcpy(its, ho + ob_uv, sizeof(int32_t) * n);

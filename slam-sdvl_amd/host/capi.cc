@@ -3,6 +3,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sdvl_host.h"
@@ -27,6 +28,7 @@ extern "C" {
 struct sdvlh_frame_stats {
   int state, quality, matches, attempts, inliers, outliers, n_corners, align_meas, keyframe, relocalized;
   double pose[7];
+  int align_features, align_iters, search_requests, lk_iters;
 };
 
 const char *sdvlh_last_error() { return g_err.c_str(); }
@@ -90,12 +92,23 @@ static int step(Batch *b, const std::vector<Image> &imgs, sdvlh_frame_stats *out
       o.outliers = s.outliers; o.n_corners = s.n_corners; o.align_meas = s.align_meas; o.keyframe = s.keyframe;
       o.relocalized = s.relocalized;
       std::memcpy(o.pose, s.pose, sizeof(o.pose));
+      o.align_features = s.align_features; o.align_iters = s.align_iters; o.search_requests = s.search_requests; o.lk_iters = s.lk_iters;
     }
     return 0;
   } catch (const std::exception &e) {
     g_err = e.what();
     return -1;
   }
+}
+
+// accumulated wall time per SDVLBatch stage (seconds, sdvl::StageId order); returns the number of steps; reset != 0 clears
+long sdvlh_batch_stage_times(void *bp, double *out, int cap, int reset) {
+  Batch *b = static_cast<Batch *>(bp);
+  StageTimes &st = b->batch->stage_times;
+  for (int i = 0; i < cap && i < ST_COUNT; i++) out[i] = st.t[i];
+  const long n = st.steps;
+  if (reset) st = StageTimes();
+  return n;
 }
 
 // imgs: B host pointers (row stride `stride`)
@@ -112,6 +125,67 @@ int sdvlh_batch_step_device(void *bp, const void *const *dev_imgs, int stride, s
   std::vector<Image> v;
   for (size_t i = 0; i < b->trackers.size(); i++) v.push_back(Image::WrapDevice(dev_imgs[i], b->w, b->h, stride));
   return step(b, v, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Farm: G groups x Bg sequences on ONE GPU.  Every group owns a host thread, an sdvl::Device (= sdvl_ctx = HIP stream
+// + staging + frame pool) and an SDVLBatch; groups free-run through their steps, so the host stages of one group
+// overlap the kernels and PCIe copies of the others (one context per host thread, as include/sdvl_hip.h prescribes).
+struct Farm {
+  int gpu, G, Bg, w, h;
+  std::vector<void *> devices;
+  std::vector<void *> batches;
+  std::string err;
+};
+
+void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4, const double *plane4, const double *first_poses7,
+                        int host_threads_per_group) {
+  Farm *f = new Farm();
+  f->gpu = gpu; f->G = G; f->Bg = Bg; f->w = w; f->h = h;
+  for (int g = 0; g < G; g++) {
+    void *d = sdvlh_device_create(gpu);
+    if (!d) { delete f; return nullptr; }
+    f->devices.push_back(d);
+    void *b = sdvlh_batch_create(d, Bg, w, h, cam4, plane4, first_poses7 + static_cast<size_t>(7) * g * Bg, host_threads_per_group);
+    if (!b) { delete f; return nullptr; }
+    f->batches.push_back(b);
+  }
+  return f;
+}
+
+void sdvlh_farm_destroy(void *fp) {
+  Farm *f = static_cast<Farm *>(fp);
+  if (!f) return;
+  for (void *b : f->batches) sdvlh_batch_destroy(b);
+  for (void *d : f->devices) sdvlh_device_destroy(d);
+  delete f;
+}
+
+void *sdvlh_farm_ctx(void *fp, int g) { return sdvlh_device_ctx(static_cast<Farm *>(fp)->devices[g]); }
+void *sdvlh_farm_batch(void *fp, int g) { return static_cast<Farm *>(fp)->batches[g]; }
+
+// Runs n_steps steps.  dev_frames[(step * G*Bg) + g*Bg + i] = device pointer of the frame of sequence (g, i) at that step
+// (row stride = `stride`).  out[(step * G*Bg) + g*Bg + i] receives its stats.  Returns 0, or -1 with sdvlh_last_error.
+int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int stride, sdvlh_frame_stats *out) {
+  Farm *f = static_cast<Farm *>(fp);
+  const int total = f->G * f->Bg;
+  std::vector<std::thread> threads;
+  std::vector<std::string> errs(f->G);
+  for (int g = 0; g < f->G; g++) {
+    threads.emplace_back([=, &errs]() {
+      for (int s = 0; s < n_steps; s++) {
+        const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * f->Bg;
+        if (sdvlh_batch_step_device(f->batches[g], dev_frames + off, stride, out + off) != 0) {
+          errs[g] = sdvlh_last_error();
+          return;
+        }
+      }
+    });
+  }
+  for (auto &t : threads) t.join();
+  for (int g = 0; g < f->G; g++)
+    if (!errs[g].empty()) { g_err = errs[g]; return -1; }
+  return 0;
 }
 
 }  // extern "C"

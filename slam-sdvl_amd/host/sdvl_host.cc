@@ -10,6 +10,7 @@
 #include <iostream>
 #include <mutex>
 #include <stdexcept>
+#include <chrono>
 #include <thread>
 
 namespace sdvl {
@@ -19,6 +20,19 @@ using std::vector;
 
 // ------------------------------------------------------------------------------------------------------ Device
 static thread_local Device *g_current_device = nullptr;
+static thread_local StageTimes *g_stage_times = nullptr;
+StageTimes *&StageTimes::Active() { return g_stage_times; }
+
+namespace {
+struct StageClock {
+  int id;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageClock(int i) : id(i), t0(std::chrono::steady_clock::now()) {}
+  ~StageClock() {
+    if (g_stage_times) g_stage_times->t[id] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+}  // namespace
 
 Device::Device(int gpu) {
   const int rc = sdvl_ctx_create(gpu, &ctx_);
@@ -278,7 +292,9 @@ void FastDetector::FilterCorners(const vector<Image> &pyramid, const vector<Vect
   }
   Device *dev = Device::Current();
   sdvl_frame *fr = pyramid[0].dev;
-  if (sdvl_frame_num_corners(fr) != static_cast<int>(corners.size())) {
+  int32_t dev_count = 0;
+  dev->Check(sdvl_frames_corner_counts(dev->ctx(), 1, &fr, &dev_count), "sdvl_frames_corner_counts");
+  if (dev_count != static_cast<int>(corners.size())) {
     std::cerr << "[ERROR] FastDetector::FilterCorners: corners differ from the frame's HBM corner list" << std::endl;
     return;
   }
@@ -388,55 +404,22 @@ void Frame::InitCommon(Camera *camera, ORBDetector *detector, int w, int h) {
 
 namespace {
 // pyramid + FAST + selection + ORB for a set of already-initialised frames (frame.cc:34-56 for each)
-void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs, const vector<Image> &imgs, bool corners, int nfeatures,
-                 vector<vector<Vector3i> *> corner_lists, const std::function<void(int, std::function<void(int)>)> *pfor) {
+void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs, const vector<Image> &imgs, bool corners, int nfeatures) {
   Device *dev = Device::Current();
   const int n = static_cast<int>(frames.size());
   if (n == 0) return;
+  std::unique_ptr<StageClock> clk(new StageClock(ST_UPLOAD_PYR));
   for (int i = 0; i < n; i++) {
     if (imgs[i].dev_src) dev->Check(sdvl_frame_set_image_device(dev->ctx(), devs[i], imgs[i].dev_src, imgs[i].step), "sdvl_frame_set_image_device");
     else dev->Check(sdvl_frame_upload(dev->ctx(), devs[i], imgs[i].data, imgs[i].step), "sdvl_frame_upload");
   }
   dev->Check(sdvl_pyramid_build(dev->ctx(), n, devs.data()), "sdvl_pyramid_build");
   if (!corners) return;
+  // FastDetector::DetectPyramid on the device (FAST + quota + retainBest in libstdc++ order); nothing returns to the host
   const sdvl_detect_params dp = DetectParams();
-  const int W = imgs[0].cols, H = imgs[0].rows;
-  int cpl[4] = {0, 0, 0, 0}, total = 0;
-  dev->Check(sdvl_fast_num_cells(W, H, &dp, cpl, &total), "sdvl_fast_num_cells");
-  const int cap = 32768;
-  static thread_local vector<sdvl_keypoint> kps;
-  static thread_local vector<int32_t> offs;
-  kps.resize(static_cast<size_t>(n) * cap);
-  offs.resize(static_cast<size_t>(n) * (total + 1));
-  dev->Check(sdvl_fast_cells(dev->ctx(), n, devs.data(), &dp, cap, kps.data(), offs.data()), "sdvl_fast_cells");
-  // quota per level, fast_detector.cc:161-174
-  const double scale = 1.2;
-  double factor = 1.0, val = 0.0;
-  for (int i = 0; i < Config::MaxFastLevels(); i++) { val += factor; factor /= scale; }
-  const int first_quota = static_cast<int>(nfeatures / val);
-  // plain pointers: a lambda body that names a thread_local variable reads the EXECUTING thread's instance
-  const sdvl_keypoint *kps_p = kps.data();
-  const int32_t *offs_p = offs.data();
-  auto select_one = [&, kps_p, offs_p](int i) {
-    int levelfeatures = first_quota, begin = 0, lw = W, lh = H;
-    for (int l = 0; l < Config::MaxFastLevels(); l++) {
-      const int wc = (lw + dp.cell_size - 1) / dp.cell_size, hc = (lh + dp.cell_size - 1) / dp.cell_size;
-      FastDetector::SelectFromCells(kps_p + static_cast<size_t>(i) * cap, offs_p + static_cast<size_t>(i) * (total + 1), begin, wc, hc,
-                                    l, lw, lh, levelfeatures, corner_lists[i]);
-      begin += cpl[l];
-      levelfeatures = static_cast<int>(levelfeatures / scale);
-      lw /= 2;
-      lh /= 2;
-    }
-  };
-  if (pfor) (*pfor)(n, select_one);
-  else for (int i = 0; i < n; i++) select_one(i);
-  vector<int32_t> counts(n), xyl;
-  for (int i = 0; i < n; i++) {
-    counts[i] = static_cast<int32_t>(corner_lists[i]->size());
-    for (const Vector3i &c : *corner_lists[i]) { xyl.push_back(c(0)); xyl.push_back(c(1)); xyl.push_back(c(2)); }
-  }
-  dev->Check(sdvl_frames_set_corners(dev->ctx(), n, devs.data(), counts.data(), xyl.data()), "sdvl_frames_set_corners");
+  clk.reset(new StageClock(ST_FAST));
+  dev->Check(sdvl_detect_corners(dev->ctx(), n, devs.data(), &dp, nfeatures), "sdvl_detect_corners");
+  clk.reset(new StageClock(ST_CORNERS_ORB));
   if (Config::UseORB()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
 }
 }  // namespace
@@ -444,8 +427,8 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
 // frame.cc:34-56
 Frame::Frame(Camera *camera, ORBDetector *detector, const Image &img, bool corners) {
   InitCommon(camera, detector, img.cols, img.rows);
-  BuildFrames({this}, {dev_}, {img}, corners, Config::NumFeatures(), {&corners_}, nullptr);
-  if (corners && Config::UseORB()) descriptors_.resize(corners_.size());
+  BuildFrames({this}, {dev_}, {img}, corners, Config::NumFeatures());
+  corners_on_host_ = !corners;
 }
 
 void Frame::CreateBatch(Camera *camera, ORBDetector *detector, const vector<Image> &imgs, bool corners, int nfeatures,
@@ -453,19 +436,17 @@ void Frame::CreateBatch(Camera *camera, ORBDetector *detector, const vector<Imag
   const int n = static_cast<int>(imgs.size());
   vector<Frame *> raw(n);
   vector<sdvl_frame *> devs(n);
-  vector<vector<Vector3i> *> lists(n);
   out->clear();
   for (int i = 0; i < n; i++) {
     shared_ptr<Frame> f(new Frame());
     f->InitCommon(camera, detector, imgs[i].cols, imgs[i].rows);
     raw[i] = f.get();
     devs[i] = f->dev_;
-    lists[i] = &f->corners_;
+    f->corners_on_host_ = !corners;
     out->push_back(f);
   }
-  BuildFrames(raw, devs, imgs, corners, nfeatures, lists, pfor);
-  if (corners && Config::UseORB())
-    for (auto &f : *out) f->descriptors_.resize(f->corners_.size());
+  (void)pfor;
+  BuildFrames(raw, devs, imgs, corners, nfeatures);
 }
 
 Frame::~Frame() {
@@ -479,19 +460,35 @@ Frame::~Frame() {
 
 // frame.cc:122-131
 void Frame::CreateCorners(int, int nfeatures) {
-  corners_.clear();
-  FastDetector detector(width_, height_, false);
-  detector.DetectPyramid(pyramid_, &corners_, nfeatures);
   Device *dev = Device::Current();
-  vector<int32_t> xyl;
-  for (const Vector3i &c : corners_) { xyl.push_back(c(0)); xyl.push_back(c(1)); xyl.push_back(c(2)); }
-  dev->Check(sdvl_frame_set_corners(dev->ctx(), dev_, static_cast<int>(corners_.size()), xyl.data()), "sdvl_frame_set_corners");
+  const sdvl_detect_params dp = DetectParams();
+  corners_.clear();
   descriptors_.clear();
   descriptors_on_host_ = false;
-  if (Config::UseORB()) {
-    dev->Check(sdvl_orb_describe(dev->ctx(), 1, &dev_, SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
-    descriptors_.resize(corners_.size());
+  dev->Check(sdvl_detect_corners(dev->ctx(), 1, &dev_, &dp, nfeatures), "sdvl_detect_corners");
+  corners_on_host_ = false;
+  if (Config::UseORB()) dev->Check(sdvl_orb_describe(dev->ctx(), 1, &dev_, SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
+}
+
+vector<Vector3i> &Frame::GetCorners() {
+  if (!corners_on_host_) {
+    Device *dev = Device::Current();
+    vector<int32_t> xyl(static_cast<size_t>(SDVL_MAX_CORNERS) * 3);
+    int n = 0;
+    dev->Check(sdvl_frame_download_corners(dev->ctx(), dev_, SDVL_MAX_CORNERS, xyl.data(), &n), "sdvl_frame_download_corners");
+    corners_.resize(n);
+    for (int i = 0; i < n; i++) corners_[i] = Vector3i(xyl[3 * i], xyl[3 * i + 1], xyl[3 * i + 2]);
+    corners_on_host_ = true;
   }
+  return corners_;
+}
+
+int Frame::GetNumCorners() {
+  if (corners_on_host_) return static_cast<int>(corners_.size());
+  Device *dev = Device::Current();
+  int32_t n = 0;
+  dev->Check(sdvl_frames_corner_counts(dev->ctx(), 1, &dev_, &n), "sdvl_frames_corner_counts");
+  return n;
 }
 
 vector<Image> &Frame::GetPyramid() {
@@ -509,7 +506,7 @@ vector<Image> &Frame::GetPyramid() {
 }
 
 vector<vector<uchar>> &Frame::GetDescriptors() {
-  if (!descriptors_on_host_ && Config::UseORB() && !corners_.empty()) {
+  if (!descriptors_on_host_ && Config::UseORB() && !GetCorners().empty()) {
     Device *dev = Device::Current();
     vector<uint8_t> buf(corners_.size() * 32);
     dev->Check(sdvl_frame_download_descriptors(dev->ctx(), dev_, static_cast<int>(corners_.size()), buf.data()), "sdvl_frame_download_descriptors");
@@ -528,7 +525,10 @@ void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
   if (n == 0) return;
   Device *dev = Device::Current();
   vector<sdvl_frame *> devs(n);
-  for (int i = 0; i < n; i++) devs[i] = frames[i]->dev_;
+  for (int i = 0; i < n; i++) {
+    devs[i] = frames[i]->dev_;
+    frames[i]->GetCorners();  // the grid logic below walks the corner list on the host
+  }
   vector<double> scores(static_cast<size_t>(n) * SDVL_MAX_CORNERS);
   dev->Check(sdvl_shi_tomasi(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, scores.data()), "sdvl_shi_tomasi");
   for (int i = 0; i < n; i++) {
@@ -572,10 +572,11 @@ static sdvl_align_params AlignParams(bool fast) {
 
 // image_align.cc:46-84 for n pairs with one launch
 void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> &pairs, bool fast, vector<int> *n_meas,
-                                  vector<double> *errors) {
+                                  vector<double> *errors, vector<int> *iters) {
   const int n = static_cast<int>(pairs.size());
   n_meas->assign(n, 0);
   errors->assign(n, 1e10);
+  if (iters) iters->assign(n, 0);
   vector<sdvl_align_job> jobs;
   vector<int> job_of;
   vector<sdvl_align_feature> feats;
@@ -624,6 +625,7 @@ void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shar
     pairs[i].second->SetPose(SE3::FromArray(res[j].T) * pairs[i].first->GetPose());  // image_align.cc:79
     (*n_meas)[i] = res[j].n_meas;
     (*errors)[i] = res[j].error;
+    if (iters) (*iters)[i] = res[j].iters_run;
   }
 }
 
@@ -1212,19 +1214,21 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   const int B = static_cast<int>(trk_.size());
   if (static_cast<int>(imgs.size()) != B) throw std::runtime_error("SDVLBatch::HandleFrames: one image per tracker");
   Device::SetCurrent(dev_);
+  g_stage_times = &stage_times;
+  stage_times.steps++;
   const std::function<void(int, std::function<void(int)>)> pfor = [this](int n, std::function<void(int)> fn) { ParallelFor(n, fn); };
 
   // ---- stage 0: Frame construction (pyramid + FAST + selection + ORB), sdvl.cc:59
   vector<shared_ptr<Frame>> frames;
   Frame::CreateBatch(trk_[0]->camera_, &trk_[0]->orb_detector_, imgs, true, Config::NumFeatures(), &frames, &pfor);
   vector<int> run;  // trackers that execute ProcessFrame this step
+  std::unique_ptr<StageClock> clk(new StageClock(ST_PRELUDE));
   for (int i = 0; i < B; i++) {
     SDVL &t = *trk_[i];
     FrameStats &st = stats[i];
     st = FrameStats();
     t.current_frame_ = frames[i];
     t.current_frame_->SetID(t.frame_counter_++);
-    st.n_corners = static_cast<int>(frames[i]->GetCorners().size());
     if (t.state_ != SDVL::STATE_RUNNING) {
       // bootstrap replacement (SaveFirstFrame/SaveSecondFrame are out of scope): first frame = keyframe at first_pose
       t.current_frame_->SetPose(t.first_pose_);
@@ -1270,18 +1274,24 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
 
   // ---- stage 1: ImageAlign for every running tracker, sdvl.cc:185-190
   const int R = static_cast<int>(run.size());
+  clk.reset(new StageClock(ST_IMAGE_ALIGN));
   {
     vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> pairs;
     for (int i : run) pairs.push_back({trk_[i]->last_frame_, trk_[i]->current_frame_});
-    vector<int> n_meas;
+    vector<int> n_meas, iters;
     vector<double> errors;
-    ImageAlign::ComputePoseBatch(pairs, false, &n_meas, &errors);
-    for (int k = 0; k < R; k++) stats[run[k]].align_meas = n_meas[k];
+    ImageAlign::ComputePoseBatch(pairs, false, &n_meas, &errors, &iters);
+    for (int k = 0; k < R; k++) {
+      stats[run[k]].align_meas = n_meas[k];
+      stats[run[k]].align_iters = iters[k];
+      stats[run[k]].align_features = static_cast<int>(pairs[k].first->GetFeatures().size());
+    }
   }
 
   // ---- stage 2: FeatureAlign::Reproject, sdvl.cc:193 — all candidates of all trackers in one launch
   {
     vector<vector<sdvl_search_req>> per(R);
+    clk.reset(new StageClock(ST_PREPARE));
     ParallelFor(R, [&](int k) {
       SDVL &t = *trk_[run[k]];
       t.feature_align_.PrepareReproject(t.current_frame_, t.last_frame_, false, &per[k]);
@@ -1294,12 +1304,16 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     }
     begin[R] = reqs.size();
     vector<sdvl_search_res> res;
+    clk.reset(new StageClock(ST_SEARCH));
     if (R > 0) Matcher::SearchPoints(dev_, reqs, *trk_[run[0]]->camera_, &res);
+    clk.reset(new StageClock(ST_FINISH));
     // ---- stage 3: replay + RANSAC + pose refinement + bookkeeping, sdvl.cc:193-127
     ParallelFor(R, [&](int k) {
       const int i = run[k];
       SDVL &t = *trk_[i];
       FrameStats &st = stats[i];
+      st.search_requests = static_cast<int>(begin[k + 1] - begin[k]);
+      for (size_t q = begin[k]; q < begin[k + 1]; q++) st.lk_iters += res[q].lk_its;
       t.feature_align_.FinishReproject(t.current_frame_, res.data() + begin[k]);
       t.matches_ = t.feature_align_.GetMatches();
       t.attempts_ = t.feature_align_.GetAttempts();
@@ -1331,6 +1345,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   }
 
   // ---- stage 4: mapper stand-in for fresh keyframes (sequential mode, main.cc:148-149): one K3 launch for all
+  clk.reset(new StageClock(ST_MAPPING));
   {
     vector<shared_ptr<Frame>> kfs;
     vector<int> owner;
@@ -1347,6 +1362,14 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     }
   }
 
+  clk.reset(new StageClock(ST_EPILOGUE));
+  {
+    vector<sdvl_frame *> devs(B);
+    vector<int32_t> counts(B);
+    for (int i = 0; i < B; i++) devs[i] = frames[i]->device();
+    dev_->Check(sdvl_frames_corner_counts(dev_->ctx(), B, devs.data(), counts.data()), "sdvl_frames_corner_counts");
+    for (int i = 0; i < B; i++) stats[i].n_corners = counts[i];
+  }
   for (int i = 0; i < B; i++) {
     SDVL &t = *trk_[i];
     FrameStats &st = stats[i];
@@ -1358,6 +1381,8 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     t.current_frame_ = nullptr;
     t.map_->EmptyTrash();  // sdvl.cc:127
   }
+  clk.reset();
+  g_stage_times = nullptr;
 }
 
 }  // namespace sdvl

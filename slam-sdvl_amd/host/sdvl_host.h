@@ -217,7 +217,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void SetPose(const SE3 &se3) { pose_ = se3; }
   std::vector<Image> &GetPyramid();  // host mirror is filled on first call
   std::vector<std::shared_ptr<Feature>> &GetFeatures() { return features_; }
-  std::vector<Vector3i> &GetCorners() { return corners_; }
+  std::vector<Vector3i> &GetCorners();  // host mirror of the HBM corner list, filled on first call
+  int GetNumCorners();                  // corner count without mirroring the list
   std::vector<int> &GetFilteredCorners() { return filtered_corners_; }
   std::vector<Vector2d> &GetOutliers() { return outliers_; }
   std::vector<std::vector<uchar>> &GetDescriptors();  // host mirror of the HBM descriptors
@@ -257,6 +258,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   std::vector<Vector2d> outliers_;
   std::vector<std::vector<uchar>> descriptors_;
   bool descriptors_on_host_ = false;
+  bool corners_on_host_ = true;  // false after a device-side DetectPyramid until GetCorners() mirrors the list
   sdvl_frame *dev_ = nullptr;
   Device *owner_ = nullptr;
   static int counter_;
@@ -270,7 +272,7 @@ class ImageAlign {
   double GetError() { return error_; }
   // n frame pairs, one launch; returns per-pair ComputePose results and errors
   static void ComputePoseBatch(const std::vector<std::pair<std::shared_ptr<Frame>, std::shared_ptr<Frame>>> &pairs, bool fast,
-                               std::vector<int> *n_meas, std::vector<double> *errors);
+                               std::vector<int> *n_meas, std::vector<double> *errors, std::vector<int> *iters = nullptr);
 
  private:
   double error_ = 1e10;
@@ -375,10 +377,21 @@ class FeatureAlign {
   static constexpr double KTukeyC = 4.6851 * 4.6851;
 };
 
+// wall-clock per stage of SDVLBatch::HandleFrames, accumulated (seconds); index = StageId
+enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_MAPPING,
+               ST_EPILOGUE, ST_COUNT };
+struct StageTimes {
+  double t[ST_COUNT] = {0};
+  long steps = 0;
+  static StageTimes *&Active();  // stage clock of the batch currently running on this thread (may be null)
+};
+
 struct FrameStats {
   int state = 0, quality = 0, matches = 0, attempts = 0, inliers = 0, outliers = 0, n_corners = 0, align_meas = 0, keyframe = 0,
       relocalized = 0;
   double pose[7] = {1, 0, 0, 0, 0, 0, 0};
+  // traffic accounting: features / GN evaluations of the alignment job, SearchPoint requests / LK iterations
+  int align_features = 0, align_iters = 0, search_requests = 0, lk_iters = 0;
 };
 
 class SDVLBatch;
@@ -427,6 +440,9 @@ class SDVLBatch {
 
  private:
   void ParallelFor(int n, const std::function<void(int)> &fn);
+ public:
+  StageTimes stage_times;
+ private:
   Device *dev_;
   std::vector<SDVL *> trk_;
   int threads_;

@@ -11,7 +11,8 @@ HOST_LIB_PATH = os.path.join(_HERE, "host", "libsdvl_host.so")
 
 class FrameStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("state", "quality", "matches", "attempts", "inliers", "outliers", "n_corners",
-                                       "align_meas", "keyframe", "relocalized")] + [("pose", C.c_double * 7)]
+                                       "align_meas", "keyframe", "relocalized")] + [("pose", C.c_double * 7)] + [
+        (n, C.c_int) for n in ("align_features", "align_iters", "search_requests", "lk_iters")]
 
 
 _lib = None
@@ -95,7 +96,73 @@ class TrackerBatch:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return self._stats
 
+    STAGES = ["upload_pyr", "fast", "select", "corners_orb", "prelude", "image_align", "prepare", "search", "finish", "mapping",
+              "epilogue"]
+
+    def stage_times(self, reset=False):
+        """accumulated wall seconds per host stage of SDVLBatch::HandleFrames -> (dict, steps)"""
+        out = (C.c_double * len(self.STAGES))()
+        self.lib.sdvlh_batch_stage_times.restype = C.c_long
+        self.lib.sdvlh_batch_stage_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        n = self.lib.sdvlh_batch_stage_times(self.h, out, len(self.STAGES), int(reset))
+        return {k: out[i] for i, k in enumerate(self.STAGES)}, n
+
     def close(self):
         if self.h:
             self.lib.sdvlh_batch_destroy(self.h)
+            self.h = None
+
+
+class TrackerFarm:
+    """G groups x Bg sequences on one GPU; each group = host thread + sdvl_ctx (stream) + SDVLBatch, free-running."""
+
+    def __init__(self, gpu, G, Bg, w, h, cam4, plane4=(0, 0, 1, 2.0), first_poses=None, host_threads_per_group=1):
+        self.lib = load_host_library()
+        self.G, self.Bg, self.w, self.h_img = G, Bg, w, h
+        n = G * Bg
+        cam4 = np.ascontiguousarray(cam4, np.float64)
+        plane4 = np.ascontiguousarray(plane4, np.float64)
+        if first_poses is None:
+            first_poses = np.tile(np.array([1, 0, 0, 0, 0, 0, 0], np.float64), (n, 1))
+        first_poses = np.ascontiguousarray(first_poses, np.float64).reshape(n, 7)
+        self.lib.sdvlh_farm_create.restype = C.c_void_p
+        self.lib.sdvlh_farm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.sdvlh_farm_destroy.argtypes = [C.c_void_p]
+        self.lib.sdvlh_farm_ctx.restype = C.c_void_p
+        self.lib.sdvlh_farm_ctx.argtypes = [C.c_void_p, C.c_int]
+        self.lib.sdvlh_farm_batch.restype = C.c_void_p
+        self.lib.sdvlh_farm_batch.argtypes = [C.c_void_p, C.c_int]
+        self.lib.sdvlh_farm_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self.h = self.lib.sdvlh_farm_create(gpu, G, Bg, w, h, cam4.ctypes.data, plane4.ctypes.data, first_poses.ctypes.data,
+                                            host_threads_per_group)
+        if not self.h:
+            raise RuntimeError("no MI355X: %s" % self.lib.sdvlh_last_error().decode())
+
+    def ctx_handle(self, g=0):
+        return self.lib.sdvlh_farm_ctx(self.h, g)
+
+    def run(self, dev_frames):
+        """dev_frames: int array [n_steps, G*Bg] of device pointers -> FrameStats array [n_steps*G*Bg]"""
+        dev_frames = np.ascontiguousarray(dev_frames, np.uint64)
+        n_steps = dev_frames.shape[0]
+        assert dev_frames.shape[1] == self.G * self.Bg
+        out = (FrameStats * (n_steps * self.G * self.Bg))()
+        if self.lib.sdvlh_farm_run(self.h, n_steps, dev_frames.ctypes.data, self.w, out) != 0:
+            raise RuntimeError(self.lib.sdvlh_last_error().decode())
+        return out
+
+    def stage_times(self, reset=False):
+        tot, steps = None, 0
+        self.lib.sdvlh_batch_stage_times.restype = C.c_long
+        self.lib.sdvlh_batch_stage_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        for g in range(self.G):
+            out = (C.c_double * len(TrackerBatch.STAGES))()
+            n = self.lib.sdvlh_batch_stage_times(self.lib.sdvlh_farm_batch(self.h, g), out, len(TrackerBatch.STAGES), int(reset))
+            steps += n
+            tot = [a + b for a, b in zip(tot, out)] if tot else list(out)
+        return {k: tot[i] for i, k in enumerate(TrackerBatch.STAGES)}, steps
+
+    def close(self):
+        if self.h:
+            self.lib.sdvlh_farm_destroy(self.h)
             self.h = None

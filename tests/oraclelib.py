@@ -135,6 +135,11 @@ class Oracle:
         assert n <= cap
         return out[:n].copy()
 
+    def retain_best(self, packed, n_points):
+        packed = np.ascontiguousarray(packed, np.uint32).copy()
+        n = self.lib.sdvl_ref_retain_best(ptr(packed, C.POINTER(C.c_uint32)), len(packed), int(n_points))
+        return packed[:n]
+
     def shi_tomasi(self, img, x, y):
         img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
         return self.lib.sdvl_ref_shi_tomasi(ptr(img, u8p), w, h, w, int(x), int(y))

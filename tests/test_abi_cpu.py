@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(sdvl):
     assert C.sizeof(sdvl.AlignJob) == 8 + 8 + 8 + 56
     assert C.sizeof(sdvl.SearchReq) == 8 + 8 + 56 + 56 + 16 + 24 + 16 + 16 + 8 + 32
     assert C.sizeof(sdvl.SearchRes) == 16 + 6 * 4
-    assert C.sizeof(sdvl.AlignResult) == 56 + 16 + 4 + 32 + 4
+    assert C.sizeof(sdvl.AlignResult) == 56 + 16 + 4 + 32 + 4 + 8
 
 
 def test_no_cpu_fallback_without_gpu(sdvl):

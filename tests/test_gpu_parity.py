@@ -93,6 +93,45 @@ def test_fast_cells_euroc_size(ctx, sdvl, orc, synth):
     assert check_fast(ctx, sdvl, orc, frames_of(synth, orc, EUROC_CAM, 752, 480, [3])) > 3000
 
 
+def test_device_retain_best_is_libstdcxx_order(ctx, orc):
+    """the device restatement of nth_element + partition leaves the list exactly as libstdc++ does"""
+    rng = np.random.default_rng(42)
+    cases = []
+    for n in [1, 2, 3, 4, 5, 7, 16, 33, 64, 169, 500, 1500, 4000]:
+        for hi in (4, 30, 255):                      # few distinct responses -> many ties; many -> few ties
+            sc = rng.integers(1, hi + 1, n).astype(np.uint32)
+            xy = np.arange(n, dtype=np.uint32)
+            v = (xy & 0xFFF) | (((xy >> 12) & 0xFFF) << 12) | (sc << 24)
+            for k in sorted({0, 1, 2, n // 3, n // 2, n - 1, n, n + 5}):
+                cases.append((v, k))
+    # adversarial shapes for introselect: sorted, reversed, organ pipe, constant
+    n = 3000
+    xy = np.arange(n, dtype=np.uint32)
+    for sc in (np.arange(n) % 250 + 1, (n - np.arange(n)) % 250 + 1, np.minimum(np.arange(n), n - np.arange(n)) % 250 + 1, np.full(n, 9)):
+        v = (xy & 0xFFF) | (((xy >> 12) & 0xFFF) << 12) | (sc.astype(np.uint32) << 24)
+        for k in (1, 17, 395, 1500, 2999):
+            cases.append((v, k))
+    for v, k in cases:
+        want = orc.retain_best(v, k)
+        got = ctx.retain_best(v, k)
+        assert np.array_equal(got, want), (len(v), k)
+
+
+@pytest.mark.parametrize("shape,cam,ks", [((480, 640), TUM_CAM, [0, 3, 11]), ((480, 752), EUROC_CAM, [2])])
+def test_detect_corners_on_device_equals_detect_pyramid(ctx, sdvl, orc, synth, shape, cam, ks):
+    """FastDetector::DetectPyramid entirely on device: same corners in the same order as the CPU path"""
+    h, w = shape
+    imgs = frames_of(synth, orc, cam, w, h, ks) + [rand_img(3, h, w)]
+    fr = [ctx.frame(im) for im in imgs]
+    for nfeat in (1000, 2000, 150):
+        got = ctx.detect_corners(fr, sdvl.default_detect_params(), nfeat)
+        for im, g in zip(imgs, got):
+            want = orc.detect_pyramid(im, nfeatures=nfeat)
+            assert np.array_equal(g, want), "nfeatures=%d" % nfeat
+    for f in fr:
+        f.close()
+
+
 # ------------------------------------------------------------------------------------------------ K3 / K4
 def test_shi_tomasi_and_orb_bit_exact(ctx, sdvl, orc, synth):
     img = frames_of(synth, orc, TUM_CAM, 640, 480, [2])[0]
