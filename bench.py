@@ -67,12 +67,6 @@ def make_view(pkg, T, seed, frame_id):
     return v
 
 
-def seq_twist(gidx):
-    """per-sequence camera twist per frame: the S-A twist scaled / mirrored so that sequences differ"""
-    s = 1.0 + 0.05 * (gidx % 7)
-    sign = 1.0 if (gidx // 7) % 2 == 0 else -1.0
-    return XI * s * np.array([sign, 1, 1, 1, sign, 1])
-
 
 class CtxView:
     """minimal view of the sdvl_ctx owned by the host layer's Device (timing + synthetic rendering)"""
@@ -113,16 +107,34 @@ class CtxView:
         return {names[i].value.decode(): (ms[i], launches[i]) for i in range(n.value)}
 
 
-def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa):
+def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_kp=10000):
     """SURVEY §8(d) per-frame algorithmic bytes, split by kernel (640x480, 5 levels, 3 FAST levels)."""
     P = [(W_IMG >> l) * (H_IMG >> l) for l in range(5)]
     return {
+        "select_corners": 4 * n_kp + 16 * n_c,                       # per-cell keypoint lists read once + corner records written
+        "pack_corners": 32 * n_c,
         "pyr_down": sum(P[:4]) + sum(P[1:]),                         # pyramid read + write (4 launches per frame batch)
         "fast_cells": sum(P[:3]) + 16 * n_c,                         # FAST read + keypoint write
         "orb_describe": n_c * (961 + 32),                            # 31x31 window + descriptor
         "image_align": 3 * n_f * 49 + i_ia * n_f * 25,               # reference windows + current windows per GN iteration
         "search_points": 12 * n_c + n_s * (121 + 164 + i_fa * 81),   # corner list + warp window + patches + LK windows
     }.get(kernel)
+
+
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask and cgroup quota (the GPU boxes run under a CPU quota)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(frames):
@@ -147,7 +159,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "512")), help="independent sequences per GPU")
+    ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "256")), help="independent sequences per GPU")
     ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
     ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip)")
@@ -158,6 +170,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "WORLD_SIZE must equal --gpus (launch with torch.distributed.run)"
     distributed = world > 1
+    dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -167,10 +180,12 @@ def main():
 
     pkg = importlib.import_module("slam-sdvl_amd")
     trk = importlib.import_module("slam-sdvl_amd.tracker")
+    shard = importlib.import_module("slam-sdvl_amd.shard")
     trk.configure()
-    ncpu = os.cpu_count() or 8
+    ncpu = effective_cpus()
     B, K, Wm = args.seqs, args.steps, args.warmup
-    G = args.groups or max(1, min(B // 8 if B >= 8 else 1, max(1, (ncpu // max(1, world)) // 2), 32))
+    # one group = one host thread + one HIP stream; the host side is the limiter, so: one group per usable CPU
+    G = args.groups or max(1, min(B // 8 if B >= 8 else 1, max(1, ncpu // max(1, world)), 32))
     while B % G:
         G -= 1
     Bg = B // G
@@ -179,11 +194,12 @@ def main():
     ctxs = [CtxView(pkg, farm.ctx_handle(g)) for g in range(G)]
     ctx = ctxs[0]
 
+    my_seqs = shard.sequences_for_rank(rank, world, B)   # independent sequences: no data-path collective
     n_frames = 1 + Wm + K                     # bootstrap keyframe + warmup + timed
     frame_bytes = W_IMG * H_IMG
     buf = ctx.malloc(B * n_frames * frame_bytes)
     for k in range(n_frames):                 # frame-major layout: step k reads B consecutive frames
-        views = [make_view(pkg, se3_exp(seq_twist(rank * B + i) * k), 20260001 + rank * B + i, k) for i in range(B)]
+        views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * k), shard.sequence_seed(g), k) for g in my_seqs]
         ctx.render(views, buf + k * B * frame_bytes)
     ptrs = (buf + (np.arange(n_frames, dtype=np.uint64)[:, None] * B + np.arange(B, dtype=np.uint64)[None, :]) * frame_bytes).astype(np.uint64)
 
@@ -219,14 +235,7 @@ def main():
         n_ia += st.align_iters
         n_lk += st.lk_iters
 
-    tot = torch.tensor([float(tracked), elapsed], dtype=torch.float64, device="cuda")
-    if distributed:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed_max, tracked_all = float(mx[1]), float(tot[0])
-    else:
-        elapsed_max, tracked_all = elapsed, float(tracked)
+    tracked_all, elapsed_max = shard.reduce_throughput(tracked, elapsed, dist if distributed else None, "cuda")
 
     if rank == 0:
         frames_rank = B * K
@@ -249,12 +258,12 @@ def main():
         if args.cpu_frames > 0:
             n_cpu = args.cpu_frames
             cbuf = ctx.malloc(n_cpu * frame_bytes)
-            views = [make_view(pkg, se3_exp(seq_twist(0) * k), 20260001, k) for k in range(n_cpu)]
+            views = [make_view(pkg, se3_exp(shard.sequence_twist(0) * k), shard.sequence_seed(0), k) for k in range(n_cpu)]
             ctx.render(views, cbuf)
             host = ctx.download(cbuf, n_cpu * frame_bytes).reshape(n_cpu, H_IMG, W_IMG)
             fps, n_tracked, secs = cpu_baseline([host[k] for k in range(n_cpu)])
             cpu = {"value": round(fps, 2), "unit": "tracked frames/s", "cores": 1, "kind": "port",
-                   "sample": "sequence 0 of the same workload, %d tracked frames, %.1f s on one host core (%d cores present)" % (n_tracked, secs, ncpu)}
+                   "sample": "sequence 0 of the same workload, %d tracked frames, %.1f s on one host core (%d usable CPUs)" % (n_tracked, secs, ncpu)}
         value = tracked_all / elapsed_max
         out = {
             "metric": "tracked frames/sec (640x480, 5-lvl pyr, ~200 feats)", "value": round(value, 2), "unit": "frames/s",

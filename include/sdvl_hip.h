@@ -138,6 +138,9 @@ int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f);
 int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stride);
 /* same, image already in HBM (device pointer) */
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride);
+/* same without the copy: level 0 aliases the caller's HBM image (row stride == width), which must stay valid and
+ * unmodified for as long as the frame is used; the next upload / set_image returns the frame to its own storage */
+int sdvl_frame_borrow_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img);
 /* Frame::CreatePyramid, frame.cc:114-120: levels 1..L-1 by cv::pyrDown for n frames */
 int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames);
 /* host mirror of GetPyramid()[level] (read by the mapper / UI) */
@@ -160,8 +163,9 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
 int sdvl_frames_corner_counts(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int32_t *counts);
 /* host mirror of corners_ (GetCorners()): xyl = [n][3], *n_out = count */
 int sdvl_frame_download_corners(sdvl_ctx *ctx, sdvl_frame *f, int cap, int32_t *xyl, int *n_out);
-/* diagnostic: cv::KeyPointsFilter::retainBest on packed keypoints (response in the top byte) run by the device code */
-int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int *out_len);
+/* diagnostic: cv::KeyPointsFilter::retainBest on packed keypoints (response in the top byte) run by the device code;
+ * cooperative = 0: the one-lane form used per cell, 1: the workgroup form used for a level's list (len <= 4096) */
+int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int cooperative, int *out_len);
 
 /* corners_ of a frame (x, y in level coordinates, level), fast_detector.cc:151 -> HBM; descriptors are invalidated */
 int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *xyl);

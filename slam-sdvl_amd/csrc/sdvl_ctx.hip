@@ -17,6 +17,24 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned) 
   return SDVL_OK;
 }
 
+int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d) {
+  const size_t need = (bytes + 255) / 256 * 256;
+  const size_t cap = ctx->h_stage_bytes < ctx->d_stage_bytes ? ctx->h_stage_bytes : ctx->d_stage_bytes;
+  if (!ctx->h_stage || !ctx->d_stage || ctx->stage_off + need > cap) {
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // everything staged so far has been consumed; the ring restarts
+    if (need > cap || !ctx->h_stage || !ctx->d_stage) {
+      const size_t want = need * 2 + (static_cast<size_t>(4) << 20);
+      int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, want, true);
+      if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, want, false);
+      if (rc) return rc;
+    }
+  }
+  *h = static_cast<uint8_t *>(ctx->h_stage) + ctx->stage_off;
+  *d = static_cast<uint8_t *>(ctx->d_stage) + ctx->stage_off;
+  ctx->stage_off += need;
+  return SDVL_OK;
+}
+
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
   if (!ctx->wait_event) {
     hipError_t e = hipEventCreateWithFlags(&ctx->wait_event, hipEventBlockingSync | hipEventDisableTiming);
@@ -24,10 +42,21 @@ hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
   }
   hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
   if (e != hipSuccess) return e;
-  return hipEventSynchronize(ctx->wait_event);
+  e = hipEventSynchronize(ctx->wait_event);
+  if (e == hipSuccess) ctx->stage_off = 0;
+  return e;
+}
+
+int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f) {
+  if (f->hdr_stale) {
+    SDVL_HIP_CHECK(ctx, hipMemsetAsync(f->v.corner_hdr, 0, 16, ctx->stream));
+    f->hdr_stale = 0;
+  }
+  return SDVL_OK;
 }
 
 int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n) {
+  if (f->hdr_stale) f->v.n_corners = 0;
   if (f->v.n_corners < 0) {
     int rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, 64, true);
     if (rc) return rc;
@@ -39,8 +68,10 @@ int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n) {
   return SDVL_OK;
 }
 
-int sdvl_timer_begin(sdvl_ctx *ctx, const char *name) {
-  if (!ctx->timing) return -1;
+bool sdvl_timer_events(sdvl_ctx *ctx, const char *name, hipEvent_t *a, hipEvent_t *b) {
+  *a = nullptr;
+  *b = nullptr;
+  if (!ctx->timing) return false;
   int t = -1;
   for (size_t i = 0; i < ctx->timers.size(); i++)
     if (ctx->timers[i].name == name) { t = static_cast<int>(i); break; }
@@ -57,17 +88,13 @@ int sdvl_timer_begin(sdvl_ctx *ctx, const char *name) {
       *e = ctx->free_events.back();
       ctx->free_events.pop_back();
     } else if (hipEventCreate(e) != hipSuccess) {
-      return -1;
+      return false;
     }
   }
-  (void)hipEventRecord(p.a, ctx->stream);
   ctx->pending.push_back(p);
-  return static_cast<int>(ctx->pending.size()) - 1;
-}
-
-void sdvl_timer_end(sdvl_ctx *ctx, int pending) {
-  if (pending < 0) return;
-  (void)hipEventRecord(ctx->pending[pending].b, ctx->stream);
+  *a = p.a;
+  *b = p.b;
+  return true;
 }
 
 static void sdvl_timer_collect(sdvl_ctx *ctx) {
@@ -206,6 +233,8 @@ int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_fra
     return SDVL_ERR_HIP;
   }
   for (int l = 0; l < levels; l++) f->v.level[l] = f->base + lo[l];
+  f->own_level0 = f->v.level[0];
+  f->hdr_stale = 0;
   f->v.levels = levels;
   f->v.n_corners = 0;
   f->v.corner_hdr = reinterpret_cast<int32_t *>(f->base + corners_off);
@@ -239,9 +268,10 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
   if (!ctx || !f || !img) return SDVL_ERR_INVALID;
   SDVL_REQUIRE(ctx, stride >= f->width, "stride smaller than width");
   // hipMemcpy2DAsync from pageable memory stages internally; it returns once the source has been consumed.
+  f->v.level[0] = f->own_level0;
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, img, stride, f->width, f->height, hipMemcpyHostToDevice,
                                        ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipMemsetAsync(f->v.corner_hdr, 0, 16, ctx->stream));
+  f->hdr_stale = 1;
   f->v.n_corners = 0;
   f->desc_valid = 0;
   return SDVL_OK;
@@ -250,9 +280,19 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride) {
   if (!ctx || !f || !dev_img) return SDVL_ERR_INVALID;
   SDVL_REQUIRE(ctx, stride >= f->width, "stride smaller than width");
+  f->v.level[0] = f->own_level0;
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, dev_img, stride, f->width, f->height,
                                        hipMemcpyDeviceToDevice, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipMemsetAsync(f->v.corner_hdr, 0, 16, ctx->stream));
+  f->hdr_stale = 1;
+  f->v.n_corners = 0;
+  f->desc_valid = 0;
+  return SDVL_OK;
+}
+
+int sdvl_frame_borrow_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img) {
+  if (!ctx || !f || !dev_img) return SDVL_ERR_INVALID;
+  f->v.level[0] = static_cast<uint8_t *>(const_cast<void *>(dev_img));  // read-only use: kernels never write level 0
+  f->hdr_stale = 1;
   f->v.n_corners = 0;
   f->desc_valid = 0;
   return SDVL_OK;
@@ -282,10 +322,10 @@ int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *x
   }
   {
     const size_t bytes = sizeof(int32_t) * 4 * (n + 1);
-    int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
+    void *hs = nullptr, *dsx = nullptr;
+    int rc = sdvl_stage_alloc(ctx, bytes, &hs, &dsx);
     if (rc) return rc;
-    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // the staging buffer may still feed an earlier copy
-    int32_t *st = static_cast<int32_t *>(ctx->h_stage);
+    int32_t *st = static_cast<int32_t *>(hs);
     st[0] = n; st[1] = 0; st[2] = 0; st[3] = 0;
     for (int i = 0; i < n; i++) {
       st[4 * (i + 1)] = xyl[3 * i]; st[4 * (i + 1) + 1] = xyl[3 * i + 1]; st[4 * (i + 1) + 2] = xyl[3 * i + 2]; st[4 * (i + 1) + 3] = 0;
@@ -293,6 +333,7 @@ int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *x
     SDVL_HIP_CHECK(ctx, hipMemcpyAsync(f->v.corner_hdr, st, bytes, hipMemcpyHostToDevice, ctx->stream));
     SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   }
+  f->hdr_stale = 0;
   f->v.n_corners = n;
   f->desc_valid = 0;
   return SDVL_OK;
@@ -323,10 +364,10 @@ int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, con
     }
   }
   const size_t bytes = sizeof(int32_t) * 4 * (total + n);
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_stage_alloc(ctx, bytes, &hs, &dsx);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  int32_t *st = static_cast<int32_t *>(ctx->h_stage);
+  int32_t *st = static_cast<int32_t *>(hs);
   size_t k = 0, w = 0;
   for (int i = 0; i < n; i++) {
     int32_t *rec = st + 4 * w;  // {count,0,0,0} header + records: one copy per frame
@@ -336,6 +377,7 @@ int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, con
     }
     SDVL_HIP_CHECK(ctx, hipMemcpyAsync(frames[i]->v.corner_hdr, rec, sizeof(int32_t) * 4 * (counts[i] + 1), hipMemcpyHostToDevice, ctx->stream));
     frames[i]->v.n_corners = counts[i];
+    frames[i]->hdr_stale = 0;
     frames[i]->desc_valid = 0;
     w += counts[i] + 1;
   }

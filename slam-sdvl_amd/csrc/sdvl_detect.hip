@@ -72,7 +72,9 @@ struct FastJob {
 };
 
 
-constexpr int kTile = 32, kTilePitch = 36;
+constexpr int kTile = 32;
+constexpr int kPitchW = 12;  // LDS row pitch in 32-bit words: 4 left pad + 32 px + 12 right pad bytes = 48 B
+constexpr int kPadRows = 3;  // rows of padding above and below the 32 ROI rows
 
 // has the 16-bit circular mask m a run of >= 9 ones?
 __device__ __forceinline__ bool ring_run9(uint32_t m) {
@@ -84,32 +86,72 @@ __device__ __forceinline__ bool ring_run9(uint32_t m) {
   return (r & 0xFFFFu) != 0;
 }
 
-// cornerScore<16> in closed form: max(t, max_arcs min9(v-p), max_arcs min9(p-v)) - 1
-__device__ __forceinline__ int fast_score(const int *d, int t) {
+// byte `i` (0..11) of the three consecutive words w0 w1 w2
+__device__ __forceinline__ int byte_of(uint32_t w0, uint32_t w1, uint32_t w2, int i) {
+  return static_cast<int>(((i < 4 ? w0 : (i < 8 ? w1 : w2)) >> (8 * (i & 3))) & 0xFFu);
+}
+
+// One thread owns 4 horizontally adjacent pixels (x = cg .. cg+3).  The ring of pixel x needs bytes x-3 .. x+3 of rows
+// y-3 .. y+3: per row three aligned 32-bit LDS words (bytes cg-4 .. cg+7) serve all four pixels -> 21 ds_read_b32
+// instead of 68 byte reads.  Everything stays in named registers (no arrays: the previous version spilled 88 B/lane of
+// scratch = 130 MB of HBM writes per launch).
+#define SDVL_RING_PX(K, R, OFF) const int p##K = byte_of(r##R##0, r##R##1, r##R##2, 4 + (OFF) + k)
+#define SDVL_MIN2(a, b) min((a), (b))
+#define SDVL_MAX2(a, b) max((a), (b))
+
+__device__ __forceinline__ int fast_eval_pixel(uint32_t rm30, uint32_t rm31, uint32_t rm32, uint32_t rm20, uint32_t rm21, uint32_t rm22,
+                                               uint32_t rm10, uint32_t rm11, uint32_t rm12, uint32_t rz0, uint32_t rz1, uint32_t rz2,
+                                               uint32_t rp10, uint32_t rp11, uint32_t rp12, uint32_t rp20, uint32_t rp21, uint32_t rp22,
+                                               uint32_t rp30, uint32_t rp31, uint32_t rp32, int k, int t) {
+  const int v = byte_of(rz0, rz1, rz2, 4 + k);
+  // Bresenham circle, cv::FAST offsets16: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+  SDVL_RING_PX(0, p3, 0);   SDVL_RING_PX(1, p3, 1);   SDVL_RING_PX(2, p2, 2);   SDVL_RING_PX(3, p1, 3);
+  SDVL_RING_PX(4, z, 3);    SDVL_RING_PX(5, m1, 3);   SDVL_RING_PX(6, m2, 2);   SDVL_RING_PX(7, m3, 1);
+  SDVL_RING_PX(8, m3, 0);   SDVL_RING_PX(9, m3, -1);  SDVL_RING_PX(10, m2, -2); SDVL_RING_PX(11, m1, -3);
+  SDVL_RING_PX(12, z, -3);  SDVL_RING_PX(13, p1, -3); SDVL_RING_PX(14, p2, -2); SDVL_RING_PX(15, p3, -1);
+  const int hi = v + t, lo = v - t;
+  uint32_t br = 0, dk = 0;
+#define SDVL_BIT(K) br |= (p##K > hi ? 1u : 0u) << K; dk |= (p##K < lo ? 1u : 0u) << K;
+  SDVL_BIT(0) SDVL_BIT(1) SDVL_BIT(2) SDVL_BIT(3) SDVL_BIT(4) SDVL_BIT(5) SDVL_BIT(6) SDVL_BIT(7)
+  SDVL_BIT(8) SDVL_BIT(9) SDVL_BIT(10) SDVL_BIT(11) SDVL_BIT(12) SDVL_BIT(13) SDVL_BIT(14) SDVL_BIT(15)
+#undef SDVL_BIT
+  if (!(ring_run9(br) || ring_run9(dk))) return 0;
+  // cornerScore<16> in closed form: max(t, max_arcs min9(v-p), max_arcs min9(p-v)) - 1, by min/max doubling
   int best = t;
-#pragma unroll
-  for (int sgn = 0; sgn < 2; sgn++) {
-    int e[16], m2[16], m4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = sgn ? -d[k] : d[k];
-#pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = min(e[k], e[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int m8 = min(m4[k], m4[(k + 4) & 15]);
-      best = max(best, min(m8, e[(k + 8) & 15]));
-    }
+#define SDVL_SCORE(OP, SGN)                                                                                                     \
+  {                                                                                                                             \
+    const int e0 = SGN(v - p0), e1 = SGN(v - p1), e2 = SGN(v - p2), e3 = SGN(v - p3), e4 = SGN(v - p4), e5 = SGN(v - p5),       \
+              e6 = SGN(v - p6), e7 = SGN(v - p7), e8 = SGN(v - p8), e9 = SGN(v - p9), e10 = SGN(v - p10), e11 = SGN(v - p11),   \
+              e12 = SGN(v - p12), e13 = SGN(v - p13), e14 = SGN(v - p14), e15 = SGN(v - p15);                                   \
+    const int a0 = OP(e0, e1), a1 = OP(e1, e2), a2 = OP(e2, e3), a3 = OP(e3, e4), a4 = OP(e4, e5), a5 = OP(e5, e6),             \
+              a6 = OP(e6, e7), a7 = OP(e7, e8), a8 = OP(e8, e9), a9 = OP(e9, e10), a10 = OP(e10, e11), a11 = OP(e11, e12),      \
+              a12 = OP(e12, e13), a13 = OP(e13, e14), a14 = OP(e14, e15), a15 = OP(e15, e0);                                    \
+    const int b0 = OP(a0, a2), b1 = OP(a1, a3), b2 = OP(a2, a4), b3 = OP(a3, a5), b4 = OP(a4, a6), b5 = OP(a5, a7),             \
+              b6 = OP(a6, a8), b7 = OP(a7, a9), b8 = OP(a8, a10), b9 = OP(a9, a11), b10 = OP(a10, a12), b11 = OP(a11, a13),     \
+              b12 = OP(a12, a14), b13 = OP(a13, a15), b14 = OP(a14, a0), b15 = OP(a15, a1);                                     \
+    best = max(best, OP(OP(b0, b4), e8));   best = max(best, OP(OP(b1, b5), e9));   best = max(best, OP(OP(b2, b6), e10));      \
+    best = max(best, OP(OP(b3, b7), e11));  best = max(best, OP(OP(b4, b8), e12));  best = max(best, OP(OP(b5, b9), e13));      \
+    best = max(best, OP(OP(b6, b10), e14)); best = max(best, OP(OP(b7, b11), e15)); best = max(best, OP(OP(b8, b12), e0));      \
+    best = max(best, OP(OP(b9, b13), e1));  best = max(best, OP(OP(b10, b14), e2)); best = max(best, OP(OP(b11, b15), e3));     \
+    best = max(best, OP(OP(b12, b0), e4));  best = max(best, OP(OP(b13, b1), e5));  best = max(best, OP(OP(b14, b2), e6));      \
+    best = max(best, OP(OP(b15, b3), e7));                                                                                      \
   }
-  return best - 1;
+#define SDVL_POS(x) (x)
+#define SDVL_NEG(x) (-(x))
+  SDVL_SCORE(SDVL_MIN2, SDVL_POS)
+  SDVL_SCORE(SDVL_MIN2, SDVL_NEG)
+#undef SDVL_POS
+#undef SDVL_NEG
+#undef SDVL_SCORE
+  return (best - 1) & 0xFF;  // stored as uchar like OpenCV's score buffer
 }
 
 __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restrict__ jobs, FastLevels lv) {
-  __shared__ uint8_t s_img[kTile][kTilePitch];
-  __shared__ uint8_t s_score[kTile][kTilePitch];
+  // image tile with a 3-row / 4-byte halo of zeros so that every ring read is unconditional
+  __shared__ uint32_t s_img[(kTile + 2 * kPadRows) * kPitchW];
+  __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // 1 pad row above / below, 4 pad bytes left, >= 4 right
   __shared__ int s_wave_tot[4];
-  const FastJob job = jobs[blockIdx.y];
+  const FastJob &job = jobs[blockIdx.y];  // by reference: a by-value copy indexed with the runtime level lands in scratch
   const int gcell = blockIdx.x;
   int l = 0;
   while (l + 1 < lv.n_levels && gcell >= lv.cell_begin[l + 1]) l++;
@@ -125,8 +167,16 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   }
   const int rw = x1 - x0, rh = y1 - y0;  // <= 32
   const uint8_t *img = job.level[l];
-  const int row = tid >> 3, cg = (tid & 7) * 4;
-  // stage the ROI (zero outside it)
+  const int row = tid >> 3, wq = tid & 7, cg = wq * 4;
+  // zero the halo words, stage the ROI (zero outside it)
+  for (int i = tid; i < (kTile + 2 * kPadRows) * kPitchW; i += 256) {
+    const int r = i / kPitchW, w = i - r * kPitchW;
+    if (r < kPadRows || r >= kPadRows + kTile || w == 0 || w > 8) s_img[i] = 0;
+  }
+  for (int i = tid; i < (kTile + 2) * kPitchW; i += 256) {
+    const int r = i / kPitchW, w = i - r * kPitchW;
+    if (r == 0 || r == kTile + 1 || w == 0 || w > 8) s_score[i] = 0;
+  }
   {
     uint32_t pack = 0;
     if (row < rh) {
@@ -135,49 +185,42 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
       for (int k = 0; k < 4; k++)
         if (cg + k < rw) pack |= static_cast<uint32_t>(src[k]) << (8 * k);
     }
-    *reinterpret_cast<uint32_t *>(&s_img[row][cg]) = pack;
+    s_img[(row + kPadRows) * kPitchW + 1 + wq] = pack;
   }
   __syncthreads();
   const int t = lv.threshold;
   uint32_t sc_pack = 0;
   if (row >= 3 && row < rh - 3) {
+    // rows y-3 .. y+3, words covering bytes cg-4 .. cg+7
+#define SDVL_ROW(N, DY)                                                                  \
+  const uint32_t *q##N = &s_img[(row + kPadRows + (DY)) * kPitchW + wq];                  \
+  const uint32_t r##N##0 = q##N[0], r##N##1 = q##N[1], r##N##2 = q##N[2];
+    SDVL_ROW(m3, -3) SDVL_ROW(m2, -2) SDVL_ROW(m1, -1) SDVL_ROW(z, 0) SDVL_ROW(p1, 1) SDVL_ROW(p2, 2) SDVL_ROW(p3, 3)
+#undef SDVL_ROW
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int x = cg + k;
       if (x < 3 || x >= rw - 3) continue;
-      const int v = s_img[row][x];
-      // Bresenham circle of radius 3 (cv::FAST offsets16); folded to immediates by the full unroll
-      const int ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-      const int ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-      int d[16];
-      uint32_t brighter = 0, darker = 0;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int p = s_img[row + ring_dy[r]][x + ring_dx[r]];
-        d[r] = v - p;
-        brighter |= (p > v + t ? 1u : 0u) << r;
-        darker |= (p < v - t ? 1u : 0u) << r;
-      }
-      if (ring_run9(brighter) || ring_run9(darker)) {
-        const int s = fast_score(d, t);
-        sc_pack |= static_cast<uint32_t>(s & 0xFF) << (8 * k);  // stored as uchar like OpenCV's buf[]
-      }
+      const int s = fast_eval_pixel(rm30, rm31, rm32, rm20, rm21, rm22, rm10, rm11, rm12, rz0, rz1, rz2, rp10, rp11, rp12, rp20, rp21,
+                                    rp22, rp30, rp31, rp32, k, t);
+      sc_pack |= static_cast<uint32_t>(s) << (8 * k);
     }
   }
-  *reinterpret_cast<uint32_t *>(&s_score[row][cg]) = sc_pack;
+  s_score[(row + 1) * kPitchW + 1 + wq] = sc_pack;
   __syncthreads();
   // 3x3 strict non-max suppression; survivors in row-major order
   uint32_t keep = 0;
   int cnt = 0;
   if (sc_pack) {
+    const uint32_t *u = &s_score[row * kPitchW + wq], *m = u + kPitchW, *d = m + kPitchW;
+    const uint32_t u0 = u[0], u1 = u[1], u2 = u[2], m0 = m[0], m1 = m[1], m2 = m[2], d0 = d[0], d1 = d[1], d2 = d[2];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int s = (sc_pack >> (8 * k)) & 0xFF;
+      const int s = static_cast<int>((sc_pack >> (8 * k)) & 0xFF);
       if (!s) continue;
-      const int x = cg + k;  // x >= 3, row >= 3 here
-      const bool ok = s > s_score[row][x - 1] && s > s_score[row][x + 1] && s > s_score[row - 1][x - 1] &&
-                      s > s_score[row - 1][x] && s > s_score[row - 1][x + 1] && s > s_score[row + 1][x - 1] &&
-                      s > s_score[row + 1][x] && s > s_score[row + 1][x + 1];
+      const bool ok = s > byte_of(m0, m1, m2, 3 + k) && s > byte_of(m0, m1, m2, 5 + k) && s > byte_of(u0, u1, u2, 3 + k) &&
+                      s > byte_of(u0, u1, u2, 4 + k) && s > byte_of(u0, u1, u2, 5 + k) && s > byte_of(d0, d1, d2, 3 + k) &&
+                      s > byte_of(d0, d1, d2, 4 + k) && s > byte_of(d0, d1, d2, 5 + k);
       if (ok) { keep |= 1u << k; cnt++; }
     }
   }
@@ -208,6 +251,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   }
   if (tid == 0) job.cell_counts[gcell] = min(total, SDVL_CELL_KP_CAP);
 }
+#undef SDVL_RING_PX
+#undef SDVL_MIN2
+#undef SDVL_MAX2
 
 // one workgroup per frame: exclusive scan of the cell counts, dense gather (cell-major, scan order inside a cell)
 __global__ __launch_bounds__(256) void compact_cells_kernel(const FastJob *__restrict__ jobs, int total_cells, int cap,
@@ -413,119 +459,322 @@ struct SelJob {
   int lw[4], lh[4];
 };
 
+constexpr int kSelThreads = 1024;  // 16 waves: one lane per cell leaves <= ~20 divergent lanes per wave
+constexpr int kSelWaves = kSelThreads / 64;
+constexpr int kSelCellsPerThread = kSelMaxCells / kSelThreads;  // 2 consecutive cells per thread
+constexpr int kSelParMin = 96;     // ranges shorter than this are finished by one lane
+
+// block-wide exclusive prefix sum of one int per thread; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave, int *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int n = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += n;
+  }
+  __syncthreads();  // s_wave may still be read from a previous call
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kSelWaves; w++) {
+    const int x = s_wave[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+// The two-pointer partitions of libstdc++ (__unguarded_partition and the bidirectional __partition) swap the k-th
+// element that stops the left scan with the k-th element that stops the right scan for as long as the former lies left
+// of the latter; no position takes part in two swaps.  So the final arrangement follows from two rank computations:
+//   left-stoppers  L[0] < L[1] < ...  (ascending positions),  right-stoppers  R[0] > R[1] > ...  (descending positions),
+//   K = #{k : L[k] < R[k]},  swap v[L[k]] <-> v[R[k]] for k < K.
+// All threads call this with identical arguments.  is_left / is_right classify a packed keypoint.
+template <typename FL, typename FR>
+__device__ void block_two_pointer_partition(uint32_t *v, int first, int last, uint16_t *Ls, uint16_t *Rs, int *s_wave, FL is_left, FR is_right,
+                                            int *out_K, int *out_nL, int *out_nR) {
+  const int tid = threadIdx.x;
+  const int n = last - first;
+  const int chunk = (n + kSelThreads - 1) / kSelThreads;
+  const int my0 = min(last, first + tid * chunk), my1 = min(last, my0 + chunk);
+  int cl = 0, cr = 0;
+  for (int i = my0; i < my1; i++) {
+    const uint32_t x = v[i];
+    cl += is_left(x) ? 1 : 0;
+    cr += is_right(x) ? 1 : 0;
+  }
+  int nL = 0, nR = 0;
+  int el = block_exclusive_scan(cl, s_wave, &nL);
+  int er = block_exclusive_scan(cr, s_wave, &nR);
+  for (int i = my0; i < my1; i++) {
+    const uint32_t x = v[i];
+    if (is_left(x)) Ls[el++] = static_cast<uint16_t>(i);
+    if (is_right(x)) Rs[nR - 1 - (er++)] = static_cast<uint16_t>(i);
+  }
+  __syncthreads();
+  const int m = min(nL, nR);
+  int ck = 0;
+  for (int k = tid; k < m; k += kSelThreads) ck += (Ls[k] < Rs[k]) ? 1 : 0;
+  int K = 0;
+  block_exclusive_scan(ck, s_wave, &K);
+  for (int k = tid; k < K; k += kSelThreads) {
+    const int a = Ls[k], b = Rs[k];
+    const uint32_t t = v[a];
+    v[a] = v[b];
+    v[b] = t;
+  }
+  __syncthreads();
+  *out_K = K;
+  *out_nL = nL;
+  *out_nR = nR;
+}
+
+// sequential continuation of __introselect from an intermediate state (one lane)
+__device__ void sel_introselect_from(uint32_t *v, int first, int nth, int last, int depth_limit) {
+  while (last - first > 3) {
+    if (depth_limit == 0) {
+      sel_heap_select(v, first, nth + 1, last);
+      kp_swap(v, first, nth);
+      return;
+    }
+    --depth_limit;
+    const int mid = first + (last - first) / 2;
+    sel_move_median_to_first(v, first, first + 1, mid, last - 1);
+    const int cut = sel_unguarded_partition(v, first + 1, last, first);
+    if (cut <= nth) first = cut;
+    else last = cut;
+  }
+  sel_insertion_sort(v, first, last);
+}
+
+// cv::KeyPointsFilter::retainBest(v[0..len), n_points) by the whole workgroup; every thread gets the new length
+__device__ int block_retain_best(uint32_t *v, int len, int n_points, uint16_t *Ls, uint16_t *Rs, int *s_wave) {
+  if (!(n_points >= 0 && len > n_points)) return len;
+  if (n_points == 0) return 0;
+  const int tid = threadIdx.x;
+  // ---- std::nth_element(v, v + n_points, v + len)
+  {
+    int first = 0, last = len;
+    const int nth = n_points;
+    int depth_limit = (31 - __clz(len)) * 2;
+    while (last - first > 3 && last - first >= kSelParMin && depth_limit > 0) {
+      --depth_limit;
+      if (tid == 0) {
+        const int mid = first + (last - first) / 2;
+        sel_move_median_to_first(v, first, first + 1, mid, last - 1);
+      }
+      __syncthreads();
+      const uint32_t pv = v[first] >> 24;
+      int K, nL, nR;
+      block_two_pointer_partition(
+          v, first + 1, last, Ls, Rs, s_wave, [pv](uint32_t x) { return !((x >> 24) > pv); }, [pv](uint32_t x) { return !(pv > (x >> 24)); }, &K,
+          &nL, &nR);
+      // where the left scan finally stops: the next original left-stopper or the slot the last swap filled from the left
+      int cut = 0x7FFFFFFF;
+      if (K < nL) cut = Ls[K];
+      if (K > 0) cut = min(cut, static_cast<int>(Rs[K - 1]));
+      __syncthreads();  // Ls/Rs are rewritten by the next round
+      if (cut <= nth) first = cut;
+      else last = cut;
+    }
+    if (tid == 0) sel_introselect_from(v, first, nth, last, depth_limit);
+    __syncthreads();
+  }
+  // ---- std::partition(v + n_points, v + len, response >= amb)
+  const uint32_t amb = v[n_points - 1] >> 24;
+  int new_len;
+  if (len - n_points >= kSelParMin) {
+    int K, nL, nR;
+    block_two_pointer_partition(
+        v, n_points, len, Ls, Rs, s_wave, [amb](uint32_t x) { return !((x >> 24) >= amb); }, [amb](uint32_t x) { return (x >> 24) >= amb; }, &K, &nL,
+        &nR);
+    new_len = n_points + nR;  // the elements that satisfy the predicate end up in front
+    __syncthreads();
+  } else {
+    __shared__ int s_len;
+    if (tid == 0) {
+      int first = n_points, last = len;
+      int res = -1;
+      while (res < 0) {
+        while (true) {
+          if (first == last) { res = first; break; }
+          else if ((v[first] >> 24) >= amb) ++first;
+          else break;
+        }
+        if (res >= 0) break;
+        --last;
+        while (true) {
+          if (first == last) { res = first; break; }
+          else if (!((v[last] >> 24) >= amb)) --last;
+          else break;
+        }
+        if (res >= 0) break;
+        kp_swap(v, first, last);
+        ++first;
+      }
+      s_len = res;
+    }
+    __syncthreads();
+    new_len = s_len;
+    __syncthreads();
+  }
+  return new_len;
+}
+
 // one workgroup per (level, frame)
-__global__ __launch_bounds__(256) void select_corners_kernel(const SelJob *__restrict__ jobs, SelLevels lv) {
+__global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJob *__restrict__ jobs, SelLevels lv) {
   __shared__ uint32_t s_stage[kSelStage];
   __shared__ uint32_t s_fts[kSelFts];
-  __shared__ uint8_t s_nleft[kSelMaxCells], s_nsel[kSelMaxCells], s_newlen[kSelMaxCells];
-  __shared__ int s_off[kSelMaxCells];  // offset of the cell inside s_stage for the current round
-  __shared__ int s_round[3];           // c0, c1, total staged
-  __shared__ int s_nfts, s_overflow;
+  __shared__ uint8_t s_cnt[kSelMaxCells], s_nleft[kSelMaxCells], s_nsel[kSelMaxCells], s_newlen[kSelMaxCells];
+  __shared__ int s_pre[kSelMaxCells + 1];  // exclusive prefix of the cell counts (level-wide)
+  __shared__ int s_wave[kSelWaves];
+  __shared__ int s_c1;
   const SelJob &job = jobs[blockIdx.y];
   const int l = blockIdx.x;
   const int tid = threadIdx.x;
-  const int ncells = lv.wcells[l] * lv.hcells[l];
+  const int wc = lv.wcells[l], hc = lv.hcells[l];
+  const int ncells = wc * hc;
   const int cbeg = lv.cell_begin[l];
   const int nfeatures = lv.quota[l];
-  // ---- quota loop, fast_detector.cc:108-135 (thread 0; a handful of passes over <= 2048 bytes of LDS)
-  for (int c = tid; c < ncells; c += 256) {
-    s_nleft[c] = static_cast<uint8_t>(job.cell_counts[cbeg + c]);
-    s_nsel[c] = 0;
+  const int cfirst = tid * kSelCellsPerThread;
+  // ---- load the cell counts, count the cells where cv::FAST ran but found nothing (fast_detector.cc:104-105)
+  int my_empty = 0, my_sum = 0;
+#pragma unroll
+  for (int k = 0; k < kSelCellsPerThread; k++) {
+    const int c = cfirst + k;
+    if (c < ncells) {
+      const int cnt = job.cell_counts[cbeg + c];
+      s_cnt[c] = static_cast<uint8_t>(cnt);
+      s_nleft[c] = static_cast<uint8_t>(cnt);
+      s_nsel[c] = 0;
+      my_sum += cnt;
+      const int i = c / wc, j = c - i * wc;
+      const bool ran = (min(job.lh[l] - lv.margin, i * lv.cell_size + lv.cell_size) > max(lv.margin, i * lv.cell_size)) &&
+                       (min(job.lw[l] - lv.margin, j * lv.cell_size + lv.cell_size) > max(lv.margin, j * lv.cell_size));
+      if (ran && cnt == 0) my_empty++;
+    }
   }
-  __syncthreads();
-  if (tid == 0) {
-    int nempty = 0;
-    for (int i = 0; i < lv.hcells[l]; i++) {
-      const int inity = max(lv.margin, i * lv.cell_size), maxy = min(job.lh[l] - lv.margin, i * lv.cell_size + lv.cell_size);
-      if (maxy <= inity) continue;
-      for (int j = 0; j < lv.wcells[l]; j++) {
-        const int initx = max(lv.margin, j * lv.cell_size), maxx = min(job.lw[l] - lv.margin, j * lv.cell_size + lv.cell_size);
-        if (maxx <= initx) continue;
-        if (s_nleft[i * lv.wcells[l] + j] == 0) nempty++;  // only cells where cv::FAST ran count as empty (Appendix B)
+  int total_kps = 0;
+  {
+    int run = block_exclusive_scan(my_sum, s_wave, &total_kps);
+#pragma unroll
+    for (int k = 0; k < kSelCellsPerThread; k++) {
+      const int c = cfirst + k;
+      if (c < ncells) {
+        s_pre[c] = run;
+        run += s_cnt[c];
       }
     }
-    int selected = 0;
-    int cells_left = ncells - nempty;
-    while ((nfeatures - selected) > 0 && cells_left > 0) {
-      const int rem = nfeatures - selected;
-      const int npercell = (rem + cells_left - 1) / cells_left;  // ceil(double(rem) / double(cells_left)), exact for ints this small
-      cells_left = 0;
-      for (int c = 0; c < ncells; c++) {
+    if (cfirst < ncells && cfirst + kSelCellsPerThread >= ncells) s_pre[ncells] = run;  // the thread that owns the last cell
+  }
+  int nempty = 0;
+  block_exclusive_scan(my_empty, s_wave, &nempty);
+  // ---- quota loop, fast_detector.cc:108-135: every pass is a map over the cells + two sums (order-free)
+  int selected = 0;
+  int cells_left = ncells - nempty;
+  while ((nfeatures - selected) > 0 && cells_left > 0) {
+    const int rem = nfeatures - selected;
+    const int npercell = (rem + cells_left - 1) / cells_left;  // ceil(double(rem) / double(cells_left))
+    int d_sel = 0, d_left = 0;
+#pragma unroll
+    for (int k = 0; k < kSelCellsPerThread; k++) {
+      const int c = cfirst + k;
+      if (c < ncells) {
         const int nl = s_nleft[c];
         if (nl > 0) {
           if (nl > npercell) {
             s_nsel[c] = static_cast<uint8_t>(s_nsel[c] + npercell);
-            selected += npercell;
+            d_sel += npercell;
             s_nleft[c] = static_cast<uint8_t>(nl - npercell);
-            cells_left++;
+            d_left++;
           } else {
             s_nsel[c] = static_cast<uint8_t>(s_nsel[c] + nl);
-            selected += nl;
+            d_sel += nl;
             s_nleft[c] = 0;
           }
         }
       }
     }
-    s_nfts = 0;
-    s_overflow = 0;
+    int tsel = 0, tleft = 0;
+    block_exclusive_scan(d_sel, s_wave, &tsel);
+    block_exclusive_scan(d_left, s_wave, &tleft);
+    selected += tsel;
+    cells_left = tleft;
   }
   __syncthreads();
-  // ---- per-cell retainBest (fast_detector.cc:138-145): cells are staged into LDS in rounds, one thread per cell
+  // ---- per-cell retainBest (fast_detector.cc:138-145): cells staged into LDS in rounds, one lane per cell (the lanes
+  //      of a wave follow different control flow, hence 16 waves: few active lanes per wave);
+  //      survivors appended to s_fts in cell order through a prefix sum of the surviving lengths
+  int nfts = 0;
+  bool overflow = false;
   int c0 = 0;
   while (c0 < ncells) {
-    if (tid == 0) {
-      int tot = 0, c = c0;
-      while (c < ncells) {
-        const int cnt = job.cell_counts[cbeg + c];
-        if (tot + cnt > kSelStage) break;
-        s_off[c] = tot;
-        tot += cnt;
-        c++;
+    if (tid == 0) s_c1 = ncells;
+    __syncthreads();
+    {  // c1 = first cell whose list no longer fits the staging buffer
+      const int base = s_pre[c0];
+      int mine = ncells;
+#pragma unroll
+      for (int k = kSelCellsPerThread - 1; k >= 0; k--) {
+        const int c = cfirst + k;
+        if (c >= c0 && c < ncells && s_pre[c + 1] - base > kSelStage) mine = c;
       }
-      s_round[0] = c0;
-      s_round[1] = c;
-      s_round[2] = tot;
+      if (mine < ncells) atomicMin(&s_c1, mine);
     }
     __syncthreads();
-    const int c1 = s_round[1];
-    for (int c = c0 + (tid >> 2); c < c1; c += 64) {  // 4 lanes copy one cell
-      const int cnt = job.cell_counts[cbeg + c];
+    const int c1 = s_c1;
+    if (c1 == c0) { overflow = true; break; }  // a single cell larger than the staging buffer: impossible (<= 176)
+    const int base = s_pre[c0];
+    for (int c = c0 + (tid >> 2); c < c1; c += kSelThreads / 4) {  // 4 lanes copy one cell
+      const int cnt = s_cnt[c];
       const uint32_t *src = job.cell_kps + static_cast<size_t>(cbeg + c) * SDVL_CELL_KP_CAP;
-      for (int k = (tid & 3); k < cnt; k += 4) s_stage[s_off[c] + k] = src[k];
+      for (int k = (tid & 3); k < cnt; k += 4) s_stage[s_pre[c] - base + k] = src[k];
     }
     __syncthreads();
-    for (int c = c0 + tid; c < c1; c += 256) {
-      const int cnt = job.cell_counts[cbeg + c];
-      s_newlen[c] = static_cast<uint8_t>(sel_retain_best(&s_stage[s_off[c]], cnt, s_nsel[c]));
+    {  // cell (c0 + w + 16*j) goes to lane j of wave w: consecutive cells land in different waves
+      const int w = tid >> 6, j = tid & 63;
+      const int c = c0 + w + kSelWaves * j;
+      if (c < c1) s_newlen[c] = static_cast<uint8_t>(sel_retain_best(&s_stage[s_pre[c] - base], s_cnt[c], s_nsel[c]));
     }
     __syncthreads();
-    if (tid == 0) {  // append the survivors in cell order (fast_detector.cc:141-143)
-      int n = s_nfts;
-      for (int c = c0; c < c1; c++) {
+    int my_len = 0;
+#pragma unroll
+    for (int k = 0; k < kSelCellsPerThread; k++) {
+      const int c = cfirst + k;
+      if (c >= c0 && c < c1) my_len += s_newlen[c];
+    }
+    int round_total = 0;
+    int dst = nfts + block_exclusive_scan(my_len, s_wave, &round_total);
+    if (nfts + round_total > kSelFts) { overflow = true; break; }
+#pragma unroll
+    for (int k = 0; k < kSelCellsPerThread; k++) {
+      const int c = cfirst + k;
+      if (c >= c0 && c < c1) {
         const int len = s_newlen[c];
-        if (n + len > kSelFts) { s_overflow = 1; break; }
-        for (int k = 0; k < len; k++) s_fts[n + k] = s_stage[s_off[c] + k];
-        n += len;
+        const uint32_t *src = &s_stage[s_pre[c] - base];
+        for (int q = 0; q < len; q++) s_fts[dst + q] = src[q];
+        dst += len;
       }
-      s_nfts = n;
     }
+    nfts += round_total;
     __syncthreads();
     c0 = c1;
-    if (s_overflow) break;
   }
-  // ---- final retainBest over the level (fast_detector.cc:147-148)
-  if (tid == 0 && !s_overflow) {
-    if (s_nfts > nfeatures) s_nfts = sel_retain_best(s_fts, s_nfts, nfeatures);
+  // ---- final retainBest over the level (fast_detector.cc:147-148), cooperatively; s_stage is free now
+  int n = -1;
+  if (!overflow) {
+    uint16_t *Ls = reinterpret_cast<uint16_t *>(s_stage), *Rs = Ls + kSelFts;
+    n = (nfts > nfeatures) ? block_retain_best(s_fts, nfts, nfeatures, Ls, Rs, s_wave) : nfts;
+    n = min(n, SDVL_MAX_CORNERS);
   }
   __syncthreads();
-  int n = s_overflow ? -1 : min(s_nfts, SDVL_MAX_CORNERS);
   int32_t *dst = job.level_corners + static_cast<size_t>(l) * SDVL_MAX_CORNERS * 4;
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += kSelThreads) {
     const uint32_t v = s_fts[k];
-    dst[4 * k] = static_cast<int32_t>(v & 0xFFF);
-    dst[4 * k + 1] = static_cast<int32_t>((v >> 12) & 0xFFF);
-    dst[4 * k + 2] = l;
-    dst[4 * k + 3] = 0;
+    reinterpret_cast<int4 *>(dst)[k] = make_int4(static_cast<int>(v & 0xFFF), static_cast<int>((v >> 12) & 0xFFF), l, 0);
   }
   if (tid == 0) job.level_counts[l] = n;
 }
@@ -552,8 +801,20 @@ __global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restr
 }
 
 // diagnostic: retainBest of one list by one thread (tests the libstdc++ restatement against the host calls)
-__global__ void retain_best_kernel(uint32_t *v, int len, int n_points, int *out_len) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *out_len = sel_retain_best(v, len, n_points);
+__global__ __launch_bounds__(kSelThreads) void retain_best_kernel(uint32_t *v, int len, int n_points, int *out_len, int cooperative) {
+  __shared__ uint32_t s_v[kSelFts];
+  __shared__ uint16_t s_l[kSelFts], s_r[kSelFts];
+  __shared__ int s_wave[kSelWaves];
+  if (cooperative && len <= kSelFts) {  // the workgroup-cooperative form used for the per-level list
+    for (int i = threadIdx.x; i < len; i += kSelThreads) s_v[i] = v[i];
+    __syncthreads();
+    const int n = block_retain_best(s_v, len, n_points, s_l, s_r, s_wave);
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += kSelThreads) v[i] = s_v[i];
+    if (threadIdx.x == 0) *out_len = n;
+  } else if (threadIdx.x == 0) {        // the one-lane form used per cell
+    *out_len = sel_retain_best(v, len, n_points);
+  }
 }
 
 }  // namespace
@@ -571,23 +832,20 @@ int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
   }
   if (levels < 2) return SDVL_OK;
   const size_t bytes = sizeof(PyrJob) * n * (levels - 1);
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_stage_alloc(ctx, bytes, &hs, &dsx);
   if (rc) return rc;
-  rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, bytes, false);
-  if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // staging reuse
-  PyrJob *hj = static_cast<PyrJob *>(ctx->h_stage);
+  PyrJob *hj = static_cast<PyrJob *>(hs);
   for (int l = 1; l < levels; l++)
     for (int i = 0; i < n; i++) {
       const FrameView &v = frames[i]->v;
       hj[(l - 1) * n + i] = PyrJob{v.level[l - 1], v.level[l], v.lw[l - 1], v.lh[l - 1], v.lw[l], v.lh[l]};
     }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
   for (int l = 1; l < levels; l++) {
     const FrameView &v = frames[0]->v;
     dim3 grid((v.lw[l] + kPyrTW - 1) / kPyrTW, (v.lh[l] + kPyrTH - 1) / kPyrTH, n);
-    ScopedKernelTimer tm(ctx, "pyr_down");
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, ctx->stream, static_cast<const PyrJob *>(ctx->d_stage) + (l - 1) * n);
+    SDVL_LAUNCH(ctx, "pyr_down", pyr_down_kernel, grid, dim3(256), static_cast<const PyrJob *>(dsx) + (l - 1) * n);
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
@@ -641,13 +899,12 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   const size_t job_bytes = sizeof(FastJob) * n;
   const size_t offs_bytes = sizeof(int32_t) * static_cast<size_t>(n) * (total_cells + 1);
   const size_t kps_bytes = sizeof(uint32_t) * static_cast<size_t>(n) * cap;
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, job_bytes, true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, job_bytes, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, offs_bytes + kps_bytes, false);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, offs_bytes + kps_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, offs_bytes + kps_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, job_bytes, &hs, &dsx);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  FastJob *hj = static_cast<FastJob *>(ctx->h_stage);
+  FastJob *hj = static_cast<FastJob *>(hs);
   for (int i = 0; i < n; i++) {
     memset(&hj[i], 0, sizeof(FastJob));
     for (int l = 0; l < lv.n_levels; l++) {
@@ -658,19 +915,11 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
     hj[i].cell_kps = frames[i]->cell_kps;
     hj[i].cell_counts = frames[i]->cell_counts;
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, hj, job_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, job_bytes, hipMemcpyHostToDevice, ctx->stream));
   int32_t *d_offs = static_cast<int32_t *>(ctx->d_out);
   uint32_t *d_kps = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->d_out) + offs_bytes);
-  {
-    ScopedKernelTimer tm(ctx, "fast_cells");
-    hipLaunchKernelGGL(fast_cells_kernel, dim3(total_cells, n), dim3(256), 0, ctx->stream,
-                       static_cast<const FastJob *>(ctx->d_stage), lv);
-  }
-  {
-    ScopedKernelTimer tm(ctx, "compact_cells");
-    hipLaunchKernelGGL(compact_cells_kernel, dim3(n), dim3(256), 0, ctx->stream, static_cast<const FastJob *>(ctx->d_stage),
-                       total_cells, cap, d_kps, d_offs);
-  }
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3(total_cells, n), dim3(256), static_cast<const FastJob *>(dsx), lv);
+  SDVL_LAUNCH(ctx, "compact_cells", compact_cells_kernel, dim3(n), dim3(256), static_cast<const FastJob *>(dsx), total_cells, cap, d_kps, d_offs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   int32_t *h_offs = static_cast<int32_t *>(ctx->h_out);
   uint32_t *h_kps = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->h_out) + offs_bytes);
@@ -755,14 +1004,13 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
     }
   }
   const size_t fj_bytes = (sizeof(FastJob) * n + 255) / 256 * 256, sj_bytes = sizeof(SelJob) * n;
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, fj_bytes + sj_bytes, true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, fj_bytes + sj_bytes, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_counts, &ctx->d_counts_bytes, sizeof(int32_t) * n, false);
+  void *hst = nullptr, *dst = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_counts, &ctx->d_counts_bytes, sizeof(int32_t) * n, false);
+  if (!rc) rc = sdvl_stage_alloc(ctx, fj_bytes + sj_bytes, &hst, &dst);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   ctx->detect_frames.assign(frames, frames + n);
-  FastJob *hf = static_cast<FastJob *>(ctx->h_stage);
-  SelJob *hs = reinterpret_cast<SelJob *>(static_cast<uint8_t *>(ctx->h_stage) + fj_bytes);
+  FastJob *hf = static_cast<FastJob *>(hst);
+  SelJob *hs = reinterpret_cast<SelJob *>(static_cast<uint8_t *>(hst) + fj_bytes);
   for (int i = 0; i < n; i++) {
     memset(&hf[i], 0, sizeof(FastJob));
     memset(&hs[i], 0, sizeof(SelJob));
@@ -779,23 +1027,15 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
     hs[i].level_counts = frames[i]->level_counts;
     hs[i].corner_hdr = frames[i]->v.corner_hdr;
     frames[i]->v.n_corners = -1;  // known on the device only
+    frames[i]->hdr_stale = 0;     // the pack kernel rewrites the header
     frames[i]->desc_valid = 0;
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, fj_bytes + sj_bytes, hipMemcpyHostToDevice, ctx->stream));
-  const FastJob *df = static_cast<const FastJob *>(ctx->d_stage);
-  const SelJob *ds = reinterpret_cast<const SelJob *>(static_cast<uint8_t *>(ctx->d_stage) + fj_bytes);
-  {
-    ScopedKernelTimer tm(ctx, "fast_cells");
-    hipLaunchKernelGGL(fast_cells_kernel, dim3(total_cells, n), dim3(256), 0, ctx->stream, df, lv);
-  }
-  {
-    ScopedKernelTimer tm(ctx, "select_corners");
-    hipLaunchKernelGGL(select_corners_kernel, dim3(lv.n_levels, n), dim3(256), 0, ctx->stream, ds, sl);
-  }
-  {
-    ScopedKernelTimer tm(ctx, "pack_corners");
-    hipLaunchKernelGGL(pack_corners_kernel, dim3(n), dim3(256), 0, ctx->stream, ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts));
-  }
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst, hst, fj_bytes + sj_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const FastJob *df = static_cast<const FastJob *>(dst);
+  const SelJob *ds = reinterpret_cast<const SelJob *>(static_cast<uint8_t *>(dst) + fj_bytes);
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3(total_cells, n), dim3(256), df, lv);
+  SDVL_LAUNCH(ctx, "select_corners", select_corners_kernel, dim3(lv.n_levels, n), dim3(kSelThreads), ds, sl);
+  SDVL_LAUNCH(ctx, "pack_corners", pack_corners_kernel, dim3(n), dim3(256), ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
 }
@@ -861,7 +1101,7 @@ int sdvl_frames_corner_counts(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, i
 }
 
 // diagnostic: cv::KeyPointsFilter::retainBest on packed keypoints (score = top byte) by the device restatement
-int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int *out_len) {
+int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int cooperative, int *out_len) {
   if (!ctx || !packed || !out_len || len < 0 || len > (1 << 20)) return SDVL_ERR_INVALID;
   if (len == 0) { *out_len = 0; return SDVL_OK; }
   const size_t bytes = sizeof(uint32_t) * len + 64;
@@ -871,8 +1111,8 @@ int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(static_cast<uint8_t *>(ctx->h_out) + 64, packed, sizeof(uint32_t) * len);
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_out, ctx->h_out, bytes, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(retain_best_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->d_out) + 64), len,
-                     n_points, static_cast<int *>(ctx->d_out));
+  hipLaunchKernelGGL(retain_best_kernel, dim3(1), dim3(kSelThreads), 0, ctx->stream,
+                     reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->d_out) + 64), len, n_points, static_cast<int *>(ctx->d_out), cooperative);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -311,14 +311,13 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
   const size_t job_bytes = (sizeof(IaJob) * n_jobs + 255) / 256 * 256;
   const size_t feat_bytes = sizeof(sdvl_align_feature) * static_cast<size_t>(n_features);
   const size_t res_bytes = sizeof(sdvl_align_result) * n_jobs;
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, job_bytes + feat_bytes, true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, job_bytes + feat_bytes, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, work + 256, false);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, work + 256, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, res_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, res_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, job_bytes + feat_bytes, &hs, &dsx);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  IaJob *hj = static_cast<IaJob *>(ctx->h_stage);
+  IaJob *hj = static_cast<IaJob *>(hs);
   uint8_t *wbase = static_cast<uint8_t *>(ctx->d_work);
   size_t woff = 0;
   for (int j = 0; j < n_jobs; j++) {
@@ -340,15 +339,10 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
     woff += items * (sizeof(float) + 6 * sizeof(double));
     woff = (woff + 255) / 256 * 256;
   }
-  if (feat_bytes) memcpy(static_cast<uint8_t *>(ctx->h_stage) + job_bytes, features, feat_bytes);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, job_bytes + feat_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (feat_bytes) memcpy(static_cast<uint8_t *>(hs) + job_bytes, features, feat_bytes);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, job_bytes + feat_bytes, hipMemcpyHostToDevice, ctx->stream));
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  {
-    ScopedKernelTimer tm(ctx, "image_align");
-    hipLaunchKernelGGL(image_align_kernel, dim3(n_jobs), dim3(kThreads), 0, ctx->stream, static_cast<const IaJob *>(ctx->d_stage),
-                       reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(ctx->d_stage) + job_bytes), c, *p,
-                       static_cast<sdvl_align_result *>(ctx->d_out));
-  }
+  SDVL_LAUNCH(ctx, "image_align", image_align_kernel, dim3(n_jobs), dim3(kThreads), static_cast<const IaJob *>(dsx), reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p, static_cast<sdvl_align_result *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -3,6 +3,7 @@
 #define SDVL_INTERNAL_H_
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -34,6 +35,8 @@ struct sdvl_frame {
   int32_t *level_counts;   // [4]
   int max_cells;
   int desc_valid;
+  int hdr_stale;         // device corner header still holds the count of a previous image (reset lazily)
+  uint8_t *own_level0;   // the frame's own level-0 storage (level[0] may point at a borrowed caller image)
 };
 
 struct KernelTimer {
@@ -52,6 +55,7 @@ struct sdvl_ctx {
   void *h_out = nullptr;   size_t h_out_bytes = 0;
   void *d_out = nullptr;   size_t d_out_bytes = 0;
   void *d_work = nullptr;  size_t d_work_bytes = 0;
+  size_t stage_off = 0;  // bump pointer into h_stage/d_stage; reset by every sdvl_stream_wait
   // corner counts of the last sdvl_detect_corners batch, written by the pack kernel: one D2H serves all frames
   void *d_counts = nullptr; size_t d_counts_bytes = 0;
   std::vector<sdvl_frame *> detect_frames;
@@ -82,18 +86,26 @@ struct sdvl_ctx {
   } while (0)
 
 int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);
+// `bytes` of pinned host staging + its device mirror (same offset in h_stage / d_stage).  Allocations made since the
+// last sdvl_stream_wait never overlap, so a call can fill its records while earlier copies are still in flight;
+// only when the ring is exhausted does this wait for the stream.
+int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d);
 // wait for everything queued on ctx->stream WITHOUT spinning: hipEventBlockingSync event + hipEventSynchronize.
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
 // host copy of a frame's corner count; fetches it (blocking) when only the device knows it
 int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n);
-int sdvl_timer_begin(sdvl_ctx *ctx, const char *name);  // returns pending index or -1
-void sdvl_timer_end(sdvl_ctx *ctx, int pending);
+// make the device corner header match the host view before a kernel reads it (after an image change without detection)
+int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f);
 
-struct ScopedKernelTimer {
-  sdvl_ctx *ctx;
-  int idx;
-  ScopedKernelTimer(sdvl_ctx *c, const char *name) : ctx(c), idx(sdvl_timer_begin(c, name)) {}
-  ~ScopedKernelTimer() { sdvl_timer_end(ctx, idx); }
-};
+// Kernel launch with optional DISPATCH timing: hipExtLaunchKernelGGL attaches the start/stop events to the kernel's
+// own AQL packet, so the measured span is the dispatch itself (what rocprofv3 --kernel-trace reports), not the queueing
+// behind other streams that share a hardware queue.
+bool sdvl_timer_events(sdvl_ctx *ctx, const char *name, hipEvent_t *a, hipEvent_t *b);
+#define SDVL_LAUNCH(ctx, name, kernel, grid, block, ...)                                                   \
+  do {                                                                                                     \
+    hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;                                                           \
+    sdvl_timer_events((ctx), (name), &ev_a_, &ev_b_);                                                      \
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, ev_a_, ev_b_, 0, __VA_ARGS__);            \
+  } while (0)
 
 #endif  // SDVL_INTERNAL_H_

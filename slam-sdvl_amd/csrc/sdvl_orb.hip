@@ -151,13 +151,14 @@ __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restric
 int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *d_out_desc, double *d_out_score,
               OrbJob **d_jobs, int *max_n) {
   const size_t bytes = sizeof(OrbJob) * n;
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, bytes, false);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_stage_alloc(ctx, bytes, &hs, &dsx);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  OrbJob *hj = static_cast<OrbJob *>(ctx->h_stage);
+  OrbJob *hj = static_cast<OrbJob *>(hs);
   *max_n = 0;
   for (int i = 0; i < n; i++) {
+    int rcf = sdvl_frame_fix_header(ctx, frames[i]);
+    if (rcf) return rcf;
     const FrameView &v = frames[i]->v;
     memset(&hj[i], 0, sizeof(OrbJob));
     for (int l = 0; l < v.levels; l++) { hj[i].level[l] = v.level[l]; hj[i].lw[l] = v.lw[l]; hj[i].lh[l] = v.lh[l]; }
@@ -172,8 +173,8 @@ int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t 
     const int bound = v.n_corners >= 0 ? v.n_corners : SDVL_MAX_CORNERS / 2;  // device-only count: launch for the capacity
     if (bound > *max_n) *max_n = bound;
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
-  *d_jobs = static_cast<OrbJob *>(ctx->d_stage);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *d_jobs = static_cast<OrbJob *>(dsx);
   return SDVL_OK;
 }
 
@@ -208,11 +209,8 @@ int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, 
   int max_n = 0;
   int rc = fill_jobs(ctx, n, frames, cap, d_desc, nullptr, &d_jobs, &max_n);
   if (rc) return rc;
-  if (max_n > 0) {
-    ScopedKernelTimer tm(ctx, "orb_describe");
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_n + 3) / 4, n), dim3(256), 0, ctx->stream, d_jobs);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
-  }
   for (int i = 0; i < n; i++) frames[i]->desc_valid = 1;
   if (out_desc) {
     if (max_n > 0) {
@@ -249,10 +247,7 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   rc = fill_jobs(ctx, n, frames, cap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   if (max_n == 0) return SDVL_OK;
-  {
-    ScopedKernelTimer tm(ctx, "shi_tomasi");
-    hipLaunchKernelGGL(shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), 0, ctx->stream, d_jobs);
-  }
+  SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, sizeof(double) * cap, ctx->d_out, sizeof(double) * cap, sizeof(double) * max_n, n,
                                        hipMemcpyDeviceToHost, ctx->stream));
@@ -293,30 +288,25 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   const size_t c_bytes = sizeof(int32_t) * 4 * n, d_bytes = 32 * static_cast<size_t>(n), a_bytes = sizeof(float) * n;
   const size_t job_off = (c_bytes + 255) / 256 * 256;
   const size_t a_off = (d_bytes + 255) / 256 * 256;
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, job_off + sizeof(OrbJob), true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, job_off + sizeof(OrbJob), false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, a_off + a_bytes, false);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, a_off + a_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, a_off + a_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, job_off + sizeof(OrbJob), &hs, &dsx);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  int32_t *hc = static_cast<int32_t *>(ctx->h_stage);
+  int32_t *hc = static_cast<int32_t *>(hs);
   for (int i = 0; i < n; i++) { hc[4 * i] = xyl[3 * i]; hc[4 * i + 1] = xyl[3 * i + 1]; hc[4 * i + 2] = xyl[3 * i + 2]; hc[4 * i + 3] = 0; }
-  OrbJob *hj = reinterpret_cast<OrbJob *>(static_cast<uint8_t *>(ctx->h_stage) + job_off);
+  OrbJob *hj = reinterpret_cast<OrbJob *>(static_cast<uint8_t *>(hs) + job_off);
   memset(hj, 0, sizeof(OrbJob));
   for (int l = 0; l < f->v.levels; l++) { hj->level[l] = f->v.level[l]; hj->lw[l] = f->v.lw[l]; hj->lh[l] = f->v.lh[l]; }
-  hj->corners = static_cast<int32_t *>(ctx->d_stage);
+  hj->corners = static_cast<int32_t *>(dsx);
   hj->desc = static_cast<uint8_t *>(ctx->d_out);
   hj->out = nullptr;
   hj->out_angle = reinterpret_cast<float *>(static_cast<uint8_t *>(ctx->d_out) + a_off);
   hj->n_ptr = nullptr;
   hj->n = n;
   hj->levels = f->v.levels;
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, job_off + sizeof(OrbJob), hipMemcpyHostToDevice, ctx->stream));
-  {
-    ScopedKernelTimer tm(ctx, "orb_describe");
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((n + 3) / 4, 1), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(ctx->d_stage) + job_off));
-  }
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, job_off + sizeof(OrbJob), hipMemcpyHostToDevice, ctx->stream));
+  SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, dim3((n + 3) / 4, 1), dim3(256), reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(dsx) + job_off));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, a_off + a_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

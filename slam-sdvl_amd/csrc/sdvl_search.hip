@@ -437,6 +437,7 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
   for (int i = 0; i < n; i++) {
     const sdvl_search_req &r = reqs[i];
     SDVL_REQUIRE(ctx, r.cur && r.ref, "null frame in search request");
+    SDVL_REQUIRE(ctx, !r.cur->hdr_stale, "current frame has a new image but no corners (detect or set corners first)");
     SDVL_REQUIRE(ctx, r.level >= 0 && r.level < r.ref->v.levels, "feature level outside the reference pyramid");
     SDVL_REQUIRE(ctx, p->max_fast_levels <= r.cur->v.levels, "max_fast_levels exceeds the pyramid depth");
     if (p->use_orb) SDVL_REQUIRE(ctx, r.cur->v.n_corners == 0 || r.cur->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
@@ -444,13 +445,12 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
   }
   const size_t in_bytes = sizeof(SearchReqDev) * static_cast<size_t>(n);
   const size_t out_bytes = sizeof(sdvl_search_res) * static_cast<size_t>(n);
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, in_bytes, true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, in_bytes, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes, &hs, &dsx);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  SearchReqDev *hd = static_cast<SearchReqDev *>(ctx->h_stage);
+  SearchReqDev *hd = static_cast<SearchReqDev *>(hs);
   for (int i = 0; i < n; i++) {
     const sdvl_search_req &r = reqs[i];
     SearchReqDev &d = hd[i];
@@ -465,13 +465,9 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     d.level = r.level; d.fixed = r.fixed;
     memcpy(d.desc, r.desc, 32);
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, hd, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hd, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  {
-    ScopedKernelTimer tm(ctx, "search_points");
-    hipLaunchKernelGGL(search_points_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, ctx->stream,
-                       static_cast<const SearchReqDev *>(ctx->d_stage), n, c, *p, static_cast<sdvl_search_res *>(ctx->d_out));
-  }
+  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), static_cast<const SearchReqDev *>(dsx), n, c, *p, static_cast<sdvl_search_res *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
@@ -488,13 +484,12 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
   const size_t pb = static_cast<size_t>(n) * 64;
   const size_t ob_uv = (sizeof(double) * 2 * n + 255) / 256 * 256, ob_its = (sizeof(int32_t) * n + 255) / 256 * 256;
   const size_t ob = ob_uv + ob_its + n;
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, jb + bb + pb, true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, jb + bb + pb, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, ob, false);
+  void *hsv = nullptr, *dsv = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, ob, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, ob, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, jb + bb + pb, &hsv, &dsv);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  PatchJob *hj = static_cast<PatchJob *>(ctx->h_stage);
+  PatchJob *hj = static_cast<PatchJob *>(hsv);
   for (int i = 0; i < n; i++) {
     SDVL_REQUIRE(ctx, frames[i] && levels[i] >= 0 && levels[i] < frames[i]->v.levels, "bad frame / level");
     hj[i].img = frames[i]->v.level[levels[i]];
@@ -503,17 +498,12 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
     hj[i].u = uv_io[2 * i];
     hj[i].v = uv_io[2 * i + 1];
   }
-  uint8_t *hs = static_cast<uint8_t *>(ctx->h_stage), *ds = static_cast<uint8_t *>(ctx->d_stage);
+  uint8_t *hs = static_cast<uint8_t *>(hsv), *ds = static_cast<uint8_t *>(dsv);
   memcpy(hs + jb, border, static_cast<size_t>(n) * 100);
   memcpy(hs + jb + bb, patch, pb);
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, jb + bb + pb, hipMemcpyHostToDevice, ctx->stream));
   uint8_t *dout = static_cast<uint8_t *>(ctx->d_out);
-  {
-    ScopedKernelTimer tm(ctx, "align_patches");
-    hipLaunchKernelGGL(align_patches_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, ctx->stream,
-                       reinterpret_cast<const PatchJob *>(ds), ds + jb, ds + jb + bb, n, max_its, reinterpret_cast<double *>(dout),
-                       dout + ob_uv + ob_its, reinterpret_cast<int32_t *>(dout + ob_uv));
-  }
+  SDVL_LAUNCH(ctx, "align_patches", align_patches_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), reinterpret_cast<const PatchJob *>(ds), ds + jb, ds + jb + bb, n, max_its, reinterpret_cast<double *>(dout), dout + ob_uv + ob_its, reinterpret_cast<int32_t *>(dout + ob_uv));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -21,14 +21,13 @@ extern "C" int sdvl_synth_render(sdvl_ctx *ctx, int n, const sdvl_synth_view *vi
   SDVL_REQUIRE(ctx, width > 0 && height > 0 && frame_bytes >= static_cast<int64_t>(width) * height, "bad frame geometry");
   SDVL_REQUIRE(ctx, n <= 65535, "at most 65535 views per call");
   const size_t bytes = sizeof(sdvl_synth_view) * n;
-  int rc = sdvl_ensure(ctx, &ctx->h_stage, &ctx->h_stage_bytes, bytes, true);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_stage, &ctx->d_stage_bytes, bytes, false);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_stage_alloc(ctx, bytes, &hs, &dsx);
   if (rc) return rc;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  memcpy(ctx->h_stage, views, bytes);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(hs, views, bytes);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, bytes, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(synth_render_kernel, dim3((width + 63) / 64, (height + 3) / 4, n), dim3(256), 0, ctx->stream,
-                     static_cast<const sdvl_synth_view *>(ctx->d_stage), width, height, static_cast<uint8_t *>(dev_out),
+                     static_cast<const sdvl_synth_view *>(dsx), width, height, static_cast<uint8_t *>(dev_out),
                      static_cast<long long>(frame_bytes));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -119,11 +119,12 @@ int sdvlh_batch_step_host(void *bp, const uint8_t *const *imgs, int stride, sdvl
   return step(b, v, out);
 }
 
-// imgs: B device pointers (frames already in HBM)
+// imgs: B device pointers (frames already in HBM).  The images are aliased, not copied: they must stay valid while the
+// trackers may still read them (the last frame and every keyframe keep their level 0).
 int sdvlh_batch_step_device(void *bp, const void *const *dev_imgs, int stride, sdvlh_frame_stats *out) {
   Batch *b = static_cast<Batch *>(bp);
   std::vector<Image> v;
-  for (size_t i = 0; i < b->trackers.size(); i++) v.push_back(Image::WrapDevice(dev_imgs[i], b->w, b->h, stride));
+  for (size_t i = 0; i < b->trackers.size(); i++) v.push_back(Image::WrapDevice(dev_imgs[i], b->w, b->h, stride, true));
   return step(b, v, out);
 }
 

@@ -410,7 +410,9 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
   if (n == 0) return;
   std::unique_ptr<StageClock> clk(new StageClock(ST_UPLOAD_PYR));
   for (int i = 0; i < n; i++) {
-    if (imgs[i].dev_src) dev->Check(sdvl_frame_set_image_device(dev->ctx(), devs[i], imgs[i].dev_src, imgs[i].step), "sdvl_frame_set_image_device");
+    if (imgs[i].dev_src && imgs[i].step == imgs[i].cols && imgs[i].borrow)
+      dev->Check(sdvl_frame_borrow_image_device(dev->ctx(), devs[i], imgs[i].dev_src), "sdvl_frame_borrow_image_device");
+    else if (imgs[i].dev_src) dev->Check(sdvl_frame_set_image_device(dev->ctx(), devs[i], imgs[i].dev_src, imgs[i].step), "sdvl_frame_set_image_device");
     else dev->Check(sdvl_frame_upload(dev->ctx(), devs[i], imgs[i].data, imgs[i].step), "sdvl_frame_upload");
   }
   dev->Check(sdvl_pyramid_build(dev->ctx(), n, devs.data()), "sdvl_pyramid_build");

@@ -63,9 +63,10 @@ struct Image {
   }
   // an image that already lives in HBM (device pointer), e.g. a decoded camera frame
   const void *dev_src = nullptr;
-  static Image WrapDevice(const void *dev_ptr, int w, int h, int stride) {
+  bool borrow = false;  // the HBM image outlives every Frame built from it: alias it instead of copying
+  static Image WrapDevice(const void *dev_ptr, int w, int h, int stride, bool borrow_storage = false) {
     Image r;
-    r.dev_src = dev_ptr; r.cols = w; r.rows = h; r.step = stride;
+    r.dev_src = dev_ptr; r.cols = w; r.rows = h; r.step = stride; r.borrow = borrow_storage;
     return r;
   }
 };

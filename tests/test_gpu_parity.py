@@ -113,8 +113,8 @@ def test_device_retain_best_is_libstdcxx_order(ctx, orc):
             cases.append((v, k))
     for v, k in cases:
         want = orc.retain_best(v, k)
-        got = ctx.retain_best(v, k)
-        assert np.array_equal(got, want), (len(v), k)
+        assert np.array_equal(ctx.retain_best(v, k), want), (len(v), k, "one lane")
+        assert np.array_equal(ctx.retain_best(v, k, cooperative=True), want), (len(v), k, "workgroup")
 
 
 @pytest.mark.parametrize("shape,cam,ks", [((480, 640), TUM_CAM, [0, 3, 11]), ((480, 752), EUROC_CAM, [2])])

@@ -1,0 +1,59 @@
+"""The N > 1 path on CPU: two processes over gloo shard the sequences and reduce the throughput counters exactly as
+bench.py does over RCCL (there is no data-path collective to test — sequences are independent)."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, per_gpu, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = importlib.import_module("slam-sdvl_amd.shard")
+    ids = shard.sequences_for_rank(rank, world, per_gpu)
+    tracked = 100 * (rank + 1) + len(ids)          # pretend counters
+    elapsed = 1.0 + 0.25 * rank
+    dist.barrier()
+    total, tmax = shard.reduce_throughput(tracked, elapsed, dist)
+    q.put((rank, ids, total, tmax))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_reduce():
+    world, per_gpu = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_gpu, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all_ids = res[0][1] + res[1][1]
+    assert sorted(all_ids) == list(range(world * per_gpu))             # disjoint and complete
+    for _, _, total, tmax in res:
+        assert total == (100 + 6) + (200 + 6) and tmax == 1.25          # every rank sees the job-wide numbers
+
+
+def test_sequences_differ():
+    shard = importlib.import_module("slam-sdvl_amd.shard")
+    seeds = {shard.sequence_seed(i) for i in range(64)}
+    assert len(seeds) == 64
+    tw = np.array([shard.sequence_twist(i) for i in range(14)])
+    assert len({tuple(np.round(t, 9)) for t in tw}) == 14
+    assert shard.reduce_throughput(5, 2.0) == (5.0, 2.0)                # single process: no collective
