@@ -159,9 +159,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "256")), help="independent sequences per GPU")
+    ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "1024")), help="independent sequences per GPU")
     ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
     ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")
+    ap.add_argument("--workers", type=int, default=0, help="host threads that execute group-steps (0 = auto)")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -185,7 +186,7 @@ def main():
     ncpu = effective_cpus()
     B, K, Wm = args.seqs, args.steps, args.warmup
     # one group = one host thread + one HIP stream; the host side is the limiter, so: one group per usable CPU
-    G = args.groups or max(1, min(B // 8 if B >= 8 else 1, max(1, ncpu // max(1, world)), 32))
+    G = args.groups or max(1, min(B // 8 if B >= 8 else 1, max(1, ncpu // max(1, world)), 16))
     while B % G:
         G -= 1
     Bg = B // G
@@ -209,13 +210,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    farm.run(ptrs[:1 + Wm])                   # bootstrap + warmup (untimed)
+    workers = args.workers or G
+    farm.run(ptrs[:1 + Wm], workers)          # bootstrap + warmup (untimed)
     farm.stage_times(reset=True)
     for c in ctxs:
         c.timing(True)
     barrier()
     t0 = time.perf_counter()
-    stats = farm.run(ptrs[1 + Wm:])           # the K timed steps: every group free-runs through its K steps
+    stats = farm.run(ptrs[1 + Wm:], workers)  # the K timed steps: group-steps are scheduled onto the worker threads
     barrier()
     elapsed = time.perf_counter() - t0
     timers = {}
@@ -271,7 +273,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
             "config": {"workload": "S-A: synthetic TUM fr1-like 640x480 mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step" % B,
-                       "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "parallelism": "sequences sharded over %d GPU(s)" % world,
+                       "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
                        "lk_iterations_per_request": round(n_lk / max(1, n_s), 2)},

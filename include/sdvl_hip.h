@@ -182,6 +182,11 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
 int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *out_desc);
 /* host mirror of descriptors_ (GetDescriptors()): out = [n_corners][32]; needs a prior sdvl_orb_describe */
 int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap, uint8_t *out);
+/* Everything Frame::FilterCorners (frame.cc:133-163) needs from n frames in ONE round trip: corner lists, their
+ * Shi-Tomasi scores (K3 launched here) and ORB descriptors.  xyl[n][cap][3], scores[n][cap], desc[n][cap][32]
+ * (desc may be NULL), counts[n]. */
+int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
+                       int32_t *counts);
 /* ORBDetector::GetDescriptor at arbitrary (x,y,level) points of one frame; out_angle_deg may be NULL */
 int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const int32_t *xyl, uint8_t *out_desc,
                              float *out_angle_deg);

@@ -99,7 +99,8 @@ __device__ __forceinline__ int byte_of(uint32_t w0, uint32_t w1, uint32_t w2, in
 #define SDVL_MIN2(a, b) min((a), (b))
 #define SDVL_MAX2(a, b) max((a), (b))
 
-__device__ __forceinline__ int fast_eval_pixel(uint32_t rm30, uint32_t rm31, uint32_t rm32, uint32_t rm20, uint32_t rm21, uint32_t rm22,
+// segment test of pixel k (0..3) of the thread's quad: is it a FAST-9 corner at threshold t?
+__device__ __forceinline__ bool fast_is_corner(uint32_t rm30, uint32_t rm31, uint32_t rm32, uint32_t rm20, uint32_t rm21, uint32_t rm22,
                                                uint32_t rm10, uint32_t rm11, uint32_t rm12, uint32_t rz0, uint32_t rz1, uint32_t rz2,
                                                uint32_t rp10, uint32_t rp11, uint32_t rp12, uint32_t rp20, uint32_t rp21, uint32_t rp22,
                                                uint32_t rp30, uint32_t rp31, uint32_t rp32, int k, int t) {
@@ -115,8 +116,17 @@ __device__ __forceinline__ int fast_eval_pixel(uint32_t rm30, uint32_t rm31, uin
   SDVL_BIT(0) SDVL_BIT(1) SDVL_BIT(2) SDVL_BIT(3) SDVL_BIT(4) SDVL_BIT(5) SDVL_BIT(6) SDVL_BIT(7)
   SDVL_BIT(8) SDVL_BIT(9) SDVL_BIT(10) SDVL_BIT(11) SDVL_BIT(12) SDVL_BIT(13) SDVL_BIT(14) SDVL_BIT(15)
 #undef SDVL_BIT
-  if (!(ring_run9(br) || ring_run9(dk))) return 0;
-  // cornerScore<16> in closed form: max(t, max_arcs min9(v-p), max_arcs min9(p-v)) - 1, by min/max doubling
+  return ring_run9(br) || ring_run9(dk);
+}
+
+// cornerScore<16> of the pixel at byte address (row, x) of the padded LDS tile, closed form:
+// max(t, max_arcs min9(v-p), max_arcs min9(p-v)) - 1 by min doubling.  Called for corners only (dense list).
+__device__ __forceinline__ int fast_corner_score(const uint8_t *tile, int pitch_bytes, int t) {
+  const int v = tile[0];
+#define SDVL_P(K, DX, DY) const int p##K = tile[(DY) * pitch_bytes + (DX)];
+  SDVL_P(0, 0, 3) SDVL_P(1, 1, 3) SDVL_P(2, 2, 2) SDVL_P(3, 3, 1) SDVL_P(4, 3, 0) SDVL_P(5, 3, -1) SDVL_P(6, 2, -2) SDVL_P(7, 1, -3)
+  SDVL_P(8, 0, -3) SDVL_P(9, -1, -3) SDVL_P(10, -2, -2) SDVL_P(11, -3, -1) SDVL_P(12, -3, 0) SDVL_P(13, -3, 1) SDVL_P(14, -2, 2) SDVL_P(15, -1, 3)
+#undef SDVL_P
   int best = t;
 #define SDVL_SCORE(OP, SGN)                                                                                                     \
   {                                                                                                                             \
@@ -150,6 +160,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   // image tile with a 3-row / 4-byte halo of zeros so that every ring read is unconditional
   __shared__ uint32_t s_img[(kTile + 2 * kPadRows) * kPitchW];
   __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // 1 pad row above / below, 4 pad bytes left, >= 4 right
+  __shared__ uint16_t s_list[kTile * kTile];           // (row << 5 | x) of the pixels that pass the segment test
   __shared__ int s_wave_tot[4];
   const FastJob &job = jobs[blockIdx.y];  // by reference: a by-value copy indexed with the runtime level lands in scratch
   const int gcell = blockIdx.x;
@@ -189,7 +200,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   }
   __syncthreads();
   const int t = lv.threshold;
-  uint32_t sc_pack = 0;
+  // ---- phase 1: segment test for the thread's 4 pixels (cheap part, every pixel)
+  uint32_t cflags = 0;
   if (row >= 3 && row < rh - 3) {
     // rows y-3 .. y+3, words covering bytes cg-4 .. cg+7
 #define SDVL_ROW(N, DY)                                                                  \
@@ -201,13 +213,42 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     for (int k = 0; k < 4; k++) {
       const int x = cg + k;
       if (x < 3 || x >= rw - 3) continue;
-      const int s = fast_eval_pixel(rm30, rm31, rm32, rm20, rm21, rm22, rm10, rm11, rm12, rz0, rz1, rz2, rp10, rp11, rp12, rp20, rp21,
-                                    rp22, rp30, rp31, rp32, k, t);
-      sc_pack |= static_cast<uint32_t>(s) << (8 * k);
+      if (fast_is_corner(rm30, rm31, rm32, rm20, rm21, rm22, rm10, rm11, rm12, rz0, rz1, rz2, rp10, rp11, rp12, rp20, rp21, rp22, rp30, rp31,
+                         rp32, k, t))
+        cflags |= 1u << k;
     }
   }
-  s_score[(row + 1) * kPitchW + 1 + wq] = sc_pack;
+  s_score[(row + 1) * kPitchW + 1 + wq] = 0;
+  // ---- phase 2: the corners (a few % of the pixels) are listed densely and scored one per thread
+  const int lane = tid & 63, wave = tid >> 6;
+  {
+    const int cc = __popc(cflags);
+    int incl = cc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int nn = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += nn;
+    }
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    int cbase = 0;
+    for (int w = 0; w < wave; w++) cbase += s_wave_tot[w];
+    const int ncorner = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    int cpos = cbase + incl - cc;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (cflags & (1u << k)) s_list[cpos++] = static_cast<uint16_t>((row << 5) | (cg + k));
+    __syncthreads();
+    uint8_t *score_bytes = reinterpret_cast<uint8_t *>(s_score);
+    const uint8_t *img_bytes = reinterpret_cast<const uint8_t *>(s_img);
+    for (int i = tid; i < ncorner; i += 256) {
+      const int rc = s_list[i], r = rc >> 5, x = rc & 31;
+      const int sc = fast_corner_score(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
+      score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>(sc);
+    }
+  }
   __syncthreads();
+  const uint32_t sc_pack = s_score[(row + 1) * kPitchW + 1 + wq];
   // 3x3 strict non-max suppression; survivors in row-major order
   uint32_t keep = 0;
   int cnt = 0;
@@ -225,7 +266,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     }
   }
   // block exclusive prefix sum of cnt (thread order == scan order)
-  const int lane = tid & 63, wave = tid >> 6;
+  __syncthreads();  // s_wave_tot is reused
   int incl = cnt;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {

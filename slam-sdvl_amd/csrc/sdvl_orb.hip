@@ -11,12 +11,10 @@
 
 namespace {
 
-__constant__ int8_t c_orb_pattern[256 * 4] = {
+__constant__ __attribute__((aligned(16))) int8_t c_orb_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
-// umax_[v] for HALF_PATCH_SIZE = 15 (orb_detector.cc:325-348)
-__constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 struct OrbJob {
   const uint8_t *level[SDVL_MAX_LEVELS];
@@ -65,11 +63,11 @@ __device__ __forceinline__ int cv_round_f(float v) { return static_cast<int>(__b
 __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restrict__ jobs) {
   const OrbJob &job = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
-  if (ci >= n) return;  // wave-uniform
+  // wave-uniform grid-stride loop: the corner count may only be known on the device
+  for (int ci = blockIdx.x * 4 + (threadIdx.x >> 6); ci < n; ci += gridDim.x * 4) {
   const int cx = job.corners[4 * ci], cy = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
-  if (cl < 0 || cl >= job.levels) return;
+  if (cl < 0 || cl >= job.levels) continue;
   const int W = job.lw[cl], H = job.lh[cl];
   uint8_t *dst = job.desc + static_cast<size_t>(ci) * 32;
   // ORBDetector::IsInsideLimits (orb_detector.cc:439-445); the reference asserts it
@@ -79,18 +77,31 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
       if (job.out) job.out[static_cast<size_t>(ci) * 32 + lane] = 0;
     }
     if (lane == 0 && job.out_angle) job.out_angle[ci] = -1.f;
-    return;
+    continue;
   }
   const uint8_t *center = job.level[cl] + static_cast<size_t>(cy) * W + cx;
-  // intensity centroid over the disc: 31 rows x 31 cols candidates, masked by umax
+  // intensity centroid over the disc: 31 rows x 8 four-pixel segments (u = -16 .. 15) = 248 tasks over 64 lanes,
+  // one unaligned 32-bit load per task; umax_ (orb_detector.cc:325-348) lives in two immediates, 4 bits per row
   int m10 = 0, m01 = 0;
-  for (int idx = lane; idx < 31 * 31; idx += 64) {
-    const int v = idx / 31 - 15, u = idx - (v + 15) * 31 - 15;
-    const int av = v < 0 ? -v : v;
-    if ((u < 0 ? -u : u) <= c_umax[av]) {
-      const int p = center[v * W + u];
-      m10 += u * p;
-      m01 += v * p;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int task = lane + 64 * r;
+    if (task < 248) {
+      const int v = (task >> 3) - 15, u0 = -16 + 4 * (task & 7);
+      const int av = v < 0 ? -v : v;
+      // umax = {15,15,15,15,14,14,14,13, 13,12,11,10,9,8,6,3}
+      const int um = static_cast<int>(((av < 8 ? 0xDEEEFFFFu : 0x3689ABCDu) >> (4 * (av & 7))) & 15u);
+      uint32_t w;
+      __builtin_memcpy(&w, center + v * W + u0, 4);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int u = u0 + k;
+        if ((u < 0 ? -u : u) <= um) {
+          const int p = static_cast<int>((w >> (8 * k)) & 0xFFu);
+          m10 += u * p;
+          m01 += v * p;
+        }
+      }
     }
   }
   m10 = wave_sum_i32(m10);
@@ -100,12 +111,14 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
   const float angle = static_cast<float>(static_cast<double>(angle_deg) * factorPI);
   const float a = static_cast<float>(cos(static_cast<double>(angle)));
   const float b = static_cast<float>(sin(static_cast<double>(angle)));
-  // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..)
+  // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..); its 16 pattern bytes come in one 128-bit load
+  const uint4 pw = reinterpret_cast<const uint4 *>(c_orb_pattern)[lane];
+  const uint32_t pq[4] = {pw.x, pw.y, pw.z, pw.w};
   uint32_t nib = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int8_t *pt = &c_orb_pattern[(4 * lane + q) * 4];
-    const int x0 = pt[0], y0 = pt[1], x1 = pt[2], y1 = pt[3];
+    const int x0 = static_cast<int8_t>(pq[q] & 0xFF), y0 = static_cast<int8_t>((pq[q] >> 8) & 0xFF);
+    const int x1 = static_cast<int8_t>((pq[q] >> 16) & 0xFF), y1 = static_cast<int8_t>(pq[q] >> 24);
     const int t0 = center[cv_round_f(x0 * b + y0 * a) * W + cv_round_f(x0 * a - y0 * b)];
     const int t1 = center[cv_round_f(x1 * b + y1 * a) * W + cv_round_f(x1 * a - y1 * b)];
     nib |= (t0 < t1 ? 1u : 0u) << q;
@@ -117,21 +130,21 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
     if (job.out) job.out[static_cast<size_t>(ci) * 32 + (lane >> 1)] = byte;
   }
   if (lane == 0 && job.out_angle) job.out_angle[ci] = angle_deg;
+  }
 }
 
 __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restrict__ jobs) {
   const OrbJob &job = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
-  if (ci >= n) return;
+  for (int ci = blockIdx.x * 4 + (threadIdx.x >> 6); ci < n; ci += gridDim.x * 4) {
   const int px = job.corners[4 * ci], py = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
-  if (cl < 0 || cl >= job.levels) return;
+  if (cl < 0 || cl >= job.levels) continue;
   const int W = job.lw[cl], H = job.lh[cl];
   const int x_min = px - 4, x_max = px + 4, y_min = py - 4, y_max = py + 4;
   if (x_min < 1 || x_max >= W - 1 || y_min < 1 || y_max >= H - 1) {
     if (lane == 0) job.out_score[ci] = 0.0;
-    return;
+    continue;
   }
   const uint8_t *img = job.level[cl];
   const int y = y_min + (lane >> 3), x = x_min + (lane & 7);
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restric
     dXY = static_cast<float>(dXY / (2.0 * 64));
     const float disc = (dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY);
     job.out_score[ci] = 0.5 * (dXX + dYY - sqrt(static_cast<double>(disc)));
+  }
   }
 }
 
@@ -170,7 +184,7 @@ int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t 
     hj[i].n_ptr = v.corner_hdr;
     hj[i].n = v.n_corners;
     hj[i].levels = v.levels;
-    const int bound = v.n_corners >= 0 ? v.n_corners : SDVL_MAX_CORNERS / 2;  // device-only count: launch for the capacity
+    const int bound = v.n_corners >= 0 ? v.n_corners : 1280;  // device-only count: a typical grid; the kernels grid-stride
     if (bound > *max_n) *max_n = bound;
   }
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -255,6 +269,60 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   for (int i = 0; i < n; i++)
     memcpy(out_scores + static_cast<size_t>(i) * cap, static_cast<double *>(ctx->h_out) + static_cast<size_t>(i) * cap,
            sizeof(double) * frames[i]->v.n_corners);
+  return SDVL_OK;
+}
+
+int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
+                       int32_t *counts) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !xyl || !scores || !counts)) || cap <= 0) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    if (desc) SDVL_REQUIRE(ctx, frames[i]->desc_valid, "frame has no ORB descriptors (call sdvl_orb_describe)");
+  }
+  const int ccap = cap < SDVL_MAX_CORNERS ? cap : SDVL_MAX_CORNERS;
+  // device layout per frame i: scores[ccap] doubles | then everything is copied out of the frames themselves
+  const size_t sc_bytes = sizeof(double) * static_cast<size_t>(n) * ccap;
+  const size_t row = sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1) + (desc ? static_cast<size_t>(ccap) * 32 : 0);
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, sc_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, sc_bytes + row * n, true);
+  if (rc) return rc;
+  OrbJob *d_jobs = nullptr;
+  int max_n = 0;
+  rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
+  if (rc) return rc;
+  max_n = max_n > ccap ? ccap : max_n;
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  uint8_t *h = static_cast<uint8_t *>(ctx->h_out);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_out, sc_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  for (int i = 0; i < n; i++) {  // header + corners (+ descriptors) of every frame, then ONE wait
+    uint8_t *dst = h + sc_bytes + row * i;
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst, frames[i]->v.corner_hdr, sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    if (desc)
+      SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst + sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1), frames[i]->v.desc,
+                                         static_cast<size_t>(ccap) * 32, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  for (int i = 0; i < n; i++) {
+    const uint8_t *src = h + sc_bytes + row * i;
+    const int32_t *hdr = reinterpret_cast<const int32_t *>(src);
+    int cnt = frames[i]->hdr_stale ? 0 : hdr[0];
+    if (cnt > cap) {
+      ctx->err = "corner output capacity smaller than the corner count";
+      return SDVL_ERR_CAPACITY;
+    }
+    frames[i]->v.n_corners = cnt;
+    counts[i] = cnt;
+    for (int k = 0; k < cnt; k++) {
+      xyl[(static_cast<size_t>(i) * cap + k) * 3] = hdr[4 * (k + 1)];
+      xyl[(static_cast<size_t>(i) * cap + k) * 3 + 1] = hdr[4 * (k + 1) + 1];
+      xyl[(static_cast<size_t>(i) * cap + k) * 3 + 2] = hdr[4 * (k + 1) + 2];
+    }
+    memcpy(scores + static_cast<size_t>(i) * cap, reinterpret_cast<const double *>(h) + static_cast<size_t>(i) * ccap, sizeof(double) * cnt);
+    if (desc) memcpy(desc + static_cast<size_t>(i) * cap * 32, src + sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1), static_cast<size_t>(cnt) * 32);
+  }
   return SDVL_OK;
 }
 

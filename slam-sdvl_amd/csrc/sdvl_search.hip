@@ -12,6 +12,10 @@
 //            and three lanes accumulate them IN THE REFERENCE'S SEQUENTIAL ORDER so that update / convergence
 //            decisions are bit-identical to the CPU path.
 // Compiled with -ffp-contract=off.  sdvl_align_patches exposes phase 3 alone.
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
 
@@ -31,13 +35,19 @@ struct SearchFrame {
   int pad_;
 };
 
+// (frame, pose) pairs are shared by many requests of a launch: they go into a table, requests carry two indices
+struct SearchFramePose {
+  SearchFrame f;
+  double pose[7];
+  double pad_;
+};
+
 struct SearchReqDev {
-  SearchFrame cur, ref;
-  double cur_pose[7], ref_pose[7];
+  int cur, ref;  // indices into the SearchFramePose table of the launch
+  int level, fixed;
   double px[2], bearing[3];
   double idepth, idepth_std;
   double px0[2];
-  int level, fixed;
   uint32_t desc[8];
 };
 
@@ -172,7 +182,8 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
   return converged;
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(const SearchReqDev *__restrict__ reqs, int n, Cam cam,
+__global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
+                                                                            const SearchFramePose *__restrict__ table, int n, Cam cam,
                                                                             sdvl_search_params prm,
                                                                             sdvl_search_res *__restrict__ out) {
   __shared__ WaveLds s_lds[kWavesPerBlock];
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
   if (ri >= n) return;
   WaveLds &L = s_lds[wv];
   const SearchReqDev &rq = reqs[ri];
+  const SearchFramePose &tcur = table[rq.cur], &tref = table[rq.ref];
   sdvl_search_res res;
   res.px[0] = rq.px0[0];
   res.px[1] = rq.px0[1];
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
   res.slevel = -1;
 
   const int level = rq.level;
-  const Rigid cur_pose = se3_from7(rq.cur_pose), ref_pose = se3_from7(rq.ref_pose);
+  const Rigid cur_pose = se3_from7(tcur.pose), ref_pose = se3_from7(tref.pose);
   const Rigid ref_world = se3_inverse(ref_pose);
   const Rigid pose = se3_mul(cur_pose, ref_world);
   const V3 fvec = {rq.bearing[0], rq.bearing[1], rq.bearing[2]};
@@ -255,8 +267,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
     const double det = A00 * A11 - A01 * A10;
     const double invdet = 1.0 / det;
     const double I00 = A11 * invdet, I01 = -A01 * invdet, I10 = -A10 * invdet, I11 = A00 * invdet;
-    const uint8_t *img = rq.ref.level[level];
-    const int W = rq.ref.lw[level], H = rq.ref.lh[level];
+    const uint8_t *img = tref.f.level[level];
+    const int W = tref.f.lw[level], H = tref.f.lh[level];
     const double pyrx = rq.px[0] / (1 << level), pyry = rq.px[1] / (1 << level);
     const bool bad = (I00 != I00);  // std::isnan(matrix_inv(0,0)): the reference returns leaving stale patches
     for (int s = lane; s < 100; s += 64) {
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
   const int threshold = prm.use_orb ? 100 : prm.patch_size * prm.patch_size * 500;
   unsigned long long best = ~0ull;
   {
-    const SearchFrame &cf = rq.cur;
+    const SearchFrame &cf = tcur.f;
     // epipolar line constants (matcher.cc:139-148)
     double ex = pxa.x - pxb.x, ey = pxa.y - pxb.y;
     const double en = sqrt(ex * ex + ey * ey);
@@ -366,14 +378,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
     return;
   }
   res.best_corner = best_ci;
-  const int bx = rq.cur.corners[4 * best_ci], by = rq.cur.corners[4 * best_ci + 1], bl = rq.cur.corners[4 * best_ci + 2];
+  const int bx = tcur.f.corners[4 * best_ci], by = tcur.f.corners[4 * best_ci + 1], bl = tcur.f.corners[4 * best_ci + 2];
   const double mpx = static_cast<double>(bx * (1 << bl)), mpy = static_cast<double>(by * (1 << bl));
   res.px[0] = mpx;
   res.px[1] = mpy;
   // ---- AlignPatch at the search level
   float u = static_cast<float>(mpx / (1 << slevel)), v = static_cast<float>(mpy / (1 << slevel));
   int its = 0;
-  const bool conv = align_patch_wave(L, rq.cur.level[slevel], rq.cur.lw[slevel], rq.cur.lh[slevel], prm.max_align_its, lane, &u, &v, &its);
+  const bool conv = align_patch_wave(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v, &its);
   res.lk_its = its;
   res.stage = 2;
   if (conv) {
@@ -443,31 +455,55 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     if (p->use_orb) SDVL_REQUIRE(ctx, r.cur->v.n_corners == 0 || r.cur->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
     SDVL_REQUIRE(ctx, r.idepth == r.idepth && r.idepth != 0.0, "inverse depth must be finite and non-zero");
   }
-  const size_t in_bytes = sizeof(SearchReqDev) * static_cast<size_t>(n);
+  // table of distinct (frame, pose) pairs: one entry per frame in practice (a frame has one pose during a launch)
+  static thread_local std::vector<SearchFramePose> table;
+  static thread_local std::unordered_map<const sdvl_frame *, int> where;
+  table.clear();
+  where.clear();
+  auto lookup = [&](const sdvl_frame *f, const double *pose, int *last) -> int {
+    if (*last >= 0 && table[*last].f.corners == f->v.corners && memcmp(table[*last].pose, pose, sizeof(double) * 7) == 0) return *last;
+    auto it = where.find(f);
+    if (it != where.end() && memcmp(table[it->second].pose, pose, sizeof(double) * 7) == 0) { *last = it->second; return *last; }
+    SearchFramePose e;
+    fill_frame(&e.f, f);
+    memcpy(e.pose, pose, sizeof(double) * 7);
+    e.pad_ = 0.0;
+    table.push_back(e);
+    where[f] = static_cast<int>(table.size()) - 1;  // the same frame under another pose: the newest entry wins the cache
+    *last = static_cast<int>(table.size()) - 1;
+    return *last;
+  };
+  const size_t in_bytes = (sizeof(SearchReqDev) * static_cast<size_t>(n) + 255) / 256 * 256;
   const size_t out_bytes = sizeof(sdvl_search_res) * static_cast<size_t>(n);
-  void *hs = nullptr, *dsx = nullptr;
-  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
-  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes, &hs, &dsx);
-  if (rc) return rc;
-  SearchReqDev *hd = static_cast<SearchReqDev *>(hs);
+  // worst case one table entry per request and side; staged after the requests
+  static thread_local std::vector<SearchReqDev> tmp;
+  tmp.resize(n);
+  int last_cur = -1, last_ref = -1;
   for (int i = 0; i < n; i++) {
     const sdvl_search_req &r = reqs[i];
-    SearchReqDev &d = hd[i];
-    fill_frame(&d.cur, r.cur);
-    fill_frame(&d.ref, r.ref);
-    memcpy(d.cur_pose, r.cur_pose, sizeof(d.cur_pose));
-    memcpy(d.ref_pose, r.ref_pose, sizeof(d.ref_pose));
+    SearchReqDev &d = tmp[i];
+    d.cur = lookup(r.cur, r.cur_pose, &last_cur);
+    d.ref = lookup(r.ref, r.ref_pose, &last_ref);
+    d.level = r.level; d.fixed = r.fixed;
     d.px[0] = r.px[0]; d.px[1] = r.px[1];
     d.bearing[0] = r.bearing[0]; d.bearing[1] = r.bearing[1]; d.bearing[2] = r.bearing[2];
     d.idepth = r.idepth; d.idepth_std = r.idepth_std;
     d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
-    d.level = r.level; d.fixed = r.fixed;
     memcpy(d.desc, r.desc, 32);
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hd, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const size_t tab_bytes = sizeof(SearchFramePose) * table.size();
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes + tab_bytes, &hs, &dsx);
+  if (rc) return rc;
+  memcpy(hs, tmp.data(), sizeof(SearchReqDev) * static_cast<size_t>(n));
+  memcpy(static_cast<uint8_t *>(hs) + in_bytes, table.data(), tab_bytes);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + tab_bytes, hipMemcpyHostToDevice, ctx->stream));
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), static_cast<const SearchReqDev *>(dsx), n, c, *p, static_cast<sdvl_search_res *>(ctx->d_out));
+  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock),
+              static_cast<const SearchReqDev *>(dsx), reinterpret_cast<const SearchFramePose *>(static_cast<uint8_t *>(dsx) + in_bytes), n, c, *p,
+              static_cast<sdvl_search_res *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -2,6 +2,8 @@
 // B independent SDVL trackers on one MI355X stepping together through sdvl::SDVLBatch.
 #include <cstring>
 #include <memory>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -165,27 +167,53 @@ void sdvlh_farm_destroy(void *fp) {
 void *sdvlh_farm_ctx(void *fp, int g) { return sdvlh_device_ctx(static_cast<Farm *>(fp)->devices[g]); }
 void *sdvlh_farm_batch(void *fp, int g) { return static_cast<Farm *>(fp)->batches[g]; }
 
-// Runs n_steps steps.  dev_frames[(step * G*Bg) + g*Bg + i] = device pointer of the frame of sequence (g, i) at that step
-// (row stride = `stride`).  out[(step * G*Bg) + g*Bg + i] receives its stats.  Returns 0, or -1 with sdvlh_last_error.
-int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int stride, sdvlh_frame_stats *out) {
+// Runs n_steps steps with `workers` host threads (0 = one per group).  A worker repeatedly takes the idle group that is
+// furthest behind and executes its next step, so a descheduled or throttled thread delays one group-step, not a group.
+// dev_frames[(step * G*Bg) + g*Bg + i] = device pointer of the frame of sequence (g, i) at that step (row stride =
+// `stride`); out[(step * G*Bg) + g*Bg + i] receives its stats.  Returns 0, or -1 with sdvlh_last_error.
+int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int stride, sdvlh_frame_stats *out, int workers) {
   Farm *f = static_cast<Farm *>(fp);
   const int total = f->G * f->Bg;
-  std::vector<std::thread> threads;
-  std::vector<std::string> errs(f->G);
-  for (int g = 0; g < f->G; g++) {
-    threads.emplace_back([=, &errs]() {
-      for (int s = 0; s < n_steps; s++) {
-        const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * f->Bg;
-        if (sdvlh_batch_step_device(f->batches[g], dev_frames + off, stride, out + off) != 0) {
-          errs[g] = sdvlh_last_error();
-          return;
+  const int W = workers > 0 ? (workers < f->G ? workers : f->G) : f->G;
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<int> done(f->G, 0);
+  std::vector<char> busy(f->G, 0);
+  std::string err;
+  bool failed = false;
+  auto worker = [&]() {
+    for (;;) {
+      int g = -1;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          if (failed) return;
+          int best = -1, remaining = 0;
+          for (int k = 0; k < f->G; k++) {
+            if (done[k] < n_steps) remaining++;
+            if (!busy[k] && done[k] < n_steps && (best < 0 || done[k] < done[best])) best = k;
+          }
+          if (remaining == 0) return;
+          if (best >= 0) { g = best; busy[g] = 1; break; }
+          cv.wait(lk);
         }
       }
-    });
-  }
+      const int s = done[g];
+      const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * f->Bg;
+      const int rc = sdvlh_batch_step_device(f->batches[g], dev_frames + off, stride, out + off);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (rc != 0) { failed = true; err = sdvlh_last_error(); }
+        done[g]++;
+        busy[g] = 0;
+      }
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int w = 0; w < W; w++) threads.emplace_back(worker);
   for (auto &t : threads) t.join();
-  for (int g = 0; g < f->G; g++)
-    if (!errs[g].empty()) { g_err = errs[g]; return -1; }
+  if (failed) { g_err = err; return -1; }
   return 0;
 }
 

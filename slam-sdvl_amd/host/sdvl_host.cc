@@ -305,19 +305,18 @@ void FastDetector::FilterCorners(const vector<Image> &pyramid, const vector<Vect
 
 // ------------------------------------------------------------------------------------------------ Feature / Point
 // feature.cc:28-56
+// (the reference sizes descriptor_ to 32 bytes in every ctor; here the storage appears with SetDescriptor — features the
+//  tracker creates never get a descriptor, feature_align.cc:132, and there are ~200 of them per frame)
 Feature::Feature(const shared_ptr<Frame> &f, const Vector2d &p, int l) : frame_(f), point_(nullptr), p2d_(p), level_(l) {
   v_ = f->GetCamera()->Unproject(p2d_);
-  descriptor_.resize(32);
   has_descriptor_ = false;
 }
 Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, int l) : frame_(f), point_(ft), p2d_(p), level_(l) {
   v_ = f->GetCamera()->Unproject(p2d_);
-  descriptor_.resize(32);
   has_descriptor_ = false;
 }
 Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, const Vector3d &v, int l)
     : frame_(f), point_(ft), p2d_(p), v_(v), level_(l) {
-  descriptor_.resize(32);
   has_descriptor_ = false;
 }
 
@@ -514,7 +513,7 @@ vector<vector<uchar>> &Frame::GetDescriptors() {
     dev->Check(sdvl_frame_download_descriptors(dev->ctx(), dev_, static_cast<int>(corners_.size()), buf.data()), "sdvl_frame_download_descriptors");
     descriptors_.resize(corners_.size());
     for (size_t i = 0; i < corners_.size(); i++) descriptors_[i].assign(buf.begin() + 32 * i, buf.begin() + 32 * (i + 1));
-    descriptors_on_host_ = true;
+    descriptors_on_host_ = true;  // every entry mirrored (FilterCorners alone mirrors only the filtered ones)
   }
   return descriptors_;
 }
@@ -526,19 +525,36 @@ void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
   const int n = static_cast<int>(frames.size());
   if (n == 0) return;
   Device *dev = Device::Current();
+  const bool orb = Config::UseORB();
   vector<sdvl_frame *> devs(n);
-  for (int i = 0; i < n; i++) {
-    devs[i] = frames[i]->dev_;
-    frames[i]->GetCorners();  // the grid logic below walks the corner list on the host
-  }
-  vector<double> scores(static_cast<size_t>(n) * SDVL_MAX_CORNERS);
-  dev->Check(sdvl_shi_tomasi(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, scores.data()), "sdvl_shi_tomasi");
+  for (int i = 0; i < n; i++) devs[i] = frames[i]->dev_;
+  // corners + Shi-Tomasi scores + descriptors of all frames in one round trip
+  static thread_local vector<int32_t> xyl;
+  static thread_local vector<double> scores;
+  static thread_local vector<uint8_t> desc;
+  vector<int32_t> counts(n);
+  const size_t cap = SDVL_MAX_CORNERS;
+  if (xyl.size() < n * cap * 3) xyl.resize(n * cap * 3);
+  if (scores.size() < n * cap) scores.resize(n * cap);
+  if (orb && desc.size() < n * cap * 32) desc.resize(n * cap * 32);
+  dev->Check(sdvl_filter_inputs(dev->ctx(), n, devs.data(), static_cast<int>(cap), xyl.data(), scores.data(), orb ? desc.data() : nullptr,
+                                counts.data()), "sdvl_filter_inputs");
   for (int i = 0; i < n; i++) {
     Frame &f = *frames[i];
+    const int cnt = counts[i];
+    if (!f.corners_on_host_) {
+      f.corners_.resize(cnt);
+      for (int k = 0; k < cnt; k++) f.corners_[k] = Vector3i(xyl[(i * cap + k) * 3], xyl[(i * cap + k) * 3 + 1], xyl[(i * cap + k) * 3 + 2]);
+      f.corners_on_host_ = true;
+    }
     FastDetector detector(f.width_, f.height_);
     for (auto it = f.features_.begin(); it != f.features_.end(); it++) detector.LockCell((*it)->GetPosition());
-    detector.FilterWithScores(f.pyramid_, f.corners_, scores.data() + static_cast<size_t>(i) * SDVL_MAX_CORNERS, &f.filtered_corners_);
-    if (Config::UseORB()) f.GetDescriptors();  // frame.cc:145-161: descriptors of the filtered corners on the host
+    detector.FilterWithScores(f.pyramid_, f.corners_, scores.data() + i * cap, &f.filtered_corners_);
+    if (orb) {  // frame.cc:145-161: descriptors of the filtered corners on the host
+      f.descriptors_.resize(cnt);
+      for (int index : f.filtered_corners_)
+        if (f.descriptors_[index].empty()) f.descriptors_[index].assign(desc.begin() + (i * cap + index) * 32, desc.begin() + (i * cap + index + 1) * 32);
+    }
   }
 }
 
@@ -598,7 +614,7 @@ void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shar
       sdvl_align_feature a;
       a.px = ft->GetPosition()(0); a.py = ft->GetPosition()(1);
       a.fx = ft->GetVector()(0); a.fy = ft->GetVector()(1); a.fz = ft->GetVector()(2);
-      shared_ptr<Point> pt = ft->GetPoint();
+      Point *pt = ft->GetPointRaw();
       a.valid = (pt && !pt->ToDelete()) ? 1 : 0;
       a.depth = 0.0;
       if (a.valid) {
@@ -666,7 +682,8 @@ bool Matcher::MakeRequest(const shared_ptr<Frame> &frame, const shared_ptr<Featu
   req->px0[0] = px(0); req->px0[1] = px(1);
   req->level = feature->GetLevel();
   req->fixed = fixed ? 1 : 0;
-  std::memcpy(req->desc, feature->GetDescriptor().data(), 32);
+  if (feature->HasDescriptor()) std::memcpy(req->desc, feature->GetDescriptor().data(), 32);
+  else std::memset(req->desc, 0, 32);
   return true;
 }
 
@@ -733,7 +750,7 @@ void PlaneMap::SeedFromFiltered(const shared_ptr<Frame> &kf) {
   const M3 Rw = world.GetRotation();
   const Vector3d tw = world.GetTranslation();
   vector<Vector3i> &corners = kf->GetCorners();
-  vector<vector<uchar>> &descriptors = kf->GetDescriptors();
+  vector<vector<uchar>> &descriptors = kf->HostDescriptors();  // filled by FilterCorners (frame.cc:145-161)
   for (int index : kf->GetFilteredCorners()) {
     const Vector3i corner = corners[index];
     const int scale = (1 << corner(2));
@@ -769,50 +786,48 @@ FeatureAlign::FeatureAlign(Map *map, Camera *camera, int max_matches, RandStream
   grid_height_ = static_cast<int>(std::ceil(static_cast<double>(camera->GetHeight()) / cell_size_));
   const int size = grid_width_ * grid_height_;
   grid_.resize(size);
-  for (auto &c : grid_) c = new GridCell;
   for (int i = 0; i < size; ++i) cell_order_.push_back(i);
   rng_->Shuffle(&cell_order_);
 }
 
-FeatureAlign::~FeatureAlign() {
-  for (auto c : grid_) delete c;
-}
+FeatureAlign::~FeatureAlign() {}
 
-// feature_align.cc:285-294
-void FeatureAlign::ResetGrid() {
+// feature_align.cc:285-339 (ResetGrid + ProjectPoints + ProjectPoint)
+void FeatureAlign::ProjectPoints(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame) {
   matches_ = 0;
   num_attempts_ = 0;
-  for (auto c : grid_) c->clear();
-}
-
-// feature_align.cc:296-339
-void FeatureAlign::ProjectPoints(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame) {
-  ResetGrid();
+  for (auto &c : grid_) c.clear();
   vector<shared_ptr<Feature>> &features = last_frame->GetFeatures();
-  for (auto it = features.begin(); it != features.end(); it++) {
-    if (*it == nullptr) continue;
-    shared_ptr<Point> point = (*it)->GetPoint();
+  const Rigid pose = frame->GetPose().pod();
+  const M3 R = se3_rot(pose);  // Frame::Project = pose_ * p3D (frame.cc:94-103), rotation hoisted out of the loop
+  const int patch = Config::PatchSize();
+  const int frame_id = frame->GetID();
+  const int n = static_cast<int>(features.size());
+  for (int i = 0; i < n; i++) {
+    Feature *ft = features[i].get();
+    if (ft == nullptr) continue;
+    Point *point = ft->GetPointRaw();
     if (!point || point->ToDelete()) continue;
-    if (frame->GetID() == point->GetLastFrame()) continue;
-    ProjectPoint(frame, point);
-    if (!relocalizing_) point->SetLastFrame(frame->GetID());
+    if (frame_id == point->GetLastFrame()) continue;
+    {  // ProjectPoint
+      const Vector3d P = point->GetPosition();
+      const V3 rel = vadd(mvec(R, {P(0), P(1), P(2)}), pose.t);
+      bool ok = !(rel.z < 0.0);
+      Vector2d p;
+      if (ok) {
+        camera_->Project(Vector3d(rel.x, rel.y, rel.z), &p);
+        ok = camera_->IsInsideImage(Vector2i(static_cast<int>(p(0)), static_cast<int>(p(1))), patch);
+      }
+      if (!ok) {
+        point->SetStatus(Point::P_UNSEEN);
+      } else {
+        const int k = static_cast<int>(p(1) / cell_size_) * grid_width_ + static_cast<int>(p(0) / cell_size_);
+        grid_.at(k).push_back(CellEntry{i, p, point->Score()});
+        point->SetStatus(Point::P_SEEN);
+      }
+    }
+    if (!relocalizing_) point->SetLastFrame(frame_id);
   }
-}
-
-bool FeatureAlign::ProjectPoint(const shared_ptr<Frame> &frame, const shared_ptr<Point> &point) {
-  Vector2d p;
-  if (!frame->Project(point->GetPosition(), &p)) {
-    point->SetStatus(Point::P_UNSEEN);
-    return false;
-  }
-  if (!frame->GetCamera()->IsInsideImage(Vector2i(static_cast<int>(p(0)), static_cast<int>(p(1))), Config::PatchSize())) {
-    point->SetStatus(Point::P_UNSEEN);
-    return false;
-  }
-  const int k = static_cast<int>(p(1) / cell_size_) * grid_width_ + static_cast<int>(p(0) / cell_size_);
-  grid_.at(k)->push_back(std::make_pair(point, p));
-  point->SetStatus(Point::P_SEEN);
-  return true;
 }
 
 // first half of SelectPoints (feature_align.cc:88-118): project, shuffle, sort every cell, emit ALL candidates
@@ -820,65 +835,97 @@ void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared
                                     vector<sdvl_search_req> *reqs) {
   inliers_.clear();
   outliers_.clear();
+  found_.clear();
+  obs_.clear();
   relocalizing_ = reloc;
+  last_frame_ = last_frame;
   ProjectPoints(frame, last_frame);
   matches_ = 0;
   num_attempts_ = 0;
   rng_->Shuffle(&cell_order_);
   const int size = static_cast<int>(grid_.size());
-  plan_.assign(size, {});
+  plan_.clear();
+  plan_begin_.assign(size + 1, 0);
+  vector<shared_ptr<Feature>> &features = last_frame->GetFeatures();
+  double cur_pose[7];
+  frame->GetPose().ToArray(cur_pose);
+  size_t total = 0;
+  for (auto &c : grid_) total += c.size();
+  reqs->reserve(reqs->size() + total);
+  req_base_ = static_cast<int>(reqs->size());
   for (int i = 0; i < size; i++) {
-    GridCell *cell = grid_.at(cell_order_[i]);
-    cell->sort([](const PointInfo &a, const PointInfo &b) { return a.first->Score() > b.first->Score(); });
-    for (auto it = cell->begin(); it != cell->end(); it++) {
-      shared_ptr<Point> point = it->first;
+    plan_begin_[i] = static_cast<int>(plan_.size());
+    vector<CellEntry> &cell = grid_[cell_order_[i]];
+    // cell->sort(CompareQuality): std::list::sort is a stable merge sort
+    if (cell.size() > 1) std::stable_sort(cell.begin(), cell.end(), [](const CellEntry &a, const CellEntry &b) { return a.score > b.score; });
+    for (const CellEntry &e : cell) {
+      Point *point = features[e.src]->GetPointRaw();
       if (point->ToDelete()) continue;
-      shared_ptr<Feature> feature = point->GetInitFeature();
+      Feature *feature = point->GetInitFeatureRaw();
       if (!feature) continue;
-      Candidate c;
-      c.point = point;
-      c.pos = it->second;
-      c.req = -1;
-      sdvl_search_req rq;
-      if (Matcher::MakeRequest(frame, feature, point->GetInverseDepth(), point->GetStd(), point->IsFixed(), it->second, &rq)) {
-        c.req = static_cast<int>(reqs->size());
-        reqs->push_back(rq);
+      Candidate c{e.src, -1};
+      shared_ptr<Frame> ref_frame = feature->GetFrame();
+      if (ref_frame) {
+        reqs->emplace_back();
+        sdvl_search_req &rq = reqs->back();
+        rq.cur = frame->device();
+        rq.ref = ref_frame->device();
+        std::memcpy(rq.cur_pose, cur_pose, sizeof(cur_pose));
+        ref_frame->GetPose().ToArray(rq.ref_pose);
+        rq.px[0] = feature->GetPosition()(0); rq.px[1] = feature->GetPosition()(1);
+        rq.bearing[0] = feature->GetVector()(0); rq.bearing[1] = feature->GetVector()(1); rq.bearing[2] = feature->GetVector()(2);
+        rq.idepth = point->GetInverseDepth();
+        rq.idepth_std = point->GetStd();
+        rq.px0[0] = e.p(0); rq.px0[1] = e.p(1);
+        rq.level = feature->GetLevel();
+        rq.fixed = point->IsFixed() ? 1 : 0;
+        if (feature->HasDescriptor()) std::memcpy(rq.desc, feature->GetDescriptor().data(), 32);
+        else std::memset(rq.desc, 0, 32);
+        c.req = static_cast<int>(reqs->size()) - 1 - req_base_;  // relative: FinishReproject gets res + req_base
       }
-      plan_[i].push_back(c);
+      plan_.push_back(c);
     }
   }
+  plan_begin_[size] = static_cast<int>(plan_.size());
 }
 
 // second half of SelectPoints (feature_align.cc:105-149) replayed over the batch results, then SelectInliers
 void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
-  vector<shared_ptr<Feature>> selected_fs;
-  const int size = static_cast<int>(plan_.size());
+  const int size = static_cast<int>(plan_begin_.size()) - 1;
+  vector<shared_ptr<Feature>> &src_features = last_frame_->GetFeatures();
   for (int i = 0; i < size && matches_ < max_matches_; i++) {
     bool found = false;
-    for (auto it = plan_[i].begin(); it != plan_[i].end() && !found; it++) {
-      shared_ptr<Point> point = it->point;
+    for (int k = plan_begin_[i]; k < plan_begin_[i + 1] && !found; k++) {
+      const Candidate &cand = plan_[k];
       num_attempts_++;
-      found = it->req >= 0 && res[it->req].found != 0;
+      const sdvl_search_res *r = cand.req >= 0 ? &res[cand.req] : nullptr;
+      found = r && r->found != 0;
       if (found) {
         if (!relocalizing_) {
+          shared_ptr<Point> point = src_features[cand.src]->GetPoint();
           point->Promote();
-          shared_ptr<Feature> feature = std::make_shared<Feature>(frame, Vector2d(res[it->req].px[0], res[it->req].px[1]), res[it->req].level);
+          shared_ptr<Feature> feature = std::make_shared<Feature>(frame, Vector2d(r->px[0], r->px[1]), r->level);
           feature->SetPoint(point);
           frame->AddFeature(feature);
           point->SetStatus(Point::P_FOUND);
-          selected_fs.push_back(feature);
+          const Vector3d P = point->GetPosition();
+          const Vector3d &v = feature->GetVector();
+          obs_.push_back(Obs{v(0) / v(2), v(1) / v(2), P(0), P(1), P(2), 1.0 / (1 << r->level)});
+          found_.push_back(std::move(feature));
         }
         matches_++;
       } else {
         if (!relocalizing_) {
-          if (point->Unpromote()) map_->DeletePoint(point);
+          Point *point = src_features[cand.src]->GetPointRaw();
+          if (point->Unpromote()) map_->DeletePoint(src_features[cand.src]->GetPoint());
           point->SetStatus(Point::P_NOT_FOUND);
         }
       }
     }
   }
   plan_.clear();
-  SelectInliers(frame, selected_fs, &inliers_, &outliers_);
+  last_frame_.reset();
+  SelectInliers(frame);
 }
 
 // feature_align.cc:59-71
@@ -887,38 +934,38 @@ void FeatureAlign::Reproject(const shared_ptr<Frame> &frame, const shared_ptr<Fr
   PrepareReproject(frame, last_frame, reloc, &reqs);
   vector<sdvl_search_res> res;
   Matcher::SearchPoints(Device::Current(), reqs, *camera_, &res);
-  FinishReproject(frame, res.data());
+  FinishReproject(frame, res.data() + req_base_);
 }
 
 // feature_align.cc:73-82
 bool FeatureAlign::OptimizePose(const shared_ptr<Frame> &frame) {
-  OptimizePose(frame, &inliers_, &outliers_);
-  if (RescueOutliers(frame, &inliers_, &outliers_)) OptimizePose(frame, &inliers_, &outliers_);
-  RemoveOutliers(frame, &outliers_);
+  OptimizePoseOnce(frame);
+  if (RescueOutliers(frame)) OptimizePoseOnce(frame);
+  RemoveOutliers(frame);
   return true;
 }
 
 // feature_align.cc:152-216
-void FeatureAlign::SelectInliers(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> &fs_found, vector<shared_ptr<Feature>> *inliers,
-                                 vector<shared_ptr<Feature>> *outliers) {
-  inliers->clear();
-  outliers->clear();
-  if (fs_found.empty()) return;
-  const int size = static_cast<int>(fs_found.size());
+void FeatureAlign::SelectInliers(const shared_ptr<Frame> &frame) {
+  inliers_.clear();
+  outliers_.clear();
+  if (found_.empty()) return;
+  const int size = static_cast<int>(found_.size());
   const int npoints = std::min(Config::MaxRansacPoints(), size);
-  vector<shared_ptr<Feature>> selected;
+  vector<int> all(size), selected(npoints);
+  for (int i = 0; i < size; i++) all[i] = i;
   SE3 se3, best_se3;
+  const SE3 frame_pose = frame->GetPose();
   const double sprob = 0.99;
   int nits = Config::MaxRansacIts();
   int best_supporters = 0;
   int it = 0;
   const double thr = Config::InlierErrorThreshold() / frame->GetCamera()->GetFx();
   while (it < nits) {
-    selected.clear();
     const int index = rng_->Next() % size;
-    for (int i = 0; i < npoints; i++) selected.push_back(fs_found.at((index + i) % size));
-    if (!ConvergePose(frame, selected, &se3)) { it++; continue; }
-    const int supporters = CheckReprojectionError(fs_found, se3, thr);
+    for (int i = 0; i < npoints; i++) selected[i] = (index + i) % size;
+    if (!ConvergePose(frame_pose, selected.data(), npoints, &se3)) { it++; continue; }
+    const int supporters = CheckReprojectionError(all, se3, thr, nullptr, nullptr);
     if (supporters > best_supporters) {
       best_supporters = supporters;
       best_se3 = se3;
@@ -930,99 +977,99 @@ void FeatureAlign::SelectInliers(const shared_ptr<Frame> &frame, vector<shared_p
     }
     it++;
   }
-  CheckReprojectionError(fs_found, best_se3, thr, inliers, outliers);
+  CheckReprojectionError(all, best_se3, thr, &inliers_, &outliers_);
 }
 
 // feature_align.cc:218-230
-void FeatureAlign::OptimizePose(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> *features, vector<shared_ptr<Feature>> *outliers) {
+void FeatureAlign::OptimizePoseOnce(const shared_ptr<Frame> &frame) {
   SE3 se3 = frame->GetPose();
-  if (!ConvergePose(frame, *features, &se3)) return;
+  if (!ConvergePose(frame->GetPose(), inliers_.data(), static_cast<int>(inliers_.size()), &se3)) return;
   frame->SetPose(se3);
-  vector<shared_ptr<Feature>> cfeatures = *features;
-  features->clear();
-  CheckReprojectionError(cfeatures, frame->GetPose(), Config::InlierErrorThreshold() / frame->GetCamera()->GetFx(), features, outliers);
+  vector<int> cfeatures = inliers_;
+  inliers_.clear();
+  CheckReprojectionError(cfeatures, frame->GetPose(), Config::InlierErrorThreshold() / frame->GetCamera()->GetFx(), &inliers_, &outliers_);
 }
 
 // feature_align.cc:232-243
-bool FeatureAlign::RescueOutliers(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> *inliers, vector<shared_ptr<Feature>> *outliers) {
-  const int init_inliers = static_cast<int>(inliers->size());
-  vector<shared_ptr<Feature>> cfeatures = *outliers;
-  outliers->clear();
-  CheckReprojectionError(cfeatures, frame->GetPose(), 2 * Config::InlierErrorThreshold() / frame->GetCamera()->GetFx(), inliers, outliers);
-  return static_cast<int>(inliers->size()) > init_inliers;
+bool FeatureAlign::RescueOutliers(const shared_ptr<Frame> &frame) {
+  const int init_inliers = static_cast<int>(inliers_.size());
+  vector<int> cfeatures = outliers_;
+  outliers_.clear();
+  CheckReprojectionError(cfeatures, frame->GetPose(), 2 * Config::InlierErrorThreshold() / frame->GetCamera()->GetFx(), &inliers_, &outliers_);
+  return static_cast<int>(inliers_.size()) > init_inliers;
 }
 
 // feature_align.cc:245-256
-void FeatureAlign::RemoveOutliers(const shared_ptr<Frame> &frame, vector<shared_ptr<Feature>> *outliers) {
-  for (auto it = outliers->begin(); it != outliers->end(); it++) {
-    shared_ptr<Point> p = (*it)->GetPoint();
+void FeatureAlign::RemoveOutliers(const shared_ptr<Frame> &frame) {
+  for (int i : outliers_) {
+    Feature &ft = *found_[i];
+    shared_ptr<Point> p = ft.GetPoint();
     if (!p) continue;
-    (*it)->SetPoint(nullptr);
+    ft.SetPoint(nullptr);
     p->SetStatus(Point::P_NOT_FOUND);
-    frame->AddOutlier((*it)->GetPosition());
+    frame->AddOutlier(ft.GetPosition());
   }
 }
 
-// feature_align.cc:258-283
-int FeatureAlign::CheckReprojectionError(const vector<shared_ptr<Feature>> &features, const SE3 &se3, double threshold,
-                                         vector<shared_ptr<Feature>> *inliers, vector<shared_ptr<Feature>> *outliers) {
+// feature_align.cc:258-283 over observation records (every found feature has a point until RemoveOutliers)
+int FeatureAlign::CheckReprojectionError(const vector<int> &idx, const SE3 &se3, double threshold, vector<int> *inliers, vector<int> *outliers) {
   int valids = 0;
-  for (auto it = features.begin(); it != features.end(); it++) {
-    shared_ptr<Point> point = (*it)->GetPoint();
-    if (!point) continue;
-    const Vector3d pos = se3 * point->GetPosition();
-    const Vector2d a = Camera::SimpleProject((*it)->GetVector()), b = Camera::SimpleProject(pos);
-    double ex = a(0) - b(0), ey = a(1) - b(1);
-    const double sqrt_inv_cov = 1.0 / (1 << (*it)->GetLevel());
-    ex *= sqrt_inv_cov;
-    ey *= sqrt_inv_cov;
+  const Rigid s = se3.pod();
+  const M3 R = se3_rot(s);
+  for (int i : idx) {
+    const Obs &o = obs_[i];
+    const V3 pos = vadd(mvec(R, {o.px, o.py, o.pz}), s.t);
+    double ex = o.ax - pos.x / pos.z, ey = o.ay - pos.y / pos.z;
+    ex *= o.inv_cov;
+    ey *= o.inv_cov;
     if (std::sqrt(ex * ex + ey * ey) <= threshold) {
       valids++;
-      if (inliers != NULL) inliers->push_back(*it);
+      if (inliers != NULL) inliers->push_back(i);
     } else {
-      if (outliers != NULL) outliers->push_back(*it);
+      if (outliers != NULL) outliers->push_back(i);
     }
   }
   return valids;
 }
 
 // feature_align.cc:341-421
-bool FeatureAlign::ConvergePose(const shared_ptr<Frame> &frame, const vector<shared_ptr<Feature>> &features, SE3 *se3) {
-  SE3 last_se3 = frame->GetPose();
-  Camera *camera = frame->GetCamera();
+bool FeatureAlign::ConvergePose(const SE3 &frame_pose, const int *idx, int n, SE3 *se3) {
+  SE3 last_se3 = frame_pose;
   *se3 = last_se3;
   double chi2 = 0.0;
-  vector<double> errors;
-  for (auto it = features.begin(); it != features.end(); it++) {
-    shared_ptr<Point> point = (*it)->GetPoint();
-    if (!point) continue;
-    const Vector3d pos = (*se3) * point->GetPosition();
-    const Vector2d a = Camera::SimpleProject((*it)->GetVector()), b = Camera::SimpleProject(pos);
-    double ex = a(0) - b(0), ey = a(1) - b(1);
-    const double s = 1.0 / (1 << (*it)->GetLevel());
-    ex *= s;
-    ey *= s;
-    errors.push_back(std::sqrt(ex * ex + ey * ey));
+  errors_.clear();
+  {
+    const Rigid s = se3->pod();
+    const M3 R = se3_rot(s);
+    for (int q = 0; q < n; q++) {
+      const Obs &o = obs_[idx[q]];
+      const V3 pos = vadd(mvec(R, {o.px, o.py, o.pz}), s.t);
+      double ex = o.ax - pos.x / pos.z, ey = o.ay - pos.y / pos.z;
+      ex *= o.inv_cov;
+      ey *= o.inv_cov;
+      errors_.push_back(std::sqrt(ex * ex + ey * ey));
+    }
   }
-  if (errors.empty()) return false;
-  auto mid = errors.begin() + static_cast<long>(std::floor(errors.size() / 2));  // GetMedianVector, extra/utils.cc:215-220
-  std::nth_element(errors.begin(), mid, errors.end());
+  if (errors_.empty()) return false;
+  auto mid = errors_.begin() + static_cast<long>(std::floor(errors_.size() / 2));  // GetMedianVector, extra/utils.cc:215-220
+  std::nth_element(errors_.begin(), mid, errors_.end());
   double scale = KMADNorm * (*mid);
+  const double fx = camera_->GetFx();
   for (int i = 0; i < Config::MaxOptimPoseIts(); i++) {
     double A[36], b[6];
     for (int r = 0; r < 6; r++) b[r] = 0.0;
     for (int r = 0; r < 36; r++) A[r] = 0.0;
     double new_chi2 = 0.0;
-    if (i == 5) scale = 0.85 / camera->GetFx();
-    for (auto it = features.begin(); it != features.end(); it++) {
-      shared_ptr<Point> point = (*it)->GetPoint();
-      if (!point) continue;
-      const Vector3d pos = (*se3) * point->GetPosition();
+    if (i == 5) scale = 0.85 / fx;
+    const Rigid s = se3->pod();
+    const M3 R = se3_rot(s);
+    for (int q = 0; q < n; q++) {
+      const Obs &o = obs_[idx[q]];
+      const V3 pos = vadd(mvec(R, {o.px, o.py, o.pz}), s.t);
       double J[12];
-      jacobian_3d_to_plane({pos(0), pos(1), pos(2)}, J);
-      const Vector2d pa = Camera::SimpleProject((*it)->GetVector()), pb = Camera::SimpleProject(pos);
-      double ex = pa(0) - pb(0), ey = pa(1) - pb(1);
-      const double sqrt_inv_cov = 1.0 / (1 << (*it)->GetLevel());
+      jacobian_3d_to_plane(pos, J);
+      double ex = o.ax - pos.x / pos.z, ey = o.ay - pos.y / pos.z;
+      const double sqrt_inv_cov = o.inv_cov;
       ex *= sqrt_inv_cov;
       ey *= sqrt_inv_cov;
       for (int c = 0; c < 12; c++) J[c] *= sqrt_inv_cov;

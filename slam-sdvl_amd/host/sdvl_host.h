@@ -140,6 +140,7 @@ class Feature {
   std::shared_ptr<Frame> GetFrame() { return frame_.lock(); }
   void SetFrame(const std::shared_ptr<Frame> &f) { frame_ = f; }
   std::shared_ptr<Point> GetPoint() const { return point_; }
+  Point *GetPointRaw() const { return point_.get(); }  // no reference-count traffic in the per-frame loops
   void SetPoint(const std::shared_ptr<Point> &p) { point_ = p; }
   const Vector2d &GetPosition() const { return p2d_; }
   const Vector3d &GetVector() const { return v_; }
@@ -168,6 +169,7 @@ class Point {
   double GetInverseDepth() { return rho_; }
   double GetStd();
   std::shared_ptr<Feature> GetInitFeature() { return feature_; }
+  Feature *GetInitFeatureRaw() const { return feature_.get(); }
   void SetInitFeature(const std::shared_ptr<Feature> &f) { feature_ = f; }
   int GetID() const { return id_; }
   Vector3d GetPosition() const;
@@ -222,6 +224,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   std::vector<int> &GetFilteredCorners() { return filtered_corners_; }
   std::vector<Vector2d> &GetOutliers() { return outliers_; }
   std::vector<std::vector<uchar>> &GetDescriptors();  // host mirror of the HBM descriptors
+  // the mirror as it stands (after FilterCorners: the filtered corners' entries), never touches the device
+  std::vector<std::vector<uchar>> &HostDescriptors() { return descriptors_; }
   Camera *GetCamera() const { return camera_; }
   int GetWidth() const { return width_; }
   int GetHeight() const { return height_; }
@@ -329,7 +333,9 @@ class PlaneMap : public Map {
 typedef std::pair<std::shared_ptr<Point>, Vector2d> PointInfo;
 typedef std::list<PointInfo> GridCell;
 
-// feature_align.h:42-116
+// feature_align.h:42-116.  Same public interface and arithmetic; internally the per-frame working set is flat
+// (observation records + index lists) instead of lists of shared_ptr, because this code is what the host CPU spends
+// its time on once the kernels are batched.
 class FeatureAlign {
  public:
   FeatureAlign(Map *map, Camera *camera, int max_matches, RandStream *rng);
@@ -347,32 +353,38 @@ class FeatureAlign {
   void FinishReproject(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res);
 
  private:
-  struct Candidate { std::shared_ptr<Point> point; Vector2d pos; int req; };  // req < 0: SearchPoint not evaluated
-  void SelectInliers(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> &fs_found,
-                     std::vector<std::shared_ptr<Feature>> *inliers, std::vector<std::shared_ptr<Feature>> *outliers);
-  void OptimizePose(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> *features,
-                    std::vector<std::shared_ptr<Feature>> *outliers);
-  bool RescueOutliers(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> *inliers,
-                      std::vector<std::shared_ptr<Feature>> *outliers);
-  void RemoveOutliers(const std::shared_ptr<Frame> &frame, std::vector<std::shared_ptr<Feature>> *outliers);
-  int CheckReprojectionError(const std::vector<std::shared_ptr<Feature>> &features, const SE3 &se3, double threshold,
-                             std::vector<std::shared_ptr<Feature>> *inliers = NULL, std::vector<std::shared_ptr<Feature>> *outliers = NULL);
-  void ResetGrid();
+  struct CellEntry { int src; Vector2d p; int score; };      // src = index into last_frame->GetFeatures()
+  struct Candidate { int src; int req; };                     // req < 0: SearchPoint not evaluated
+  struct Obs {                                                // one matched feature of the current frame
+    double ax, ay;       // Camera::SimpleProject(feature->GetVector())
+    double px, py, pz;   // point->GetPosition()
+    double inv_cov;      // 1 / (1 << level)
+  };
+  void SelectInliers(const std::shared_ptr<Frame> &frame);
+  void OptimizePoseOnce(const std::shared_ptr<Frame> &frame);
+  bool RescueOutliers(const std::shared_ptr<Frame> &frame);
+  void RemoveOutliers(const std::shared_ptr<Frame> &frame);
+  int CheckReprojectionError(const std::vector<int> &idx, const SE3 &se3, double threshold, std::vector<int> *inliers, std::vector<int> *outliers);
   void ProjectPoints(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame);
-  bool ProjectPoint(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Point> &point);
-  bool ConvergePose(const std::shared_ptr<Frame> &frame, const std::vector<std::shared_ptr<Feature>> &features, SE3 *se3);
-  double GetTukeyValue(double x);
+  bool ConvergePose(const SE3 &frame_pose, const int *idx, int n, SE3 *se3);
+  static double GetTukeyValue(double x);
 
   Map *map_;
   Camera *camera_;
   RandStream *rng_;
   int cell_size_, max_matches_, grid_width_, grid_height_;
-  std::vector<GridCell *> grid_;
+  std::vector<std::vector<CellEntry>> grid_;
   std::vector<int> cell_order_;
-  std::vector<std::vector<Candidate>> plan_;  // per visited cell (in cell_order_), candidates in Score order
+  std::vector<Candidate> plan_;             // candidates of all visited cells, in visiting order
+  std::vector<int> plan_begin_;             // per visited cell: first candidate (size = cells + 1)
+  int req_base_ = 0;                        // index of this tracker's first request in the caller's vector
+  std::shared_ptr<Frame> last_frame_;       // source of the projected points of the current Prepare/Finish pair
+  std::vector<std::shared_ptr<Feature>> found_;  // features created on the current frame (fs_found)
+  std::vector<Obs> obs_;                    // parallel to found_
+  std::vector<int> inliers_, outliers_;     // indices into found_
+  std::vector<double> errors_;              // scratch of ConvergePose
   int matches_, num_attempts_;
   bool relocalizing_;
-  std::vector<std::shared_ptr<Feature>> inliers_, outliers_;
   static constexpr double KMADNorm = 1.4826;
   static constexpr double KTukeyC = 4.6851 * 4.6851;
 };

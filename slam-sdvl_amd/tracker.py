@@ -132,7 +132,7 @@ class TrackerFarm:
         self.lib.sdvlh_farm_ctx.argtypes = [C.c_void_p, C.c_int]
         self.lib.sdvlh_farm_batch.restype = C.c_void_p
         self.lib.sdvlh_farm_batch.argtypes = [C.c_void_p, C.c_int]
-        self.lib.sdvlh_farm_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.sdvlh_farm_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         self.h = self.lib.sdvlh_farm_create(gpu, G, Bg, w, h, cam4.ctypes.data, plane4.ctypes.data, first_poses.ctypes.data,
                                             host_threads_per_group)
         if not self.h:
@@ -141,13 +141,14 @@ class TrackerFarm:
     def ctx_handle(self, g=0):
         return self.lib.sdvlh_farm_ctx(self.h, g)
 
-    def run(self, dev_frames):
-        """dev_frames: int array [n_steps, G*Bg] of device pointers -> FrameStats array [n_steps*G*Bg]"""
+    def run(self, dev_frames, workers=0):
+        """dev_frames: int array [n_steps, G*Bg] of device pointers -> FrameStats array [n_steps*G*Bg];
+        workers = host threads (0 = one per group); workers < G schedules group-steps dynamically"""
         dev_frames = np.ascontiguousarray(dev_frames, np.uint64)
         n_steps = dev_frames.shape[0]
         assert dev_frames.shape[1] == self.G * self.Bg
         out = (FrameStats * (n_steps * self.G * self.Bg))()
-        if self.lib.sdvlh_farm_run(self.h, n_steps, dev_frames.ctypes.data, self.w, out) != 0:
+        if self.lib.sdvlh_farm_run(self.h, n_steps, dev_frames.ctypes.data, self.w, out, int(workers)) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return out
 

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark through the C-ABI (one stream, no tracker): dispatch time of every kernel on a batch of
+n synthetic 640x480 frames, with the algorithmic bytes of SURVEY §8(d) -> GB/s.  Used to tune kernels in isolation.
+    python tools/kernel_bench.py [n_frames] [reps]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+sdvl = importlib.import_module("slam-sdvl_amd")
+shard = importlib.import_module("slam-sdvl_amd.shard")
+import bench as B  # noqa: E402  (se3_exp, make_view)
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+W, H = 640, 480
+ctx = sdvl.Context(0)
+buf = ctx.device_malloc(2 * n * W * H)
+views = [B.make_view(sdvl, B.se3_exp(shard.sequence_twist(i) * k), shard.sequence_seed(i), k) for k in (0, 3) for i in range(n)]
+ctx.synth_render(views, W, H, buf)
+fr0 = [sdvl.Frame(ctx, W, H) for _ in range(n)]
+fr3 = [sdvl.Frame(ctx, W, H) for _ in range(n)]
+for i in range(n):
+    fr0[i].set_image_device(buf + i * W * H)
+    fr3[i].set_image_device(buf + (n + i) * W * H)
+dp = sdvl.default_detect_params()
+cam = sdvl.Camera(W, H, *B.TUM_CAM)
+import ctypes as C
+arr0 = (C.c_void_p * n)(*[f.h for f in fr0])
+arr3 = (C.c_void_p * n)(*[f.h for f in fr3])
+lib = ctx.lib
+ctx.pyramid_build(fr0); ctx.pyramid_build(fr3)
+ctx._check(lib.sdvl_detect_corners(ctx.h, n, arr3, C.byref(dp), 1000))
+ctx._check(lib.sdvl_orb_describe(ctx.h, n, arr3, 4096, None))
+# alignment features on the plane z=2 seen from frame 0
+nf = 190
+rng = np.random.default_rng(1)
+feats = (sdvl.AlignFeature * (nf * n))()
+for j in range(n):
+    px = np.stack([rng.uniform(48, W - 48, nf), rng.uniform(48, H - 48, nf)], 1)
+    ray = np.stack([(px[:, 0] - B.TUM_CAM[2]) / B.TUM_CAM[0], (px[:, 1] - B.TUM_CAM[3]) / B.TUM_CAM[1], np.ones(nf)], 1)
+    b = ray / np.linalg.norm(ray, axis=1, keepdims=True)
+    for i in range(nf):
+        f = feats[j * nf + i]
+        f.px, f.py = px[i]; f.fx, f.fy, f.fz = b[i]; f.depth = 2.0 / b[i, 2]; f.valid = 1
+jobs = [(fr0[j], fr3[j], j * nf, (j + 1) * nf, [1, 0, 0, 0, 0, 0, 0]) for j in range(n)]
+ap = sdvl.default_align_params()
+ctx.timing_enable(True)
+ctx.timing_reset()
+its = 0
+for _ in range(reps):
+    ctx.pyramid_build(fr0)
+    ctx._check(lib.sdvl_detect_corners(ctx.h, n, arr0, C.byref(dp), 1000))
+    ctx._check(lib.sdvl_orb_describe(ctx.h, n, arr0, 4096, None))
+    res = ctx.image_align(jobs, feats, cam, ap)
+    its += sum(r.iters_run for r in res)
+ctx.synchronize()
+t = ctx.timing_get()
+counts = np.zeros(n, np.int32)
+ctx._check(lib.sdvl_frames_corner_counts(ctx.h, n, arr0, counts.ctypes.data_as(C.POINTER(C.c_int32))))
+nc = float(counts.mean())
+i_ia = its / (reps * n)
+P = [(W >> l) * (H >> l) for l in range(5)]
+alg = {"pyr_down": (sum(P[:4]) + sum(P[1:])) / 4.0, "fast_cells": sum(P[:3]) + 16 * nc, "select_corners": 4 * 10000 + 16 * nc, "pack_corners": 32 * nc,
+       "orb_describe": 993 * nc, "image_align": 147 * nf + 25 * nf * i_ia}
+print("n_frames=%d reps=%d corners/frame=%.0f GN evaluations/job=%.1f" % (n, reps, nc, i_ia))
+for k, (ms, launches) in sorted(t.items()):
+    us = ms / launches * 1e3
+    a = alg.get(k)
+    gbs = (a * n / (us * 1e-6) / 1e9) if a else float("nan")
+    print("  %-16s %8.1f us/launch  %7.2f us/frame  %8.1f GB/s algorithmic  (%.4f of 8 TB/s)" % (k, us, us / n, gbs, gbs / 8000))
