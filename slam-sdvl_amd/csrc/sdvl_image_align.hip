@@ -10,6 +10,8 @@
 //   Optimize (:86-125)            thread 0: pivoted LDLT 6x6, chi2 / NaN / stop_ tests, roll-back, T <- T * Exp(-x).
 // Float vs double follow the reference statement by statement; the only deviation is the reduction ORDER of H, Jres
 // (double) and chi2 (float in the reference, accumulated in double here), hence tolerance-class parity (1e-4).
+#include <stdlib.h>
+
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
 
@@ -282,6 +284,359 @@ __global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__re
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ LDS-resident path
+// Same algorithm for jobs with <= kLdsMaxF features (the tracking case: <= max_matches + one seed per grid cell).
+//  * reference patch value and template gradient (dx, dy) of every (feature, pixel) item live in LDS, the 2x6 frame
+//    Jacobian of every feature too; the 6-vector J of an item is rebuilt in registers exactly as the reference computes it
+//    ((dx*J0 + dy*J1) * fx/2^level, image_align.cc:263) — no Jacobian cache in HBM, no zero-fill per level;
+//  * J does not depend on the iteration (inverse compositional), so H = sum J J^T changes only when the SET of features
+//    that project inside the image changes; phase A detects that, and H is re-accumulated only then.  Reusing the stored
+//    H yields the value a full recomputation would (same items, same fixed reduction order);
+//  * thread 0 solves with a scratch-free, fully unrolled pivoted LDLT (same pivots and operation order as ldlt_solve6).
+constexpr int kLdsMaxF = 384;
+
+struct IaItem { float patch, dx, dy; };
+
+// ldlt_solve6 (sdvl_math.h) with compile-time indices only: swaps become predicated moves, so everything stays in registers
+__device__ void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
+  double a[36];
+  int tr[6];
+#pragma unroll
+  for (int i = 0; i < 36; i++) a[i] = Ain[i];
+  bool alive = true;  // false once the k == 0 pivot is exactly zero (all-zero diagonal): nothing more to do
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    int idx = k;
+    double big = fabs(a[7 * k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double v = fabs(a[7 * i]);
+      if (v > big) { big = v; idx = i; }
+    }
+    if (!alive) idx = k;
+    tr[k] = idx;
+    if (alive) {
+      // swap rows/cols k <-> idx of the lower triangle (Eigen ldlt unblocked), predicated on the run-time idx
+#pragma unroll
+      for (int c = k + 1; c < 6; c++) {
+        if (c == idx) {
+#pragma unroll
+          for (int j = 0; j < k; j++) { const double t = a[6 * k + j]; a[6 * k + j] = a[6 * c + j]; a[6 * c + j] = t; }
+#pragma unroll
+          for (int i = c + 1; i < 6; i++) { const double t = a[6 * i + k]; a[6 * i + k] = a[6 * i + c]; a[6 * i + c] = t; }
+          { const double t = a[7 * k]; a[7 * k] = a[7 * c]; a[7 * c] = t; }
+#pragma unroll
+          for (int i = k + 1; i < c; i++) { const double t = a[6 * i + k]; a[6 * i + k] = a[6 * c + i]; a[6 * c + i] = t; }
+        }
+      }
+      if (k > 0) {
+        double temp[6];
+#pragma unroll
+        for (int j = 0; j < k; j++) temp[j] = a[7 * j] * a[6 * k + j];
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < k; j++) acc += a[6 * k + j] * temp[j];
+        a[7 * k] -= acc;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+          double a2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < k; j++) a2 += a[6 * i + j] * temp[j];
+          a[6 * i + k] -= a2;
+        }
+      }
+      const double akk = a[7 * k];
+      const bool valid = fabs(akk) > 0.0;
+      if (k == 0 && !valid) {
+        alive = false;
+      } else if (valid) {
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) a[6 * i + k] /= akk;
+      }
+    }
+  }
+  double d[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) d[i] = bin[i];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+#pragma unroll
+    for (int c = k + 1; c < 6; c++)
+      if (tr[k] == c) { const double t = d[k]; d[k] = d[c]; d[c] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double acc = d[i];
+#pragma unroll
+    for (int j = 0; j < i; j++) acc -= a[6 * i + j] * d[j];
+    d[i] = acc;
+  }
+  const double tol = 1.0 / 1.7976931348623157e308;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (fabs(a[7 * i]) > tol) d[i] /= a[7 * i];
+    else d[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double acc = d[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) acc -= a[6 * j + i] * d[j];
+    d[i] = acc;
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+#pragma unroll
+    for (int c = k + 1; c < 6; c++)
+      if (tr[k] == c) { const double t = d[k]; d[k] = d[c]; d[c] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = d[i];
+}
+
+__global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *__restrict__ jobs,
+                                                                   const sdvl_align_feature *__restrict__ feats_all, Cam cam,
+                                                                   sdvl_align_params prm, int max_f, sdvl_align_result *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  // carve: items[max_f*16] | fjac[max_f*12] doubles | ui, vi ints | w[4] floats | ok, okprev, vis bytes
+  double *s_fj = reinterpret_cast<double *>(s_dyn);                       // [max_f][12], already multiplied by nothing (raw 2x6)
+  IaItem *s_item = reinterpret_cast<IaItem *>(s_fj + static_cast<size_t>(max_f) * 12);  // [max_f*16]
+  int *s_ui = reinterpret_cast<int *>(s_item + static_cast<size_t>(max_f) * 16);
+  int *s_vi = s_ui + max_f;
+  float *s_w = reinterpret_cast<float *>(s_vi + max_f);                   // [4][max_f]
+  uint8_t *s_ok = reinterpret_cast<uint8_t *>(s_w + static_cast<size_t>(4) * max_f);
+  uint8_t *s_okprev = s_ok + max_f;
+  uint8_t *s_vis = s_okprev + max_f;
+  __shared__ double s_red[kWaves][32];
+  __shared__ double s_sum[32];
+  __shared__ double s_H[21];
+  __shared__ double s_T[7], s_R[9];
+  __shared__ int s_break, s_abort, s_changed;
+
+  const IaJob &job = jobs[blockIdx.x];
+  const int nf = job.n_feat;
+  const sdvl_align_feature *F = feats_all + job.feat_begin;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_items = nf * 16;
+
+  Rigid T = se3_identity(), T_bk = se3_identity();
+  double chi2 = 1e10, error = 1e10;
+  bool stop = false;
+  int n_meas = 0, iters_run = 0;
+  int its0 = 0, its1 = 0, its2 = 0, its3 = 0, its4 = 0, its5 = 0, its6 = 0, its7 = 0;
+
+  for (int f = tid; f < nf; f += kThreads) s_vis[f] = 0;
+  if (tid == 0) {
+    T = se3_from7(job.T);
+    se3_to7(T, s_T);
+    const M3 R = se3_rot(T);
+    for (int i = 0; i < 9; i++) s_R[i] = R.m[i];
+    s_abort = 0;
+  }
+  __syncthreads();
+
+  for (int level = prm.max_level; level >= prm.min_level; level--) {
+    const int W = job.lw[level], H = job.lh[level];
+    const uint8_t *ref_img = job.ref_level[level];
+    const uint8_t *cur_img = job.cur_level[level];
+    const float scale = 1.0f / (1 << level);
+    const double fl = cam.fx / (1 << level);
+    // jacobian_cache_.setZero() (image_align.cc:69): items of features that fail this level's border test keep a zero J
+    for (int i = tid; i < n_items; i += kThreads) { s_item[i].dx = 0.f; s_item[i].dy = 0.f; }
+    for (int f = tid; f < nf; f += kThreads) s_okprev[f] = 2;  // forces H to be accumulated in the first iteration
+    if (tid == 0) T_bk = T;
+    __syncthreads();
+
+    for (int it = 0; it < prm.max_its; it++) {
+      if (it == 0) {
+        // ---- PrecomputePatches(level), image_align.cc:208-267
+        for (int idx = tid; idx < n_items; idx += kThreads) {
+          const int f = idx >> 4, p = idx & 15;
+          const sdvl_align_feature ft = F[f];
+          const float u_ref = static_cast<float>(ft.px * scale);
+          const float v_ref = static_cast<float>(ft.py * scale);
+          const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
+          const int border = 3;
+          if (!ft.valid || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) continue;
+          if (p == 0) {
+            s_vis[f] = 1;
+            const V3 xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+            double fj[12];
+            jacobian_3d_to_plane(xyz, fj);
+#pragma unroll
+            for (int c = 0; c < 12; c++) s_fj[f * 12 + c] = fj[c];
+          }
+          const float su = u_ref - ui, sv = v_ref - vi;
+          const float w_tl = static_cast<float>((1.0 - su) * (1.0 - sv));
+          const float w_tr = static_cast<float>(su * (1.0 - sv));
+          const float w_bl = static_cast<float>((1.0 - su) * sv);
+          const float w_br = su * sv;
+          const int y = p >> 2, x = p & 3;
+          const uint8_t *ip = ref_img + static_cast<size_t>(vi + y - 2) * W + (ui + x - 2);
+          const int st = W;
+          IaItem item;
+          item.patch = w_tl * ip[0] + w_tr * ip[1] + w_bl * ip[st] + w_br * ip[st + 1];
+          item.dx = 0.5f * ((w_tl * ip[1] + w_tr * ip[2] + w_bl * ip[st + 1] + w_br * ip[st + 2]) -
+                            (w_tl * ip[-1] + w_tr * ip[0] + w_bl * ip[st - 1] + w_br * ip[st]));
+          item.dy = 0.5f * ((w_tl * ip[st] + w_tr * ip[1 + st] + w_bl * ip[st * 2] + w_br * ip[st * 2 + 1]) -
+                            (w_tl * ip[-st] + w_tr * ip[1 - st] + w_bl * ip[0] + w_br * ip[1]));
+          s_item[idx] = item;
+        }
+        __syncthreads();
+      }
+      // ---- ComputeResiduals phase A: per-feature projection, image_align.cc:147-181
+      if (tid == 0) s_changed = 0;
+      __syncthreads();
+      for (int f = tid; f < nf; f += kThreads) {
+        uint8_t ok = 0;
+        if (s_vis[f]) {
+          const sdvl_align_feature ft = F[f];
+          const V3 xr = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+          const V3 xc = {s_R[0] * xr.x + s_R[1] * xr.y + s_R[2] * xr.z + s_T[4], s_R[3] * xr.x + s_R[4] * xr.y + s_R[5] * xr.z + s_T[5],
+                         s_R[6] * xr.x + s_R[7] * xr.y + s_R[8] * xr.z + s_T[6]};
+          const V2 pr = cam_project(cam, xc);
+          const float u_cur = static_cast<float>(pr.x * scale);
+          const float v_cur = static_cast<float>(pr.y * scale);
+          const float fu = floorf(u_cur), fv = floorf(v_cur);
+          if (fu >= 3.f && fv >= 3.f && fu < static_cast<float>(W - 3) && fv < static_cast<float>(H - 3)) {
+            const int ui = static_cast<int>(fu), vi = static_cast<int>(fv);
+            const float su = u_cur - ui, sv = v_cur - vi;
+            s_ui[f] = ui;
+            s_vi[f] = vi;
+            s_w[f] = static_cast<float>((1.0 - su) * (1.0 - sv));
+            s_w[max_f + f] = static_cast<float>(su * (1.0 - sv));
+            s_w[2 * max_f + f] = static_cast<float>((1.0 - su) * sv);
+            s_w[3 * max_f + f] = su * sv;
+            ok = 1;
+          }
+        }
+        if (ok != s_okprev[f]) s_changed = 1;
+        s_ok[f] = ok;
+        s_okprev[f] = ok;
+      }
+      __syncthreads();
+      const bool rebuild_h = s_changed != 0;
+      // ---- phase B: residuals + normal equations, image_align.cc:182-203
+      double acc[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) acc[i] = 0.0;
+      for (int idx = tid; idx < n_items; idx += kThreads) {
+        const int f = idx >> 4;
+        if (!s_ok[f]) continue;
+        const int p = idx & 15, y = p >> 2, x = p & 3;
+        const uint8_t *ip = cur_img + static_cast<size_t>(s_vi[f] + y - 2) * W + (s_ui[f] + x - 2);
+        const float intensity = s_w[f] * ip[0] + s_w[max_f + f] * ip[1] + s_w[2 * max_f + f] * ip[W] + s_w[3 * max_f + f] * ip[W + 1];
+        const IaItem item = s_item[idx];
+        const float res = intensity - item.patch;
+        const double *fj = &s_fj[f * 12];
+        double J[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) J[c] = (item.dx * fj[c] + item.dy * fj[6 + c]) * fl;
+        if (rebuild_h) {
+          int k = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = r; c < 6; c++) acc[k++] += J[r] * J[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[21 + r] -= J[r] * res;
+        acc[27] += static_cast<double>(res * res);
+        acc[28] += 1.0;
+      }
+      const double tot = wave_reduce32(acc, lane);
+      if ((lane & 1) == 0) {
+        const int vidx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) |
+                         ((lane >> 1) & 1);
+        s_red[wave][vidx] = tot;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) sacc += s_red[w][tid];
+        if (tid < 21) {
+          if (rebuild_h) s_H[tid] = sacc;  // keep for the iterations in which the contributing set stays the same
+          else sacc = s_H[tid];
+        }
+        s_sum[tid] = sacc;
+      }
+      __syncthreads();
+      // ---- Optimize body, image_align.cc:93-124
+      if (tid == 0) {
+        double Hm[36], Jres[6], xs[6];
+        {
+          int k = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = r; c < 6; c++) {
+              Hm[6 * r + c] = s_sum[k];
+              Hm[6 * c + r] = s_sum[k];
+              k++;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) Jres[r] = s_sum[21 + r];
+        n_meas = static_cast<int>(s_sum[28]);
+        iters_run++;
+        const double new_chi2 = static_cast<double>(static_cast<float>(s_sum[27]) / static_cast<float>(n_meas));
+        if (n_meas == 0) stop = true;
+        ldlt_solve6_reg(Hm, Jres, xs);
+        if (xs[0] != xs[0]) stop = true;
+        int brk = 0;
+        if ((it > 0 && new_chi2 > chi2) || stop) {
+          T = T_bk;
+          brk = 1;
+        } else {
+          T_bk = T;
+          double mx[6];
+#pragma unroll
+          for (int r = 0; r < 6; r++) mx[r] = -xs[r];
+          T = se3_mul(T, se3_exp(mx));
+          chi2 = new_chi2;
+          switch (level) {
+            case 0: its0++; break; case 1: its1++; break; case 2: its2++; break; case 3: its3++; break;
+            case 4: its4++; break; case 5: its5++; break; case 6: its6++; break; default: its7++; break;
+          }
+          error = abs_max6(xs);
+          if (error <= 1e-10) brk = 1;
+        }
+        se3_to7(T, s_T);
+        const M3 R = se3_rot(T);
+#pragma unroll
+        for (int i = 0; i < 9; i++) s_R[i] = R.m[i];
+        s_break = brk;
+      }
+      __syncthreads();
+      if (s_break) break;
+    }
+    if (tid == 0 && prm.fast && error > 0.01) {
+      error = 1e10;
+      s_abort = 1;
+    }
+    __syncthreads();
+    if (s_abort) break;
+  }
+  if (tid == 0) {
+    sdvl_align_result r;
+    se3_to7(T, r.T);
+    r.error = error;
+    r.chi2 = chi2;
+    r.n_meas = n_meas / 16;
+    r.its[0] = its0; r.its[1] = its1; r.its[2] = its2; r.its[3] = its3; r.its[4] = its4; r.its[5] = its5; r.its[6] = its6; r.its[7] = its7;
+    r.stop = stop ? 1 : 0;
+    r.iters_run = iters_run;
+    r.pad_ = 0;
+    out[blockIdx.x] = r;
+  }
+}
+
+size_t ia_lds_bytes(int max_f) {
+  return static_cast<size_t>(max_f) * (12 * sizeof(double) + 16 * sizeof(IaItem) + 2 * sizeof(int) + 4 * sizeof(float) + 3) + 64;
+}
+
 }  // namespace
 
 extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
@@ -294,6 +649,7 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
   SDVL_REQUIRE(ctx, p->min_level >= 0 && p->max_level >= p->min_level && p->max_level < SDVL_MAX_LEVELS, "bad align levels");
   SDVL_REQUIRE(ctx, p->max_its >= 0, "bad max_its");
   size_t work = 0;
+  int max_nf = 0;
   for (int j = 0; j < n_jobs; j++) {
     const sdvl_align_job &a = jobs[j];
     SDVL_REQUIRE(ctx, a.ref && a.cur, "null frame in alignment job");
@@ -305,6 +661,7 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
       ctx->err = "too many features in one alignment job (SDVL_MAX_ALIGN_FEATURES)";
       return SDVL_ERR_CAPACITY;
     }
+    if (a.feat_end - a.feat_begin > max_nf) max_nf = a.feat_end - a.feat_begin;
     work += static_cast<size_t>(a.feat_end - a.feat_begin) * 16 * (sizeof(float) + 6 * sizeof(double));
     work = (work + 255) / 256 * 256;
   }
@@ -342,7 +699,26 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
   if (feat_bytes) memcpy(static_cast<uint8_t *>(hs) + job_bytes, features, feat_bytes);
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, job_bytes + feat_bytes, hipMemcpyHostToDevice, ctx->stream));
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  SDVL_LAUNCH(ctx, "image_align", image_align_kernel, dim3(n_jobs), dim3(kThreads), static_cast<const IaJob *>(dsx), reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p, static_cast<sdvl_align_result *>(ctx->d_out));
+  const bool use_lds = max_nf <= kLdsMaxF && !getenv("SDVL_IMAGE_ALIGN_GENERIC");
+  if (use_lds) {
+    const int max_f = (max_nf + 7) / 8 * 8 + 8;
+    const size_t lds = ia_lds_bytes(max_f);
+    static bool attr_set = false;
+    if (!attr_set) {
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_lds_bytes(kLdsMaxF + 16))));
+      attr_set = true;
+    }
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
+    hipExtLaunchKernelGGL(image_align_lds_kernel, dim3(n_jobs), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                          reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p, max_f,
+                          static_cast<sdvl_align_result *>(ctx->d_out));
+  } else {
+    SDVL_LAUNCH(ctx, "image_align", image_align_kernel, dim3(n_jobs), dim3(kThreads), static_cast<const IaJob *>(dsx),
+                reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p,
+                static_cast<sdvl_align_result *>(ctx->d_out));
+  }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
