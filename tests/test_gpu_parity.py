@@ -313,3 +313,74 @@ def test_errors_are_reported_not_swallowed(ctx, sdvl):
     with pytest.raises(sdvl.SdvlError):
         f.set_corners(np.zeros((5000, 3), np.int32))         # capacity
     f.close()
+
+
+# ------------------------------------------------------------------------------------------------ more cases
+def test_search_points_zmssd_mode(ctx, sdvl, orc, synth):
+    """use_orb = 0 (the config.cc default): margin 1 + PatchSize/2, best corner by integer ZMSSD (matcher.cc:447-476)"""
+    img_ref, img_cur = frames_of(synth, orc, TUM_CAM, 640, 480, [0, 4])
+    T_ref, T_cur = trajectory_pose(orc, 0), trajectory_pose(orc, 4)
+    orc.params.use_orb = 0
+    try:
+        rng = np.random.default_rng(5)
+        cref, ccur = orc.detect_pyramid(img_ref), orc.detect_pyramid(img_cur)
+        f_ref, f_cur = ctx.frame(img_ref), ctx.frame(img_cur)
+        f_cur.set_corners(ccur)
+        sel = rng.choice(len(cref), size=120, replace=False)
+        reqs = (sdvl.SearchReq * len(sel))()
+        meta = []
+        from oraclelib import quat_to_R
+        Rc, tc = quat_to_R(T_cur[:4]), T_cur[4:]
+        for i, ci in enumerate(sel):
+            x, y, l = cref[ci]
+            px = np.array([x * (1 << l), y * (1 << l)], np.float64)
+            ray = np.array([(px[0] - TUM_CAM[2]) / TUM_CAM[0], (px[1] - TUM_CAM[3]) / TUM_CAM[1], 1.0])
+            bearing = ray / np.linalg.norm(ray)
+            s = 2.0 / bearing[2]
+            pc = Rc @ (bearing * s) + tc
+            px0 = np.array([TUM_CAM[2] + TUM_CAM[0] * pc[0] / pc[2], TUM_CAM[3] + TUM_CAM[1] * pc[1] / pc[2]]) + rng.normal(size=2) * 0.5
+            r = reqs[i]
+            r.cur, r.ref = f_cur.h.value, f_ref.h.value
+            for k in range(7):
+                r.cur_pose[k], r.ref_pose[k] = T_cur[k], T_ref[k]
+            r.px[0], r.px[1] = px
+            r.bearing[0], r.bearing[1], r.bearing[2] = bearing
+            r.idepth, r.idepth_std = 1.0 / s, 0.05 / s
+            r.px0[0], r.px0[1] = px0
+            r.level, r.fixed = int(l), 1
+            meta.append((px, bearing, int(l), 1.0 / s, 0.05 / s, px0))
+        res = ctx.search_points(reqs, sdvl.Camera(640, 480, *TUM_CAM), sdvl.default_search_params(use_orb=False))
+        n_found = 0
+        for r, (px, bearing, l, idep, istd, px0) in zip(res, meta):
+            want = orc.search_point(img_ref, img_cur, TUM_CAM, T_ref, T_cur, px, bearing, l, np.zeros(32, np.uint8), idep, istd, True, ccur, px0)
+            assert r.found == want["found"]
+            if want["found"]:
+                n_found += 1
+                assert np.array_equal(np.array(r.px[:]), want["px"]) and r.level == want["level"]
+        assert n_found >= 30
+        f_ref.close(); f_cur.close()
+    finally:
+        orc.params.use_orb = 1
+
+
+def test_detect_corners_config_c_size(ctx, sdvl, orc):
+    """1280x960 (BASELINE config 5): 1200 + 300 + 80 cells, 4000 features"""
+    img = rand_img(9, 960, 1280)
+    img = (img.astype(np.float32) * 0.25 + 96).astype(np.uint8)      # lower contrast: fewer, less tied corners
+    f = ctx.frame(img)
+    got = ctx.detect_corners([f], sdvl.default_detect_params(), 4000)[0]
+    assert len(got) <= 4096
+    want = orc.detect_pyramid(img, nfeatures=4000)
+    assert np.array_equal(got, want)
+    f.close()
+
+
+def test_empty_batches_and_flat_frames(ctx, sdvl, orc):
+    lib = ctx.lib
+    assert lib.sdvl_pyramid_build(ctx.h, 0, None) == 0
+    assert lib.sdvl_search_points(ctx.h, 0, None, C.byref(sdvl.Camera(640, 480, *TUM_CAM)), C.byref(sdvl.default_search_params()), None) == 0
+    flat = np.full((480, 640), 128, np.uint8)
+    f = ctx.frame(flat)
+    assert len(ctx.detect_corners([f], sdvl.default_detect_params(), 1000)[0]) == 0
+    assert ctx.orb_describe([f])[0].shape == (0, 32)
+    f.close()

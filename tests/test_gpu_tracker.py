@@ -55,3 +55,33 @@ def test_single_sequence_closed_loop(trk, orc, synth):
 def test_batch_of_sequences_closed_loop_threaded(trk, orc, synth):
     worst = run_case(trk, orc, synth, B=5, n_frames=9, threads=4)
     assert worst <= POSE_TOL
+
+
+def test_euroc_size_closed_loop(trk, orc, synth):
+    from oraclelib import EUROC_CAM
+    worst = run_case(trk, orc, synth, B=2, n_frames=8, threads=2, w=752, h=480, cam=EUROC_CAM)
+    assert worst <= POSE_TOL
+
+
+def test_lost_and_relocalize_matches_oracle(trk, orc, synth):
+    """three featureless frames -> TRACKING_BAD x3 -> Relocalize over the keyframes (sdvl.cc:73-89,205-238)"""
+    trk.configure()
+    dev = trk.HostDevice(0)
+    batch = trk.TrackerBatch(dev, 1, 640, 480, TUM_CAM)
+    ref = orc.tracker(640, 480, TUM_CAM)
+    seq = [0, 1, 2, 3, 4, 5, -1, -1, -1, 5, 6, 7]
+    relocs = 0
+    for k, idx in enumerate(seq):
+        if idx < 0:
+            img = np.full((480, 640), 127, np.uint8)
+        else:
+            img = synth.render(trajectory_pose(orc, idx), TUM_CAM, 640, 480, frame_id=idx)
+        g = batch.step_host([img])[0]
+        w = ref.handle_frame(img)
+        assert (g.quality, g.matches, g.attempts, g.inliers, g.keyframe, g.relocalized) == \
+               (w.quality, w.matches, w.attempts, w.inliers, w.keyframe, w.relocalized), (k, idx)
+        if idx >= 0:   # on a featureless frame the alignment is degenerate (its pose is discarded: TRACKING_BAD keeps last_frame_)
+            assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, (k, idx)
+        relocs += g.relocalized
+    assert relocs == 1
+    batch.close(); ref.close(); dev.close()
