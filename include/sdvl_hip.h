@@ -133,6 +133,8 @@ int sdvl_ctx_timing_reset(sdvl_ctx *ctx);
 
 /* ---- Frame: pyramid + corners (frame.cc:34-56) -------------------------------------------------------------- */
 int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_frame **out);
+/* n frames backed by one allocation (hipMalloc is slow and synchronises); the storage is released with the context */
+int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int n, sdvl_frame **out);
 int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f);
 /* pyramid_[0] = img (frame.cc:116): host image -> HBM (async on the context stream, staged through pinned memory) */
 int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stride);

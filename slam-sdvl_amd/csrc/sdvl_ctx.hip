@@ -141,6 +141,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+  for (void *sl : ctx->slabs) (void)hipFree(sl);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SDVL_OK;
@@ -190,76 +191,112 @@ int sdvl_ctx_timing_reset(sdvl_ctx *ctx) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_frame **out) {
-  if (!ctx || !out) return SDVL_ERR_INVALID;
-  *out = nullptr;
-  SDVL_REQUIRE(ctx, width >= 16 && height >= 16 && width <= 4095 && height <= 4095, "frame size out of range");
-  SDVL_REQUIRE(ctx, levels >= 1 && levels <= SDVL_MAX_LEVELS, "pyramid levels out of range");
-  SDVL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+
+namespace {
+struct FrameLayout {
+  size_t level_off[SDVL_MAX_LEVELS], corners_off, lvl_off, desc_off, counts_off, kps_off, bytes;
+  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS], max_cells;
+};
+
+bool frame_layout(int width, int height, int levels, FrameLayout *L) {
+  size_t off = 0;
+  int w = width, h = height;
+  for (int l = 0; l < levels; l++) {
+    if (w < 1 || h < 1) return false;
+    L->lw[l] = w;
+    L->lh[l] = h;
+    L->level_off[l] = off;
+    off = align_up(off + static_cast<size_t>(w) * h + 64, 256);  // +64: slack so that word loads may overrun a row end
+    w /= 2;
+    h /= 2;
+  }
+  L->corners_off = off;  // 16-byte header {count,0,0,0} + corner records, written by ONE copy
+  off = align_up(off + sizeof(int32_t) * 4 * (SDVL_MAX_CORNERS + 1), 256);
+  L->lvl_off = off;      // selection-kernel scratch: per-level segments + counts
+  off = align_up(off + sizeof(int32_t) * 4 * SDVL_MAX_CORNERS * 4 + 64, 256);
+  L->desc_off = off;
+  off = align_up(off + 32 * SDVL_MAX_CORNERS, 256);
+  // per-cell FAST lists: cell_size >= 32 on the 4 finest levels (smaller cells hold fewer corners each)
+  int max_cells = 0;
+  for (int l = 0; l < levels && l < 4; l++) max_cells += ((L->lw[l] + 15) / 16) * ((L->lh[l] + 15) / 16);
+  L->max_cells = max_cells / 4 + 64;
+  L->counts_off = off;
+  off = align_up(off + sizeof(int32_t) * (max_cells + 1), 256);
+  L->kps_off = off;
+  off = align_up(off + sizeof(uint32_t) * SDVL_CELL_KP_CAP * L->max_cells, 256);
+  L->bytes = off;
+  return true;
+}
+
+sdvl_frame *frame_bind(const FrameLayout &L, int width, int height, int levels, uint8_t *base, int in_slab) {
   sdvl_frame *f = new sdvl_frame();
   memset(&f->v, 0, sizeof(f->v));
   f->width = width;
   f->height = height;
-  size_t off = 0, lo[SDVL_MAX_LEVELS];
-  int w = width, h = height;
+  f->base = base;
+  f->bytes = L.bytes;
+  f->in_slab = in_slab;
   for (int l = 0; l < levels; l++) {
-    f->v.lw[l] = w;
-    f->v.lh[l] = h;
-    lo[l] = off;
-    off = align_up(off + static_cast<size_t>(w) * h + 64, 256);  // +64: slack so that 16-byte tile loads may overrun a row end
-    w /= 2;
-    h /= 2;
-    if (w < 1 || h < 1) { delete f; SDVL_REQUIRE(ctx, false, "image too small for the pyramid depth"); }
+    f->v.level[l] = base + L.level_off[l];
+    f->v.lw[l] = L.lw[l];
+    f->v.lh[l] = L.lh[l];
   }
-  const size_t corners_off = off;  // 16-byte header {count,0,0,0} + corner records, written by ONE copy
-  off = align_up(off + sizeof(int32_t) * 4 * (SDVL_MAX_CORNERS + 1), 256);
-  const size_t lvl_off = off;      // selection-kernel scratch: per-level segments + counts
-  off = align_up(off + sizeof(int32_t) * 4 * SDVL_MAX_CORNERS * 4 + 64, 256);
-  const size_t desc_off = off;
-  off = align_up(off + 32 * SDVL_MAX_CORNERS, 256);
-  // per-cell FAST lists: worst case cell size 16 on the 3 finest levels
-  int max_cells = 0;
-  for (int l = 0; l < levels && l < 4; l++) max_cells += ((f->v.lw[l] + 15) / 16) * ((f->v.lh[l] + 15) / 16);
-  f->max_cells = max_cells / 4 + 64;  // capacity (in cells) of the per-cell lists below: cell_size >= 32
-  const size_t counts_off = off;
-  off = align_up(off + sizeof(int32_t) * (max_cells + 1), 256);
-  const size_t kps_off = off;
-  off = align_up(off + sizeof(uint32_t) * SDVL_CELL_KP_CAP * f->max_cells, 256);
-  f->bytes = off;
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&f->base), off);
-  if (e != hipSuccess) {
-    ctx->err = std::string("hipMalloc(frame): ") + hipGetErrorString(e);
-    delete f;
-    return SDVL_ERR_HIP;
-  }
-  for (int l = 0; l < levels; l++) f->v.level[l] = f->base + lo[l];
   f->own_level0 = f->v.level[0];
   f->hdr_stale = 0;
   f->v.levels = levels;
   f->v.n_corners = 0;
-  f->v.corner_hdr = reinterpret_cast<int32_t *>(f->base + corners_off);
+  f->v.corner_hdr = reinterpret_cast<int32_t *>(base + L.corners_off);
   f->v.corners = f->v.corner_hdr + 4;
-  f->level_corners = reinterpret_cast<int32_t *>(f->base + lvl_off);
+  f->level_corners = reinterpret_cast<int32_t *>(base + L.lvl_off);
   f->level_counts = f->level_corners + static_cast<size_t>(4) * SDVL_MAX_CORNERS * 4;
-  f->v.desc = f->base + desc_off;
-  f->cell_counts = reinterpret_cast<int32_t *>(f->base + counts_off);
-  f->cell_kps = reinterpret_cast<uint32_t *>(f->base + kps_off);
+  f->v.desc = base + L.desc_off;
+  f->cell_counts = reinterpret_cast<int32_t *>(base + L.counts_off);
+  f->cell_kps = reinterpret_cast<uint32_t *>(base + L.kps_off);
+  f->max_cells = L.max_cells;
   f->desc_valid = 0;
-  hipError_t e2 = hipMemsetAsync(f->v.corner_hdr, 0, 16, ctx->stream);
-  if (e2 != hipSuccess) {
-    ctx->err = std::string("hipMemsetAsync(frame): ") + hipGetErrorString(e2);
-    (void)hipFree(f->base);
-    delete f;
+  return f;
+}
+}  // namespace
+
+int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_frame **out) {
+  return sdvl_frame_create_many(ctx, width, height, levels, 1, out);
+}
+
+// n frames out of ONE allocation (hipMalloc costs ~0.2 ms and synchronises; a tracker farm turns frames into keyframes
+// all the time).  The slab belongs to the context and is released with it; sdvl_frame_destroy only drops the handle.
+int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int n, sdvl_frame **out) {
+  if (!ctx || !out || n <= 0) return SDVL_ERR_INVALID;
+  for (int i = 0; i < n; i++) out[i] = nullptr;
+  SDVL_REQUIRE(ctx, width >= 16 && height >= 16 && width <= 4095 && height <= 4095, "frame size out of range");
+  SDVL_REQUIRE(ctx, levels >= 1 && levels <= SDVL_MAX_LEVELS, "pyramid levels out of range");
+  FrameLayout L;
+  SDVL_REQUIRE(ctx, frame_layout(width, height, levels, &L), "image too small for the pyramid depth");
+  SDVL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint8_t *base = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), L.bytes * static_cast<size_t>(n));
+  if (e != hipSuccess) {
+    ctx->err = std::string("hipMalloc(frames): ") + hipGetErrorString(e);
     return SDVL_ERR_HIP;
   }
-  *out = f;
+  const int in_slab = n > 1 ? 1 : 0;
+  if (in_slab) ctx->slabs.push_back(base);
+  for (int i = 0; i < n; i++) {
+    out[i] = frame_bind(L, width, height, levels, base + L.bytes * static_cast<size_t>(i), in_slab);
+    e = hipMemsetAsync(out[i]->v.corner_hdr, 0, 16, ctx->stream);
+    if (e != hipSuccess) {
+      ctx->err = std::string("hipMemsetAsync(frame): ") + hipGetErrorString(e);
+      return SDVL_ERR_HIP;
+    }
+  }
   return SDVL_OK;
 }
 
 int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f) {
   if (!ctx || !f) return SDVL_ERR_INVALID;
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  SDVL_HIP_CHECK(ctx, hipFree(f->base));
+  if (!f->in_slab) {
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+    SDVL_HIP_CHECK(ctx, hipFree(f->base));
+  }
   delete f;
   return SDVL_OK;
 }

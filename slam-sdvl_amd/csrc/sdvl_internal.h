@@ -35,6 +35,7 @@ struct sdvl_frame {
   int32_t *level_counts;   // [4]
   int max_cells;
   int desc_valid;
+  int in_slab;           // storage belongs to a slab owned by the context (sdvl_frame_create_many)
   int hdr_stale;         // device corner header still holds the count of a previous image (reset lazily)
   uint8_t *own_level0;   // the frame's own level-0 storage (level[0] may point at a borrowed caller image)
 };
@@ -59,6 +60,7 @@ struct sdvl_ctx {
   // corner counts of the last sdvl_detect_corners batch, written by the pack kernel: one D2H serves all frames
   void *d_counts = nullptr; size_t d_counts_bytes = 0;
   std::vector<sdvl_frame *> detect_frames;
+  std::vector<void *> slabs;  // bulk frame storage, released with the context
   hipEvent_t wait_event = nullptr;  // created with hipEventBlockingSync | hipEventDisableTiming
   // per-kernel timing (HIP events on `stream`)
   int timing = 0;

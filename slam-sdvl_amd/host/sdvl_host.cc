@@ -66,9 +66,12 @@ sdvl_frame *Device::AcquireFrame(int w, int h, int levels) {
       return f;
     }
   }
-  sdvl_frame *f = nullptr;
-  Check(sdvl_frame_create(ctx_, w, h, levels, &f), "sdvl_frame_create");
-  return f;
+  // pool empty: take a slab of frames at once (a farm of trackers keeps turning frames into keyframes)
+  const int kChunk = 32;
+  sdvl_frame *fresh[kChunk];
+  Check(sdvl_frame_create_many(ctx_, w, h, levels, kChunk, fresh), "sdvl_frame_create_many");
+  for (int i = 1; i < kChunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels});
+  return fresh[0];
 }
 
 // frames die wherever their last shared_ptr is dropped, including the host worker threads
@@ -438,6 +441,7 @@ void Frame::CreateBatch(Camera *camera, ORBDetector *detector, const vector<Imag
   vector<Frame *> raw(n);
   vector<sdvl_frame *> devs(n);
   out->clear();
+  std::unique_ptr<StageClock> clk(new StageClock(ST_PRELUDE));
   for (int i = 0; i < n; i++) {
     shared_ptr<Frame> f(new Frame());
     f->InitCommon(camera, detector, imgs[i].cols, imgs[i].rows);
@@ -447,6 +451,7 @@ void Frame::CreateBatch(Camera *camera, ORBDetector *detector, const vector<Imag
     out->push_back(f);
   }
   (void)pfor;
+  clk.reset();
   BuildFrames(raw, devs, imgs, corners, nfeatures);
 }
 
@@ -1265,6 +1270,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   Device::SetCurrent(dev_);
   g_stage_times = &stage_times;
   stage_times.steps++;
+  const auto t_begin = std::chrono::steady_clock::now();
   const std::function<void(int, std::function<void(int)>)> pfor = [this](int n, std::function<void(int)> fn) { ParallelFor(n, fn); };
 
   // ---- stage 0: Frame construction (pyramid + FAST + selection + ORB), sdvl.cc:59
@@ -1431,6 +1437,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     t.map_->EmptyTrash();  // sdvl.cc:127
   }
   clk.reset();
+  stage_times.t[ST_TOTAL] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
   g_stage_times = nullptr;
 }
 

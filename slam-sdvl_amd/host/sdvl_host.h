@@ -391,7 +391,7 @@ class FeatureAlign {
 
 // wall-clock per stage of SDVLBatch::HandleFrames, accumulated (seconds); index = StageId
 enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_MAPPING,
-               ST_EPILOGUE, ST_COUNT };
+               ST_EPILOGUE, ST_TOTAL, ST_COUNT };
 struct StageTimes {
   double t[ST_COUNT] = {0};
   long steps = 0;

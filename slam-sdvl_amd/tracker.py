@@ -97,7 +97,7 @@ class TrackerBatch:
         return self._stats
 
     STAGES = ["upload_pyr", "fast", "select", "corners_orb", "prelude", "image_align", "prepare", "search", "finish", "mapping",
-              "epilogue"]
+              "epilogue", "total"]
 
     def stage_times(self, reset=False):
         """accumulated wall seconds per host stage of SDVLBatch::HandleFrames -> (dict, steps)"""
