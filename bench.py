@@ -157,8 +157,8 @@ def cpu_baseline(frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "1024")), help="independent sequences per GPU")
     ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
     ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")

@@ -211,6 +211,47 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
                        const uint8_t *border, const uint8_t *patch, int max_its, double *uv_io,
                        uint8_t *converged, int32_t *its);
 
+/* ---- pose from matches: FeatureAlign::SelectInliers + OptimizePose (feature_align.cc:73-82,152-243,258-283,341-431) --
+ * One job per frame.  obs[] are the frame's matched features in found order: ax, ay = feature bearing x/z, y/z
+ * (feature_align.cc:268), p = 3D point position, inv_cov = 1 / (1 << level).  The reference draws rand() % size once
+ * per RANSAC iteration and shrinks its iteration budget from log() of the supporter ratio: the caller passes
+ *   rand_idx[rand_begin .. rand_begin + max_ransac_its)   the draws the reference WOULD make (a copy of the stream), and
+ *   nits_table[nits_begin + s], s = 0..size               the budget after an improvement to s supporters (:199-207),
+ * and commits result.n_draws draws on its real stream afterwards.  out_lists[obs_begin ..) receives the final inlier
+ * indices (n_inliers of them, reference order) followed by the outlier indices (n_outliers), relative to obs_begin.
+ * At most 256 observations per job (SDVL_ERR_CAPACITY beyond). */
+typedef struct sdvl_pose_obs {
+  double ax, ay;
+  double px, py, pz;
+  double inv_cov;
+} sdvl_pose_obs;
+
+typedef struct sdvl_pose_job {
+  int32_t obs_begin, obs_end;
+  int32_t rand_begin, nits_begin;
+  double pose[7]; /* frame pose on entry (q0 q1 q2 q3 tx ty tz) */
+} sdvl_pose_job;
+
+typedef struct sdvl_pose_params {
+  int32_t max_ransac_points; /* Config::MaxRansacPoints(), <= 8 */
+  int32_t max_ransac_its;    /* Config::MaxRansacIts() */
+  int32_t max_optim_pose_its;/* Config::MaxOptimPoseIts() */
+  int32_t pad_;
+  double inlier_threshold;   /* Config::InlierErrorThreshold() / fx */
+  double fx;
+} sdvl_pose_params;
+
+typedef struct sdvl_pose_result {
+  double pose[7];
+  int32_t n_draws;    /* rand() calls SelectInliers made */
+  int32_t n_inliers, n_outliers;
+  int32_t refined;    /* ConvergePose ran on a non-empty inlier set at least once (pose was set) */
+} sdvl_pose_result;
+
+int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose_job *jobs, int n_obs, const sdvl_pose_obs *obs,
+                           int n_rand, const int32_t *rand_idx, int n_nits, const int32_t *nits_table,
+                           const sdvl_pose_params *p, sdvl_pose_result *results, int32_t *out_lists);
+
 /* ---- synthetic sequence generator (no dataset ships with the repo) ------------------------------- */
 struct sdvl_synth_view;
 /* renders n views of the textured plane straight into HBM: dev_out + i*frame_bytes, row stride = width */

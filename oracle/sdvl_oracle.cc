@@ -269,4 +269,52 @@ int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_
   return 0;
 }
 
+// FeatureAlign::SelectInliers + OptimizePose (feature_align.cc:73-82,152-243) on a caller-given match list.
+// obs[n][6] = {ax, ay, px, py, pz, level}: feature bearing (ax, ay, 1), fixed 3D point, pyramid level.
+// rand_seed / rand_skip position the glibc stream; n_draws returns how many rand() calls the RANSAC loop made.
+// in_idx / out_idx receive the final inlier / outlier lists as indices into obs (reference order).
+int sdvl_ref_pose_from_matches(const sdvl_ref_params *p, int w, int h, const double *cam, int n, const double *obs,
+                               unsigned rand_seed, int rand_skip, double *pose7_io, int *n_draws, int *n_in, int *in_idx,
+                               int *n_out, int *out_idx) {
+  ScenePlane pl;
+  Tracker t(ToParams(p), ToCam(cam, w, h), pl, SE3());
+  t.rng.Seed(rand_seed);
+  for (int i = 0; i < rand_skip; i++) t.rng.Next();
+  auto frame = std::make_shared<RFrame>();
+  frame->pose = ToSE3(pose7_io);
+  std::vector<std::shared_ptr<RFeature>> found;
+  for (int i = 0; i < n; i++) {
+    auto pt = std::make_shared<RPoint>();
+    pt->fixed = true;
+    pt->p3d = Vec3{obs[6 * i + 2], obs[6 * i + 3], obs[6 * i + 4]};
+    auto ft = std::make_shared<RFeature>();
+    ft->frame = frame.get();
+    ft->point = pt;
+    ft->v = Vec3{obs[6 * i], obs[6 * i + 1], 1.0};
+    ft->level = static_cast<int>(obs[6 * i + 5]);
+    found.push_back(ft);
+  }
+  GlibcRand before = t.rng;
+  t.SelectInliers(frame, found, &t.inliers, &t.outliers);
+  // count the draws: advance the saved copy until it matches the live stream
+  int draws = 0;
+  while (!(before.fi == t.rng.fi && before.ri == t.rng.ri && before.ring == t.rng.ring) && draws <= t.prm.max_ransac_its) {
+    before.Next();
+    draws++;
+  }
+  *n_draws = draws;
+  t.OptimizePose(frame, &t.inliers, &t.outliers);
+  if (t.RescueOutliers(frame, &t.inliers, &t.outliers)) t.OptimizePose(frame, &t.inliers, &t.outliers);
+  auto index_of = [&](const std::shared_ptr<RFeature> &f) {
+    for (int i = 0; i < n; i++) if (found[i] == f) return i;
+    return -1;
+  };
+  *n_in = static_cast<int>(t.inliers.size());
+  *n_out = static_cast<int>(t.outliers.size());
+  for (int i = 0; i < *n_in; i++) in_idx[i] = index_of(t.inliers[i]);
+  for (int i = 0; i < *n_out; i++) out_idx[i] = index_of(t.outliers[i]);
+  FromSE3(frame->pose, pose7_io);
+  return 0;
+}
+
 }  // extern "C"

@@ -71,6 +71,12 @@ void sdvl_ref_se3_inv(const double *A7, double *B7);
 void sdvl_ref_ldlt_solve6(const double *A36, const double *b6, double *x6);
 void sdvl_ref_rand_stream(unsigned seed, int n, int *out);
 
+/* FeatureAlign::SelectInliers + OptimizePose (feature_align.cc:73-82,152-243) on a given match list:
+ * obs[n][6] = {ax, ay, px, py, pz, level}; the glibc rand stream is seeded with rand_seed and advanced rand_skip draws */
+int sdvl_ref_pose_from_matches(const sdvl_ref_params *p, int w, int h, const double *cam, int n, const double *obs,
+                               unsigned rand_seed, int rand_skip, double *pose7_io, int *n_draws, int *n_in, int *in_idx,
+                               int *n_out, int *out_idx);
+
 /* closed-loop tracker: sdvl.cc:55-130 with the plane map stub (oracle/ref_tracker.h) */
 void *sdvl_ref_tracker_create(const sdvl_ref_params *p, int w, int h, const double *cam, const double *plane4,
                               const double *first_pose7);

@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
     "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
     "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
-    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches",
+    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches", "sdvl_pose_from_matches",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
 ]
 
@@ -159,6 +159,41 @@ class Frame:
             self.ctx.lib.sdvl_frame_destroy(self.ctx.h, self.h)
             self.h = None
 
+
+
+class PoseObs(C.Structure):
+    _fields_ = [("ax", C.c_double), ("ay", C.c_double), ("px", C.c_double), ("py", C.c_double), ("pz", C.c_double), ("inv_cov", C.c_double)]
+
+
+class PoseJob(C.Structure):
+    _fields_ = [("obs_begin", C.c_int32), ("obs_end", C.c_int32), ("rand_begin", C.c_int32), ("nits_begin", C.c_int32), ("pose", C.c_double * 7)]
+
+
+class PoseParams(C.Structure):
+    _fields_ = [("max_ransac_points", C.c_int32), ("max_ransac_its", C.c_int32), ("max_optim_pose_its", C.c_int32), ("pad_", C.c_int32),
+                ("inlier_threshold", C.c_double), ("fx", C.c_double)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 7), ("n_draws", C.c_int32), ("n_inliers", C.c_int32), ("n_outliers", C.c_int32), ("refined", C.c_int32)]
+
+
+def ransac_budget_table(size, max_points, max_its):
+    """iteration budget after an improvement to s supporters, s = 0..size (feature_align.cc:199-207)"""
+    import math
+    npoints = min(max_points, size)
+    out = []
+    for s in range(size + 1):
+        nits = max_its
+        if size > 0:
+            tmp = 1.0 - (1.0 - (float(s) / float(size)))
+            for _ in range(1, npoints):
+                tmp *= tmp
+            if not tmp < 1e-5:
+                den = math.log(1.0 - tmp) if tmp < 1.0 else -math.inf
+                nits = min(max_its, int(math.log(1.0 - 0.99) / den))
+        out.append(nits)
+    return out
 
 class Context:
     """One sdvl_ctx = one HIP stream on one MI355X."""
@@ -311,6 +346,41 @@ class Context:
         self._check(self.lib.sdvl_align_patches(self.h, n, arr, _ptr(levels, i32p), _ptr(border, u8p), _ptr(patch, u8p), max_its,
                                                 _ptr(uv, f64p), _ptr(conv, u8p), _ptr(its, i32p)))
         return uv, conv, its
+
+    def pose_from_matches(self, jobs, fx, max_ransac_points=5, max_ransac_its=100, max_optim_pose_its=10, inlier_error_threshold=2.0):
+        """jobs: list of (obs[n][6] = ax, ay, px, py, pz, level; pose7; rand_draws[max_ransac_its] raw rand() values).
+        Returns per job dict(pose, n_draws, inliers, outliers, refined)."""
+        n = len(jobs)
+        pj = (PoseJob * n)()
+        obs_all, rand_all, nits_all = [], [], []
+        for k, (obs, pose, draws) in enumerate(jobs):
+            obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 6)
+            size = len(obs)
+            pj[k].obs_begin = len(obs_all); pj[k].obs_end = len(obs_all) + size
+            pj[k].rand_begin = len(rand_all); pj[k].nits_begin = len(nits_all)
+            for c in range(7):
+                pj[k].pose[c] = float(pose[c])
+            for o in obs:
+                obs_all.append(PoseObs(o[0], o[1], o[2], o[3], o[4], 1.0 / (1 << int(o[5]))))
+            assert len(draws) >= max_ransac_its
+            rand_all += [int(d) % size if size else 0 for d in draws[:max_ransac_its]]
+            nits_all += ransac_budget_table(size, max_ransac_points, max_ransac_its)
+        po = (PoseObs * max(len(obs_all), 1))(*obs_all)
+        ra = np.asarray(rand_all, np.int32); ni = np.asarray(nits_all, np.int32)
+        prm = PoseParams(max_ransac_points, max_ransac_its, max_optim_pose_its, 0, inlier_error_threshold / fx, fx)
+        res = (PoseResult * n)()
+        lists = np.zeros(max(len(obs_all), 1), np.int32)
+        self.lib.sdvl_pose_from_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(self.lib.sdvl_pose_from_matches(self.h, n, pj, len(obs_all), po, len(ra), _ptr(ra, i32p), len(ni), _ptr(ni, i32p),
+                                                    C.byref(prm), res, _ptr(lists, i32p)))
+        out = []
+        for k in range(n):
+            b = pj[k].obs_begin
+            out.append(dict(pose=np.array(list(res[k].pose)), n_draws=res[k].n_draws, refined=res[k].refined,
+                            inliers=lists[b:b + res[k].n_inliers].copy(),
+                            outliers=lists[b + res[k].n_inliers:b + res[k].n_inliers + res[k].n_outliers].copy()))
+        return out
 
     # ---- synthetic frames in HBM
     def device_malloc(self, nbytes):

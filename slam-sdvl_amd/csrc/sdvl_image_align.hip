@@ -298,103 +298,6 @@ constexpr int kLdsMaxF = 384;
 
 struct IaItem { float patch, dx, dy; };
 
-// ldlt_solve6 (sdvl_math.h) with compile-time indices only: swaps become predicated moves, so everything stays in registers
-__device__ void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
-  double a[36];
-  int tr[6];
-#pragma unroll
-  for (int i = 0; i < 36; i++) a[i] = Ain[i];
-  bool alive = true;  // false once the k == 0 pivot is exactly zero (all-zero diagonal): nothing more to do
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    int idx = k;
-    double big = fabs(a[7 * k]);
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      const double v = fabs(a[7 * i]);
-      if (v > big) { big = v; idx = i; }
-    }
-    if (!alive) idx = k;
-    tr[k] = idx;
-    if (alive) {
-      // swap rows/cols k <-> idx of the lower triangle (Eigen ldlt unblocked), predicated on the run-time idx
-#pragma unroll
-      for (int c = k + 1; c < 6; c++) {
-        if (c == idx) {
-#pragma unroll
-          for (int j = 0; j < k; j++) { const double t = a[6 * k + j]; a[6 * k + j] = a[6 * c + j]; a[6 * c + j] = t; }
-#pragma unroll
-          for (int i = c + 1; i < 6; i++) { const double t = a[6 * i + k]; a[6 * i + k] = a[6 * i + c]; a[6 * i + c] = t; }
-          { const double t = a[7 * k]; a[7 * k] = a[7 * c]; a[7 * c] = t; }
-#pragma unroll
-          for (int i = k + 1; i < c; i++) { const double t = a[6 * i + k]; a[6 * i + k] = a[6 * c + i]; a[6 * c + i] = t; }
-        }
-      }
-      if (k > 0) {
-        double temp[6];
-#pragma unroll
-        for (int j = 0; j < k; j++) temp[j] = a[7 * j] * a[6 * k + j];
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < k; j++) acc += a[6 * k + j] * temp[j];
-        a[7 * k] -= acc;
-#pragma unroll
-        for (int i = k + 1; i < 6; i++) {
-          double a2 = 0.0;
-#pragma unroll
-          for (int j = 0; j < k; j++) a2 += a[6 * i + j] * temp[j];
-          a[6 * i + k] -= a2;
-        }
-      }
-      const double akk = a[7 * k];
-      const bool valid = fabs(akk) > 0.0;
-      if (k == 0 && !valid) {
-        alive = false;
-      } else if (valid) {
-#pragma unroll
-        for (int i = k + 1; i < 6; i++) a[6 * i + k] /= akk;
-      }
-    }
-  }
-  double d[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) d[i] = bin[i];
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-#pragma unroll
-    for (int c = k + 1; c < 6; c++)
-      if (tr[k] == c) { const double t = d[k]; d[k] = d[c]; d[c] = t; }
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    double acc = d[i];
-#pragma unroll
-    for (int j = 0; j < i; j++) acc -= a[6 * i + j] * d[j];
-    d[i] = acc;
-  }
-  const double tol = 1.0 / 1.7976931348623157e308;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    if (fabs(a[7 * i]) > tol) d[i] /= a[7 * i];
-    else d[i] = 0.0;
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-    double acc = d[i];
-#pragma unroll
-    for (int j = i + 1; j < 6; j++) acc -= a[6 * j + i] * d[j];
-    d[i] = acc;
-  }
-#pragma unroll
-  for (int k = 5; k >= 0; k--) {
-#pragma unroll
-    for (int c = k + 1; c < 6; c++)
-      if (tr[k] == c) { const double t = d[k]; d[k] = d[c]; d[c] = t; }
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) x[i] = d[i];
-}
-
 __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *__restrict__ jobs,
                                                                    const sdvl_align_feature *__restrict__ feats_all, Cam cam,
                                                                    sdvl_align_params prm, int max_f, sdvl_align_result *__restrict__ out) {

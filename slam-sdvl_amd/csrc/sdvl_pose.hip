@@ -1,0 +1,448 @@
+// sdvl_pose.hip — K8 pose from matches: FeatureAlign::SelectInliers (RANSAC, feature_align.cc:152-216) and
+// FeatureAlign::OptimizePose / RescueOutliers (feature_align.cc:73-82,218-243) around ConvergePose (:341-421) and
+// CheckReprojectionError (:258-283), for a batch of frames.  SURVEY §8(f) "next" row 1.
+//
+//   pose_hypotheses_kernel : one LANE per (frame, RANSAC draw).  The reference evaluates draws one after the other and
+//       adapts the iteration budget as it goes; a draw's result does not depend on earlier draws, so all max_ransac_its
+//       draws are evaluated at once (the lanes of a wave share the frame: every observation load is a broadcast) and the
+//       sequential bookkeeping is replayed afterwards.
+//   pose_refine_kernel     : one WAVE per frame.  Replays the RANSAC loop over the draw results (iteration budget from a
+//       host-computed table, so no device log()), then inliers / Tukey-weighted Gauss-Newton / rescue / second pass.
+//       Per-observation work (projection, Jacobian, weight, 28 normal-equation terms) is lane-parallel; lanes 0..27 each
+//       add one term IN OBSERVATION ORDER — the sums carry the rounding of the reference's sequential loop; inlier and
+//       outlier lists keep the reference's order through ballot-prefix appends; the median is found by rank counting.
+// FP64 throughout, -ffp-contract=off, same expression order as host/sdvl_host.cc (which is the reference's).
+// Only sin/cos inside SE3::Exp differ from the host libm by <= 1 ulp (tolerance class, like image alignment).
+#include "sdvl_internal.h"
+#include "sdvl_math.h"
+
+namespace {
+
+using namespace sdvl;
+
+constexpr int kMaxObs = 256;  // observations (matched features) per frame handled on device
+constexpr double kMADNorm = 1.4826;
+constexpr double kTukeyC = 4.6851 * 4.6851;
+
+struct PoseJobDev {
+  int obs_begin, n_obs;
+  int rand_begin, nits_begin;
+  double pose[7];
+  double pad_;
+};
+
+struct HypResult {
+  double se3[7];
+  int ok, supporters;
+};
+
+__device__ __forceinline__ double tukey(double x) {  // feature_align.cc:423-431
+  const double x_square = x * x;
+  if (x_square <= kTukeyC) {
+    const double tmp = 1.0 - x_square / kTukeyC;
+    return tmp * tmp;
+  }
+  return 0.0;
+}
+
+// scaled reprojection error of one observation under (R, t): feature_align.cc:270-274
+__device__ __forceinline__ void reproj_error(const sdvl_pose_obs &o, const M3 &R, const V3 &t, double *ex, double *ey, V3 *pos_out) {
+  const V3 pos = vadd(mvec(R, {o.px, o.py, o.pz}), t);
+  double x = o.ax - pos.x / pos.z, y = o.ay - pos.y / pos.z;
+  x *= o.inv_cov;
+  y *= o.inv_cov;
+  *ex = x;
+  *ey = y;
+  *pos_out = pos;
+}
+
+// ---------------------------------------------------------------------------------------------- hypotheses (lane each)
+// ConvergePose over `npts` observations idx[0..npts) (npts <= 8), all in registers / small local arrays
+__device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, int npts, const Rigid &frame_pose, double fx, int max_its,
+                                    Rigid *se3) {
+  Rigid last = frame_pose;
+  *se3 = last;
+  double chi2 = 0.0;
+  double errs[8];
+  {
+    const M3 R = se3_rot(*se3);
+    for (int q = 0; q < npts; q++) {
+      double ex, ey;
+      V3 pos;
+      reproj_error(obs[idx[q]], R, se3->t, &ex, &ey, &pos);
+      errs[q] = sqrt(ex * ex + ey * ey);
+    }
+  }
+  if (npts == 0) return false;
+  // GetMedianVector: element floor(n/2) of the sorted order (extra/utils.cc:215-220) — insertion sort of <= 8 values
+  for (int i = 1; i < npts; i++) {
+    const double v = errs[i];
+    int j = i - 1;
+    while (j >= 0 && errs[j] > v) { errs[j + 1] = errs[j]; j--; }
+    errs[j + 1] = v;
+  }
+  double scale = kMADNorm * errs[npts / 2];
+  for (int i = 0; i < max_its; i++) {
+    double A[36], b[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) b[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 36; r++) A[r] = 0.0;
+    double new_chi2 = 0.0;
+    if (i == 5) scale = 0.85 / fx;
+    const M3 R = se3_rot(*se3);
+    for (int q = 0; q < npts; q++) {
+      double ex, ey;
+      V3 pos;
+      reproj_error(obs[idx[q]], R, se3->t, &ex, &ey, &pos);
+      double J[12];
+      jacobian_3d_to_plane(pos, J);
+      const double ic = obs[idx[q]].inv_cov;
+#pragma unroll
+      for (int c = 0; c < 12; c++) J[c] *= ic;
+      const double weight = tukey(sqrt(ex * ex + ey * ey) / scale);
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) A[6 * r + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+        b[r] -= (J[r] * ex + J[6 + r] * ey) * weight;
+      }
+      new_chi2 += (ex * ex + ey * ey) * weight;
+    }
+    double dT[6];
+    ldlt_solve6_reg(A, b, dT);
+    if ((i > 0 && new_chi2 > chi2) || dT[0] != dT[0]) {
+      *se3 = last;
+      break;
+    }
+    const Rigid T_new = se3_mul(se3_exp(dT), *se3);
+    last = *se3;
+    *se3 = T_new;
+    chi2 = new_chi2;
+    if (abs_max6(dT) <= 1e-10) break;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(64) void pose_hypotheses_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+                                                             const int32_t *__restrict__ rand_idx, sdvl_pose_params prm,
+                                                             HypResult *__restrict__ hyp) {
+  const PoseJobDev &job = jobs[blockIdx.y];
+  const int h = blockIdx.x * 64 + threadIdx.x;
+  if (h >= prm.max_ransac_its) return;
+  HypResult r;
+  r.ok = 0;
+  r.supporters = 0;
+  for (int k = 0; k < 7; k++) r.se3[k] = job.pose[k];
+  const int size = job.n_obs;
+  if (size > 0) {
+    const sdvl_pose_obs *obs = obs_all + job.obs_begin;
+    const int npoints = min(prm.max_ransac_points, size);
+    const int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180)
+    int sel[8];
+    for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
+    Rigid se3;
+    if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
+      r.ok = 1;
+      se3_to7(se3, r.se3);
+      const M3 R = se3_rot(se3);
+      int sup = 0;
+      for (int q = 0; q < size; q++) {  // CheckReprojectionError over every match: all lanes of the wave read the same obs
+        double ex, ey;
+        V3 pos;
+        reproj_error(obs[q], R, se3.t, &ex, &ey, &pos);
+        if (sqrt(ex * ex + ey * ey) <= prm.inlier_threshold) sup++;
+      }
+      r.supporters = sup;
+    }
+  }
+  hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h] = r;
+}
+
+// ---------------------------------------------------------------------------------------------- refinement (wave each)
+struct RefineLds {
+  double terms[64][29];  // 28 normal-equation terms of up to 64 observations (+1 pad: no 2-way bank conflict pattern)
+  double sums[28];
+  double errs[kMaxObs];
+  uint16_t inl[kMaxObs], outl[kMaxObs], tmp[kMaxObs];
+};
+
+// CheckReprojectionError over list[0..n) in order; appends to inl (at *n_in) and outl (at *n_out)
+__device__ void check_list(const sdvl_pose_obs *obs, const uint16_t *list, int n, const Rigid &se3, double thr, uint16_t *inl, int *n_in,
+                           uint16_t *outl, int *n_out, int lane) {
+  const M3 R = se3_rot(se3);
+  int ni = *n_in, no = *n_out;
+  for (int q0 = 0; q0 < n; q0 += 64) {
+    const int q = q0 + lane;
+    bool is_in = false, is_out = false;
+    int id = 0;
+    if (q < n) {
+      id = list[q];
+      double ex, ey;
+      V3 pos;
+      reproj_error(obs[id], R, se3.t, &ex, &ey, &pos);
+      is_in = sqrt(ex * ex + ey * ey) <= thr;
+      is_out = !is_in;
+    }
+    const unsigned long long bi = __ballot(is_in), bo = __ballot(is_out);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (is_in) inl[ni + __popcll(bi & below)] = static_cast<uint16_t>(id);
+    if (is_out) outl[no + __popcll(bo & below)] = static_cast<uint16_t>(id);
+    ni += __popcll(bi);
+    no += __popcll(bo);
+  }
+  *n_in = ni;
+  *n_out = no;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ConvergePose over list[0..n) (n <= kMaxObs) by one wave; returns false when the list is empty
+__device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const uint16_t *list, int n, const Rigid &frame_pose, double fx,
+                                   int max_its, Rigid *se3, int lane) {
+  Rigid last = frame_pose;
+  *se3 = last;
+  double chi2 = 0.0;
+  if (n == 0) return false;
+  {
+    const M3 R = se3_rot(*se3);
+    for (int q = lane; q < n; q += 64) {
+      double ex, ey;
+      V3 pos;
+      reproj_error(obs[list[q]], R, se3->t, &ex, &ey, &pos);
+      L.errs[q] = sqrt(ex * ex + ey * ey);
+    }
+  }
+  wave_lds_sync();
+  // median = element floor(n/2) of the sorted order: rank counting, candidates spread over the lanes
+  double median = 0.0;
+  {
+    const int k = n / 2;
+    bool mine = false;
+    double val = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      const double e = L.errs[i];
+      int less = 0, eq = 0;
+      for (int j = 0; j < n; j++) {
+        const double f = L.errs[j];
+        less += (f < e) ? 1 : 0;
+        eq += (f == e) ? 1 : 0;
+      }
+      if (less <= k && k < less + eq) { mine = true; val = e; }
+    }
+    const unsigned long long b = __ballot(mine);
+    const int src = b ? __ffsll(static_cast<long long>(b)) - 1 : 0;  // every qualifying candidate holds the same value
+    const int lo = __shfl(__double2loint(val), src, 64), hi = __shfl(__double2hiint(val), src, 64);
+    median = __hiloint2double(hi, lo);
+  }
+  double scale = kMADNorm * median;
+  for (int i = 0; i < max_its; i++) {
+    if (i == 5) scale = 0.85 / fx;
+    const M3 R = se3_rot(*se3);
+    if (lane < 28) L.sums[lane] = 0.0;
+    double acc = 0.0;  // lanes 0..27: running sum of term `lane` in observation order
+    for (int q0 = 0; q0 < n; q0 += 64) {
+      const int q = q0 + lane;
+      if (q < n) {
+        const sdvl_pose_obs o = obs[list[q]];
+        double ex, ey;
+        V3 pos;
+        reproj_error(o, R, se3->t, &ex, &ey, &pos);
+        double J[12];
+        jacobian_3d_to_plane(pos, J);
+#pragma unroll
+        for (int c = 0; c < 12; c++) J[c] *= o.inv_cov;
+        const double weight = tukey(sqrt(ex * ex + ey * ey) / scale);
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = r; c < 6; c++) L.terms[lane][t++] = (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+#pragma unroll
+        for (int r = 0; r < 6; r++) L.terms[lane][21 + r] = (J[r] * ex + J[6 + r] * ey) * weight;
+        L.terms[lane][27] = (ex * ex + ey * ey) * weight;
+      }
+      wave_lds_sync();
+      if (lane < 28) {
+        const int m = min(64, n - q0);
+        if (lane >= 21 && lane < 27) {
+          for (int j = 0; j < m; j++) acc -= L.terms[j][lane];  // b -= ...
+        } else {
+          for (int j = 0; j < m; j++) acc += L.terms[j][lane];
+        }
+      }
+      wave_lds_sync();
+    }
+    if (lane < 28) L.sums[lane] = acc;
+    wave_lds_sync();
+    double A[36], b[6], dT[6];
+    {
+      int t = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++) {
+          A[6 * r + c] = L.sums[t];
+          A[6 * c + r] = L.sums[t];  // the reference adds the same terms in the same order to both halves
+          t++;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) b[r] = L.sums[21 + r];
+    const double new_chi2 = L.sums[27];
+    wave_lds_sync();
+    ldlt_solve6_reg(A, b, dT);
+    if ((i > 0 && new_chi2 > chi2) || dT[0] != dT[0]) {
+      *se3 = last;
+      break;
+    }
+    const Rigid T_new = se3_mul(se3_exp(dT), *se3);
+    last = *se3;
+    *se3 = T_new;
+    chi2 = new_chi2;
+    if (abs_max6(dT) <= 1e-10) break;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(64) void pose_refine_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+                                                         const int32_t *__restrict__ nits_table, const HypResult *__restrict__ hyp,
+                                                         sdvl_pose_params prm, sdvl_pose_result *__restrict__ results,
+                                                         int32_t *__restrict__ out_lists) {
+  __shared__ RefineLds L;
+  const PoseJobDev &job = jobs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int size = job.n_obs;
+  const sdvl_pose_obs *obs = obs_all + job.obs_begin;
+  sdvl_pose_result res;
+  for (int k = 0; k < 7; k++) res.pose[k] = job.pose[k];
+  res.n_draws = 0;
+  res.n_inliers = 0;
+  res.n_outliers = 0;
+  res.refined = 0;
+  if (size == 0) {  // SelectInliers returns at once; OptimizePose finds no features (feature_align.cc:165-166,220-221)
+    if (lane == 0) results[blockIdx.x] = res;
+    return;
+  }
+  // ---- RANSAC bookkeeping replayed over the draw results (feature_align.cc:172-212); uniform across the lanes
+  const HypResult *hy = hyp + static_cast<size_t>(blockIdx.x) * prm.max_ransac_its;
+  const int32_t *nits_of = nits_table + job.nits_begin;  // iteration budget after an improvement to s supporters
+  Rigid best = se3_identity();  // SE3 best_se3 default-constructed
+  int nits = prm.max_ransac_its, best_sup = 0, it = 0;
+  while (it < nits) {
+    const HypResult &r = hy[it];
+    if (r.ok && r.supporters > best_sup) {
+      best_sup = r.supporters;
+      best = se3_from7(r.se3);
+      nits = nits_of[best_sup];
+    }
+    it++;
+  }
+  res.n_draws = it;
+  // ---- final CheckReprojectionError with the best hypothesis -> inliers / outliers (feature_align.cc:215)
+  for (int q = lane; q < size; q += 64) L.tmp[q] = static_cast<uint16_t>(q);
+  wave_lds_sync();
+  int n_in = 0, n_out = 0;
+  check_list(obs, L.tmp, size, best, prm.inlier_threshold, L.inl, &n_in, L.outl, &n_out, lane);
+  wave_lds_sync();
+  // ---- OptimizePose(frame): feature_align.cc:73-82
+  Rigid pose = se3_from7(job.pose);
+  for (int pass = 0; pass < 2; pass++) {
+    // OptimizePose(frame, &inliers, &outliers), :218-230
+    Rigid se3;
+    if (converge_pose_wave(L, obs, L.inl, n_in, pose, prm.fx, prm.max_optim_pose_its, &se3, lane)) {
+      pose = se3;
+      res.refined = 1;
+      for (int q = lane; q < n_in; q += 64) L.tmp[q] = L.inl[q];
+      wave_lds_sync();
+      const int n_c = n_in;
+      n_in = 0;
+      check_list(obs, L.tmp, n_c, pose, prm.inlier_threshold, L.inl, &n_in, L.outl, &n_out, lane);
+      wave_lds_sync();
+    }
+    if (pass == 1) break;
+    // RescueOutliers, :232-243
+    const int init_in = n_in;
+    for (int q = lane; q < n_out; q += 64) L.tmp[q] = L.outl[q];
+    wave_lds_sync();
+    const int n_c = n_out;
+    n_out = 0;
+    check_list(obs, L.tmp, n_c, pose, 2 * prm.inlier_threshold, L.inl, &n_in, L.outl, &n_out, lane);
+    wave_lds_sync();
+    if (!(n_in > init_in)) break;
+  }
+  se3_to7(pose, res.pose);
+  res.n_inliers = n_in;
+  res.n_outliers = n_out;
+  int32_t *lists = out_lists + job.obs_begin;
+  for (int q = lane; q < n_in; q += 64) lists[q] = L.inl[q];
+  for (int q = lane; q < n_out; q += 64) lists[n_in + q] = L.outl[q];
+  if (lane == 0) results[blockIdx.x] = res;
+}
+
+}  // namespace
+
+extern "C" int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose_job *jobs, int n_obs, const sdvl_pose_obs *obs, int n_rand,
+                                      const int32_t *rand_idx, int n_nits, const int32_t *nits_table, const sdvl_pose_params *p,
+                                      sdvl_pose_result *results, int32_t *out_lists) {
+  if (!ctx || !p || n_jobs < 0 || (n_jobs > 0 && (!jobs || !results)) || n_obs < 0 || (n_obs > 0 && (!obs || !out_lists))) return SDVL_ERR_INVALID;
+  if (n_jobs == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, p->max_ransac_points >= 1 && p->max_ransac_points <= 8, "max_ransac_points must be in [1,8]");
+  SDVL_REQUIRE(ctx, p->max_ransac_its >= 1 && p->max_ransac_its <= 4096 && p->max_optim_pose_its >= 0, "bad iteration limits");
+  SDVL_REQUIRE(ctx, rand_idx && nits_table, "rand / nits tables missing");
+  for (int j = 0; j < n_jobs; j++) {
+    const sdvl_pose_job &a = jobs[j];
+    SDVL_REQUIRE(ctx, a.obs_begin >= 0 && a.obs_end >= a.obs_begin && a.obs_end <= n_obs, "observation range out of bounds");
+    if (a.obs_end - a.obs_begin > kMaxObs) {
+      ctx->err = "too many matches in one pose job for the device path (256)";
+      return SDVL_ERR_CAPACITY;
+    }
+    const int size = a.obs_end - a.obs_begin;
+    SDVL_REQUIRE(ctx, a.rand_begin >= 0 && a.rand_begin + p->max_ransac_its <= n_rand, "rand range out of bounds");
+    SDVL_REQUIRE(ctx, a.nits_begin >= 0 && a.nits_begin + size + 1 <= n_nits, "nits table range out of bounds");
+    for (int h = 0; h < p->max_ransac_its && size > 0; h++)
+      SDVL_REQUIRE(ctx, rand_idx[a.rand_begin + h] >= 0 && rand_idx[a.rand_begin + h] < size, "rand index outside the match list");
+  }
+  const size_t jb = (sizeof(PoseJobDev) * n_jobs + 255) / 256 * 256, ob = (sizeof(sdvl_pose_obs) * static_cast<size_t>(n_obs) + 255) / 256 * 256;
+  const size_t rb = (sizeof(int32_t) * static_cast<size_t>(n_rand) + 255) / 256 * 256, nb = (sizeof(int32_t) * static_cast<size_t>(n_nits) + 255) / 256 * 256;
+  const size_t hyp_bytes = sizeof(HypResult) * static_cast<size_t>(n_jobs) * p->max_ransac_its;
+  const size_t res_bytes = (sizeof(sdvl_pose_result) * n_jobs + 255) / 256 * 256, list_bytes = sizeof(int32_t) * static_cast<size_t>(n_obs);
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, hyp_bytes + 256, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, res_bytes + list_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, res_bytes + list_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, jb + ob + rb + nb, &hs, &dsx);
+  if (rc) return rc;
+  uint8_t *h8 = static_cast<uint8_t *>(hs), *d8 = static_cast<uint8_t *>(dsx);
+  PoseJobDev *hj = reinterpret_cast<PoseJobDev *>(h8);
+  for (int j = 0; j < n_jobs; j++) {
+    hj[j].obs_begin = jobs[j].obs_begin;
+    hj[j].n_obs = jobs[j].obs_end - jobs[j].obs_begin;
+    hj[j].rand_begin = jobs[j].rand_begin;
+    hj[j].nits_begin = jobs[j].nits_begin;
+    memcpy(hj[j].pose, jobs[j].pose, sizeof(double) * 7);
+    hj[j].pad_ = 0.0;
+  }
+  if (n_obs) memcpy(h8 + jb, obs, sizeof(sdvl_pose_obs) * static_cast<size_t>(n_obs));
+  memcpy(h8 + jb + ob, rand_idx, sizeof(int32_t) * static_cast<size_t>(n_rand));
+  memcpy(h8 + jb + ob + rb, nits_table, sizeof(int32_t) * static_cast<size_t>(n_nits));
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, jb + ob + rb + nb, hipMemcpyHostToDevice, ctx->stream));
+  const PoseJobDev *dj = reinterpret_cast<const PoseJobDev *>(d8);
+  const sdvl_pose_obs *dobs = reinterpret_cast<const sdvl_pose_obs *>(d8 + jb);
+  const int32_t *drand = reinterpret_cast<const int32_t *>(d8 + jb + ob), *dnits = reinterpret_cast<const int32_t *>(d8 + jb + ob + rb);
+  HypResult *dhyp = static_cast<HypResult *>(ctx->d_work);
+  sdvl_pose_result *dres = static_cast<sdvl_pose_result *>(ctx->d_out);
+  int32_t *dlists = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(ctx->d_out) + res_bytes);
+  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + 63) / 64, n_jobs), dim3(64), dj, dobs, drand, *p, dhyp);
+  SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel, dim3(n_jobs), dim3(64), dj, dobs, dnits, static_cast<const HypResult *>(dhyp), *p, dres, dlists);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes + list_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  memcpy(results, ctx->h_out, sizeof(sdvl_pose_result) * n_jobs);
+  if (n_obs) memcpy(out_lists, static_cast<uint8_t *>(ctx->h_out) + res_bytes, list_bytes);
+  return SDVL_OK;
+}

@@ -894,8 +894,14 @@ void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared
   plan_begin_[size] = static_cast<int>(plan_.size());
 }
 
-// second half of SelectPoints (feature_align.cc:105-149) replayed over the batch results, then SelectInliers
+// feature_align.cc:59-71 tail: SelectPoints replay, then SelectInliers
 void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
+  FinishSelect(frame, res);
+  SelectInliers(frame);
+}
+
+// second half of SelectPoints (feature_align.cc:105-149) replayed over the batch results
+void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
   const int size = static_cast<int>(plan_begin_.size()) - 1;
   vector<shared_ptr<Feature>> &src_features = last_frame_->GetFeatures();
   for (int i = 0; i < size && matches_ < max_matches_; i++) {
@@ -930,7 +936,70 @@ void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_se
   }
   plan_.clear();
   last_frame_.reset();
-  SelectInliers(frame);
+  inliers_.clear();
+  outliers_.clear();
+}
+
+// ---- device pose stage (sdvl_pose_from_matches): what SelectInliers needs from the host — the rand() draws it would
+// make (taken from a COPY of the stream; CommitPose advances the real one by the number actually used) and the
+// iteration budget as a function of the supporter count (feature_align.cc:199-207: libm log stays on the host)
+void FeatureAlign::PoseBatch::Append(const PoseBatch &o) {
+  const int ob = static_cast<int>(obs.size()), rb = static_cast<int>(rand_idx.size()), nb = static_cast<int>(nits.size());
+  for (sdvl_pose_job j : o.jobs) {
+    j.obs_begin += ob; j.obs_end += ob; j.rand_begin += rb; j.nits_begin += nb;
+    jobs.push_back(j);
+  }
+  obs.insert(obs.end(), o.obs.begin(), o.obs.end());
+  rand_idx.insert(rand_idx.end(), o.rand_idx.begin(), o.rand_idx.end());
+  nits.insert(nits.end(), o.nits.begin(), o.nits.end());
+}
+
+sdvl_pose_params FeatureAlign::PoseParams(const Camera &cam) {
+  sdvl_pose_params p;
+  p.max_ransac_points = Config::MaxRansacPoints();
+  p.max_ransac_its = Config::MaxRansacIts();
+  p.max_optim_pose_its = Config::MaxOptimPoseIts();
+  p.pad_ = 0;
+  p.inlier_threshold = Config::InlierErrorThreshold() / cam.GetFx();
+  p.fx = cam.GetFx();
+  return p;
+}
+
+bool FeatureAlign::EmitPoseJob(const shared_ptr<Frame> &frame, PoseBatch *batch) {
+  const int size = static_cast<int>(found_.size());
+  if (size > kMaxDevicePoseObs || Config::MaxRansacPoints() > 8) return false;
+  sdvl_pose_job job;
+  job.obs_begin = static_cast<int>(batch->obs.size());
+  job.obs_end = job.obs_begin + size;
+  job.rand_begin = static_cast<int>(batch->rand_idx.size());
+  job.nits_begin = static_cast<int>(batch->nits.size());
+  frame->GetPose().ToArray(job.pose);
+  for (const Obs &o : obs_) batch->obs.push_back(sdvl_pose_obs{o.ax, o.ay, o.px, o.py, o.pz, o.inv_cov});
+  const int max_its = Config::MaxRansacIts();
+  RandStream peek = *rng_;
+  for (int h = 0; h < max_its; h++) batch->rand_idx.push_back(size > 0 ? peek.Next() % size : 0);
+  const int npoints = std::min(Config::MaxRansacPoints(), size);
+  const double sprob = 0.99;
+  for (int supporters = 0; supporters <= size; supporters++) {
+    int nits = max_its;
+    if (size > 0) {
+      const double epsilon = 1.0 - (static_cast<double>(supporters) / static_cast<double>(size));
+      double tmp = 1.0 - epsilon;
+      for (int k = 1; k < npoints; k++) tmp *= tmp;
+      if (!(tmp < 1e-5)) nits = std::min(max_its, static_cast<int>(std::log(1.0 - sprob) / std::log(1.0 - tmp)));
+    }
+    batch->nits.push_back(nits);
+  }
+  batch->jobs.push_back(job);
+  return true;
+}
+
+void FeatureAlign::CommitPose(const shared_ptr<Frame> &frame, const sdvl_pose_result &r, const int32_t *lists) {
+  for (int k = 0; k < r.n_draws; k++) rng_->Next();
+  if (r.refined) frame->SetPose(SE3(se3_from7(r.pose)));
+  inliers_.assign(lists, lists + r.n_inliers);
+  outliers_.assign(lists + r.n_inliers, lists + r.n_inliers + r.n_outliers);
+  RemoveOutliers(frame);
 }
 
 // feature_align.cc:59-71
@@ -1263,8 +1332,19 @@ void SDVLBatch::ParallelFor(int n, const std::function<void(int)> &fn) {
   g_pool_of(g_pool_slot, threads_)->For(n, fn);
 }
 
+static int g_device_pose = -1;  // -1: not decided yet (environment)
+void SDVLBatch::SetDevicePose(bool on) { g_device_pose = on ? 1 : 0; }
+bool SDVLBatch::DevicePose() {
+  if (g_device_pose < 0) {
+    const char *e = std::getenv("SDVL_POSE_HOST");
+    g_device_pose = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_device_pose != 0;
+}
+
 // SDVL::HandleFrame (sdvl.cc:55-130) for B trackers, stage by stage
 void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
+  const bool device_pose = DevicePose();
   const int B = static_cast<int>(trk_.size());
   if (static_cast<int>(imgs.size()) != B) throw std::runtime_error("SDVLBatch::HandleFrames: one image per tracker");
   Device::SetCurrent(dev_);
@@ -1362,17 +1442,50 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     clk.reset(new StageClock(ST_SEARCH));
     if (R > 0) Matcher::SearchPoints(dev_, reqs, *trk_[run[0]]->camera_, &res);
     clk.reset(new StageClock(ST_FINISH));
-    // ---- stage 3: replay + RANSAC + pose refinement + bookkeeping, sdvl.cc:193-127
+    // ---- stage 3: replay of SelectPoints, sdvl.cc:193
+    vector<FeatureAlign::PoseBatch> pb(R);
+    vector<char> on_device(R, 0);
     ParallelFor(R, [&](int k) {
       const int i = run[k];
       SDVL &t = *trk_[i];
       FrameStats &st = stats[i];
       st.search_requests = static_cast<int>(begin[k + 1] - begin[k]);
       for (size_t q = begin[k]; q < begin[k + 1]; q++) st.lk_iters += res[q].lk_its;
-      t.feature_align_.FinishReproject(t.current_frame_, res.data() + begin[k]);
+      t.feature_align_.FinishSelect(t.current_frame_, res.data() + begin[k]);
       t.matches_ = t.feature_align_.GetMatches();
       t.attempts_ = t.feature_align_.GetAttempts();
-      t.feature_align_.OptimizePose(t.current_frame_);
+      if (device_pose) on_device[k] = t.feature_align_.EmitPoseJob(t.current_frame_, &pb[k]) ? 1 : 0;
+    });
+    // ---- stage 3b: RANSAC + pose refinement (feature_align.cc:73-82,152-243), one launch pair for every tracker
+    clk.reset(new StageClock(ST_POSE));
+    FeatureAlign::PoseBatch all;
+    vector<int> job_of(R, -1);
+    vector<sdvl_pose_result> pres;
+    vector<int32_t> lists;
+    for (int k = 0; k < R; k++)
+      if (on_device[k]) {
+        job_of[k] = static_cast<int>(all.jobs.size());
+        all.Append(pb[k]);
+      }
+    if (!all.jobs.empty()) {
+      pres.resize(all.jobs.size());
+      lists.resize(all.obs.size() + 1);
+      const sdvl_pose_params pp = FeatureAlign::PoseParams(*trk_[run[0]]->camera_);
+      dev_->Check(sdvl_pose_from_matches(dev_->ctx(), static_cast<int>(all.jobs.size()), all.jobs.data(), static_cast<int>(all.obs.size()),
+                                         all.obs.data(), static_cast<int>(all.rand_idx.size()), all.rand_idx.data(),
+                                         static_cast<int>(all.nits.size()), all.nits.data(), &pp, pres.data(), lists.data()),
+                  "sdvl_pose_from_matches");
+    }
+    ParallelFor(R, [&](int k) {
+      const int i = run[k];
+      SDVL &t = *trk_[i];
+      FrameStats &st = stats[i];
+      if (job_of[k] >= 0) {
+        t.feature_align_.CommitPose(t.current_frame_, pres[job_of[k]], lists.data() + all.jobs[job_of[k]].obs_begin);
+      } else {
+        t.feature_align_.SelectInliers(t.current_frame_);
+        t.feature_align_.OptimizePose(t.current_frame_);
+      }
       st.inliers = t.feature_align_.GetInliers();
       st.outliers = t.feature_align_.GetOutliers();
       {  // GetMotionModel, sdvl.cc:266-276

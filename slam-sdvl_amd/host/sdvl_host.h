@@ -351,6 +351,20 @@ class FeatureAlign {
   void PrepareReproject(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, bool reloc,
                         std::vector<sdvl_search_req> *reqs);
   void FinishReproject(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res);
+  // FinishReproject without SelectInliers: the pose stage then runs either on the host (SelectInliers + OptimizePose)
+  // or batched on the device: EmitPoseJob for every tracker, ONE sdvl_pose_from_matches, CommitPose for every tracker.
+  struct PoseBatch {
+    std::vector<sdvl_pose_job> jobs;
+    std::vector<sdvl_pose_obs> obs;
+    std::vector<int32_t> rand_idx, nits;
+    void Append(const PoseBatch &o);
+  };
+  static constexpr int kMaxDevicePoseObs = 256;
+  void FinishSelect(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res);
+  bool EmitPoseJob(const std::shared_ptr<Frame> &frame, PoseBatch *batch);  // false: too many matches, use the host path
+  void CommitPose(const std::shared_ptr<Frame> &frame, const sdvl_pose_result &r, const int32_t *lists);
+  static sdvl_pose_params PoseParams(const Camera &cam);
+  void SelectInliers(const std::shared_ptr<Frame> &frame);  // host RANSAC (feature_align.cc:152-216)
 
  private:
   struct CellEntry { int src; Vector2d p; int score; };      // src = index into last_frame->GetFeatures()
@@ -360,7 +374,6 @@ class FeatureAlign {
     double px, py, pz;   // point->GetPosition()
     double inv_cov;      // 1 / (1 << level)
   };
-  void SelectInliers(const std::shared_ptr<Frame> &frame);
   void OptimizePoseOnce(const std::shared_ptr<Frame> &frame);
   bool RescueOutliers(const std::shared_ptr<Frame> &frame);
   void RemoveOutliers(const std::shared_ptr<Frame> &frame);
@@ -390,7 +403,7 @@ class FeatureAlign {
 };
 
 // wall-clock per stage of SDVLBatch::HandleFrames, accumulated (seconds); index = StageId
-enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_MAPPING,
+enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_POSE, ST_MAPPING,
                ST_EPILOGUE, ST_TOTAL, ST_COUNT };
 struct StageTimes {
   double t[ST_COUNT] = {0};
@@ -449,6 +462,10 @@ class SDVLBatch {
   ~SDVLBatch();
   // imgs[i] feeds tracker i; stats[i] receives its FrameStats
   void HandleFrames(const std::vector<Image> &imgs, FrameStats *stats);
+  // pose stage (RANSAC + refinement) on the device (default) or with the host implementation; process-wide switch,
+  // also set by SDVL_POSE_HOST=1 in the environment.  Both produce the same decisions (tests/test_gpu_tracker.py).
+  static void SetDevicePose(bool on);
+  static bool DevicePose();
 
  private:
   void ParallelFor(int n, const std::function<void(int)> &fn);

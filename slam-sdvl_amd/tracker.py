@@ -52,6 +52,15 @@ def configure(overrides=None):
             raise KeyError(k)
 
 
+def set_device_pose(on):
+    """pose stage (RANSAC + refinement, feature_align.cc:73-82,152-243) on the device (default) or the host implementation"""
+    load_host_library().sdvlh_set_device_pose(int(bool(on)))
+
+
+def device_pose():
+    return bool(load_host_library().sdvlh_device_pose())
+
+
 class HostDevice:
     def __init__(self, gpu=0):
         self.lib = load_host_library()
@@ -96,7 +105,7 @@ class TrackerBatch:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return self._stats
 
-    STAGES = ["upload_pyr", "fast", "select", "corners_orb", "prelude", "image_align", "prepare", "search", "finish", "mapping",
+    STAGES = ["upload_pyr", "fast", "select", "corners_orb", "prelude", "image_align", "prepare", "search", "finish", "pose", "mapping",
               "epilogue", "total"]
 
     def stage_times(self, reset=False):

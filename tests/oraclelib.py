@@ -164,6 +164,17 @@ class Oracle:
         a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
         return self.lib.sdvl_ref_orb_distance(ptr(a, u8p), ptr(b, u8p))
 
+    def pose_from_matches(self, cam, obs, pose, w=640, h=480, rand_seed=1, rand_skip=0):
+        """SelectInliers + OptimizePose on obs[n][6] = ax, ay, px, py, pz, level"""
+        cam = np.ascontiguousarray(cam, np.float64); obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 6)
+        n = len(obs); pose = np.array(pose, np.float64)
+        nd = C.c_int(); ni = C.c_int(); no = C.c_int()
+        ii = np.zeros(max(n, 1), np.int32); oi = np.zeros(max(n, 1), np.int32)
+        self.lib.sdvl_ref_pose_from_matches(C.byref(self.params), w, h, ptr(cam, f64p), n, ptr(obs, f64p), C.c_uint(rand_seed),
+                                            int(rand_skip), ptr(pose, f64p), C.byref(nd), C.byref(ni), ptr(ii, i32p),
+                                            C.byref(no), ptr(oi, i32p))
+        return dict(pose=pose, n_draws=nd.value, inliers=ii[:ni.value].copy(), outliers=oi[:no.value].copy())
+
     # --- alignment
     def image_align(self, img1, img2, cam, px, bearing, depth, valid, T, fast=False):
         img1 = np.ascontiguousarray(img1, np.uint8); img2 = np.ascontiguousarray(img2, np.uint8); h, w = img1.shape
@@ -254,6 +265,14 @@ class Synth:
         out = np.zeros((h, w), np.uint8)
         self.lib.sdvl_synth_render_host(C.byref(v), w, h, ptr(out, u8p), w)
         return out
+
+
+def quat_rot(q):
+    """rotation matrix of a unit quaternion (w, x, y, z)"""
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
 def trajectory_pose(orc, k, xi=XI):

@@ -384,3 +384,60 @@ def test_empty_batches_and_flat_frames(ctx, sdvl, orc):
     assert len(ctx.detect_corners([f], sdvl.default_detect_params(), 1000)[0]) == 0
     assert ctx.orb_describe([f])[0].shape == (0, 32)
     f.close()
+
+
+# ------------------------------------------------------------------------------------------------ K8
+def make_matches(orc, n, seed, outlier_frac=0.25, noise_px=0.4, fx=525.0):
+    """n matches of a camera that moved by a small twist: obs rows = ax, ay, px, py, pz, level"""
+    rng = np.random.default_rng(seed)
+    true_pose = orc.se3_exp(np.array([0.03, -0.02, 0.01, 0.004, -0.006, 0.003]) * (1 + seed % 3))
+    guess = orc.se3_exp(np.zeros(6))
+    P = np.stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-0.9, 0.9, n), rng.uniform(1.5, 3.0, n)], 1)
+    from oraclelib import quat_rot
+    R = quat_rot(true_pose[:4])
+    pc = P @ R.T + true_pose[4:]
+    a = pc[:, :2] / pc[:, 2:3] + rng.normal(0, noise_px / fx, (n, 2))
+    bad = rng.random(n) < outlier_frac
+    a[bad] += rng.uniform(-40, 40, (int(bad.sum()), 2)) / fx
+    lvl = rng.integers(0, 3, n)
+    obs = np.concatenate([a, P, lvl[:, None].astype(np.float64)], 1)
+    return obs, guess
+
+
+@pytest.mark.parametrize("sizes", [(150, 40, 5, 3, 1, 0), (256, 255, 64, 65, 129, 7)])
+def test_pose_from_matches_equals_oracle(ctx, orc, sizes):
+    """RANSAC replay + Tukey Gauss-Newton + rescue on the device: same rand() consumption, same inlier / outlier lists
+    in the same order; pose within 1e-9 (device sin/cos inside SE3::Exp differ from libm by an ulp)"""
+    cam = TUM_CAM
+    jobs, wants = [], []
+    for j, n in enumerate(sizes):
+        obs, guess = make_matches(orc, n, seed=100 + j, outlier_frac=0.1 + 0.1 * (j % 4))
+        skip = 17 * j
+        draws = orc.rand_stream(skip + 100, seed=3)[skip:]
+        jobs.append((obs, guess, draws))
+        wants.append(orc.pose_from_matches(cam, obs, guess, rand_seed=3, rand_skip=skip))
+    got = ctx.pose_from_matches(jobs, fx=cam[0])
+    for j, (g, w) in enumerate(zip(got, wants)):
+        assert g["n_draws"] == w["n_draws"], j
+        assert np.array_equal(g["inliers"], w["inliers"]), j
+        assert np.array_equal(g["outliers"], w["outliers"]), j
+        assert np.abs(g["pose"] - w["pose"]).max() <= 1e-9, (j, g["pose"], w["pose"])
+    # the big jobs really exercise RANSAC: outliers were rejected and the true motion recovered
+    assert len(got[0]["outliers"]) >= 10 and len(got[0]["inliers"]) >= 90
+
+
+def test_pose_from_matches_degenerate_inputs(ctx, orc):
+    """all matches identical / all outliers / more matches than the device path takes"""
+    cam = TUM_CAM
+    obs = np.tile(np.array([[0.1, -0.05, 0.2, -0.1, 2.0, 0.0]]), (12, 1))
+    obs2, guess = make_matches(orc, 30, seed=5, outlier_frac=1.0)
+    draws = orc.rand_stream(100, seed=1)
+    got = ctx.pose_from_matches([(obs, guess, draws), (obs2, guess, draws)], fx=cam[0])
+    for g, o in zip(got, (obs, obs2)):
+        w = orc.pose_from_matches(cam, o, guess, rand_seed=1)
+        assert g["n_draws"] == w["n_draws"]
+        assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["outliers"], w["outliers"])
+        assert np.abs(g["pose"] - w["pose"]).max() <= 1e-9
+    big, _ = make_matches(orc, 257, seed=9)
+    with pytest.raises(RuntimeError, match="too many matches"):
+        ctx.pose_from_matches([(big, guess, draws)], fx=cam[0])

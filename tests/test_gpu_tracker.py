@@ -48,7 +48,18 @@ def run_case(trk, orc, synth, B, n_frames, threads, w=640, h=480, cam=TUM_CAM):
 
 
 def test_single_sequence_closed_loop(trk, orc, synth):
+    assert trk.device_pose()      # RANSAC + pose refinement run in sdvl_pose_from_matches by default
     worst = run_case(trk, orc, synth, B=1, n_frames=14, threads=1)
+    assert worst <= POSE_TOL
+
+
+def test_closed_loop_with_host_pose_stage(trk, orc, synth):
+    """the host implementation of the pose stage stays selectable and gives the same decisions"""
+    trk.set_device_pose(False)
+    try:
+        worst = run_case(trk, orc, synth, B=3, n_frames=7, threads=2)
+    finally:
+        trk.set_device_pose(True)
     assert worst <= POSE_TOL
 
 
