@@ -215,9 +215,10 @@ def main():
     farm.stage_times(reset=True)
     for c in ctxs:
         c.timing(True)
+    stats_buf = farm.alloc_stats(K)
     barrier()
     t0 = time.perf_counter()
-    stats = farm.run(ptrs[1 + Wm:], workers)  # the K timed steps: group-steps are scheduled onto the worker threads
+    stats = farm.run(ptrs[1 + Wm:], workers, stats_buf)  # the K timed steps: group-steps are scheduled onto the worker threads
     barrier()
     elapsed = time.perf_counter() - t0
     timers = {}

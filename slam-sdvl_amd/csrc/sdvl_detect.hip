@@ -91,77 +91,75 @@ __device__ __forceinline__ int byte_of(uint32_t w0, uint32_t w1, uint32_t w2, in
   return static_cast<int>(((i < 4 ? w0 : (i < 8 ? w1 : w2)) >> (8 * (i & 3))) & 0xFFu);
 }
 
-// One thread owns 4 horizontally adjacent pixels (x = cg .. cg+3).  The ring of pixel x needs bytes x-3 .. x+3 of rows
-// y-3 .. y+3: per row three aligned 32-bit LDS words (bytes cg-4 .. cg+7) serve all four pixels -> 21 ds_read_b32
-// instead of 68 byte reads.  Everything stays in named registers (no arrays: the previous version spilled 88 B/lane of
-// scratch = 130 MB of HBM writes per launch).
-#define SDVL_RING_PX(K, R, OFF) const int p##K = byte_of(r##R##0, r##R##1, r##R##2, 4 + (OFF) + k)
+// One thread owns 4 horizontally adjacent pixels (x = cg .. cg+3).
+// Phase A — compass pre-test.  Any 9 consecutive positions of the 16-ring contain two ADJACENT compass points
+// (ring positions 0, 4, 8, 12 = (0,3) (3,0) (0,-3) (-3,0)), so a FAST-9 corner needs two adjacent compass pixels that are
+// both brighter than v + t or both darker than v - t.  The test reads 5 aligned LDS words per thread (row y: bytes
+// cg-4 .. cg+7, rows y-3 / y+3: bytes cg .. cg+3) and rejects most pixels; only the survivors get the 16-pixel
+// arithmetic of phase C, one candidate per lane.
+__device__ __forceinline__ bool fast_compass_pass(int v, int p_dn, int p_rt, int p_up, int p_lf, int t) {
+  const int hi = v + t, lo = v - t;
+  const bool b0 = p_dn > hi, b4 = p_rt > hi, b8 = p_up > hi, b12 = p_lf > hi;
+  const bool d0 = p_dn < lo, d4 = p_rt < lo, d8 = p_up < lo, d12 = p_lf < lo;
+  return (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0);
+}
+
 #define SDVL_MIN2(a, b) min((a), (b))
 #define SDVL_MAX2(a, b) max((a), (b))
 
-// segment test of pixel k (0..3) of the thread's quad: is it a FAST-9 corner at threshold t?
-__device__ __forceinline__ bool fast_is_corner(uint32_t rm30, uint32_t rm31, uint32_t rm32, uint32_t rm20, uint32_t rm21, uint32_t rm22,
-                                               uint32_t rm10, uint32_t rm11, uint32_t rm12, uint32_t rz0, uint32_t rz1, uint32_t rz2,
-                                               uint32_t rp10, uint32_t rp11, uint32_t rp12, uint32_t rp20, uint32_t rp21, uint32_t rp22,
-                                               uint32_t rp30, uint32_t rp31, uint32_t rp32, int k, int t) {
-  const int v = byte_of(rz0, rz1, rz2, 4 + k);
-  // Bresenham circle, cv::FAST offsets16: (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-  SDVL_RING_PX(0, p3, 0);   SDVL_RING_PX(1, p3, 1);   SDVL_RING_PX(2, p2, 2);   SDVL_RING_PX(3, p1, 3);
-  SDVL_RING_PX(4, z, 3);    SDVL_RING_PX(5, m1, 3);   SDVL_RING_PX(6, m2, 2);   SDVL_RING_PX(7, m3, 1);
-  SDVL_RING_PX(8, m3, 0);   SDVL_RING_PX(9, m3, -1);  SDVL_RING_PX(10, m2, -2); SDVL_RING_PX(11, m1, -3);
-  SDVL_RING_PX(12, z, -3);  SDVL_RING_PX(13, p1, -3); SDVL_RING_PX(14, p2, -2); SDVL_RING_PX(15, p3, -1);
-  const int hi = v + t, lo = v - t;
-  uint32_t br = 0, dk = 0;
-#define SDVL_BIT(K) br |= (p##K > hi ? 1u : 0u) << K; dk |= (p##K < lo ? 1u : 0u) << K;
-  SDVL_BIT(0) SDVL_BIT(1) SDVL_BIT(2) SDVL_BIT(3) SDVL_BIT(4) SDVL_BIT(5) SDVL_BIT(6) SDVL_BIT(7)
-  SDVL_BIT(8) SDVL_BIT(9) SDVL_BIT(10) SDVL_BIT(11) SDVL_BIT(12) SDVL_BIT(13) SDVL_BIT(14) SDVL_BIT(15)
-#undef SDVL_BIT
-  return ring_run9(br) || ring_run9(dk);
+// cornerScore<16> of the pixel at byte address (row, x) of the padded LDS tile in closed form, by min doubling:
+// best = max(t, max_arcs min9(v-p), max_arcs min9(p-v)); OpenCV's score is best - 1.  The segment test itself falls out
+// of the same number: a 9-arc with every |difference| > t exists  <=>  best > t  (cv::FAST_t / cornerScore<16>).
+__device__ __forceinline__ int fast_corner_best(const uint8_t *tile, int pitch_bytes, int t) {
+  const int v = tile[0];
+  // e_k = v - p_k over the Bresenham circle, cv::FAST offsets16:
+  // (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+#define SDVL_E(K, DX, DY) const int e##K = v - static_cast<int>(tile[(DY) * pitch_bytes + (DX)]);
+  SDVL_E(0, 0, 3) SDVL_E(1, 1, 3) SDVL_E(2, 2, 2) SDVL_E(3, 3, 1) SDVL_E(4, 3, 0) SDVL_E(5, 3, -1) SDVL_E(6, 2, -2) SDVL_E(7, 1, -3)
+  SDVL_E(8, 0, -3) SDVL_E(9, -1, -3) SDVL_E(10, -2, -2) SDVL_E(11, -3, -1) SDVL_E(12, -3, 0) SDVL_E(13, -3, 1) SDVL_E(14, -2, 2) SDVL_E(15, -1, 3)
+#undef SDVL_E
+  // sliding windows on the ring with 3-input min / max (v_min3_i32 / v_max3_i32): 3-windows, then 9-windows = three
+  // 3-windows.  Darker ring: max over arcs of min9(e); brighter ring: max over arcs of min9(-e) = -min over arcs of max9(e).
+#define SDVL_MIN3(a, b, c) min(min((a), (b)), (c))
+#define SDVL_MAX3(a, b, c) max(max((a), (b)), (c))
+#define SDVL_W3(K, A, B, C) const int n##K = SDVL_MIN3(e##A, e##B, e##C), x##K = SDVL_MAX3(e##A, e##B, e##C);
+  SDVL_W3(0, 0, 1, 2) SDVL_W3(1, 1, 2, 3) SDVL_W3(2, 2, 3, 4) SDVL_W3(3, 3, 4, 5) SDVL_W3(4, 4, 5, 6) SDVL_W3(5, 5, 6, 7)
+  SDVL_W3(6, 6, 7, 8) SDVL_W3(7, 7, 8, 9) SDVL_W3(8, 8, 9, 10) SDVL_W3(9, 9, 10, 11) SDVL_W3(10, 10, 11, 12) SDVL_W3(11, 11, 12, 13)
+  SDVL_W3(12, 12, 13, 14) SDVL_W3(13, 13, 14, 15) SDVL_W3(14, 14, 15, 0) SDVL_W3(15, 15, 0, 1)
+#undef SDVL_W3
+#define SDVL_W9(K, A, B, C) const int N##K = SDVL_MIN3(n##A, n##B, n##C), X##K = SDVL_MAX3(x##A, x##B, x##C);
+  SDVL_W9(0, 0, 3, 6) SDVL_W9(1, 1, 4, 7) SDVL_W9(2, 2, 5, 8) SDVL_W9(3, 3, 6, 9) SDVL_W9(4, 4, 7, 10) SDVL_W9(5, 5, 8, 11)
+  SDVL_W9(6, 6, 9, 12) SDVL_W9(7, 7, 10, 13) SDVL_W9(8, 8, 11, 14) SDVL_W9(9, 9, 12, 15) SDVL_W9(10, 10, 13, 0) SDVL_W9(11, 11, 14, 1)
+  SDVL_W9(12, 12, 15, 2) SDVL_W9(13, 13, 0, 3) SDVL_W9(14, 14, 1, 4) SDVL_W9(15, 15, 2, 5)
+#undef SDVL_W9
+  const int dark = SDVL_MAX3(SDVL_MAX3(N0, N1, N2), SDVL_MAX3(N3, N4, N5), SDVL_MAX3(SDVL_MAX3(N6, N7, N8), SDVL_MAX3(N9, N10, N11), SDVL_MAX3(N12, N13, SDVL_MAX2(N14, N15))));
+  const int brig = SDVL_MIN3(SDVL_MIN3(X0, X1, X2), SDVL_MIN3(X3, X4, X5), SDVL_MIN3(SDVL_MIN3(X6, X7, X8), SDVL_MIN3(X9, X10, X11), SDVL_MIN3(X12, X13, SDVL_MIN2(X14, X15))));
+#undef SDVL_MIN3
+#undef SDVL_MAX3
+  return max(max(t, dark), -brig);
 }
 
-// cornerScore<16> of the pixel at byte address (row, x) of the padded LDS tile, closed form:
-// max(t, max_arcs min9(v-p), max_arcs min9(p-v)) - 1 by min doubling.  Called for corners only (dense list).
-__device__ __forceinline__ int fast_corner_score(const uint8_t *tile, int pitch_bytes, int t) {
-  const int v = tile[0];
-#define SDVL_P(K, DX, DY) const int p##K = tile[(DY) * pitch_bytes + (DX)];
-  SDVL_P(0, 0, 3) SDVL_P(1, 1, 3) SDVL_P(2, 2, 2) SDVL_P(3, 3, 1) SDVL_P(4, 3, 0) SDVL_P(5, 3, -1) SDVL_P(6, 2, -2) SDVL_P(7, 1, -3)
-  SDVL_P(8, 0, -3) SDVL_P(9, -1, -3) SDVL_P(10, -2, -2) SDVL_P(11, -3, -1) SDVL_P(12, -3, 0) SDVL_P(13, -3, 1) SDVL_P(14, -2, 2) SDVL_P(15, -1, 3)
-#undef SDVL_P
-  int best = t;
-#define SDVL_SCORE(OP, SGN)                                                                                                     \
-  {                                                                                                                             \
-    const int e0 = SGN(v - p0), e1 = SGN(v - p1), e2 = SGN(v - p2), e3 = SGN(v - p3), e4 = SGN(v - p4), e5 = SGN(v - p5),       \
-              e6 = SGN(v - p6), e7 = SGN(v - p7), e8 = SGN(v - p8), e9 = SGN(v - p9), e10 = SGN(v - p10), e11 = SGN(v - p11),   \
-              e12 = SGN(v - p12), e13 = SGN(v - p13), e14 = SGN(v - p14), e15 = SGN(v - p15);                                   \
-    const int a0 = OP(e0, e1), a1 = OP(e1, e2), a2 = OP(e2, e3), a3 = OP(e3, e4), a4 = OP(e4, e5), a5 = OP(e5, e6),             \
-              a6 = OP(e6, e7), a7 = OP(e7, e8), a8 = OP(e8, e9), a9 = OP(e9, e10), a10 = OP(e10, e11), a11 = OP(e11, e12),      \
-              a12 = OP(e12, e13), a13 = OP(e13, e14), a14 = OP(e14, e15), a15 = OP(e15, e0);                                    \
-    const int b0 = OP(a0, a2), b1 = OP(a1, a3), b2 = OP(a2, a4), b3 = OP(a3, a5), b4 = OP(a4, a6), b5 = OP(a5, a7),             \
-              b6 = OP(a6, a8), b7 = OP(a7, a9), b8 = OP(a8, a10), b9 = OP(a9, a11), b10 = OP(a10, a12), b11 = OP(a11, a13),     \
-              b12 = OP(a12, a14), b13 = OP(a13, a15), b14 = OP(a14, a0), b15 = OP(a15, a1);                                     \
-    best = max(best, OP(OP(b0, b4), e8));   best = max(best, OP(OP(b1, b5), e9));   best = max(best, OP(OP(b2, b6), e10));      \
-    best = max(best, OP(OP(b3, b7), e11));  best = max(best, OP(OP(b4, b8), e12));  best = max(best, OP(OP(b5, b9), e13));      \
-    best = max(best, OP(OP(b6, b10), e14)); best = max(best, OP(OP(b7, b11), e15)); best = max(best, OP(OP(b8, b12), e0));      \
-    best = max(best, OP(OP(b9, b13), e1));  best = max(best, OP(OP(b10, b14), e2)); best = max(best, OP(OP(b11, b15), e3));     \
-    best = max(best, OP(OP(b12, b0), e4));  best = max(best, OP(OP(b13, b1), e5));  best = max(best, OP(OP(b14, b2), e6));      \
-    best = max(best, OP(OP(b15, b3), e7));                                                                                      \
+// exclusive rank of (lane, bit k) in lane-major order over the wave for the 4-bit flag sets `flags`, and the wave total
+__device__ __forceinline__ int wave_rank4(uint32_t flags, int *wave_total) {
+  int below = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned long long m = __ballot((flags >> k) & 1u);
+    below += __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+    total += __popcll(m);
   }
-#define SDVL_POS(x) (x)
-#define SDVL_NEG(x) (-(x))
-  SDVL_SCORE(SDVL_MIN2, SDVL_POS)
-  SDVL_SCORE(SDVL_MIN2, SDVL_NEG)
-#undef SDVL_POS
-#undef SDVL_NEG
-#undef SDVL_SCORE
-  return (best - 1) & 0xFF;  // stored as uchar like OpenCV's score buffer
+  *wave_total = total;
+  return below;
 }
 
 __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restrict__ jobs, FastLevels lv) {
-  // image tile with a 3-row / 4-byte halo of zeros so that every ring read is unconditional
+  // ROI tile with room for a 3-row / 4-byte halo.  The halo is never initialised: every value that decides something
+  // is read within 3 px of a tested pixel, i.e. inside the ROI; halo bytes only flow into results that are masked out.
   __shared__ uint32_t s_img[(kTile + 2 * kPadRows) * kPitchW];
-  __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // 1 pad row above / below, 4 pad bytes left, >= 4 right
-  __shared__ uint16_t s_list[kTile * kTile];           // (row << 5 | x) of the pixels that pass the segment test
+  __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // scores of the corners, 0 elsewhere inside the ROI
+  __shared__ uint16_t s_list[kTile * kTile];           // (row << 5 | x) of the pixels that pass the compass pre-test
   __shared__ int s_wave_tot[4];
+  __shared__ int s_keep_tot[3][4];
   const FastJob &job = jobs[blockIdx.y];  // by reference: a by-value copy indexed with the runtime level lands in scratch
   const int gcell = blockIdx.x;
   int l = 0;
@@ -179,120 +177,117 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   const int rw = x1 - x0, rh = y1 - y0;  // <= 32
   const uint8_t *img = job.level[l];
   const int row = tid >> 3, wq = tid & 7, cg = wq * 4;
-  // zero the halo words, stage the ROI (zero outside it)
-  for (int i = tid; i < (kTile + 2 * kPadRows) * kPitchW; i += 256) {
-    const int r = i / kPitchW, w = i - r * kPitchW;
-    if (r < kPadRows || r >= kPadRows + kTile || w == 0 || w > 8) s_img[i] = 0;
-  }
-  for (int i = tid; i < (kTile + 2) * kPitchW; i += 256) {
-    const int r = i / kPitchW, w = i - r * kPitchW;
-    if (r == 0 || r == kTile + 1 || w == 0 || w > 8) s_score[i] = 0;
-  }
   {
     uint32_t pack = 0;
     if (row < rh) {
       const uint8_t *src = img + static_cast<size_t>(y0 + row) * W + x0 + cg;
+      if (cg + 4 <= rw && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {  // every cell column but the margin-clipped ones
+        pack = *reinterpret_cast<const uint32_t *>(src);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (cg + k < rw) pack |= static_cast<uint32_t>(src[k]) << (8 * k);
+        for (int k = 0; k < 4; k++)
+          if (cg + k < rw) pack |= static_cast<uint32_t>(src[k]) << (8 * k);
+      }
     }
     s_img[(row + kPadRows) * kPitchW + 1 + wq] = pack;
+    s_score[(row + 1) * kPitchW + 1 + wq] = 0;
   }
   __syncthreads();
   const int t = lv.threshold;
-  // ---- phase 1: segment test for the thread's 4 pixels (cheap part, every pixel)
+  // ---- phase A: compass pre-test of the thread's 4 pixels
   uint32_t cflags = 0;
   if (row >= 3 && row < rh - 3) {
-    // rows y-3 .. y+3, words covering bytes cg-4 .. cg+7
-#define SDVL_ROW(N, DY)                                                                  \
-  const uint32_t *q##N = &s_img[(row + kPadRows + (DY)) * kPitchW + wq];                  \
-  const uint32_t r##N##0 = q##N[0], r##N##1 = q##N[1], r##N##2 = q##N[2];
-    SDVL_ROW(m3, -3) SDVL_ROW(m2, -2) SDVL_ROW(m1, -1) SDVL_ROW(z, 0) SDVL_ROW(p1, 1) SDVL_ROW(p2, 2) SDVL_ROW(p3, 3)
-#undef SDVL_ROW
+    const uint32_t *qz = &s_img[(row + kPadRows) * kPitchW + wq];
+    const uint32_t rz0 = qz[0], rz1 = qz[1], rz2 = qz[2];
+    const uint32_t up = s_img[(row + kPadRows - 3) * kPitchW + wq + 1], dn = s_img[(row + kPadRows + 3) * kPitchW + wq + 1];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int x = cg + k;
       if (x < 3 || x >= rw - 3) continue;
-      if (fast_is_corner(rm30, rm31, rm32, rm20, rm21, rm22, rm10, rm11, rm12, rz0, rz1, rz2, rp10, rp11, rp12, rp20, rp21, rp22, rp30, rp31,
-                         rp32, k, t))
+      const int v = static_cast<int>((rz1 >> (8 * k)) & 0xFFu);
+      if (fast_compass_pass(v, static_cast<int>((dn >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 7 + k),
+                            static_cast<int>((up >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 1 + k), t))
         cflags |= 1u << k;
     }
   }
-  s_score[(row + 1) * kPitchW + 1 + wq] = 0;
-  // ---- phase 2: the corners (a few % of the pixels) are listed densely and scored one per thread
+  // ---- phase B: candidates listed densely in scan order (thread order == row-major pixel order)
   const int lane = tid & 63, wave = tid >> 6;
+  int wtot;
+  const int wrank = wave_rank4(cflags, &wtot);
+  if (lane == 0) s_wave_tot[wave] = wtot;
+  __syncthreads();
+  int cbase = 0;
+  for (int w = 0; w < wave; w++) cbase += s_wave_tot[w];
+  const int ncand = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
   {
-    const int cc = __popc(cflags);
-    int incl = cc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int nn = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += nn;
-    }
-    if (lane == 63) s_wave_tot[wave] = incl;
-    __syncthreads();
-    int cbase = 0;
-    for (int w = 0; w < wave; w++) cbase += s_wave_tot[w];
-    const int ncorner = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-    int cpos = cbase + incl - cc;
+    int cpos = cbase + wrank;
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if (cflags & (1u << k)) s_list[cpos++] = static_cast<uint16_t>((row << 5) | (cg + k));
-    __syncthreads();
-    uint8_t *score_bytes = reinterpret_cast<uint8_t *>(s_score);
-    const uint8_t *img_bytes = reinterpret_cast<const uint8_t *>(s_img);
-    for (int i = tid; i < ncorner; i += 256) {
-      const int rc = s_list[i], r = rc >> 5, x = rc & 31;
-      const int sc = fast_corner_score(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
-      score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>(sc);
-    }
   }
   __syncthreads();
-  const uint32_t sc_pack = s_score[(row + 1) * kPitchW + 1 + wq];
-  // 3x3 strict non-max suppression; survivors in row-major order
-  uint32_t keep = 0;
-  int cnt = 0;
-  if (sc_pack) {
-    const uint32_t *u = &s_score[row * kPitchW + wq], *m = u + kPitchW, *d = m + kPitchW;
-    const uint32_t u0 = u[0], u1 = u[1], u2 = u[2], m0 = m[0], m1 = m[1], m2 = m[2], d0 = d[0], d1 = d[1], d2 = d[2];
+  // ---- phase C: one candidate per lane gets the 16-pixel arithmetic, which yields the segment test AND the score
+  uint8_t *score_bytes = reinterpret_cast<uint8_t *>(s_score);
+  const uint8_t *img_bytes = reinterpret_cast<const uint8_t *>(s_img);
+  const int npass = (ncand + 255) >> 8;  // <= 3 (26 x 26 tested pixels)
+  int rc_of[3], sc_of[3];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int s = static_cast<int>((sc_pack >> (8 * k)) & 0xFF);
-      if (!s) continue;
-      const bool ok = s > byte_of(m0, m1, m2, 3 + k) && s > byte_of(m0, m1, m2, 5 + k) && s > byte_of(u0, u1, u2, 3 + k) &&
-                      s > byte_of(u0, u1, u2, 4 + k) && s > byte_of(u0, u1, u2, 5 + k) && s > byte_of(d0, d1, d2, 3 + k) &&
-                      s > byte_of(d0, d1, d2, 4 + k) && s > byte_of(d0, d1, d2, 5 + k);
-      if (ok) { keep |= 1u << k; cnt++; }
-    }
-  }
-  // block exclusive prefix sum of cnt (thread order == scan order)
-  __syncthreads();  // s_wave_tot is reused
-  int incl = cnt;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int n = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += n;
-  }
-  if (lane == 63) s_wave_tot[wave] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; w++) base += s_wave_tot[w];
-  const int total = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-  int pos = base + incl - cnt;
-  uint32_t *out = job.cell_kps + static_cast<size_t>(gcell) * SDVL_CELL_KP_CAP;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (keep & (1u << k)) {
-      if (pos < SDVL_CELL_KP_CAP) {
-        const uint32_t s = (sc_pack >> (8 * k)) & 0xFF;
-        out[pos] = static_cast<uint32_t>(x0 + cg + k) | (static_cast<uint32_t>(y0 + row) << 12) | (s << 24);
+  for (int ps = 0; ps < 3; ps++) {
+    rc_of[ps] = 0;
+    sc_of[ps] = 0;
+    if (ps < npass) {
+      const int i = ps * 256 + tid;
+      if (i < ncand) {
+        const int rc = s_list[i], r = rc >> 5, x = rc & 31;
+        const int best = fast_corner_best(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
+        if (best > t) {
+          const int sc = (best - 1) & 0xFF;  // uchar like OpenCV's score buffer
+          score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>(sc);
+          rc_of[ps] = rc;
+          sc_of[ps] = sc;
+        }
       }
-      pos++;
     }
   }
-  if (tid == 0) job.cell_counts[gcell] = min(total, SDVL_CELL_KP_CAP);
+  __syncthreads();
+  // ---- 3x3 strict non-max suppression of the corners (a score of 0 never survives, as in the per-pixel formulation)
+  uint32_t keep = 0;
+#pragma unroll
+  for (int ps = 0; ps < 3; ps++) {
+    if (ps < npass) {
+      const int sc = sc_of[ps];
+      bool ok = false;
+      if (sc) {
+        const int r = rc_of[ps] >> 5, x = rc_of[ps] & 31;
+        const uint8_t *q = score_bytes + (r + 1) * (kPitchW * 4) + 4 + x;
+        const int pb = kPitchW * 4;
+        ok = sc > q[-1] && sc > q[1] && sc > q[-pb - 1] && sc > q[-pb] && sc > q[-pb + 1] && sc > q[pb - 1] && sc > q[pb] && sc > q[pb + 1];
+      }
+      if (ok) keep |= 1u << ps;
+      const unsigned long long m = __ballot(ok);
+      if (lane == 0) s_keep_tot[ps][wave] = __popcll(m);
+    }
+  }
+  __syncthreads();
+  // survivors in list order = row-major order = cv::FAST's output order
+  uint32_t *out = job.cell_kps + static_cast<size_t>(gcell) * SDVL_CELL_KP_CAP;
+  int base = 0;
+#pragma unroll
+  for (int ps = 0; ps < 3; ps++) {
+    if (ps < npass) {
+      const bool ok = (keep >> ps) & 1u;
+      const unsigned long long m = __ballot(ok);
+      int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+      for (int w = 0; w < wave; w++) pos += s_keep_tot[ps][w];
+      if (ok && pos < SDVL_CELL_KP_CAP) {
+        const int r = rc_of[ps] >> 5, x = rc_of[ps] & 31;
+        out[pos] = static_cast<uint32_t>(x0 + x) | (static_cast<uint32_t>(y0 + r) << 12) | (static_cast<uint32_t>(sc_of[ps]) << 24);
+      }
+      base += s_keep_tot[ps][0] + s_keep_tot[ps][1] + s_keep_tot[ps][2] + s_keep_tot[ps][3];
+    }
+  }
+  if (tid == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
 }
-#undef SDVL_RING_PX
 #undef SDVL_MIN2
 #undef SDVL_MAX2
 

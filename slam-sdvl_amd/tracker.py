@@ -150,13 +150,21 @@ class TrackerFarm:
     def ctx_handle(self, g=0):
         return self.lib.sdvlh_farm_ctx(self.h, g)
 
-    def run(self, dev_frames, workers=0):
+    def alloc_stats(self, n_steps):
+        """output records for run(); touched here so that the workers do not take the first-touch page faults"""
+        out = (FrameStats * (n_steps * self.G * self.Bg))()
+        C.memset(out, 0, C.sizeof(out))
+        return out
+
+    def run(self, dev_frames, workers=0, out=None):
         """dev_frames: int array [n_steps, G*Bg] of device pointers -> FrameStats array [n_steps*G*Bg];
         workers = host threads (0 = one per group); workers < G schedules group-steps dynamically"""
         dev_frames = np.ascontiguousarray(dev_frames, np.uint64)
         n_steps = dev_frames.shape[0]
         assert dev_frames.shape[1] == self.G * self.Bg
-        out = (FrameStats * (n_steps * self.G * self.Bg))()
+        if out is None:
+            out = self.alloc_stats(n_steps)
+        assert len(out) >= n_steps * self.G * self.Bg
         if self.lib.sdvlh_farm_run(self.h, n_steps, dev_frames.ctypes.data, self.w, out, int(workers)) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return out
