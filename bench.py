@@ -107,7 +107,7 @@ class CtxView:
         return {names[i].value.decode(): (ms[i], launches[i]) for i in range(n.value)}
 
 
-def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_kp=10000):
+def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp=10000):
     """SURVEY §8(d) per-frame algorithmic bytes, split by kernel (640x480, 5 levels, 3 FAST levels)."""
     P = [(W_IMG >> l) * (H_IMG >> l) for l in range(5)]
     return {
@@ -118,6 +118,8 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_kp=10000):
         "orb_describe": n_c * (961 + 32),                            # 31x31 window + descriptor
         "image_align": 3 * n_f * 49 + i_ia * n_f * 25,               # reference windows + current windows per GN iteration
         "search_points": 12 * n_c + n_s * (121 + 164 + i_fa * 81),   # corner list + warp window + patches + LK windows
+        "pose_hypotheses": 48 * n_m + 100 * 64,                      # match records read once + one result per RANSAC draw
+        "pose_refine": 48 * n_m + 100 * 64 + 4 * n_m + 80,           # matches + draw results read, index lists + pose written
     }.get(kernel)
 
 
@@ -211,6 +213,8 @@ def main():
         torch.cuda.synchronize()
 
     workers = args.workers or G
+    # keyframe budget: every keyframe keeps its HBM frame; S-A turns about one frame in five into a keyframe
+    farm.reserve(Bg * (4 + (Wm + K + 3) // 4))
     farm.run(ptrs[:1 + Wm], workers)          # bootstrap + warmup (untimed)
     farm.stage_times(reset=True)
     for c in ctxs:
@@ -229,8 +233,10 @@ def main():
         c.timing(False)
     stage_s, stage_n = farm.stage_times()
     tracked = 0
-    n_c = n_s = n_f = n_ia = n_lk = 0
+    n_c = n_s = n_f = n_ia = n_lk = n_m = n_kf = 0
     for st in stats:
+        n_m += st.matches
+        n_kf += st.keyframe
         tracked += int(st.quality != 2)
         n_c += st.n_corners
         n_s += st.search_requests
@@ -249,7 +255,7 @@ def main():
             avg_s = ms / max(1, launches) * 1e-3
             # measured per-frame averages (corners, features, requests, GN evaluations, LK iterations) feed the §8(d) formula
             per_frame = algorithmic_bytes_per_frame(name, n_c / frames_rank, n_f / frames_rank, n_s / frames_rank,
-                                                    n_ia / frames_rank, n_lk / max(1, n_s))
+                                                    n_ia / frames_rank, n_lk / max(1, n_s), n_m / frames_rank)
             launches_per_step = launches / K          # all groups together
             if per_frame is not None:
                 bytes_per_launch = per_frame * B / launches_per_step
@@ -277,7 +283,8 @@ def main():
                        "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
-                       "lk_iterations_per_request": round(n_lk / max(1, n_s), 2)},
+                       "lk_iterations_per_request": round(n_lk / max(1, n_s), 2),
+                       "matches_per_frame": round(n_m / frames_rank, 1), "keyframes_per_frame": round(n_kf / frames_rank, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: round(v[0] / K, 4) for k, v in sorted(timers.items())},
             "host_stage_ms_per_group_step": {k: round(v / max(1, stage_n) * 1e3, 3) for k, v in stage_s.items()},

@@ -213,6 +213,18 @@ void sdvlh_farm_destroy(void *fp) {
   delete f;
 }
 
+// pool `frames_per_group` free HBM frames in every group (keyframe budget), so the run allocates nothing
+int sdvlh_farm_reserve(void *fp, int frames_per_group) {
+  Farm *f = static_cast<Farm *>(fp);
+  try {
+    for (void *d : f->devices) static_cast<Device *>(d)->Reserve(f->w, f->h, Config::PyramidLevels(), frames_per_group);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 void *sdvlh_farm_ctx(void *fp, int g) { return sdvlh_device_ctx(static_cast<Farm *>(fp)->devices[g]); }
 void *sdvlh_farm_batch(void *fp, int g) { return static_cast<Farm *>(fp)->batches[g]; }
 

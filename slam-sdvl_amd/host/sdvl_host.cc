@@ -66,12 +66,28 @@ sdvl_frame *Device::AcquireFrame(int w, int h, int levels) {
       return f;
     }
   }
-  // pool empty: take a slab of frames at once (a farm of trackers keeps turning frames into keyframes)
-  const int kChunk = 32;
-  sdvl_frame *fresh[kChunk];
-  Check(sdvl_frame_create_many(ctx_, w, h, levels, kChunk, fresh), "sdvl_frame_create_many");
-  for (int i = 1; i < kChunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels});
+  // pool empty: take a slab of frames at once (a farm of trackers keeps turning frames into keyframes).  hipMalloc costs
+  // milliseconds, so the slabs grow geometrically; callers that know their keyframe budget call Reserve() up front.
+  const int chunk = std::min(512, std::max(32, total_frames_ / 2));
+  std::vector<sdvl_frame *> fresh(chunk);
+  Check(sdvl_frame_create_many(ctx_, w, h, levels, chunk, fresh.data()), "sdvl_frame_create_many");
+  total_frames_ += chunk;
+  for (int i = 1; i < chunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels});
   return fresh[0];
+}
+
+void Device::Reserve(int w, int h, int levels, int frames) {
+  std::lock_guard<std::mutex> lk(pool_mutex_);
+  int have = 0;
+  for (const Pooled &p : pool_) have += (p.w == w && p.h == h && p.levels == levels) ? 1 : 0;
+  while (have < frames) {
+    const int chunk = std::min(512, frames - have);
+    std::vector<sdvl_frame *> fresh(chunk);
+    Check(sdvl_frame_create_many(ctx_, w, h, levels, chunk, fresh.data()), "sdvl_frame_create_many");
+    total_frames_ += chunk;
+    for (int i = 0; i < chunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels});
+    have += chunk;
+  }
 }
 
 // frames die wherever their last shared_ptr is dropped, including the host worker threads

@@ -45,6 +45,9 @@ class Device {
   sdvl_ctx *ctx() const { return ctx_; }
   sdvl_frame *AcquireFrame(int w, int h, int levels);
   void ReleaseFrame(sdvl_frame *f, int w, int h, int levels);
+  // make sure `frames` free HBM frames of this shape are pooled (keyframes keep theirs for good: size it from the
+  // keyframe budget so that no hipMalloc lands on the tracking path)
+  void Reserve(int w, int h, int levels, int frames);
   void Check(int rc, const char *what) const;
   static Device *Current();
   static void SetCurrent(Device *d);
@@ -54,6 +57,7 @@ class Device {
   struct Pooled { sdvl_frame *f; int w, h, levels; };
   std::vector<Pooled> pool_;
   std::mutex pool_mutex_;
+  int total_frames_ = 0;
 };
 
 // glibc rand() (TYPE_3, seed 1) as a private stream: the reference draws from the process-global rand()

@@ -142,6 +142,7 @@ class TrackerFarm:
         self.lib.sdvlh_farm_batch.restype = C.c_void_p
         self.lib.sdvlh_farm_batch.argtypes = [C.c_void_p, C.c_int]
         self.lib.sdvlh_farm_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        self.lib.sdvlh_farm_reserve.argtypes = [C.c_void_p, C.c_int]
         self.h = self.lib.sdvlh_farm_create(gpu, G, Bg, w, h, cam4.ctypes.data, plane4.ctypes.data, first_poses.ctypes.data,
                                             host_threads_per_group)
         if not self.h:
@@ -149,6 +150,11 @@ class TrackerFarm:
 
     def ctx_handle(self, g=0):
         return self.lib.sdvlh_farm_ctx(self.h, g)
+
+    def reserve(self, frames_per_group):
+        """pool HBM frames up front (keyframes keep theirs): no hipMalloc on the tracking path for that many frames"""
+        if self.lib.sdvlh_farm_reserve(self.h, int(frames_per_group)) != 0:
+            raise RuntimeError(self.lib.sdvlh_last_error().decode())
 
     def alloc_stats(self, n_steps):
         """output records for run(); touched here so that the workers do not take the first-touch page faults"""

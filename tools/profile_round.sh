@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box from the repo root:  bash tools/profile_round.sh
+# Three separate rocprofv3 runs of bench.py (the program itself follows `--`): kernel trace + stats on the default
+# workload, then one PMC pass per counter (FETCH_SIZE, WRITE_SIZE) on a shorter run.  Raw output -> gpurun_out/,
+# (kernel trace at 20 steps: with 30+ steps, 16 groups and the device pose stage this rocprofv3 build segfaults inside
+# hipMemcpyAsync; the same command runs clean without the profiler and with --pmc)
+# summaries are made from it by tools/summarize_profiles.py and committed under profiles/.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+O=gpurun_out
+rm -rf $O/prof_kt $O/prof_fetch $O/prof_write
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --steps 20 --warmup 3 --cpu-frames 0 > $O/prof_kt.json 2> $O/prof_kt.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 > $O/prof_fetch.json 2> $O/prof_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 > $O/prof_write.json 2> $O/prof_write.err
+# the stats files are small; the raw traces are not needed back
+find $O/prof_kt -name "*kernel_trace.csv" -delete
+find $O/prof_fetch $O/prof_write -name "*kernel_trace.csv" -delete
+python3 tools/summarize_profiles.py $O $O/summary_r
+ls -la $O/summary_r

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_round.sh into the small CSV / JSON files kept under profiles/.
+    python tools/summarize_profiles.py <gpurun_out> <dest_dir>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+
+
+def biggest(pattern):
+    files = glob.glob(os.path.join(src, pattern), recursive=True)
+    return max(files, key=os.path.getsize) if files else None
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    return name.split("(")[0]
+
+
+# kernel-trace stats of the bench process (the largest stats file belongs to the python process, not to helpers)
+ks = biggest("prof_kt/**/*kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(dst, "kernel_stats.csv"))
+ds = biggest("prof_kt/**/*domain_stats.csv")
+if ds:
+    shutil.copy(ds, os.path.join(dst, "domain_stats.csv"))
+for name in ("bench_default.json", "prof_kt.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, "bench_under_rocprof.json" if name == "prof_kt.json" else name))
+
+# PMC passes: per kernel average FETCH_SIZE / WRITE_SIZE (KB as reported by rocprofv3)
+acc = {}
+for counter, sub in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
+    f = biggest(sub + "/**/*counter_collection.csv")
+    if not f:
+        continue
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row["Kernel_Name"])
+            a = acc.setdefault(k, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+            a[counter][0] += float(row["Counter_Value"])
+            a[counter][1] += 1
+cfg = ""
+pj = os.path.join(src, "prof_fetch.json")
+if os.path.exists(pj) and os.path.getsize(pj):
+    try:
+        c = json.loads(open(pj).read().strip().splitlines()[-1])["config"]
+        cfg = "%d sequences in %d groups -> %d frames per dispatch" % (c["sequences_per_gpu"], c["groups_per_gpu"], c["sequences_per_group"])
+    except Exception:
+        pass
+with open(os.path.join(dst, "pmc_hbm_traffic.csv"), "w") as out:
+    out.write("kernel,dispatches,FETCH_SIZE_avg_KB,WRITE_SIZE_avg_KB,note\n")
+    note = "separate --pmc passes; %s; FETCH_SIZE may read 1/2 of wide streaming loads on gfx950 (MI355X_MICROARCH.md HBM)" % cfg
+    for k in sorted(acc):
+        a = acc[k]
+        n = max(a["FETCH_SIZE"][1], a["WRITE_SIZE"][1])
+        fa = a["FETCH_SIZE"][0] / a["FETCH_SIZE"][1] if a["FETCH_SIZE"][1] else float("nan")
+        wa = a["WRITE_SIZE"][0] / a["WRITE_SIZE"][1] if a["WRITE_SIZE"][1] else float("nan")
+        out.write("%s,%d,%.2f,%.2f,%s\n" % (k, n, fa, wa, note))
+print("wrote", sorted(os.listdir(dst)))
