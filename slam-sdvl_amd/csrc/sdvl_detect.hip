@@ -161,7 +161,13 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   __shared__ int s_wave_tot[4];
   __shared__ int s_keep_tot[3][4];
   const FastJob &job = jobs[blockIdx.y];  // by reference: a by-value copy indexed with the runtime level lands in scratch
-  const int gcell = blockIdx.x;
+  // Workgroups go to the 8 XCDs round-robin by linear id; gridDim.x is a multiple of 32, so XCD = blockIdx.x % 8.  Within
+  // every run of 32 cells an XCD gets 4 horizontally adjacent ones: a cell row is 32 bytes, so the 4 cells share their
+  // 128-byte lines and find them in ONE L2 instead of fetching them once per XCD — and every XCD still sees the same mix
+  // of full and margin-clipped cells.
+  const int total_cells = lv.cell_begin[lv.n_levels];
+  const int gcell = static_cast<int>(blockIdx.x & ~31u) + static_cast<int>(blockIdx.x & 7u) * 4 + static_cast<int>((blockIdx.x >> 3) & 3u);
+  if (gcell >= total_cells) return;
   int l = 0;
   while (l + 1 < lv.n_levels && gcell >= lv.cell_begin[l + 1]) l++;
   const int c = gcell - lv.cell_begin[l];
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256) void compact_cells_kernel(const FastJob *__res
 __device__ __forceinline__ bool kp_gt(uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); }  // response greater
 __device__ __forceinline__ void kp_swap(uint32_t *v, int i, int j) { const uint32_t t = v[i]; v[i] = v[j]; v[j] = t; }
 
-__device__ void sel_move_median_to_first(uint32_t *v, int result, int a, int b, int c) {
+__device__ __forceinline__ void sel_move_median_to_first(uint32_t *v, int result, int a, int b, int c) {
   if (kp_gt(v[a], v[b])) {
     if (kp_gt(v[b], v[c])) kp_swap(v, result, b);
     else if (kp_gt(v[a], v[c])) kp_swap(v, result, c);
@@ -351,7 +357,7 @@ __device__ void sel_move_median_to_first(uint32_t *v, int result, int a, int b, 
   else kp_swap(v, result, b);
 }
 
-__device__ int sel_unguarded_partition(uint32_t *v, int first, int last, int pivot) {
+__device__ __forceinline__ int sel_unguarded_partition(uint32_t *v, int first, int last, int pivot) {
   while (true) {
     while (kp_gt(v[first], v[pivot])) ++first;
     --last;
@@ -362,7 +368,7 @@ __device__ int sel_unguarded_partition(uint32_t *v, int first, int last, int piv
   }
 }
 
-__device__ void sel_push_heap(uint32_t *v, int first, int hole, int top, uint32_t value) {
+__device__ __forceinline__ void sel_push_heap(uint32_t *v, int first, int hole, int top, uint32_t value) {
   int parent = (hole - 1) / 2;
   while (hole > top && kp_gt(v[first + parent], value)) {
     v[first + hole] = v[first + parent];
@@ -372,7 +378,7 @@ __device__ void sel_push_heap(uint32_t *v, int first, int hole, int top, uint32_
   v[first + hole] = value;
 }
 
-__device__ void sel_adjust_heap(uint32_t *v, int first, int hole, int len, uint32_t value) {
+__device__ __forceinline__ void sel_adjust_heap(uint32_t *v, int first, int hole, int len, uint32_t value) {
   const int top = hole;
   int second = hole;
   while (second < (len - 1) / 2) {
@@ -389,7 +395,7 @@ __device__ void sel_adjust_heap(uint32_t *v, int first, int hole, int len, uint3
   sel_push_heap(v, first, hole, top, value);
 }
 
-__device__ void sel_heap_select(uint32_t *v, int first, int middle, int last) {
+__device__ __forceinline__ void sel_heap_select(uint32_t *v, int first, int middle, int last) {
   const int len = middle - first;
   if (len >= 2) {  // __make_heap
     int parent = (len - 2) / 2;
@@ -408,7 +414,7 @@ __device__ void sel_heap_select(uint32_t *v, int first, int middle, int last) {
     }
 }
 
-__device__ void sel_insertion_sort(uint32_t *v, int first, int last) {
+__device__ __forceinline__ void sel_insertion_sort(uint32_t *v, int first, int last) {
   if (first == last) return;
   for (int i = first + 1; i != last; ++i) {
     const uint32_t val = v[i];
@@ -428,7 +434,7 @@ __device__ void sel_insertion_sort(uint32_t *v, int first, int last) {
 }
 
 // std::nth_element(v+first, v+nth, v+last, response-greater)
-__device__ void sel_nth_element(uint32_t *v, int first, int nth, int last) {
+__device__ __forceinline__ void sel_nth_element(uint32_t *v, int first, int nth, int last) {
   if (first == last || nth == last) return;
   int depth_limit = (31 - __clz(last - first)) * 2;  // std::__lg(n) * 2
   while (last - first > 3) {
@@ -448,7 +454,7 @@ __device__ void sel_nth_element(uint32_t *v, int first, int nth, int last) {
 }
 
 // cv::KeyPointsFilter::retainBest(kps, n_points) on v[0..len): returns the new length
-__device__ int sel_retain_best(uint32_t *v, int len, int n_points) {
+__device__ __forceinline__ int sel_retain_best(uint32_t *v, int len, int n_points) {
   if (n_points >= 0 && len > n_points) {
     if (n_points == 0) return 0;
     sel_nth_element(v, 0, n_points, len);
@@ -530,7 +536,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave, int *tot
 //   K = #{k : L[k] < R[k]},  swap v[L[k]] <-> v[R[k]] for k < K.
 // All threads call this with identical arguments.  is_left / is_right classify a packed keypoint.
 template <typename FL, typename FR>
-__device__ void block_two_pointer_partition(uint32_t *v, int first, int last, uint16_t *Ls, uint16_t *Rs, int *s_wave, FL is_left, FR is_right,
+__device__ __forceinline__ void block_two_pointer_partition(uint32_t *v, int first, int last, uint16_t *Ls, uint16_t *Rs, int *s_wave, FL is_left, FR is_right,
                                             int *out_K, int *out_nL, int *out_nR) {
   const int tid = threadIdx.x;
   const int n = last - first;
@@ -569,7 +575,7 @@ __device__ void block_two_pointer_partition(uint32_t *v, int first, int last, ui
 }
 
 // sequential continuation of __introselect from an intermediate state (one lane)
-__device__ void sel_introselect_from(uint32_t *v, int first, int nth, int last, int depth_limit) {
+__device__ __forceinline__ void sel_introselect_from(uint32_t *v, int first, int nth, int last, int depth_limit) {
   while (last - first > 3) {
     if (depth_limit == 0) {
       sel_heap_select(v, first, nth + 1, last);
@@ -587,7 +593,7 @@ __device__ void sel_introselect_from(uint32_t *v, int first, int nth, int last, 
 }
 
 // cv::KeyPointsFilter::retainBest(v[0..len), n_points) by the whole workgroup; every thread gets the new length
-__device__ int block_retain_best(uint32_t *v, int len, int n_points, uint16_t *Ls, uint16_t *Rs, int *s_wave) {
+__device__ __forceinline__ int block_retain_best(uint32_t *v, int len, int n_points, uint16_t *Ls, uint16_t *Rs, int *s_wave) {
   if (!(n_points >= 0 && len > n_points)) return len;
   if (n_points == 0) return 0;
   const int tid = threadIdx.x;
@@ -954,7 +960,7 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, job_bytes, hipMemcpyHostToDevice, ctx->stream));
   int32_t *d_offs = static_cast<int32_t *>(ctx->d_out);
   uint32_t *d_kps = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->d_out) + offs_bytes);
-  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3(total_cells, n), dim3(256), static_cast<const FastJob *>(dsx), lv);
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv);
   SDVL_LAUNCH(ctx, "compact_cells", compact_cells_kernel, dim3(n), dim3(256), static_cast<const FastJob *>(dsx), total_cells, cap, d_kps, d_offs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   int32_t *h_offs = static_cast<int32_t *>(ctx->h_out);
@@ -1069,7 +1075,7 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst, hst, fj_bytes + sj_bytes, hipMemcpyHostToDevice, ctx->stream));
   const FastJob *df = static_cast<const FastJob *>(dst);
   const SelJob *ds = reinterpret_cast<const SelJob *>(static_cast<uint8_t *>(dst) + fj_bytes);
-  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3(total_cells, n), dim3(256), df, lv);
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv);
   SDVL_LAUNCH(ctx, "select_corners", select_corners_kernel, dim3(lv.n_levels, n), dim3(kSelThreads), ds, sl);
   SDVL_LAUNCH(ctx, "pack_corners", pack_corners_kernel, dim3(n), dim3(256), ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts));
   SDVL_HIP_CHECK(ctx, hipGetLastError());

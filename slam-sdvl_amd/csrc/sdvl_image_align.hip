@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__re
         iters_run++;
         const double new_chi2 = static_cast<double>(static_cast<float>(s_sum[27]) / static_cast<float>(n_meas));
         if (n_meas == 0) stop = true;
-        ldlt_solve6(Hm, Jres, x);
+        ldlt_solve6_reg<true>(Hm, Jres, x);
         if (x[0] != x[0]) stop = true;
         int brk = 0;
         if ((it > 0 && new_chi2 > chi2) || stop) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
         iters_run++;
         const double new_chi2 = static_cast<double>(static_cast<float>(s_sum[27]) / static_cast<float>(n_meas));
         if (n_meas == 0) stop = true;
-        ldlt_solve6_reg(Hm, Jres, xs);
+        ldlt_solve6_reg<true>(Hm, Jres, xs);
         if (xs[0] != xs[0]) stop = true;
         int brk = 0;
         if ((it > 0 && new_chi2 > chi2) || stop) {

@@ -106,13 +106,14 @@ SDVL_HD Rigid se3_exp(const double *u) {
   const double theta = vnorm(om);
   const double half_theta = 0.5 * theta;
   double imag;
-  const double real = cos(half_theta);
+  double real, sin_half;
+  sincos(half_theta, &sin_half, &real);  // same values as sin() and cos(), one argument reduction
   if (theta < kEps) {
     const double t2 = theta * theta;
     const double t4 = t2 * t2;
     imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t4;
   } else {
-    imag = sin(half_theta) / theta;
+    imag = sin_half / theta;
   }
   Rigid r;
   r.q0 = real; r.q1 = imag * om.x; r.q2 = imag * om.y; r.q3 = imag * om.z;
@@ -126,8 +127,10 @@ SDVL_HD Rigid se3_exp(const double *u) {
     V = quat_to_mat(r.q0, r.q1, r.q2, r.q3);
   } else {
     const double t2 = theta * theta;
-    const double ca = (1 - cos(theta)) / (t2);
-    const double cb = (theta - sin(theta)) / (t2 * theta);
+    double sin_theta, cos_theta;
+    sincos(theta, &sin_theta, &cos_theta);
+    const double ca = (1 - cos_theta) / (t2);
+    const double cb = (theta - sin_theta) / (t2 * theta);
     for (int i = 0; i < 9; i++) V.m[i] = (((i % 4) == 0 ? 1.0 : 0.0) + ca * Om.m[i]) + cb * Om2.m[i];
   }
   r.t = mvec(V, ups);
@@ -272,6 +275,9 @@ SDVL_HD void ldlt_solve6(const double *Ain, const double *bin, double *x) {
 // Same factorisation and solve with every array index a compile-time constant (run-time pivot handled by predicated
 // swaps): stays in registers on the device where ldlt_solve6's dynamic indexing would go to scratch.
 // ldlt_solve6 (sdvl_math.h) with compile-time indices only: swaps become predicated moves, so everything stays in registers
+// kUniform: every active lane of the wave solves the SAME system (or only one lane is active): the pivot index is then
+// made a scalar, the swap blocks become scalar branches and only the one that applies is executed.
+template <bool kUniform = false>
 SDVL_HD void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
   double a[36];
   int tr[6];
@@ -288,6 +294,9 @@ SDVL_HD void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
       if (v > big) { big = v; idx = i; }
     }
     if (!alive) idx = k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kUniform) idx = __builtin_amdgcn_readfirstlane(idx);
+#endif
     tr[k] = idx;
     if (alive) {
       // swap rows/cols k <-> idx of the lower triangle (Eigen ldlt unblocked), predicated on the run-time idx

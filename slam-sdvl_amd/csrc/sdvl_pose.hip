@@ -218,26 +218,27 @@ __device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const
     }
   }
   wave_lds_sync();
-  // median = element floor(n/2) of the sorted order: rank counting, candidates spread over the lanes
+  // median = element floor(n/2) of the sorted order (what nth_element leaves there).  The errors are non-negative
+  // doubles, whose bit patterns order like unsigned integers: the k-th smallest is built bit by bit from the top,
+  // counting with ballots how many values lie below the candidate prefix — 63 uniform steps, no sorting.
   double median = 0.0;
   {
     const int k = n / 2;
-    bool mine = false;
-    double val = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      const double e = L.errs[i];
-      int less = 0, eq = 0;
-      for (int j = 0; j < n; j++) {
-        const double f = L.errs[j];
-        less += (f < e) ? 1 : 0;
-        eq += (f == e) ? 1 : 0;
-      }
-      if (less <= k && k < less + eq) { mine = true; val = e; }
+    unsigned long long v[kMaxObs / 64];
+#pragma unroll
+    for (int u = 0; u < kMaxObs / 64; u++) {
+      const int i = u * 64 + lane;
+      v[u] = i < n ? static_cast<unsigned long long>(__double_as_longlong(L.errs[i])) : ~0ull;
     }
-    const unsigned long long b = __ballot(mine);
-    const int src = b ? __ffsll(static_cast<long long>(b)) - 1 : 0;  // every qualifying candidate holds the same value
-    const int lo = __shfl(__double2loint(val), src, 64), hi = __shfl(__double2hiint(val), src, 64);
-    median = __hiloint2double(hi, lo);
+    unsigned long long prefix = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+      const unsigned long long cand = prefix | (1ull << bit);
+      int cnt = 0;
+#pragma unroll
+      for (int u = 0; u < kMaxObs / 64; u++) cnt += __popcll(__ballot(v[u] < cand));
+      if (cnt <= k) prefix = cand;
+    }
+    median = __longlong_as_double(static_cast<long long>(prefix));
   }
   double scale = kMADNorm * median;
   for (int i = 0; i < max_its; i++) {
@@ -268,12 +269,19 @@ __device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const
       }
       wave_lds_sync();
       if (lane < 28) {
+        // in observation order; b accumulates with -= in the reference, and x - t == x + (-t) exactly.  Loads are issued
+        // eight at a time so that the LDS latency is paid once per group, the adds stay a dependent chain.
         const int m = min(64, n - q0);
-        if (lane >= 21 && lane < 27) {
-          for (int j = 0; j < m; j++) acc -= L.terms[j][lane];  // b -= ...
-        } else {
-          for (int j = 0; j < m; j++) acc += L.terms[j][lane];
+        const bool neg = lane >= 21 && lane < 27;
+        int j = 0;
+        for (; j + 8 <= m; j += 8) {
+          double t8[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) t8[u] = L.terms[j + u][lane];
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += neg ? -t8[u] : t8[u];
         }
+        for (; j < m; j++) acc += neg ? -L.terms[j][lane] : L.terms[j][lane];
       }
       wave_lds_sync();
     }
@@ -295,7 +303,7 @@ __device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const
     for (int r = 0; r < 6; r++) b[r] = L.sums[21 + r];
     const double new_chi2 = L.sums[27];
     wave_lds_sync();
-    ldlt_solve6_reg(A, b, dT);
+    ldlt_solve6_reg<true>(A, b, dT);
     if ((i > 0 && new_chi2 > chi2) || dT[0] != dT[0]) {
       *se3 = last;
       break;
@@ -328,20 +336,30 @@ __global__ __launch_bounds__(64) void pose_refine_kernel(const PoseJobDev *__res
     if (lane == 0) results[blockIdx.x] = res;
     return;
   }
-  // ---- RANSAC bookkeeping replayed over the draw results (feature_align.cc:172-212); uniform across the lanes
+  // ---- RANSAC bookkeeping replayed over the draw results (feature_align.cc:172-212).  The loop is inherently serial
+  // (the budget shrinks as supporters improve), so it must not touch memory: lane h holds the supporter count of draws h
+  // and h + 64 (-1 = ConvergePose failed), the loop reads them with readlane; uniform across the lanes.
   const HypResult *hy = hyp + static_cast<size_t>(blockIdx.x) * prm.max_ransac_its;
   const int32_t *nits_of = nits_table + job.nits_begin;  // iteration budget after an improvement to s supporters
-  Rigid best = se3_identity();  // SE3 best_se3 default-constructed
+  int best_it = -1;
   int nits = prm.max_ransac_its, best_sup = 0, it = 0;
-  while (it < nits) {
-    const HypResult &r = hy[it];
-    if (r.ok && r.supporters > best_sup) {
-      best_sup = r.supporters;
-      best = se3_from7(r.se3);
-      nits = nits_of[best_sup];
+  for (int base = 0; base < prm.max_ransac_its && it < nits; base += 64) {
+    const int h = base + lane;
+    int sup = -1;
+    if (h < prm.max_ransac_its && hy[h].ok) sup = hy[h].supporters;
+    const int end = min(base + 64, prm.max_ransac_its);
+    while (it < nits && it < end) {
+      const int s_it = __builtin_amdgcn_readlane(sup, it - base);
+      if (s_it > best_sup) {
+        best_sup = s_it;
+        best_it = it;
+        nits = nits_of[best_sup];
+      }
+      it++;
     }
-    it++;
   }
+  Rigid best = se3_identity();  // SE3 best_se3 default-constructed
+  if (best_it >= 0) best = se3_from7(hy[best_it].se3);
   res.n_draws = it;
   // ---- final CheckReprojectionError with the best hypothesis -> inliers / outliers (feature_align.cc:215)
   for (int q = lane; q < size; q += 64) L.tmp[q] = static_cast<uint16_t>(q);

@@ -58,15 +58,35 @@ for _ in range(reps):
     ctx._check(lib.sdvl_orb_describe(ctx.h, n, arr0, 4096, None))
     res = ctx.image_align(jobs, feats, cam, ap)
     its += sum(r.iters_run for r in res)
+# pose stage: n jobs of 190 matches (20 % gross outliers) of a small camera motion; rand() draws from numpy (timing only)
+prng = np.random.default_rng(7)
+pose_jobs = []
+true_pose = B.se3_exp(np.array([0.03, -0.02, 0.01, 0.004, -0.006, 0.003]))
+qw, qx, qy, qz = true_pose[:4]
+Rm = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+               [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+               [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+for j in range(n):
+    P3 = np.stack([prng.uniform(-1.2, 1.2, nf), prng.uniform(-0.9, 0.9, nf), prng.uniform(1.5, 3.0, nf)], 1)
+    pc = P3 @ Rm.T + true_pose[4:]
+    a = pc[:, :2] / pc[:, 2:3] + prng.normal(0, 0.4 / 517.3, (nf, 2))
+    bad = prng.random(nf) < 0.2
+    a[bad] += prng.uniform(-40, 40, (int(bad.sum()), 2)) / 517.3
+    obs = np.concatenate([a, P3, prng.integers(0, 3, nf)[:, None].astype(np.float64)], 1)
+    pose_jobs.append((obs, [1, 0, 0, 0, 0, 0, 0], prng.integers(0, 2**31 - 1, 100)))
+for _ in range(max(1, reps // 3)):
+    pres = ctx.pose_from_matches(pose_jobs, fx=B.TUM_CAM[0])
 ctx.synchronize()
 t = ctx.timing_get()
+print("pose: draws/job=%.1f inliers/job=%.1f" % (np.mean([r["n_draws"] for r in pres]), np.mean([len(r["inliers"]) for r in pres])))
 counts = np.zeros(n, np.int32)
 ctx._check(lib.sdvl_frames_corner_counts(ctx.h, n, arr0, counts.ctypes.data_as(C.POINTER(C.c_int32))))
 nc = float(counts.mean())
 i_ia = its / (reps * n)
 P = [(W >> l) * (H >> l) for l in range(5)]
 alg = {"pyr_down": (sum(P[:4]) + sum(P[1:])) / 4.0, "fast_cells": sum(P[:3]) + 16 * nc, "select_corners": 4 * 10000 + 16 * nc, "pack_corners": 32 * nc,
-       "orb_describe": 993 * nc, "image_align": 147 * nf + 25 * nf * i_ia}
+       "orb_describe": 993 * nc, "image_align": 147 * nf + 25 * nf * i_ia, "pose_hypotheses": 48 * nf + 6400,
+       "pose_refine": 52 * nf + 6480}
 print("n_frames=%d reps=%d corners/frame=%.0f GN evaluations/job=%.1f" % (n, reps, nc, i_ia))
 for k, (ms, launches) in sorted(t.items()):
     us = ms / launches * 1e3
