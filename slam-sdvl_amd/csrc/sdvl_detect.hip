@@ -481,7 +481,7 @@ __device__ __forceinline__ int sel_retain_best(uint32_t *v, int len, int n_point
 }
 
 constexpr int kSelMaxCells = 2048;  // cells of one level
-constexpr int kSelStage = 8192;     // keypoints staged in LDS per round
+constexpr int kSelStage = 16384;    // keypoints staged in LDS per round (a 640x480 level 0 holds ~12k: one round)
 constexpr int kSelFts = 4096;       // concatenated selection of one level before the final retainBest
 
 struct SelLevels {
