@@ -123,6 +123,31 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
     }.get(kernel)
 
 
+def pmc_traffic_bytes(kernel, frames_per_launch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN/pmc_hbm_traffic.csv, newest round):
+    (FETCH_SIZE + WRITE_SIZE) * 1024 as the CDNA guide prices it, scaled to this run's frames per launch.  The counters
+    need their own rocprofv3 passes (tools/profile_round.sh), so they cannot be sampled inside the timed region."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_hbm_traffic.csv")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        for row in csv.DictReader(fh):
+            if row["kernel"].startswith(kernel):
+                m = re.search(r"-> (\d+) frames per dispatch", row.get("note", ""))
+                per = float(m.group(1)) if m else None
+                try:
+                    total = (float(row["FETCH_SIZE_avg_KB"]) + float(row["WRITE_SIZE_avg_KB"])) * 1024.0
+                except ValueError:
+                    return None
+                if not per or total != total:
+                    return None
+                return int(total * frames_per_launch / per)
+    return None
+
+
 def effective_cpus():
     """CPUs this process may actually use: affinity mask and cgroup quota (the GPU boxes run under a CPU quota)"""
     n = os.cpu_count() or 1
@@ -261,7 +286,7 @@ def main():
                 bytes_per_launch = per_frame * B / launches_per_step
                 achieved = bytes_per_launch / avg_s / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes(name, B / launches_per_step),
                             "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch)}
         cpu = None
         if args.cpu_frames > 0:
