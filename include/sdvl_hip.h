@@ -211,6 +211,22 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
                        const uint8_t *border, const uint8_t *patch, int max_its, double *uv_io,
                        uint8_t *converged, int32_t *its);
 
+/* ---- input stage: Camera::UndistortImage = cv::undistort(in, out, K, D) (camera.cc:39-67,100-105, main.cc:133) ----
+ * d[0..4] = Camera.d1..d5 of the config = (k1, k2, p1, p2, k3).  As in the reference, d[0] == 0 means "no distortion":
+ * the image is copied unchanged (Camera::SetDistortions tests d0 only, camera.cc:46). */
+typedef struct sdvl_distortion {
+  double d[5];
+} sdvl_distortion;
+
+/* n images of one camera: src[i] (host pointers, or device pointers if src_on_device) -> dst_dev[i] (device, distinct
+ * from src).  Asynchronous on the context's stream like every other producer of frame data. */
+int sdvl_undistort(sdvl_ctx *ctx, int n, const void *const *src, int src_stride, int src_on_device, int width, int height,
+                   const sdvl_camera *cam, const sdvl_distortion *dist, void *const *dst_dev, int dst_stride);
+/* the fused form main.cc:133-135 needs: raw camera images -> undistorted level 0 of the frames (replaces
+ * sdvl_frame_upload / sdvl_frame_set_image_device for a camera with distortion); follow with sdvl_pyramid_build */
+int sdvl_frames_upload_undistorted(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const void *const *src, int src_stride,
+                                   int src_on_device, const sdvl_camera *cam, const sdvl_distortion *dist);
+
 /* ---- pose from matches: FeatureAlign::SelectInliers + OptimizePose (feature_align.cc:73-82,152-243,258-283,341-431) --
  * One job per frame.  obs[] are the frame's matched features in found order: ax, ay = feature bearing x/z, y/z
  * (feature_align.cc:268), p = 3D point position, inv_cov = 1 / (1 << level).  The reference draws rand() % size once

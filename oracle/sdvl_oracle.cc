@@ -10,6 +10,7 @@
 #include "ref_math.h"
 #include "ref_orb.h"
 #include "ref_tracker.h"
+#include "ref_undistort.h"
 
 using namespace sdvlref;
 
@@ -316,5 +317,17 @@ int sdvl_ref_pose_from_matches(const sdvl_ref_params *p, int w, int h, const dou
   FromSE3(frame->pose, pose7_io);
   return 0;
 }
+
+// Camera::UndistortImage = cv::undistort (camera.cc:100-105): cam4 = fx fy u0 v0, dist5 = d0..d4 (k1 k2 p1 p2 k3)
+int sdvl_ref_undistort(const uint8_t *img, int w, int h, int stride, const double *cam4, const double *dist5, uint8_t *out) {
+  if (dist5[0] == 0.0) {  // Camera::SetDistortions only tests d0 (camera.cc:46): no distortion -> in.clone()
+    for (int y = 0; y < h; y++) std::memcpy(out + static_cast<size_t>(y) * w, img + static_cast<size_t>(y) * stride, w);
+    return 0;
+  }
+  Undistort(img, w, h, stride, cam4, dist5, out);
+  return 1;
+}
+// the 32x32x4 bilinear weight table of cv::remap (shorts, scale 32768)
+void sdvl_ref_remap_weights(int16_t *out4096) { std::memcpy(out4096, BilinearTabI(), sizeof(int16_t) * 4096); }
 
 }  // extern "C"

@@ -71,6 +71,10 @@ void sdvl_ref_se3_inv(const double *A7, double *B7);
 void sdvl_ref_ldlt_solve6(const double *A36, const double *b6, double *x6);
 void sdvl_ref_rand_stream(unsigned seed, int n, int *out);
 
+/* Camera::UndistortImage = cv::undistort(in, out, K, D) (camera.cc:39-67,100-105).  Returns 1 if remapped, 0 if cloned */
+int sdvl_ref_undistort(const uint8_t *img, int w, int h, int stride, const double *cam4, const double *dist5, uint8_t *out);
+void sdvl_ref_remap_weights(int16_t *out4096);
+
 /* FeatureAlign::SelectInliers + OptimizePose (feature_align.cc:73-82,152-243) on a given match list:
  * obs[n][6] = {ax, ay, px, py, pz, level}; the glibc rand stream is seeded with rand_seed and advanced rand_skip draws */
 int sdvl_ref_pose_from_matches(const sdvl_ref_params *p, int w, int h, const double *cam, int n, const double *obs,

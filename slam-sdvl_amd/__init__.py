@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
     "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
     "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
-    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches", "sdvl_pose_from_matches",
+    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_search_points", "sdvl_align_patches", "sdvl_pose_from_matches", "sdvl_undistort", "sdvl_frames_upload_undistorted",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
 ]
 
@@ -159,6 +159,10 @@ class Frame:
             self.ctx.lib.sdvl_frame_destroy(self.ctx.h, self.h)
             self.h = None
 
+
+
+class Distortion(C.Structure):
+    _fields_ = [("d", C.c_double * 5)]
 
 
 class PoseObs(C.Structure):
@@ -381,6 +385,29 @@ class Context:
                             inliers=lists[b:b + res[k].n_inliers].copy(),
                             outliers=lists[b + res[k].n_inliers:b + res[k].n_inliers + res[k].n_outliers].copy()))
         return out
+
+    def undistort(self, imgs, cam, dist, frames=None):
+        """Camera::UndistortImage for a batch of host images (numpy u8 [h, w]).  With `frames` the result becomes their
+        level 0 (fused upload); otherwise it is returned as numpy arrays."""
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in imgs]
+        h, w = imgs[0].shape
+        src = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        d = Distortion((C.c_double * 5)(*[float(x) for x in dist]))
+        if frames is not None:
+            arr = (C.c_void_p * n)(*[f.h for f in frames])
+            self._check(self.lib.sdvl_frames_upload_undistorted(self.h, n, arr, src, w, 0, C.byref(cam), C.byref(d)))
+            return None
+        buf = self.device_malloc(n * w * h)
+        try:
+            dst = (C.c_void_p * n)(*[buf + i * w * h for i in range(n)])
+            self.lib.sdvl_undistort.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int]
+            self._check(self.lib.sdvl_undistort(self.h, n, src, w, 0, w, h, C.byref(cam), C.byref(d), dst, w))
+            out = self.device_download(buf, n * w * h).reshape(n, h, w)
+        finally:
+            self.device_free(buf)
+        return [out[i].copy() for i in range(n)]
 
     # ---- synthetic frames in HBM
     def device_malloc(self, nbytes):

@@ -23,7 +23,11 @@ namespace {
 
 using namespace sdvl;
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 4;  // requests of one workgroup; they all search the SAME current frame (block table)
+
+struct SearchBlock {
+  int first, count;  // requests [first, first + count) of the launch, count <= kWavesPerBlock
+};
 
 struct SearchFrame {
   const uint8_t *level[SDVL_MAX_LEVELS];
@@ -183,16 +187,28 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
 }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
-                                                                            const SearchFramePose *__restrict__ table, int n, Cam cam,
+                                                                            const SearchFramePose *__restrict__ table,
+                                                                            const SearchBlock *__restrict__ blocks, Cam cam,
                                                                             sdvl_search_params prm,
                                                                             sdvl_search_res *__restrict__ out) {
   __shared__ WaveLds s_lds[kWavesPerBlock];
+  // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
+  // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
+  __shared__ uint32_t s_corners[SDVL_MAX_CORNERS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ri = blockIdx.x * kWavesPerBlock + wv;
-  if (ri >= n) return;
+  const SearchBlock blk = blocks[blockIdx.x];
+  const SearchFramePose &tcur = table[reqs[blk.first].cur];
+  const int n_corners = min(tcur.f.n_ptr[0], SDVL_MAX_CORNERS);
+  for (int ci = threadIdx.x; ci < n_corners; ci += 64 * kWavesPerBlock) {
+    const int4 c = reinterpret_cast<const int4 *>(tcur.f.corners)[ci];
+    s_corners[ci] = static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24);
+  }
+  __syncthreads();
+  if (wv >= blk.count) return;
+  const int ri = blk.first + wv;
   WaveLds &L = s_lds[wv];
   const SearchReqDev &rq = reqs[ri];
-  const SearchFramePose &tcur = table[rq.cur], &tref = table[rq.ref];
+  const SearchFramePose &tref = table[rq.ref];
   sdvl_search_res res;
   res.px[0] = rq.px0[0];
   res.px[1] = rq.px0[1];
@@ -310,9 +326,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
       sumA = wave_sum_i32(pv);
       sumAA = wave_sum_i32(pv * pv);
     }
-    const int n_corners = min(cf.n_ptr[0], SDVL_MAX_CORNERS);
     for (int ci = lane; ci < n_corners; ci += 64) {
-      const int cx = cf.corners[4 * ci], cy = cf.corners[4 * ci + 1], cl = cf.corners[4 * ci + 2];
+      const uint32_t pk = s_corners[ci];
+      const int cx = static_cast<int>(pk & 0xFFFu), cy = static_cast<int>((pk >> 12) & 0xFFFu), cl = static_cast<int>(pk >> 24);
       int d = cl - level;
       if (d < 0) d = -d;
       if (d > 1) continue;
@@ -378,7 +394,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
     return;
   }
   res.best_corner = best_ci;
-  const int bx = tcur.f.corners[4 * best_ci], by = tcur.f.corners[4 * best_ci + 1], bl = tcur.f.corners[4 * best_ci + 2];
+  const uint32_t bpk = s_corners[best_ci];
+  const int bx = static_cast<int>(bpk & 0xFFFu), by = static_cast<int>((bpk >> 12) & 0xFFFu), bl = static_cast<int>(bpk >> 24);
   const double mpx = static_cast<double>(bx * (1 << bl)), mpy = static_cast<double>(by * (1 << bl));
   res.px[0] = mpx;
   res.px[1] = mpy;
@@ -491,18 +508,30 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
     memcpy(d.desc, r.desc, 32);
   }
-  const size_t tab_bytes = sizeof(SearchFramePose) * table.size();
+  const size_t tab_bytes = (sizeof(SearchFramePose) * table.size() + 255) / 256 * 256;
+  // workgroups: runs of up to kWavesPerBlock consecutive requests that search the same current frame
+  static thread_local std::vector<SearchBlock> blocks;
+  blocks.clear();
+  for (int i = 0; i < n;) {
+    int cnt = 1;
+    while (i + cnt < n && cnt < kWavesPerBlock && tmp[i + cnt].cur == tmp[i].cur) cnt++;
+    blocks.push_back(SearchBlock{i, cnt});
+    i += cnt;
+  }
+  const size_t blk_bytes = sizeof(SearchBlock) * blocks.size();
   void *hs = nullptr, *dsx = nullptr;
   int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
-  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes + tab_bytes, &hs, &dsx);
+  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes + tab_bytes + blk_bytes, &hs, &dsx);
   if (rc) return rc;
   memcpy(hs, tmp.data(), sizeof(SearchReqDev) * static_cast<size_t>(n));
-  memcpy(static_cast<uint8_t *>(hs) + in_bytes, table.data(), tab_bytes);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(static_cast<uint8_t *>(hs) + in_bytes, table.data(), sizeof(SearchFramePose) * table.size());
+  memcpy(static_cast<uint8_t *>(hs) + in_bytes + tab_bytes, blocks.data(), blk_bytes);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + tab_bytes + blk_bytes, hipMemcpyHostToDevice, ctx->stream));
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock),
-              static_cast<const SearchReqDev *>(dsx), reinterpret_cast<const SearchFramePose *>(static_cast<uint8_t *>(dsx) + in_bytes), n, c, *p,
+  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>(blocks.size())), dim3(64 * kWavesPerBlock),
+              static_cast<const SearchReqDev *>(dsx), reinterpret_cast<const SearchFramePose *>(static_cast<uint8_t *>(dsx) + in_bytes),
+              reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes + tab_bytes), c, *p,
               static_cast<sdvl_search_res *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));

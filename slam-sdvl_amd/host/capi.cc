@@ -104,6 +104,23 @@ static int step(Batch *b, const std::vector<Image> &imgs, sdvlh_frame_stats *out
   }
 }
 
+// Camera::UndistortImage of the host layer (camera.cc:100-105) for one host image; the result comes back to the host
+int sdvlh_camera_undistort(void *device, int w, int h, const double *cam4, const double *dist5, const uint8_t *in, int stride, uint8_t *out) {
+  try {
+    Device *dev = static_cast<Device *>(device);
+    Device::SetCurrent(dev);
+    Camera cam(w, h, cam4[0], cam4[1], cam4[2], cam4[3]);
+    cam.SetDistortions(dist5[0], dist5[1], dist5[2], dist5[3], dist5[4]);
+    Image u;
+    cam.UndistortImage(Image::Wrap(in, w, h, stride), &u);
+    dev->Check(sdvl_device_download(dev->ctx(), u.dev_src, static_cast<int64_t>(w) * h, out), "sdvl_device_download");
+    return cam.HasDistortion() ? 1 : 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // pose stage on the device (default) or with the host implementation; process-wide
 void sdvlh_set_device_pose(int on) { SDVLBatch::SetDevicePose(on != 0); }
 int sdvlh_device_pose() { return SDVLBatch::DevicePose() ? 1 : 0; }

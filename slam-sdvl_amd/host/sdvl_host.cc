@@ -123,9 +123,33 @@ int RandStream::Next() {
 Camera::Camera() {
   const CameraParameters &p = Config::GetCameraParameters();
   width_ = p.width; height_ = p.height; fx_ = p.fx; fy_ = p.fy; u0_ = p.u0; v0_ = p.v0;
+  SetDistortions(p.d1, p.d2, p.d3, p.d4, p.d5);
 }
 Camera::Camera(int width, int height, double fx, double fy, double u0, double v0)
     : width_(width), height_(height), fx_(fx), fy_(fy), u0_(u0), v0_(v0) {}
+
+// camera.cc:39-67
+void Camera::SetDistortions(double d0, double d1, double d2, double d3, double d4) {
+  d_[0] = d0; d_[1] = d1; d_[2] = d2; d_[3] = d3; d_[4] = d4;
+  has_distortion_ = !(d_[0] == 0.0);
+}
+
+// camera.cc:100-105
+void Camera::UndistortImage(const Image &in, Image *out) const {
+  Device *dev = Device::Current();
+  if (!dev) throw std::runtime_error("Camera::UndistortImage: no sdvl::Device bound to this thread");
+  const int w = in.cols, h = in.rows;
+  void *buf = nullptr;
+  dev->Check(sdvl_device_malloc(dev->ctx(), static_cast<int64_t>(w) * h, &buf), "sdvl_device_malloc");
+  sdvl_ctx *ctx = dev->ctx();
+  std::shared_ptr<void> owner(buf, [ctx](void *p) { sdvl_device_free(ctx, p); });
+  const void *src = in.dev_src ? in.dev_src : static_cast<const void *>(in.data);
+  const sdvl_camera cam = abi();
+  const sdvl_distortion dist = distortion();  // d0 == 0 -> plain copy, like in.clone()
+  dev->Check(sdvl_undistort(ctx, 1, &src, in.step, in.dev_src ? 1 : 0, w, h, &cam, &dist, &buf, w), "sdvl_undistort");
+  *out = Image::WrapDevice(buf, w, h, w, false);
+  out->dev_owner = owner;
+}
 
 // camera.cc:69-79
 void Camera::Project(const Vector3d &p3D, Vector2d *p2D) const {
@@ -611,11 +635,15 @@ static sdvl_align_params AlignParams(bool fast) {
 
 // image_align.cc:46-84 for n pairs with one launch
 void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> &pairs, bool fast, vector<int> *n_meas,
-                                  vector<double> *errors, vector<int> *iters) {
+                                  vector<double> *errors, vector<int> *iters, const vector<SE3> *start_poses, vector<SE3> *out_poses) {
   const int n = static_cast<int>(pairs.size());
   n_meas->assign(n, 0);
   errors->assign(n, 1e10);
   if (iters) iters->assign(n, 0);
+  if (out_poses) {
+    out_poses->resize(n);
+    for (int i = 0; i < n; i++) (*out_poses)[i] = start_poses ? (*start_poses)[i] : pairs[i].second->GetPose();
+  }
   vector<sdvl_align_job> jobs;
   vector<int> job_of;
   vector<sdvl_align_feature> feats;
@@ -647,7 +675,7 @@ void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shar
       feats.push_back(a);
     }
     job.feat_end = static_cast<int32_t>(feats.size());
-    const SE3 T = f2.GetPose() * f1.GetPose().Inverse();  // image_align.cc:66
+    const SE3 T = (start_poses ? (*start_poses)[i] : f2.GetPose()) * f1.GetPose().Inverse();  // image_align.cc:66
     T.ToArray(job.T);
     jobs.push_back(job);
     job_of.push_back(i);
@@ -661,7 +689,9 @@ void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shar
                               res.data()), "sdvl_image_align");
   for (size_t j = 0; j < jobs.size(); j++) {
     const int i = job_of[j];
-    pairs[i].second->SetPose(SE3::FromArray(res[j].T) * pairs[i].first->GetPose());  // image_align.cc:79
+    const SE3 pose2 = SE3::FromArray(res[j].T) * pairs[i].first->GetPose();  // image_align.cc:79
+    if (out_poses) (*out_poses)[i] = pose2;
+    else pairs[i].second->SetPose(pose2);
     (*n_meas)[i] = res[j].n_meas;
     (*errors)[i] = res[j].error;
     if (iters) (*iters)[i] = res[j].iters_run;
@@ -1395,15 +1425,25 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       st.state = 2;
       bool relocalize = t.lost_frames_ >= 3;
       if (relocalize) {
-        // sdvl.cc:73-89,205-238: sequential over keyframes with the single-object calls (rare path)
+        // Relocalize, sdvl.cc:73-89,205-238.  The alignment of the current frame against EVERY keyframe (each started
+        // from that keyframe's pose, fast mode) is independent of the others: one launch with |keyframes| jobs.  The
+        // keyframe loop then runs in the reference's order (newest first) over the results; Reproject stays sequential
+        // because it draws from rand() and stops at the first keyframe that gathers MinMatches.
         for (int k = 0; k < 6; k++) t.vel_[k] = 0.0;
         vector<shared_ptr<Frame>> &kfs = t.map_->GetKeyframes();
+        vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> pairs;
+        vector<SE3> start, aligned;
         for (auto it = kfs.rbegin(); it != kfs.rend(); it++) {
-          shared_ptr<Frame> cframe = *it;
-          t.current_frame_->SetPose(cframe->GetPose());
-          ImageAlign image_align;
-          image_align.ComputePose(cframe, t.current_frame_, true);
-          if (image_align.GetError() >= 0.001) continue;
+          pairs.push_back({*it, t.current_frame_});
+          start.push_back((*it)->GetPose());
+        }
+        vector<int> n_meas;
+        vector<double> errors;
+        ImageAlign::ComputePoseBatch(pairs, true, &n_meas, &errors, nullptr, &start, &aligned);
+        for (size_t j = 0; j < pairs.size(); j++) {
+          const shared_ptr<Frame> &cframe = pairs[j].first;
+          t.current_frame_->SetPose(aligned[j]);
+          if (errors[j] >= 0.001) continue;
           t.feature_align_.Reproject(t.current_frame_, cframe, cframe, true);
           t.matches_ = t.feature_align_.GetMatches();
           t.attempts_ = t.feature_align_.GetAttempts();

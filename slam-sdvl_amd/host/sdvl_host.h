@@ -100,9 +100,18 @@ class Camera {
   }
   static Vector2d SimpleProject(const Vector3d &p) { return Vector2d(p(0) / p(2), p(1) / p(2)); }
   sdvl_camera abi() const { return sdvl_camera{width_, height_, fx_, fy_, u0_, v0_}; }
+  // camera.cc:39-67: d0..d4 = Camera.d1..d5 of the config; as in the reference only d0 decides whether there is distortion
+  void SetDistortions(double d0, double d1, double d2, double d3, double d4);
+  bool HasDistortion() const { return has_distortion_; }
+  sdvl_distortion distortion() const { return sdvl_distortion{{d_[0], d_[1], d_[2], d_[3], d_[4]}}; }
+  // camera.cc:100-105: cv::undistort on the device of the calling thread.  `in` may live on the host or in HBM; `out`
+  // is an HBM image that owns its storage (hand it to SDVL::HandleFrame / Frame like any other image).
+  void UndistortImage(const Image &in, Image *out) const;
 
  private:
   double width_, height_, fx_, fy_, u0_, v0_;
+  double d_[5] = {0, 0, 0, 0, 0};
+  bool has_distortion_ = false;
 };
 
 // extra/orb_detector.h:34-56.  Descriptors come from the K4 kernel; Distance is the reference's popcount.
@@ -280,7 +289,10 @@ class ImageAlign {
   double GetError() { return error_; }
   // n frame pairs, one launch; returns per-pair ComputePose results and errors
   static void ComputePoseBatch(const std::vector<std::pair<std::shared_ptr<Frame>, std::shared_ptr<Frame>>> &pairs, bool fast,
-                               std::vector<int> *n_meas, std::vector<double> *errors, std::vector<int> *iters = nullptr);
+                               std::vector<int> *n_meas, std::vector<double> *errors, std::vector<int> *iters = nullptr,
+                               const std::vector<SE3> *start_poses = nullptr, std::vector<SE3> *out_poses = nullptr);
+  // start_poses[i]: pose of pairs[i].second to start from (default: its current pose); out_poses: where the aligned
+  // poses go instead of into the frames — together they let ONE frame be aligned against many references at once
 
  private:
   double error_ = 1e10;

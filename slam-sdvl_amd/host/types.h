@@ -63,6 +63,7 @@ struct Image {
   }
   // an image that already lives in HBM (device pointer), e.g. a decoded camera frame
   const void *dev_src = nullptr;
+  std::shared_ptr<void> dev_owner;  // keeps an HBM image produced by this layer alive (Camera::UndistortImage)
   bool borrow = false;  // the HBM image outlives every Frame built from it: alias it instead of copying
   static Image WrapDevice(const void *dev_ptr, int w, int h, int stride, bool borrow_storage = false) {
     Image r;

@@ -62,6 +62,8 @@ def ptr(a, t):
     return a.ctypes.data_as(t)
 
 
+TUM_DIST = np.array([0.2624, -0.9531, -0.0054, 0.0026, 1.1633])   # config/config_tum_f1.cfg:15-19
+EUROC_DIST = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0])  # config/config_euroc.cfg:15-19
 TUM_CAM = np.array([517.3, 516.5, 318.6, 255.3])          # config/config_tum_f1.cfg:11-14
 EUROC_CAM = np.array([458.654, 457.296, 367.215, 248.375])  # config/config_euroc.cfg
 XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])  # SURVEY §8d trajectory twist per frame
@@ -174,6 +176,19 @@ class Oracle:
                                             int(rand_skip), ptr(pose, f64p), C.byref(nd), C.byref(ni), ptr(ii, i32p),
                                             C.byref(no), ptr(oi, i32p))
         return dict(pose=pose, n_draws=nd.value, inliers=ii[:ni.value].copy(), outliers=oi[:no.value].copy())
+
+    def undistort(self, img, cam, dist):
+        """Camera::UndistortImage = cv::undistort; cam = fx fy u0 v0, dist = d0..d4"""
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        cam = np.ascontiguousarray(cam, np.float64); dist = np.ascontiguousarray(dist, np.float64)
+        out = np.zeros((h, w), np.uint8)
+        self.lib.sdvl_ref_undistort(ptr(img, u8p), w, h, w, ptr(cam, f64p), ptr(dist, f64p), ptr(out, u8p))
+        return out
+
+    def remap_weights(self):
+        out = np.zeros(4096, np.int16)
+        self.lib.sdvl_ref_remap_weights(out.ctypes.data_as(C.POINTER(C.c_int16)))
+        return out.reshape(32, 32, 4)
 
     # --- alignment
     def image_align(self, img1, img2, cam, px, bearing, depth, valid, T, fast=False):

@@ -441,3 +441,56 @@ def test_pose_from_matches_degenerate_inputs(ctx, orc):
     big, _ = make_matches(orc, 257, seed=9)
     with pytest.raises(RuntimeError, match="too many matches"):
         ctx.pose_from_matches([(big, guess, draws)], fx=cam[0])
+
+
+# ------------------------------------------------------------------------------------------------ K0 (input stage)
+@pytest.mark.parametrize("shape,cam,dist", [((480, 640), "tum", "tum"), ((480, 752), "euroc", "euroc"), ((66, 130), "tum", "strong")])
+def test_undistort_bit_exact(ctx, sdvl, orc, synth, shape, cam, dist):
+    """Camera::UndistortImage = cv::undistort (camera.cc:100-105): the remap kernel reproduces the oracle byte for byte —
+    stripe-wise principal point, accumulated column coordinates, fixed-point map and weights, constant border"""
+    from oraclelib import TUM_DIST, EUROC_DIST
+    h, w = shape
+    cam4 = TUM_CAM if cam == "tum" else EUROC_CAM
+    if shape == (66, 130):
+        cam4 = np.array([110.0, 108.0, 63.7, 31.2])
+    d = {"tum": TUM_DIST, "euroc": EUROC_DIST, "strong": np.array([-0.45, 0.3, 0.01, -0.008, 0.05])}[dist]
+    imgs = [rand_img(77, h, w)]
+    if shape == (480, 640):
+        imgs.append(frames_of(synth, orc, TUM_CAM, 640, 480, [2])[0])
+    c = sdvl.Camera(w, h, *cam4)
+    got = ctx.undistort(imgs, c, d)
+    for g, im in zip(got, imgs):
+        want = orc.undistort(im, cam4, d)
+        assert np.array_equal(g, want), int((g != want).sum())
+        assert (want != im).mean() > 0.5          # the distortion really moves pixels
+    # fused form: raw image -> undistorted level 0 -> pyramid
+    levels = 5 if min(shape) >= 256 else 3
+    fr = [ctx.frame(width=w, height=h, levels=levels, pyramid=False) for _ in imgs]
+    ctx.undistort(imgs, c, d, frames=fr)
+    ctx.pyramid_build(fr)
+    for f, im in zip(fr, imgs):
+        want = orc.pyramid(orc.undistort(im, cam4, d), levels)
+        for l in range(levels):
+            assert np.array_equal(f.level(l), want[l]), l
+        f.close()
+    # d0 == 0: the reference clones the image (camera.cc:46)
+    same = ctx.undistort(imgs[:1], c, [0.0, 0.4, 0.0, 0.0, 0.0])[0]
+    assert np.array_equal(same, imgs[0])
+
+
+def test_host_layer_camera_undistort(orc):
+    """sdvl::Camera::SetDistortions / UndistortImage of the host layer (camera.cc:39-67,100-105)"""
+    import ctypes as C
+    import importlib
+    from oraclelib import TUM_DIST
+    importlib.import_module("slam-sdvl_amd")
+    trk = importlib.import_module("slam-sdvl_amd.tracker")
+    dev = trk.HostDevice(0)
+    img = rand_img(5, 480, 640)
+    out = np.zeros_like(img)
+    cam = np.ascontiguousarray(TUM_CAM, np.float64); dist = np.ascontiguousarray(TUM_DIST, np.float64)
+    f = dev.lib.sdvlh_camera_undistort
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    assert f(dev.h, 640, 480, cam.ctypes.data, dist.ctypes.data, img.ctypes.data, 640, out.ctypes.data) == 1
+    assert np.array_equal(out, orc.undistort(img, TUM_CAM, TUM_DIST))
+    dev.close()

@@ -252,3 +252,40 @@ def test_pose_from_matches_recovers_motion_and_rejects_outliers(orc):
     assert 1 <= r["n_draws"] < 100
     empty = orc.pose_from_matches(TUM_CAM, np.zeros((0, 6)), true_pose)
     assert empty["n_draws"] == 0 and len(empty["inliers"]) == 0 and np.array_equal(empty["pose"], true_pose)
+
+
+def test_undistort_against_float_remap(orc):
+    """cv::undistort restatement (camera.cc:100-105) vs an independent float pipeline: the radial-tangential model in
+    numpy + scipy's bilinear map_coordinates.  The fixed-point remap (1/32 px coordinates, 15-bit weights) may differ
+    from the float result by the coordinate quantisation only: a few grey levels at most on a smooth image, and the
+    weight table must be the exact bilinear products."""
+    import scipy.ndimage as ndi
+    from oraclelib import TUM_CAM, TUM_DIST, EUROC_CAM, EUROC_DIST
+    wt = orc.remap_weights().astype(np.int64)
+    a = np.arange(32)
+    for iy in (0, 1, 7, 31):
+        for ix in (0, 5, 16, 31):
+            want = np.array([(32 - iy) * (32 - ix), (32 - iy) * ix, iy * (32 - ix), iy * ix]) * 32
+            if iy == 0 and ix == 0:
+                want = np.array([32767, 0, 0, 1])     # saturate_cast<short>(32768) and the table's sum repair
+            assert wt[iy, ix].tolist() == want.tolist(), (iy, ix)
+    assert (wt.sum(axis=2) == 32768).all()
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float64)
+    smooth = (127 + 80 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + 30 * np.sin((xx + yy) / 41.0)).astype(np.uint8)
+    for (w, h, cam, dist) in ((640, 480, TUM_CAM, TUM_DIST), (752, 480, EUROC_CAM, EUROC_DIST)):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        img = (127 + 80 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + 30 * np.sin((xx + yy) / 41.0)).astype(np.uint8)
+        got = orc.undistort(img, cam, dist).astype(np.int32)
+        x = (xx - cam[2]) / cam[0]; y = (yy - cam[3]) / cam[1]
+        r2 = x * x + y * y
+        kr = 1 + ((dist[4] * r2 + dist[1]) * r2 + dist[0]) * r2
+        u = cam[0] * (x * kr + dist[2] * 2 * x * y + dist[3] * (r2 + 2 * x * x)) + cam[2]
+        v = cam[1] * (y * kr + dist[2] * (r2 + 2 * y * y) + dist[3] * 2 * x * y) + cam[3]
+        ref = ndi.map_coordinates(img.astype(np.float64), [v, u], order=1, mode="constant", cval=0.0)
+        inside = (u >= 1) & (u < w - 2) & (v >= 1) & (v < h - 2)
+        diff = np.abs(got - ref)[inside]
+        assert diff.max() <= 3.0 and diff.mean() < 0.6, (diff.max(), diff.mean())
+        outside = (u < -1) | (u > w) | (v < -1) | (v > h)
+        assert (got[outside] == 0).all()                       # BORDER_CONSTANT
+    # d0 == 0 -> the reference does not remap at all (camera.cc:46)
+    assert np.array_equal(orc.undistort(smooth, TUM_CAM, [0, 0.3, 0, 0, 0]), smooth)

@@ -58,6 +58,54 @@ for _ in range(reps):
     ctx._check(lib.sdvl_orb_describe(ctx.h, n, arr0, 4096, None))
     res = ctx.image_align(jobs, feats, cam, ap)
     its += sum(r.iters_run for r in res)
+# input stage: cv::undistort of n raw frames already in HBM (TUM fr1 coefficients) into the frames' level 0
+import ctypes as _C
+dist = sdvl.Distortion((_C.c_double * 5)(0.2624, -0.9531, -0.0054, 0.0026, 1.1633))
+raw = (C.c_void_p * n)(*[buf + i * W * H for i in range(n)])
+und = [sdvl.Frame(ctx, W, H) for _ in range(n)]
+arru = (C.c_void_p * n)(*[f.h for f in und])
+for _ in range(reps):
+    ctx._check(lib.sdvl_frames_upload_undistorted(ctx.h, n, arru, raw, W, 1, C.byref(cam), C.byref(dist)))
+# SearchPoint: per pair (frame 0 -> frame 3) nf fixed points on corners of frame 0, depth from the plane z = 2
+c0s = ctx.detect_corners(fr0, dp, 1000)
+d0s = ctx.orb_describe(fr0)
+sreqs = (sdvl.SearchReq * (nf * n))()
+nreq = 0
+for j in range(n):
+    T0 = B.se3_exp(shard.sequence_twist(j) * 0)
+    T3 = B.se3_exp(shard.sequence_twist(j) * 3)
+    R0, t0 = B.quat_to_R(T0[:4]), T0[4:]
+    R3, t3 = B.quat_to_R(T3[:4]), T3[4:]
+    Rw, tw = R0.T, -R0.T @ t0
+    cs = c0s[j]
+    sel = rng.choice(len(cs), size=min(nf, len(cs)), replace=False)
+    for ci in sel:
+        x, y, l = [int(q) for q in cs[ci]]
+        px = np.array([x * (1 << l), y * (1 << l)], np.float64)
+        ray = np.array([(px[0] - B.TUM_CAM[2]) / B.TUM_CAM[0], (px[1] - B.TUM_CAM[3]) / B.TUM_CAM[1], 1.0])
+        bearing = ray / np.linalg.norm(ray)
+        rw = Rw @ bearing
+        sdepth = (2.0 - tw[2]) / rw[2]
+        pc = R3 @ (Rw @ (bearing * sdepth) + tw) + t3
+        r = sreqs[nreq]; nreq += 1
+        r.cur, r.ref = fr3[j].h.value, fr0[j].h.value
+        for k in range(7):
+            r.cur_pose[k], r.ref_pose[k] = float(T3[k]), float(T0[k])
+        r.px[0], r.px[1] = px
+        r.bearing[0], r.bearing[1], r.bearing[2] = bearing
+        r.idepth, r.idepth_std = 1.0 / sdepth, 0.05 / sdepth
+        r.px0[0] = B.TUM_CAM[2] + B.TUM_CAM[0] * pc[0] / pc[2] + rng.normal() * 0.7
+        r.px0[1] = B.TUM_CAM[3] + B.TUM_CAM[1] * pc[1] / pc[2] + rng.normal() * 0.7
+        r.level, r.fixed = l, 1
+        for k in range(32):
+            r.desc[k] = int(d0s[j][ci, k])
+sreqs = (sdvl.SearchReq * nreq).from_buffer(sreqs)
+sp = sdvl.default_search_params()
+for _ in range(max(1, reps // 3)):
+    sres = ctx.search_points(sreqs, cam, sp)
+n_found = sum(r.found for r in sres)
+lk = sum(r.lk_its for r in sres) / max(1, n_found)
+print("search: requests=%d found=%d lk_its/found=%.2f" % (nreq, n_found, lk))
 # pose stage: n jobs of 190 matches (20 % gross outliers) of a small camera motion; rand() draws from numpy (timing only)
 prng = np.random.default_rng(7)
 pose_jobs = []
@@ -85,7 +133,8 @@ nc = float(counts.mean())
 i_ia = its / (reps * n)
 P = [(W >> l) * (H >> l) for l in range(5)]
 alg = {"pyr_down": (sum(P[:4]) + sum(P[1:])) / 4.0, "fast_cells": sum(P[:3]) + 16 * nc, "select_corners": 4 * 10000 + 16 * nc, "pack_corners": 32 * nc,
-       "orb_describe": 993 * nc, "image_align": 147 * nf + 25 * nf * i_ia, "pose_hypotheses": 48 * nf + 6400,
+       "orb_describe": 993 * nc, "image_align": 147 * nf + 25 * nf * i_ia, "pose_hypotheses": 48 * nf + 6400, "undistort": 2 * W * H,
+       "search_points": 12 * nc + nf * (121 + 164 + lk * 81),
        "pose_refine": 52 * nf + 6480}
 print("n_frames=%d reps=%d corners/frame=%.0f GN evaluations/job=%.1f" % (n, reps, nc, i_ia))
 for k, (ms, launches) in sorted(t.items()):
