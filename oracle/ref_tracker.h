@@ -8,16 +8,31 @@
 //   Point (read side + Promote/Unpromote): /root/reference/point.cc:105-142
 //   FeatureAlign: /root/reference/feature_align.cc:33-433
 //   SDVL:         /root/reference/sdvl.cc:55-130,179-281 ; Map::NeedKeyframe map.cc:170-188
-// The mapper / initialiser (map.cc, homography_init.cc — out of scope) is replaced by a
-// "plane map stub": keyframes seed fixed points on their FilterCorners() corners with depth taken from
-// a known scene plane.  rand() is the glibc TYPE_3 generator with seed 1, one private stream per tracker.
+// The initialiser (homography_init.cc — out of scope) is replaced by a "plane bootstrap": the first
+// keyframe seeds fixed points on its FilterCorners() corners with depth taken from a known scene plane.  After that
+// two map modes exist:
+//   * plane map stub (default): every later keyframe is seeded the same way (no mapper at all);
+//   * use_mapper: the reference's mapper in SEQUENTIAL mode (main.cc:148-149 -> SDVL::Mapping -> Map::UpdateMap after
+//     every frame): Map::UpdateMap / AddKeyframe / AddFrame / EmptyTrash / LimitKeyframes (map.cc:75-259),
+//     InitCandidates (:262-400), UpdateCandidates (:402-498), CheckConnections (:500-558), AddConnectionsPoints
+//     (:560-617), CheckRedundantKeyframes (:619-690), the depth filter Point::InitCandidate / Update / HasConverged /
+//     ComputeTau / PDFNormal (point.cc:49-100,164-217), GetDepthFromTriangulation / GetParallax (extra/utils.cc:193-213),
+//     Frame::GetSceneDepth / GetBestConnections / IsPointVisible (frame.cc:70-113,185-215).  Bundle adjustment
+//     (Map::BundleAdjustment -> extra/bundle.cc) is out of scope and not run.  Two containers of the reference iterate in
+//     pointer-address order (std::map<shared_ptr<Frame>,int> in CheckConnections, std::set<shared_ptr<Point>> in
+//     AddConnectionsPoints): frozen here to creation order (frame id / point id), which is what increasing heap
+//     addresses give the reference in the common case.
+// rand() is the glibc TYPE_3 generator with seed 1, one private stream per tracker.
 #ifndef SDVL_ORACLE_REF_TRACKER_H_
 #define SDVL_ORACLE_REF_TRACKER_H_
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <deque>
+#include <map>
 #include <memory>
+#include <set>
 #include <vector>
 
 #include "ref_align.h"
@@ -91,8 +106,14 @@ struct RFrame {
   std::vector<std::vector<uint8_t>> descriptors;
   std::vector<int> filtered;
   std::vector<std::shared_ptr<RFeature>> features;
+  // mapper state (frame.h:149-171)
+  int kf_id = 0;
+  bool del = false, selected = false;
+  std::vector<std::pair<RFrame *, int>> connections;
 
   Vec3 WorldPosition() const { return pose.Inverse().t; }
+  double DistanceTo(const RFrame &o) const { return Norm(WorldPosition() - o.WorldPosition()); }  // frame.h:129-131
+  double DistanceTo(const Vec3 &p) const { return Norm(WorldPosition() - p); }                     // frame.h:134-136
   int NumPoints() const {
     int c = 0;
     for (auto &f : features) if (f && f->point) c++;
@@ -107,6 +128,7 @@ struct RPoint {
   int last_frame = -1;
   int n_successful = 0, n_failed = 0;
   double rho = 1.0, sigma2 = 1.0;
+  double a = 10, b = 10, z_range = 6.0, cos_alpha = 1.0, last_distance = 1.0;  // depth filter, point.cc:49-62
   bool fixed = false;
   Vec3 p3d{0, 0, 0};
   std::shared_ptr<RFeature> init_feature;
@@ -154,6 +176,16 @@ struct Tracker {
   std::vector<std::shared_ptr<RFrame>> keyframes;
   std::vector<std::shared_ptr<RPoint>> points_trash;
   int last_matches = 0;  // Map::last_matches_
+  // ---- mapper (map.h:44-139), sequential mode
+  bool use_mapper = false;
+  int max_search_keyframes = 5, max_keyframes = 100;  // config.cc:60,63
+  double map_scale = 1.0, scale_min_dist = 0.25;       // config.cc:70,75
+  std::vector<std::shared_ptr<RPoint>> candidates;
+  std::deque<std::shared_ptr<RFrame>> frame_queue, keyframe_queue;
+  std::vector<std::shared_ptr<RFrame>> frame_trash, keepalive;
+  int num_kfs = 0, initial_kf_id = 0, last_kf_checked = -1, n_initializations = 0;
+  bool map_relocalizing = false;
+  struct MapStats { int candidates = 0, converged = 0, initialized = 0, linked = 0, connected = 0, keyframes = 0; } map_stats;
   // FeatureAlign state
   int grid_width, grid_height;
   std::vector<std::vector<std::pair<std::shared_ptr<RPoint>, Vec2>>> grid;
@@ -258,8 +290,12 @@ struct Tracker {
     if (!running) {
       current->pose = init_pose;
       current->is_keyframe = true;
-      keyframes.push_back(current);
-      map_last_kf = current;
+      if (use_mapper) {
+        MapAddKeyframe(current, false);  // the bootstrap keyframe plays the role of SaveSecondFrame's (sdvl.cc:165)
+      } else {
+        keyframes.push_back(current);
+        map_last_kf = current;
+      }
       SeedPoints(current);
       last_frame = current;
       last_kf = current;
@@ -271,8 +307,10 @@ struct Tracker {
       st.state = 2;
       bool relocalize = lost_frames >= 3;
       if (relocalize) {
+        map_relocalizing = true;  // sdvl.cc:80
         for (int i = 0; i < 6; i++) vel[i] = 0.0;
         if (Relocalize(&last_kf)) {
+          map_relocalizing = false;
           last_frame = last_kf;
           relocalize = false;
           st.relocalized = 1;
@@ -295,11 +333,19 @@ struct Tracker {
             for (auto &ft : current->features)
               if (ft->point) ft->point->features.insert(ft->point->features.begin(), ft);
             current->is_keyframe = true;
-            keyframes.push_back(current);
-            map_last_kf = current;
-            last_kf = current;
-            SeedPoints(current);  // sequential-mode mapper work, outside the reference's timing window
+            if (use_mapper) {
+              MapAddKeyframe(current, true);
+              last_kf = current;
+              MapLimitKeyframes(current);
+            } else {
+              keyframes.push_back(current);
+              map_last_kf = current;
+              last_kf = current;
+              SeedPoints(current);  // plane map stub instead of the mapper, outside the reference's timing window
+            }
             st.keyframe = 1;
+          } else if (use_mapper) {
+            frame_queue.push_back(current);  // Map::AddFrame, map.cc:160-163
           }
           last_frame = current;
         }
@@ -333,12 +379,504 @@ struct Tracker {
 
   // Map::EmptyTrash (points part), map.cc:207-259
   void EmptyTrash() {
+    EmptyFrameTrash();
     for (auto &p : points_trash) {
       for (auto &f : p->features) f->point = nullptr;
       p->features.clear();
       p->del = true;
     }
     points_trash.clear();
+  }
+
+
+  // ================================================================================================ mapper (map.cc)
+  // Map::AddKeyframe, map.cc:143-158
+  void MapAddKeyframe(const std::shared_ptr<RFrame> &frame, bool search) {
+    if (search) keyframe_queue.push_back(frame);
+    else initial_kf_id = std::max(initial_kf_id, frame->id);
+    num_kfs++;
+    frame->kf_id = num_kfs;
+    keyframes.push_back(frame);
+    keepalive.push_back(frame);
+    map_last_kf = frame;
+  }
+
+  // Map::LimitKeyframes + GetFurthestKeyframe, map.cc:190-205,692-706
+  void MapLimitKeyframes(const std::shared_ptr<RFrame> &frame) {
+    if (static_cast<int>(keyframes.size()) < max_keyframes) return;
+    const Vec3 pos = frame->WorldPosition();
+    std::shared_ptr<RFrame> kf;
+    double maxdist = 0.0;
+    for (auto &k : keyframes) {
+      const double dist = Norm(k->WorldPosition() - pos);
+      if (dist > maxdist) { maxdist = dist; kf = k; }
+    }
+    if (!kf) return;
+    kf->del = true;
+    frame_trash.push_back(kf);
+  }
+
+  // Map::EmptyTrash (frames part), map.cc:207-246
+  void EmptyFrameTrash() {
+    for (auto &f : frame_trash) {
+      if (f->is_keyframe)
+        for (auto it = keyframes.begin(); it != keyframes.end(); it++)
+          if (*it == f) { keyframes.erase(it); break; }
+      f->features.clear();  // RemoveFeatures
+      f->del = true;
+    }
+    frame_trash.clear();
+  }
+
+  // Map::UpdateMap, map.cc:75-141 (bundle adjustment not run)
+  void UpdateMap() {
+    if (map_relocalizing) return;
+    if (frame_queue.empty() && keyframe_queue.empty()) return;
+    std::shared_ptr<RFrame> frame;
+    if (!keyframe_queue.empty()) {
+      while (!frame_queue.empty()) {
+        frame_trash.push_back(frame_queue.front());
+        frame_queue.pop_front();
+      }
+      frame = keyframe_queue.front();
+      keyframe_queue.pop_front();
+    } else {
+      frame = frame_queue.front();
+      frame_queue.pop_front();
+    }
+    UpdateCandidates(frame);
+    if (frame->is_keyframe) {
+      CheckConnections(frame);
+      AddConnectionsPoints(frame);
+      InitCandidates(frame);
+    } else {
+      CheckRedundantKeyframes();
+      frame_trash.push_back(frame);
+    }
+    map_stats.candidates = static_cast<int>(candidates.size());
+    map_stats.keyframes = static_cast<int>(keyframes.size());
+  }
+
+  Vec3 RelativePos(const RFrame &f, const Vec3 &p) const { return f.pose * p; }
+
+  // Frame::GetSceneDepth, frame.cc:70-92
+  double SceneDepth(const RFrame &f) const {
+    std::vector<double> depth_vec;
+    for (auto &ft : f.features) {
+      if (!ft) continue;
+      if (!ft->point) continue;
+      depth_vec.push_back(RelativePos(f, ft->point->GetPosition()).z);
+    }
+    if (depth_vec.empty()) return 0.0;
+    auto mid = depth_vec.begin() + static_cast<long>(std::floor(depth_vec.size() / 2));
+    std::nth_element(depth_vec.begin(), mid, depth_vec.end());
+    return *mid;
+  }
+
+  // Frame::IsPointVisible, frame.cc:105-113
+  bool IsPointVisible(const RFrame &f, const Vec3 &p) const {
+    const Vec3 rel = RelativePos(f, p);
+    if (rel.z < 0.0) return false;
+    const Vec2 ip = cam.Project(rel);
+    return cam.IsInsideImage(static_cast<int>(ip.x), static_cast<int>(ip.y), 0);
+  }
+
+  // Frame::GetBestConnections, frame.cc:185-207 (std::sort on the frame's own connection list, as there)
+  void BestConnections(RFrame *f, std::vector<RFrame *> *out, int n) {
+    out->clear();
+    if (n == 0 || n >= static_cast<int>(f->connections.size())) {
+      for (auto &c : f->connections)
+        if (!c.first->del) out->push_back(c.first);
+    } else {
+      std::sort(f->connections.begin(), f->connections.end(),
+                [](const std::pair<RFrame *, int> &l, const std::pair<RFrame *, int> &r) { return l.second > r.second; });
+      int count = 0;
+      for (auto it = f->connections.begin(); it != f->connections.end() && count < n; it++)
+        if (!it->first->del) { out->push_back(it->first); count++; }
+    }
+  }
+
+  // extra/utils.cc:193-205
+  static bool DepthFromTriangulation(const SE3 &pose, const Vec3 &v_ref, const Vec3 &v_cur, double *depth) {
+    const Vec3 a0 = MatVec(pose.Rotation(), v_ref), a1 = v_cur;
+    const double m00 = Dot(a0, a0), m01 = Dot(a0, a1), m11 = Dot(a1, a1);
+    const double det = m00 * m11 - m01 * m01;  // Matrix2d::determinant
+    if (det < 0.000001) return false;
+    // Matrix2d::inverse = adjugate / det; depth2 = -AtA^-1 * (A^T t), evaluated left to right as Eigen does:
+    // (-(AtA^-1)) * A^T is a 2x3 product, then times t
+    const double invdet = 1.0 / det;
+    const double i00 = m11 * invdet, i01 = -m01 * invdet, i10 = -m01 * invdet, i11 = m00 * invdet;
+    const double n00 = -i00, n01 = -i01, n10 = -i10, n11 = -i11;
+    (void)n10; (void)n11;
+    // row 0 of (-(AtA^-1)) * A^T
+    const double r0x = n00 * a0.x + n01 * a1.x, r0y = n00 * a0.y + n01 * a1.y, r0z = n00 * a0.z + n01 * a1.z;
+    const double d0 = r0x * pose.t.x + r0y * pose.t.y + r0z * pose.t.z;
+    *depth = std::fabs(d0);
+    return true;
+  }
+
+  // extra/utils.cc:207-213
+  static double Parallax(const Vec3 &src1, const Vec3 &src2, const Vec3 &p3d) {
+    Vec3 v1 = src1 - p3d, v2 = src2 - p3d;
+    const double n1 = Norm(v1), n2 = Norm(v2);
+    v1 = {v1.x / n1, v1.y / n1, v1.z / n1};  // Eigen normalize(): divide by the norm
+    v2 = {v2.x / n2, v2.y / n2, v2.z / n2};
+    return Dot(v1, v2);
+  }
+
+  // point.cc:49-62
+  static void InitCandidatePoint(RPoint *pt, const std::shared_ptr<RFeature> &f, double depth) {
+    pt->init_feature = f;
+    pt->a = 10;
+    pt->b = 10;
+    pt->rho = 1.0 / depth;
+    pt->sigma2 = 1.0;
+    pt->z_range = std::sqrt(pt->sigma2 * 36);
+    pt->cos_alpha = 1.0;
+    pt->last_distance = 1.0 / pt->rho;
+  }
+
+  // point.cc:189-201
+  static double ComputeTau(const SE3 &pose, const Vec3 &v, double depth, double px_error_angle) {
+    const double PI = 3.14159265;
+    const Vec3 t = pose.t;
+    const Vec3 a = v * depth - t;
+    const double t_norm = Norm(t), a_norm = Norm(a);
+    const double alpha = std::acos(Dot(v, t) / t_norm);
+    const Vec3 mt = {-t.x, -t.y, -t.z};
+    const double beta = std::acos(Dot(a, mt) / (t_norm * a_norm));
+    const double beta_plus = beta + px_error_angle;
+    const double gamma_plus = PI - alpha - beta_plus;
+    const double depth_plus = t_norm * std::sin(beta_plus) / std::sin(gamma_plus);
+    return depth_plus - depth;
+  }
+
+  // point.cc:203-217
+  static double PDFNormal(double mean, double sd, double x) {
+    const double PI = 3.14159265;
+    double result = 0.0;
+    if (sd <= 0) return result;
+    double exponent = x - mean;
+    exponent *= -exponent;
+    exponent /= 2 * sd * sd;
+    result = std::exp(exponent);
+    result /= sd * std::sqrt(2.0 * PI);
+    return result;
+  }
+
+  // Point::Update, point.cc:64-100
+  void PointUpdate(RPoint *pt, const RFrame &frame, double depth, double px_error_angle) {
+    const RFrame &f0 = *pt->init_feature->frame;
+    const SE3 pose = f0.pose * frame.pose.Inverse();
+    const double tau = ComputeTau(pose, pt->init_feature->v, depth, px_error_angle);
+    const double tau_inverse = 0.5 * (1.0 / std::max(0.0000001, depth - tau) - 1.0 / (depth + tau));
+    const double tau2 = tau_inverse * tau_inverse;
+    const double x = 1. / depth;
+    const double norm_scale = std::sqrt(pt->sigma2 + tau2);
+    if (std::isnan(norm_scale)) return;
+    const double s2 = 1. / (1. / pt->sigma2 + 1. / tau2);
+    const double m = s2 * (pt->rho / pt->sigma2 + x / tau2);
+    double C1 = pt->a / (pt->a + pt->b) * PDFNormal(pt->rho, norm_scale, x);
+    double C2 = pt->b / (pt->a + pt->b) * 1. / pt->z_range;
+    const double normalization_constant = C1 + C2;
+    C1 /= normalization_constant;
+    C2 /= normalization_constant;
+    const double f = C1 * (pt->a + 1.) / (pt->a + pt->b + 1.) + C2 * pt->a / (pt->a + pt->b + 1.);
+    // the reference mixes float literals in (1.0f, 2.0f): they promote to double exactly
+    const double e = C1 * (pt->a + 1.) * (pt->a + 2.) / ((pt->a + pt->b + 1.) * (pt->a + pt->b + 2.)) +
+                     C2 * pt->a * (pt->a + 1.0) / ((pt->a + pt->b + 1.0) * (pt->a + pt->b + 2.0));
+    const double rho_new = C1 * m + C2 * pt->rho;
+    pt->sigma2 = C1 * (s2 + m * m) + C2 * (pt->sigma2 + pt->rho * pt->rho) - rho_new * rho_new;
+    pt->rho = rho_new;
+    pt->a = (e - f) / (f - e / f);
+    pt->b = pt->a * (1.0 - f) / f;
+    const Vec3 pos = pt->GetPosition();
+    pt->cos_alpha = Parallax(f0.WorldPosition(), frame.WorldPosition(), pos);
+    pt->last_distance = frame.DistanceTo(pos);
+    pt->n_failed = 0;
+  }
+
+  // Point::HasConverged, point.cc:164-178
+  static bool PointHasConverged(RPoint *pt) {
+    if (pt->fixed) return true;
+    const double std_d = std::sqrt(pt->sigma2) / (pt->rho * pt->rho);
+    const double l = 4 * std_d * pt->cos_alpha / pt->last_distance;
+    if (l < 0.1) {
+      pt->p3d = pt->GetPosition();
+      pt->fixed = true;
+      return true;
+    }
+    return false;
+  }
+
+  // Point::Unpromote for the mapper's callers, point.cc:111-118
+  bool PointUnpromote(RPoint *pt) {
+    pt->n_failed++;
+    pt->b++;
+    return pt->n_failed > prm.max_failed;
+  }
+
+  SearchRef RefOf(const RFeature &feature) const {
+    SearchRef ref;
+    ref.ref_pyr = &feature.frame->pyr;
+    ref.ref_pose = feature.frame->pose;
+    ref.px = feature.p.x; ref.py = feature.p.y; ref.f = feature.v; ref.level = feature.level;
+    std::memcpy(ref.desc, feature.desc, 32);
+    return ref;
+  }
+
+  // Map::UpdateCandidates, map.cc:402-498
+  void UpdateCandidates(const std::shared_ptr<RFrame> &frame) {
+    Matcher matcher(prm.patch_size, prm, cam);
+    const double px_error_angle = std::atan(1.0 / (2.0 * cam.fx)) * 2.0;  // Camera::GetPixelErrorAngle, camera.h:104-107
+    const double depth_mean = SceneDepth(*frame);
+    const int min_kf_id = map_last_kf->kf_id - 2 * max_search_keyframes;
+    SearchCur cur{&frame->pyr, frame->pose, &frame->corners, &frame->descriptors};
+    auto it = candidates.begin();
+    while (it != candidates.end()) {
+      std::shared_ptr<RPoint> point = *it;
+      if (point->del) {
+        points_trash.push_back(point);
+        it = candidates.erase(it);
+        continue;
+      }
+      const Vec3 pos = point->GetPosition();
+      if (!IsPointVisible(*frame, pos)) {
+        if (point->features.front()->frame->kf_id < min_kf_id) {  // GetLastFeature()
+          points_trash.push_back(point);
+          it = candidates.erase(it);
+        } else {
+          it++;
+        }
+        continue;
+      }
+      std::shared_ptr<RFeature> feature = point->init_feature;
+      const double distance = frame->DistanceTo(*feature->frame);
+      if (distance / depth_mean < 0.01) { it++; continue; }
+      Vec2 imgpos{0, 0};
+      int level = 0;
+      cur.pose = frame->pose;
+      if (!matcher.SearchPoint(&cur, RefOf(*feature), point->rho, point->GetStd(), false, &imgpos, &level)) {
+        if (PointUnpromote(point.get())) points_trash.push_back(point);
+        it++;
+        continue;
+      }
+      const SE3 pose = frame->pose * feature->frame->pose.Inverse();
+      const Vec3 v3d = cam.Unproject(imgpos);
+      double depth = 0.0;
+      if (!DepthFromTriangulation(pose, feature->v, v3d, &depth)) { it++; continue; }
+      const Vec3 p3d = feature->frame->pose.Inverse() * (depth * feature->v);
+      const double cos_alpha = Parallax(feature->frame->WorldPosition(), frame->WorldPosition(), p3d);
+      if (cos_alpha >= 0.999999) { it++; continue; }
+      if (depth < map_scale * scale_min_dist || depth < depth_mean * scale_min_dist) { it++; continue; }
+      PointUpdate(point.get(), *frame, depth, px_error_angle);
+      if (PointHasConverged(point.get())) {
+        it = candidates.erase(it);
+        map_stats.converged++;
+      } else {
+        it++;
+      }
+    }
+  }
+
+  // Map::CheckConnections, map.cc:500-558 (std::map keyed by frame pointer there: frozen to frame id order)
+  void CheckConnections(const std::shared_ptr<RFrame> &frame) {
+    std::map<int, std::pair<RFrame *, int>> kfs;
+    for (auto &ft : frame->features) {
+      std::shared_ptr<RPoint> point = ft->point;
+      if (!point || point->del) continue;
+      for (auto &pf : point->features) {
+        if (pf->frame->del) continue;
+        if (pf->frame->id == frame->id) continue;
+        auto &e = kfs[pf->frame->id];
+        e.first = pf->frame;
+        e.second++;
+      }
+    }
+    if (kfs.empty()) return;
+    int best_n = 0;
+    bool saved = false;
+    RFrame *best_kf = nullptr;
+    const int min_connections = prm.min_matches / 2;
+    for (auto &kv : kfs) {
+      RFrame *kf = kv.second.first;
+      const int n = kv.second.second;
+      if (n > best_n) { best_n = n; best_kf = kf; }
+      if (n >= min_connections) {
+        frame->connections.push_back({kf, n});
+        kf->connections.push_back({frame.get(), n});
+        saved = true;
+        map_stats.connected++;
+      }
+    }
+    if (!saved && best_n > 0) {
+      frame->connections.push_back({best_kf, best_n});
+      best_kf->connections.push_back({frame.get(), best_n});
+      map_stats.connected++;
+    }
+  }
+
+  static bool SeenFrom(const RPoint &pt, const RFrame &frame) {  // point.cc:180-187
+    for (auto &f : pt.features)
+      if (frame.id == f->frame->id) return true;
+    return false;
+  }
+
+  // Map::AddConnectionsPoints, map.cc:560-617 (std::set keyed by point pointer there: frozen to point id order)
+  void AddConnectionsPoints(const std::shared_ptr<RFrame> &frame) {
+    std::vector<RFrame *> best_kfs;
+    BestConnections(frame.get(), &best_kfs, max_search_keyframes);
+    if (best_kfs.empty()) return;
+    std::map<int, std::shared_ptr<RPoint>> points;
+    for (RFrame *kf : best_kfs)
+      for (auto &ft : kf->features) {
+        if (!ft) continue;
+        std::shared_ptr<RPoint> point = ft->point;
+        if (!point || point->del) continue;
+        if (SeenFrom(*point, *frame)) continue;
+        points[point->id] = point;
+      }
+    Matcher matcher(prm.patch_size, prm, cam);
+    SearchCur cur{&frame->pyr, frame->pose, &frame->corners, &frame->descriptors};
+    for (auto &kv : points) {
+      const std::shared_ptr<RPoint> &pt = kv.second;
+      std::shared_ptr<RFeature> feature = pt->init_feature;
+      if (!feature) continue;
+      Vec2 pos;
+      if (!FrameProject(frame->pose, pt->GetPosition(), &pos)) continue;
+      if (!cam.IsInsideImage(static_cast<int>(pos.x), static_cast<int>(pos.y), prm.patch_size)) continue;
+      int level = 0;
+      cur.pose = frame->pose;
+      if (matcher.SearchPoint(&cur, RefOf(*feature), pt->rho, pt->GetStd(), pt->fixed, &pos, &level)) {
+        auto nf = std::make_shared<RFeature>();
+        nf->frame = frame.get();
+        nf->p = pos;
+        nf->v = cam.Unproject(pos);
+        nf->level = level;
+        nf->point = pt;
+        frame->features.push_back(nf);
+        pt->features.insert(pt->features.begin(), nf);
+        map_stats.linked++;
+      }
+    }
+  }
+
+  // Map::InitCandidates, map.cc:262-400
+  void InitCandidates(const std::shared_ptr<RFrame> &frame) {
+    Matcher matcher(prm.patch_size, prm, cam);
+    for (auto &k : keyframes) k->selected = false;  // ResetSelected
+    frame->selected = true;
+    std::vector<RFrame *> best_kfs;
+    BestConnections(frame.get(), &best_kfs, max_search_keyframes);
+    if (best_kfs.empty()) return;
+    FilterCorners(frame.get());
+    std::vector<bool> imatches(frame->filtered.size(), false);
+    n_initializations++;
+    const double depth_mean = SceneDepth(*frame);
+    for (RFrame *cframe : best_kfs) {
+      cframe->selected = true;
+      const double distance = frame->DistanceTo(*cframe);
+      if (distance / depth_mean < 0.01) continue;
+      SearchCur cur{&cframe->pyr, cframe->pose, &cframe->corners, &cframe->descriptors};
+      int count = 0;
+      for (auto it = frame->filtered.begin(); it != frame->filtered.end(); it++, count++) {
+        if (imatches[count]) continue;
+        const int index = *it;
+        const Corner corner = frame->corners[index];
+        const int scale = (1 << corner.level);
+        auto candidate = std::make_shared<RPoint>();
+        candidate->id = point_counter++;
+        auto feature = std::make_shared<RFeature>();
+        feature->frame = frame.get();
+        feature->p = Vec2{static_cast<double>(corner.x * scale), static_cast<double>(corner.y * scale)};
+        feature->v = cam.Unproject(feature->p);
+        feature->level = corner.level;
+        if (prm.use_orb) {
+          std::memcpy(feature->desc, frame->descriptors[index].data(), 32);
+          feature->has_desc = true;
+        }
+        Vec2 imgpos{0, 0};
+        int level = 0;
+        if (!matcher.SearchPoint(&cur, RefOf(*feature), 1.0 / depth_mean, 1.0, false, &imgpos, &level)) continue;
+        // an existing 3D point of the selected keyframe at that position: link instead of creating
+        bool mfound = false;
+        for (auto fit = cframe->features.begin(); fit != cframe->features.end() && !mfound; fit++) {
+          if (!*fit) continue;
+          std::shared_ptr<RPoint> point = (*fit)->point;
+          if (!point || point->del) continue;
+          const double d1 = imgpos.x - (*fit)->p.x, d2 = imgpos.y - (*fit)->p.y;
+          if (std::sqrt(d1 * d1 + d2 * d2) < 1.0) {  // Distance2D, extra/utils.cc:222-226
+            feature->point = point;
+            frame->features.push_back(feature);
+            point->features.insert(point->features.begin(), feature);
+            mfound = true;
+            map_stats.linked++;
+          }
+        }
+        if (mfound) continue;
+        const SE3 pose = cframe->pose * frame->pose.Inverse();
+        auto feature2 = std::make_shared<RFeature>();
+        feature2->frame = cframe;
+        feature2->p = imgpos;
+        feature2->v = cam.Unproject(imgpos);
+        feature2->level = level;
+        double depth = 0.0;
+        if (!DepthFromTriangulation(pose, feature->v, feature2->v, &depth)) continue;
+        const Vec3 p3d = frame->pose.Inverse() * (depth * feature->v);
+        const double cos_alpha = Parallax(frame->WorldPosition(), cframe->WorldPosition(), p3d);
+        if (cos_alpha >= 0.999999) continue;
+        if (depth < map_scale * scale_min_dist || depth < depth_mean * scale_min_dist) continue;
+        InitCandidatePoint(candidate.get(), feature, depth);
+        frame->features.push_back(feature);
+        candidate->features.insert(candidate->features.begin(), feature);
+        feature->point = candidate;
+        cframe->features.push_back(feature2);
+        candidate->features.insert(candidate->features.begin(), feature2);
+        feature2->point = candidate;
+        imatches[count] = true;
+        candidates.push_back(candidate);
+        candidates.push_back(candidate);  // pushed twice in the reference (map.cc:381 and :389, `fixed` is false)
+        map_stats.initialized++;
+      }
+    }
+  }
+
+  // Map::CheckRedundantKeyframes, map.cc:619-690
+  void CheckRedundantKeyframes() {
+    const int min_features = 3;
+    if (last_kf_checked == map_last_kf->id) return;
+    last_kf_checked = map_last_kf->id;
+    std::vector<RFrame *> fov_kfs;
+    BestConnections(map_last_kf.get(), &fov_kfs, 0);
+    for (RFrame *kf : fov_kfs) {
+      if (kf->del || kf->id <= initial_kf_id) continue;
+      int nredundant = 0, npoints = 0;
+      for (auto &ft : kf->features) {
+        if (!ft) continue;
+        std::shared_ptr<RPoint> point = ft->point;
+        if (!point || point->del) continue;
+        npoints++;
+        const int level1 = ft->level;
+        const int size = static_cast<int>(point->features.size());
+        if (size > min_features) {
+          int nmatches = 0;
+          for (auto &pf : point->features) {
+            RFrame *fkf = pf->frame;
+            if (fkf->del || fkf->id == kf->id) continue;
+            if (pf->level <= level1 + 1) {
+              nmatches++;
+              if (nmatches >= min_features) break;
+            }
+          }
+          if (nmatches >= min_features) nredundant++;
+        }
+      }
+      if (nredundant > 0.8 * npoints) {
+        kf->del = true;
+        for (auto &k : keyframes)
+          if (k.get() == kf) { frame_trash.push_back(k); break; }
+      }
+    }
   }
 
   // SDVL::CalcTrackingQuality, sdvl.cc:240-264
@@ -498,7 +1036,8 @@ struct Tracker {
           matches++;
         } else {
           if (!relocalizing) {
-            point->n_failed++;  // Unpromote, point.cc:111-118 (b_ is map state, not read by the path)
+            point->n_failed++;  // Unpromote, point.cc:111-118
+            point->b++;
             if (point->n_failed > prm.max_failed) points_trash.push_back(point);
             point->status = P_NOT_FOUND;
           }

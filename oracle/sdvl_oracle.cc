@@ -261,8 +261,25 @@ void *sdvl_ref_tracker_create(const sdvl_ref_params *p, int w, int h, const doub
   return new Tracker(ToParams(p), ToCam(cam, w, h), pl, ToSE3(first_pose7));
 }
 void sdvl_ref_tracker_destroy(void *t) { delete static_cast<Tracker *>(t); }
+// switch the tracker to the reference's mapper in sequential mode (SDVL::Mapping after every frame, main.cc:148-149)
+void sdvl_ref_tracker_use_mapper(void *t, int on, int max_search_keyframes, int max_keyframes, double map_scale, double scale_min_dist) {
+  Tracker *tr = static_cast<Tracker *>(t);
+  tr->use_mapper = on != 0;
+  tr->max_search_keyframes = max_search_keyframes;
+  tr->max_keyframes = max_keyframes;
+  tr->map_scale = map_scale;
+  tr->scale_min_dist = scale_min_dist;
+}
+// candidates, converged (cumulative), initialized (cumulative), linked (cumulative), connections (cumulative), keyframes
+void sdvl_ref_tracker_map_stats(void *t, int *out6) {
+  const Tracker *tr = static_cast<Tracker *>(t);
+  out6[0] = static_cast<int>(tr->candidates.size()); out6[1] = tr->map_stats.converged; out6[2] = tr->map_stats.initialized;
+  out6[3] = tr->map_stats.linked; out6[4] = tr->map_stats.connected; out6[5] = static_cast<int>(tr->keyframes.size());
+}
 int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_ref_frame_stats *out) {
-  const FrameStats s = static_cast<Tracker *>(t)->HandleFrame(img, stride);
+  Tracker *tr = static_cast<Tracker *>(t);
+  const FrameStats s = tr->HandleFrame(img, stride);
+  if (tr->use_mapper) tr->UpdateMap();  // sequential mode: the mapper runs inline, outside the tracking time window
   out->state = s.state; out->quality = s.quality; out->matches = s.matches; out->attempts = s.attempts;
   out->inliers = s.inliers; out->outliers = s.outliers; out->n_corners = s.n_corners; out->align_meas = s.align_meas;
   out->keyframe = s.keyframe; out->relocalized = s.relocalized;

@@ -85,6 +85,8 @@ int sdvl_ref_pose_from_matches(const sdvl_ref_params *p, int w, int h, const dou
 void *sdvl_ref_tracker_create(const sdvl_ref_params *p, int w, int h, const double *cam, const double *plane4,
                               const double *first_pose7);
 void sdvl_ref_tracker_destroy(void *t);
+void sdvl_ref_tracker_use_mapper(void *t, int on, int max_search_keyframes, int max_keyframes, double map_scale, double scale_min_dist);
+void sdvl_ref_tracker_map_stats(void *t, int *out6);
 int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_ref_frame_stats *out);
 
 #ifdef __cplusplus

@@ -24,6 +24,7 @@ struct Batch {
   std::string err;
 };
 thread_local std::string g_err;
+bool g_use_mapper = false;  // batches created from now on own the reference's mapper instead of the plane map stub
 }  // namespace
 
 extern "C" {
@@ -62,7 +63,8 @@ void *sdvlh_batch_create(void *device, int B, int w, int h, const double *cam4, 
     b->cam.reset(new Camera(w, h, cam4[0], cam4[1], cam4[2], cam4[3]));
     std::vector<SDVL *> raw;
     for (int i = 0; i < B; i++) {
-      b->maps.emplace_back(new PlaneMap(Vector3d(plane4[0], plane4[1], plane4[2]), plane4[3]));
+      if (g_use_mapper) b->maps.emplace_back(new MapperMap(Vector3d(plane4[0], plane4[1], plane4[2]), plane4[3], b->cam.get()));
+      else b->maps.emplace_back(new PlaneMap(Vector3d(plane4[0], plane4[1], plane4[2]), plane4[3]));
       b->trackers.emplace_back(new SDVL(b->cam.get(), b->maps.back().get(), SE3::FromArray(first_poses7 + 7 * i)));
       raw.push_back(b->trackers.back().get());
     }
@@ -72,6 +74,18 @@ void *sdvlh_batch_create(void *device, int B, int w, int h, const double *cam4, 
     g_err = e.what();
     return nullptr;
   }
+}
+
+// map mode of the batches created AFTER the call: 0 = plane map stub (every keyframe seeded from the scene plane),
+// 1 = the reference's mapper in sequential mode (map.cc; the first keyframe is still bootstrapped from the plane)
+void sdvlh_set_mapper(int on) { g_use_mapper = on != 0; }
+int sdvlh_batch_map_stats(void *bp, int i, int *out6) {
+  Batch *b = static_cast<Batch *>(bp);
+  MapperMap *m = dynamic_cast<MapperMap *>(b->maps[i].get());
+  if (!m) return -1;
+  const MapperMap::Stats s = m->GetStats();
+  out6[0] = s.candidates; out6[1] = s.converged; out6[2] = s.initialized; out6[3] = s.linked; out6[4] = s.connected; out6[5] = s.keyframes;
+  return 0;
 }
 
 void sdvlh_batch_destroy(void *bp) {

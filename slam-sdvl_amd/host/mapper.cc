@@ -1,0 +1,653 @@
+// mapper.cc — the reference's mapper (map.cc, point.cc depth filter) on top of the batched K7 search kernel: SURVEY §8f
+// row 3.  Sequential mode only (main.cc:148-149); bundle adjustment (extra/bundle.cc) is out of scope and not run.
+// Every function cites the reference lines it restates; arithmetic keeps the reference's expression order (the file is
+// built with -ffp-contract=off like the rest of the host layer).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "config.h"
+#include "sdvl_host.h"
+
+namespace sdvl {
+
+using std::shared_ptr;
+using std::vector;
+
+namespace {
+
+// extra/utils.cc:193-205: A = [R v_ref | v_cur], depth2 = -(A^T A)^-1 A^T t, |depth2[0]|
+bool GetDepthFromTriangulation(const SE3 &pose, const Vector3d &v_ref, const Vector3d &v_cur, double *depth) {
+  const M3 R = pose.GetRotation();
+  const V3 a0 = mvec(R, {v_ref(0), v_ref(1), v_ref(2)});
+  const V3 a1 = {v_cur(0), v_cur(1), v_cur(2)};
+  const double m00 = vdot(a0, a0), m01 = vdot(a0, a1), m11 = vdot(a1, a1);
+  const double det = m00 * m11 - m01 * m01;
+  if (det < 0.000001) return false;
+  const double invdet = 1.0 / det;
+  const double i00 = m11 * invdet, i01 = -m01 * invdet;
+  const double n00 = -i00, n01 = -i01;
+  const double r0x = n00 * a0.x + n01 * a1.x, r0y = n00 * a0.y + n01 * a1.y, r0z = n00 * a0.z + n01 * a1.z;
+  const Vector3d t = pose.GetTranslation();
+  const double d0 = r0x * t(0) + r0y * t(1) + r0z * t(2);
+  *depth = std::fabs(d0);
+  return true;
+}
+
+// extra/utils.cc:207-213
+double GetParallax(const Vector3d &src1, const Vector3d &src2, const Vector3d &p3d) {
+  V3 v1 = {src1(0) - p3d(0), src1(1) - p3d(1), src1(2) - p3d(2)}, v2 = {src2(0) - p3d(0), src2(1) - p3d(1), src2(2) - p3d(2)};
+  const double n1 = vnorm(v1), n2 = vnorm(v2);
+  v1 = {v1.x / n1, v1.y / n1, v1.z / n1};
+  v2 = {v2.x / n2, v2.y / n2, v2.z / n2};
+  return vdot(v1, v2);
+}
+
+void FillRequest(sdvl_search_req *rq, Frame *cur, Frame *ref, const Vector2d &px, const Vector3d &bearing, int level, const uchar *desc,
+                 double idepth, double idepth_std, bool fixed, const Vector2d &px0) {
+  rq->cur = cur->device();
+  rq->ref = ref->device();
+  cur->GetPose().ToArray(rq->cur_pose);
+  ref->GetPose().ToArray(rq->ref_pose);
+  rq->px[0] = px(0); rq->px[1] = px(1);
+  rq->bearing[0] = bearing(0); rq->bearing[1] = bearing(1); rq->bearing[2] = bearing(2);
+  rq->idepth = idepth;
+  rq->idepth_std = idepth_std;
+  rq->px0[0] = px0(0); rq->px0[1] = px0(1);
+  rq->level = level;
+  rq->fixed = fixed ? 1 : 0;
+  if (desc) std::memcpy(rq->desc, desc, 32);
+  else std::memset(rq->desc, 0, 32);
+}
+
+void FillRequestFromFeature(sdvl_search_req *rq, Frame *cur, Feature *feature, Frame *ref, double idepth, double idepth_std, bool fixed,
+                            const Vector2d &px0) {
+  FillRequest(rq, cur, ref, feature->GetPosition(), feature->GetVector(), feature->GetLevel(),
+              feature->HasDescriptor() ? feature->GetDescriptor().data() : nullptr, idepth, idepth_std, fixed, px0);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------- Point (depth filter)
+// point.cc:189-201
+double Point::ComputeTau(const SE3 &pose, const Vector3d &v, double depth, double px_error_angle) {
+  const double PI = 3.14159265;
+  const Vector3d t = pose.GetTranslation();
+  const V3 tt = {t(0), t(1), t(2)};
+  const V3 a = {v(0) * depth - t(0), v(1) * depth - t(1), v(2) * depth - t(2)};
+  const double t_norm = vnorm(tt), a_norm = vnorm(a);
+  const double alpha = std::acos((v(0) * t(0) + v(1) * t(1) + v(2) * t(2)) / t_norm);
+  const double beta = std::acos((a.x * -t(0) + a.y * -t(1) + a.z * -t(2)) / (t_norm * a_norm));
+  const double beta_plus = beta + px_error_angle;
+  const double gamma_plus = PI - alpha - beta_plus;
+  const double depth_plus = t_norm * std::sin(beta_plus) / std::sin(gamma_plus);
+  return depth_plus - depth;
+}
+
+// point.cc:203-217
+double Point::PDFNormal(double mean, double sd, double x) {
+  const double PI = 3.14159265;
+  double result = 0.0;
+  if (sd <= 0) return result;
+  double exponent = x - mean;
+  exponent *= -exponent;
+  exponent /= 2 * sd * sd;
+  result = std::exp(exponent);
+  result /= sd * std::sqrt(2.0 * PI);
+  return result;
+}
+
+// point.cc:64-100
+void Point::Update(const shared_ptr<Frame> &frame, double depth, double px_error_angle) {
+  shared_ptr<Frame> f0 = feature_->GetFrame();
+  const SE3 pose = f0->GetPose() * frame->GetPose().Inverse();
+  const double tau = ComputeTau(pose, feature_->GetVector(), depth, px_error_angle);
+  const double tau_inverse = 0.5 * (1.0 / std::max(0.0000001, depth - tau) - 1.0 / (depth + tau));
+  const double tau2 = tau_inverse * tau_inverse;
+  const double x = 1. / depth;
+  const double norm_scale = std::sqrt(sigma2_ + tau2);
+  if (std::isnan(norm_scale)) return;
+  const double s2 = 1. / (1. / sigma2_ + 1. / tau2);
+  const double m = s2 * (rho_ / sigma2_ + x / tau2);
+  double C1 = a_ / (a_ + b_) * PDFNormal(rho_, norm_scale, x);
+  double C2 = b_ / (a_ + b_) * 1. / z_range_;
+  const double normalization_constant = C1 + C2;
+  C1 /= normalization_constant;
+  C2 /= normalization_constant;
+  const double f = C1 * (a_ + 1.) / (a_ + b_ + 1.) + C2 * a_ / (a_ + b_ + 1.);
+  const double e = C1 * (a_ + 1.) * (a_ + 2.) / ((a_ + b_ + 1.) * (a_ + b_ + 2.)) + C2 * a_ * (a_ + 1.0) / ((a_ + b_ + 1.0) * (a_ + b_ + 2.0));
+  const double rho_new = C1 * m + C2 * rho_;
+  sigma2_ = C1 * (s2 + m * m) + C2 * (sigma2_ + rho_ * rho_) - rho_new * rho_new;
+  rho_ = rho_new;
+  a_ = (e - f) / (f - e / f);
+  b_ = a_ * (1.0 - f) / f;
+  const Vector3d pos = GetPosition();
+  cos_alpha_ = GetParallax(f0->GetWorldPosition(), frame->GetWorldPosition(), pos);
+  last_distance_ = frame->DistanceTo(pos);
+  n_failed_ = 0;
+}
+
+// point.cc:164-178
+bool Point::HasConverged() {
+  if (fixed_) return true;
+  const double std_d = std::sqrt(sigma2_) / (rho_ * rho_);
+  const double l = 4 * std_d * cos_alpha_ / last_distance_;
+  if (l < 0.1) {
+    p3d_ = GetPosition();
+    fixed_ = true;
+    return true;
+  }
+  return false;
+}
+
+// point.cc:180-187
+bool Point::SeenFrom(const shared_ptr<Frame> &frame) const {
+  for (auto it = features_.begin(); it != features_.end(); it++) {
+    shared_ptr<Frame> f = (*it)->GetFrame();
+    if (f && frame->GetID() == f->GetID()) return true;
+  }
+  return false;
+}
+
+// ----------------------------------------------------------------------------------------------------- Frame (map side)
+// frame.cc:70-92
+double Frame::GetSceneDepth() {
+  vector<double> depth_vec;
+  for (auto it = features_.begin(); it != features_.end(); it++) {
+    if (!(*it)) continue;
+    Point *point = (*it)->GetPointRaw();
+    if (!point) continue;
+    depth_vec.push_back(GetRelativePos(point->GetPosition())(2));
+  }
+  if (depth_vec.empty()) return 0.0;
+  auto mid = depth_vec.begin() + static_cast<long>(std::floor(depth_vec.size() / 2));  // GetMedianVector, extra/utils.cc:215-220
+  std::nth_element(depth_vec.begin(), mid, depth_vec.end());
+  return *mid;
+}
+
+// frame.cc:105-113
+bool Frame::IsPointVisible(const Vector3d &p) {
+  const Vector3d rel_p = GetRelativePos(p);
+  if (rel_p(2) < 0.0) return false;
+  Vector2d image_p;
+  camera_->Project(rel_p, &image_p);
+  return camera_->IsInsideImage(Vector2i(static_cast<int>(image_p(0)), static_cast<int>(image_p(1))));
+}
+
+// frame.h:129-136
+double Frame::DistanceTo(const Frame &frame) const {
+  const Vector3d a = GetWorldPosition(), b = frame.GetWorldPosition();
+  return vnorm({a(0) - b(0), a(1) - b(1), a(2) - b(2)});
+}
+double Frame::DistanceTo(const Vector3d &p) const {
+  const Vector3d a = GetWorldPosition();
+  return vnorm({a(0) - p(0), a(1) - p(1), a(2) - p(2)});
+}
+
+// frame.cc:185-207
+void Frame::GetBestConnections(vector<shared_ptr<Frame>> *connections, int n) {
+  int count = 0;
+  connections->clear();
+  if (n == 0 || n >= static_cast<int>(connections_.size())) {
+    for (auto it = connections_.begin(); it != connections_.end(); it++)
+      if (!it->first->ToDelete()) connections->push_back(it->first);
+  } else {
+    std::sort(connections_.begin(), connections_.end(),
+              [](const std::pair<shared_ptr<Frame>, int> &l, const std::pair<shared_ptr<Frame>, int> &r) { return l.second > r.second; });
+    for (auto it = connections_.begin(); it != connections_.end() && count < n; it++)
+      if (!it->first->ToDelete()) {
+        connections->push_back(it->first);
+        count++;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------- MapperMap
+// map.cc:143-158
+void MapperMap::AddKeyframe(const shared_ptr<Frame> &frame, bool search) {
+  if (search) keyframe_queue_.push_back(frame);
+  else initial_kf_id_ = std::max(initial_kf_id_, frame->GetID());
+  num_kfs_++;
+  frame->SetKeyframeID(num_kfs_);
+  keyframes_.push_back(frame);
+  retired_.push_back(frame);
+  last_kf_ = frame;
+}
+
+// map.cc:190-205,692-706
+void MapperMap::LimitKeyframes(const shared_ptr<Frame> &frame) {
+  if (static_cast<int>(keyframes_.size()) < Config::MaxKeyframes()) return;
+  const Vector3d pos = frame->GetWorldPosition();
+  shared_ptr<Frame> kf;
+  double maxdist = 0.0;
+  for (auto it = keyframes_.begin(); it != keyframes_.end(); it++) {
+    const Vector3d q = (*it)->GetWorldPosition();
+    const double dist = vnorm({q(0) - pos(0), q(1) - pos(1), q(2) - pos(2)});
+    if (dist > maxdist) {
+      maxdist = dist;
+      kf = *it;
+    }
+  }
+  if (!kf) return;
+  kf->SetDelete();
+  frame_trash_.push_back(kf);
+}
+
+// map.cc:207-259
+void MapperMap::EmptyTrash() {
+  for (auto fit = frame_trash_.begin(); fit != frame_trash_.end(); fit++) {
+    if ((*fit)->IsKeyframe())
+      for (auto it = keyframes_.begin(); it != keyframes_.end(); it++)
+        if (*it == *fit) {
+          keyframes_.erase(it);
+          break;
+        }
+    (*fit)->RemoveFeatures();
+    (*fit)->SetDelete();
+  }
+  frame_trash_.clear();
+  Map::EmptyTrash();
+}
+
+MapperMap::Stats MapperMap::GetStats() const {
+  Stats s = stats_;
+  s.candidates = static_cast<int>(candidates_.size());
+  s.keyframes = static_cast<int>(keyframes_.size());
+  return s;
+}
+
+// head of Map::UpdateMap, map.cc:75-108
+bool MapperMap::BeginUpdate() {
+  cur_.reset();
+  if (relocalizing_) return false;
+  if (frame_queue_.empty() && keyframe_queue_.empty()) return false;
+  if (!keyframe_queue_.empty()) {
+    while (!frame_queue_.empty()) {
+      frame_trash_.push_back(frame_queue_.front());
+      frame_queue_.pop_front();
+    }
+    cur_ = keyframe_queue_.front();
+    keyframe_queue_.pop_front();
+  } else {
+    cur_ = frame_queue_.front();
+    frame_queue_.pop_front();
+  }
+  depth_mean_ = cur_->GetSceneDepth();
+  pass_ = 0;
+  occurrence_.assign(candidates_.size(), 0);
+  {  // the reference pushes every new candidate twice (map.cc:381,389): entry k is the occurrence_[k]-th of its point
+    std::map<Point *, int> seen;
+    for (size_t k = 0; k < candidates_.size(); k++) occurrence_[k] = seen[candidates_[k].get()]++;
+  }
+  return true;
+}
+
+// Map::UpdateCandidates, map.cc:402-498, one pass = the `pass_`-th occurrence of every point in the list.  Points do not
+// interact, so processing the list occurrence by occurrence leaves every point in the state the sequential loop does.
+bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs) {
+  cand_work_.clear();
+  if (!cur_) return false;
+  req_base_ = static_cast<int>(reqs->size());
+  bool any = false;
+  for (size_t k = 0; k < candidates_.size(); k++) {
+    if (occurrence_[k] != pass_) continue;
+    any = true;
+    Point *point = candidates_[k].get();
+    CandWork w{k, -1};
+    // the checks that precede SearchPoint are repeated in ApplyCandidates; here they only decide whether a request exists
+    if (!point->ToDelete()) {
+      const Vector3d pos = point->GetPosition();
+      if (cur_->IsPointVisible(pos)) {
+        shared_ptr<Feature> feature = point->GetInitFeature();
+        shared_ptr<Frame> f0 = feature->GetFrame();
+        const double distance = cur_->DistanceTo(*f0);
+        if (!(distance / depth_mean_ < 0.01)) {
+          reqs->emplace_back();
+          FillRequestFromFeature(&reqs->back(), cur_.get(), feature.get(), f0.get(), point->GetInverseDepth(), point->GetStd(), false,
+                                 Vector2d(0, 0));
+          w.req = static_cast<int>(reqs->size()) - 1 - req_base_;
+        }
+      }
+    }
+    cand_work_.push_back(w);
+  }
+  return any;
+}
+
+void MapperMap::ApplyCandidates(const sdvl_search_res *res_all) {
+  if (!cur_) return;
+  const sdvl_search_res *res = res_all + req_base_;
+  const double px_error_angle = std::atan(1.0 / (2.0 * camera_->GetFx())) * 2.0;  // Camera::GetPixelErrorAngle, camera.h:104-107
+  const int min_kf_id = last_kf_->GetKeyframeID() - 2 * Config::MaxSearchKeyframes();
+  vector<char> erase(candidates_.size(), 0);
+  for (const CandWork &w : cand_work_) {
+    shared_ptr<Point> point = candidates_[w.index];
+    if (point->ToDelete()) {
+      DeletePoint(point);
+      erase[w.index] = 1;
+      continue;
+    }
+    const Vector3d pos = point->GetPosition();
+    if (!cur_->IsPointVisible(pos)) {
+      shared_ptr<Frame> lf = point->GetLastFeature()->GetFrame();
+      if (lf->GetKeyframeID() < min_kf_id) {
+        DeletePoint(point);
+        erase[w.index] = 1;
+      }
+      continue;
+    }
+    shared_ptr<Feature> feature = point->GetInitFeature();
+    shared_ptr<Frame> f0 = feature->GetFrame();
+    const double distance = cur_->DistanceTo(*f0);
+    if (distance / depth_mean_ < 0.01) continue;
+    const sdvl_search_res &r = res[w.req];
+    if (!r.found) {
+      if (point->Unpromote()) DeletePoint(point);
+      continue;
+    }
+    const Vector2d imgpos(r.px[0], r.px[1]);
+    const SE3 pose = cur_->GetPose() * f0->GetPose().Inverse();
+    const Vector3d v3d = camera_->Unproject(imgpos);
+    double depth = 0.0;
+    if (!GetDepthFromTriangulation(pose, feature->GetVector(), v3d, &depth)) continue;
+    const Vector3d &fv = feature->GetVector();
+    const Vector3d p3d = f0->GetWorldPose() * Vector3d(depth * fv(0), depth * fv(1), depth * fv(2));
+    const double cos_alpha = GetParallax(f0->GetWorldPosition(), cur_->GetWorldPosition(), p3d);
+    if (cos_alpha >= 0.999999) continue;
+    if (depth < Config::MapScale() * Config::ScaleMinDist() || depth < depth_mean_ * Config::ScaleMinDist()) continue;
+    point->Update(cur_, depth, px_error_angle);
+    if (point->HasConverged()) {
+      erase[w.index] = 1;
+      stats_.converged++;
+    }
+  }
+  // erasures keep the order of the survivors; occurrence numbers are unchanged for them
+  size_t o = 0;
+  for (size_t k = 0; k < candidates_.size(); k++)
+    if (!erase[k]) {
+      candidates_[o] = candidates_[k];
+      occurrence_[o] = occurrence_[k];
+      o++;
+    }
+  candidates_.resize(o);
+  occurrence_.resize(o);
+  pass_++;
+}
+
+// Map::CheckConnections, map.cc:500-558.  The reference iterates a std::map keyed by frame POINTER; frozen to frame id.
+void MapperMap::CheckConnections() {
+  std::map<int, std::pair<shared_ptr<Frame>, int>> kfs;
+  vector<shared_ptr<Feature>> &features = cur_->GetFeatures();
+  for (auto it = features.begin(); it != features.end(); it++) {
+    Point *point = (*it)->GetPointRaw();
+    if (!point || point->ToDelete()) continue;
+    std::list<shared_ptr<Feature>> &ffeatures = point->GetFeatures();
+    for (auto fit = ffeatures.begin(); fit != ffeatures.end(); fit++) {
+      shared_ptr<Frame> ff = (*fit)->GetFrame();
+      if (ff->ToDelete()) continue;
+      if (ff->GetID() == cur_->GetID()) continue;
+      auto &e = kfs[ff->GetID()];
+      e.first = ff;
+      e.second++;
+    }
+  }
+  if (kfs.empty()) return;
+  int best_n = 0;
+  bool saved = false;
+  shared_ptr<Frame> best_kf;
+  const int min_connections = Config::MinMatches() / 2;
+  for (auto it = kfs.begin(); it != kfs.end(); it++) {
+    const shared_ptr<Frame> &kf = it->second.first;
+    const int n = it->second.second;
+    if (n > best_n) {
+      best_n = n;
+      best_kf = kf;
+    }
+    if (n >= min_connections) {
+      cur_->AddConnection(std::make_pair(kf, n));
+      kf->AddConnection(std::make_pair(cur_, n));
+      saved = true;
+      stats_.connected++;
+    }
+  }
+  if (!saved && best_n > 0) {
+    cur_->AddConnection(std::make_pair(best_kf, best_n));
+    best_kf->AddConnection(std::make_pair(cur_, best_n));
+    stats_.connected++;
+  }
+}
+
+// Map::AddConnectionsPoints, map.cc:560-617.  std::set keyed by point POINTER there; frozen to point id.
+void MapperMap::EmitConnectionsPoints(vector<sdvl_search_req> *reqs) {
+  acp_work_.clear();
+  req_base_ = static_cast<int>(reqs->size());
+  vector<shared_ptr<Frame>> best_kfs;
+  cur_->GetBestConnections(&best_kfs, Config::MaxSearchKeyframes());
+  if (best_kfs.empty()) return;
+  std::map<int, shared_ptr<Point>> points;
+  for (auto it_kf = best_kfs.begin(); it_kf != best_kfs.end(); it_kf++) {
+    vector<shared_ptr<Feature>> &features = (*it_kf)->GetFeatures();
+    for (auto it = features.begin(); it != features.end(); it++) {
+      if (!*it) continue;
+      shared_ptr<Point> point = (*it)->GetPoint();
+      if (!point || point->ToDelete()) continue;
+      if (point->SeenFrom(cur_)) continue;
+      points[point->GetID()] = point;
+    }
+  }
+  for (auto it = points.begin(); it != points.end(); it++) {
+    const shared_ptr<Point> &pt = it->second;
+    shared_ptr<Feature> feature = pt->GetInitFeature();
+    if (!feature) continue;
+    Vector2d pos;
+    if (!cur_->Project(pt->GetPosition(), &pos)) continue;
+    if (!camera_->IsInsideImage(Vector2i(static_cast<int>(pos(0)), static_cast<int>(pos(1))), Config::PatchSize())) continue;
+    reqs->emplace_back();
+    shared_ptr<Frame> f0 = feature->GetFrame();
+    FillRequestFromFeature(&reqs->back(), cur_.get(), feature.get(), f0.get(), pt->GetInverseDepth(), pt->GetStd(), pt->IsFixed(), pos);
+    acp_work_.push_back({pt, static_cast<int>(reqs->size()) - 1 - req_base_});
+  }
+}
+
+void MapperMap::ApplyConnectionsPoints(const sdvl_search_res *res_all) {
+  const sdvl_search_res *res = res_all + req_base_;
+  for (auto &w : acp_work_) {
+    const sdvl_search_res &r = res[w.second];
+    if (!r.found) continue;
+    shared_ptr<Feature> feature = std::make_shared<Feature>(cur_, Vector2d(r.px[0], r.px[1]), r.level);
+    feature->SetPoint(w.first);
+    cur_->AddFeature(feature);
+    w.first->AddFeature(feature);
+    stats_.linked++;
+  }
+  acp_work_.clear();
+}
+
+// Map::InitCandidates up to FilterCorners, map.cc:262-283
+bool MapperMap::PrepareInitCandidates() {
+  for (auto it = keyframes_.begin(); it != keyframes_.end(); it++) (*it)->SetSelected(false);  // ResetSelected
+  cur_->SetSelected(true);
+  best_kfs_.clear();
+  cur_->GetBestConnections(&best_kfs_, Config::MaxSearchKeyframes());
+  return !best_kfs_.empty();
+}
+
+// every (connected keyframe, filtered corner) pair the loops at map.cc:296-388 could visit
+void MapperMap::EmitInitCandidates(vector<sdvl_search_req> *reqs) {
+  ic_req_.clear();
+  req_base_ = static_cast<int>(reqs->size());
+  if (best_kfs_.empty()) return;
+  depth_mean_ = cur_->GetSceneDepth();
+  vector<Vector3i> &corners = cur_->GetCorners();
+  vector<int> &fcorners = cur_->GetFilteredCorners();
+  vector<vector<uchar>> &descriptors = cur_->HostDescriptors();
+  const int nc = static_cast<int>(fcorners.size());
+  ic_req_.assign(best_kfs_.size() * static_cast<size_t>(nc), -1);
+  for (size_t k = 0; k < best_kfs_.size(); k++) {
+    Frame *cframe = best_kfs_[k].get();
+    const double distance = cur_->DistanceTo(*cframe);
+    if (distance / depth_mean_ < 0.01) continue;
+    for (int c = 0; c < nc; c++) {
+      const Vector3i corner = corners[fcorners[c]];
+      const int scale = (1 << corner(2));
+      const Vector2d px(corner(0) * scale, corner(1) * scale);
+      const Vector3d bearing = camera_->Unproject(px);
+      reqs->emplace_back();
+      FillRequest(&reqs->back(), cframe, cur_.get(), px, bearing, corner(2), Config::UseORB() ? descriptors[fcorners[c]].data() : nullptr,
+                  1.0 / depth_mean_, 1.0, false, Vector2d(0, 0));
+      ic_req_[k * nc + c] = static_cast<int>(reqs->size()) - 1 - req_base_;
+    }
+  }
+}
+
+// the loops of Map::InitCandidates (map.cc:290-392) replayed over the search results
+void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
+  if (best_kfs_.empty()) return;
+  const sdvl_search_res *res = res_all + req_base_;
+  vector<Vector3i> &corners = cur_->GetCorners();
+  vector<int> &fcorners = cur_->GetFilteredCorners();
+  vector<vector<uchar>> &descriptors = cur_->HostDescriptors();
+  const int nc = static_cast<int>(fcorners.size());
+  vector<bool> imatches(fcorners.size(), false);
+  for (size_t k = 0; k < best_kfs_.size(); k++) {
+    shared_ptr<Frame> cframe = best_kfs_[k];
+    cframe->SetSelected(true);
+    const double distance = cur_->DistanceTo(*cframe);
+    if (distance / depth_mean_ < 0.01) continue;
+    for (int count = 0; count < nc; count++) {
+      if (imatches[count]) continue;
+      const int index = fcorners[count];
+      const Vector3i corner = corners[index];
+      const int scale = (1 << corner(2));
+      shared_ptr<Point> candidate = std::make_shared<Point>();
+      shared_ptr<Feature> feature = std::make_shared<Feature>(cur_, Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
+      if (Config::UseORB()) feature->SetDescriptor(descriptors[index]);
+      const sdvl_search_res &r = res[ic_req_[k * nc + count]];
+      if (!r.found) continue;
+      const Vector2d imgpos(r.px[0], r.px[1]);
+      const int level = r.level;
+      bool mfound = false;
+      vector<shared_ptr<Feature>> &features = cframe->GetFeatures();
+      for (size_t q = 0; q < features.size() && !mfound; q++) {  // index loop: AddFeature below may grow the vector
+        if (!features[q]) continue;
+        shared_ptr<Point> point = features[q]->GetPoint();
+        if (!point || point->ToDelete()) continue;
+        const double d1 = imgpos(0) - features[q]->GetPosition()(0), d2 = imgpos(1) - features[q]->GetPosition()(1);
+        if (std::sqrt(d1 * d1 + d2 * d2) < 1.0) {  // Distance2D, extra/utils.cc:222-226
+          feature->SetPoint(point);
+          cur_->AddFeature(feature);
+          point->AddFeature(feature);
+          mfound = true;
+          stats_.linked++;
+        }
+      }
+      if (mfound) continue;
+      const SE3 pose = cframe->GetPose() * cur_->GetPose().Inverse();
+      shared_ptr<Feature> feature2 = std::make_shared<Feature>(cframe, imgpos, level);
+      double depth = 0.0;
+      if (!GetDepthFromTriangulation(pose, feature->GetVector(), feature2->GetVector(), &depth)) continue;
+      const Vector3d &fv = feature->GetVector();
+      const Vector3d p3d = cur_->GetWorldPose() * Vector3d(depth * fv(0), depth * fv(1), depth * fv(2));
+      const double cos_alpha = GetParallax(cur_->GetWorldPosition(), cframe->GetWorldPosition(), p3d);
+      if (cos_alpha >= 0.999999) continue;
+      if (depth < Config::MapScale() * Config::ScaleMinDist() || depth < depth_mean_ * Config::ScaleMinDist()) continue;
+      candidate->InitCandidate(feature, depth);
+      cur_->AddFeature(feature);
+      candidate->AddFeature(feature);
+      feature->SetPoint(candidate);
+      cframe->AddFeature(feature2);
+      candidate->AddFeature(feature2);
+      feature2->SetPoint(candidate);
+      imatches[count] = true;
+      candidates_.push_back(candidate);
+      candidates_.push_back(candidate);  // twice, as map.cc:381 and :389 do (`fixed` is false there)
+      stats_.initialized++;
+    }
+  }
+  best_kfs_.clear();
+}
+
+// Map::CheckRedundantKeyframes, map.cc:619-690
+void MapperMap::CheckRedundantKeyframes() {
+  const int min_features = 3;
+  if (last_kf_checked_ == last_kf_->GetID()) return;
+  last_kf_checked_ = last_kf_->GetID();
+  vector<shared_ptr<Frame>> fov_kfs;
+  last_kf_->GetBestConnections(&fov_kfs, 0);
+  for (auto it = fov_kfs.begin(); it != fov_kfs.end(); it++) {
+    shared_ptr<Frame> kf = *it;
+    if (kf->ToDelete() || kf->GetID() <= initial_kf_id_) continue;
+    int nredundant = 0, npoints = 0;
+    vector<shared_ptr<Feature>> &features = kf->GetFeatures();
+    for (auto it_fts = features.begin(); it_fts != features.end(); it_fts++) {
+      if (!*it_fts) continue;
+      Point *point = (*it_fts)->GetPointRaw();
+      if (!point || point->ToDelete()) continue;
+      npoints++;
+      const int level1 = (*it_fts)->GetLevel();
+      std::list<shared_ptr<Feature>> &ffeatures = point->GetFeatures();
+      const int size = static_cast<int>(ffeatures.size());
+      if (size > min_features) {
+        int nmatches = 0;
+        for (auto fit = ffeatures.begin(); fit != ffeatures.end(); fit++) {
+          shared_ptr<Frame> fkf = (*fit)->GetFrame();
+          if (fkf->ToDelete() || fkf->GetID() == kf->GetID()) continue;
+          if ((*fit)->GetLevel() <= level1 + 1) {
+            nmatches++;
+            if (nmatches >= min_features) break;
+          }
+        }
+        if (nmatches >= min_features) nredundant++;
+      }
+    }
+    if (nredundant > 0.8 * npoints) {
+      kf->SetDelete();
+      frame_trash_.push_back(kf);
+    }
+  }
+}
+
+// tail of Map::UpdateMap for an ordinary frame, map.cc:117-125
+void MapperMap::FinishUpdate() {
+  if (!cur_) return;
+  if (!cur_->IsKeyframe()) {
+    CheckRedundantKeyframes();
+    frame_trash_.push_back(cur_);
+  }
+  cur_.reset();
+}
+
+// Map::UpdateMap for ONE tracker (one K7 launch per phase); SDVLBatch runs the same phases for many trackers at once
+void MapperMap::UpdateMap() {
+  if (!BeginUpdate()) return;
+  Device *dev = Device::Current();
+  vector<sdvl_search_req> reqs;
+  vector<sdvl_search_res> res;
+  for (;;) {
+    reqs.clear();
+    if (!EmitCandidates(&reqs)) break;
+    res.clear();
+    Matcher::SearchPoints(dev, reqs, *camera_, &res);
+    ApplyCandidates(res.data());
+  }
+  if (IsKeyframeUpdate()) {
+    CheckConnections();
+    reqs.clear();
+    EmitConnectionsPoints(&reqs);
+    res.clear();
+    Matcher::SearchPoints(dev, reqs, *camera_, &res);
+    ApplyConnectionsPoints(res.data());
+    if (PrepareInitCandidates()) {
+      cur_->FilterCorners();
+      reqs.clear();
+      EmitInitCandidates(&reqs);
+      res.clear();
+      Matcher::SearchPoints(dev, reqs, *camera_, &res);
+      ApplyInitCandidates(res.data());
+    }
+  }
+  FinishUpdate();
+}
+
+}  // namespace sdvl

@@ -775,7 +775,7 @@ bool Map::NeedKeyframe(const shared_ptr<Frame> &frame, int) {
 }
 
 // map.cc:145-159
-void Map::AddKeyframe(const shared_ptr<Frame> &frame) {
+void Map::AddKeyframe(const shared_ptr<Frame> &frame, bool) {
   keyframes_.push_back(frame);
   last_kf_ = frame;
 }
@@ -1270,9 +1270,16 @@ bool SDVL::HandleFrame(const Image &img) {
 
 void SDVL::Mapping() {
   if (pending_kf_) {
-    map_->InitCandidates(pending_kf_);
+    PlaneMap *pm = dynamic_cast<PlaneMap *>(map_);
+    if (pm) {
+      pending_kf_->FilterCorners();
+      pm->SeedFromFiltered(pending_kf_);
+    } else {
+      map_->InitCandidates(pending_kf_);
+    }
     pending_kf_ = nullptr;
   }
+  if (MapperMap *m = dynamic_cast<MapperMap *>(map_)) m->UpdateMap();  // main.cc:148-149
 }
 
 // ------------------------------------------------------------------------------------------------------ SDVLBatch
@@ -1414,8 +1421,8 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       // bootstrap replacement (SaveFirstFrame/SaveSecondFrame are out of scope): first frame = keyframe at first_pose
       t.current_frame_->SetPose(t.first_pose_);
       t.current_frame_->SetKeyframe();
-      t.map_->AddKeyframe(t.current_frame_);
-      t.pending_kf_ = t.current_frame_;
+      t.map_->AddKeyframe(t.current_frame_, false);  // like SaveFirstFrame / SaveSecondFrame (sdvl.cc:144,165): not queued
+      t.pending_kf_ = t.current_frame_;              // seeded from the scene plane in the mapping stage
       t.last_frame_ = t.current_frame_;
       t.last_kf_ = t.current_frame_;
       t.state_ = SDVL::STATE_RUNNING;
@@ -1429,6 +1436,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
         // from that keyframe's pose, fast mode) is independent of the others: one launch with |keyframes| jobs.  The
         // keyframe loop then runs in the reference's order (newest first) over the results; Reproject stays sequential
         // because it draws from rand() and stops at the first keyframe that gathers MinMatches.
+        t.map_->SetRelocalizing(true);  // sdvl.cc:80
         for (int k = 0; k < 6; k++) t.vel_[k] = 0.0;
         vector<shared_ptr<Frame>> &kfs = t.map_->GetKeyframes();
         vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> pairs;
@@ -1448,6 +1456,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
           t.matches_ = t.feature_align_.GetMatches();
           t.attempts_ = t.feature_align_.GetAttempts();
           if (t.matches_ >= Config::MinMatches()) {
+            t.map_->SetRelocalizing(false);  // sdvl.cc:84
             t.last_kf_ = cframe;
             t.last_frame_ = cframe;
             relocalize = false;
@@ -1558,7 +1567,8 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
           t.current_frame_->SetKeyframe();
           t.map_->AddKeyframe(t.current_frame_);
           t.last_kf_ = t.current_frame_;
-          t.pending_kf_ = t.current_frame_;
+          t.map_->LimitKeyframes(t.current_frame_);  // sdvl.cc:114
+          if (!dynamic_cast<MapperMap *>(t.map_)) t.pending_kf_ = t.current_frame_;  // plane map stub: seed every keyframe
           st.keyframe = 1;
         } else {
           t.map_->AddFrame(t.current_frame_);
@@ -1604,6 +1614,73 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     t.stats_ = st;
     t.current_frame_ = nullptr;
     t.map_->EmptyTrash();  // sdvl.cc:127
+  }
+  // ---- stage 5: SDVL::Mapping() of sequential mode (main.cc:148-149) for the trackers that own a real mapper: the phases of
+  // Map::UpdateMap run in lock step, every phase's SearchPoint requests of ALL trackers in one K7 launch
+  clk.reset(new StageClock(ST_MAPPER));
+  {
+    vector<MapperMap *> mm;
+    for (int i = 0; i < B; i++) {
+      MapperMap *m = dynamic_cast<MapperMap *>(trk_[i]->map_);
+      if (m && m->BeginUpdate()) mm.push_back(m);
+    }
+    const int M = static_cast<int>(mm.size());
+    if (M > 0) {
+      const Camera &cam = *trk_[0]->camera_;
+      vector<vector<sdvl_search_req>> per(M);
+      vector<sdvl_search_req> reqs;
+      vector<sdvl_search_res> res;
+      vector<size_t> begin(M + 1, 0);
+      auto launch = [&]() {  // concatenate, search, leave the offsets in `begin`
+        reqs.clear();
+        for (int k = 0; k < M; k++) {
+          begin[k] = reqs.size();
+          reqs.insert(reqs.end(), per[k].begin(), per[k].end());
+          per[k].clear();
+        }
+        begin[M] = reqs.size();
+        res.clear();
+        if (!reqs.empty()) Matcher::SearchPoints(dev_, reqs, cam, &res);
+        if (res.empty()) res.resize(1);
+      };
+      for (;;) {  // UpdateCandidates, one occurrence pass at a time
+        vector<char> more(M, 0);
+        ParallelFor(M, [&](int k) { more[k] = mm[k]->EmitCandidates(&per[k]) ? 1 : 0; });
+        bool any = false;
+        for (int k = 0; k < M; k++) any = any || more[k];
+        if (!any) break;
+        launch();
+        ParallelFor(M, [&](int k) { if (more[k]) mm[k]->ApplyCandidates(res.data() + begin[k]); });
+      }
+      vector<int> kf_idx;
+      for (int k = 0; k < M; k++)
+        if (mm[k]->IsKeyframeUpdate()) kf_idx.push_back(k);
+      if (!kf_idx.empty()) {
+        const int K = static_cast<int>(kf_idx.size());
+        ParallelFor(K, [&](int q) {
+          MapperMap *m = mm[kf_idx[q]];
+          m->CheckConnections();
+          m->EmitConnectionsPoints(&per[kf_idx[q]]);
+        });
+        launch();
+        vector<char> need(K, 0);
+        ParallelFor(K, [&](int q) {
+          MapperMap *m = mm[kf_idx[q]];
+          m->ApplyConnectionsPoints(res.data() + begin[kf_idx[q]]);
+          need[q] = m->PrepareInitCandidates() ? 1 : 0;
+        });
+        vector<shared_ptr<Frame>> to_filter;
+        for (int q = 0; q < K; q++)
+          if (need[q]) to_filter.push_back(mm[kf_idx[q]]->CurrentFrame());
+        if (!to_filter.empty()) {
+          Frame::FilterCornersBatch(to_filter);
+          ParallelFor(K, [&](int q) { if (need[q]) mm[kf_idx[q]]->EmitInitCandidates(&per[kf_idx[q]]); });
+          launch();
+          ParallelFor(K, [&](int q) { if (need[q]) mm[kf_idx[q]]->ApplyInitCandidates(res.data() + begin[kf_idx[q]]); });
+        }
+      }
+      ParallelFor(M, [&](int k) { mm[k]->FinishUpdate(); });
+    }
   }
   clk.reset();
   stage_times.t[ST_TOTAL] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -17,6 +17,7 @@
 #define SDVL_HOST_H_
 
 #include <functional>
+#include <deque>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -199,8 +200,15 @@ class Point {
   void SetFixed() { fixed_ = true; }
   bool IsFixed() { return fixed_; }
   void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_front(f); }
+  std::shared_ptr<Feature> GetLastFeature() { return features_.front(); }
   bool Promote();
   bool Unpromote();
+  // depth filter (point.cc:64-100,164-217): used by the mapper (MapperMap), not by the tracking path
+  void Update(const std::shared_ptr<Frame> &frame, double depth, double px_error_angle);
+  bool HasConverged();
+  bool SeenFrom(const std::shared_ptr<Frame> &frame) const;
+  static double ComputeTau(const SE3 &pose, const Vector3d &v, double depth, double px_error_angle);
+  static double PDFNormal(double mean, double sd, double x);
 
  private:
   int id_;
@@ -209,6 +217,7 @@ class Point {
   std::list<std::shared_ptr<Feature>> features_;
   int last_frame_, n_successful_, n_failed_;
   double a_, b_, rho_, sigma2_, z_range_;
+  double cos_alpha_ = 1.0, last_distance_ = 1.0;
   std::shared_ptr<Feature> feature_;
   bool fixed_;
   Vector3d p3d_;
@@ -254,6 +263,19 @@ class Frame : public std::enable_shared_from_this<Frame> {
   bool Project(const Vector3d &p3D, Vector2d *p2D);
   void CreateCorners(int levels, int nfeatures);
   void RemoveFeatures() { features_.clear(); }
+  // mapper-side state and queries (frame.h:71-87,120-136; frame.cc:70-113,181-207)
+  void SetKeyframeID(int id) { kf_id_ = id; }
+  int GetKeyframeID() const { return kf_id_; }
+  bool IsSelected() { return selected_; }
+  void SetSelected(bool v) { selected_ = v; }
+  bool ToDelete() const { return delete_; }
+  void SetDelete() { delete_ = true; }
+  double GetSceneDepth();
+  bool IsPointVisible(const Vector3d &p);
+  double DistanceTo(const Frame &frame) const;
+  double DistanceTo(const Vector3d &p) const;
+  void AddConnection(const std::pair<std::shared_ptr<Frame>, int> kf) { connections_.push_back(kf); }
+  void GetBestConnections(std::vector<std::shared_ptr<Frame>> *connections, int n);
   sdvl_frame *device() const { return dev_; }
   Device *owner() const { return owner_; }
 
@@ -278,6 +300,9 @@ class Frame : public std::enable_shared_from_this<Frame> {
   bool corners_on_host_ = true;  // false after a device-side DetectPyramid until GetCorners() mirrors the list
   sdvl_frame *dev_ = nullptr;
   Device *owner_ = nullptr;
+  int kf_id_ = 0;
+  bool delete_ = false, selected_ = false;
+  std::vector<std::pair<std::shared_ptr<Frame>, int>> connections_;
   static int counter_;
 };
 
@@ -319,9 +344,11 @@ class Map {
   virtual ~Map() {}
   void DeletePoint(const std::shared_ptr<Point> &p) { points_trash_.push_back(p); }
   bool NeedKeyframe(const std::shared_ptr<Frame> &frame, int matches);  // map.cc:170-188
-  void AddKeyframe(const std::shared_ptr<Frame> &frame);
-  void AddFrame(const std::shared_ptr<Frame> &) {}
-  void EmptyTrash();  // map.cc:207-259 (points part)
+  virtual void AddKeyframe(const std::shared_ptr<Frame> &frame, bool search = true);
+  virtual void AddFrame(const std::shared_ptr<Frame> &) {}
+  virtual void LimitKeyframes(const std::shared_ptr<Frame> &) {}
+  virtual void SetRelocalizing(bool) {}
+  virtual void EmptyTrash();  // map.cc:207-259
   std::vector<std::shared_ptr<Frame>> &GetKeyframes() { return keyframes_; }
   // mapper work for a fresh keyframe (Map::InitCandidates stand-in); called outside the tracking stages
   virtual void InitCandidates(const std::shared_ptr<Frame> &) {}
@@ -344,6 +371,64 @@ class PlaneMap : public Map {
  private:
   Vector3d n_;
   double d_;
+};
+
+// map.h:44-139 — the reference's mapper in SEQUENTIAL mode (main.cc:148-149: SDVL::Mapping() = Map::UpdateMap() after every
+// frame).  The first keyframe is still bootstrapped from the scene plane (homography_init is out of scope); every later
+// keyframe goes through UpdateCandidates / CheckConnections / AddConnectionsPoints / InitCandidates, ordinary frames
+// through UpdateCandidates / CheckRedundantKeyframes.  Bundle adjustment is out of scope and not run.
+// Every SearchPoint the mapper would issue one at a time is emitted as a request instead (Emit*), evaluated for MANY
+// trackers in one K7 launch, and the reference's sequential logic is replayed over the results (Apply*) — the same
+// speculate-then-replay scheme FeatureAlign uses (SearchPoint is a pure function of its arguments).
+class MapperMap : public PlaneMap {
+ public:
+  MapperMap(const Vector3d &n, double d, Camera *camera) : PlaneMap(n, d), camera_(camera) {}
+  void AddKeyframe(const std::shared_ptr<Frame> &frame, bool search = true) override;  // map.cc:143-158
+  void AddFrame(const std::shared_ptr<Frame> &frame) override { frame_queue_.push_back(frame); }
+  void LimitKeyframes(const std::shared_ptr<Frame> &frame) override;                   // map.cc:190-205
+  void SetRelocalizing(bool v) override { relocalizing_ = v; }
+  void EmptyTrash() override;
+  void InitCandidates(const std::shared_ptr<Frame> &) override {}  // the bootstrap keyframe is seeded by the driver
+
+  // ---- Map::UpdateMap (map.cc:75-141) cut into phases; a driver calls them in this order for all its trackers
+  bool BeginUpdate();                                            // pops the next frame; false = nothing to do
+  bool EmitCandidates(std::vector<sdvl_search_req> *reqs);       // UpdateCandidates, one pass; false = no more passes
+  void ApplyCandidates(const sdvl_search_res *res);
+  bool IsKeyframeUpdate() const { return cur_ && cur_->IsKeyframe(); }
+  void CheckConnections();                                       // map.cc:500-558
+  void EmitConnectionsPoints(std::vector<sdvl_search_req> *reqs);  // AddConnectionsPoints, map.cc:560-617
+  void ApplyConnectionsPoints(const sdvl_search_res *res);
+  bool PrepareInitCandidates();                                  // map.cc:262-283; true = the keyframe needs FilterCorners
+  const std::shared_ptr<Frame> &CurrentFrame() const { return cur_; }
+  void EmitInitCandidates(std::vector<sdvl_search_req> *reqs);   // after Frame::FilterCorners of CurrentFrame()
+  void ApplyInitCandidates(const sdvl_search_res *res);
+  void FinishUpdate();                                           // CheckRedundantKeyframes + trash for ordinary frames
+  // the whole of it for one tracker (one launch per phase)
+  void UpdateMap();
+
+  struct Stats { int candidates = 0, converged = 0, initialized = 0, linked = 0, connected = 0, keyframes = 0; };
+  Stats GetStats() const;
+
+ private:
+  void CheckRedundantKeyframes();  // map.cc:619-690
+  Camera *camera_;
+  std::vector<std::shared_ptr<Point>> candidates_;
+  std::deque<std::shared_ptr<Frame>> frame_queue_, keyframe_queue_;
+  std::vector<std::shared_ptr<Frame>> frame_trash_, retired_;  // retired_: culled keyframes stay alive while features name them
+  int num_kfs_ = 0, initial_kf_id_ = 0, last_kf_checked_ = -1;
+  bool relocalizing_ = false;
+  Stats stats_;
+  // state of the update in flight
+  std::shared_ptr<Frame> cur_;
+  double depth_mean_ = 0.0;
+  int pass_ = 0, req_base_ = 0;
+  struct CandWork { size_t index; int req; };             // position in candidates_, request (relative) or -1
+  std::vector<CandWork> cand_work_;
+  std::vector<int> occurrence_;                            // per candidates_ entry: which occurrence of its point it is
+  std::vector<std::pair<std::shared_ptr<Point>, int>> acp_work_;  // AddConnectionsPoints: point, request or -1
+  std::vector<std::shared_ptr<Frame>> best_kfs_;
+  std::vector<int> ic_req_;                                // InitCandidates: request of (kf k, filtered corner c) or -1
+  std::vector<std::shared_ptr<Feature>> ic_feature_;
 };
 
 typedef std::pair<std::shared_ptr<Point>, Vector2d> PointInfo;
@@ -420,7 +505,7 @@ class FeatureAlign {
 
 // wall-clock per stage of SDVLBatch::HandleFrames, accumulated (seconds); index = StageId
 enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_POSE, ST_MAPPING,
-               ST_EPILOGUE, ST_TOTAL, ST_COUNT };
+               ST_EPILOGUE, ST_MAPPER, ST_TOTAL, ST_COUNT };
 struct StageTimes {
   double t[ST_COUNT] = {0};
   long steps = 0;

@@ -57,6 +57,12 @@ def set_device_pose(on):
     load_host_library().sdvlh_set_device_pose(int(bool(on)))
 
 
+def set_mapper(on):
+    """map mode of the batches / farms created afterwards: the reference's mapper in sequential mode (map.cc) instead of
+    the plane map stub; the first keyframe is bootstrapped from the scene plane in both modes"""
+    load_host_library().sdvlh_set_mapper(int(bool(on)))
+
+
 def device_pose():
     return bool(load_host_library().sdvlh_device_pose())
 
@@ -106,7 +112,15 @@ class TrackerBatch:
         return self._stats
 
     STAGES = ["upload_pyr", "fast", "select", "corners_orb", "prelude", "image_align", "prepare", "search", "finish", "pose", "mapping",
-              "epilogue", "total"]
+              "epilogue", "mapper", "total"]
+
+    def map_stats(self, i):
+        """mapper mode only: candidates, converged, initialized, linked, connected, keyframes of tracker i"""
+        out = (C.c_int * 6)()
+        self.lib.sdvlh_batch_map_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if self.lib.sdvlh_batch_map_stats(self.h, int(i), out) != 0:
+            raise RuntimeError("tracker %d has no mapper" % i)
+        return dict(zip(("candidates", "converged", "initialized", "linked", "connected", "keyframes"), list(out)))
 
     def stage_times(self, reset=False):
         """accumulated wall seconds per host stage of SDVLBatch::HandleFrames -> (dict, steps)"""

@@ -245,6 +245,16 @@ class OracleTracker:
         self.lib.sdvl_ref_tracker_handle_frame(C.c_void_p(self.h_), ptr(img, u8p), self.w, C.byref(st))
         return st
 
+    def use_mapper(self, on=True, max_search_keyframes=5, max_keyframes=100, map_scale=1.0, scale_min_dist=0.25):
+        """the reference's mapper in sequential mode (map.cc) instead of the plane map stub"""
+        self.lib.sdvl_ref_tracker_use_mapper(C.c_void_p(self.h_), int(on), int(max_search_keyframes), int(max_keyframes),
+                                             C.c_double(map_scale), C.c_double(scale_min_dist))
+
+    def map_stats(self):
+        out = np.zeros(6, np.int32)
+        self.lib.sdvl_ref_tracker_map_stats(C.c_void_p(self.h_), ptr(out, i32p))
+        return dict(zip(("candidates", "converged", "initialized", "linked", "connected", "keyframes"), out.tolist()))
+
     def close(self):
         if self.h_:
             self.lib.sdvl_ref_tracker_destroy(C.c_void_p(self.h_)); self.h_ = None

@@ -96,3 +96,56 @@ def test_lost_and_relocalize_matches_oracle(trk, orc, synth):
         relocs += g.relocalized
     assert relocs == 1
     batch.close(); ref.close(); dev.close()
+
+
+def run_mapper_case(trk, orc, synth, B, n_frames, threads):
+    """closed loop with the reference's mapper (map.cc, sequential mode) on both sides: the tracker's per-frame decisions,
+    the poses AND the map bookkeeping (candidates alive / converged / initialised / linked, connections, keyframes after
+    culling) must agree frame by frame"""
+    trk.configure()
+    trk.set_mapper(True)
+    try:
+        dev = trk.HostDevice(0)
+        xis = [XI * (1.0 + 0.2 * i) * (1 if i % 2 == 0 else -1) for i in range(B)]
+        seeds = [20260001 + i for i in range(B)]
+        batch = trk.TrackerBatch(dev, B, 640, 480, TUM_CAM, host_threads=threads)
+    finally:
+        trk.set_mapper(False)
+    oracles = [orc.tracker(640, 480, TUM_CAM) for _ in range(B)]
+    for o in oracles:
+        o.use_mapper(True)
+    worst = 0.0
+    stats = None
+    for k in range(n_frames):
+        imgs = [synth.render(trajectory_pose(orc, k, xis[i]), TUM_CAM, 640, 480, seed=seeds[i], frame_id=k) for i in range(B)]
+        got = batch.step_host(imgs)
+        for i in range(B):
+            want = oracles[i].handle_frame(imgs[i])
+            g = got[i]
+            assert (g.state, g.quality, g.keyframe, g.n_corners) == (want.state, want.quality, want.keyframe, want.n_corners), (k, i)
+            assert (g.matches, g.attempts, g.inliers, g.outliers) == (want.matches, want.attempts, want.inliers, want.outliers), (k, i)
+            assert g.align_meas == want.align_meas, (k, i)
+            d = np.abs(np.array(g.pose[:]) - np.array(want.pose[:])).max()
+            worst = max(worst, d)
+            assert d <= POSE_TOL, (k, i, d)
+            stats = batch.map_stats(i)
+            assert stats == oracles[i].map_stats(), (k, i, stats, oracles[i].map_stats())
+            if k > 0:
+                assert g.quality == 0 and g.matches >= 100
+    batch.close()
+    for o in oracles:
+        o.close()
+    dev.close()
+    return worst, stats
+
+
+def test_closed_loop_with_reference_mapper(trk, orc, synth):
+    worst, stats = run_mapper_case(trk, orc, synth, B=1, n_frames=32, threads=1)
+    assert worst <= POSE_TOL
+    # the map is really being built by triangulation + depth filter, and keyframes get connected
+    assert stats["initialized"] >= 100 and stats["converged"] >= 50 and stats["linked"] >= 200 and stats["connected"] >= 10
+
+
+def test_closed_loop_with_reference_mapper_batched(trk, orc, synth):
+    worst, _ = run_mapper_case(trk, orc, synth, B=4, n_frames=16, threads=3)
+    assert worst <= POSE_TOL
