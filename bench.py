@@ -164,11 +164,13 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(frames):
+def cpu_baseline(frames, mapper=False):
     """the CPU oracle (oracle/, kind "port") on ONE host core over a bounded sample of sequence 0"""
     import oraclelib as ol
     orc = ol.Oracle()
     trk = orc.tracker(W_IMG, H_IMG, TUM_CAM)
+    if mapper:
+        trk.use_mapper(True)
     tracked, t_total = 0, 0.0
     for k, im in enumerate(frames):
         t0 = time.perf_counter()
@@ -190,6 +192,8 @@ def main():
     ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
     ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")
     ap.add_argument("--workers", type=int, default=0, help="host threads that execute group-steps (0 = auto)")
+    ap.add_argument("--mapper", action="store_true",
+                    help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -218,6 +222,7 @@ def main():
         G -= 1
     Bg = B // G
     threads = args.threads or 1
+    trk.set_mapper(args.mapper)
     farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
     ctxs = [CtxView(pkg, farm.ctx_handle(g)) for g in range(G)]
     ctx = ctxs[0]
@@ -295,7 +300,7 @@ def main():
             views = [make_view(pkg, se3_exp(shard.sequence_twist(0) * k), shard.sequence_seed(0), k) for k in range(n_cpu)]
             ctx.render(views, cbuf)
             host = ctx.download(cbuf, n_cpu * frame_bytes).reshape(n_cpu, H_IMG, W_IMG)
-            fps, n_tracked, secs = cpu_baseline([host[k] for k in range(n_cpu)])
+            fps, n_tracked, secs = cpu_baseline([host[k] for k in range(n_cpu)], args.mapper)
             cpu = {"value": round(fps, 2), "unit": "tracked frames/s", "cores": 1, "kind": "port",
                    "sample": "sequence 0 of the same workload, %d tracked frames, %.1f s on one host core (%d usable CPUs)" % (n_tracked, secs, ncpu)}
         value = tracked_all / elapsed_max
@@ -304,7 +309,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed_max / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
             "config": {"workload": "S-A: synthetic TUM fr1-like 640x480 mono, textured plane z=2m, %d independent sequences per GPU, "
-                                   "one tracked frame per sequence per step" % B,
+                                   "one tracked frame per sequence per step%s" % (B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
