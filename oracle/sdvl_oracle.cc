@@ -276,6 +276,33 @@ void sdvl_ref_tracker_map_stats(void *t, int *out6) {
   out6[0] = static_cast<int>(tr->candidates.size()); out6[1] = tr->map_stats.converged; out6[2] = tr->map_stats.initialized;
   out6[3] = tr->map_stats.linked; out6[4] = tr->map_stats.connected; out6[5] = static_cast<int>(tr->keyframes.size());
 }
+// positions of the points the mapper itself created (not the plane-bootstrapped ones) that are still alive:
+// out[i] = x y z converged(0/1).  Returns the number written (<= cap).
+int sdvl_ref_tracker_mapper_points(void *t, int cap, double *out) {
+  Tracker *tr = static_cast<Tracker *>(t);
+  std::set<const RPoint *> seen;
+  int n = 0;
+  for (auto &kf : tr->keepalive)
+    for (auto &ft : kf->features) {
+      if (!ft || !ft->point || ft->point->del) continue;
+      const RPoint *p = ft->point.get();
+      if (p->init_feature->frame->id <= tr->initial_kf_id) continue;  // bootstrap points come from the plane itself
+      if (!seen.insert(p).second) continue;
+      if (n >= cap) return n;
+      const Vec3 pos = p->GetPosition();
+      out[4 * n] = pos.x; out[4 * n + 1] = pos.y; out[4 * n + 2] = pos.z; out[4 * n + 3] = p->fixed ? 1.0 : 0.0;
+      n++;
+    }
+  return n;
+}
+// GetDepthFromTriangulation (extra/utils.cc:193-205) and the depth-filter helpers, for direct checks
+int sdvl_ref_triangulate(const double *pose7, const double *v_ref3, const double *v_cur3, double *depth) {
+  return Tracker::DepthFromTriangulation(ToSE3(pose7), Vec3{v_ref3[0], v_ref3[1], v_ref3[2]}, Vec3{v_cur3[0], v_cur3[1], v_cur3[2]}, depth) ? 1 : 0;
+}
+double sdvl_ref_pdf_normal(double mean, double sd, double x) { return Tracker::PDFNormal(mean, sd, x); }
+double sdvl_ref_compute_tau(const double *pose7, const double *v3, double depth, double px_error_angle) {
+  return Tracker::ComputeTau(ToSE3(pose7), Vec3{v3[0], v3[1], v3[2]}, depth, px_error_angle);
+}
 int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_ref_frame_stats *out) {
   Tracker *tr = static_cast<Tracker *>(t);
   const FrameStats s = tr->HandleFrame(img, stride);

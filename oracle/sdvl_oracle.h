@@ -87,6 +87,10 @@ void *sdvl_ref_tracker_create(const sdvl_ref_params *p, int w, int h, const doub
 void sdvl_ref_tracker_destroy(void *t);
 void sdvl_ref_tracker_use_mapper(void *t, int on, int max_search_keyframes, int max_keyframes, double map_scale, double scale_min_dist);
 void sdvl_ref_tracker_map_stats(void *t, int *out6);
+int sdvl_ref_tracker_mapper_points(void *t, int cap, double *out_xyzc);
+int sdvl_ref_triangulate(const double *pose7, const double *v_ref3, const double *v_cur3, double *depth);
+double sdvl_ref_pdf_normal(double mean, double sd, double x);
+double sdvl_ref_compute_tau(const double *pose7, const double *v3, double depth, double px_error_angle);
 int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_ref_frame_stats *out);
 
 #ifdef __cplusplus

@@ -100,7 +100,7 @@ double Point::PDFNormal(double mean, double sd, double x) {
 
 // point.cc:64-100
 void Point::Update(const shared_ptr<Frame> &frame, double depth, double px_error_angle) {
-  shared_ptr<Frame> f0 = feature_->GetFrame();
+  Frame *f0 = feature_->GetFrameRaw();
   const SE3 pose = f0->GetPose() * frame->GetPose().Inverse();
   const double tau = ComputeTau(pose, feature_->GetVector(), depth, px_error_angle);
   const double tau_inverse = 0.5 * (1.0 / std::max(0.0000001, depth - tau) - 1.0 / (depth + tau));
@@ -144,7 +144,7 @@ bool Point::HasConverged() {
 // point.cc:180-187
 bool Point::SeenFrom(const shared_ptr<Frame> &frame) const {
   for (auto it = features_.begin(); it != features_.end(); it++) {
-    shared_ptr<Frame> f = (*it)->GetFrame();
+    Frame *f = (*it)->GetFrameRaw();
     if (f && frame->GetID() == f->GetID()) return true;
   }
   return false;
@@ -299,13 +299,12 @@ bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs) {
     if (!point->ToDelete()) {
       const Vector3d pos = point->GetPosition();
       if (cur_->IsPointVisible(pos)) {
-        shared_ptr<Feature> feature = point->GetInitFeature();
-        shared_ptr<Frame> f0 = feature->GetFrame();
+        Feature *feature = point->GetInitFeatureRaw();
+        Frame *f0 = feature->GetFrameRaw();
         const double distance = cur_->DistanceTo(*f0);
         if (!(distance / depth_mean_ < 0.01)) {
           reqs->emplace_back();
-          FillRequestFromFeature(&reqs->back(), cur_.get(), feature.get(), f0.get(), point->GetInverseDepth(), point->GetStd(), false,
-                                 Vector2d(0, 0));
+          FillRequestFromFeature(&reqs->back(), cur_.get(), feature, f0, point->GetInverseDepth(), point->GetStd(), false, Vector2d(0, 0));
           w.req = static_cast<int>(reqs->size()) - 1 - req_base_;
         }
       }
@@ -322,7 +321,7 @@ void MapperMap::ApplyCandidates(const sdvl_search_res *res_all) {
   const int min_kf_id = last_kf_->GetKeyframeID() - 2 * Config::MaxSearchKeyframes();
   vector<char> erase(candidates_.size(), 0);
   for (const CandWork &w : cand_work_) {
-    shared_ptr<Point> point = candidates_[w.index];
+    const shared_ptr<Point> &point = candidates_[w.index];
     if (point->ToDelete()) {
       DeletePoint(point);
       erase[w.index] = 1;
@@ -330,15 +329,15 @@ void MapperMap::ApplyCandidates(const sdvl_search_res *res_all) {
     }
     const Vector3d pos = point->GetPosition();
     if (!cur_->IsPointVisible(pos)) {
-      shared_ptr<Frame> lf = point->GetLastFeature()->GetFrame();
+      Frame *lf = point->GetLastFeature()->GetFrameRaw();
       if (lf->GetKeyframeID() < min_kf_id) {
         DeletePoint(point);
         erase[w.index] = 1;
       }
       continue;
     }
-    shared_ptr<Feature> feature = point->GetInitFeature();
-    shared_ptr<Frame> f0 = feature->GetFrame();
+    Feature *feature = point->GetInitFeatureRaw();
+    Frame *f0 = feature->GetFrameRaw();
     const double distance = cur_->DistanceTo(*f0);
     if (distance / depth_mean_ < 0.01) continue;
     const sdvl_search_res &r = res[w.req];
@@ -384,11 +383,11 @@ void MapperMap::CheckConnections() {
     if (!point || point->ToDelete()) continue;
     std::list<shared_ptr<Feature>> &ffeatures = point->GetFeatures();
     for (auto fit = ffeatures.begin(); fit != ffeatures.end(); fit++) {
-      shared_ptr<Frame> ff = (*fit)->GetFrame();
+      Frame *ff = (*fit)->GetFrameRaw();
       if (ff->ToDelete()) continue;
       if (ff->GetID() == cur_->GetID()) continue;
       auto &e = kfs[ff->GetID()];
-      e.first = ff;
+      if (!e.first) e.first = (*fit)->GetFrame();
       e.second++;
     }
   }
@@ -444,8 +443,7 @@ void MapperMap::EmitConnectionsPoints(vector<sdvl_search_req> *reqs) {
     if (!cur_->Project(pt->GetPosition(), &pos)) continue;
     if (!camera_->IsInsideImage(Vector2i(static_cast<int>(pos(0)), static_cast<int>(pos(1))), Config::PatchSize())) continue;
     reqs->emplace_back();
-    shared_ptr<Frame> f0 = feature->GetFrame();
-    FillRequestFromFeature(&reqs->back(), cur_.get(), feature.get(), f0.get(), pt->GetInverseDepth(), pt->GetStd(), pt->IsFixed(), pos);
+    FillRequestFromFeature(&reqs->back(), cur_.get(), feature.get(), feature->GetFrameRaw(), pt->GetInverseDepth(), pt->GetStd(), pt->IsFixed(), pos);
     acp_work_.push_back({pt, static_cast<int>(reqs->size()) - 1 - req_base_});
   }
 }
@@ -591,7 +589,7 @@ void MapperMap::CheckRedundantKeyframes() {
       if (size > min_features) {
         int nmatches = 0;
         for (auto fit = ffeatures.begin(); fit != ffeatures.end(); fit++) {
-          shared_ptr<Frame> fkf = (*fit)->GetFrame();
+          Frame *fkf = (*fit)->GetFrameRaw();
           if (fkf->ToDelete() || fkf->GetID() == kf->GetID()) continue;
           if ((*fit)->GetLevel() <= level1 + 1) {
             nmatches++;

@@ -350,16 +350,17 @@ void FastDetector::FilterCorners(const vector<Image> &pyramid, const vector<Vect
 // feature.cc:28-56
 // (the reference sizes descriptor_ to 32 bytes in every ctor; here the storage appears with SetDescriptor — features the
 //  tracker creates never get a descriptor, feature_align.cc:132, and there are ~200 of them per frame)
-Feature::Feature(const shared_ptr<Frame> &f, const Vector2d &p, int l) : frame_(f), point_(nullptr), p2d_(p), level_(l) {
+Feature::Feature(const shared_ptr<Frame> &f, const Vector2d &p, int l) : frame_(f), frame_raw_(f.get()), point_(nullptr), p2d_(p), level_(l) {
   v_ = f->GetCamera()->Unproject(p2d_);
   has_descriptor_ = false;
 }
-Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, int l) : frame_(f), point_(ft), p2d_(p), level_(l) {
+Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, int l)
+    : frame_(f), frame_raw_(f.get()), point_(ft), p2d_(p), level_(l) {
   v_ = f->GetCamera()->Unproject(p2d_);
   has_descriptor_ = false;
 }
 Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, const Vector3d &v, int l)
-    : frame_(f), point_(ft), p2d_(p), v_(v), level_(l) {
+    : frame_(f), frame_raw_(f.get()), point_(ft), p2d_(p), v_(v), level_(l) {
   has_descriptor_ = false;
 }
 
@@ -399,7 +400,7 @@ void Point::InitFixed(const shared_ptr<Feature> &f, double depth, double sigma2,
 // point.cc:128-142
 Vector3d Point::GetPosition() const {
   if (fixed_) return p3d_;
-  shared_ptr<Frame> fr = feature_->GetFrame();
+  Frame *fr = feature_->GetFrameRaw();
   const SE3 se3 = fr->GetWorldPose();
   const Vector3d &v = feature_->GetVector();
   const double s = 1.0 / rho_;
@@ -915,7 +916,7 @@ void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared
       Feature *feature = point->GetInitFeatureRaw();
       if (!feature) continue;
       Candidate c{e.src, -1};
-      shared_ptr<Frame> ref_frame = feature->GetFrame();
+      Frame *ref_frame = feature->GetFrameRaw();
       if (ref_frame) {
         reqs->emplace_back();
         sdvl_search_req &rq = reqs->back();
@@ -1643,6 +1644,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
         if (!reqs.empty()) Matcher::SearchPoints(dev_, reqs, cam, &res);
         if (res.empty()) res.resize(1);
       };
+      std::unique_ptr<StageClock> sub(new StageClock(ST_MAP_CANDIDATES));
       for (;;) {  // UpdateCandidates, one occurrence pass at a time
         vector<char> more(M, 0);
         ParallelFor(M, [&](int k) { more[k] = mm[k]->EmitCandidates(&per[k]) ? 1 : 0; });
@@ -1655,6 +1657,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       vector<int> kf_idx;
       for (int k = 0; k < M; k++)
         if (mm[k]->IsKeyframeUpdate()) kf_idx.push_back(k);
+      sub.reset(new StageClock(ST_MAP_CONNECTIONS));
       if (!kf_idx.empty()) {
         const int K = static_cast<int>(kf_idx.size());
         ParallelFor(K, [&](int q) {
@@ -1669,6 +1672,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
           m->ApplyConnectionsPoints(res.data() + begin[kf_idx[q]]);
           need[q] = m->PrepareInitCandidates() ? 1 : 0;
         });
+        sub.reset(new StageClock(ST_MAP_INIT));
         vector<shared_ptr<Frame>> to_filter;
         for (int q = 0; q < K; q++)
           if (need[q]) to_filter.push_back(mm[kf_idx[q]]->CurrentFrame());
@@ -1679,7 +1683,9 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
           ParallelFor(K, [&](int q) { if (need[q]) mm[kf_idx[q]]->ApplyInitCandidates(res.data() + begin[kf_idx[q]]); });
         }
       }
+      sub.reset(new StageClock(ST_MAP_FINISH));
       ParallelFor(M, [&](int k) { mm[k]->FinishUpdate(); });
+      sub.reset();
     }
   }
   clk.reset();

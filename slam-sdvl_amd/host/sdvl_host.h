@@ -152,7 +152,9 @@ class Feature {
   Feature(const std::shared_ptr<Frame> &f, const std::shared_ptr<Point> &ft, const Vector2d &p, int l);
   Feature(const std::shared_ptr<Frame> &f, const std::shared_ptr<Point> &ft, const Vector2d &p, const Vector3d &v, int l);
   std::shared_ptr<Frame> GetFrame() { return frame_.lock(); }
-  void SetFrame(const std::shared_ptr<Frame> &f) { frame_ = f; }
+  // the frame without reference-count traffic (per-candidate loops); null once the frame is gone
+  Frame *GetFrameRaw() const { return frame_.expired() ? nullptr : frame_raw_; }
+  void SetFrame(const std::shared_ptr<Frame> &f) { frame_ = f; frame_raw_ = f.get(); }
   std::shared_ptr<Point> GetPoint() const { return point_; }
   Point *GetPointRaw() const { return point_.get(); }  // no reference-count traffic in the per-frame loops
   void SetPoint(const std::shared_ptr<Point> &p) { point_ = p; }
@@ -167,6 +169,7 @@ class Feature {
 
  private:
   std::weak_ptr<Frame> frame_;  // the reference holds a shared_ptr (a frame<->feature cycle it never breaks)
+  Frame *frame_raw_ = nullptr;
   std::shared_ptr<Point> point_;
   Vector2d p2d_;
   Vector3d v_;
@@ -236,9 +239,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void SetKeyframe() { is_keyframe_ = true; }
   void FilterCorners();
   static void FilterCornersBatch(const std::vector<std::shared_ptr<Frame>> &frames);
-  SE3 &GetPose() { return pose_; }
   const SE3 &GetPose() const { return pose_; }
-  void SetPose(const SE3 &se3) { pose_ = se3; }
+  void SetPose(const SE3 &se3) { pose_ = se3; world_valid_ = false; }
   std::vector<Image> &GetPyramid();  // host mirror is filled on first call
   std::vector<std::shared_ptr<Feature>> &GetFeatures() { return features_; }
   std::vector<Vector3i> &GetCorners();  // host mirror of the HBM corner list, filled on first call
@@ -253,8 +255,12 @@ class Frame : public std::enable_shared_from_this<Frame> {
   int GetHeight() const { return height_; }
   int GetID() const { return id_; }
   void SetID(int id) { id_ = id; }
-  SE3 GetWorldPose() const { return pose_.Inverse(); }
-  Vector3d GetWorldPosition() const { return pose_.Inverse().GetTranslation(); }
+  // pose_.Inverse(), computed once per SetPose (the mapper asks for it for every candidate of every frame)
+  const SE3 &GetWorldPose() const {
+    if (!world_valid_) { world_ = pose_.Inverse(); world_valid_ = true; }
+    return world_;
+  }
+  Vector3d GetWorldPosition() const { return GetWorldPose().GetTranslation(); }
   Vector3d GetRelativePos(const Vector3d &pos) const { return pose_ * pos; }
   void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_back(f); }
   void AddOutlier(const Vector2d &p) { outliers_.push_back(p); }
@@ -291,6 +297,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   bool pyramid_on_host_ = false;
   int width_ = 0, height_ = 0;
   SE3 pose_;
+  mutable SE3 world_;
+  mutable bool world_valid_ = false;
   std::vector<std::shared_ptr<Feature>> features_;
   std::vector<Vector3i> corners_;
   std::vector<int> filtered_corners_;
@@ -505,7 +513,7 @@ class FeatureAlign {
 
 // wall-clock per stage of SDVLBatch::HandleFrames, accumulated (seconds); index = StageId
 enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_POSE, ST_MAPPING,
-               ST_EPILOGUE, ST_MAPPER, ST_TOTAL, ST_COUNT };
+               ST_EPILOGUE, ST_MAPPER, ST_TOTAL, ST_MAP_CANDIDATES, ST_MAP_CONNECTIONS, ST_MAP_INIT, ST_MAP_FINISH, ST_COUNT };
 struct StageTimes {
   double t[ST_COUNT] = {0};
   long steps = 0;

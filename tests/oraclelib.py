@@ -255,6 +255,12 @@ class OracleTracker:
         self.lib.sdvl_ref_tracker_map_stats(C.c_void_p(self.h_), ptr(out, i32p))
         return dict(zip(("candidates", "converged", "initialized", "linked", "connected", "keyframes"), out.tolist()))
 
+    def mapper_points(self, cap=20000):
+        """x y z converged of the live points created by the mapper (bootstrap points excluded)"""
+        out = np.zeros((cap, 4), np.float64)
+        n = self.lib.sdvl_ref_tracker_mapper_points(C.c_void_p(self.h_), cap, ptr(out, f64p))
+        return out[:n].copy()
+
     def close(self):
         if self.h_:
             self.lib.sdvl_ref_tracker_destroy(C.c_void_p(self.h_)); self.h_ = None

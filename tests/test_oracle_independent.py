@@ -289,3 +289,64 @@ def test_undistort_against_float_remap(orc):
         assert (got[outside] == 0).all()                       # BORDER_CONSTANT
     # d0 == 0 -> the reference does not remap at all (camera.cc:46)
     assert np.array_equal(orc.undistort(smooth, TUM_CAM, [0, 0.3, 0, 0, 0]), smooth)
+
+
+def test_mapper_helpers_against_numpy(orc):
+    """GetDepthFromTriangulation (extra/utils.cc:193-205) vs a least-squares solve, PDFNormal (point.cc:203-217) vs the
+    closed form, ComputeTau (point.cc:189-201) vs a direct perturbation of the observation angle"""
+    import ctypes as C
+    from oraclelib import quat_rot
+    lib = orc.lib
+    lib.sdvl_ref_pdf_normal.restype = C.c_double
+    lib.sdvl_ref_pdf_normal.argtypes = [C.c_double] * 3
+    lib.sdvl_ref_compute_tau.restype = C.c_double
+    lib.sdvl_ref_compute_tau.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+    lib.sdvl_ref_triangulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    for _ in range(30):
+        T = orc.se3_exp(rng.normal(size=6) * [0.3, 0.3, 0.1, 0.05, 0.05, 0.05])     # cur <- ref
+        P_ref = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(1.5, 4.0)])
+        v_ref = P_ref / np.linalg.norm(P_ref)
+        P_cur = quat_rot(T[:4]) @ P_ref + T[4:]
+        v_cur = P_cur / np.linalg.norm(P_cur)
+        d = C.c_double()
+        assert lib.sdvl_ref_triangulate(T.ctypes.data, v_ref.ctypes.data, v_cur.ctypes.data, C.byref(d)) == 1
+        A = np.stack([quat_rot(T[:4]) @ v_ref, v_cur], 1)
+        want = np.abs(np.linalg.lstsq(A, -T[4:], rcond=None)[0][0])
+        assert abs(d.value - want) < 1e-9 * max(1.0, want)
+        assert abs(d.value - np.linalg.norm(P_ref)) < 1e-9          # it IS the distance along the reference bearing
+    for mean, sd, x in [(0.5, 0.1, 0.45), (1.0, 2.0, -3.0), (0.2, 1e-3, 0.2)]:
+        want = np.exp(-(x - mean) ** 2 / (2 * sd * sd)) / (sd * np.sqrt(2.0 * 3.14159265))
+        assert abs(lib.sdvl_ref_pdf_normal(mean, sd, x) - want) <= 1e-12 * want
+    assert lib.sdvl_ref_pdf_normal(0.0, 0.0, 0.0) == 0.0
+    # tau: depth change when the observation ray in the second view turns by one pixel-error angle
+    T = orc.se3_exp(np.array([0.3, 0.0, 0.0, 0, 0, 0]))
+    v = np.array([0.0, 0.0, 1.0]); depth = 2.0; ang = 2 * np.arctan(1.0 / (2 * 517.3))
+    tau = lib.sdvl_ref_compute_tau(T.ctypes.data, v.ctypes.data, depth, ang)
+    t = T[4:]; a = v * depth - t
+    alpha = np.arccos(v @ t / np.linalg.norm(t)); beta = np.arccos(a @ -t / (np.linalg.norm(t) * np.linalg.norm(a)))
+    want = np.linalg.norm(t) * np.sin(beta + ang) / np.sin(3.14159265 - alpha - beta - ang) - depth
+    assert abs(tau - want) < 1e-12 and 0.0 < tau < 0.1
+
+
+def test_reference_mapper_reconstructs_the_scene_plane(orc, synth):
+    """independent end-to-end check of the mapper restatement (map.cc + point.cc depth filter): in the synthetic scene
+    every surface point lies on the plane z = 2.  Points the mapper triangulates and filters on its own — no knowledge
+    of the plane past the bootstrap keyframe — must land on it, and the trajectory must stay on the ground truth."""
+    from oraclelib import TUM_CAM, trajectory_pose
+    t = orc.tracker(640, 480, TUM_CAM)
+    t.use_mapper(True)
+    worst = 0.0
+    for k in range(36):
+        st = t.handle_frame(synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, seed=20260001, frame_id=k))
+        worst = max(worst, np.abs(np.array(st.pose[:]) - trajectory_pose(orc, k)).max())
+        if k > 0:
+            assert st.quality == 0 and st.matches >= 100
+    pts = t.mapper_points()
+    ms = t.map_stats()
+    t.close()
+    assert worst < 2e-3
+    conv = pts[pts[:, 3] == 1.0]
+    assert len(conv) >= 60 and ms["initialized"] >= 150 and ms["keyframes"] >= 4
+    err = np.abs(conv[:, 2] - 2.0)
+    assert np.median(err) < 0.01 and np.percentile(err, 90) < 0.04, (np.median(err), np.percentile(err, 90))
