@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
     ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")
     ap.add_argument("--workers", type=int, default=0, help="host threads that execute group-steps (0 = auto)")
+    ap.add_argument("--fibers", type=int, default=1,
+                    help="group-steps a worker thread interleaves, switching at GPU waits (1 = one at a time)")
     ap.add_argument("--mapper", action="store_true",
                     help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip)")
@@ -216,14 +218,25 @@ def main():
     trk.configure()
     ncpu = effective_cpus()
     B, K, Wm = args.seqs, args.steps, args.warmup
-    # one group = one host thread + one HIP stream; the host side is the limiter, so: one group per usable CPU
-    G = args.groups or max(1, min(B // 8 if B >= 8 else 1, max(1, ncpu // max(1, world)), 16))
+    # one group = one HIP stream + one host-side step at a time; workers = host threads.  With a full CPU share (16 per
+    # GPU on the MI355X boxes) one group per worker is best; with fewer CPUs every worker interleaves two groups (fibers),
+    # which hides their GPU waits and is worth ~10 % there.
+    cpus_rank = max(1, ncpu // max(1, world))
+    fibers = args.fibers
+    if args.groups:
+        G = args.groups
+    else:
+        workers_auto = max(1, min(cpus_rank, 16))
+        if fibers <= 1 and cpus_rank < 12 and not args.workers:
+            fibers = 2
+        G = max(1, min(B // 8 if B >= 8 else 1, workers_auto * max(1, fibers)))
     while B % G:
         G -= 1
     Bg = B // G
     threads = args.threads or 1
     trk.set_mapper(args.mapper)
     farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
+    farm.set_fibers(fibers)
     ctxs = [CtxView(pkg, farm.ctx_handle(g)) for g in range(G)]
     ctx = ctxs[0]
 
@@ -242,7 +255,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    workers = args.workers or G
+    workers = args.workers or max(1, G // max(1, fibers))
     # keyframe budget: every keyframe keeps its HBM frame; S-A turns about one frame in five into a keyframe
     farm.reserve(Bg * (4 + (Wm + K + 3) // 4))
     farm.run(ptrs[:1 + Wm], workers)          # bootstrap + warmup (untimed)
@@ -310,7 +323,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
             "config": {"workload": "S-A: synthetic TUM fr1-like 640x480 mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step%s" % (B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
-                       "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "parallelism": "sequences sharded over %d GPU(s)" % world,
+                       "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
                        "lk_iterations_per_request": round(n_lk / max(1, n_s), 2),

@@ -211,6 +211,15 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
                        const uint8_t *border, const uint8_t *patch, int max_its, double *uv_io,
                        uint8_t *converged, int32_t *its);
 
+/* ---- cooperative waits ----------------------------------------------------------------------------------------------
+ * Every entry point that returns results waits for the context's stream.  By default the calling thread sleeps on a
+ * blocking event.  With a hook installed the wait polls instead and calls hook(user, ctx) while the stream is busy: a
+ * host thread that drives several contexts (one per group of sequences) switches to another context's host work there
+ * and comes back when sdvl_ctx_wait_done(ctx) says 1; when nothing else is runnable it sleeps in sdvl_ctx_wait_block. */
+int sdvl_ctx_set_wait_hook(sdvl_ctx *ctx, void (*hook)(void *user, sdvl_ctx *ctx), void *user);
+int sdvl_ctx_wait_done(sdvl_ctx *ctx);
+int sdvl_ctx_wait_block(sdvl_ctx *ctx);
+
 /* ---- input stage: Camera::UndistortImage = cv::undistort(in, out, K, D) (camera.cc:39-67,100-105, main.cc:133) ----
  * d[0..4] = Camera.d1..d5 of the config = (k1, k2, p1, p2, k3).  As in the reference, d[0] == 0 means "no distortion":
  * the image is copied unchanged (Camera::SetDistortions tests d0 only, camera.cc:46). */

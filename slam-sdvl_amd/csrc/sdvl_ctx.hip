@@ -42,9 +42,32 @@ hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
   }
   hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
   if (e != hipSuccess) return e;
-  e = hipEventSynchronize(ctx->wait_event);
+  if (ctx->wait_hook) {
+    while ((e = hipEventQuery(ctx->wait_event)) == hipErrorNotReady) ctx->wait_hook(ctx->wait_user, ctx);
+  } else {
+    e = hipEventSynchronize(ctx->wait_event);
+  }
   if (e == hipSuccess) ctx->stage_off = 0;
   return e;
+}
+
+extern "C" int sdvl_ctx_set_wait_hook(sdvl_ctx *ctx, void (*hook)(void *user, sdvl_ctx *ctx), void *user) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  ctx->wait_hook = hook;
+  ctx->wait_user = user;
+  return SDVL_OK;
+}
+
+// 1 = everything queued before the wait in flight has completed, 0 = still running (never blocks)
+extern "C" int sdvl_ctx_wait_done(sdvl_ctx *ctx) {
+  if (!ctx || !ctx->wait_event) return 1;
+  return hipEventQuery(ctx->wait_event) == hipErrorNotReady ? 0 : 1;
+}
+
+// sleep (no spinning) until the wait in flight has completed
+extern "C" int sdvl_ctx_wait_block(sdvl_ctx *ctx) {
+  if (!ctx || !ctx->wait_event) return SDVL_OK;
+  return hipEventSynchronize(ctx->wait_event) == hipSuccess ? SDVL_OK : SDVL_ERR_HIP;
 }
 
 int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f) {

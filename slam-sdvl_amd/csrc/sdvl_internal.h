@@ -62,6 +62,10 @@ struct sdvl_ctx {
   std::vector<sdvl_frame *> detect_frames;
   std::vector<void *> slabs;  // bulk frame storage, released with the context
   hipEvent_t wait_event = nullptr;  // created with hipEventBlockingSync | hipEventDisableTiming
+  // cooperative waits: when set, sdvl_stream_wait polls the event and calls the hook while the stream is still busy, so a
+  // host thread that drives several contexts can run another one's host stage instead of sleeping
+  void (*wait_hook)(void *user, sdvl_ctx *ctx) = nullptr;
+  void *wait_user = nullptr;
   // per-kernel timing (HIP events on `stream`)
   int timing = 0;
   std::vector<KernelTimer> timers;

@@ -1,5 +1,7 @@
 // capi.cc — flat C entry points over the host layer (sdvl_host.h) for the Python harness (tests, smoke, bench):
 // B independent SDVL trackers on one MI355X stepping together through sdvl::SDVLBatch.
+#include <ucontext.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -187,39 +189,160 @@ struct Farm {
   std::vector<char> busy;
   bool failed = false;
 
+  int fibers_per_worker = 1;  // > 1: a worker interleaves that many group-steps, switching at every GPU wait
+
+  // next (group, step) for a worker: the idle group that is furthest behind.  Returns -1 when nothing is left, -2 when
+  // every remaining group is busy elsewhere (only with `may_block` false; otherwise it waits for one to come free).
+  int TakeGroup(bool may_block) {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      if (failed) return -1;
+      int best = -1, remaining = 0;
+      for (int k = 0; k < G; k++) {
+        if (done[k] < n_steps) remaining++;
+        if (!busy[k] && done[k] < n_steps && (best < 0 || done[k] < done[best])) best = k;
+      }
+      if (remaining == 0) return -1;
+      if (best >= 0) { busy[best] = 1; return best; }
+      if (!may_block) return -2;
+      cv_work.wait(lk);
+    }
+  }
+
+  int StepGroup(int g) {
+    const int total = G * Bg;
+    const int s = done[g];  // only the owner of a busy group reads or writes its counter
+    const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
+    return sdvlh_batch_step_device(batches[g], dev_frames + off, stride, out + off);
+  }
+
+  void FinishGroup(int g, int rc) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      if (rc != 0) { failed = true; err = sdvlh_last_error(); }
+      done[g]++;
+      busy[g] = 0;
+    }
+    cv_work.notify_all();
+  }
+
   // A worker repeatedly takes the idle group that is furthest behind and executes its next step, so a descheduled or
   // throttled thread delays one group-step, not a whole group.
   void RunShare() {
-    const int total = G * Bg;
     for (;;) {
-      int g = -1;
-      {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-          if (failed) return;
-          int best = -1, remaining = 0;
-          for (int k = 0; k < G; k++) {
-            if (done[k] < n_steps) remaining++;
-            if (!busy[k] && done[k] < n_steps && (best < 0 || done[k] < done[best])) best = k;
-          }
-          if (remaining == 0) return;
-          if (best >= 0) { g = best; busy[g] = 1; break; }
-          cv_work.wait(lk);
-        }
-      }
-      const int s = done[g];
-      const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
-      const int rc = sdvlh_batch_step_device(batches[g], dev_frames + off, stride, out + off);
-      {
-        std::lock_guard<std::mutex> lk(m);
-        if (rc != 0) { failed = true; err = sdvlh_last_error(); }
-        done[g]++;
-        busy[g] = 0;
-      }
-      cv_work.notify_all();
+      const int g = TakeGroup(true);
+      if (g < 0) return;
+      FinishGroup(g, StepGroup(g));
     }
   }
+
+  void RunShareFibers();
 };
+
+// ---- cooperative group-steps -------------------------------------------------------------------------------------
+// A group-step spends ~40 % of its time blocked on its own stream (alignment, search, pose, filter results).  With
+// fibers_per_worker > 1 a worker thread runs several group-steps on separate stacks (ucontext); the library's wait hook
+// (sdvl_ctx_set_wait_hook) switches to another fiber whenever a step would sleep, and the thread only sleeps — in
+// hipEventSynchronize, no spinning: the CPU quota is the scarce resource — when every fiber is waiting for the GPU.
+namespace {
+struct Fiber {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  Farm *farm = nullptr;
+  int group = -1;      // -1 = free
+  int rc = 0;
+  bool finished = true;
+  sdvl_ctx *waiting_on = nullptr;
+  // per-thread state of the host layer, saved across switches
+  Device *tls_device = nullptr;
+  StageTimes *tls_stage = nullptr;
+};
+struct FiberScheduler {
+  ucontext_t main;
+  Fiber *current = nullptr;
+};
+thread_local FiberScheduler *g_sched = nullptr;
+
+void FiberWaitHook(void *, sdvl_ctx *ctx) {
+  FiberScheduler *s = g_sched;
+  if (!s || !s->current) {  // not on a fiber (plain batch use): sleep like the default wait
+    sdvl_ctx_wait_block(ctx);
+    return;
+  }
+  Fiber *f = s->current;
+  f->waiting_on = ctx;
+  f->tls_device = Device::Current();
+  f->tls_stage = StageTimes::Active();
+  swapcontext(&f->ctx, &s->main);
+  Device::SetCurrent(f->tls_device);
+  StageTimes::Active() = f->tls_stage;
+  f->waiting_on = nullptr;
+}
+
+void FiberMain(unsigned lo, unsigned hi) {
+  Fiber *f = reinterpret_cast<Fiber *>((static_cast<uintptr_t>(hi) << 32) | lo);
+  f->rc = f->farm->StepGroup(f->group);
+  f->finished = true;
+  // returning ends the context: uc_link takes the thread back to the scheduler
+}
+}  // namespace
+
+void Farm::RunShareFibers() {
+  FiberScheduler sched;
+  g_sched = &sched;
+  std::vector<Fiber> fibers(fibers_per_worker);
+  for (Fiber &f : fibers) {
+    f.stack.resize(1 << 20);
+    f.farm = this;
+  }
+  bool no_more = false;
+  for (;;) {
+    int active = 0;
+    for (Fiber &f : fibers) {  // give every free fiber a group-step
+      if (f.group < 0 && !no_more) {
+        const int g = TakeGroup(false);
+        if (g == -1) no_more = true;
+        if (g >= 0) {
+          f.group = g;
+          f.finished = false;
+          f.waiting_on = nullptr;
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = f.stack.data();
+          f.ctx.uc_stack.ss_size = f.stack.size();
+          f.ctx.uc_link = &sched.main;
+          const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
+          makecontext(&f.ctx, reinterpret_cast<void (*)()>(FiberMain), 2, static_cast<unsigned>(p & 0xFFFFFFFFu), static_cast<unsigned>(p >> 32));
+        }
+      }
+      if (f.group >= 0) active++;
+    }
+    if (active == 0) {
+      if (no_more) break;
+      const int g = TakeGroup(true);  // everything left is busy on other workers: wait for one (or for the end)
+      if (g < 0) break;
+      FinishGroup(g, StepGroup(g));   // no fiber needed: nothing else to overlap with right now
+      continue;
+    }
+    bool progressed = false;
+    for (Fiber &f : fibers) {
+      if (f.group < 0) continue;
+      if (f.waiting_on && !sdvl_ctx_wait_done(f.waiting_on)) continue;  // its stream is still busy
+      sched.current = &f;
+      swapcontext(&sched.main, &f.ctx);
+      sched.current = nullptr;
+      progressed = true;
+      if (f.finished) {
+        FinishGroup(f.group, f.rc);
+        f.group = -1;
+      }
+    }
+    if (!progressed) {  // every fiber waits for the GPU: sleep on the first one's event
+      for (Fiber &f : fibers)
+        if (f.group >= 0 && f.waiting_on) { sdvl_ctx_wait_block(f.waiting_on); break; }
+    }
+  }
+  g_sched = nullptr;
+}
 
 void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4, const double *plane4, const double *first_poses7,
                         int host_threads_per_group) {
@@ -234,6 +357,14 @@ void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4
     f->batches.push_back(b);
   }
   return f;
+}
+
+// n > 1: every worker thread interleaves n group-steps and switches between them at GPU waits (0 / 1 = one at a time)
+void sdvlh_farm_set_fibers(void *fp, int n) {
+  Farm *f = static_cast<Farm *>(fp);
+  f->fibers_per_worker = n > 1 ? n : 1;
+  for (void *d : f->devices)
+    sdvl_ctx_set_wait_hook(static_cast<Device *>(d)->ctx(), f->fibers_per_worker > 1 ? FiberWaitHook : nullptr, nullptr);
 }
 
 void sdvlh_farm_destroy(void *fp) {
@@ -276,7 +407,11 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
     f->failed = false;
   }
   std::vector<std::thread> threads;
-  for (int w = 0; w < W; w++) threads.emplace_back([f] { f->RunShare(); });
+  for (int w = 0; w < W; w++)
+    threads.emplace_back([f] {
+      if (f->fibers_per_worker > 1) f->RunShareFibers();
+      else f->RunShare();
+    });
   for (auto &t : threads) t.join();
   if (f->failed) { g_err = f->err; return -1; }
   return 0;

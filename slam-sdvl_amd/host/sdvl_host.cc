@@ -575,9 +575,10 @@ void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
   vector<sdvl_frame *> devs(n);
   for (int i = 0; i < n; i++) devs[i] = frames[i]->dev_;
   // corners + Shi-Tomasi scores + descriptors of all frames in one round trip
-  static thread_local vector<int32_t> xyl;
-  static thread_local vector<double> scores;
-  static thread_local vector<uint8_t> desc;
+  // scratch owned by the Device (= one group): a host thread may interleave several groups, so nothing here is per thread
+  vector<int32_t> &xyl = dev->scratch_xyl;
+  vector<double> &scores = dev->scratch_scores;
+  vector<uint8_t> &desc = dev->scratch_desc;
   vector<int32_t> counts(n);
   const size_t cap = SDVL_MAX_CORNERS;
   if (xyl.size() < n * cap * 3) xyl.resize(n * cap * 3);

@@ -52,6 +52,9 @@ class Device {
   void Check(int rc, const char *what) const;
   static Device *Current();
   static void SetCurrent(Device *d);
+  std::vector<int32_t> scratch_xyl;  // Frame::FilterCornersBatch round-trip buffers
+  std::vector<double> scratch_scores;
+  std::vector<uint8_t> scratch_desc;
 
  private:
   sdvl_ctx *ctx_ = nullptr;

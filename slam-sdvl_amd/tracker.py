@@ -170,6 +170,11 @@ class TrackerFarm:
         if self.lib.sdvlh_farm_reserve(self.h, int(frames_per_group)) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
 
+    def set_fibers(self, n):
+        """n > 1: every worker thread interleaves n group-steps, switching at GPU waits (use G = n * workers groups)"""
+        self.lib.sdvlh_farm_set_fibers.argtypes = [C.c_void_p, C.c_int]
+        self.lib.sdvlh_farm_set_fibers(self.h, int(n))
+
     def alloc_stats(self, n_steps):
         """output records for run(); touched here so that the workers do not take the first-touch page faults"""
         out = (FrameStats * (n_steps * self.G * self.Bg))()

@@ -149,3 +149,34 @@ def test_closed_loop_with_reference_mapper(trk, orc, synth):
 def test_closed_loop_with_reference_mapper_batched(trk, orc, synth):
     worst, _ = run_mapper_case(trk, orc, synth, B=4, n_frames=16, threads=3)
     assert worst <= POSE_TOL
+
+
+def test_farm_fibers_give_identical_results(trk, orc, synth):
+    """TrackerFarm with cooperative group-steps (a worker thread interleaves two groups, switching at GPU waits) must
+    produce exactly the per-frame results of the plain one-step-at-a-time farm"""
+    import importlib
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    G, Bg, n_steps = 4, 3, 7
+    n = G * Bg
+    trk.configure()
+
+    def run(fibers, workers):
+        farm = trk.TrackerFarm(0, G, Bg, 640, 480, TUM_CAM)
+        farm.set_fibers(fibers)
+        ctx = B.CtxView(sdvl, farm.ctx_handle(0))
+        fb = 640 * 480
+        buf = ctx.malloc(n * n_steps * fb)
+        for k in range(n_steps):
+            views = [B.make_view(sdvl, trajectory_pose(orc, k, XI * (1.0 + 0.1 * i)), 20260001 + i, k) for i in range(n)]
+            ctx.render(views, buf + k * n * fb)
+        ptrs = (buf + (np.arange(n_steps, dtype=np.uint64)[:, None] * n + np.arange(n, dtype=np.uint64)[None, :]) * fb).astype(np.uint64)
+        st = farm.run(ptrs, workers)
+        out = [(s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas, tuple(s.pose[:])) for s in st]
+        farm.close()
+        return out
+
+    plain = run(1, 4)
+    coop = run(2, 2)
+    assert plain == coop
+    assert all(r[1] == 0 and r[4] >= 100 for r in plain[n:])      # tracking, not idling
