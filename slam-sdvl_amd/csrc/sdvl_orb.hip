@@ -162,6 +162,23 @@ __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restric
   }
 }
 
+// header + corners (+ descriptors) of a frame -> one contiguous row, in 16-byte units (sdvl_filter_inputs)
+__global__ __launch_bounds__(256) void filter_gather_kernel(const OrbJob *__restrict__ jobs, uint4 *__restrict__ dst, int row_units, int ccap,
+                                                            int with_desc) {
+  const OrbJob &job = jobs[blockIdx.y];
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= row_units) return;
+  uint4 v;
+  if (u <= ccap) {  // header (unit 0) and corner records: contiguous in the frame, starting at the header
+    v = reinterpret_cast<const uint4 *>(job.n_ptr)[u];
+  } else if (with_desc) {
+    v = reinterpret_cast<const uint4 *>(job.desc)[u - (ccap + 1)];
+  } else {
+    return;
+  }
+  dst[static_cast<size_t>(blockIdx.y) * row_units + u] = v;
+}
+
 int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *d_out_desc, double *d_out_score,
               OrbJob **d_jobs, int *max_n) {
   const size_t bytes = sizeof(OrbJob) * n;
@@ -280,11 +297,23 @@ int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap,
     SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
     if (desc) SDVL_REQUIRE(ctx, frames[i]->desc_valid, "frame has no ORB descriptors (call sdvl_orb_describe)");
   }
-  const int ccap = cap < SDVL_MAX_CORNERS ? cap : SDVL_MAX_CORNERS;
-  // device layout per frame i: scores[ccap] doubles | then everything is copied out of the frames themselves
-  const size_t sc_bytes = sizeof(double) * static_cast<size_t>(n) * ccap;
+  // rows only as long as they have to be: the largest corner count when the host already knows every count
+  int ccap = cap < SDVL_MAX_CORNERS ? cap : SDVL_MAX_CORNERS;
+  {
+    int known_max = 0;
+    bool all_known = true;
+    for (int i = 0; i < n; i++) {
+      const int c = frames[i]->hdr_stale ? 0 : frames[i]->v.n_corners;
+      if (c < 0) all_known = false;
+      else known_max = c > known_max ? c : known_max;
+    }
+    if (all_known && known_max < ccap) ccap = known_max > 0 ? known_max : 1;
+  }
+  // device layout: scores[n][ccap] doubles | n rows of {header + corners[ccap] (+ descriptors[ccap])} gathered from the
+  // frames by one kernel, so that everything returns in ONE device-to-host copy
+  const size_t sc_bytes = (sizeof(double) * static_cast<size_t>(n) * ccap + 255) / 256 * 256;
   const size_t row = sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1) + (desc ? static_cast<size_t>(ccap) * 32 : 0);
-  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, sc_bytes, false);
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, sc_bytes + row * n, false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, sc_bytes + row * n, true);
   if (rc) return rc;
   OrbJob *d_jobs = nullptr;
@@ -293,17 +322,14 @@ int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap,
   if (rc) return rc;
   max_n = max_n > ccap ? ccap : max_n;
   if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
+  {
+    const int units = (ccap + 1) + (desc ? 2 * ccap : 0);  // 16-byte units per row
+    SDVL_LAUNCH(ctx, "filter_gather", filter_gather_kernel, dim3((units + 255) / 256, n), dim3(256), static_cast<const OrbJob *>(d_jobs),
+                reinterpret_cast<uint4 *>(static_cast<uint8_t *>(ctx->d_out) + sc_bytes), static_cast<int>(row / 16), ccap, desc ? 1 : 0);
+  }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   uint8_t *h = static_cast<uint8_t *>(ctx->h_out);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_out, sc_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  for (int i = 0; i < n; i++) {  // header + corners (+ descriptors) of every frame, then ONE wait
-    uint8_t *dst = h + sc_bytes + row * i;
-    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst, frames[i]->v.corner_hdr, sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1),
-                                       hipMemcpyDeviceToHost, ctx->stream));
-    if (desc)
-      SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst + sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1), frames[i]->v.desc,
-                                         static_cast<size_t>(ccap) * 32, hipMemcpyDeviceToHost, ctx->stream));
-  }
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_out, sc_bytes + row * n, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   for (int i = 0; i < n; i++) {
     const uint8_t *src = h + sc_bytes + row * i;

@@ -1582,6 +1582,14 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
 
   // ---- stage 4: mapper stand-in for fresh keyframes (sequential mode, main.cc:148-149): one K3 launch for all
   clk.reset(new StageClock(ST_MAPPING));
+  {  // corner counts of this step's frames (one small copy): the statistics need them, and with them known the keyframe
+     // round trip below returns rows of exactly the right length
+    vector<sdvl_frame *> devs(B);
+    vector<int32_t> counts(B);
+    for (int i = 0; i < B; i++) devs[i] = frames[i]->device();
+    dev_->Check(sdvl_frames_corner_counts(dev_->ctx(), B, devs.data(), counts.data()), "sdvl_frames_corner_counts");
+    for (int i = 0; i < B; i++) stats[i].n_corners = counts[i];
+  }
   {
     vector<shared_ptr<Frame>> kfs;
     vector<int> owner;
@@ -1599,13 +1607,6 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   }
 
   clk.reset(new StageClock(ST_EPILOGUE));
-  {
-    vector<sdvl_frame *> devs(B);
-    vector<int32_t> counts(B);
-    for (int i = 0; i < B; i++) devs[i] = frames[i]->device();
-    dev_->Check(sdvl_frames_corner_counts(dev_->ctx(), B, devs.data(), counts.data()), "sdvl_frames_corner_counts");
-    for (int i = 0; i < B; i++) stats[i].n_corners = counts[i];
-  }
   for (int i = 0; i < B; i++) {
     SDVL &t = *trk_[i];
     FrameStats &st = stats[i];
