@@ -243,6 +243,13 @@ def main():
     my_seqs = shard.sequences_for_rank(rank, world, B)   # independent sequences: no data-path collective
     n_frames = 1 + Wm + K                     # bootstrap keyframe + warmup + timed
     frame_bytes = W_IMG * H_IMG
+    reserve_frames = Bg * (4 + (Wm + K + 3) // 4)   # keyframe budget: S-A turns about one frame in five into a keyframe
+    pkg.load_library().sdvl_frame_footprint.restype = C.c_int64
+    need = B * n_frames * frame_bytes + G * reserve_frames * pkg.load_library().sdvl_frame_footprint(W_IMG, H_IMG, 5)
+    free_b, total_b = torch.cuda.mem_get_info()
+    if need > 0.9 * free_b:
+        raise SystemExit("bench.py: %d sequences x %d steps need %.0f GB of HBM (input frames stay resident, keyframes keep their frame); "
+                         "%.0f GB are free - use fewer --steps or --seqs" % (B, K, need / 1e9, free_b / 1e9))
     buf = ctx.malloc(B * n_frames * frame_bytes)
     for k in range(n_frames):                 # frame-major layout: step k reads B consecutive frames
         views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * k), shard.sequence_seed(g), k) for g in my_seqs]
@@ -256,8 +263,7 @@ def main():
         torch.cuda.synchronize()
 
     workers = args.workers or max(1, G // max(1, fibers))
-    # keyframe budget: every keyframe keeps its HBM frame; S-A turns about one frame in five into a keyframe
-    farm.reserve(Bg * (4 + (Wm + K + 3) // 4))
+    farm.reserve(reserve_frames)              # every keyframe keeps its HBM frame: no hipMalloc inside the run
     farm.run(ptrs[:1 + Wm], workers)          # bootstrap + warmup (untimed)
     farm.stage_times(reset=True)
     for c in ctxs:

@@ -137,6 +137,8 @@ int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_fra
 int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int n, sdvl_frame **out);
 int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f);
 /* pyramid_[0] = img (frame.cc:116): host image -> HBM (async on the context stream, staged through pinned memory) */
+/* HBM bytes one frame of this shape occupies (pyramid + corner / descriptor / cell lists); -1 for an invalid shape */
+int64_t sdvl_frame_footprint(int width, int height, int levels);
 int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stride);
 /* same, image already in HBM (device pointer) */
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride);

@@ -287,6 +287,12 @@ int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_fra
 
 // n frames out of ONE allocation (hipMalloc costs ~0.2 ms and synchronises; a tracker farm turns frames into keyframes
 // all the time).  The slab belongs to the context and is released with it; sdvl_frame_destroy only drops the handle.
+int64_t sdvl_frame_footprint(int width, int height, int levels) {
+  FrameLayout L;
+  if (width < 16 || height < 16 || levels < 1 || levels > SDVL_MAX_LEVELS || !frame_layout(width, height, levels, &L)) return -1;
+  return static_cast<int64_t>(L.bytes);
+}
+
 int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int n, sdvl_frame **out) {
   if (!ctx || !out || n <= 0) return SDVL_ERR_INVALID;
   for (int i = 0; i < n; i++) out[i] = nullptr;
