@@ -463,15 +463,6 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
   SDVL_REQUIRE(ctx, p->patch_size == 8, "only patch_size 8 is supported (one wave64 per 8x8 patch)");
   SDVL_REQUIRE(ctx, p->max_fast_levels >= 1 && p->max_fast_levels <= 4, "bad max_fast_levels");
   SDVL_REQUIRE(ctx, p->max_align_its >= 0 && p->margin >= 4, "bad max_align_its / margin");
-  for (int i = 0; i < n; i++) {
-    const sdvl_search_req &r = reqs[i];
-    SDVL_REQUIRE(ctx, r.cur && r.ref, "null frame in search request");
-    SDVL_REQUIRE(ctx, !r.cur->hdr_stale, "current frame has a new image but no corners (detect or set corners first)");
-    SDVL_REQUIRE(ctx, r.level >= 0 && r.level < r.ref->v.levels, "feature level outside the reference pyramid");
-    SDVL_REQUIRE(ctx, p->max_fast_levels <= r.cur->v.levels, "max_fast_levels exceeds the pyramid depth");
-    if (p->use_orb) SDVL_REQUIRE(ctx, r.cur->v.n_corners == 0 || r.cur->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
-    SDVL_REQUIRE(ctx, r.idepth == r.idepth && r.idepth != 0.0, "inverse depth must be finite and non-zero");
-  }
   // table of distinct (frame, pose) pairs: one entry per frame in practice (a frame has one pose during a launch)
   static thread_local std::vector<SearchFramePose> table;
   static thread_local std::unordered_map<const sdvl_frame *, int> where;
@@ -490,15 +481,29 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     *last = static_cast<int>(table.size()) - 1;
     return *last;
   };
+  // staging layout: requests | workgroup table (<= n entries) | frame table.  The requests are validated and converted in
+  // ONE pass straight into the pinned staging area; the frame table is small and follows.
   const size_t in_bytes = (sizeof(SearchReqDev) * static_cast<size_t>(n) + 255) / 256 * 256;
   const size_t out_bytes = sizeof(sdvl_search_res) * static_cast<size_t>(n);
-  // worst case one table entry per request and side; staged after the requests
-  static thread_local std::vector<SearchReqDev> tmp;
-  tmp.resize(n);
+  const size_t blk_cap_bytes = (sizeof(SearchBlock) * static_cast<size_t>(n) + 255) / 256 * 256;
+  const size_t tab_cap_entries = 512;
+  const size_t tab_cap_bytes = sizeof(SearchFramePose) * tab_cap_entries;
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes + blk_cap_bytes + tab_cap_bytes, &hs, &dsx);
+  if (rc) return rc;
+  SearchReqDev *hreq = static_cast<SearchReqDev *>(hs);
   int last_cur = -1, last_ref = -1;
   for (int i = 0; i < n; i++) {
     const sdvl_search_req &r = reqs[i];
-    SearchReqDev &d = tmp[i];
+    SDVL_REQUIRE(ctx, r.cur && r.ref, "null frame in search request");
+    SDVL_REQUIRE(ctx, !r.cur->hdr_stale, "current frame has a new image but no corners (detect or set corners first)");
+    SDVL_REQUIRE(ctx, r.level >= 0 && r.level < r.ref->v.levels, "feature level outside the reference pyramid");
+    SDVL_REQUIRE(ctx, p->max_fast_levels <= r.cur->v.levels, "max_fast_levels exceeds the pyramid depth");
+    if (p->use_orb) SDVL_REQUIRE(ctx, r.cur->v.n_corners == 0 || r.cur->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
+    SDVL_REQUIRE(ctx, r.idepth == r.idepth && r.idepth != 0.0, "inverse depth must be finite and non-zero");
+    SearchReqDev &d = hreq[i];
     d.cur = lookup(r.cur, r.cur_pose, &last_cur);
     d.ref = lookup(r.ref, r.ref_pose, &last_ref);
     d.level = r.level; d.fixed = r.fixed;
@@ -508,30 +513,31 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
     memcpy(d.desc, r.desc, 32);
   }
-  const size_t tab_bytes = (sizeof(SearchFramePose) * table.size() + 255) / 256 * 256;
   // workgroups: runs of up to kWavesPerBlock consecutive requests that search the same current frame
-  static thread_local std::vector<SearchBlock> blocks;
-  blocks.clear();
+  SearchBlock *hblk = reinterpret_cast<SearchBlock *>(static_cast<uint8_t *>(hs) + in_bytes);
+  int n_blocks = 0;
   for (int i = 0; i < n;) {
     int cnt = 1;
-    while (i + cnt < n && cnt < kWavesPerBlock && tmp[i + cnt].cur == tmp[i].cur) cnt++;
-    blocks.push_back(SearchBlock{i, cnt});
+    while (i + cnt < n && cnt < kWavesPerBlock && hreq[i + cnt].cur == hreq[i].cur) cnt++;
+    hblk[n_blocks++] = SearchBlock{i, cnt};
     i += cnt;
   }
-  const size_t blk_bytes = sizeof(SearchBlock) * blocks.size();
-  void *hs = nullptr, *dsx = nullptr;
-  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
-  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes + tab_bytes + blk_bytes, &hs, &dsx);
-  if (rc) return rc;
-  memcpy(hs, tmp.data(), sizeof(SearchReqDev) * static_cast<size_t>(n));
-  memcpy(static_cast<uint8_t *>(hs) + in_bytes, table.data(), sizeof(SearchFramePose) * table.size());
-  memcpy(static_cast<uint8_t *>(hs) + in_bytes + tab_bytes, blocks.data(), blk_bytes);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + tab_bytes + blk_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const SearchFramePose *d_table = nullptr;
+  if (table.size() <= tab_cap_entries) {
+    memcpy(static_cast<uint8_t *>(hs) + in_bytes + blk_cap_bytes, table.data(), sizeof(SearchFramePose) * table.size());
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + blk_cap_bytes + sizeof(SearchFramePose) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+    d_table = reinterpret_cast<const SearchFramePose *>(static_cast<uint8_t *>(dsx) + in_bytes + blk_cap_bytes);
+  } else {  // more distinct (frame, pose) pairs than the staging reserve: the table travels through the work buffer
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + blk_cap_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, sizeof(SearchFramePose) * table.size(), false);
+    if (rc) return rc;
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_work, table.data(), sizeof(SearchFramePose) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `table` is pageable and reused by the next call
+    d_table = static_cast<const SearchFramePose *>(ctx->d_work);
+  }
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>(blocks.size())), dim3(64 * kWavesPerBlock),
-              static_cast<const SearchReqDev *>(dsx), reinterpret_cast<const SearchFramePose *>(static_cast<uint8_t *>(dsx) + in_bytes),
-              reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes + tab_bytes), c, *p,
+  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>(n_blocks)), dim3(64 * kWavesPerBlock),
+              static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes), c, *p,
               static_cast<sdvl_search_res *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));

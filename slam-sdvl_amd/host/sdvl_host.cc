@@ -902,10 +902,7 @@ void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared
   vector<shared_ptr<Feature>> &features = last_frame->GetFeatures();
   double cur_pose[7];
   frame->GetPose().ToArray(cur_pose);
-  size_t total = 0;
-  for (auto &c : grid_) total += c.size();
-  reqs->reserve(reqs->size() + total);
-  req_base_ = static_cast<int>(reqs->size());
+  req_base_ = static_cast<int>(reqs->size());  // no exact-size reserve here: callers append many trackers to one list
   for (int i = 0; i < size; i++) {
     plan_begin_[i] = static_cast<int>(plan_.size());
     vector<CellEntry> &cell = grid_[cell_order_[i]];
@@ -1026,18 +1023,31 @@ bool FeatureAlign::EmitPoseJob(const shared_ptr<Frame> &frame, PoseBatch *batch)
   const int max_its = Config::MaxRansacIts();
   RandStream peek = *rng_;
   for (int h = 0; h < max_its; h++) batch->rand_idx.push_back(size > 0 ? peek.Next() % size : 0);
-  const int npoints = std::min(Config::MaxRansacPoints(), size);
-  const double sprob = 0.99;
-  for (int supporters = 0; supporters <= size; supporters++) {
-    int nits = max_its;
-    if (size > 0) {
-      const double epsilon = 1.0 - (static_cast<double>(supporters) / static_cast<double>(size));
-      double tmp = 1.0 - epsilon;
-      for (int k = 1; k < npoints; k++) tmp *= tmp;
-      if (!(tmp < 1e-5)) nits = std::min(max_its, static_cast<int>(std::log(1.0 - sprob) / std::log(1.0 - tmp)));
-    }
-    batch->nits.push_back(nits);
+  // the budget table depends on (size, MaxRansacPoints, MaxRansacIts) only: computed once per size and thread (two
+  // log() per entry otherwise, ~20k calls per batch step)
+  struct BudgetCache { int points = -1, its = -1; vector<vector<int32_t>> by_size; };
+  static thread_local BudgetCache cache;
+  if (cache.points != Config::MaxRansacPoints() || cache.its != max_its) {
+    cache.points = Config::MaxRansacPoints();
+    cache.its = max_its;
+    cache.by_size.assign(kMaxDevicePoseObs + 1, vector<int32_t>());
   }
+  vector<int32_t> &table = cache.by_size[size];
+  if (table.empty()) {
+    const int npoints = std::min(Config::MaxRansacPoints(), size);
+    const double sprob = 0.99;
+    for (int supporters = 0; supporters <= size; supporters++) {
+      int nits = max_its;
+      if (size > 0) {
+        const double epsilon = 1.0 - (static_cast<double>(supporters) / static_cast<double>(size));
+        double tmp = 1.0 - epsilon;
+        for (int k = 1; k < npoints; k++) tmp *= tmp;
+        if (!(tmp < 1e-5)) nits = std::min(max_its, static_cast<int>(std::log(1.0 - sprob) / std::log(1.0 - tmp)));
+      }
+      table.push_back(nits);
+    }
+  }
+  batch->nits.insert(batch->nits.end(), table.begin(), table.end());
   batch->jobs.push_back(job);
   return true;
 }
@@ -1492,17 +1502,26 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
 
   // ---- stage 2: FeatureAlign::Reproject, sdvl.cc:193 — all candidates of all trackers in one launch
   {
-    vector<vector<sdvl_search_req>> per(R);
     clk.reset(new StageClock(ST_PREPARE));
-    ParallelFor(R, [&](int k) {
-      SDVL &t = *trk_[run[k]];
-      t.feature_align_.PrepareReproject(t.current_frame_, t.last_frame_, false, &per[k]);
-    });
-    vector<sdvl_search_req> reqs;
+    vector<sdvl_search_req> &reqs = scratch_reqs_;  // keeps its capacity from step to step
+    reqs.clear();
     vector<size_t> begin(R + 1, 0);
-    for (int k = 0; k < R; k++) {
-      begin[k] = reqs.size();
-      reqs.insert(reqs.end(), per[k].begin(), per[k].end());
+    if (threads_ <= 1) {  // one host thread per batch (the farm's case): every tracker appends to the shared request list
+      for (int k = 0; k < R; k++) {
+        SDVL &t = *trk_[run[k]];
+        begin[k] = reqs.size();
+        t.feature_align_.PrepareReproject(t.current_frame_, t.last_frame_, false, &reqs);
+      }
+    } else {
+      vector<vector<sdvl_search_req>> per(R);
+      ParallelFor(R, [&](int k) {
+        SDVL &t = *trk_[run[k]];
+        t.feature_align_.PrepareReproject(t.current_frame_, t.last_frame_, false, &per[k]);
+      });
+      for (int k = 0; k < R; k++) {
+        begin[k] = reqs.size();
+        reqs.insert(reqs.end(), per[k].begin(), per[k].end());
+      }
     }
     begin[R] = reqs.size();
     vector<sdvl_search_res> res;
@@ -1510,7 +1529,10 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     if (R > 0) Matcher::SearchPoints(dev_, reqs, *trk_[run[0]]->camera_, &res);
     clk.reset(new StageClock(ST_FINISH));
     // ---- stage 3: replay of SelectPoints, sdvl.cc:193
-    vector<FeatureAlign::PoseBatch> pb(R);
+    vector<FeatureAlign::PoseBatch> pb(threads_ <= 1 ? 0 : R);
+    FeatureAlign::PoseBatch &all = scratch_pose_;
+    all.jobs.clear(); all.obs.clear(); all.rand_idx.clear(); all.nits.clear();
+    vector<int> job_of(R, -1);
     vector<char> on_device(R, 0);
     ParallelFor(R, [&](int k) {
       const int i = run[k];
@@ -1521,19 +1543,26 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       t.feature_align_.FinishSelect(t.current_frame_, res.data() + begin[k]);
       t.matches_ = t.feature_align_.GetMatches();
       t.attempts_ = t.feature_align_.GetAttempts();
-      if (device_pose) on_device[k] = t.feature_align_.EmitPoseJob(t.current_frame_, &pb[k]) ? 1 : 0;
+      if (device_pose) {
+        if (threads_ <= 1) {  // sequential: straight into the shared batch
+          const int job = static_cast<int>(all.jobs.size());
+          on_device[k] = t.feature_align_.EmitPoseJob(t.current_frame_, &all) ? 1 : 0;
+          if (on_device[k]) job_of[k] = job;
+        } else {
+          on_device[k] = t.feature_align_.EmitPoseJob(t.current_frame_, &pb[k]) ? 1 : 0;
+        }
+      }
     });
     // ---- stage 3b: RANSAC + pose refinement (feature_align.cc:73-82,152-243), one launch pair for every tracker
     clk.reset(new StageClock(ST_POSE));
-    FeatureAlign::PoseBatch all;
-    vector<int> job_of(R, -1);
     vector<sdvl_pose_result> pres;
     vector<int32_t> lists;
-    for (int k = 0; k < R; k++)
-      if (on_device[k]) {
-        job_of[k] = static_cast<int>(all.jobs.size());
-        all.Append(pb[k]);
-      }
+    if (threads_ > 1)
+      for (int k = 0; k < R; k++)
+        if (on_device[k]) {
+          job_of[k] = static_cast<int>(all.jobs.size());
+          all.Append(pb[k]);
+        }
     if (!all.jobs.empty()) {
       pres.resize(all.jobs.size());
       lists.resize(all.obs.size() + 1);

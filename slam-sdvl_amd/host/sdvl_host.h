@@ -587,6 +587,8 @@ class SDVLBatch {
   Device *dev_;
   std::vector<SDVL *> trk_;
   int threads_;
+  std::vector<sdvl_search_req> scratch_reqs_;  // per-step request / pose batches, reused so that they never reallocate
+  FeatureAlign::PoseBatch scratch_pose_;
 };
 
 }  // namespace sdvl

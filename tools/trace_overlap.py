@@ -33,3 +33,17 @@ for s, e, k in rows:
     by[k] = by.get(k, 0) + (e - s)
 for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:14]:
     print("  %-28s %8.1f ms  %5.1f %% of wall" % (k, v / 1e6, 100.0 * v / wall))
+
+# time-weighted histogram of the number of kernels in flight
+ev = []
+for s, e, _ in rows:
+    ev.append((s, 1))
+    ev.append((e, -1))
+ev.sort()
+hist, level, last = {}, 0, ev[0][0]
+for t, d in ev:
+    hist[level] = hist.get(level, 0) + (t - last)
+    last = t
+    level += d
+tot = float(sum(hist.values()))
+print("kernels in flight (share of the window): " + "  ".join("%d: %.1f%%" % (k, 100.0 * v / tot) for k, v in sorted(hist.items())))
