@@ -215,6 +215,7 @@ def main():
     pkg = importlib.import_module("slam-sdvl_amd")
     trk = importlib.import_module("slam-sdvl_amd.tracker")
     shard = importlib.import_module("slam-sdvl_amd.shard")
+    numa_node = None if os.environ.get("SDVL_NO_NUMA_BIND") else trk.bind_to_gpu_numa_node(local_rank)
     trk.configure()
     ncpu = effective_cpus()
     B, K, Wm = args.seqs, args.steps, args.warmup
@@ -329,7 +330,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
             "config": {"workload": "S-A: synthetic TUM fr1-like 640x480 mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step%s" % (B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
-                       "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "parallelism": "sequences sharded over %d GPU(s)" % world,
+                       "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "numa_node": numa_node, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
                        "lk_iterations_per_request": round(n_lk / max(1, n_s), 2),

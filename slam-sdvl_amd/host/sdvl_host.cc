@@ -649,6 +649,13 @@ void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shar
   vector<sdvl_align_job> jobs;
   vector<int> job_of;
   vector<sdvl_align_feature> feats;
+  {
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += pairs[i].first->GetFeatures().size();
+    feats.reserve(total);
+    jobs.reserve(n);
+    job_of.reserve(n);
+  }
   for (int i = 0; i < n; i++) {
     Frame &f1 = *pairs[i].first, &f2 = *pairs[i].second;
     vector<shared_ptr<Feature>> &features = f1.GetFeatures();

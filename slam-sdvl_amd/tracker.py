@@ -57,6 +57,31 @@ def set_device_pose(on):
     load_host_library().sdvlh_set_device_pose(int(bool(on)))
 
 
+def bind_to_gpu_numa_node(gpu=0):
+    """Restrict this process (and the threads it creates later) to the CPUs of the NUMA node the GPU hangs off: the host
+    objects of the trackers, the pinned staging buffers and the doorbell writes then stay on that socket.  Returns the
+    node, or None when the topology cannot be read (nothing is changed then).  Call it before creating devices."""
+    import os
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(gpu)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
 def set_mapper(on):
     """map mode of the batches / farms created afterwards: the reference's mapper in sequential mode (map.cc) instead of
     the plane map stub; the first keyframe is bootstrapped from the scene plane in both modes"""
