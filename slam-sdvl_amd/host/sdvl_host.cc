@@ -814,7 +814,7 @@ void PlaneMap::SeedFromFiltered(const shared_ptr<Frame> &kf) {
   for (int index : kf->GetFilteredCorners()) {
     const Vector3i corner = corners[index];
     const int scale = (1 << corner(2));
-    shared_ptr<Feature> feature = std::make_shared<Feature>(kf, Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
+    shared_ptr<Feature> feature = kf->NewFeature(Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
     if (Config::UseORB()) feature->SetDescriptor(descriptors[index]);
     const Vector3d &v = feature->GetVector();
     const V3 ray = mvec(Rw, {v(0), v(1), v(2)});
@@ -967,7 +967,7 @@ void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_searc
         if (!relocalizing_) {
           shared_ptr<Point> point = src_features[cand.src]->GetPoint();
           point->Promote();
-          shared_ptr<Feature> feature = std::make_shared<Feature>(frame, Vector2d(r->px[0], r->px[1]), r->level);
+          shared_ptr<Feature> feature = frame->NewFeature(Vector2d(r->px[0], r->px[1]), r->level);
           feature->SetPoint(point);
           frame->AddFeature(feature);
           point->SetStatus(Point::P_FOUND);

@@ -181,6 +181,44 @@ class Feature {
   bool has_descriptor_;
 };
 
+// Bump allocator for the many small objects that live and die with one frame (its features): one malloc per chunk instead
+// of one per object.  std::allocate_shared keeps a copy of the allocator — and with it the arena — in every control block,
+// so an arena lives exactly as long as the last object carved out of it (a keyframe's features outlive the tracking step,
+// an ordinary frame's die with it).
+class FrameArena {
+ public:
+  void *Allocate(size_t bytes, size_t align) {
+    size_t at = (off_ + align - 1) / align * align;
+    if (chunks_.empty() || at + bytes > cap_) {
+      cap_ = bytes > kChunk ? bytes : kChunk;
+      chunks_.emplace_back(new char[cap_]);
+      at = 0;
+    }
+    off_ = at + bytes;
+    return chunks_.back().get() + at;
+  }
+
+ private:
+  static constexpr size_t kChunk = 32 * 1024;
+  std::vector<std::unique_ptr<char[]>> chunks_;
+  size_t off_ = 0, cap_ = 0;
+};
+
+template <typename T>
+struct ArenaAllocator {
+  typedef T value_type;
+  std::shared_ptr<FrameArena> arena;
+  explicit ArenaAllocator(const std::shared_ptr<FrameArena> &a) : arena(a) {}
+  template <typename U>
+  ArenaAllocator(const ArenaAllocator<U> &o) : arena(o.arena) {}
+  T *allocate(size_t n) { return static_cast<T *>(arena->Allocate(n * sizeof(T), alignof(T))); }
+  void deallocate(T *, size_t) {}
+  template <typename U>
+  bool operator==(const ArenaAllocator<U> &o) const { return arena == o.arena; }
+  template <typename U>
+  bool operator!=(const ArenaAllocator<U> &o) const { return arena != o.arena; }
+};
+
 // point.h:37-147 — the part the front-end reads or updates (the depth filter itself is map state, out of scope)
 class Point {
  public:
@@ -266,6 +304,11 @@ class Frame : public std::enable_shared_from_this<Frame> {
   Vector3d GetWorldPosition() const { return GetWorldPose().GetTranslation(); }
   Vector3d GetRelativePos(const Vector3d &pos) const { return pose_ * pos; }
   void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_back(f); }
+  // a Feature on this frame whose storage comes from the frame's arena (same object as make_shared<Feature>(frame, ...))
+  std::shared_ptr<Feature> NewFeature(const Vector2d &p, int level) {
+    if (!arena_) arena_ = std::make_shared<FrameArena>();
+    return std::allocate_shared<Feature>(ArenaAllocator<Feature>(arena_), shared_from_this(), p, level);
+  }
   void AddOutlier(const Vector2d &p) { outliers_.push_back(p); }
   int GetNumFeatures() const { return static_cast<int>(features_.size()); }
   int GetNumPoints() const;
@@ -311,6 +354,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   bool corners_on_host_ = true;  // false after a device-side DetectPyramid until GetCorners() mirrors the list
   sdvl_frame *dev_ = nullptr;
   Device *owner_ = nullptr;
+  std::shared_ptr<FrameArena> arena_;
   int kf_id_ = 0;
   bool delete_ = false, selected_ = false;
   std::vector<std::pair<std::shared_ptr<Frame>, int>> connections_;
