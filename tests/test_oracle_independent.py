@@ -350,3 +350,47 @@ def test_reference_mapper_reconstructs_the_scene_plane(orc, synth):
     assert len(conv) >= 60 and ms["initialized"] >= 150 and ms["keyframes"] >= 4
     err = np.abs(conv[:, 2] - 2.0)
     assert np.median(err) < 0.01 and np.percentile(err, 90) < 0.04, (np.median(err), np.percentile(err, 90))
+
+
+def test_image_align_recovers_the_rendered_camera_motion(orc, synth):
+    """independent check of the ImageAlign restatement (image_align.cc:46-267): frames of the textured plane z = 2 rendered
+    from known poses, features with their true depth -> the inverse-compositional Gauss-Newton must land on the pose the
+    renderer used, starting from identity"""
+    from oraclelib import TUM_CAM, trajectory_pose
+    img0 = synth.render(trajectory_pose(orc, 0), TUM_CAM, 640, 480, seed=20260001, frame_id=0)
+    rng = np.random.default_rng(20260200)
+    n = 200
+    px = np.stack([rng.uniform(48, 640 - 48, n), rng.uniform(48, 480 - 48, n)], 1)
+    ray = np.stack([(px[:, 0] - TUM_CAM[2]) / TUM_CAM[0], (px[:, 1] - TUM_CAM[3]) / TUM_CAM[1], np.ones(n)], 1)
+    bearing = ray / np.linalg.norm(ray, axis=1, keepdims=True)
+    depth = 2.0 / bearing[:, 2]
+    for k in (1, 3, 6):
+        imgk = synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, seed=20260001, frame_id=k)
+        r = orc.image_align(img0, imgk, TUM_CAM, px, bearing, depth, np.ones(n, np.uint8), [1, 0, 0, 0, 0, 0, 0])
+        assert r["n"] > 150
+        assert np.abs(r["T"] - trajectory_pose(orc, k)).max() < 2e-3, (k, r["T"], trajectory_pose(orc, k))
+
+
+def test_align_patch_recovers_a_known_shift(orc, synth):
+    """Matcher::AlignPatch restatement (matcher.cc:359-445): template cut at an integer position of an image, search image
+    = the same image shifted by a known sub-pixel offset (bilinear resampling) -> the LK iterations converge onto it"""
+    import scipy.ndimage as ndi
+    from oraclelib import TUM_CAM, trajectory_pose
+    base = synth.render(trajectory_pose(orc, 0), TUM_CAM, 640, 480, seed=20260001, frame_id=0).astype(np.float64)
+    smooth = ndi.gaussian_filter(base, 1.5)
+    img_ref = np.clip(np.rint(smooth), 0, 255).astype(np.uint8)
+    rng = np.random.default_rng(4)
+    n_ok = 0
+    for _ in range(25):
+        sx, sy = rng.uniform(-1.2, 1.2, 2)
+        moved = ndi.shift(smooth, (sy, sx), order=1, mode="nearest")   # moved(y, x) = smooth(y - sy, x - sx)
+        img_cur = np.clip(np.rint(moved), 0, 255).astype(np.uint8)
+        cx, cy = int(rng.integers(60, 580)), int(rng.integers(60, 420))
+        border = img_ref[cy - 5:cy + 5, cx - 5:cx + 5].copy()           # 10x10 around (cx, cy): rows cy-5 .. cy+4
+        patch = border[1:9, 1:9].copy()
+        ok, px = orc.align_patch(img_cur, border, patch, [cx, cy])
+        if ok:
+            n_ok += 1
+            # the patch centre convention of the 8x8 template (pixels cx-4 .. cx+3) puts its content at (cx + sx, cy + sy)
+            assert abs(px[0] - (cx + sx)) < 0.2 and abs(px[1] - (cy + sy)) < 0.2, (sx, sy, px, cx, cy)
+    assert n_ok >= 20
