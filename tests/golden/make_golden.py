@@ -18,7 +18,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from oraclelib import Oracle, Synth, TUM_CAM, trajectory_pose  # noqa: E402
+from oraclelib import Oracle, Synth, TUM_CAM, TUM_DIST, quat_rot, trajectory_pose  # noqa: E402
 
 W, H = 640, 480
 FRAMES = [0, 3]
@@ -37,6 +37,19 @@ def align_features(n, seed):
     valid = np.ones(n, np.uint8)
     valid[::17] = 0
     return px, bearing, depth, valid
+
+
+def pose_matches(orc, n=150, seed=20260400):
+    """matches of a small camera motion with 20 % gross outliers: rows ax, ay, px, py, pz, level; plus 100 rand() draws"""
+    rng = np.random.default_rng(seed)
+    true_pose = orc.se3_exp(np.array([0.04, -0.03, 0.015, 0.006, -0.008, 0.004]))
+    P = np.stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-0.9, 0.9, n), rng.uniform(1.5, 3.0, n)], 1)
+    pc = P @ quat_rot(true_pose[:4]).T + true_pose[4:]
+    a = pc[:, :2] / pc[:, 2:3] + rng.normal(0, 0.4 / TUM_CAM[0], (n, 2))
+    bad = rng.random(n) < 0.2
+    a[bad] += rng.uniform(-40, 40, (int(bad.sum()), 2)) / TUM_CAM[0]
+    obs = np.concatenate([a, P, rng.integers(0, 3, n)[:, None].astype(np.float64)], 1)
+    return obs, orc.se3_exp(np.zeros(6)), orc.rand_stream(100, seed=7)
 
 
 def compute(orc, syn):
@@ -75,6 +88,26 @@ def compute(orc, syn):
         poses.append(list(st.pose)); counts.append([st.matches, st.attempts, st.inliers, st.n_corners, st.keyframe])
     trk.close()
     out["track_pose"] = np.array(poses); out["track_counts"] = np.array(counts, np.int32)
+    # input stage: cv::undistort with the TUM fr1 coefficients
+    und = orc.undistort(img0, TUM_CAM, TUM_DIST)
+    out["undistort_sha256"] = hashlib.sha256(und.tobytes()).hexdigest()
+    out["undistort_row240"] = und[240]
+    # pose from matches: RANSAC + Tukey Gauss-Newton + rescue
+    obs, guess, _ = pose_matches(orc)
+    r = orc.pose_from_matches(TUM_CAM, obs, guess, rand_seed=7)
+    out["pose_T"] = r["pose"]; out["pose_draws"] = r["n_draws"]
+    out["pose_inliers"] = r["inliers"].astype(np.int32); out["pose_outliers"] = r["outliers"].astype(np.int32)
+    # closed loop with the reference's mapper (sequential mode)
+    trk = orc.tracker(W, H, TUM_CAM)
+    trk.use_mapper(True)
+    poses, counts, mstats = [], [], []
+    for k in range(14):
+        st = trk.handle_frame(syn.render(trajectory_pose(orc, k), TUM_CAM, W, H, seed=20260001, frame_id=k))
+        ms = trk.map_stats()
+        poses.append(list(st.pose)); counts.append([st.matches, st.attempts, st.inliers, st.n_corners, st.keyframe])
+        mstats.append([ms[q] for q in ("candidates", "converged", "initialized", "linked", "connected", "keyframes")])
+    trk.close()
+    out["mapper_pose"] = np.array(poses); out["mapper_counts"] = np.array(counts, np.int32); out["mapper_stats"] = np.array(mstats, np.int32)
     return out
 
 

@@ -19,7 +19,7 @@ def golden():
     return np.load(os.path.join(HERE, "golden", "front_end_golden.npz"), allow_pickle=False)
 
 
-def check(got, gold, tol_keys=("align_T", "align_error", "track_pose")):
+def check(got, gold, tol_keys=("align_T", "align_error", "track_pose", "pose_T", "mapper_pose")):
     for k in gold.files:
         g, w = np.asarray(got[k]), gold[k]
         if k in tol_keys:
@@ -74,4 +74,27 @@ def test_hip_path_hits_golden(orc, synth, golden):
         st = batch.step_host([synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, seed=20260001, frame_id=k)])[0]
         assert [st.matches, st.attempts, st.inliers, st.n_corners, st.keyframe] == golden["track_counts"][k].tolist()
         assert np.abs(np.array(st.pose[:]) - golden["track_pose"][k]).max() <= 1e-4
+    batch.close(); dev.close()
+    # input stage, pose stage and the mapper loop
+    from oraclelib import TUM_DIST
+    ctx = sdvl.Context(0)
+    und = ctx.undistort([img0], sdvl.Camera(640, 480, *TUM_CAM), TUM_DIST)[0]
+    assert hashlib.sha256(und.tobytes()).hexdigest() == str(golden["undistort_sha256"])
+    obs, guess, draws = mg.pose_matches(orc)
+    r = ctx.pose_from_matches([(obs, guess, draws)], fx=TUM_CAM[0])[0]
+    assert r["n_draws"] == int(golden["pose_draws"]) and np.array_equal(r["inliers"], golden["pose_inliers"])
+    assert np.array_equal(r["outliers"], golden["pose_outliers"]) and np.abs(r["pose"] - golden["pose_T"]).max() <= 1e-9
+    ctx.close()
+    trk.set_mapper(True)
+    try:
+        dev = trk.HostDevice(0)
+        batch = trk.TrackerBatch(dev, 1, 640, 480, TUM_CAM)
+    finally:
+        trk.set_mapper(False)
+    for k in range(14):
+        st = batch.step_host([synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, seed=20260001, frame_id=k)])[0]
+        assert [st.matches, st.attempts, st.inliers, st.n_corners, st.keyframe] == golden["mapper_counts"][k].tolist()
+        assert np.abs(np.array(st.pose[:]) - golden["mapper_pose"][k]).max() <= 1e-4
+        ms = batch.map_stats(0)
+        assert [ms[q] for q in ("candidates", "converged", "initialized", "linked", "connected", "keyframes")] == golden["mapper_stats"][k].tolist()
     batch.close(); dev.close()
