@@ -294,15 +294,21 @@ bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs) {
     if (occurrence_[k] != pass_) continue;
     any = true;
     Point *point = candidates_[k].get();
-    CandWork w{k, -1};
-    // the checks that precede SearchPoint are repeated in ApplyCandidates; here they only decide whether a request exists
+    CandWork w{k, -1, kDeleted};
+    // the checks that precede SearchPoint (map.cc:421-452): decided here, acted upon in ApplyCandidates — nothing the
+    // decision depends on can change in between (a point appears once per pass)
     if (!point->ToDelete()) {
       const Vector3d pos = point->GetPosition();
-      if (cur_->IsPointVisible(pos)) {
+      if (!cur_->IsPointVisible(pos)) {
+        w.state = kInvisible;
+      } else {
         Feature *feature = point->GetInitFeatureRaw();
         Frame *f0 = feature->GetFrameRaw();
         const double distance = cur_->DistanceTo(*f0);
-        if (!(distance / depth_mean_ < 0.01)) {
+        if (distance / depth_mean_ < 0.01) {
+          w.state = kTooClose;
+        } else {
+          w.state = kSearch;
           reqs->emplace_back();
           FillRequestFromFeature(&reqs->back(), cur_.get(), feature, f0, point->GetInverseDepth(), point->GetStd(), false, Vector2d(0, 0));
           w.req = static_cast<int>(reqs->size()) - 1 - req_base_;
@@ -322,13 +328,12 @@ void MapperMap::ApplyCandidates(const sdvl_search_res *res_all) {
   vector<char> erase(candidates_.size(), 0);
   for (const CandWork &w : cand_work_) {
     const shared_ptr<Point> &point = candidates_[w.index];
-    if (point->ToDelete()) {
+    if (w.state == kDeleted) {
       DeletePoint(point);
       erase[w.index] = 1;
       continue;
     }
-    const Vector3d pos = point->GetPosition();
-    if (!cur_->IsPointVisible(pos)) {
+    if (w.state == kInvisible) {
       Frame *lf = point->GetLastFeature()->GetFrameRaw();
       if (lf->GetKeyframeID() < min_kf_id) {
         DeletePoint(point);
@@ -336,10 +341,9 @@ void MapperMap::ApplyCandidates(const sdvl_search_res *res_all) {
       }
       continue;
     }
+    if (w.state == kTooClose) continue;
     Feature *feature = point->GetInitFeatureRaw();
     Frame *f0 = feature->GetFrameRaw();
-    const double distance = cur_->DistanceTo(*f0);
-    if (distance / depth_mean_ < 0.01) continue;
     const sdvl_search_res &r = res[w.req];
     if (!r.found) {
       if (point->Unpromote()) DeletePoint(point);
@@ -424,18 +428,22 @@ void MapperMap::EmitConnectionsPoints(vector<sdvl_search_req> *reqs) {
   vector<shared_ptr<Frame>> best_kfs;
   cur_->GetBestConnections(&best_kfs, Config::MaxSearchKeyframes());
   if (best_kfs.empty()) return;
-  std::map<int, shared_ptr<Point>> points;
+  // the reference collects into a std::set keyed by pointer; here: by point id, unique (see the class comment)
+  vector<std::pair<int, shared_ptr<Point>>> ids;
   for (auto it_kf = best_kfs.begin(); it_kf != best_kfs.end(); it_kf++) {
     vector<shared_ptr<Feature>> &features = (*it_kf)->GetFeatures();
     for (auto it = features.begin(); it != features.end(); it++) {
       if (!*it) continue;
-      shared_ptr<Point> point = (*it)->GetPoint();
+      Point *point = (*it)->GetPointRaw();
       if (!point || point->ToDelete()) continue;
       if (point->SeenFrom(cur_)) continue;
-      points[point->GetID()] = point;
+      ids.push_back({point->GetID(), (*it)->GetPoint()});
     }
   }
-  for (auto it = points.begin(); it != points.end(); it++) {
+  typedef std::pair<int, shared_ptr<Point>> IdPoint;
+  std::sort(ids.begin(), ids.end(), [](const IdPoint &a, const IdPoint &b) { return a.first < b.first; });
+  ids.erase(std::unique(ids.begin(), ids.end(), [](const IdPoint &a, const IdPoint &b) { return a.first == b.first; }), ids.end());
+  for (auto it = ids.begin(); it != ids.end(); it++) {
     const shared_ptr<Point> &pt = it->second;
     shared_ptr<Feature> feature = pt->GetInitFeature();
     if (!feature) continue;

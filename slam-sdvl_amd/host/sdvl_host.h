@@ -477,7 +477,8 @@ class MapperMap : public PlaneMap {
   std::shared_ptr<Frame> cur_;
   double depth_mean_ = 0.0;
   int pass_ = 0, req_base_ = 0;
-  struct CandWork { size_t index; int req; };             // position in candidates_, request (relative) or -1
+  enum CandState { kDeleted, kInvisible, kTooClose, kSearch };
+  struct CandWork { size_t index; int req; CandState state; };  // position in candidates_, request (relative) or -1, decision before the search
   std::vector<CandWork> cand_work_;
   std::vector<int> occurrence_;                            // per candidates_ entry: which occurrence of its point it is
   std::vector<std::pair<std::shared_ptr<Point>, int>> acp_work_;  // AddConnectionsPoints: point, request or -1
