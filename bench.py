@@ -270,11 +270,17 @@ def main():
     for c in ctxs:
         c.timing(True)
     stats_buf = farm.alloc_stats(K)
+    import resource
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    flt0 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
     barrier()
     t0 = time.perf_counter()
     stats = farm.run(ptrs[1 + Wm:], workers, stats_buf)  # the K timed steps: group-steps are scheduled onto the worker threads
     barrier()
     elapsed = time.perf_counter() - t0
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    flt1 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
+    sys.stderr.write("host memory: max RSS %.0f -> %.0f MB, minor page faults in the timed region: %d\n" % (rss0 / 1024, rss1 / 1024, flt1 - flt0))
     timers = {}
     for c in ctxs:
         for name, (ms, n) in c.timing_get().items():
