@@ -1,9 +1,18 @@
 // capi.cc — flat C entry points over the host layer (sdvl_host.h) for the Python harness (tests, smoke, bench):
 // B independent SDVL trackers on one MI355X stepping together through sdvl::SDVLBatch.
+#include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/time.h>
 #include <ucontext.h>
+#include <cxxabi.h>
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <set>
+#include <atomic>
+#include <algorithm>
 #include <memory>
 #include <condition_variable>
 #include <mutex>
@@ -425,6 +434,82 @@ int sdvlh_farm_reserve(void *fp, int frames_per_group) {
 void *sdvlh_farm_ctx(void *fp, int g) { return sdvlh_device_ctx(static_cast<Farm *>(fp)->devices[g]); }
 void *sdvlh_farm_batch(void *fp, int g) { return static_cast<Farm *>(fp)->batches[g]; }
 
+
+// ---- SDVL_PROFILE=1: a sampling profile of the host threads during sdvlh_farm_run (the boxes have no perf): SIGPROF
+// every millisecond of process CPU time, the handler records the call stack, the run prints self / inclusive shares.
+namespace {
+constexpr int kProfDepth = 24, kProfMax = 400000;
+struct ProfSample { int n; void *pc[kProfDepth]; };
+ProfSample *g_prof = nullptr;
+std::atomic<int> g_prof_n{0};
+void ProfHandler(int) {
+  const int i = g_prof_n.fetch_add(1);
+  if (i >= kProfMax) return;
+  g_prof[i].n = backtrace(g_prof[i].pc, kProfDepth);
+}
+std::string ProfName(void *pc) {
+  Dl_info info;
+  if (dladdr(pc, &info) && info.dli_sname) {
+    int st = 0;
+    char *d = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
+    std::string r = (st == 0 && d) ? d : info.dli_sname;
+    free(d);
+    if (r.size() > 90) r.resize(90);
+    return r;
+  }
+  if (dladdr(pc, &info) && info.dli_fname) {
+    std::string f = info.dli_fname;
+    const size_t k = f.rfind('/');
+    return "[" + (k == std::string::npos ? f : f.substr(k + 1)) + "]";
+  }
+  return "[?]";
+}
+void ProfStart() {
+  if (!g_prof) g_prof = new ProfSample[kProfMax];
+  g_prof_n = 0;
+  void *warm[4];
+  backtrace(warm, 4);  // loads libgcc outside the handler
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = ProfHandler;
+  sa.sa_flags = SA_RESTART;
+  sigaction(SIGPROF, &sa, nullptr);
+  struct itimerval tv = {{0, 1000}, {0, 1000}};
+  setitimer(ITIMER_PROF, &tv, nullptr);
+}
+void ProfStop() {
+  struct itimerval tv = {{0, 0}, {0, 0}};
+  setitimer(ITIMER_PROF, &tv, nullptr);
+  const int n = std::min(g_prof_n.load(), kProfMax);
+  std::map<std::string, int> self, incl, own;
+  for (int i = 0; i < n; i++) {
+    std::set<std::string> seen;
+    bool mine = false;
+    for (int d = 2; d < g_prof[i].n; d++) {  // 0 = handler, 1 = signal trampoline
+      const std::string name = ProfName(g_prof[i].pc[d]);
+      if (d == 2) self[name]++;
+      if (seen.insert(name).second) incl[name]++;
+      if (!mine && (name.compare(0, 4, "sdvl") == 0 || name.compare(0, 5, "void ") == 0 || name.compare(0, 5, "std::") == 0)) {
+        // innermost frame of this repo's code (or a libstdc++ template instantiated in it): everything below it, HIP / HSA
+        // / libc included, is charged to it
+        if (name.compare(0, 4, "sdvl") == 0) { own[name]++; mine = true; }
+      }
+    }
+    if (!mine) own[g_prof[i].n > 2 ? "(other threads) " + ProfName(g_prof[i].pc[g_prof[i].n - 1]) : "(empty)"]++;
+  }
+  auto dump = [&](const char *title, std::map<std::string, int> &m, int top) {
+    std::vector<std::pair<int, std::string>> v;
+    for (auto &kv : m) v.push_back({kv.second, kv.first});
+    std::sort(v.rbegin(), v.rend());
+    fprintf(stderr, "---- %s (%d samples of 1 ms CPU)\n", title, n);
+    for (int i = 0; i < top && i < static_cast<int>(v.size()); i++) fprintf(stderr, "%6.2f%%  %s\n", 100.0 * v[i].first / std::max(1, n), v[i].second.c_str());
+  };
+  dump("charged to the innermost sdvl function (callees in HIP / HSA / libc included)", own, 40);
+  dump("self", self, 25);
+  dump("inclusive", incl, 30);
+}
+}  // namespace
+
 // Runs n_steps steps with `workers` host threads (0 = one per group).
 // dev_frames[(step * G*Bg) + g*Bg + i] = device pointer of the frame of sequence (g, i) at that step (row stride =
 // `stride`); out[(step * G*Bg) + g*Bg + i] receives its stats.  Returns 0, or -1 with sdvlh_last_error.
@@ -441,6 +526,8 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
     f->busy.assign(f->G, 0);
     f->failed = false;
   }
+  static const bool profile = std::getenv("SDVL_PROFILE") != nullptr;
+  if (profile) ProfStart();
   std::vector<std::thread> threads;
   for (int w = 0; w < W; w++)
     threads.emplace_back([f, w, W] {
@@ -448,6 +535,7 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
       else f->RunShare(w, W);
     });
   for (auto &t : threads) t.join();
+  if (profile) ProfStop();
   if (f->failed) { g_err = f->err; return -1; }
   return 0;
 }
