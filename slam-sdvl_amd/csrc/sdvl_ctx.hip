@@ -47,7 +47,10 @@ hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
   } else {
     e = hipEventSynchronize(ctx->wait_event);
   }
-  if (e == hipSuccess) ctx->stage_off = 0;
+  if (e == hipSuccess) {
+    ctx->stage_off = 0;
+    ctx->wait_gen++;
+  }
   return e;
 }
 
@@ -160,6 +163,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+  if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
   if (ctx->d_stage) (void)hipFree(ctx->d_stage);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_work) (void)hipFree(ctx->d_work);

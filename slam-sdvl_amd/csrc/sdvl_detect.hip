@@ -1079,6 +1079,11 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   SDVL_LAUNCH(ctx, "select_corners", select_corners_kernel, dim3(lv.n_levels, n), dim3(kSelThreads), ds, sl);
   SDVL_LAUNCH(ctx, "pack_corners", pack_corners_kernel, dim3(n), dim3(256), ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
+  // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts)
+  ctx->counts_gen = ~0ull;
+  if (sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK &&
+      hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess)
+    ctx->counts_gen = ctx->wait_gen;
   return SDVL_OK;
 }
 
@@ -1095,7 +1100,6 @@ int sdvl_frames_corner_counts(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, i
     const size_t nd = ctx->detect_frames.size();
     int rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, sizeof(int32_t) * (4 * static_cast<size_t>(n) + nd), true);
     if (rc) return rc;
-    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
     int32_t *h = static_cast<int32_t *>(ctx->h_out);
     // fast path: the pack kernel of the last detect batch left every count in one array
     bool batch_ok = nd > 0;
@@ -1111,6 +1115,19 @@ int sdvl_frames_corner_counts(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, i
         }
       }
     }
+    if (batch_ok && ctx->counts_gen != ~0ull && ctx->wait_gen > ctx->counts_gen) {
+      // the copy queued by sdvl_detect_corners has completed: some wait on this stream returned since
+      const int32_t *hc = static_cast<const int32_t *>(ctx->h_counts);
+      for (int i = 0; i < n; i++)
+        if (frames[i]->v.n_corners < 0) {
+          const int c = hc[where[i]];
+          if (c < 0) {
+            ctx->err = "corner selection overflowed a device capacity (SDVL_MAX_CORNERS / level staging)";
+            return SDVL_ERR_CAPACITY;
+          }
+          frames[i]->v.n_corners = c;
+        }
+    } else
     if (batch_ok) {
       SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_counts, sizeof(int32_t) * nd, hipMemcpyDeviceToHost, ctx->stream));
       SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -60,6 +60,10 @@ struct sdvl_ctx {
   // corner counts of the last sdvl_detect_corners batch, written by the pack kernel: one D2H serves all frames
   void *d_counts = nullptr; size_t d_counts_bytes = 0;
   std::vector<sdvl_frame *> detect_frames;
+  // the counts of that batch also travel to this pinned array right behind the pack kernel; they have landed as soon as
+  // any later wait on the stream has returned (wait_gen > counts_gen), so asking for them then costs no round trip
+  void *h_counts = nullptr; size_t h_counts_bytes = 0;
+  uint64_t wait_gen = 0, counts_gen = ~0ull;
   std::vector<void *> slabs;  // bulk frame storage, released with the context
   hipEvent_t wait_event = nullptr;  // created with hipEventBlockingSync | hipEventDisableTiming
   // cooperative waits: when set, sdvl_stream_wait polls the event and calls the hook while the stream is still busy, so a
