@@ -180,3 +180,34 @@ def test_farm_fibers_give_identical_results(trk, orc, synth):
     coop = run(2, 2)
     assert plain == coop
     assert all(r[1] == 0 and r[4] >= 100 for r in plain[n:])      # tracking, not idling
+
+
+def test_closed_loop_without_orb_uses_zmssd_matching(trk, orc, synth):
+    """SDVL.use_orb: 0 (the reference's default, config.cc:85): detection margin 1 + PatchSize/2, no descriptors, candidates
+    ranked by the integer ZMSSD of the warped 8x8 patch (matcher.cc:447-476) — the whole loop must still agree"""
+    over = dict(trk.TUM_OVERRIDES)
+    over["SDVL.use_orb"] = 0
+    trk.configure(over)
+    old = orc.params.use_orb
+    orc.params.use_orb = 0
+    try:
+        dev = trk.HostDevice(0)
+        batch = trk.TrackerBatch(dev, 2, 640, 480, TUM_CAM)
+        refs = [orc.tracker(640, 480, TUM_CAM) for _ in range(2)]
+        for k in range(9):
+            imgs = [synth.render(trajectory_pose(orc, k, XI * (1 + 0.3 * i)), TUM_CAM, 640, 480, seed=20260001 + i, frame_id=k) for i in range(2)]
+            got = batch.step_host(imgs)
+            for i in range(2):
+                w, g = refs[i].handle_frame(imgs[i]), got[i]
+                assert (g.state, g.quality, g.keyframe, g.n_corners, g.matches, g.attempts, g.inliers, g.outliers, g.align_meas) == \
+                       (w.state, w.quality, w.keyframe, w.n_corners, w.matches, w.attempts, w.inliers, w.outliers, w.align_meas), (k, i)
+                assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, (k, i)
+                if k > 0:
+                    assert g.quality == 0 and g.matches >= 80
+        batch.close()
+        for r in refs:
+            r.close()
+        dev.close()
+    finally:
+        orc.params.use_orb = old
+        trk.configure()
