@@ -211,3 +211,30 @@ def test_closed_loop_without_orb_uses_zmssd_matching(trk, orc, synth):
     finally:
         orc.params.use_orb = old
         trk.configure()
+
+
+def test_closed_loop_config_c_large_frames_many_features(trk, orc, synth):
+    """BASELINE config C: 1280x960, num_features 4000, max_matches 1000.  Exercises the paths the 640x480 loop does not:
+    the global-memory image-alignment kernel (> 384 features per job) and the host pose stage (> 256 matches per frame)."""
+    cam = np.array([1034.6, 1033.0, 637.2, 510.6])
+    over = dict(trk.TUM_OVERRIDES)
+    over.update({"SDVL.num_features": 4000, "SDVL.max_matches": 1000})
+    trk.configure(over)
+    saved = (orc.params.num_features, orc.params.max_matches)
+    orc.params.num_features, orc.params.max_matches = 4000, 1000
+    try:
+        dev = trk.HostDevice(0)
+        batch = trk.TrackerBatch(dev, 1, 1280, 960, cam)
+        ref = orc.tracker(1280, 960, cam)
+        for k in range(5):
+            img = synth.render(trajectory_pose(orc, k), cam, 1280, 960, seed=20260100, frame_id=k)
+            g, w = batch.step_host([img])[0], ref.handle_frame(img)
+            assert (g.state, g.quality, g.keyframe, g.n_corners, g.matches, g.attempts, g.inliers, g.outliers, g.align_meas) == \
+                   (w.state, w.quality, w.keyframe, w.n_corners, w.matches, w.attempts, w.inliers, w.outliers, w.align_meas), k
+            assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, k
+            if k > 0:
+                assert g.matches > 256 and g.align_meas > 384      # really beyond the fast-path limits
+        batch.close(); ref.close(); dev.close()
+    finally:
+        orc.params.num_features, orc.params.max_matches = saved
+        trk.configure()
