@@ -246,7 +246,7 @@ int sdvl_frames_upload_undistorted(sdvl_ctx *ctx, int n, sdvl_frame *const *fram
  *   nits_table[nits_begin + s], s = 0..size               the budget after an improvement to s supporters (:199-207),
  * and commits result.n_draws draws on its real stream afterwards.  out_lists[obs_begin ..) receives the final inlier
  * indices (n_inliers of them, reference order) followed by the outlier indices (n_outliers), relative to obs_begin.
- * At most 256 observations per job (SDVL_ERR_CAPACITY beyond). */
+ * At most 1024 observations per job (SDVL_ERR_CAPACITY beyond). */
 typedef struct sdvl_pose_obs {
   double ax, ay;
   double px, py, pz;

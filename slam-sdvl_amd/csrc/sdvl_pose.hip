@@ -20,7 +20,7 @@ namespace {
 
 using namespace sdvl;
 
-constexpr int kMaxObs = 256;  // observations (matched features) per frame handled on device
+constexpr int kMaxObs = 1024;  // observations (matched features) per frame handled on device (config C: max_matches 1000)
 constexpr double kMADNorm = 1.4826;
 constexpr double kTukeyC = 4.6851 * 4.6851;
 
@@ -201,6 +201,28 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// k-th smallest (0-based) of the n non-negative doubles vals[0..n), n <= 64 * kSlots, by one wave; uniform result.
+// Non-negative doubles order like their bit patterns: the answer is built bit by bit from the top, counting with ballots
+// how many values lie below the candidate prefix — 63 uniform steps, no sorting.
+template <int kSlots>
+__device__ __forceinline__ double wave_kth_smallest(const double *vals, int n, int k, int lane) {
+  unsigned long long v[kSlots];
+#pragma unroll
+  for (int u = 0; u < kSlots; u++) {
+    const int i = u * 64 + lane;
+    v[u] = i < n ? static_cast<unsigned long long>(__double_as_longlong(vals[i])) : ~0ull;
+  }
+  unsigned long long prefix = 0;
+  for (int bit = 62; bit >= 0; bit--) {
+    const unsigned long long cand = prefix | (1ull << bit);
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < kSlots; u++) cnt += __popcll(__ballot(v[u] < cand));
+    if (cnt <= k) prefix = cand;
+  }
+  return __longlong_as_double(static_cast<long long>(prefix));
+}
+
 // ConvergePose over list[0..n) (n <= kMaxObs) by one wave; returns false when the list is empty
 __device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const uint16_t *list, int n, const Rigid &frame_pose, double fx,
                                    int max_its, Rigid *se3, int lane) {
@@ -218,28 +240,8 @@ __device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const
     }
   }
   wave_lds_sync();
-  // median = element floor(n/2) of the sorted order (what nth_element leaves there).  The errors are non-negative
-  // doubles, whose bit patterns order like unsigned integers: the k-th smallest is built bit by bit from the top,
-  // counting with ballots how many values lie below the candidate prefix — 63 uniform steps, no sorting.
-  double median = 0.0;
-  {
-    const int k = n / 2;
-    unsigned long long v[kMaxObs / 64];
-#pragma unroll
-    for (int u = 0; u < kMaxObs / 64; u++) {
-      const int i = u * 64 + lane;
-      v[u] = i < n ? static_cast<unsigned long long>(__double_as_longlong(L.errs[i])) : ~0ull;
-    }
-    unsigned long long prefix = 0;
-    for (int bit = 62; bit >= 0; bit--) {
-      const unsigned long long cand = prefix | (1ull << bit);
-      int cnt = 0;
-#pragma unroll
-      for (int u = 0; u < kMaxObs / 64; u++) cnt += __popcll(__ballot(v[u] < cand));
-      if (cnt <= k) prefix = cand;
-    }
-    median = __longlong_as_double(static_cast<long long>(prefix));
-  }
+  // median = element floor(n/2) of the sorted order (what nth_element leaves there)
+  const double median = n <= 256 ? wave_kth_smallest<4>(L.errs, n, n / 2, lane) : wave_kth_smallest<kMaxObs / 64>(L.errs, n, n / 2, lane);
   double scale = kMADNorm * median;
   for (int i = 0; i < max_its; i++) {
     if (i == 5) scale = 0.85 / fx;
@@ -416,7 +418,7 @@ extern "C" int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose
     const sdvl_pose_job &a = jobs[j];
     SDVL_REQUIRE(ctx, a.obs_begin >= 0 && a.obs_end >= a.obs_begin && a.obs_end <= n_obs, "observation range out of bounds");
     if (a.obs_end - a.obs_begin > kMaxObs) {
-      ctx->err = "too many matches in one pose job for the device path (256)";
+      ctx->err = "too many matches in one pose job for the device path (1024)";
       return SDVL_ERR_CAPACITY;
     }
     const int size = a.obs_end - a.obs_begin;

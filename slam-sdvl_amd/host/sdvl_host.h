@@ -516,7 +516,7 @@ class FeatureAlign {
     std::vector<int32_t> rand_idx, nits;
     void Append(const PoseBatch &o);
   };
-  static constexpr int kMaxDevicePoseObs = 256;
+  static constexpr int kMaxDevicePoseObs = 1024;
   void FinishSelect(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res);
   bool EmitPoseJob(const std::shared_ptr<Frame> &frame, PoseBatch *batch);  // false: too many matches, use the host path
   void CommitPose(const std::shared_ptr<Frame> &frame, const sdvl_pose_result &r, const int32_t *lists);

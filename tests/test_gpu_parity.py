@@ -404,7 +404,7 @@ def make_matches(orc, n, seed, outlier_frac=0.25, noise_px=0.4, fx=525.0):
     return obs, guess
 
 
-@pytest.mark.parametrize("sizes", [(150, 40, 5, 3, 1, 0), (256, 255, 64, 65, 129, 7)])
+@pytest.mark.parametrize("sizes", [(150, 40, 5, 3, 1, 0), (256, 255, 64, 65, 129, 7), (1024, 700, 257)])
 def test_pose_from_matches_equals_oracle(ctx, orc, sizes):
     """RANSAC replay + Tukey Gauss-Newton + rescue on the device: same rand() consumption, same inlier / outlier lists
     in the same order; pose within 1e-9 (device sin/cos inside SE3::Exp differ from libm by an ulp)"""
@@ -438,7 +438,7 @@ def test_pose_from_matches_degenerate_inputs(ctx, orc):
         assert g["n_draws"] == w["n_draws"]
         assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["outliers"], w["outliers"])
         assert np.abs(g["pose"] - w["pose"]).max() <= 1e-9
-    big, _ = make_matches(orc, 257, seed=9)
+    big, _ = make_matches(orc, 1025, seed=9)
     with pytest.raises(RuntimeError, match="too many matches"):
         ctx.pose_from_matches([(big, guess, draws)], fx=cam[0])
 

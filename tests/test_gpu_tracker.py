@@ -215,7 +215,7 @@ def test_closed_loop_without_orb_uses_zmssd_matching(trk, orc, synth):
 
 def test_closed_loop_config_c_large_frames_many_features(trk, orc, synth):
     """BASELINE config C: 1280x960, num_features 4000, max_matches 1000.  Exercises the paths the 640x480 loop does not:
-    the global-memory image-alignment kernel (> 384 features per job) and the host pose stage (> 256 matches per frame)."""
+    the global-memory image-alignment kernel (> 384 features per job) and pose jobs with up to 1000 matches."""
     cam = np.array([1034.6, 1033.0, 637.2, 510.6])
     over = dict(trk.TUM_OVERRIDES)
     over.update({"SDVL.num_features": 4000, "SDVL.max_matches": 1000})
@@ -233,7 +233,7 @@ def test_closed_loop_config_c_large_frames_many_features(trk, orc, synth):
                    (w.state, w.quality, w.keyframe, w.n_corners, w.matches, w.attempts, w.inliers, w.outliers, w.align_meas), k
             assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, k
             if k > 0:
-                assert g.matches > 256 and g.align_meas > 384      # really beyond the fast-path limits
+                assert g.matches > 256 and g.align_meas > 384      # really beyond the limits of the LDS paths
         batch.close(); ref.close(); dev.close()
     finally:
         orc.params.num_features, orc.params.max_matches = saved
