@@ -864,6 +864,9 @@ void FeatureAlign::ProjectPoints(const shared_ptr<Frame> &frame, const shared_pt
   const int frame_id = frame->GetID();
   const int n = static_cast<int>(features.size());
   for (int i = 0; i < n; i++) {
+    // features and points are separate heap objects reached through pointers: ask for the ones a few iterations ahead
+    if (i + 8 < n && features[i + 8]) __builtin_prefetch(features[i + 8].get());
+    if (i + 4 < n && features[i + 4]) __builtin_prefetch(features[i + 4]->GetPointRaw());
     Feature *ft = features[i].get();
     if (ft == nullptr) continue;
     Point *point = ft->GetPointRaw();
@@ -915,11 +918,13 @@ void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared
     vector<CellEntry> &cell = grid_[cell_order_[i]];
     // cell->sort(CompareQuality): std::list::sort is a stable merge sort
     if (cell.size() > 1) std::stable_sort(cell.begin(), cell.end(), [](const CellEntry &a, const CellEntry &b) { return a.score > b.score; });
-    for (const CellEntry &e : cell) {
+    for (size_t ce = 0; ce < cell.size(); ce++) {
+      const CellEntry &e = cell[ce];
       Point *point = features[e.src]->GetPointRaw();
       if (point->ToDelete()) continue;
       Feature *feature = point->GetInitFeatureRaw();
       if (!feature) continue;
+      __builtin_prefetch(feature);
       Candidate c{e.src, -1};
       Frame *ref_frame = feature->GetFrameRaw();
       if (ref_frame) {
