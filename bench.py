@@ -118,6 +118,7 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
         "orb_describe": n_c * (961 + 32),                            # 31x31 window + descriptor
         "image_align": 3 * n_f * 49 + i_ia * n_f * 25,               # reference windows + current windows per GN iteration
         "search_points": 12 * n_c + n_s * (121 + 164 + i_fa * 81),   # corner list + warp window + patches + LK windows
+        "search_prepare": n_s * (120 + 80),                            # request records read, scalar-phase records written
         "pose_hypotheses": 48 * n_m + 100 * 64,                      # match records read once + one result per RANSAC draw
         "pose_refine": 48 * n_m + 100 * 64 + 4 * n_m + 80,           # matches + draw results read, index lists + pose written
     }.get(kernel)

@@ -55,6 +55,13 @@ struct SearchReqDev {
   uint32_t desc[8];
 };
 
+// what the scalar part of SearchPoint (matcher.cc:45-96) leaves for the wave part: one record per request
+struct SearchPrep {
+  int alive, slevel;
+  double pxa[2], pxb[2];        // projected ends of the depth interval (pxb only for epipolar searches)
+  double I00, I01, I10, I11;    // inverse of the affine warp (CreatePatch, matcher.cc:330)
+};
+
 struct PatchJob {  // sdvl_align_patches
   const uint8_t *img;
   int w, h;
@@ -186,39 +193,19 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
   return converged;
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
-                                                                            const SearchFramePose *__restrict__ table,
-                                                                            const SearchBlock *__restrict__ blocks, Cam cam,
-                                                                            sdvl_search_params prm,
-                                                                            sdvl_search_res *__restrict__ out) {
-  __shared__ WaveLds s_lds[kWavesPerBlock];
-  // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
-  // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
-  __shared__ uint32_t s_corners[SDVL_MAX_CORNERS];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const SearchBlock blk = blocks[blockIdx.x];
-  const SearchFramePose &tcur = table[reqs[blk.first].cur];
-  const int n_corners = min(tcur.f.n_ptr[0], SDVL_MAX_CORNERS);
-  for (int ci = threadIdx.x; ci < n_corners; ci += 64 * kWavesPerBlock) {
-    const int4 c = reinterpret_cast<const int4 *>(tcur.f.corners)[ci];
-    s_corners[ci] = static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24);
-  }
-  __syncthreads();
-  if (wv >= blk.count) return;
-  const int ri = blk.first + wv;
-  WaveLds &L = s_lds[wv];
+// Phase 0 of SearchPoint is scalar work per request (relative pose, depth-interval projection, margin test, affine warp,
+// search level): one LANE per request here instead of a whole wave repeating it 64 times in search_points_kernel.
+__global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev *__restrict__ reqs, const SearchFramePose *__restrict__ table,
+                                                             int n, Cam cam, sdvl_search_params prm, SearchPrep *__restrict__ prep) {
+  const int ri = blockIdx.x * 256 + threadIdx.x;
+  if (ri >= n) return;
   const SearchReqDev &rq = reqs[ri];
-  const SearchFramePose &tref = table[rq.ref];
-  sdvl_search_res res;
-  res.px[0] = rq.px0[0];
-  res.px[1] = rq.px0[1];
-  res.found = 0;
-  res.level = -1;
-  res.best_corner = -1;
-  res.stage = 0;
-  res.lk_its = 0;
-  res.slevel = -1;
-
+  const SearchFramePose &tcur = table[rq.cur], &tref = table[rq.ref];
+  SearchPrep out;
+  out.alive = 0;
+  out.slevel = -1;
+  out.pxa[0] = out.pxa[1] = out.pxb[0] = out.pxb[1] = 0.0;
+  out.I00 = out.I01 = out.I10 = out.I11 = 0.0;
   const int level = rq.level;
   const Rigid cur_pose = se3_from7(tcur.pose), ref_pose = se3_from7(tref.pose);
   const Rigid ref_world = se3_inverse(ref_pose);
@@ -244,7 +231,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
     if (!cam_inside_level(cam, lx, ly, prm.patch_size / 2 + 2, level)) alive = false;
   }
   if (!alive) {
-    if (lane == 0) out[ri] = res;
+    prep[ri] = out;
     return;
   }
   // ---- WarpMatrixAffine, matcher.cc:293-312
@@ -277,12 +264,63 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
       det *= 0.25;
     }
   }
-  res.slevel = slevel;
-  // ---- CreatePatch, matcher.cc:325-357
   {
     const double det = A00 * A11 - A01 * A10;
     const double invdet = 1.0 / det;
-    const double I00 = A11 * invdet, I01 = -A01 * invdet, I10 = -A10 * invdet, I11 = A00 * invdet;
+    out.I00 = A11 * invdet; out.I01 = -A01 * invdet; out.I10 = -A10 * invdet; out.I11 = A00 * invdet;
+  }
+  out.alive = 1;
+  out.slevel = slevel;
+  out.pxa[0] = pxa.x; out.pxa[1] = pxa.y; out.pxb[0] = pxb.x; out.pxb[1] = pxb.y;
+  prep[ri] = out;
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
+                                                                            const SearchFramePose *__restrict__ table,
+                                                                            const SearchBlock *__restrict__ blocks,
+                                                                            const SearchPrep *__restrict__ prep, Cam cam,
+                                                                            sdvl_search_params prm,
+                                                                            sdvl_search_res *__restrict__ out) {
+  __shared__ WaveLds s_lds[kWavesPerBlock];
+  // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
+  // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
+  __shared__ uint32_t s_corners[SDVL_MAX_CORNERS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const SearchBlock blk = blocks[blockIdx.x];
+  const SearchFramePose &tcur = table[reqs[blk.first].cur];
+  const int n_corners = min(tcur.f.n_ptr[0], SDVL_MAX_CORNERS);
+  for (int ci = threadIdx.x; ci < n_corners; ci += 64 * kWavesPerBlock) {
+    const int4 c = reinterpret_cast<const int4 *>(tcur.f.corners)[ci];
+    s_corners[ci] = static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24);
+  }
+  __syncthreads();
+  if (wv >= blk.count) return;
+  const int ri = blk.first + wv;
+  WaveLds &L = s_lds[wv];
+  const SearchReqDev &rq = reqs[ri];
+  const SearchFramePose &tref = table[rq.ref];
+  sdvl_search_res res;
+  res.px[0] = rq.px0[0];
+  res.px[1] = rq.px0[1];
+  res.found = 0;
+  res.level = -1;
+  res.best_corner = -1;
+  res.stage = 0;
+  res.lk_its = 0;
+  res.slevel = -1;
+
+  const int level = rq.level;
+  const SearchPrep pr = prep[ri];
+  if (!pr.alive) {
+    if (lane == 0) out[ri] = res;
+    return;
+  }
+  const V2 pxa = {pr.pxa[0], pr.pxa[1]}, pxb = {pr.pxb[0], pr.pxb[1]};
+  const int slevel = pr.slevel;
+  res.slevel = slevel;
+  // ---- CreatePatch, matcher.cc:325-357
+  {
+    const double I00 = pr.I00, I01 = pr.I01, I10 = pr.I10, I11 = pr.I11;
     const uint8_t *img = tref.f.level[level];
     const int W = tref.f.lw[level], H = tref.f.lh[level];
     const double pyrx = rq.px[0] / (1 << level), pyry = rq.px[1] / (1 << level);
@@ -489,7 +527,8 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
   const size_t tab_cap_entries = 512;
   const size_t tab_cap_bytes = sizeof(SearchFramePose) * tab_cap_entries;
   void *hs = nullptr, *dsx = nullptr;
-  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_bytes, false);
+  const size_t out_dev_bytes = (out_bytes + 255) / 256 * 256;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_dev_bytes + sizeof(SearchPrep) * static_cast<size_t>(n), false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
   if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes + blk_cap_bytes + tab_cap_bytes, &hs, &dsx);
   if (rc) return rc;
@@ -536,9 +575,13 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     d_table = static_cast<const SearchFramePose *>(ctx->d_work);
   }
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  // d_out: results | per-request records of the scalar phase
+  SearchPrep *d_prep = reinterpret_cast<SearchPrep *>(static_cast<uint8_t *>(ctx->d_out) + out_dev_bytes);
+  SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n + 255) / 256), dim3(256), static_cast<const SearchReqDev *>(dsx), d_table, n, c,
+              *p, d_prep);
   SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>(n_blocks)), dim3(64 * kWavesPerBlock),
-              static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes), c, *p,
-              static_cast<sdvl_search_res *>(ctx->d_out));
+              static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
+              static_cast<const SearchPrep *>(d_prep), c, *p, static_cast<sdvl_search_res *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
