@@ -238,3 +238,31 @@ def test_closed_loop_config_c_large_frames_many_features(trk, orc, synth):
     finally:
         orc.params.num_features, orc.params.max_matches = saved
         trk.configure()
+
+
+def test_mapper_mode_lost_and_relocalize(trk, orc, synth):
+    """mapper mode through a tracking loss: while relocalisation is pending the mapper stands still (Map::SetRelocalizing,
+    sdvl.cc:80-84, map.cc:79-80); afterwards it resumes — decisions and map bookkeeping stay identical to the oracle"""
+    trk.configure()
+    trk.set_mapper(True)
+    try:
+        dev = trk.HostDevice(0)
+        batch = trk.TrackerBatch(dev, 1, 640, 480, TUM_CAM)
+    finally:
+        trk.set_mapper(False)
+    ref = orc.tracker(640, 480, TUM_CAM)
+    ref.use_mapper(True)
+    seq = list(range(12)) + [-1, -1, -1, -1] + [11, 12, 13, 14, 15]
+    relocs = 0
+    for k, idx in enumerate(seq):
+        img = np.full((480, 640), 127, np.uint8) if idx < 0 else synth.render(trajectory_pose(orc, idx), TUM_CAM, 640, 480, frame_id=idx)
+        g = batch.step_host([img])[0]
+        w = ref.handle_frame(img)
+        assert (g.quality, g.matches, g.attempts, g.inliers, g.keyframe, g.relocalized) == \
+               (w.quality, w.matches, w.attempts, w.inliers, w.keyframe, w.relocalized), (k, idx)
+        assert batch.map_stats(0) == ref.map_stats(), (k, idx)
+        if idx >= 0:
+            assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, (k, idx)
+        relocs += g.relocalized
+    assert relocs == 1
+    batch.close(); ref.close(); dev.close()
