@@ -207,6 +207,26 @@ int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int 
 int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
                        const sdvl_search_params *p, sdvl_search_res *out);
 
+/* The same search for callers that issue thousands of requests per call (SDVLBatch): the requests are written once,
+ * in the device layout, straight into the context's pinned staging area, and name their frames by slot.
+ *   sdvl_search_begin  reserves room for max_requests records and returns the array to fill;
+ *   sdvl_search_slot   registers a (frame, pose) pair of this batch and returns its slot (>= 0), or a negative status;
+ *                      the frame must have corners (and descriptors in ORB mode) as for sdvl_search_points;
+ *   sdvl_search_run    evaluates the first n records.
+ * No other call on this context between begin and run. */
+typedef struct sdvl_search_req_packed {
+  int32_t cur, ref;      /* slots of the current frame and of feature->GetFrame() */
+  int32_t level, fixed;
+  double px[2];
+  double bearing[3];
+  double idepth, idepth_std;
+  double px0[2];
+  uint8_t desc[32];
+} sdvl_search_req_packed;
+int sdvl_search_begin(sdvl_ctx *ctx, int max_requests, sdvl_search_req_packed **reqs);
+int sdvl_search_slot(sdvl_ctx *ctx, const sdvl_frame *frame, const double *pose7);
+int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, sdvl_search_res *out);
+
 /* Matcher::AlignPatch alone, matcher.cc:359-445: n patches against level images of frames.
  * border[n][100], patch[n][64], uv_io[n][2] (level coordinates), converged[n], its[n] (may be NULL) */
 int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const int32_t *levels,

@@ -494,64 +494,86 @@ void fill_frame(SearchFrame *d, const sdvl_frame *f) {
 
 extern "C" {
 
-int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
-                       const sdvl_search_params *p, sdvl_search_res *out) {
-  if (!ctx || !cam || !p || n < 0 || (n > 0 && (!reqs || !out))) return SDVL_ERR_INVALID;
+// ---- request batches ------------------------------------------------------------------------------------------------
+// A batch lives in the context's pinned staging area: requests | workgroup table | frame table.  sdvl_search_begin
+// reserves it, sdvl_search_slot names the (frame, pose) pairs, the caller (or sdvl_search_points) writes the requests in
+// their device format, sdvl_search_run adds the tables and launches.
+static_assert(sizeof(sdvl_search_req_packed) == sizeof(SearchReqDev), "public and device request records are one layout");
+
+struct SearchBatch {
+  void *hs = nullptr, *dsx = nullptr;
+  int cap = 0;
+  size_t in_bytes = 0, blk_cap_bytes = 0;
+  std::vector<SearchFramePose> table;
+  std::vector<const sdvl_frame *> frames;  // parallel to `table`
+  std::unordered_map<const sdvl_frame *, int> where;
+  int last = -1;
+};
+constexpr size_t kSearchTabCap = 512;  // frame-table entries that fit the staging reserve (more go through d_work)
+
+static SearchBatch &batch_of(sdvl_ctx *ctx) {
+  static thread_local std::unordered_map<sdvl_ctx *, SearchBatch> batches;  // one builder per context
+  return batches[ctx];
+}
+
+int sdvl_search_begin(sdvl_ctx *ctx, int max_requests, sdvl_search_req_packed **reqs) {
+  if (!ctx || !reqs || max_requests < 0) return SDVL_ERR_INVALID;
+  SearchBatch &B = batch_of(ctx);
+  B.cap = max_requests;
+  B.table.clear();
+  B.frames.clear();
+  B.where.clear();
+  B.last = -1;
+  B.in_bytes = (sizeof(SearchReqDev) * static_cast<size_t>(max_requests) + 255) / 256 * 256;
+  B.blk_cap_bytes = (sizeof(SearchBlock) * static_cast<size_t>(max_requests) + 255) / 256 * 256;
+  int rc = sdvl_stage_alloc(ctx, B.in_bytes + B.blk_cap_bytes + sizeof(SearchFramePose) * kSearchTabCap, &B.hs, &B.dsx);
+  if (rc) return rc;
+  *reqs = static_cast<sdvl_search_req_packed *>(B.hs);
+  return SDVL_OK;
+}
+
+int sdvl_search_slot(sdvl_ctx *ctx, const sdvl_frame *f, const double *pose) {
+  if (!ctx || !f || !pose) return SDVL_ERR_INVALID;
+  SearchBatch &B = batch_of(ctx);
+  std::vector<SearchFramePose> &table = B.table;
+  if (B.last >= 0 && table[B.last].f.corners == f->v.corners && memcmp(table[B.last].pose, pose, sizeof(double) * 7) == 0) return B.last;
+  auto it = B.where.find(f);
+  if (it != B.where.end() && memcmp(table[it->second].pose, pose, sizeof(double) * 7) == 0) { B.last = it->second; return B.last; }
+  SearchFramePose e;
+  fill_frame(&e.f, f);
+  memcpy(e.pose, pose, sizeof(double) * 7);
+  e.pad_ = 0.0;
+  table.push_back(e);
+  B.frames.push_back(f);
+  B.where[f] = static_cast<int>(table.size()) - 1;  // the same frame under another pose: the newest entry wins the cache
+  B.last = static_cast<int>(table.size()) - 1;
+  return B.last;
+}
+
+int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, sdvl_search_res *out) {
+  if (!ctx || !cam || !p || n < 0 || (n > 0 && !out)) return SDVL_ERR_INVALID;
   if (n == 0) return SDVL_OK;
+  SearchBatch &B = batch_of(ctx);
+  SDVL_REQUIRE(ctx, B.hs && n <= B.cap, "sdvl_search_run without a matching sdvl_search_begin");
   SDVL_REQUIRE(ctx, p->patch_size == 8, "only patch_size 8 is supported (one wave64 per 8x8 patch)");
   SDVL_REQUIRE(ctx, p->max_fast_levels >= 1 && p->max_fast_levels <= 4, "bad max_fast_levels");
   SDVL_REQUIRE(ctx, p->max_align_its >= 0 && p->margin >= 4, "bad max_align_its / margin");
-  // table of distinct (frame, pose) pairs: one entry per frame in practice (a frame has one pose during a launch)
-  static thread_local std::vector<SearchFramePose> table;
-  static thread_local std::unordered_map<const sdvl_frame *, int> where;
-  table.clear();
-  where.clear();
-  auto lookup = [&](const sdvl_frame *f, const double *pose, int *last) -> int {
-    if (*last >= 0 && table[*last].f.corners == f->v.corners && memcmp(table[*last].pose, pose, sizeof(double) * 7) == 0) return *last;
-    auto it = where.find(f);
-    if (it != where.end() && memcmp(table[it->second].pose, pose, sizeof(double) * 7) == 0) { *last = it->second; return *last; }
-    SearchFramePose e;
-    fill_frame(&e.f, f);
-    memcpy(e.pose, pose, sizeof(double) * 7);
-    e.pad_ = 0.0;
-    table.push_back(e);
-    where[f] = static_cast<int>(table.size()) - 1;  // the same frame under another pose: the newest entry wins the cache
-    *last = static_cast<int>(table.size()) - 1;
-    return *last;
-  };
-  // staging layout: requests | workgroup table (<= n entries) | frame table.  The requests are validated and converted in
-  // ONE pass straight into the pinned staging area; the frame table is small and follows.
-  const size_t in_bytes = (sizeof(SearchReqDev) * static_cast<size_t>(n) + 255) / 256 * 256;
+  const int n_slots = static_cast<int>(B.table.size());
+  for (const SearchFramePose &e : B.table) SDVL_REQUIRE(ctx, p->max_fast_levels <= e.f.levels, "max_fast_levels exceeds the pyramid depth");
+  SearchReqDev *hreq = static_cast<SearchReqDev *>(B.hs);
+  for (int i = 0; i < n; i++) {
+    const SearchReqDev &d = hreq[i];
+    SDVL_REQUIRE(ctx, d.cur >= 0 && d.cur < n_slots && d.ref >= 0 && d.ref < n_slots, "request names a frame slot outside the batch");
+    SDVL_REQUIRE(ctx, d.level >= 0 && d.level < B.table[d.ref].f.levels, "feature level outside the reference pyramid");
+    SDVL_REQUIRE(ctx, d.idepth == d.idepth && d.idepth != 0.0, "inverse depth must be finite and non-zero");
+  }
+  const size_t in_bytes = B.in_bytes, blk_cap_bytes = B.blk_cap_bytes;
   const size_t out_bytes = sizeof(sdvl_search_res) * static_cast<size_t>(n);
-  const size_t blk_cap_bytes = (sizeof(SearchBlock) * static_cast<size_t>(n) + 255) / 256 * 256;
-  const size_t tab_cap_entries = 512;
-  const size_t tab_cap_bytes = sizeof(SearchFramePose) * tab_cap_entries;
-  void *hs = nullptr, *dsx = nullptr;
   const size_t out_dev_bytes = (out_bytes + 255) / 256 * 256;
   int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_dev_bytes + sizeof(SearchPrep) * static_cast<size_t>(n), false);
   if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
-  if (!rc) rc = sdvl_stage_alloc(ctx, in_bytes + blk_cap_bytes + tab_cap_bytes, &hs, &dsx);
   if (rc) return rc;
-  SearchReqDev *hreq = static_cast<SearchReqDev *>(hs);
-  int last_cur = -1, last_ref = -1;
-  for (int i = 0; i < n; i++) {
-    const sdvl_search_req &r = reqs[i];
-    SDVL_REQUIRE(ctx, r.cur && r.ref, "null frame in search request");
-    SDVL_REQUIRE(ctx, !r.cur->hdr_stale, "current frame has a new image but no corners (detect or set corners first)");
-    SDVL_REQUIRE(ctx, r.level >= 0 && r.level < r.ref->v.levels, "feature level outside the reference pyramid");
-    SDVL_REQUIRE(ctx, p->max_fast_levels <= r.cur->v.levels, "max_fast_levels exceeds the pyramid depth");
-    if (p->use_orb) SDVL_REQUIRE(ctx, r.cur->v.n_corners == 0 || r.cur->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
-    SDVL_REQUIRE(ctx, r.idepth == r.idepth && r.idepth != 0.0, "inverse depth must be finite and non-zero");
-    SearchReqDev &d = hreq[i];
-    d.cur = lookup(r.cur, r.cur_pose, &last_cur);
-    d.ref = lookup(r.ref, r.ref_pose, &last_ref);
-    d.level = r.level; d.fixed = r.fixed;
-    d.px[0] = r.px[0]; d.px[1] = r.px[1];
-    d.bearing[0] = r.bearing[0]; d.bearing[1] = r.bearing[1]; d.bearing[2] = r.bearing[2];
-    d.idepth = r.idepth; d.idepth_std = r.idepth_std;
-    d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
-    memcpy(d.desc, r.desc, 32);
-  }
+  void *hs = B.hs, *dsx = B.dsx;
   // workgroups: runs of up to kWavesPerBlock consecutive requests that search the same current frame
   SearchBlock *hblk = reinterpret_cast<SearchBlock *>(static_cast<uint8_t *>(hs) + in_bytes);
   int n_blocks = 0;
@@ -559,10 +581,14 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     int cnt = 1;
     while (i + cnt < n && cnt < kWavesPerBlock && hreq[i + cnt].cur == hreq[i].cur) cnt++;
     hblk[n_blocks++] = SearchBlock{i, cnt};
+    const sdvl_frame *cf = B.frames[hreq[i].cur];
+    SDVL_REQUIRE(ctx, !cf->hdr_stale, "current frame has a new image but no corners (detect or set corners first)");
+    if (p->use_orb) SDVL_REQUIRE(ctx, cf->v.n_corners == 0 || cf->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
     i += cnt;
   }
+  const std::vector<SearchFramePose> &table = B.table;
   const SearchFramePose *d_table = nullptr;
-  if (table.size() <= tab_cap_entries) {
+  if (table.size() <= kSearchTabCap) {
     memcpy(static_cast<uint8_t *>(hs) + in_bytes + blk_cap_bytes, table.data(), sizeof(SearchFramePose) * table.size());
     SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + blk_cap_bytes + sizeof(SearchFramePose) * table.size(), hipMemcpyHostToDevice, ctx->stream));
     d_table = reinterpret_cast<const SearchFramePose *>(static_cast<uint8_t *>(dsx) + in_bytes + blk_cap_bytes);
@@ -571,7 +597,7 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, sizeof(SearchFramePose) * table.size(), false);
     if (rc) return rc;
     SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_work, table.data(), sizeof(SearchFramePose) * table.size(), hipMemcpyHostToDevice, ctx->stream));
-    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `table` is pageable and reused by the next call
+    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `table` is pageable and reused by the next batch
     d_table = static_cast<const SearchFramePose *>(ctx->d_work);
   }
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
@@ -587,6 +613,30 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(out, ctx->h_out, out_bytes);
   return SDVL_OK;
+}
+
+int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
+                       const sdvl_search_params *p, sdvl_search_res *out) {
+  if (!ctx || !cam || !p || n < 0 || (n > 0 && (!reqs || !out))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  sdvl_search_req_packed *packed = nullptr;
+  int rc = sdvl_search_begin(ctx, n, &packed);
+  if (rc) return rc;
+  SearchReqDev *hreq = reinterpret_cast<SearchReqDev *>(packed);
+  for (int i = 0; i < n; i++) {
+    const sdvl_search_req &r = reqs[i];
+    SDVL_REQUIRE(ctx, r.cur && r.ref, "null frame in search request");
+    SearchReqDev &d = hreq[i];
+    d.cur = sdvl_search_slot(ctx, r.cur, r.cur_pose);
+    d.ref = sdvl_search_slot(ctx, r.ref, r.ref_pose);
+    d.level = r.level; d.fixed = r.fixed;
+    d.px[0] = r.px[0]; d.px[1] = r.px[1];
+    d.bearing[0] = r.bearing[0]; d.bearing[1] = r.bearing[1]; d.bearing[2] = r.bearing[2];
+    d.idepth = r.idepth; d.idepth_std = r.idepth_std;
+    d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
+    memcpy(d.desc, r.desc, 32);
+  }
+  return sdvl_search_run(ctx, n, cam, p, out);
 }
 
 int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const int32_t *levels, const uint8_t *border,

@@ -505,6 +505,18 @@ Frame::~Frame() {
   }
 }
 
+// slot of this frame (with its current pose) in the open sdvl_search_begin batch `batch_id` of `ctx`
+int Frame::SearchSlot(sdvl_ctx *ctx, uint64_t batch_id) {
+  if (search_batch_ != batch_id) {
+    double pose[7];
+    pose_.ToArray(pose);
+    search_slot_ = sdvl_search_slot(ctx, dev_, pose);
+    if (search_slot_ < 0) throw std::runtime_error(std::string("sdvl_search_slot failed: ") + sdvl_last_error(ctx));
+    search_batch_ = batch_id;
+  }
+  return search_slot_;
+}
+
 // frame.cc:122-131
 void Frame::CreateCorners(int, int nfeatures) {
   Device *dev = Device::Current();
@@ -896,6 +908,16 @@ void FeatureAlign::ProjectPoints(const shared_ptr<Frame> &frame, const shared_pt
 // first half of SelectPoints (feature_align.cc:88-118): project, shuffle, sort every cell, emit ALL candidates
 void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame, bool reloc,
                                     vector<sdvl_search_req> *reqs) {
+  PrepareReprojectImpl(frame, last_frame, reloc, reqs, nullptr);
+}
+
+// the packed form: requests go straight into the staging area of an open sdvl_search_begin batch
+void FeatureAlign::PrepareReprojectPacked(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame, bool reloc, PackedSink *sink) {
+  PrepareReprojectImpl(frame, last_frame, reloc, nullptr, sink);
+}
+
+void FeatureAlign::PrepareReprojectImpl(const shared_ptr<Frame> &frame, const shared_ptr<Frame> &last_frame, bool reloc,
+                                        vector<sdvl_search_req> *reqs, PackedSink *sink) {
   inliers_.clear();
   outliers_.clear();
   found_.clear();
@@ -912,7 +934,8 @@ void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared
   vector<shared_ptr<Feature>> &features = last_frame->GetFeatures();
   double cur_pose[7];
   frame->GetPose().ToArray(cur_pose);
-  req_base_ = static_cast<int>(reqs->size());  // no exact-size reserve here: callers append many trackers to one list
+  req_base_ = sink ? sink->count : static_cast<int>(reqs->size());  // no exact-size reserve: callers append many trackers to one list
+  const int cur_slot = sink ? frame->SearchSlot(sink->ctx, sink->batch_id) : -1;
   for (int i = 0; i < size; i++) {
     plan_begin_[i] = static_cast<int>(plan_.size());
     vector<CellEntry> &cell = grid_[cell_order_[i]];
@@ -927,7 +950,22 @@ void FeatureAlign::PrepareReproject(const shared_ptr<Frame> &frame, const shared
       __builtin_prefetch(feature);
       Candidate c{e.src, -1};
       Frame *ref_frame = feature->GetFrameRaw();
-      if (ref_frame) {
+      if (ref_frame && sink) {
+        if (sink->count >= sink->cap) throw std::runtime_error("FeatureAlign: packed request batch too small");
+        sdvl_search_req_packed &rq = sink->reqs[sink->count++];
+        rq.cur = cur_slot;
+        rq.ref = ref_frame->SearchSlot(sink->ctx, sink->batch_id);
+        rq.px[0] = feature->GetPosition()(0); rq.px[1] = feature->GetPosition()(1);
+        rq.bearing[0] = feature->GetVector()(0); rq.bearing[1] = feature->GetVector()(1); rq.bearing[2] = feature->GetVector()(2);
+        rq.idepth = point->GetInverseDepth();
+        rq.idepth_std = point->GetStd();
+        rq.px0[0] = e.p(0); rq.px0[1] = e.p(1);
+        rq.level = feature->GetLevel();
+        rq.fixed = point->IsFixed() ? 1 : 0;
+        if (feature->HasDescriptor()) std::memcpy(rq.desc, feature->GetDescriptor().data(), 32);
+        else std::memset(rq.desc, 0, 32);
+        c.req = sink->count - 1 - req_base_;
+      } else if (ref_frame) {
         reqs->emplace_back();
         sdvl_search_req &rq = reqs->back();
         rq.cur = frame->device();
@@ -1518,12 +1556,23 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     vector<sdvl_search_req> &reqs = scratch_reqs_;  // keeps its capacity from step to step
     reqs.clear();
     vector<size_t> begin(R + 1, 0);
-    if (threads_ <= 1) {  // one host thread per batch (the farm's case): every tracker appends to the shared request list
+    bool packed = false;
+    FeatureAlign::PackedSink sink;
+    if (threads_ <= 1 && R > 0) {
+      // one host thread per batch (the farm's case): every tracker writes its requests, already in the device layout,
+      // straight into the pinned staging area of one search batch
+      int cap = 0;
+      for (int k = 0; k < R; k++) cap += static_cast<int>(trk_[run[k]]->last_frame_->GetFeatures().size());
+      sink.ctx = dev_->ctx();
+      sink.cap = cap;
+      sink.batch_id = ++search_batch_counter_;
+      dev_->Check(sdvl_search_begin(sink.ctx, cap, &sink.reqs), "sdvl_search_begin");
       for (int k = 0; k < R; k++) {
         SDVL &t = *trk_[run[k]];
-        begin[k] = reqs.size();
-        t.feature_align_.PrepareReproject(t.current_frame_, t.last_frame_, false, &reqs);
+        begin[k] = static_cast<size_t>(sink.count);
+        t.feature_align_.PrepareReprojectPacked(t.current_frame_, t.last_frame_, false, &sink);
       }
+      packed = true;
     } else {
       vector<vector<sdvl_search_req>> per(R);
       ParallelFor(R, [&](int k) {
@@ -1535,10 +1584,17 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
         reqs.insert(reqs.end(), per[k].begin(), per[k].end());
       }
     }
-    begin[R] = reqs.size();
+    begin[R] = packed ? static_cast<size_t>(sink.count) : reqs.size();
     vector<sdvl_search_res> res;
     clk.reset(new StageClock(ST_SEARCH));
-    if (R > 0) Matcher::SearchPoints(dev_, reqs, *trk_[run[0]]->camera_, &res);
+    if (packed) {
+      res.resize(std::max(1, sink.count));
+      const sdvl_camera cam = trk_[run[0]]->camera_->abi();
+      const sdvl_search_params sp = SearchParams();
+      dev_->Check(sdvl_search_run(sink.ctx, sink.count, &cam, &sp, res.data()), "sdvl_search_run");
+    } else if (R > 0) {
+      Matcher::SearchPoints(dev_, reqs, *trk_[run[0]]->camera_, &res);
+    }
     clk.reset(new StageClock(ST_FINISH));
     // ---- stage 3: replay of SelectPoints, sdvl.cc:193
     vector<FeatureAlign::PoseBatch> pb(threads_ <= 1 ? 0 : R);

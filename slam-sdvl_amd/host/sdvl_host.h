@@ -330,6 +330,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void GetBestConnections(std::vector<std::shared_ptr<Frame>> *connections, int n);
   sdvl_frame *device() const { return dev_; }
   Device *owner() const { return owner_; }
+  int SearchSlot(sdvl_ctx *ctx, uint64_t batch_id);
 
  private:
   Frame() {}
@@ -355,6 +356,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   sdvl_frame *dev_ = nullptr;
   Device *owner_ = nullptr;
   std::shared_ptr<FrameArena> arena_;
+  int search_slot_ = -1;
+  uint64_t search_batch_ = 0;
   int kf_id_ = 0;
   bool delete_ = false, selected_ = false;
   std::vector<std::pair<std::shared_ptr<Frame>, int>> connections_;
@@ -508,6 +511,15 @@ class FeatureAlign {
   void PrepareReproject(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, bool reloc,
                         std::vector<sdvl_search_req> *reqs);
   void FinishReproject(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res);
+  // packed form of PrepareReproject: the requests are written, already in the device layout, into an open
+  // sdvl_search_begin batch (many trackers share one batch; res of sdvl_search_run + the tracker's first index go to Finish*)
+  struct PackedSink {
+    sdvl_ctx *ctx = nullptr;
+    sdvl_search_req_packed *reqs = nullptr;
+    int count = 0, cap = 0;
+    uint64_t batch_id = 0;
+  };
+  void PrepareReprojectPacked(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, bool reloc, PackedSink *sink);
   // FinishReproject without SelectInliers: the pose stage then runs either on the host (SelectInliers + OptimizePose)
   // or batched on the device: EmitPoseJob for every tracker, ONE sdvl_pose_from_matches, CommitPose for every tracker.
   struct PoseBatch {
@@ -536,6 +548,8 @@ class FeatureAlign {
   void RemoveOutliers(const std::shared_ptr<Frame> &frame);
   int CheckReprojectionError(const std::vector<int> &idx, const SE3 &se3, double threshold, std::vector<int> *inliers, std::vector<int> *outliers);
   void ProjectPoints(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame);
+  void PrepareReprojectImpl(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, bool reloc,
+                            std::vector<sdvl_search_req> *reqs, PackedSink *sink);
   bool ConvergePose(const SE3 &frame_pose, const int *idx, int n, SE3 *se3);
   static double GetTukeyValue(double x);
 
@@ -632,6 +646,7 @@ class SDVLBatch {
   Device *dev_;
   std::vector<SDVL *> trk_;
   int threads_;
+  uint64_t search_batch_counter_ = 0;
   std::vector<sdvl_search_req> scratch_reqs_;  // per-step request / pose batches, reused so that they never reallocate
   FeatureAlign::PoseBatch scratch_pose_;
 };
