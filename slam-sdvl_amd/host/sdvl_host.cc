@@ -998,6 +998,7 @@ void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_se
 // second half of SelectPoints (feature_align.cc:105-149) replayed over the batch results
 void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
   const int size = static_cast<int>(plan_begin_.size()) - 1;
+  if (!relocalizing_) frame->GetFeatures().reserve(frame->GetFeatures().size() + static_cast<size_t>(max_matches_));
   vector<shared_ptr<Feature>> &src_features = last_frame_->GetFeatures();
   for (int i = 0; i < size && matches_ < max_matches_; i++) {
     bool found = false;
