@@ -200,6 +200,12 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
 int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
                      const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p,
                      sdvl_align_result *out);
+/* The same in two halves: _begin launches and queues the result copy, _end waits for exactly that.  Between the two the
+ * caller may queue work on the context that returns nothing to the host (sdvl_pyramid_build, sdvl_detect_corners,
+ * sdvl_orb_describe): it runs behind the alignment while the host already has the poses. */
+int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
+                           const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p);
+int sdvl_image_align_end(sdvl_ctx *ctx, int n_jobs, sdvl_align_result *out);
 
 /* ---- Matcher::SearchPoint, matcher.cc:45-121 (WarpMatrixAffine :293-312, GetSearchLevel :314-323,
  * CreatePatch :325-357, GetCornersInRange :123-230, SearchFeatures :232-291, AlignPatch :359-445).

@@ -42,14 +42,22 @@ hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
   }
   hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
   if (e != hipSuccess) return e;
-  if (ctx->wait_hook) {
-    while ((e = hipEventQuery(ctx->wait_event)) == hipErrorNotReady) ctx->wait_hook(ctx->wait_user, ctx);
-  } else {
-    e = hipEventSynchronize(ctx->wait_event);
-  }
+  e = sdvl_event_wait(ctx, ctx->wait_event);
   if (e == hipSuccess) {
     ctx->stage_off = 0;
     ctx->wait_gen++;
+  }
+  return e;
+}
+
+hipError_t sdvl_event_wait(sdvl_ctx *ctx, hipEvent_t ev) {
+  hipError_t e;
+  if (ctx->wait_hook) {
+    ctx->waiting_on = ev;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) ctx->wait_hook(ctx->wait_user, ctx);
+    ctx->waiting_on = nullptr;
+  } else {
+    e = hipEventSynchronize(ev);
   }
   return e;
 }
@@ -63,14 +71,14 @@ extern "C" int sdvl_ctx_set_wait_hook(sdvl_ctx *ctx, void (*hook)(void *user, sd
 
 // 1 = everything queued before the wait in flight has completed, 0 = still running (never blocks)
 extern "C" int sdvl_ctx_wait_done(sdvl_ctx *ctx) {
-  if (!ctx || !ctx->wait_event) return 1;
-  return hipEventQuery(ctx->wait_event) == hipErrorNotReady ? 0 : 1;
+  if (!ctx || !ctx->waiting_on) return 1;
+  return hipEventQuery(ctx->waiting_on) == hipErrorNotReady ? 0 : 1;
 }
 
 // sleep (no spinning) until the wait in flight has completed
 extern "C" int sdvl_ctx_wait_block(sdvl_ctx *ctx) {
-  if (!ctx || !ctx->wait_event) return SDVL_OK;
-  return hipEventSynchronize(ctx->wait_event) == hipSuccess ? SDVL_OK : SDVL_ERR_HIP;
+  if (!ctx || !ctx->waiting_on) return SDVL_OK;
+  return hipEventSynchronize(ctx->waiting_on) == hipSuccess ? SDVL_OK : SDVL_ERR_HIP;
 }
 
 int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f) {
@@ -161,6 +169,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   sdvl_timer_collect(ctx);
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
   if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
+  if (ctx->align_event) (void)hipEventDestroy(ctx->align_event);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);

@@ -542,11 +542,12 @@ size_t ia_lds_bytes(int max_f) {
 
 }  // namespace
 
-extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
-                                const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p,
-                                sdvl_align_result *out) {
-  if (!ctx || !cam || !p || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out)) || n_features < 0 || (n_features > 0 && !features))
-    return SDVL_ERR_INVALID;
+// launch + result copy, no wait: the caller may queue more work on the context (kernels that neither read results nor use
+// the context's result buffers: sdvl_pyramid_build, sdvl_detect_corners, sdvl_orb_describe) before sdvl_image_align_end
+extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
+                                      const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p) {
+  if (!ctx || !cam || !p || n_jobs < 0 || (n_jobs > 0 && !jobs) || n_features < 0 || (n_features > 0 && !features)) return SDVL_ERR_INVALID;
+  ctx->align_pending = 0;
   if (n_jobs == 0) return SDVL_OK;
   SDVL_REQUIRE(ctx, p->patch_size == 4, "only align_patch_size 4 is supported");
   SDVL_REQUIRE(ctx, p->min_level >= 0 && p->max_level >= p->min_level && p->max_level < SDVL_MAX_LEVELS, "bad align levels");
@@ -624,7 +625,28 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  memcpy(out, ctx->h_out, res_bytes);
+  if (!ctx->align_event) SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->align_event, hipEventBlockingSync | hipEventDisableTiming));
+  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->align_event, ctx->stream));
+  ctx->align_pending = n_jobs;
   return SDVL_OK;
+}
+
+// waits for the results of the matching sdvl_image_align_begin only — not for work queued after it
+extern "C" int sdvl_image_align_end(sdvl_ctx *ctx, int n_jobs, sdvl_align_result *out) {
+  if (!ctx || n_jobs < 0 || (n_jobs > 0 && !out)) return SDVL_ERR_INVALID;
+  if (n_jobs == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, ctx->align_pending == n_jobs, "sdvl_image_align_end without a matching sdvl_image_align_begin");
+  SDVL_HIP_CHECK(ctx, sdvl_event_wait(ctx, ctx->align_event));
+  memcpy(out, ctx->h_out, sizeof(sdvl_align_result) * n_jobs);
+  ctx->align_pending = 0;
+  return SDVL_OK;
+}
+
+extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
+                                const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p,
+                                sdvl_align_result *out) {
+  if (n_jobs > 0 && !out) return SDVL_ERR_INVALID;
+  const int rc = sdvl_image_align_begin(ctx, n_jobs, jobs, n_features, features, cam, p);
+  if (rc) return rc;
+  return sdvl_image_align_end(ctx, n_jobs, out);
 }

@@ -68,6 +68,9 @@ struct sdvl_ctx {
   hipEvent_t wait_event = nullptr;  // created with hipEventBlockingSync | hipEventDisableTiming
   // cooperative waits: when set, sdvl_stream_wait polls the event and calls the hook while the stream is still busy, so a
   // host thread that drives several contexts can run another one's host stage instead of sleeping
+  hipEvent_t align_event = nullptr;  // marks the result copy of sdvl_image_align_begin
+  int align_pending = 0;
+  hipEvent_t waiting_on = nullptr;   // the event a cooperative wait is polling (sdvl_ctx_wait_done / _block)
   void (*wait_hook)(void *user, sdvl_ctx *ctx) = nullptr;
   void *wait_user = nullptr;
   // per-kernel timing (HIP events on `stream`)
@@ -102,6 +105,9 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);
 int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d);
 // wait for everything queued on ctx->stream WITHOUT spinning: hipEventBlockingSync event + hipEventSynchronize.
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
+// wait (blocking or cooperative, like sdvl_stream_wait) for ONE event already recorded on the stream; work queued after the
+// event may still be running, so the staging ring is not recycled
+hipError_t sdvl_event_wait(sdvl_ctx *ctx, hipEvent_t ev);
 // host copy of a frame's corner count; fetches it (blocking) when only the device knows it
 int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n);
 // make the device corner header match the host view before a kernel reads it (after an image change without detection)

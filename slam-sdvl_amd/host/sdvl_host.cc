@@ -517,6 +517,29 @@ int Frame::SearchSlot(sdvl_ctx *ctx, uint64_t batch_id) {
   return search_slot_;
 }
 
+// Frame::CreateCorners for many frames at once, queued without waiting (the corner lists stay in HBM)
+void Frame::DetectBatch(const vector<shared_ptr<Frame>> &frames, int nfeatures) {
+  const int n = static_cast<int>(frames.size());
+  if (n == 0) return;
+  Device *dev = Device::Current();
+  vector<sdvl_frame *> devs(n);
+  for (int i = 0; i < n; i++) {
+    Frame &f = *frames[i];
+    devs[i] = f.dev_;
+    f.corners_.clear();
+    f.descriptors_.clear();
+    f.descriptors_on_host_ = false;
+    f.corners_on_host_ = false;
+  }
+  const sdvl_detect_params dp = DetectParams();
+  {
+    StageClock clk(ST_FAST);
+    dev->Check(sdvl_detect_corners(dev->ctx(), n, devs.data(), &dp, nfeatures), "sdvl_detect_corners");
+  }
+  StageClock clk(ST_CORNERS_ORB);
+  if (Config::UseORB()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
+}
+
 // frame.cc:122-131
 void Frame::CreateCorners(int, int nfeatures) {
   Device *dev = Device::Current();
@@ -649,7 +672,8 @@ static sdvl_align_params AlignParams(bool fast) {
 
 // image_align.cc:46-84 for n pairs with one launch
 void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> &pairs, bool fast, vector<int> *n_meas,
-                                  vector<double> *errors, vector<int> *iters, const vector<SE3> *start_poses, vector<SE3> *out_poses) {
+                                  vector<double> *errors, vector<int> *iters, const vector<SE3> *start_poses, vector<SE3> *out_poses,
+                                  const std::function<void()> *between) {
   const int n = static_cast<int>(pairs.size());
   n_meas->assign(n, 0);
   errors->assign(n, 1e10);
@@ -701,13 +725,18 @@ void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shar
     jobs.push_back(job);
     job_of.push_back(i);
   }
-  if (jobs.empty()) return;
+  if (jobs.empty()) {
+    if (between) (*between)();
+    return;
+  }
   Device *dev = Device::Current();
   const sdvl_camera cam = pairs[job_of[0]].second->GetCamera()->abi();
   const sdvl_align_params ap = AlignParams(fast);
   vector<sdvl_align_result> res(jobs.size());
-  dev->Check(sdvl_image_align(dev->ctx(), static_cast<int>(jobs.size()), jobs.data(), static_cast<int>(feats.size()), feats.data(), &cam, &ap,
-                              res.data()), "sdvl_image_align");
+  dev->Check(sdvl_image_align_begin(dev->ctx(), static_cast<int>(jobs.size()), jobs.data(), static_cast<int>(feats.size()), feats.data(), &cam,
+                                    &ap), "sdvl_image_align_begin");
+  if (between) (*between)();  // device work that can run behind the alignment (the new frames' corner detection)
+  dev->Check(sdvl_image_align_end(dev->ctx(), static_cast<int>(jobs.size()), res.data()), "sdvl_image_align_end");
   for (size_t j = 0; j < jobs.size(); j++) {
     const int i = job_of[j];
     const SE3 pose2 = SE3::FromArray(res[j].T) * pairs[i].first->GetPose();  // image_align.cc:79
@@ -1471,7 +1500,15 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
 
   // ---- stage 0: Frame construction (pyramid + FAST + selection + ORB), sdvl.cc:59
   vector<shared_ptr<Frame>> frames;
-  Frame::CreateBatch(trk_[0]->camera_, &trk_[0]->orb_detector_, imgs, true, Config::NumFeatures(), &frames, &pfor);
+  // pyramids now; FAST + selection + ORB are queued BEHIND the image alignment (stage 1): alignment only needs the
+  // pyramids, so its results reach the host ~0.4 ms earlier and detection overlaps the host's prepare stage
+  Frame::CreateBatch(trk_[0]->camera_, &trk_[0]->orb_detector_, imgs, false, Config::NumFeatures(), &frames, &pfor);
+  bool detected = false;
+  for (int i = 0; i < B && !detected; i++)
+    if (trk_[i]->state_ == SDVL::STATE_RUNNING && trk_[i]->lost_frames_ >= 3) {  // Relocalize searches the new frame in the prelude
+      Frame::DetectBatch(frames, Config::NumFeatures());
+      detected = true;
+    }
   vector<int> run;  // trackers that execute ProcessFrame this step
   std::unique_ptr<StageClock> clk(new StageClock(ST_PRELUDE));
   for (int i = 0; i < B; i++) {
@@ -1543,7 +1580,8 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     for (int i : run) pairs.push_back({trk_[i]->last_frame_, trk_[i]->current_frame_});
     vector<int> n_meas, iters;
     vector<double> errors;
-    ImageAlign::ComputePoseBatch(pairs, false, &n_meas, &errors, &iters);
+    const std::function<void()> detect = [&]() { Frame::DetectBatch(frames, Config::NumFeatures()); };
+    ImageAlign::ComputePoseBatch(pairs, false, &n_meas, &errors, &iters, nullptr, nullptr, detected ? nullptr : &detect);
     for (int k = 0; k < R; k++) {
       stats[run[k]].align_meas = n_meas[k];
       stats[run[k]].align_iters = iters[k];

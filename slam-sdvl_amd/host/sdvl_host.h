@@ -280,6 +280,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void SetKeyframe() { is_keyframe_ = true; }
   void FilterCorners();
   static void FilterCornersBatch(const std::vector<std::shared_ptr<Frame>> &frames);
+  // corner detection + ORB for frames built with corners = false (CreateBatch): queues the kernels, returns at once
+  static void DetectBatch(const std::vector<std::shared_ptr<Frame>> &frames, int nfeatures);
   const SE3 &GetPose() const { return pose_; }
   void SetPose(const SE3 &se3) { pose_ = se3; world_valid_ = false; }
   std::vector<Image> &GetPyramid();  // host mirror is filled on first call
@@ -373,7 +375,10 @@ class ImageAlign {
   // n frame pairs, one launch; returns per-pair ComputePose results and errors
   static void ComputePoseBatch(const std::vector<std::pair<std::shared_ptr<Frame>, std::shared_ptr<Frame>>> &pairs, bool fast,
                                std::vector<int> *n_meas, std::vector<double> *errors, std::vector<int> *iters = nullptr,
-                               const std::vector<SE3> *start_poses = nullptr, std::vector<SE3> *out_poses = nullptr);
+                               const std::vector<SE3> *start_poses = nullptr, std::vector<SE3> *out_poses = nullptr,
+                               const std::function<void()> *between = nullptr);
+  // between: called after the alignment has been launched and before its results are awaited — device work queued there
+  // (corner detection of the new frames) runs behind the alignment while the host already continues with the poses
   // start_poses[i]: pose of pairs[i].second to start from (default: its current pose); out_poses: where the aligned
   // poses go instead of into the frames — together they let ONE frame be aligned against many references at once
 
