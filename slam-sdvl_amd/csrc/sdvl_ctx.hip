@@ -1,4 +1,7 @@
 // sdvl_ctx.hip — context, staging buffers, per-kernel HIP-event timing, frame allocation and transfers.
+#include <sys/prctl.h>
+#include <time.h>
+
 #include "sdvl_internal.h"
 
 int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned) {
@@ -52,12 +55,27 @@ hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
 
 hipError_t sdvl_event_wait(sdvl_ctx *ctx, hipEvent_t ev) {
   hipError_t e;
+
   if (ctx->wait_hook) {
     ctx->waiting_on = ev;
     while ((e = hipEventQuery(ev)) == hipErrorNotReady) ctx->wait_hook(ctx->wait_user, ctx);
     ctx->waiting_on = nullptr;
   } else {
-    e = hipEventSynchronize(ev);
+    // hipEventSynchronize busy-waits here even for hipEventBlockingSync events (measured: CPU time = wall time inside the
+    // wait; with hipDeviceScheduleBlockingSync still ~2/3 of it), and CPU is what the host side is short of.  So: poll the
+    // event and sleep in between; with the timer slack of the thread at 1 us a 25 us nanosleep costs ~30 us.
+    static const int poll_ns = getenv("SDVL_WAIT_POLL_NS") ? atoi(getenv("SDVL_WAIT_POLL_NS")) : 25000;
+    if (poll_ns <= 0) {
+      e = hipEventSynchronize(ev);
+    } else {
+      static thread_local bool slack_set = false;
+      if (!slack_set) {
+        prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+        slack_set = true;
+      }
+      const struct timespec ts = {0, poll_ns};
+      while ((e = hipEventQuery(ev)) == hipErrorNotReady) nanosleep(&ts, nullptr);
+    }
   }
   return e;
 }
