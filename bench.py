@@ -287,6 +287,13 @@ def main():
         c.timing(True)
     stats_buf = farm.alloc_stats(K)
     import resource
+    def throttled():
+        try:
+            kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+            return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+        except (OSError, ValueError):
+            return 0, 0
+    thr0 = throttled()
     rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     flt0 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
     barrier()
@@ -296,7 +303,9 @@ def main():
     elapsed = time.perf_counter() - t0
     rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     flt1 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
-    sys.stderr.write("host memory: max RSS %.0f -> %.0f MB, minor page faults in the timed region: %d\n" % (rss0 / 1024, rss1 / 1024, flt1 - flt0))
+    thr1 = throttled()
+    sys.stderr.write("host memory: max RSS %.0f -> %.0f MB, minor page faults in the timed region: %d; CPU quota throttling in the timed region: "
+                     "%d periods, %.1f ms\n" % (rss0 / 1024, rss1 / 1024, flt1 - flt0, thr1[0] - thr0[0], (thr1[1] - thr0[1]) / 1e3))
     timers = {}
     for c in ctxs:
         for name, (ms, n) in c.timing_get().items():

@@ -3,7 +3,10 @@
 #include <dlfcn.h>
 #include <execinfo.h>
 #include <signal.h>
+#include <sys/syscall.h>
 #include <sys/time.h>
+#include <time.h>
+#include <unistd.h>
 #include <ucontext.h>
 #include <cxxabi.h>
 
@@ -474,12 +477,24 @@ void ProfStart() {
   sa.sa_handler = ProfHandler;
   sa.sa_flags = SA_RESTART;
   sigaction(SIGPROF, &sa, nullptr);
-  struct itimerval tv = {{0, 1000}, {0, 1000}};
-  setitimer(ITIMER_PROF, &tv, nullptr);
+}
+// one CPU-time timer per worker thread (a process-wide ITIMER_PROF fires once per scheduler tick for the whole process)
+timer_t ProfThreadStart() {
+  struct sigevent sev;
+  memset(&sev, 0, sizeof(sev));
+  sev.sigev_notify = SIGEV_THREAD_ID;
+  sev.sigev_signo = SIGPROF;
+  sev._sigev_un._tid = static_cast<pid_t>(syscall(SYS_gettid));
+  timer_t t = nullptr;
+  if (timer_create(CLOCK_THREAD_CPUTIME_ID, &sev, &t) != 0) return nullptr;
+  struct itimerspec its = {{0, 1000000}, {0, 1000000}};
+  timer_settime(t, 0, &its, nullptr);
+  return t;
+}
+void ProfThreadStop(timer_t t) {
+  if (t) timer_delete(t);
 }
 void ProfStop() {
-  struct itimerval tv = {{0, 0}, {0, 0}};
-  setitimer(ITIMER_PROF, &tv, nullptr);
   const int n = std::min(g_prof_n.load(), kProfMax);
   std::map<std::string, int> self, incl, own;
   for (int i = 0; i < n; i++) {
@@ -531,8 +546,10 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
   std::vector<std::thread> threads;
   for (int w = 0; w < W; w++)
     threads.emplace_back([f, w, W] {
+      timer_t pt = profile ? ProfThreadStart() : nullptr;
       if (f->fibers_per_worker > 1) f->RunShareFibers(w, W);
       else f->RunShare(w, W);
+      ProfThreadStop(pt);
     });
   for (auto &t : threads) t.join();
   if (profile) ProfStop();

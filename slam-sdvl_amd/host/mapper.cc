@@ -487,7 +487,6 @@ void MapperMap::EmitInitCandidates(vector<sdvl_search_req> *reqs) {
   depth_mean_ = cur_->GetSceneDepth();
   vector<Vector3i> &corners = cur_->GetCorners();
   vector<int> &fcorners = cur_->GetFilteredCorners();
-  vector<vector<uchar>> &descriptors = cur_->HostDescriptors();
   const int nc = static_cast<int>(fcorners.size());
   ic_req_.assign(best_kfs_.size() * static_cast<size_t>(nc), -1);
   for (size_t k = 0; k < best_kfs_.size(); k++) {
@@ -500,7 +499,7 @@ void MapperMap::EmitInitCandidates(vector<sdvl_search_req> *reqs) {
       const Vector2d px(corner(0) * scale, corner(1) * scale);
       const Vector3d bearing = camera_->Unproject(px);
       reqs->emplace_back();
-      FillRequest(&reqs->back(), cframe, cur_.get(), px, bearing, corner(2), Config::UseORB() ? descriptors[fcorners[c]].data() : nullptr,
+      FillRequest(&reqs->back(), cframe, cur_.get(), px, bearing, corner(2), Config::UseORB() ? cur_->HostDescriptor(fcorners[c]) : nullptr,
                   1.0 / depth_mean_, 1.0, false, Vector2d(0, 0));
       ic_req_[k * nc + c] = static_cast<int>(reqs->size()) - 1 - req_base_;
     }
@@ -513,7 +512,6 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
   const sdvl_search_res *res = res_all + req_base_;
   vector<Vector3i> &corners = cur_->GetCorners();
   vector<int> &fcorners = cur_->GetFilteredCorners();
-  vector<vector<uchar>> &descriptors = cur_->HostDescriptors();
   const int nc = static_cast<int>(fcorners.size());
   vector<bool> imatches(fcorners.size(), false);
   for (size_t k = 0; k < best_kfs_.size(); k++) {
@@ -528,7 +526,7 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
       const int scale = (1 << corner(2));
       shared_ptr<Point> candidate = std::make_shared<Point>();
       shared_ptr<Feature> feature = std::make_shared<Feature>(cur_, Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
-      if (Config::UseORB()) feature->SetDescriptor(descriptors[index]);
+      if (Config::UseORB()) feature->SetDescriptor(cur_->HostDescriptor(index));
       const sdvl_search_res &r = res[ic_req_[k * nc + count]];
       if (!r.found) continue;
       const Vector2d imgpos(r.px[0], r.px[1]);

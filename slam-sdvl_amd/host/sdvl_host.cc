@@ -9,9 +9,12 @@
 #include <cstring>
 #include <iostream>
 #include <mutex>
+#include <new>
 #include <stdexcept>
 #include <chrono>
 #include <thread>
+
+#include <sys/mman.h>
 
 namespace sdvl {
 
@@ -44,6 +47,30 @@ Device::~Device() {
   for (auto &p : pool_) sdvl_frame_destroy(ctx_, p.f);
   if (g_current_device == this) g_current_device = nullptr;
   sdvl_ctx_destroy(ctx_);
+}
+
+// ------------------------------------------------------------------------------------------------------ ChunkPool
+ChunkPool::~ChunkPool() {
+  for (auto &r : regions_) munmap(r.first, r.second);
+}
+void ChunkPool::Map(size_t bytes) {
+  bytes = (bytes + kChunk - 1) / kChunk * kChunk;
+  void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) throw std::bad_alloc();
+  regions_.push_back({p, bytes});
+  char *c = static_cast<char *>(p);
+  for (size_t off = bytes; off >= kChunk; off -= kChunk) free_.push_back(c + off - kChunk);  // lowest address handed out first
+}
+char *ChunkPool::Get() {
+  std::lock_guard<std::mutex> lk(m_);
+  if (free_.empty()) Map(8u << 20);
+  char *c = free_.back();
+  free_.pop_back();
+  return c;
+}
+void ChunkPool::Put(char *c) {
+  std::lock_guard<std::mutex> lk(m_);
+  free_.push_back(c);
 }
 
 Device *Device::Current() {
@@ -354,6 +381,11 @@ Feature::Feature(const shared_ptr<Frame> &f, const Vector2d &p, int l) : frame_(
   v_ = f->GetCamera()->Unproject(p2d_);
   has_descriptor_ = false;
 }
+Feature::Feature(std::weak_ptr<Frame> &&f, Frame *raw, const Vector2d &p, int l)
+    : frame_(std::move(f)), frame_raw_(raw), point_(nullptr), p2d_(p), level_(l) {
+  v_ = raw->GetCamera()->Unproject(p2d_);
+  has_descriptor_ = false;
+}
 Feature::Feature(const shared_ptr<Frame> &f, const shared_ptr<Point> &ft, const Vector2d &p, int l)
     : frame_(f), frame_raw_(f.get()), point_(ft), p2d_(p), level_(l) {
   v_ = f->GetCamera()->Unproject(p2d_);
@@ -368,7 +400,7 @@ static std::atomic<int> g_point_counter{0};
 
 // point.cc:32-43
 Point::Point() {
-  id_ = g_point_counter++;
+  id_ = g_current_device ? g_current_device->next_point_id++ : g_point_counter++;
   status_ = P_NOT_FOUND;
   last_frame_ = -1;
   n_failed_ = 0;
@@ -416,15 +448,10 @@ bool Point::Unpromote() {
 }
 
 // ---------------------------------------------------------------------------------------------------------- Frame
-int Frame::counter_ = 0;
-static std::mutex g_frame_counter_mutex;
+std::atomic<int> Frame::counter_{0};
 
 void Frame::InitCommon(Camera *camera, ORBDetector *detector, int w, int h) {
-  {
-    std::lock_guard<std::mutex> lk(g_frame_counter_mutex);
-    id_ = counter_;
-    counter_ += 1;
-  }
+  id_ = counter_.fetch_add(1, std::memory_order_relaxed);
   camera_ = camera;
   orb_detector_ = detector;
   pyramid_levels_ = Config::PyramidLevels();
@@ -496,8 +523,11 @@ void Frame::CreateBatch(Camera *camera, ORBDetector *detector, const vector<Imag
   BuildFrames(raw, devs, imgs, corners, nfeatures);
 }
 
+FrameArena *Frame::NewArena() const { return new FrameArena(owner_ ? owner_->chunks : nullptr); }
+
 Frame::~Frame() {
   features_.clear();
+  if (arena_) arena_->Release();  // the arena goes with the last object carved out of it
   if (dev_ && owner_) {
     sdvl_frame *f = dev_;  // hand the HBM frame back to the pool
     dev_ = nullptr;
@@ -528,6 +558,7 @@ void Frame::DetectBatch(const vector<shared_ptr<Frame>> &frames, int nfeatures) 
     devs[i] = f.dev_;
     f.corners_.clear();
     f.descriptors_.clear();
+    f.desc_flat_.clear();
     f.descriptors_on_host_ = false;
     f.corners_on_host_ = false;
   }
@@ -546,6 +577,7 @@ void Frame::CreateCorners(int, int nfeatures) {
   const sdvl_detect_params dp = DetectParams();
   corners_.clear();
   descriptors_.clear();
+  desc_flat_.clear();
   descriptors_on_host_ = false;
   dev->Check(sdvl_detect_corners(dev->ctx(), 1, &dev_, &dp, nfeatures), "sdvl_detect_corners");
   corners_on_host_ = false;
@@ -632,11 +664,8 @@ void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
     FastDetector detector(f.width_, f.height_);
     for (auto it = f.features_.begin(); it != f.features_.end(); it++) detector.LockCell((*it)->GetPosition());
     detector.FilterWithScores(f.pyramid_, f.corners_, scores.data() + i * cap, &f.filtered_corners_);
-    if (orb) {  // frame.cc:145-161: descriptors of the filtered corners on the host
-      f.descriptors_.resize(cnt);
-      for (int index : f.filtered_corners_)
-        if (f.descriptors_[index].empty()) f.descriptors_[index].assign(desc.begin() + (i * cap + index) * 32, desc.begin() + (i * cap + index + 1) * 32);
-    }
+    // frame.cc:145-161 mirrors the descriptors of the filtered corners one std::vector each; here the frame's whole block
+    if (orb) f.desc_flat_.assign(desc.begin() + i * cap * 32, desc.begin() + (i * cap + cnt) * 32);
   }
 }
 
@@ -645,7 +674,7 @@ int Frame::GetNumPoints() const {
   int count = 0;
   for (auto it = features_.begin(); it != features_.end(); it++) {
     if (!(*it)) continue;
-    if (!(*it)->GetPoint()) continue;
+    if (!(*it)->GetPointRaw()) continue;
     count++;
   }
   return count;
@@ -851,19 +880,18 @@ void PlaneMap::SeedFromFiltered(const shared_ptr<Frame> &kf) {
   const M3 Rw = world.GetRotation();
   const Vector3d tw = world.GetTranslation();
   vector<Vector3i> &corners = kf->GetCorners();
-  vector<vector<uchar>> &descriptors = kf->HostDescriptors();  // filled by FilterCorners (frame.cc:145-161)
   for (int index : kf->GetFilteredCorners()) {
     const Vector3i corner = corners[index];
     const int scale = (1 << corner(2));
     shared_ptr<Feature> feature = kf->NewFeature(Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
-    if (Config::UseORB()) feature->SetDescriptor(descriptors[index]);
+    if (Config::UseORB()) feature->SetDescriptor(kf->HostDescriptor(index));  // filled by FilterCorners (frame.cc:145-161)
     const Vector3d &v = feature->GetVector();
     const V3 ray = mvec(Rw, {v(0), v(1), v(2)});
     const double denom = n_(0) * ray.x + n_(1) * ray.y + n_(2) * ray.z;
     if (!(std::fabs(denom) > 1e-9)) continue;
     const double s = (d_ - (n_(0) * tw(0) + n_(1) * tw(1) + n_(2) * tw(2))) / denom;
     if (!(s > 0.05)) continue;
-    shared_ptr<Point> pt = std::make_shared<Point>();
+    shared_ptr<Point> pt = kf->NewPoint();
     const double rho = 1.0 / s;
     pt->InitFixed(feature, s, (0.05 * rho) * (0.05 * rho), world * Vector3d(s * v(0), s * v(1), s * v(2)));
     feature->SetPoint(pt);
@@ -907,7 +935,11 @@ void FeatureAlign::ProjectPoints(const shared_ptr<Frame> &frame, const shared_pt
   for (int i = 0; i < n; i++) {
     // features and points are separate heap objects reached through pointers: ask for the ones a few iterations ahead
     if (i + 8 < n && features[i + 8]) __builtin_prefetch(features[i + 8].get());
-    if (i + 4 < n && features[i + 4]) __builtin_prefetch(features[i + 4]->GetPointRaw());
+    if (i + 4 < n && features[i + 4]) {
+      const char *pp = reinterpret_cast<const char *>(features[i + 4]->GetPointRaw());
+      __builtin_prefetch(pp);
+      __builtin_prefetch(pp + 64);
+    }
     Feature *ft = features[i].get();
     if (ft == nullptr) continue;
     Point *point = ft->GetPointRaw();
@@ -928,6 +960,10 @@ void FeatureAlign::ProjectPoints(const shared_ptr<Frame> &frame, const shared_pt
         const int k = static_cast<int>(p(1) / cell_size_) * grid_width_ + static_cast<int>(p(0) / cell_size_);
         grid_.at(k).push_back(CellEntry{i, p, point->Score()});
         point->SetStatus(Point::P_SEEN);
+        // the request loop of PrepareReproject reads the point's first observation (position, bearing, descriptor) next
+        const char *fp = reinterpret_cast<const char *>(point->GetInitFeatureRaw());
+        __builtin_prefetch(fp);
+        __builtin_prefetch(fp + 64);
       }
     }
     if (!relocalizing_) point->SetLastFrame(frame_id);
@@ -976,7 +1012,6 @@ void FeatureAlign::PrepareReprojectImpl(const shared_ptr<Frame> &frame, const sh
       if (point->ToDelete()) continue;
       Feature *feature = point->GetInitFeatureRaw();
       if (!feature) continue;
-      __builtin_prefetch(feature);
       Candidate c{e.src, -1};
       Frame *ref_frame = feature->GetFrameRaw();
       if (ref_frame && sink) {
@@ -1038,10 +1073,11 @@ void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_searc
       found = r && r->found != 0;
       if (found) {
         if (!relocalizing_) {
-          shared_ptr<Point> point = src_features[cand.src]->GetPoint();
+          shared_ptr<Point> owner = src_features[cand.src]->GetPoint();
+          Point *point = owner.get();
           point->Promote();
           shared_ptr<Feature> feature = frame->NewFeature(Vector2d(r->px[0], r->px[1]), r->level);
-          feature->SetPoint(point);
+          feature->SetPoint(std::move(owner));
           frame->AddFeature(feature);
           point->SetStatus(Point::P_FOUND);
           const Vector3d P = point->GetPosition();
@@ -1396,6 +1432,7 @@ class Pool {
       std::lock_guard<std::mutex> lk(m_);
       fn_ = &fn;
       n_ = n;
+      dev_ = g_current_device;
       next_.store(0);
       pending_ = static_cast<int>(workers_.size());
       gen_++;
@@ -1432,6 +1469,7 @@ class Pool {
         cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
         if (stop_) return;
         seen = gen_;
+        g_current_device = dev_;  // the helpers work for the caller's device (Point ids, scratch)
       }
       Drain();
       {
@@ -1447,6 +1485,7 @@ class Pool {
   unsigned gen_;
   int pending_;
   const std::function<void(int)> *fn_ = nullptr;
+  Device *dev_ = nullptr;
   int n_ = 0;
   std::atomic<int> next_{0};
   std::exception_ptr err_;

@@ -16,6 +16,9 @@
 #ifndef SDVL_HOST_H_
 #define SDVL_HOST_H_
 
+#include <array>
+#include <atomic>
+#include <cstring>
 #include <functional>
 #include <deque>
 #include <list>
@@ -37,6 +40,24 @@ class Feature;
 class Point;
 class Map;
 
+// Host memory for the frame arenas of one Device, handed out in fixed chunks and recycled most-recent-first: the chunks of
+// the frames that die every step come back cache-warm.  (Mapping AND touching the pages up front was measured slower than
+// taking the first-touch faults inside the run: a page the kernel has just zeroed is still in cache when the tracker
+// writes its features into it.)
+class ChunkPool {
+ public:
+  static constexpr size_t kChunk = 32 * 1024;
+  ~ChunkPool();
+  char *Get();
+  void Put(char *c);
+
+ private:
+  void Map(size_t bytes);
+  std::mutex m_;
+  std::vector<char *> free_;
+  std::vector<std::pair<void *, size_t>> regions_;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Device: one sdvl_ctx (= one HIP stream) + a pool of HBM frames.  One per host thread (tracker / mapper).
 class Device {
@@ -55,6 +76,12 @@ class Device {
   std::vector<int32_t> scratch_xyl;  // Frame::FilterCornersBatch round-trip buffers
   std::vector<double> scratch_scores;
   std::vector<uint8_t> scratch_desc;
+  // source of Point ids for the trackers stepping on this device: ids only have to grow along one tracker's own history
+  // (the mapper orders by id), and a counter shared by every group would bounce between their cores
+  std::atomic<int> next_point_id{0};
+  // chunks for the frame arenas (features, points) of the trackers on this device; shared with the arenas, which may
+  // outlive the device object
+  std::shared_ptr<ChunkPool> chunks = std::make_shared<ChunkPool>();
 
  private:
   sdvl_ctx *ctx_ = nullptr;
@@ -152,6 +179,7 @@ class FastDetector {
 class Feature {
  public:
   Feature(const std::shared_ptr<Frame> &f, const Vector2d &p, int l);
+  Feature(std::weak_ptr<Frame> &&f, Frame *raw, const Vector2d &p, int l);  // Frame::NewFeature: no shared_ptr round trip
   Feature(const std::shared_ptr<Frame> &f, const std::shared_ptr<Point> &ft, const Vector2d &p, int l);
   Feature(const std::shared_ptr<Frame> &f, const std::shared_ptr<Point> &ft, const Vector2d &p, const Vector3d &v, int l);
   std::shared_ptr<Frame> GetFrame() { return frame_.lock(); }
@@ -161,12 +189,24 @@ class Feature {
   std::shared_ptr<Point> GetPoint() const { return point_; }
   Point *GetPointRaw() const { return point_.get(); }  // no reference-count traffic in the per-frame loops
   void SetPoint(const std::shared_ptr<Point> &p) { point_ = p; }
+  void SetPoint(std::shared_ptr<Point> &&p) { point_ = std::move(p); }
   const Vector2d &GetPosition() const { return p2d_; }
   const Vector3d &GetVector() const { return v_; }
   void SetVector(Vector3d &v) { v_ = v; }
   int GetLevel() const { return level_; }
-  const std::vector<uchar> &GetDescriptor() const { return descriptor_; }
-  void SetDescriptor(const std::vector<uchar> &d) { descriptor_ = d; descriptor_.resize(32); has_descriptor_ = true; }
+  // the 32 descriptor bytes live inside the feature (the reference keeps a std::vector<uchar>: one more heap block and
+  // one more cache miss per search candidate)
+  const std::array<uchar, 32> &GetDescriptor() const { return descriptor_; }
+  void SetDescriptor(const std::vector<uchar> &d) {
+    descriptor_.fill(0);
+    std::memcpy(descriptor_.data(), d.data(), d.size() < 32 ? d.size() : 32);
+    has_descriptor_ = true;
+  }
+  void SetDescriptor(const uchar *d32) {
+    if (!d32) return;
+    std::memcpy(descriptor_.data(), d32, 32);
+    has_descriptor_ = true;
+  }
   bool HasDescriptor() const { return has_descriptor_; }
   Vector2d GetLevelPosition() { return Vector2d(p2d_(0) / (1 << level_), p2d_(1) / (1 << level_)); }
 
@@ -177,42 +217,61 @@ class Feature {
   Vector2d p2d_;
   Vector3d v_;
   int level_;
-  std::vector<uchar> descriptor_;
   bool has_descriptor_;
+  std::array<uchar, 32> descriptor_;
 };
 
-// Bump allocator for the many small objects that live and die with one frame (its features): one malloc per chunk instead
-// of one per object.  std::allocate_shared keeps a copy of the allocator — and with it the arena — in every control block,
-// so an arena lives exactly as long as the last object carved out of it (a keyframe's features outlive the tracking step,
-// an ordinary frame's die with it).
+// Bump allocator for the many small objects that live and die with one frame (its features, the points it seeds): one
+// malloc per chunk instead of one per object, and neighbours in the frame's lists are neighbours in memory.  The arena
+// counts its live objects plus one reference for the owning frame and frees itself when the last of them goes (a
+// keyframe's features and points outlive the tracking step, an ordinary frame's die with it).  Like the frame's own
+// lists, an arena is used by one thread at a time; only the count is atomic, since the last object may die elsewhere.
 class FrameArena {
  public:
+  explicit FrameArena(const std::shared_ptr<ChunkPool> &pool = nullptr) : pool_(pool), live_(1) {}
   void *Allocate(size_t bytes, size_t align) {
+    live_.fetch_add(1, std::memory_order_relaxed);
     size_t at = (off_ + align - 1) / align * align;
-    if (chunks_.empty() || at + bytes > cap_) {
-      cap_ = bytes > kChunk ? bytes : kChunk;
-      chunks_.emplace_back(new char[cap_]);
+    if (!cur_ || at + bytes > cap_) {
+      if (pool_ && bytes <= ChunkPool::kChunk) {
+        cur_ = pool_->Get();
+        pooled_.push_back(cur_);
+        cap_ = ChunkPool::kChunk;
+      } else {
+        cap_ = bytes > ChunkPool::kChunk ? bytes : ChunkPool::kChunk;
+        heap_.emplace_back(new char[cap_]);
+        cur_ = heap_.back().get();
+      }
       at = 0;
     }
     off_ = at + bytes;
-    return chunks_.back().get() + at;
+    return cur_ + at;
+  }
+  void Release() {  // one object (or the owning frame) is gone
+    if (live_.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this;
   }
 
  private:
-  static constexpr size_t kChunk = 32 * 1024;
-  std::vector<std::unique_ptr<char[]>> chunks_;
+  ~FrameArena() {
+    for (char *c : pooled_) pool_->Put(c);
+  }
+  std::shared_ptr<ChunkPool> pool_;
+  std::vector<char *> pooled_;
+  std::vector<std::unique_ptr<char[]>> heap_;
+  char *cur_ = nullptr;
   size_t off_ = 0, cap_ = 0;
+  std::atomic<int> live_;
 };
 
 template <typename T>
 struct ArenaAllocator {
   typedef T value_type;
-  std::shared_ptr<FrameArena> arena;
-  explicit ArenaAllocator(const std::shared_ptr<FrameArena> &a) : arena(a) {}
+  FrameArena *arena;
+  explicit ArenaAllocator(FrameArena *a) : arena(a) {}
   template <typename U>
   ArenaAllocator(const ArenaAllocator<U> &o) : arena(o.arena) {}
   T *allocate(size_t n) { return static_cast<T *>(arena->Allocate(n * sizeof(T), alignof(T))); }
-  void deallocate(T *, size_t) {}
+  void deallocate(T *, size_t) { arena->Release(); }
   template <typename U>
   bool operator==(const ArenaAllocator<U> &o) const { return arena == o.arena; }
   template <typename U>
@@ -255,16 +314,18 @@ class Point {
   static double PDFNormal(double mean, double sd, double x);
 
  private:
-  int id_;
+  // the fields the per-frame loops touch (ProjectPoints, SelectPoints) first, so that they share a cache line
   PointStatus status_;
   bool delete_;
-  std::list<std::shared_ptr<Feature>> features_;
-  int last_frame_, n_successful_, n_failed_;
-  double a_, b_, rho_, sigma2_, z_range_;
-  double cos_alpha_ = 1.0, last_distance_ = 1.0;
-  std::shared_ptr<Feature> feature_;
   bool fixed_;
+  int last_frame_, n_successful_, n_failed_;
+  int id_;
   Vector3d p3d_;
+  double rho_;
+  std::shared_ptr<Feature> feature_;
+  double sigma2_, a_, b_, z_range_;
+  double cos_alpha_ = 1.0, last_distance_ = 1.0;
+  std::list<std::shared_ptr<Feature>> features_;
 };
 
 // frame.h:41-173
@@ -291,8 +352,10 @@ class Frame : public std::enable_shared_from_this<Frame> {
   std::vector<int> &GetFilteredCorners() { return filtered_corners_; }
   std::vector<Vector2d> &GetOutliers() { return outliers_; }
   std::vector<std::vector<uchar>> &GetDescriptors();  // host mirror of the HBM descriptors
-  // the mirror as it stands (after FilterCorners: the filtered corners' entries), never touches the device
-  std::vector<std::vector<uchar>> &HostDescriptors() { return descriptors_; }
+  // descriptor of corner `index` as FilterCorners mirrored it (one flat block per frame), null before FilterCorners
+  const uchar *HostDescriptor(int index) const {
+    return static_cast<size_t>(index) * 32 + 32 <= desc_flat_.size() ? desc_flat_.data() + static_cast<size_t>(index) * 32 : nullptr;
+  }
   Camera *GetCamera() const { return camera_; }
   int GetWidth() const { return width_; }
   int GetHeight() const { return height_; }
@@ -308,8 +371,13 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_back(f); }
   // a Feature on this frame whose storage comes from the frame's arena (same object as make_shared<Feature>(frame, ...))
   std::shared_ptr<Feature> NewFeature(const Vector2d &p, int level) {
-    if (!arena_) arena_ = std::make_shared<FrameArena>();
-    return std::allocate_shared<Feature>(ArenaAllocator<Feature>(arena_), shared_from_this(), p, level);
+    if (!arena_) arena_ = NewArena();
+    return std::allocate_shared<Feature>(ArenaAllocator<Feature>(arena_), weak_from_this(), this, p, level);
+  }
+  // a Point whose storage comes from this frame's arena (the points a keyframe seeds sit next to their features)
+  std::shared_ptr<Point> NewPoint() {
+    if (!arena_) arena_ = NewArena();
+    return std::allocate_shared<Point>(ArenaAllocator<Point>(arena_));
   }
   void AddOutlier(const Vector2d &p) { outliers_.push_back(p); }
   int GetNumFeatures() const { return static_cast<int>(features_.size()); }
@@ -353,17 +421,19 @@ class Frame : public std::enable_shared_from_this<Frame> {
   std::vector<int> filtered_corners_;
   std::vector<Vector2d> outliers_;
   std::vector<std::vector<uchar>> descriptors_;
+  std::vector<uchar> desc_flat_;
   bool descriptors_on_host_ = false;
   bool corners_on_host_ = true;  // false after a device-side DetectPyramid until GetCorners() mirrors the list
   sdvl_frame *dev_ = nullptr;
   Device *owner_ = nullptr;
-  std::shared_ptr<FrameArena> arena_;
+  FrameArena *arena_ = nullptr;
+  FrameArena *NewArena() const;
   int search_slot_ = -1;
   uint64_t search_batch_ = 0;
   int kf_id_ = 0;
   bool delete_ = false, selected_ = false;
   std::vector<std::pair<std::shared_ptr<Frame>, int>> connections_;
-  static int counter_;
+  static std::atomic<int> counter_;
 };
 
 // image_align.h:33-66
