@@ -11,8 +11,10 @@
 
 namespace {
 
-constexpr int kPyrTW = 64, kPyrTH = 16;              // output tile of one 256-thread workgroup
-constexpr int kPyrSW = 2 * kPyrTW + 3, kPyrSH = 2 * kPyrTH + 3;  // source tile 131 x 35
+constexpr int kPyrTW = 64, kPyrTH = 16;  // output tile of one 256-thread workgroup
+constexpr int kPyrSH = 2 * kPyrTH + 3;   // source rows of a tile: 35
+constexpr int kPyrSWW = kPyrTW / 2 + 2;  // source words of a tile row: bytes [2*tx0 - 4, 2*tx0 + 132)
+constexpr int kPyrPitch = (kPyrSWW + 1) * 4;  // LDS row pitch in bytes (odd number of words: rows start in different banks)
 
 struct PyrJob {
   const uint8_t *src;
@@ -26,32 +28,84 @@ __device__ __forceinline__ int reflect101_clamped(int p, int n) {
   return min(max(p, 0), n - 1);
 }
 
+// One workgroup = one 64 x 16 output tile.  The 35 source rows are staged with aligned 32-bit loads (byte b of an LDS row
+// is source column 2*tx0 - 4 + b); the columns that fall off the image are patched afterwards from their BORDER_REFLECT_101
+// mirror inside the same row.  Horizontal 1-4-6-4-1 pass into 16-bit sums, then every thread finishes 4 adjacent outputs
+// and stores them as one word.
 __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrJob *__restrict__ jobs) {
-  __shared__ uint8_t s_src[kPyrSH][kPyrSW + 1];
-  __shared__ uint16_t s_h[kPyrSH][kPyrTW];
+  __shared__ uint32_t s_srcw[kPyrSH * (kPyrSWW + 1)];
+  __shared__ __attribute__((aligned(8))) uint16_t s_h[kPyrSH][kPyrTW];
   const PyrJob job = jobs[blockIdx.z];
   const int tx0 = blockIdx.x * kPyrTW, ty0 = blockIdx.y * kPyrTH;
   if (tx0 >= job.dw || ty0 >= job.dh) return;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < kPyrSH * kPyrSW; idx += 256) {
-    const int r = idx / kPyrSW, c = idx - r * kPyrSW;
-    const int sy = reflect101_clamped(2 * ty0 - 2 + r, job.sh);
-    const int sx = reflect101_clamped(2 * tx0 - 2 + c, job.sw);
-    s_src[r][c] = job.src[static_cast<size_t>(sy) * job.sw + sx];
+  uint8_t *s_bytes = reinterpret_cast<uint8_t *>(s_srcw);
+  const int xb = 2 * tx0 - 4;  // source column of byte 0 of an LDS row
+  // the part of the tile that exists: nx x ny outputs, fed by source rows 0 .. 2*ny+2 and row bytes 2 .. 2*nx+4
+  const int nx = min(kPyrTW, job.dw - tx0), ny = min(kPyrTH, job.dh - ty0);
+  const int rows = 2 * ny + 3, last_byte = 2 * nx + 4;
+  if ((job.sw & 3) == 0 && (reinterpret_cast<uintptr_t>(job.src) & 3u) == 0) {
+    const int words_row = job.sw >> 2, w0 = xb >> 2;  // w0 = -1 for the leftmost tile
+    const int nwords = last_byte / 4 + 1;
+    for (int idx = tid; idx < rows * kPyrSWW; idx += 256) {
+      const int r = idx / kPyrSWW, c = idx - r * kPyrSWW;  // constant divisor; narrow tiles skip the words they do not need
+      if (c >= nwords) continue;
+      const int sy = reflect101_clamped(2 * ty0 - 2 + r, job.sh);
+      const int wi = min(max(w0 + c, 0), words_row - 1);
+      s_srcw[r * (kPyrSWW + 1) + c] = reinterpret_cast<const uint32_t *>(job.src + static_cast<size_t>(sy) * job.sw)[wi];
+    }
+    __syncthreads();
+    if (tid < rows && (xb < 0 || xb + last_byte >= job.sw)) {  // border tiles: one thread mends one row
+      uint8_t *row = s_bytes + tid * kPyrPitch;
+      if (xb < 0) {  // columns -2, -1 mirror columns 2, 1
+        row[2] = row[6];
+        row[3] = row[5];
+      }
+      for (int b = max(2, job.sw - xb); b <= last_byte; b++) row[b] = row[max(reflect101_clamped(xb + b, job.sw) - xb, 0)];
+    }
+  } else {  // odd widths: byte by byte
+    const int ncols = last_byte - 1;
+    for (int idx = tid; idx < rows * ncols; idx += 256) {
+      const int r = idx / ncols, c = idx - r * ncols;
+      const int sy = reflect101_clamped(2 * ty0 - 2 + r, job.sh);
+      const int sx = reflect101_clamped(2 * tx0 - 2 + c, job.sw);
+      s_bytes[r * kPyrPitch + 2 + c] = job.src[static_cast<size_t>(sy) * job.sw + sx];
+    }
   }
   __syncthreads();
-  for (int idx = tid; idx < kPyrSH * kPyrTW; idx += 256) {
+  for (int idx = tid; idx < rows * kPyrTW; idx += 256) {
     const int r = idx / kPyrTW, x = idx - r * kPyrTW;
-    const uint8_t *s = &s_src[r][2 * x];
-    s_h[r][x] = static_cast<uint16_t>(s[0] + s[4] + 4 * (s[1] + s[3]) + 6 * s[2]);
+    if (x < nx) {
+      const uint8_t *s = s_bytes + r * kPyrPitch + 2 + 2 * x;  // source columns 2*(tx0+x) - 2 .. + 2
+      s_h[r][x] = static_cast<uint16_t>(s[0] + s[4] + 4 * (s[1] + s[3]) + 6 * s[2]);
+    }
   }
   __syncthreads();
-  for (int idx = tid; idx < kPyrTH * kPyrTW; idx += 256) {
-    const int y = idx / kPyrTW, x = idx - y * kPyrTW;
+  {
+    const int y = tid >> 4, x = (tid & 15) * 4;
     const int oy = ty0 + y, ox = tx0 + x;
     if (oy < job.dh && ox < job.dw) {
-      const int v = s_h[2 * y][x] + s_h[2 * y + 4][x] + 4 * (s_h[2 * y + 1][x] + s_h[2 * y + 3][x]) + 6 * s_h[2 * y + 2][x];
-      job.dst[static_cast<size_t>(oy) * job.dw + ox] = static_cast<uint8_t>((v + 128) >> 8);
+      int acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[k] = 0;
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        const int wgt = (t == 0 || t == 4) ? 1 : (t == 2 ? 6 : 4);
+        const uint2 hv = *reinterpret_cast<const uint2 *>(&s_h[2 * y + t][x]);
+        acc[0] += wgt * static_cast<int>(hv.x & 0xFFFFu);
+        acc[1] += wgt * static_cast<int>(hv.x >> 16);
+        acc[2] += wgt * static_cast<int>(hv.y & 0xFFFFu);
+        acc[3] += wgt * static_cast<int>(hv.y >> 16);
+      }
+      uint8_t *d = job.dst + static_cast<size_t>(oy) * job.dw + ox;
+      if (ox + 3 < job.dw && (reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
+        *reinterpret_cast<uint32_t *>(d) = static_cast<uint32_t>((acc[0] + 128) >> 8) | (static_cast<uint32_t>((acc[1] + 128) >> 8) << 8) |
+                                           (static_cast<uint32_t>((acc[2] + 128) >> 8) << 16) | (static_cast<uint32_t>((acc[3] + 128) >> 8) << 24);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (ox + k < job.dw) d[k] = static_cast<uint8_t>((acc[k] + 128) >> 8);
+      }
     }
   }
 }
