@@ -117,7 +117,9 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
         "fast_cells": sum(P[:3]) + 16 * n_c,                         # FAST read + keypoint write
         "orb_describe": n_c * (961 + 32),                            # 31x31 window + descriptor
         "image_align": 3 * n_f * 49 + i_ia * n_f * 25,               # reference windows + current windows per GN iteration
-        "search_points": 12 * n_c + n_s * (121 + 164 + i_fa * 81),   # corner list + warp window + patches + LK windows
+        # corner list + warp window + patches + LK windows + the 31x31 ORB window of the matched corner (descriptors are
+        # computed by the search itself, for the corners it compares: at least one per match)
+        "search_points": 12 * n_c + n_s * (121 + 164 + i_fa * 81) + n_m * 961,
         "search_prepare": n_s * (120 + 80),                            # request records read, scalar-phase records written
         "pose_hypotheses": 48 * n_m + 100 * 64,                      # match records read once + one result per RANSAC draw
         "pose_refine": 48 * n_m + 100 * 64 + 4 * n_m + 80,           # matches + draw results read, index lists + pose written
@@ -339,10 +341,12 @@ def main():
                                                     n_ia / frames_rank, n_lk / max(1, n_s), n_m / frames_rank)
             launches_per_step = launches / K          # all groups together
             if per_frame is not None:
-                bytes_per_launch = per_frame * B / launches_per_step
+                # descriptors of whole frames, Shi-Tomasi scores and the filter gather run on the frames that become keyframes only
+                frames_per_step = n_kf / K if name in ("orb_describe", "shi_tomasi", "filter_gather") else B
+                bytes_per_launch = per_frame * frames_per_step / launches_per_step
                 achieved = bytes_per_launch / avg_s / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes(name, B / launches_per_step),
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes(name, frames_per_step / launches_per_step),
                             "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch)}
         value = tracked_all / elapsed_max
         out = {

@@ -181,10 +181,14 @@ int sdvl_frame_num_corners(const sdvl_frame *f);
  * FastDetector::FilterCorners fast_detector.cc:205); out_scores[i*cap + k]; the grid logic stays on the host */
 int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, double *out_scores);
 
-/* ORBDetector::GetDescriptor for every corner of n frames (orb_detector.cc:350-395; lazily called from
- * matcher.cc:266-269 and frame.cc:148-161).  Descriptors stay in HBM; out_desc (may be NULL) = [n][cap][32] */
+/* ORBDetector::GetDescriptor for every corner of n frames (orb_detector.cc:350-395).  Descriptors stay in HBM; out_desc
+ * (may be NULL) = [n][cap][32].  The reference computes descriptors lazily (matcher.cc:266-269: the corners a search
+ * compares; frame.cc:148-161: the filtered corners of a keyframe), and so does this library: the calls that read a
+ * frame's descriptors (sdvl_filter_inputs, sdvl_frame_download_descriptors) run this first if it has not been, and a
+ * search on a frame without descriptors computes exactly the ones it compares.  Calling it up front is never wrong —
+ * the values are the same — only more work. */
 int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *out_desc);
-/* host mirror of descriptors_ (GetDescriptors()): out = [n_corners][32]; needs a prior sdvl_orb_describe */
+/* host mirror of descriptors_ (GetDescriptors()): out = [n_corners][32] */
 int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap, uint8_t *out);
 /* Everything Frame::FilterCorners (frame.cc:133-163) needs from n frames in ONE round trip: corner lists, their
  * Shi-Tomasi scores (K3 launched here) and ORB descriptors.  xyl[n][cap][3], scores[n][cap], desc[n][cap][32]
@@ -209,7 +213,9 @@ int sdvl_image_align_end(sdvl_ctx *ctx, int n_jobs, sdvl_align_result *out);
 
 /* ---- Matcher::SearchPoint, matcher.cc:45-121 (WarpMatrixAffine :293-312, GetSearchLevel :314-323,
  * CreatePatch :325-357, GetCornersInRange :123-230, SearchFeatures :232-291, AlignPatch :359-445).
- * The current frames need corners (sdvl_frame_set_corners) and, with use_orb, descriptors (sdvl_orb_describe). -- */
+ * The current frames need corners (sdvl_frame_set_corners / sdvl_detect_corners).  With use_orb the descriptors of a
+ * current frame are read from HBM if sdvl_orb_describe has run on it; otherwise every wave computes the descriptor of
+ * each corner it finds in range (matcher.cc:266-269), about a fifth of a frame's corners in a tracking step. -- */
 int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
                        const sdvl_search_params *p, sdvl_search_res *out);
 
@@ -217,7 +223,7 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
  * in the device layout, straight into the context's pinned staging area, and name their frames by slot.
  *   sdvl_search_begin  reserves room for max_requests records and returns the array to fill;
  *   sdvl_search_slot   registers a (frame, pose) pair of this batch and returns its slot (>= 0), or a negative status;
- *                      the frame must have corners (and descriptors in ORB mode) as for sdvl_search_points;
+ *                      the frame must have corners as for sdvl_search_points;
  *   sdvl_search_run    evaluates the first n records.
  * No other call on this context between begin and run. */
 typedef struct sdvl_search_req_packed {

@@ -154,6 +154,15 @@ class Frame:
         self.ctx._check(self.ctx.lib.sdvl_frame_set_corners(self.ctx.h, self.h, len(xyl), _ptr(xyl, i32p)))
         return self
 
+    def descriptors(self, cap=4096):
+        """host mirror of the frame's ORB descriptors, [n_corners][32] (computed now if they have not been)"""
+        out = np.zeros((cap, 32), np.uint8)
+        n = (C.c_int32 * 1)()
+        hs = (C.c_void_p * 1)(self.h)
+        self.ctx._check(self.ctx.lib.sdvl_frames_corner_counts(self.ctx.h, 1, hs, n))
+        self.ctx._check(self.ctx.lib.sdvl_frame_download_descriptors(self.ctx.h, self.h, cap, _ptr(out, u8p)))
+        return out[:n[0]]
+
     def close(self):
         if self.h:
             self.ctx.lib.sdvl_frame_destroy(self.ctx.h, self.h)

@@ -1,20 +1,14 @@
 // sdvl_orb.hip — K3 Shi-Tomasi score and K4 ORB (orientation + 256-bit steered BRIEF), one wave64 per corner.
-//   K4  orb_describe_kernel : ORBDetector::GetDescriptor / GetOrientation, extra/orb_detector.cc:350-437.
-//        Orientation: lanes stride the radius-15 disc (umax_ table of InitParameters :325-348), exact int32
-//        moments, wave butterfly; cv::fastAtan2 polynomial in float (all lanes redundantly -> no broadcast);
-//        cos/sin of the float angle in double, rounded to float (DESIGN.md "frozen interpretations");
-//        lane k evaluates tests 4k..4k+3 with cvRound = v_rndne_f32, nibbles are merged pairwise into bytes.
+//   K4  orb_describe_kernel : ORBDetector::GetDescriptor / GetOrientation, extra/orb_detector.cc:350-437 — the per-corner
+//        arithmetic is orb_wave_nibble() in sdvl_orb_device.h; here nibbles are merged pairwise into bytes and stored.
 //   K3  shi_tomasi_kernel   : FindShiTomasiScoreAtPoint, extra/utils.cc:61-97 — lane = pixel of the 8x8 box,
 //        exact int32 sums (every partial sum < 2^24 so the reference's float loop is exact too), float/double tail.
-// No FMA contraction (-ffp-contract=off): sample coordinates round exactly as on the CPU.
+#include <vector>
+
 #include "sdvl_internal.h"
+#include "sdvl_orb_device.h"
 
 namespace {
-
-__constant__ __attribute__((aligned(16))) int8_t c_orb_pattern[256 * 4] = {
-#include "orb_pattern_31.inc"
-};
-
 
 struct OrbJob {
   const uint8_t *level[SDVL_MAX_LEVELS];
@@ -29,35 +23,7 @@ struct OrbJob {
   int levels;
 };
 
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// cv::fastAtan2 (degrees), OpenCV >= 2.4.9 scalar polynomial
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-  const float p1 = 0.9997878412794807f * static_cast<float>(180 / M_PI);
-  const float p3 = -0.3258083974640975f * static_cast<float>(180 / M_PI);
-  const float p5 = 0.1555786518463281f * static_cast<float>(180 / M_PI);
-  const float p7 = -0.04432655554792128f * static_cast<float>(180 / M_PI);
-  const float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = ay / (ax + static_cast<float>(2.2204460492503131e-16));
-    c2 = c * c;
-    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  } else {
-    c = ax / (ay + static_cast<float>(2.2204460492503131e-16));
-    c2 = c * c;
-    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  }
-  if (x < 0) a = 180.f - a;
-  if (y < 0) a = 360.f - a;
-  return a;
-}
-
-__device__ __forceinline__ int cv_round_f(float v) { return static_cast<int>(__builtin_rintf(v)); }
+__device__ __forceinline__ int wave_sum_i32(int v) { return orb_wave_sum_i32(v); }
 
 // grid.x = ceil(max_n / 4) workgroups of 4 waves, grid.y = jobs (frames)
 __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restrict__ jobs) {
@@ -80,49 +46,8 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
     continue;
   }
   const uint8_t *center = job.level[cl] + static_cast<size_t>(cy) * W + cx;
-  // intensity centroid over the disc: 31 rows x 8 four-pixel segments (u = -16 .. 15) = 248 tasks over 64 lanes,
-  // one unaligned 32-bit load per task; umax_ (orb_detector.cc:325-348) lives in two immediates, 4 bits per row
-  int m10 = 0, m01 = 0;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int task = lane + 64 * r;
-    if (task < 248) {
-      const int v = (task >> 3) - 15, u0 = -16 + 4 * (task & 7);
-      const int av = v < 0 ? -v : v;
-      // umax = {15,15,15,15,14,14,14,13, 13,12,11,10,9,8,6,3}
-      const int um = static_cast<int>(((av < 8 ? 0xDEEEFFFFu : 0x3689ABCDu) >> (4 * (av & 7))) & 15u);
-      uint32_t w;
-      __builtin_memcpy(&w, center + v * W + u0, 4);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int u = u0 + k;
-        if ((u < 0 ? -u : u) <= um) {
-          const int p = static_cast<int>((w >> (8 * k)) & 0xFFu);
-          m10 += u * p;
-          m01 += v * p;
-        }
-      }
-    }
-  }
-  m10 = wave_sum_i32(m10);
-  m01 = wave_sum_i32(m01);
-  const float angle_deg = fast_atan2_deg(static_cast<float>(m01), static_cast<float>(m10));
-  const float factorPI = static_cast<float>(M_PI / 180.f);
-  const float angle = static_cast<float>(static_cast<double>(angle_deg) * factorPI);
-  const float a = static_cast<float>(cos(static_cast<double>(angle)));
-  const float b = static_cast<float>(sin(static_cast<double>(angle)));
-  // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..); its 16 pattern bytes come in one 128-bit load
-  const uint4 pw = reinterpret_cast<const uint4 *>(c_orb_pattern)[lane];
-  const uint32_t pq[4] = {pw.x, pw.y, pw.z, pw.w};
-  uint32_t nib = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int x0 = static_cast<int8_t>(pq[q] & 0xFF), y0 = static_cast<int8_t>((pq[q] >> 8) & 0xFF);
-    const int x1 = static_cast<int8_t>((pq[q] >> 16) & 0xFF), y1 = static_cast<int8_t>(pq[q] >> 24);
-    const int t0 = center[cv_round_f(x0 * b + y0 * a) * W + cv_round_f(x0 * a - y0 * b)];
-    const int t1 = center[cv_round_f(x1 * b + y1 * a) * W + cv_round_f(x1 * a - y1 * b)];
-    nib |= (t0 < t1 ? 1u : 0u) << q;
-  }
+  float angle_deg;
+  const uint32_t nib = orb_wave_nibble(center, W, lane, &angle_deg);
   const uint32_t hi = __shfl_down(nib, 1, 64);
   if ((lane & 1) == 0) {
     const uint8_t byte = static_cast<uint8_t>(nib | (hi << 4));
@@ -293,9 +218,15 @@ int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap,
                        int32_t *counts) {
   if (!ctx || n < 0 || (n > 0 && (!frames || !xyl || !scores || !counts)) || cap <= 0) return SDVL_ERR_INVALID;
   if (n == 0) return SDVL_OK;
-  for (int i = 0; i < n; i++) {
-    SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
-    if (desc) SDVL_REQUIRE(ctx, frames[i]->desc_valid, "frame has no ORB descriptors (call sdvl_orb_describe)");
+  for (int i = 0; i < n; i++) SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+  if (desc) {  // frames whose descriptors have not been computed yet (searches compute only what they compare) get them now
+    std::vector<sdvl_frame *> missing;
+    for (int i = 0; i < n; i++)
+      if (!frames[i]->desc_valid) missing.push_back(frames[i]);
+    if (!missing.empty()) {
+      const int rc0 = sdvl_orb_describe(ctx, static_cast<int>(missing.size()), missing.data(), SDVL_MAX_CORNERS, nullptr);
+      if (rc0) return rc0;
+    }
   }
   // rows only as long as they have to be: the largest corner count when the host already knows every count
   int ccap = cap < SDVL_MAX_CORNERS ? cap : SDVL_MAX_CORNERS;
@@ -359,7 +290,11 @@ int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap,
     int rc0 = sdvl_frame_count_host(ctx, const_cast<sdvl_frame *>(f), &cnt);
     if (rc0) return rc0;
   }
-  SDVL_REQUIRE(ctx, f->desc_valid || f->v.n_corners == 0, "frame has no ORB descriptors (call sdvl_orb_describe)");
+  if (!f->desc_valid && f->v.n_corners != 0) {
+    sdvl_frame *fm = const_cast<sdvl_frame *>(f);
+    const int rc1 = sdvl_orb_describe(ctx, 1, &fm, SDVL_MAX_CORNERS, nullptr);
+    if (rc1) return rc1;
+  }
   if (f->v.n_corners > cap) {
     ctx->err = "descriptor output capacity smaller than the corner count";
     return SDVL_ERR_CAPACITY;

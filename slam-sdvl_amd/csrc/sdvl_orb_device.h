@@ -1,0 +1,101 @@
+// sdvl_orb_device.h — the wave64 ORB descriptor (orientation + 256-bit steered BRIEF) as a device function, shared by
+// orb_describe_kernel (sdvl_orb.hip: every corner of a frame) and search_points_kernel (sdvl_search.hip: only the corners
+// a search actually compares, when the frame's descriptors have not been computed).
+//   ORBDetector::GetDescriptor / GetOrientation, extra/orb_detector.cc:350-437.
+//   Orientation: lanes stride the radius-15 disc (umax_ table of InitParameters :325-348), exact int32 moments, wave
+//   butterfly; cv::fastAtan2 polynomial in float (all lanes redundantly -> no broadcast); cos/sin of the float angle in
+//   double, rounded to float (DESIGN.md "frozen interpretations"); lane k evaluates tests 4k..4k+3 with cvRound =
+//   v_rndne_f32.  No FMA contraction (-ffp-contract=off): sample coordinates round exactly as on the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+__constant__ __attribute__((aligned(16))) int8_t c_orb_pattern[256 * 4] = {
+#include "orb_pattern_31.inc"
+};
+
+
+__device__ __forceinline__ int orb_wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// cv::fastAtan2 (degrees), OpenCV >= 2.4.9 scalar polynomial
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * static_cast<float>(180 / M_PI);
+  const float p3 = -0.3258083974640975f * static_cast<float>(180 / M_PI);
+  const float p5 = 0.1555786518463281f * static_cast<float>(180 / M_PI);
+  const float p7 = -0.04432655554792128f * static_cast<float>(180 / M_PI);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + static_cast<float>(2.2204460492503131e-16));
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + static_cast<float>(2.2204460492503131e-16));
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__device__ __forceinline__ int cv_round_f(float v) { return static_cast<int>(__builtin_rintf(v)); }
+
+// The 4 BRIEF bits of this lane (tests 4*lane .. 4*lane+3, bit q = test 4*lane+q) for the corner at `center` (row stride
+// W); the caller has checked ORBDetector::IsInsideLimits (19 px from every border).  All 64 lanes must call.
+// Byte b of the descriptor = nibble of lane 2b | nibble of lane 2b+1 << 4.
+__device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W, int lane, float *angle_deg_out) {
+  // intensity centroid over the disc: 31 rows x 8 four-pixel segments (u = -16 .. 15) = 248 tasks over 64 lanes,
+  // one unaligned 32-bit load per task; umax_ (orb_detector.cc:325-348) lives in two immediates, 4 bits per row
+  int m10 = 0, m01 = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int task = lane + 64 * r;
+    if (task < 248) {
+      const int v = (task >> 3) - 15, u0 = -16 + 4 * (task & 7);
+      const int av = v < 0 ? -v : v;
+      // umax = {15,15,15,15,14,14,14,13, 13,12,11,10,9,8,6,3}
+      const int um = static_cast<int>(((av < 8 ? 0xDEEEFFFFu : 0x3689ABCDu) >> (4 * (av & 7))) & 15u);
+      uint32_t w;
+      __builtin_memcpy(&w, center + v * W + u0, 4);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int u = u0 + k;
+        if ((u < 0 ? -u : u) <= um) {
+          const int p = static_cast<int>((w >> (8 * k)) & 0xFFu);
+          m10 += u * p;
+          m01 += v * p;
+        }
+      }
+    }
+  }
+  m10 = orb_wave_sum_i32(m10);
+  m01 = orb_wave_sum_i32(m01);
+  const float angle_deg = fast_atan2_deg(static_cast<float>(m01), static_cast<float>(m10));
+  const float factorPI = static_cast<float>(M_PI / 180.f);
+  const float angle = static_cast<float>(static_cast<double>(angle_deg) * factorPI);
+  const float a = static_cast<float>(cos(static_cast<double>(angle)));
+  const float b = static_cast<float>(sin(static_cast<double>(angle)));
+  // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..); its 16 pattern bytes come in one 128-bit load
+  const uint4 pw = reinterpret_cast<const uint4 *>(c_orb_pattern)[lane];
+  const uint32_t pq[4] = {pw.x, pw.y, pw.z, pw.w};
+  uint32_t nib = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int x0 = static_cast<int8_t>(pq[q] & 0xFF), y0 = static_cast<int8_t>((pq[q] >> 8) & 0xFF);
+    const int x1 = static_cast<int8_t>((pq[q] >> 16) & 0xFF), y1 = static_cast<int8_t>(pq[q] >> 24);
+    const int t0 = center[cv_round_f(x0 * b + y0 * a) * W + cv_round_f(x0 * a - y0 * b)];
+    const int t1 = center[cv_round_f(x1 * b + y1 * a) * W + cv_round_f(x1 * a - y1 * b)];
+    nib |= (t0 < t1 ? 1u : 0u) << q;
+  }
+  *angle_deg_out = angle_deg;
+  return nib;
+}
+
+}  // namespace

@@ -18,6 +18,7 @@
 
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
+#include "sdvl_orb_device.h"
 
 namespace {
 
@@ -364,55 +365,90 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
       sumA = wave_sum_i32(pv);
       sumAA = wave_sum_i32(pv * pv);
     }
-    for (int ci = lane; ci < n_corners; ci += 64) {
-      const uint32_t pk = s_corners[ci];
-      const int cx = static_cast<int>(pk & 0xFFFu), cy = static_cast<int>((pk >> 12) & 0xFFFu), cl = static_cast<int>(pk >> 24);
-      int d = cl - level;
-      if (d < 0) d = -d;
-      if (d > 1) continue;
-      if (cx - prm.margin < 0 || cy - prm.margin < 0) continue;
-      if (cy + prm.margin >= cf.lh[cl] || cx + prm.margin >= cf.lw[cl]) continue;
-      const double posx = cx * (1 << cl), posy = cy * (1 << cl);
-      if (rq.fixed) {
-        const double ddx = rq.px0[0] - posx, ddy = rq.px0[1] - posy;
-        if (ddx * ddx + ddy * ddy > range2) continue;
-      } else {
-        const double dist = normdist - (posx * nx + posy * ny);
-        if (fabs(dist) > range) continue;
-        const double uu = ((posx - pxa.x) * xdiff + (posy - pxa.y) * ydiff) / vline;
-        if (uu > 1) {
-          const double ddx = posx - pxb.x, ddy = posy - pxb.y;
-          if ((ddx * ddx + ddy * ddy) > range2) continue;
-        }
-        if (uu < 0) {
-          const double ddx = posx - pxa.x, ddy = posy - pxa.y;
-          if ((ddx * ddx + ddy * ddy) > range2) continue;
-        }
+    // a current frame without descriptors (sdvl_orb_describe not run): the wave computes the descriptor of every corner
+    // that falls in range on the spot — same arithmetic, same values; a tracking step compares ~200 of ~1000 corners
+    const bool lazy_desc = prm.use_orb && cf.desc == nullptr;
+    for (int c0 = 0; c0 < n_corners; c0 += 64) {
+      const int ci = c0 + lane;
+      bool inr = ci < n_corners;
+      int cx = 0, cy = 0, cl = 0;
+      if (inr) {
+        const uint32_t pk = s_corners[ci];
+        cx = static_cast<int>(pk & 0xFFFu);
+        cy = static_cast<int>((pk >> 12) & 0xFFFu);
+        cl = static_cast<int>(pk >> 24);
+        int d = cl - level;
+        if (d < 0) d = -d;
+        if (d > 1) inr = false;
       }
-      int score;
-      if (prm.use_orb) {
-        const uint32_t *dd = reinterpret_cast<const uint32_t *>(cf.desc + static_cast<size_t>(ci) * 32);
-        score = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) score += __popc(dd[k] ^ rq.desc[k]);
-      } else {
-        // CompareZMSSDScore, matcher.cc:461-476 (integer arithmetic, integer division by 64)
-        const uint8_t *cp = cf.level[cl] + static_cast<size_t>(cy - 4) * cf.lw[cl] + (cx - 4);
-        unsigned sumB = 0, sumBB = 0, sumAB = 0;
-        for (int yy = 0, r = 0; yy < 8; yy++)
-          for (int xx = 0; xx < 8; xx++, r++) {
-            const unsigned pix = cp[yy * cf.lw[cl] + xx];
-            sumB += pix;
-            sumBB += pix * pix;
-            sumAB += pix * L.patch[r];
+      if (inr && (cx - prm.margin < 0 || cy - prm.margin < 0)) inr = false;
+      if (inr && (cy + prm.margin >= cf.lh[cl] || cx + prm.margin >= cf.lw[cl])) inr = false;
+      if (inr) {
+        const double posx = cx * (1 << cl), posy = cy * (1 << cl);
+        if (rq.fixed) {
+          const double ddx = rq.px0[0] - posx, ddy = rq.px0[1] - posy;
+          if (ddx * ddx + ddy * ddy > range2) inr = false;
+        } else {
+          const double dist = normdist - (posx * nx + posy * ny);
+          if (fabs(dist) > range) inr = false;
+          if (inr) {
+            const double uu = ((posx - pxa.x) * xdiff + (posy - pxa.y) * ydiff) / vline;
+            if (uu > 1) {
+              const double ddx = posx - pxb.x, ddy = posy - pxb.y;
+              if ((ddx * ddx + ddy * ddy) > range2) inr = false;
+            }
+            if (inr && uu < 0) {
+              const double ddx = posx - pxa.x, ddy = posy - pxa.y;
+              if ((ddx * ddx + ddy * ddy) > range2) inr = false;
+            }
           }
-        const int iB = static_cast<int>(sumB), iBB = static_cast<int>(sumBB), iAB = static_cast<int>(sumAB);
-        score = sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+        }
       }
-      // score < best_score with first-index-wins == min over (score, index); scores may be negative for ZMSSD
-      const unsigned long long key =
-          (static_cast<unsigned long long>(static_cast<unsigned>(score + 0x40000000)) << 20) | static_cast<unsigned>(ci);
-      best = key < best ? key : best;
+      int score = 0;
+      if (lazy_desc) {
+        unsigned long long m = __ballot(inr);
+        const uint32_t rq_nib = (rq.desc[lane >> 3] >> (4 * (lane & 7))) & 0xFu;
+        while (m) {
+          const int j = __ffsll(static_cast<long long>(m)) - 1;
+          m &= m - 1;
+          const uint32_t pj = s_corners[c0 + j];
+          const int jx = static_cast<int>(pj & 0xFFFu), jy = static_cast<int>((pj >> 12) & 0xFFFu), jl = static_cast<int>(pj >> 24);
+          const int Wj = cf.lw[jl], Hj = cf.lh[jl];
+          uint32_t nib = 0;  // outside ORBDetector::IsInsideLimits the descriptor is all zeros (sdvl_orb.hip)
+          if (jx >= 19 && jx < Wj - 19 && jy >= 19 && jy < Hj - 19) {
+            float angle_deg;
+            nib = orb_wave_nibble(cf.level[jl] + static_cast<size_t>(jy) * Wj + jx, Wj, lane, &angle_deg);
+          }
+          const int sc = wave_sum_i32(__popc(nib ^ rq_nib));
+          if (lane == j) score = sc;
+        }
+      }
+      if (inr) {
+        if (prm.use_orb) {
+          if (!lazy_desc) {
+            const uint32_t *dd = reinterpret_cast<const uint32_t *>(cf.desc + static_cast<size_t>(ci) * 32);
+#pragma unroll
+            for (int k = 0; k < 8; k++) score += __popc(dd[k] ^ rq.desc[k]);
+          }
+        } else {
+          // CompareZMSSDScore, matcher.cc:461-476 (integer arithmetic, integer division by 64)
+          const uint8_t *cp = cf.level[cl] + static_cast<size_t>(cy - 4) * cf.lw[cl] + (cx - 4);
+          unsigned sumB = 0, sumBB = 0, sumAB = 0;
+          for (int yy = 0, r = 0; yy < 8; yy++)
+            for (int xx = 0; xx < 8; xx++, r++) {
+              const unsigned pix = cp[yy * cf.lw[cl] + xx];
+              sumB += pix;
+              sumBB += pix * pix;
+              sumAB += pix * L.patch[r];
+            }
+          const int iB = static_cast<int>(sumB), iBB = static_cast<int>(sumBB), iAB = static_cast<int>(sumAB);
+          score = sumAA - 2 * iAB + iBB - (sumA * sumA - 2 * sumA * iB + iB * iB) / 64;
+        }
+        // score < best_score with first-index-wins == min over (score, index); scores may be negative for ZMSSD
+        const unsigned long long key =
+            (static_cast<unsigned long long>(static_cast<unsigned>(score + 0x40000000)) << 20) | static_cast<unsigned>(ci);
+        best = key < best ? key : best;
+      }
     }
     best = wave_min_u64(best);
   }
@@ -485,7 +521,7 @@ void fill_frame(SearchFrame *d, const sdvl_frame *f) {
     d->lh[l] = f->v.lh[l];
   }
   d->corners = f->v.corners;
-  d->desc = f->v.desc;
+  d->desc = f->desc_valid ? f->v.desc : nullptr;  // null: the search computes what it compares (search_points_kernel)
   d->n_ptr = f->v.corner_hdr;
   d->levels = f->v.levels;
 }
@@ -583,7 +619,6 @@ int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_sea
     hblk[n_blocks++] = SearchBlock{i, cnt};
     const sdvl_frame *cf = B.frames[hreq[i].cur];
     SDVL_REQUIRE(ctx, !cf->hdr_stale, "current frame has a new image but no corners (detect or set corners first)");
-    if (p->use_orb) SDVL_REQUIRE(ctx, cf->v.n_corners == 0 || cf->desc_valid, "current frame has no ORB descriptors (call sdvl_orb_describe)");
     i += cnt;
   }
   const std::vector<SearchFramePose> &table = B.table;

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <mutex>
@@ -23,6 +24,17 @@ using std::vector;
 
 // ------------------------------------------------------------------------------------------------------ Device
 static thread_local Device *g_current_device = nullptr;
+
+// Descriptors are lazy, as in the reference (matcher.cc:266-269, frame.cc:148-161): a new frame gets corners only; the
+// search kernel computes the descriptors of the corners it compares and FilterCorners asks for a keyframe's full set.
+// SDVL_EAGER_ORB=1 restores "every corner of every frame right after detection" (same results, ~4x the ORB work).
+static bool EagerOrb() {
+  static const bool eager = [] {
+    const char *e = std::getenv("SDVL_EAGER_ORB");
+    return e && e[0] == '1';
+  }();
+  return eager;
+}
 static thread_local StageTimes *g_stage_times = nullptr;
 StageTimes *&StageTimes::Active() { return g_stage_times; }
 
@@ -492,7 +504,7 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
   clk.reset(new StageClock(ST_FAST));
   dev->Check(sdvl_detect_corners(dev->ctx(), n, devs.data(), &dp, nfeatures), "sdvl_detect_corners");
   clk.reset(new StageClock(ST_CORNERS_ORB));
-  if (Config::UseORB()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
+  if (Config::UseORB() && EagerOrb()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
 }
 }  // namespace
 
@@ -568,7 +580,7 @@ void Frame::DetectBatch(const vector<shared_ptr<Frame>> &frames, int nfeatures) 
     dev->Check(sdvl_detect_corners(dev->ctx(), n, devs.data(), &dp, nfeatures), "sdvl_detect_corners");
   }
   StageClock clk(ST_CORNERS_ORB);
-  if (Config::UseORB()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
+  if (Config::UseORB() && EagerOrb()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
 }
 
 // frame.cc:122-131
@@ -581,7 +593,7 @@ void Frame::CreateCorners(int, int nfeatures) {
   descriptors_on_host_ = false;
   dev->Check(sdvl_detect_corners(dev->ctx(), 1, &dev_, &dp, nfeatures), "sdvl_detect_corners");
   corners_on_host_ = false;
-  if (Config::UseORB()) dev->Check(sdvl_orb_describe(dev->ctx(), 1, &dev_, SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
+  if (Config::UseORB() && EagerOrb()) dev->Check(sdvl_orb_describe(dev->ctx(), 1, &dev_, SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
 }
 
 vector<Vector3i> &Frame::GetCorners() {

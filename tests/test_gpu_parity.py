@@ -210,7 +210,7 @@ def test_image_align_batch_of_jobs_and_empty(ctx, sdvl, orc, synth):
 
 
 # ------------------------------------------------------------------------------------------------ K7
-def search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, cam4, n_req, seed, fixed, noise=0.0):
+def search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, cam4, n_req, seed, fixed, noise=0.0, describe=True):
     """points seeded on the reference frame's corners (plane z=2 in world = camera 0), searched in the current frame"""
     h, w = img_ref.shape
     rng = np.random.default_rng(seed)
@@ -220,7 +220,8 @@ def search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, cam4, n_req,
     sel = rng.choice(len(cref), size=min(n_req, len(cref)), replace=False)
     f_ref, f_cur = ctx.frame(img_ref), ctx.frame(img_cur)
     f_cur.set_corners(ccur)
-    ctx.orb_describe([f_cur], want=False)
+    if describe:   # otherwise the search computes the descriptors it compares on the spot (matcher.cc:266-269)
+        ctx.orb_describe([f_cur], want=False)
     Tw = orc.se3_inv(T_ref)
     from oraclelib import quat_to_R
     Rw, tw = quat_to_R(Tw[:4]), Tw[4:]
@@ -255,11 +256,12 @@ def search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, cam4, n_req,
     return reqs, meta, ccur, f_ref, f_cur
 
 
+@pytest.mark.parametrize("describe", [True, False], ids=["descriptors-in-hbm", "descriptors-on-demand"])
 @pytest.mark.parametrize("fixed,k_ref,k_cur,noise", [(True, 0, 4, 0.0), (False, 0, 6, 0.02), (True, 10, 3, 0.0), (False, 2, 30, 0.05)])
-def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur, noise):
+def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur, noise, describe):
     img_ref, img_cur = frames_of(synth, orc, TUM_CAM, 640, 480, [k_ref, k_cur])
     T_ref, T_cur = trajectory_pose(orc, k_ref), trajectory_pose(orc, k_cur)
-    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, 160, 11, fixed, noise)
+    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, 160, 11, fixed, noise, describe)
     cam = sdvl.Camera(640, 480, *TUM_CAM)
     res = ctx.search_points(reqs, cam, sdvl.default_search_params())
     n_found = 0
@@ -275,6 +277,13 @@ def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur
             assert np.abs(np.array(r.px[:]) - want["px"]).max() <= POSE_TOL
             assert np.array_equal(np.array(r.px[:]), want["px"])      # same op order, no contraction: bit-identical
     assert n_found >= (40 if fixed else 10)
+    if not describe:   # asking for the frame's descriptors afterwards computes all of them, equal to the oracle's
+        pyr = orc.pyramid(img_cur, 5)
+        got = f_cur.descriptors()
+        for l in range(3):
+            idx = np.nonzero(ccur[:, 2] == l)[0]
+            want_d, _ = orc.orb_describe(pyr[l], ccur[idx, :2])
+            assert np.array_equal(got[idx], want_d)
     f_ref.close(); f_cur.close()
 
 
