@@ -53,29 +53,31 @@ hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
   return e;
 }
 
+// hipEventSynchronize busy-waits here even for hipEventBlockingSync events (measured: CPU time = wall time inside the
+// wait; with hipDeviceScheduleBlockingSync still ~2/3 of it), and CPU is what the host side is short of.  So: poll the
+// event and sleep in between; with the timer slack of the thread at 1 us a 25 us nanosleep costs ~30 us.
+static hipError_t poll_event(hipEvent_t ev) {
+  static const int poll_ns = getenv("SDVL_WAIT_POLL_NS") ? atoi(getenv("SDVL_WAIT_POLL_NS")) : 25000;
+  if (poll_ns <= 0) return hipEventSynchronize(ev);
+  static thread_local bool slack_set = false;
+  if (!slack_set) {
+    prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    slack_set = true;
+  }
+  const struct timespec ts = {0, poll_ns};
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) nanosleep(&ts, nullptr);
+  return e;
+}
+
 hipError_t sdvl_event_wait(sdvl_ctx *ctx, hipEvent_t ev) {
   hipError_t e;
-
   if (ctx->wait_hook) {
     ctx->waiting_on = ev;
     while ((e = hipEventQuery(ev)) == hipErrorNotReady) ctx->wait_hook(ctx->wait_user, ctx);
     ctx->waiting_on = nullptr;
   } else {
-    // hipEventSynchronize busy-waits here even for hipEventBlockingSync events (measured: CPU time = wall time inside the
-    // wait; with hipDeviceScheduleBlockingSync still ~2/3 of it), and CPU is what the host side is short of.  So: poll the
-    // event and sleep in between; with the timer slack of the thread at 1 us a 25 us nanosleep costs ~30 us.
-    static const int poll_ns = getenv("SDVL_WAIT_POLL_NS") ? atoi(getenv("SDVL_WAIT_POLL_NS")) : 25000;
-    if (poll_ns <= 0) {
-      e = hipEventSynchronize(ev);
-    } else {
-      static thread_local bool slack_set = false;
-      if (!slack_set) {
-        prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
-        slack_set = true;
-      }
-      const struct timespec ts = {0, poll_ns};
-      while ((e = hipEventQuery(ev)) == hipErrorNotReady) nanosleep(&ts, nullptr);
-    }
+    e = poll_event(ev);
   }
   return e;
 }
@@ -96,7 +98,7 @@ extern "C" int sdvl_ctx_wait_done(sdvl_ctx *ctx) {
 // sleep (no spinning) until the wait in flight has completed
 extern "C" int sdvl_ctx_wait_block(sdvl_ctx *ctx) {
   if (!ctx || !ctx->waiting_on) return SDVL_OK;
-  return hipEventSynchronize(ctx->waiting_on) == hipSuccess ? SDVL_OK : SDVL_ERR_HIP;
+  return poll_event(ctx->waiting_on) == hipSuccess ? SDVL_OK : SDVL_ERR_HIP;
 }
 
 int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f) {
