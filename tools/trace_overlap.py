@@ -27,12 +27,13 @@ for s, e, _ in rows:
 union += cur_e - cur_s
 print("dispatches %d  wall %.1f ms  busy(union) %.1f ms = %.1f %%  sum %.1f ms  overlap x%.2f" %
       (len(rows), wall / 1e6, union / 1e6, 100.0 * union / wall, total / 1e6, total / union))
-by = {}
+by, cnt = {}, {}
 for s, e, k in rows:
     k = k.replace("(anonymous namespace)::", "").split("(")[0]
     by[k] = by.get(k, 0) + (e - s)
-for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:14]:
-    print("  %-28s %8.1f ms  %5.1f %% of wall" % (k, v / 1e6, 100.0 * v / wall))
+    cnt[k] = cnt.get(k, 0) + 1
+for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:16]:
+    print("  %-32s %8.1f ms  %5.1f %% of wall  %6d dispatches  avg %7.1f us" % (k, v / 1e6, 100.0 * v / wall, cnt[k], v / cnt[k] / 1e3))
 
 # time-weighted histogram of the number of kernels in flight
 ev = []
