@@ -280,14 +280,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
                                                                             const SearchFramePose *__restrict__ table,
                                                                             const SearchBlock *__restrict__ blocks,
                                                                             const SearchPrep *__restrict__ prep, Cam cam,
-                                                                            sdvl_search_params prm,
+                                                                            sdvl_search_params prm, int n_blocks,
                                                                             sdvl_search_res *__restrict__ out) {
   __shared__ WaveLds s_lds[kWavesPerBlock];
   // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
   __shared__ uint32_t s_corners[SDVL_MAX_CORNERS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const SearchBlock blk = blocks[blockIdx.x];
+  // Workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is padded to a multiple of 8).  XCD x takes the x-th
+  // eighth of the block table: blocks are ordered by current frame, so one frame's corner list, search-level image and
+  // ORB windows are fetched into ONE L2 instead of all eight.
+  const int per_xcd = static_cast<int>(gridDim.x >> 3);
+  const int bi = static_cast<int>(blockIdx.x & 7u) * per_xcd + static_cast<int>(blockIdx.x >> 3);
+  if (bi >= n_blocks) return;
+  const SearchBlock blk = blocks[bi];
   const SearchFramePose &tcur = table[reqs[blk.first].cur];
   const int n_corners = min(tcur.f.n_ptr[0], SDVL_MAX_CORNERS);
   for (int ci = threadIdx.x; ci < n_corners; ci += 64 * kWavesPerBlock) {
@@ -640,9 +646,9 @@ int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_sea
   SearchPrep *d_prep = reinterpret_cast<SearchPrep *>(static_cast<uint8_t *>(ctx->d_out) + out_dev_bytes);
   SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n + 255) / 256), dim3(256), static_cast<const SearchReqDev *>(dsx), d_table, n, c,
               *p, d_prep);
-  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>(n_blocks)), dim3(64 * kWavesPerBlock),
+  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
               static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
-              static_cast<const SearchPrep *>(d_prep), c, *p, static_cast<sdvl_search_res *>(ctx->d_out));
+              static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

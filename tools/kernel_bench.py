@@ -106,6 +106,17 @@ for _ in range(max(1, reps // 3)):
 n_found = sum(r.found for r in sres)
 lk = sum(r.lk_its for r in sres) / max(1, n_found)
 print("search: requests=%d found=%d lk_its/found=%.2f" % (nreq, n_found, lk))
+# the same search on frames WITHOUT descriptors: every wave computes the descriptors of the corners it compares
+ctx.synchronize()
+t_a = ctx.timing_get().get("search_points", (0.0, 0))
+ctx._check(lib.sdvl_detect_corners(ctx.h, n, arr3, C.byref(dp), 1000))   # new corner lists: descriptors invalid
+for _ in range(max(1, reps // 3)):
+    sres2 = ctx.search_points(sreqs, cam, sp)
+ctx.synchronize()
+t_b = ctx.timing_get().get("search_points", (0.0, 0))
+assert [r.found for r in sres2] == [r.found for r in sres] and [tuple(r.px) for r in sres2] == [tuple(r.px) for r in sres]
+print("search_points, descriptors on demand: %.1f us/launch (descriptors in HBM: %.1f us/launch)" %
+      ((t_b[0] - t_a[0]) / max(1, t_b[1] - t_a[1]) * 1e3, t_a[0] / max(1, t_a[1]) * 1e3))
 # pose stage: n jobs of 190 matches (20 % gross outliers) of a small camera motion; rand() draws from numpy (timing only)
 prng = np.random.default_rng(7)
 pose_jobs = []
