@@ -311,6 +311,30 @@ int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose_job *jobs,
                            int n_rand, const int32_t *rand_idx, int n_nits, const int32_t *nits_table,
                            const sdvl_pose_params *p, sdvl_pose_result *results, int32_t *out_lists);
 
+/* ---- FeatureAlign::Reproject + OptimizePose in one submission (feature_align.cc:59-82): sdvl_search_run, then ON THE
+ * DEVICE the second half of SelectPoints (feature_align.cc:105-149: candidates cell by cell in the caller's order, a cell's
+ * first found candidate is a match, at most max_matches of them) and sdvl_pose_from_matches on the matches it selects.
+ * The host still needs the search results for its own bookkeeping (features, point statistics), so
+ *   sdvl_search_run_chain  returns as soon as they are on the host, with selection and pose kernels still in flight;
+ *   sdvl_search_chain_end  waits for the pose results: results[n_frames], n_obs[n_frames] (matches selected, = what the
+ *                          host's replay of SelectPoints finds) and lists — tracker f's inlier then outlier indices start at
+ *                          sum of max_matches of the trackers before it (indices relative to its own match list).
+ * cand_req[k]  = request the k-th candidate was searched with (index into the batch) or -1 (never found);
+ * cand_first[k]= index (into cand_req) of the first candidate of k's cell;  req_point[r] = Point::GetPosition() of request r;
+ * rand_raw     = per tracker the next max_ransac_its values of its rand() stream (the device reduces them modulo the match
+ *                count, feature_align.cc:180); the iteration budget table of :199-207 is built inside, with libm log.
+ * No other call on this context between the two. */
+typedef struct sdvl_chain_frame {
+  int32_t cand_begin, cand_end; /* this tracker's candidates */
+  int32_t max_matches;          /* FeatureAlign max_matches_, <= 1024 */
+  int32_t rand_begin;           /* first of its max_ransac_its values in rand_raw */
+  double pose[7];               /* frame pose on entry to the pose stage */
+} sdvl_chain_frame;
+int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, sdvl_search_res *out, int n_frames,
+                          const sdvl_chain_frame *frames, int n_cand, const int32_t *cand_req, const int32_t *cand_first,
+                          const double *req_point, int n_rand, const int32_t *rand_raw, const sdvl_pose_params *pp);
+int sdvl_search_chain_end(sdvl_ctx *ctx, int n_frames, sdvl_pose_result *results, int32_t *n_obs, int32_t *lists);
+
 /* ---- synthetic sequence generator (no dataset ships with the repo) ------------------------------- */
 struct sdvl_synth_view;
 /* renders n views of the textured plane straight into HBM: dev_out + i*frame_bytes, row stride = width */

@@ -190,6 +190,8 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
   if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
   if (ctx->align_event) (void)hipEventDestroy(ctx->align_event);
+  if (ctx->chain_event) (void)hipEventDestroy(ctx->chain_event);
+  if (ctx->d_nits) (void)hipFree(ctx->d_nits);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);

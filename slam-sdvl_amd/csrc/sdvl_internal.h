@@ -70,6 +70,15 @@ struct sdvl_ctx {
   // host thread that drives several contexts can run another one's host stage instead of sleeping
   hipEvent_t align_event = nullptr;  // marks the result copy of sdvl_image_align_begin
   int align_pending = 0;
+  // sdvl_search_run_chain: the search results have landed at chain_event; the pose results follow at the stream's tail
+  hipEvent_t chain_event = nullptr;
+  int chain_pending = 0;             // trackers of the chained batch in flight
+  size_t chain_host_off = 0;         // where its pose results start in h_out
+  int chain_obs_total = 0;
+  // iteration budgets of SelectInliers for every match count 0..nits_max_size (row s at s*(s+1)/2), resident in HBM
+  void *d_nits = nullptr;
+  std::vector<int32_t> nits_host;
+  int nits_points = -1, nits_its = -1, nits_max_size = -1;
   hipEvent_t waiting_on = nullptr;   // the event a cooperative wait is polling (sdvl_ctx_wait_done / _block)
   void (*wait_hook)(void *user, sdvl_ctx *ctx) = nullptr;
   void *wait_user = nullptr;
@@ -80,6 +89,19 @@ struct sdvl_ctx {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
 };
+
+// device record of one pose job (sdvl_pose.hip); sdvl_search_run_chain fills these on the device
+struct PoseJobDev {
+  int obs_begin, n_obs;
+  int rand_begin, nits_begin;
+  double pose[7];
+  double pad_;
+};
+// queues pose_hypotheses + pose_refine for n_jobs device-resident jobs (no copies, no wait); d_hyp = n_jobs * max_ransac_its
+// records of sdvl_pose_hyp_bytes() each
+size_t sdvl_pose_hyp_bytes();
+int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
+                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists);
 
 #define SDVL_HIP_CHECK(ctx, expr)                                                            \
   do {                                                                                       \

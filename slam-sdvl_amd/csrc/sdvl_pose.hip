@@ -24,13 +24,6 @@ constexpr int kMaxObs = 1024;  // observations (matched features) per frame hand
 constexpr double kMADNorm = 1.4826;
 constexpr double kTukeyC = 4.6851 * 4.6851;
 
-struct PoseJobDev {
-  int obs_begin, n_obs;
-  int rand_begin, nits_begin;
-  double pose[7];
-  double pad_;
-};
-
 struct HypResult {
   double se3[7];
   int ok, supporters;
@@ -138,7 +131,8 @@ __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const PoseJobDev *_
   if (size > 0) {
     const sdvl_pose_obs *obs = obs_all + job.obs_begin;
     const int npoints = min(prm.max_ransac_points, size);
-    const int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180)
+    int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180) ...
+    if (prm.pad_ & 1) index %= size;           // ... or the raw rand() value when the host could not know `size` yet
     int sel[8];
     for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
     Rigid se3;
@@ -406,6 +400,18 @@ __global__ __launch_bounds__(64) void pose_refine_kernel(const PoseJobDev *__res
 
 }  // namespace
 
+size_t sdvl_pose_hyp_bytes() { return sizeof(HypResult); }
+
+int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
+                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists) {
+  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + 63) / 64, n_jobs), dim3(64), d_jobs, d_obs, d_rand, *p,
+              static_cast<HypResult *>(d_hyp));
+  SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel, dim3(n_jobs), dim3(64), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
+              d_lists);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  return SDVL_OK;
+}
+
 extern "C" int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose_job *jobs, int n_obs, const sdvl_pose_obs *obs, int n_rand,
                                       const int32_t *rand_idx, int n_nits, const int32_t *nits_table, const sdvl_pose_params *p,
                                       sdvl_pose_result *results, int32_t *out_lists) {
@@ -457,9 +463,10 @@ extern "C" int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose
   HypResult *dhyp = static_cast<HypResult *>(ctx->d_work);
   sdvl_pose_result *dres = static_cast<sdvl_pose_result *>(ctx->d_out);
   int32_t *dlists = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(ctx->d_out) + res_bytes);
-  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + 63) / 64, n_jobs), dim3(64), dj, dobs, drand, *p, dhyp);
-  SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel, dim3(n_jobs), dim3(64), dj, dobs, dnits, static_cast<const HypResult *>(dhyp), *p, dres, dlists);
-  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  sdvl_pose_params prm = *p;
+  prm.pad_ = 0;  // rand_idx holds indices already reduced modulo the match count
+  rc = sdvl_pose_enqueue_device(ctx, n_jobs, dj, dobs, drand, dnits, &prm, dhyp, dres, dlists);
+  if (rc) return rc;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes + list_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(results, ctx->h_out, sizeof(sdvl_pose_result) * n_jobs);

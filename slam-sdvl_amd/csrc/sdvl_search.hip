@@ -16,6 +16,8 @@
 #include <utility>
 #include <vector>
 
+#include <cmath>
+
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
 #include "sdvl_orb_device.h"
@@ -519,6 +521,80 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void align_patches_kernel(cons
   }
 }
 
+// ---- second half of FeatureAlign::SelectPoints (feature_align.cc:105-149) on the device, for sdvl_search_run_chain:
+// candidates come cell by cell in the reference's order; a cell's first found candidate is a match; the first
+// max_matches matches are kept.  One workgroup per tracker; the matches leave as pose observations (feature_align.cc:132
+// creates the Feature — bearing = Camera::Unproject(px) — SelectInliers reads bearing/z, the point and 1/2^level).
+struct ChainFrameDev {
+  int cand_begin, cand_end;
+  int max_matches, rand_begin;
+  int obs_begin, pad_;
+  double pose[7];
+  double pad2_;
+};
+constexpr int kChainMaxCand = 16384;  // candidates of one tracker the kernel can flag in LDS
+
+__global__ __launch_bounds__(256) void select_matches_kernel(const ChainFrameDev *__restrict__ frames, const int32_t *__restrict__ cand_req,
+                                                             const int32_t *__restrict__ cand_first, const sdvl_search_res *__restrict__ res,
+                                                             const double *__restrict__ req_point, Cam cam, PoseJobDev *__restrict__ jobs,
+                                                             sdvl_pose_obs *__restrict__ obs, int32_t *__restrict__ n_obs_out) {
+  __shared__ uint8_t s_found[kChainMaxCand];
+  __shared__ int s_wave[4];
+  const ChainFrameDev &fr = frames[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = fr.cand_end - fr.cand_begin;
+  const int32_t *creq = cand_req + fr.cand_begin, *cfirst = cand_first + fr.cand_begin;
+  for (int k = tid; k < n; k += 256) {
+    const int r = creq[k];
+    s_found[k] = (r >= 0 && res[r].found != 0) ? 1 : 0;
+  }
+  __syncthreads();
+  int running = 0;
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    const int k = c0 + tid;
+    bool sel = false;
+    if (k < n && s_found[k]) {
+      sel = true;
+      for (int j = cfirst[k] - fr.cand_begin; j < k; j++)
+        if (s_found[j]) { sel = false; break; }
+    }
+    const unsigned long long m = __ballot(sel);
+    const int below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+    __syncthreads();  // s_wave of the previous round has been read
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int base = running;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    const int rank = base + below;
+    if (sel && rank < fr.max_matches) {
+      const sdvl_search_res &r = res[creq[k]];
+      const V3 v = cam_unproject(cam, {r.px[0], r.px[1]});
+      sdvl_pose_obs o;
+      o.ax = v.x / v.z;
+      o.ay = v.y / v.z;
+      const double *P = req_point + 3 * static_cast<size_t>(creq[k]);
+      o.px = P[0];
+      o.py = P[1];
+      o.pz = P[2];
+      o.inv_cov = 1.0 / (1 << r.level);
+      obs[fr.obs_begin + rank] = o;
+    }
+    running += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  }
+  if (tid == 0) {
+    const int size = min(running, fr.max_matches);
+    PoseJobDev j;
+    j.obs_begin = fr.obs_begin;
+    j.n_obs = size;
+    j.rand_begin = fr.rand_begin;
+    j.nits_begin = size * (size + 1) / 2;  // row `size` of the all-sizes budget table
+    for (int q = 0; q < 7; q++) j.pose[q] = fr.pose[q];
+    j.pad_ = 0.0;
+    jobs[blockIdx.x] = j;
+    n_obs_out[blockIdx.x] = size;
+  }
+}
+
 void fill_frame(SearchFrame *d, const sdvl_frame *f) {
   memset(d, 0, sizeof(SearchFrame));
   for (int l = 0; l < f->v.levels; l++) {
@@ -592,9 +668,10 @@ int sdvl_search_slot(sdvl_ctx *ctx, const sdvl_frame *f, const double *pose) {
   return B.last;
 }
 
-int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, sdvl_search_res *out) {
-  if (!ctx || !cam || !p || n < 0 || (n > 0 && !out)) return SDVL_ERR_INVALID;
-  if (n == 0) return SDVL_OK;
+// everything of sdvl_search_run up to and including the queued copy of the results into h_out[0 .. n records); the caller
+// waits.  extra_d / extra_h: room the caller wants behind the search's own use of d_out / h_out (offsets returned).
+static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, size_t extra_d, size_t extra_h,
+                          size_t *extra_d_off, size_t *extra_h_off) {
   SearchBatch &B = batch_of(ctx);
   SDVL_REQUIRE(ctx, B.hs && n <= B.cap, "sdvl_search_run without a matching sdvl_search_begin");
   SDVL_REQUIRE(ctx, p->patch_size == 8, "only patch_size 8 is supported (one wave64 per 8x8 patch)");
@@ -612,9 +689,12 @@ int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_sea
   const size_t in_bytes = B.in_bytes, blk_cap_bytes = B.blk_cap_bytes;
   const size_t out_bytes = sizeof(sdvl_search_res) * static_cast<size_t>(n);
   const size_t out_dev_bytes = (out_bytes + 255) / 256 * 256;
-  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_dev_bytes + sizeof(SearchPrep) * static_cast<size_t>(n), false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_bytes, true);
+  const size_t prep_bytes = (sizeof(SearchPrep) * static_cast<size_t>(n) + 255) / 256 * 256;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, out_dev_bytes + prep_bytes + extra_d, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, out_dev_bytes + extra_h, true);
   if (rc) return rc;
+  if (extra_d_off) *extra_d_off = out_dev_bytes + prep_bytes;
+  if (extra_h_off) *extra_h_off = out_dev_bytes;
   void *hs = B.hs, *dsx = B.dsx;
   // workgroups: runs of up to kWavesPerBlock consecutive requests that search the same current frame
   SearchBlock *hblk = reinterpret_cast<SearchBlock *>(static_cast<uint8_t *>(hs) + in_bytes);
@@ -651,10 +731,157 @@ int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_sea
               static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
-  memcpy(out, ctx->h_out, out_bytes);
   return SDVL_OK;
 }
+
+int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, sdvl_search_res *out) {
+  if (!ctx || !cam || !p || n < 0 || (n > 0 && !out)) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  const int rc = search_enqueue(ctx, n, cam, p, 0, 0, nullptr, nullptr);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  memcpy(out, ctx->h_out, sizeof(sdvl_search_res) * static_cast<size_t>(n));
+  return SDVL_OK;
+}
+
+// ---- sdvl_search_run_chain / sdvl_search_chain_end
+// SelectInliers' iteration budget as a function of the supporter count (feature_align.cc:199-207), for every match count
+// up to max_size: row s (s + 1 entries) starts at s*(s+1)/2.  Two libm log() per entry, computed once per configuration.
+static int ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int max_size) {
+  if (ctx->d_nits && ctx->nits_points == npoints_cfg && ctx->nits_its == max_its && ctx->nits_max_size >= max_size) return SDVL_OK;
+  const size_t entries = static_cast<size_t>(max_size + 1) * (max_size + 2) / 2;
+  std::vector<int32_t> &t = ctx->nits_host;
+  t.assign(entries, max_its);
+  const double sprob = 0.99;
+  for (int size = 0; size <= max_size; size++) {
+    const int npoints = npoints_cfg < size ? npoints_cfg : size;
+    int32_t *row = t.data() + static_cast<size_t>(size) * (size + 1) / 2;
+    for (int supporters = 0; supporters <= size; supporters++) {
+      int nits = max_its;
+      if (size > 0) {
+        const double epsilon = 1.0 - (static_cast<double>(supporters) / static_cast<double>(size));
+        double tmp = 1.0 - epsilon;
+        for (int k = 1; k < npoints; k++) tmp *= tmp;
+        if (!(tmp < 1e-5)) {
+          const int v = static_cast<int>(std::log(1.0 - sprob) / std::log(1.0 - tmp));
+          nits = max_its < v ? max_its : v;
+        }
+      }
+      row[supporters] = nits;
+    }
+  }
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // nobody may still be reading the old table
+  if (ctx->d_nits) SDVL_HIP_CHECK(ctx, hipFree(ctx->d_nits));
+  ctx->d_nits = nullptr;
+  SDVL_HIP_CHECK(ctx, hipMalloc(&ctx->d_nits, entries * sizeof(int32_t)));
+  SDVL_HIP_CHECK(ctx, hipMemcpy(ctx->d_nits, t.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
+  ctx->nits_points = npoints_cfg;
+  ctx->nits_its = max_its;
+  ctx->nits_max_size = max_size;
+  return SDVL_OK;
+}
+
+int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, sdvl_search_res *out, int n_frames,
+                          const sdvl_chain_frame *frames, int n_cand, const int32_t *cand_req, const int32_t *cand_first,
+                          const double *req_point, int n_rand, const int32_t *rand_raw, const sdvl_pose_params *pp) {
+  if (!ctx || !cam || !p || !pp || n <= 0 || !out || n_frames <= 0 || !frames || n_cand < 0 || (n_cand > 0 && (!cand_req || !cand_first)) ||
+      !req_point || n_rand < 0 || !rand_raw)
+    return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, pp->max_ransac_points >= 1 && pp->max_ransac_points <= 8, "max_ransac_points must be in [1,8]");
+  SDVL_REQUIRE(ctx, pp->max_ransac_its >= 1 && pp->max_ransac_its <= 4096 && pp->max_optim_pose_its >= 0, "bad iteration limits");
+  ctx->chain_pending = 0;
+  int obs_total = 0, max_size = 0;
+  for (int f = 0; f < n_frames; f++) {
+    const sdvl_chain_frame &c = frames[f];
+    SDVL_REQUIRE(ctx, c.cand_begin >= 0 && c.cand_end >= c.cand_begin && c.cand_end <= n_cand, "candidate range out of bounds");
+    SDVL_REQUIRE(ctx, c.cand_end - c.cand_begin <= kChainMaxCand, "too many candidates for one tracker");
+    SDVL_REQUIRE(ctx, c.max_matches >= 0 && c.max_matches <= 1024, "max_matches outside the device pose stage's range (1024)");
+    SDVL_REQUIRE(ctx, c.rand_begin >= 0 && c.rand_begin + pp->max_ransac_its <= n_rand, "rand range out of bounds");
+    obs_total += c.max_matches;
+    if (c.max_matches > max_size) max_size = c.max_matches;
+  }
+  for (int k = 0; k < n_cand; k++) {
+    SDVL_REQUIRE(ctx, cand_req[k] >= -1 && cand_req[k] < n, "candidate names a request outside the batch");
+    SDVL_REQUIRE(ctx, cand_first[k] >= 0 && cand_first[k] <= k, "cand_first must point at or before the candidate");
+  }
+  for (int k = 0; k < n_rand; k++) SDVL_REQUIRE(ctx, rand_raw[k] >= 0, "rand() values are non-negative");
+  int rc = ensure_nits_table(ctx, pp->max_ransac_points, pp->max_ransac_its, max_size);
+  if (rc) return rc;
+  // behind the search's buffers — device: jobs | obs | hypotheses | results | n_obs | lists ; host: results | n_obs | lists
+  const size_t jb = (sizeof(PoseJobDev) * n_frames + 255) / 256 * 256, ob = (sizeof(sdvl_pose_obs) * static_cast<size_t>(obs_total) + 255) / 256 * 256;
+  const size_t hb = (sdvl_pose_hyp_bytes() * static_cast<size_t>(n_frames) * pp->max_ransac_its + 255) / 256 * 256;
+  const size_t rb = (sizeof(sdvl_pose_result) * n_frames + 255) / 256 * 256, nb = (sizeof(int32_t) * n_frames + 255) / 256 * 256;
+  const size_t lb = (sizeof(int32_t) * static_cast<size_t>(obs_total) + 255) / 256 * 256;
+  size_t d_off = 0, h_off = 0;
+  rc = search_enqueue(ctx, n, cam, p, jb + ob + hb + rb + nb + lb, rb + nb + lb, &d_off, &h_off);
+  if (rc) return rc;
+  if (!ctx->chain_event) SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->chain_event, hipEventBlockingSync | hipEventDisableTiming));
+  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->chain_event, ctx->stream));  // the search results are on the host from here on
+  // inputs of the selection + pose stage: one staged copy
+  const size_t fb = (sizeof(ChainFrameDev) * n_frames + 255) / 256 * 256, cb = (sizeof(int32_t) * static_cast<size_t>(n_cand) + 255) / 256 * 256;
+  const size_t pb = (sizeof(double) * 3 * static_cast<size_t>(n) + 255) / 256 * 256, rndb = (sizeof(int32_t) * static_cast<size_t>(n_rand) + 255) / 256 * 256;
+  void *hs = nullptr, *dsx = nullptr;
+  rc = sdvl_stage_alloc(ctx, fb + 2 * cb + pb + rndb, &hs, &dsx);
+  if (rc) return rc;
+  uint8_t *h8 = static_cast<uint8_t *>(hs), *d8 = static_cast<uint8_t *>(dsx);
+  ChainFrameDev *hf = reinterpret_cast<ChainFrameDev *>(h8);
+  int ob_run = 0;
+  for (int f = 0; f < n_frames; f++) {
+    hf[f].cand_begin = frames[f].cand_begin;
+    hf[f].cand_end = frames[f].cand_end;
+    hf[f].max_matches = frames[f].max_matches;
+    hf[f].rand_begin = frames[f].rand_begin;
+    hf[f].obs_begin = ob_run;
+    hf[f].pad_ = 0;
+    memcpy(hf[f].pose, frames[f].pose, sizeof(double) * 7);
+    hf[f].pad2_ = 0.0;
+    ob_run += frames[f].max_matches;
+  }
+  if (n_cand) {
+    memcpy(h8 + fb, cand_req, sizeof(int32_t) * static_cast<size_t>(n_cand));
+    memcpy(h8 + fb + cb, cand_first, sizeof(int32_t) * static_cast<size_t>(n_cand));
+  }
+  memcpy(h8 + fb + 2 * cb, req_point, sizeof(double) * 3 * static_cast<size_t>(n));
+  if (n_rand) memcpy(h8 + fb + 2 * cb + pb, rand_raw, sizeof(int32_t) * static_cast<size_t>(n_rand));
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, fb + 2 * cb + pb + rndb, hipMemcpyHostToDevice, ctx->stream));
+  uint8_t *dx = static_cast<uint8_t *>(ctx->d_out) + d_off;
+  PoseJobDev *d_jobs = reinterpret_cast<PoseJobDev *>(dx);
+  sdvl_pose_obs *d_obs = reinterpret_cast<sdvl_pose_obs *>(dx + jb);
+  void *d_hyp = dx + jb + ob;
+  sdvl_pose_result *d_res = reinterpret_cast<sdvl_pose_result *>(dx + jb + ob + hb);
+  int32_t *d_nobs = reinterpret_cast<int32_t *>(dx + jb + ob + hb + rb);
+  int32_t *d_lists = reinterpret_cast<int32_t *>(dx + jb + ob + hb + rb + nb);
+  Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  SDVL_LAUNCH(ctx, "select_matches", select_matches_kernel, dim3(n_frames), dim3(256), reinterpret_cast<const ChainFrameDev *>(d8),
+              reinterpret_cast<const int32_t *>(d8 + fb), reinterpret_cast<const int32_t *>(d8 + fb + cb),
+              static_cast<const sdvl_search_res *>(ctx->d_out), reinterpret_cast<const double *>(d8 + fb + 2 * cb), c, d_jobs, d_obs, d_nobs);
+  sdvl_pose_params prm = *pp;
+  prm.pad_ = 1;  // raw rand() values: the kernel reduces them modulo the match count it finds in the job
+  rc = sdvl_pose_enqueue_device(ctx, n_frames, d_jobs, d_obs, reinterpret_cast<const int32_t *>(d8 + fb + 2 * cb + pb),
+                                static_cast<const int32_t *>(ctx->d_nits), &prm, d_hyp, d_res, d_lists);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->h_out) + h_off, dx + jb + ob + hb, rb + nb + lb, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->chain_pending = n_frames;
+  ctx->chain_host_off = h_off;
+  ctx->chain_obs_total = obs_total;
+  SDVL_HIP_CHECK(ctx, sdvl_event_wait(ctx, ctx->chain_event));
+  memcpy(out, ctx->h_out, sizeof(sdvl_search_res) * static_cast<size_t>(n));
+  return SDVL_OK;
+}
+
+int sdvl_search_chain_end(sdvl_ctx *ctx, int n_frames, sdvl_pose_result *results, int32_t *n_obs, int32_t *lists) {
+  if (!ctx || n_frames <= 0 || !results || !n_obs || !lists) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, ctx->chain_pending == n_frames, "sdvl_search_chain_end without a matching sdvl_search_run_chain");
+  ctx->chain_pending = 0;
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  const size_t rb = (sizeof(sdvl_pose_result) * n_frames + 255) / 256 * 256, nb = (sizeof(int32_t) * n_frames + 255) / 256 * 256;
+  const uint8_t *h = static_cast<const uint8_t *>(ctx->h_out) + ctx->chain_host_off;
+  memcpy(results, h, sizeof(sdvl_pose_result) * n_frames);
+  memcpy(n_obs, h + rb, sizeof(int32_t) * n_frames);
+  memcpy(lists, h + rb + nb, sizeof(int32_t) * static_cast<size_t>(ctx->chain_obs_total));
+  return SDVL_OK;
+}
+
 
 int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
                        const sdvl_search_params *p, sdvl_search_res *out) {

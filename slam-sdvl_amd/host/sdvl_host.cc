@@ -1040,6 +1040,11 @@ void FeatureAlign::PrepareReprojectImpl(const shared_ptr<Frame> &frame, const sh
         rq.fixed = point->IsFixed() ? 1 : 0;
         if (feature->HasDescriptor()) std::memcpy(rq.desc, feature->GetDescriptor().data(), 32);
         else std::memset(rq.desc, 0, 32);
+        if (sink->points) {
+          const Vector3d P = point->GetPosition();
+          double *dst = sink->points + 3 * static_cast<size_t>(sink->count - 1);
+          dst[0] = P(0); dst[1] = P(1); dst[2] = P(2);
+        }
         c.req = sink->count - 1 - req_base_;
       } else if (ref_frame) {
         reqs->emplace_back();
@@ -1065,6 +1070,22 @@ void FeatureAlign::PrepareReprojectImpl(const shared_ptr<Frame> &frame, const sh
   plan_begin_[size] = static_cast<int>(plan_.size());
 }
 
+void FeatureAlign::EmitChainCandidates(int req_offset, vector<int32_t> *cand_req, vector<int32_t> *cand_first) const {
+  const int size = static_cast<int>(plan_begin_.size()) - 1;
+  for (int i = 0; i < size; i++) {
+    const int first = static_cast<int>(cand_req->size());
+    for (int k = plan_begin_[i]; k < plan_begin_[i + 1]; k++) {
+      cand_req->push_back(plan_[k].req >= 0 ? plan_[k].req + req_offset : -1);
+      cand_first->push_back(first);
+    }
+  }
+}
+
+void FeatureAlign::PeekRand(int n, vector<int32_t> *out) const {
+  RandStream peek = *rng_;
+  for (int h = 0; h < n; h++) out->push_back(peek.Next());
+}
+
 // feature_align.cc:59-71 tail: SelectPoints replay, then SelectInliers
 void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
   FinishSelect(frame, res);
@@ -1072,7 +1093,7 @@ void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_se
 }
 
 // second half of SelectPoints (feature_align.cc:105-149) replayed over the batch results
-void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
+void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_search_res *res, bool build_obs) {
   const int size = static_cast<int>(plan_begin_.size()) - 1;
   if (!relocalizing_) frame->GetFeatures().reserve(frame->GetFeatures().size() + static_cast<size_t>(max_matches_));
   vector<shared_ptr<Feature>> &src_features = last_frame_->GetFeatures();
@@ -1092,9 +1113,11 @@ void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_searc
           feature->SetPoint(std::move(owner));
           frame->AddFeature(feature);
           point->SetStatus(Point::P_FOUND);
-          const Vector3d P = point->GetPosition();
-          const Vector3d &v = feature->GetVector();
-          obs_.push_back(Obs{v(0) / v(2), v(1) / v(2), P(0), P(1), P(2), 1.0 / (1 << r->level)});
+          if (build_obs) {  // observation records for the pose stage; the chained device path builds its own
+            const Vector3d P = point->GetPosition();
+            const Vector3d &v = feature->GetVector();
+            obs_.push_back(Obs{v(0) / v(2), v(1) / v(2), P(0), P(1), P(2), 1.0 / (1 << r->level)});
+          }
           found_.push_back(std::move(feature));
         }
         matches_++;
@@ -1646,7 +1669,9 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     vector<sdvl_search_req> &reqs = scratch_reqs_;  // keeps its capacity from step to step
     reqs.clear();
     vector<size_t> begin(R + 1, 0);
-    bool packed = false;
+    bool packed = false, chain = false;
+    vector<sdvl_chain_frame> chain_frames;
+    vector<int> chain_obs_begin(R + 1, 0);
     FeatureAlign::PackedSink sink;
     if (threads_ <= 1 && R > 0) {
       // one host thread per batch (the farm's case): every tracker writes its requests, already in the device layout,
@@ -1656,6 +1681,17 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       sink.ctx = dev_->ctx();
       sink.cap = cap;
       sink.batch_id = ++search_batch_counter_;
+      // search -> match selection -> RANSAC + pose refinement as ONE submission (sdvl_search_run_chain): the device replays
+      // the second half of SelectPoints itself, so the pose kernels run while this thread does the same replay for its
+      // own bookkeeping (features, point statistics) instead of starting after it
+      static const bool chain_enabled = std::getenv("SDVL_NO_CHAIN") == nullptr;
+      chain = chain_enabled && device_pose && Config::MaxRansacPoints() <= 8;
+      for (int k = 0; k < R && chain; k++)
+        if (trk_[run[k]]->feature_align_.MaxMatches() > FeatureAlign::kMaxDevicePoseObs) chain = false;
+      if (chain) {
+        if (scratch_points_.size() < 3 * static_cast<size_t>(cap)) scratch_points_.resize(3 * static_cast<size_t>(cap));
+        sink.points = scratch_points_.data();
+      }
       dev_->Check(sdvl_search_begin(sink.ctx, cap, &sink.reqs), "sdvl_search_begin");
       for (int k = 0; k < R; k++) {
         SDVL &t = *trk_[run[k]];
@@ -1663,6 +1699,26 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
         t.feature_align_.PrepareReprojectPacked(t.current_frame_, t.last_frame_, false, &sink);
       }
       packed = true;
+      if (sink.count == 0) chain = false;
+      if (chain) {
+        const int max_its = Config::MaxRansacIts();
+        chain_frames.resize(R);
+        chain_cand_req_.clear();
+        chain_cand_first_.clear();
+        chain_rand_.clear();
+        for (int k = 0; k < R; k++) {
+          SDVL &t = *trk_[run[k]];
+          sdvl_chain_frame &cf = chain_frames[k];
+          cf.cand_begin = static_cast<int32_t>(chain_cand_req_.size());
+          t.feature_align_.EmitChainCandidates(static_cast<int>(begin[k]), &chain_cand_req_, &chain_cand_first_);
+          cf.cand_end = static_cast<int32_t>(chain_cand_req_.size());
+          cf.max_matches = t.feature_align_.MaxMatches();
+          cf.rand_begin = static_cast<int32_t>(chain_rand_.size());
+          t.feature_align_.PeekRand(max_its, &chain_rand_);
+          t.current_frame_->GetPose().ToArray(cf.pose);
+          chain_obs_begin[k] = k == 0 ? 0 : chain_obs_begin[k - 1] + chain_frames[k - 1].max_matches;
+        }
+      }
     } else {
       vector<vector<sdvl_search_req>> per(R);
       ParallelFor(R, [&](int k) {
@@ -1681,7 +1737,15 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       res.resize(std::max(1, sink.count));
       const sdvl_camera cam = trk_[run[0]]->camera_->abi();
       const sdvl_search_params sp = SearchParams();
-      dev_->Check(sdvl_search_run(sink.ctx, sink.count, &cam, &sp, res.data()), "sdvl_search_run");
+      if (chain) {
+        const sdvl_pose_params pp = FeatureAlign::PoseParams(*trk_[run[0]]->camera_);
+        dev_->Check(sdvl_search_run_chain(sink.ctx, sink.count, &cam, &sp, res.data(), R, chain_frames.data(),
+                                          static_cast<int>(chain_cand_req_.size()), chain_cand_req_.data(), chain_cand_first_.data(),
+                                          scratch_points_.data(), static_cast<int>(chain_rand_.size()), chain_rand_.data(), &pp),
+                    "sdvl_search_run_chain");
+      } else {
+        dev_->Check(sdvl_search_run(sink.ctx, sink.count, &cam, &sp, res.data()), "sdvl_search_run");
+      }
     } else if (R > 0) {
       Matcher::SearchPoints(dev_, reqs, *trk_[run[0]]->camera_, &res);
     }
@@ -1698,10 +1762,12 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       FrameStats &st = stats[i];
       st.search_requests = static_cast<int>(begin[k + 1] - begin[k]);
       for (size_t q = begin[k]; q < begin[k + 1]; q++) st.lk_iters += res[q].lk_its;
-      t.feature_align_.FinishSelect(t.current_frame_, res.data() + begin[k]);
+      t.feature_align_.FinishSelect(t.current_frame_, res.data() + begin[k], !chain);
       t.matches_ = t.feature_align_.GetMatches();
       t.attempts_ = t.feature_align_.GetAttempts();
-      if (device_pose) {
+      if (chain) {
+        job_of[k] = k;  // its pose job is already running
+      } else if (device_pose) {
         if (threads_ <= 1) {  // sequential: straight into the shared batch
           const int job = static_cast<int>(all.jobs.size());
           on_device[k] = t.feature_align_.EmitPoseJob(t.current_frame_, &all) ? 1 : 0;
@@ -1721,7 +1787,18 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
           job_of[k] = static_cast<int>(all.jobs.size());
           all.Append(pb[k]);
         }
-    if (!all.jobs.empty()) {
+    if (chain) {
+      int obs_total = 0;
+      for (int k = 0; k < R; k++) obs_total += chain_frames[k].max_matches;
+      pres.resize(R);
+      lists.resize(obs_total + 1);
+      vector<int32_t> n_obs(R);
+      dev_->Check(sdvl_search_chain_end(dev_->ctx(), R, pres.data(), n_obs.data(), lists.data()), "sdvl_search_chain_end");
+      for (int k = 0; k < R; k++)
+        if (n_obs[k] != trk_[run[k]]->feature_align_.FoundCount())
+          throw std::runtime_error("SDVLBatch: the device's match selection disagrees with the host replay (" + std::to_string(n_obs[k]) + " vs " +
+                                   std::to_string(trk_[run[k]]->feature_align_.FoundCount()) + " matches)");
+    } else if (!all.jobs.empty()) {
       pres.resize(all.jobs.size());
       lists.resize(all.obs.size() + 1);
       const sdvl_pose_params pp = FeatureAlign::PoseParams(*trk_[run[0]]->camera_);
@@ -1735,7 +1812,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       SDVL &t = *trk_[i];
       FrameStats &st = stats[i];
       if (job_of[k] >= 0) {
-        t.feature_align_.CommitPose(t.current_frame_, pres[job_of[k]], lists.data() + all.jobs[job_of[k]].obs_begin);
+        t.feature_align_.CommitPose(t.current_frame_, pres[job_of[k]], lists.data() + (chain ? chain_obs_begin[k] : all.jobs[job_of[k]].obs_begin));
       } else {
         t.feature_align_.SelectInliers(t.current_frame_);
         t.feature_align_.OptimizePose(t.current_frame_);

@@ -593,7 +593,15 @@ class FeatureAlign {
     sdvl_search_req_packed *reqs = nullptr;
     int count = 0, cap = 0;
     uint64_t batch_id = 0;
+    double *points = nullptr;  // optional [cap][3]: Point::GetPosition() of every request (sdvl_search_run_chain)
   };
+  // the candidates of the last PrepareReproject in SelectPoints order, for sdvl_search_run_chain: request index (made
+  // global with `req_offset`) or -1, and the index of the first candidate of the same cell
+  void EmitChainCandidates(int req_offset, std::vector<int32_t> *cand_req, std::vector<int32_t> *cand_first) const;
+  int MaxMatches() const { return max_matches_; }
+  int FoundCount() const { return static_cast<int>(found_.size()); }
+  // the next `n` values of the tracker's rand() stream, without advancing it
+  void PeekRand(int n, std::vector<int32_t> *out) const;
   void PrepareReprojectPacked(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, bool reloc, PackedSink *sink);
   // FinishReproject without SelectInliers: the pose stage then runs either on the host (SelectInliers + OptimizePose)
   // or batched on the device: EmitPoseJob for every tracker, ONE sdvl_pose_from_matches, CommitPose for every tracker.
@@ -604,7 +612,7 @@ class FeatureAlign {
     void Append(const PoseBatch &o);
   };
   static constexpr int kMaxDevicePoseObs = 1024;
-  void FinishSelect(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res);
+  void FinishSelect(const std::shared_ptr<Frame> &frame, const sdvl_search_res *res, bool build_obs = true);
   bool EmitPoseJob(const std::shared_ptr<Frame> &frame, PoseBatch *batch);  // false: too many matches, use the host path
   void CommitPose(const std::shared_ptr<Frame> &frame, const sdvl_pose_result &r, const int32_t *lists);
   static sdvl_pose_params PoseParams(const Camera &cam);
@@ -724,6 +732,8 @@ class SDVLBatch {
   uint64_t search_batch_counter_ = 0;
   std::vector<sdvl_search_req> scratch_reqs_;  // per-step request / pose batches, reused so that they never reallocate
   FeatureAlign::PoseBatch scratch_pose_;
+  std::vector<double> scratch_points_;  // sdvl_search_run_chain inputs, same idea
+  std::vector<int32_t> chain_cand_req_, chain_cand_first_, chain_rand_;
 };
 
 }  // namespace sdvl
