@@ -76,6 +76,18 @@ class SearchReq(C.Structure):
                 ("px0", C.c_double * 2), ("level", C.c_int32), ("fixed", C.c_int32), ("desc", C.c_uint8 * 32)]
 
 
+class SearchReqPacked(C.Structure):
+    """sdvl_search_req_packed: a request of a sdvl_search_begin batch (frames named by slot)"""
+    _fields_ = [("cur", C.c_int32), ("ref", C.c_int32), ("level", C.c_int32), ("fixed", C.c_int32), ("px", C.c_double * 2),
+                ("bearing", C.c_double * 3), ("idepth", C.c_double), ("idepth_std", C.c_double), ("px0", C.c_double * 2),
+                ("desc", C.c_uint8 * 32)]
+
+
+class ChainFrame(C.Structure):
+    _fields_ = [("cand_begin", C.c_int32), ("cand_end", C.c_int32), ("max_matches", C.c_int32), ("rand_begin", C.c_int32),
+                ("pose", C.c_double * 7)]
+
+
 class SearchRes(C.Structure):
     _fields_ = [("px", C.c_double * 2), ("found", C.c_int32), ("level", C.c_int32), ("best_corner", C.c_int32),
                 ("stage", C.c_int32), ("lk_its", C.c_int32), ("slevel", C.c_int32)]
@@ -346,6 +358,68 @@ class Context:
         res = (SearchRes * n)()
         self._check(self.lib.sdvl_search_points(self.h, n, reqs, C.byref(cam), C.byref(sp), res))
         return res
+
+    def search_chain(self, reqs, cam, sp, trackers, req_points, fx, max_ransac_points=5, max_ransac_its=100, max_optim_pose_its=10,
+                     inlier_error_threshold=2.0):
+        """sdvl_search_begin / _slot / _run_chain / _chain_end.  reqs: SearchReq array (frames by handle); trackers: list of
+        dict(cells=[[request index or -1, ...], ...] in SelectPoints order, max_matches, pose7, draws=raw rand() values);
+        req_points[n][3].  Returns (search results, per tracker dict(pose, n_draws, refined, n_obs, inliers, outliers))."""
+        n = len(reqs)
+        lib = self.lib
+        lib.sdvl_search_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(SearchReqPacked))]
+        lib.sdvl_search_slot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        packed = C.POINTER(SearchReqPacked)()
+        self._check(lib.sdvl_search_begin(self.h, n, C.byref(packed)))
+        for i, r in enumerate(reqs):
+            d = packed[i]
+            d.cur = lib.sdvl_search_slot(self.h, r.cur, r.cur_pose)
+            d.ref = lib.sdvl_search_slot(self.h, r.ref, r.ref_pose)
+            assert d.cur >= 0 and d.ref >= 0
+            d.level, d.fixed = r.level, r.fixed
+            d.px[0], d.px[1] = r.px[0], r.px[1]
+            for k in range(3):
+                d.bearing[k] = r.bearing[k]
+            d.idepth, d.idepth_std = r.idepth, r.idepth_std
+            d.px0[0], d.px0[1] = r.px0[0], r.px0[1]
+            for k in range(32):
+                d.desc[k] = r.desc[k]
+        nf = len(trackers)
+        cf = (ChainFrame * nf)()
+        cand_req, cand_first, rand_raw = [], [], []
+        for f, t in enumerate(trackers):
+            cf[f].cand_begin = len(cand_req)
+            for cell in t["cells"]:
+                first = len(cand_req)
+                for r in cell:
+                    cand_req.append(int(r))
+                    cand_first.append(first)
+            cf[f].cand_end = len(cand_req)
+            cf[f].max_matches = int(t["max_matches"])
+            cf[f].rand_begin = len(rand_raw)
+            rand_raw += [int(d) for d in t["draws"][:max_ransac_its]]
+            for c in range(7):
+                cf[f].pose[c] = float(t["pose"][c])
+        cr = np.asarray(cand_req, np.int32); cfi = np.asarray(cand_first, np.int32); rr = np.asarray(rand_raw, np.int32)
+        pts = np.ascontiguousarray(req_points, np.float64).reshape(n, 3)
+        prm = PoseParams(max_ransac_points, max_ransac_its, max_optim_pose_its, 0, inlier_error_threshold / fx, fx)
+        res = (SearchRes * n)()
+        lib.sdvl_search_run_chain.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self._check(lib.sdvl_search_run_chain(self.h, n, C.byref(cam), C.byref(sp), res, nf, cf, len(cr), _ptr(cr, i32p), _ptr(cfi, i32p),
+                                              _ptr(pts, f64p), len(rr), _ptr(rr, i32p), C.byref(prm)))
+        pres = (PoseResult * nf)()
+        n_obs = np.zeros(nf, np.int32)
+        total = sum(int(t["max_matches"]) for t in trackers)
+        lists = np.zeros(max(total, 1), np.int32)
+        lib.sdvl_search_chain_end.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(lib.sdvl_search_chain_end(self.h, nf, pres, _ptr(n_obs, i32p), _ptr(lists, i32p)))
+        out, b = [], 0
+        for f, t in enumerate(trackers):
+            out.append(dict(pose=np.array(list(pres[f].pose)), n_draws=pres[f].n_draws, refined=pres[f].refined, n_obs=int(n_obs[f]),
+                            inliers=lists[b:b + pres[f].n_inliers].copy(),
+                            outliers=lists[b + pres[f].n_inliers:b + pres[f].n_inliers + pres[f].n_outliers].copy()))
+            b += int(t["max_matches"])
+        return res, out
 
     def align_patches(self, frames, levels, border, patch, uv, max_its=10):
         n = len(frames)

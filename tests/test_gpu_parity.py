@@ -287,6 +287,64 @@ def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur
     f_ref.close(); f_cur.close()
 
 
+def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth):
+    """sdvl_search_run_chain / _chain_end against the separate calls: the same search results, the matches the host replay of
+    SelectPoints (first hit per cell, at most max_matches) picks, and bit-identical pose results from them"""
+    img_ref, img_cur = frames_of(synth, orc, TUM_CAM, 640, 480, [0, 5])
+    T_ref, T_cur = trajectory_pose(orc, 0), trajectory_pose(orc, 5)
+    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, 300, 21, True, 0.0, describe=False)
+    n = len(reqs)
+    cam = sdvl.Camera(640, 480, *TUM_CAM)
+    sp = sdvl.default_search_params()
+    rng = np.random.default_rng(99)
+    # the points the requests stand for (plane z = 2 in world = camera 0), as the host would hand them over
+    from oraclelib import quat_to_R
+    Tw = orc.se3_inv(T_ref)
+    Rw, tw = quat_to_R(Tw[:4]), Tw[4:]
+    pts = np.stack([Rw @ (m["bearing"] / m["idepth"]) + tw for m in meta])
+    # two trackers sharing the frame pair: cells of 1-3 candidates, a few candidates without a request, different caps
+    trackers = []
+    for lo, hi, cap in ((0, n // 2, 40), (n // 2, n, 200)):
+        cells, k = [], lo
+        while k < hi:
+            c = list(range(k, min(hi, k + int(rng.integers(1, 4)))))
+            if rng.random() < 0.1:
+                c.insert(int(rng.integers(0, len(c) + 1)), -1)
+            cells.append(c)
+            k = c[-1] + 1 if c[-1] >= 0 else max(x for x in c if x >= 0) + 1
+        trackers.append(dict(cells=cells, max_matches=cap, pose=T_cur, draws=rng.integers(0, 2**31 - 1, 100)))
+    res, got = ctx.search_chain(reqs, cam, sp, trackers, pts, fx=TUM_CAM[0])
+    want_res = ctx.search_points(reqs, cam, sp)
+    for a, b in zip(res, want_res):
+        assert (a.found, a.level, a.best_corner, a.stage, a.lk_its, a.slevel, a.px[0], a.px[1]) == \
+               (b.found, b.level, b.best_corner, b.stage, b.lk_its, b.slevel, b.px[0], b.px[1])
+    jobs = []
+    for t in trackers:
+        sel = []
+        for cell in t["cells"]:
+            if len(sel) >= t["max_matches"]:
+                break
+            for r in cell:
+                if r >= 0 and res[r].found:
+                    sel.append(r)
+                    break
+        obs = []
+        for r in sel:
+            x, y = (res[r].px[0] - TUM_CAM[2]) / TUM_CAM[0], (res[r].px[1] - TUM_CAM[3]) / TUM_CAM[1]
+            nrm = np.sqrt(x * x + y * y + 1.0)
+            v = np.array([x / nrm, y / nrm, 1.0 / nrm])          # Camera::Unproject
+            obs.append([v[0] / v[2], v[1] / v[2], pts[r, 0], pts[r, 1], pts[r, 2], res[r].level])
+        jobs.append((np.array(obs).reshape(-1, 6), T_cur, t["draws"]))
+    want = ctx.pose_from_matches(jobs, fx=TUM_CAM[0])
+    assert got[0]["n_obs"] == 40 and got[1]["n_obs"] > 60
+    for g, w, j in zip(got, want, jobs):
+        assert g["n_obs"] == len(j[0])
+        assert g["n_draws"] == w["n_draws"] and g["refined"] == w["refined"]
+        assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["outliers"], w["outliers"])
+        assert np.array_equal(g["pose"], w["pose"])
+    f_ref.close(); f_cur.close()
+
+
 def test_align_patches_bit_exact_and_recovers_shift(ctx, sdvl, orc, synth):
     img = frames_of(synth, orc, TUM_CAM, 640, 480, [0])[0]
     corners = orc.detect_pyramid(img)
