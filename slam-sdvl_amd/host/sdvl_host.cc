@@ -1111,14 +1111,15 @@ void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_searc
           point->Promote();
           shared_ptr<Feature> feature = frame->NewFeature(Vector2d(r->px[0], r->px[1]), r->level);
           feature->SetPoint(std::move(owner));
-          frame->AddFeature(feature);
+          Feature *const raw = feature.get();
+          frame->GetFeatures().push_back(std::move(feature));  // Frame::AddFeature without a second reference
           point->SetStatus(Point::P_FOUND);
           if (build_obs) {  // observation records for the pose stage; the chained device path builds its own
             const Vector3d P = point->GetPosition();
-            const Vector3d &v = feature->GetVector();
+            const Vector3d &v = raw->GetVector();
             obs_.push_back(Obs{v(0) / v(2), v(1) / v(2), P(0), P(1), P(2), 1.0 / (1 << r->level)});
           }
-          found_.push_back(std::move(feature));
+          found_.push_back(raw);
         }
         matches_++;
       } else {

@@ -646,7 +646,7 @@ class FeatureAlign {
   std::vector<int> plan_begin_;             // per visited cell: first candidate (size = cells + 1)
   int req_base_ = 0;                        // index of this tracker's first request in the caller's vector
   std::shared_ptr<Frame> last_frame_;       // source of the projected points of the current Prepare/Finish pair
-  std::vector<std::shared_ptr<Feature>> found_;  // features created on the current frame (fs_found)
+  std::vector<Feature *> found_;  // features created on the current frame (fs_found); the frame's list keeps them alive
   std::vector<Obs> obs_;                    // parallel to found_
   std::vector<int> inliers_, outliers_;     // indices into found_
   std::vector<double> errors_;              // scratch of ConvergePose
