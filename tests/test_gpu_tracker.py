@@ -182,6 +182,54 @@ def test_farm_fibers_give_identical_results(trk, orc, synth):
     assert all(r[1] == 0 and r[4] >= 100 for r in plain[n:])      # tracking, not idling
 
 
+def test_farm_at_bench_size_replicas_agree_and_match_the_oracle(trk, orc, synth):
+    """The bench configuration (1024 sequences, 16 groups of 64, one worker per group) on 8 distinct sequences replicated
+    128 times: where a sequence sits in a group, which group and which stream it runs on must not matter — every replica
+    gives the same per-frame record, bit for bit — and the 8 distinct ones equal the CPU oracle (decisions exact, poses
+    within 1e-4)."""
+    import importlib
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    G, Bg, n_steps, distinct = 16, 64, 6, 8
+    n = G * Bg
+    trk.configure()
+    farm = trk.TrackerFarm(0, G, Bg, 640, 480, TUM_CAM)
+    ctx = B.CtxView(sdvl, farm.ctx_handle(0))
+    fb = 640 * 480
+    xis = [XI * (1.0 + 0.2 * i) * (1 if i % 2 == 0 else -1) for i in range(distinct)]
+    # a replica's position: sequence i*7 mod 8 — neighbours in a group differ, the same sequence lands in every group
+    which = [(i * 7 + i // Bg) % distinct for i in range(n)]
+    buf = ctx.malloc(n * n_steps * fb)
+    for k in range(n_steps):
+        views = [B.make_view(sdvl, trajectory_pose(orc, k, xis[which[i]]), 20260101 + which[i], k) for i in range(n)]
+        ctx.render(views, buf + k * n * fb)
+    ptrs = (buf + (np.arange(n_steps, dtype=np.uint64)[:, None] * n + np.arange(n, dtype=np.uint64)[None, :]) * fb).astype(np.uint64)
+    farm.reserve(Bg * 6)
+    st = farm.run(ptrs, G)
+    rec = [(s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas, tuple(s.pose[:])) for s in st]
+    first = {}
+    for k in range(n_steps):
+        for i in range(n):
+            key = (k, which[i])
+            if key not in first:
+                first[key] = rec[k * n + i]
+            assert rec[k * n + i] == first[key], (k, i)
+    for d in range(distinct):
+        o = orc.tracker(640, 480, TUM_CAM)
+        i0 = which.index(d)
+        for k in range(n_steps):
+            img = ctx.download(buf + (k * n + i0) * fb, fb).reshape(480, 640)
+            want = o.handle_frame(img)
+            g = first[(k, d)]
+            assert g[:9] == (want.state, want.quality, want.keyframe, want.n_corners, want.matches, want.attempts, want.inliers, want.outliers,
+                             want.align_meas), (k, d)
+            assert np.abs(np.array(g[9]) - np.array(want.pose[:])).max() <= POSE_TOL
+            if k > 0:
+                assert g[1] == 0 and g[4] >= 100
+        o.close()
+    farm.close()
+
+
 def test_closed_loop_without_orb_uses_zmssd_matching(trk, orc, synth):
     """SDVL.use_orb: 0 (the reference's default, config.cc:85): detection margin 1 + PatchSize/2, no descriptors, candidates
     ranked by the integer ZMSSD of the warped 8x8 patch (matcher.cc:447-476) — the whole loop must still agree"""
