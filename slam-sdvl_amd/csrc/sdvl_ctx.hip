@@ -38,46 +38,89 @@ int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d) {
   return SDVL_OK;
 }
 
-hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
-  if (!ctx->wait_event) {
-    hipError_t e = hipEventCreateWithFlags(&ctx->wait_event, hipEventBlockingSync | hipEventDisableTiming);
-    if (e != hipSuccess) return e;
-  }
-  hipError_t e = hipEventRecord(ctx->wait_event, ctx->stream);
-  if (e != hipSuccess) return e;
-  e = sdvl_event_wait(ctx, ctx->wait_event);
-  if (e == hipSuccess) {
-    ctx->stage_off = 0;
-    ctx->wait_gen++;
-  }
-  return e;
+static bool marks_use_events() {
+  static const bool ev = getenv("SDVL_WAIT_EVENTS") != nullptr;
+  return ev;
 }
 
-// hipEventSynchronize busy-waits here even for hipEventBlockingSync events (measured: CPU time = wall time inside the
-// wait; with hipDeviceScheduleBlockingSync still ~2/3 of it), and CPU is what the host side is short of.  So: poll the
-// event and sleep in between; with the timer slack of the thread at 1 us a 25 us nanosleep costs ~30 us.
-static hipError_t poll_event(hipEvent_t ev) {
+hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket) {
+  const uint32_t seq = ++ctx->flag_seq;
+  *ticket = seq;
+  if (marks_use_events()) {
+    if (!ctx->mark_events[kind]) {
+      hipError_t e = hipEventCreateWithFlags(&ctx->mark_events[kind], hipEventBlockingSync | hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    ctx->mark_event_ticket[kind] = seq;
+    return hipEventRecord(ctx->mark_events[kind], ctx->stream);
+  }
+  if (!ctx->h_flag) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, 64, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    memset(p, 0, 64);
+    ctx->h_flag = static_cast<volatile uint32_t *>(p);
+  }
+  // the stream itself writes the sequence number once everything before it has completed: no event object, and the
+  // waiting thread polls a cache line instead of calling into the runtime
+  return hipStreamWriteValue32(ctx->stream, const_cast<uint32_t *>(ctx->h_flag), seq, 0);
+}
+
+// 1 = the mark has been reached, 0 = not yet, < 0 = the stream reported an error
+static int mark_reached(sdvl_ctx *ctx, int kind, uint32_t ticket, hipError_t *err) {
+  *err = hipSuccess;
+  if (marks_use_events()) {
+    if (ctx->mark_event_ticket[kind] != ticket) return 1;  // a later mark of this kind has been recorded and waited for
+    const hipError_t e = hipEventQuery(ctx->mark_events[kind]);
+    if (e == hipErrorNotReady) return 0;
+    *err = e;
+    return e == hipSuccess ? 1 : -1;
+  }
+  const uint32_t seen = __atomic_load_n(const_cast<const uint32_t *>(ctx->h_flag), __ATOMIC_ACQUIRE);
+  return static_cast<int32_t>(seen - ticket) >= 0 ? 1 : 0;
+}
+
+// hipEventSynchronize / hipStreamSynchronize busy-wait here even for hipEventBlockingSync events (measured: CPU time = wall
+// time inside the wait), and CPU is what the host side is short of.  So: poll and sleep in between; with the timer slack
+// of the thread at 1 us a 25 us nanosleep costs ~30 us.  Every ~100 ms the stream is asked whether it is still healthy,
+// so that a faulted kernel surfaces as an error instead of a hang.
+hipError_t sdvl_mark_wait(sdvl_ctx *ctx, int kind, uint32_t ticket) {
   static const int poll_ns = getenv("SDVL_WAIT_POLL_NS") ? atoi(getenv("SDVL_WAIT_POLL_NS")) : 25000;
-  if (poll_ns <= 0) return hipEventSynchronize(ev);
   static thread_local bool slack_set = false;
   if (!slack_set) {
     prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
     slack_set = true;
   }
-  const struct timespec ts = {0, poll_ns};
-  hipError_t e;
-  while ((e = hipEventQuery(ev)) == hipErrorNotReady) nanosleep(&ts, nullptr);
-  return e;
+  const struct timespec ts = {0, poll_ns > 0 ? poll_ns : 1000};
+  hipError_t err = hipSuccess;
+  int polls = 0;
+  if (ctx->wait_hook) {
+    ctx->waiting = 1;
+    ctx->waiting_ticket = ticket;
+    ctx->waiting_kind = kind;
+  }
+  for (;;) {
+    const int r = mark_reached(ctx, kind, ticket, &err);
+    if (r != 0) break;
+    if (ctx->wait_hook) ctx->wait_hook(ctx->wait_user, ctx);
+    else nanosleep(&ts, nullptr);
+    if (++polls % 4096 == 0 && !marks_use_events()) {
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) { err = q; break; }
+    }
+  }
+  ctx->waiting = 0;
+  return err;
 }
 
-hipError_t sdvl_event_wait(sdvl_ctx *ctx, hipEvent_t ev) {
-  hipError_t e;
-  if (ctx->wait_hook) {
-    ctx->waiting_on = ev;
-    while ((e = hipEventQuery(ev)) == hipErrorNotReady) ctx->wait_hook(ctx->wait_user, ctx);
-    ctx->waiting_on = nullptr;
-  } else {
-    e = poll_event(ev);
+hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
+  uint32_t t = 0;
+  hipError_t e = sdvl_mark_record(ctx, SDVL_MARK_STREAM, &t);
+  if (e != hipSuccess) return e;
+  e = sdvl_mark_wait(ctx, SDVL_MARK_STREAM, t);
+  if (e == hipSuccess) {
+    ctx->stage_off = 0;
+    ctx->wait_gen++;
   }
   return e;
 }
@@ -91,14 +134,18 @@ extern "C" int sdvl_ctx_set_wait_hook(sdvl_ctx *ctx, void (*hook)(void *user, sd
 
 // 1 = everything queued before the wait in flight has completed, 0 = still running (never blocks)
 extern "C" int sdvl_ctx_wait_done(sdvl_ctx *ctx) {
-  if (!ctx || !ctx->waiting_on) return 1;
-  return hipEventQuery(ctx->waiting_on) == hipErrorNotReady ? 0 : 1;
+  if (!ctx || !ctx->waiting) return 1;
+  hipError_t err;
+  return mark_reached(ctx, ctx->waiting_kind, ctx->waiting_ticket, &err) != 0 ? 1 : 0;
 }
 
 // sleep (no spinning) until the wait in flight has completed
 extern "C" int sdvl_ctx_wait_block(sdvl_ctx *ctx) {
-  if (!ctx || !ctx->waiting_on) return SDVL_OK;
-  return poll_event(ctx->waiting_on) == hipSuccess ? SDVL_OK : SDVL_ERR_HIP;
+  if (!ctx || !ctx->waiting) return SDVL_OK;
+  const struct timespec ts = {0, 25000};
+  hipError_t err = hipSuccess;
+  while (mark_reached(ctx, ctx->waiting_kind, ctx->waiting_ticket, &err) == 0) nanosleep(&ts, nullptr);
+  return err == hipSuccess ? SDVL_OK : SDVL_ERR_HIP;
 }
 
 int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f) {
@@ -188,9 +235,9 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   sdvl_timer_collect(ctx);
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
-  if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
-  if (ctx->align_event) (void)hipEventDestroy(ctx->align_event);
-  if (ctx->chain_event) (void)hipEventDestroy(ctx->chain_event);
+  for (hipEvent_t e : ctx->mark_events)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->h_flag) (void)hipHostFree(const_cast<uint32_t *>(ctx->h_flag));
   if (ctx->d_nits) (void)hipFree(ctx->d_nits);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);

@@ -625,8 +625,7 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  if (!ctx->align_event) SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->align_event, hipEventBlockingSync | hipEventDisableTiming));
-  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->align_event, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_ALIGN, &ctx->align_ticket));
   ctx->align_pending = n_jobs;
   return SDVL_OK;
 }
@@ -636,7 +635,7 @@ extern "C" int sdvl_image_align_end(sdvl_ctx *ctx, int n_jobs, sdvl_align_result
   if (!ctx || n_jobs < 0 || (n_jobs > 0 && !out)) return SDVL_ERR_INVALID;
   if (n_jobs == 0) return SDVL_OK;
   SDVL_REQUIRE(ctx, ctx->align_pending == n_jobs, "sdvl_image_align_end without a matching sdvl_image_align_begin");
-  SDVL_HIP_CHECK(ctx, sdvl_event_wait(ctx, ctx->align_event));
+  SDVL_HIP_CHECK(ctx, sdvl_mark_wait(ctx, SDVL_MARK_ALIGN, ctx->align_ticket));
   memcpy(out, ctx->h_out, sizeof(sdvl_align_result) * n_jobs);
   ctx->align_pending = 0;
   return SDVL_OK;

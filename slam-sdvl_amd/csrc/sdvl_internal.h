@@ -65,13 +65,18 @@ struct sdvl_ctx {
   void *h_counts = nullptr; size_t h_counts_bytes = 0;
   uint64_t wait_gen = 0, counts_gen = ~0ull;
   std::vector<void *> slabs;  // bulk frame storage, released with the context
-  hipEvent_t wait_event = nullptr;  // created with hipEventBlockingSync | hipEventDisableTiming
+  // Waiting for a point of the stream: a 32-bit sequence number written by the stream itself (hipStreamWriteValue32) into
+  // pinned host memory, polled by the waiting thread with plain loads (SDVL_WAIT_EVENTS=1: HIP events + hipEventQuery)
+  volatile uint32_t *h_flag = nullptr;
+  uint32_t flag_seq = 0;
+  hipEvent_t mark_events[3] = {nullptr, nullptr, nullptr};  // event mode: one per kind of mark (stream, align, chain)
+  uint32_t mark_event_ticket[3] = {0, 0, 0};
   // cooperative waits: when set, sdvl_stream_wait polls the event and calls the hook while the stream is still busy, so a
   // host thread that drives several contexts can run another one's host stage instead of sleeping
-  hipEvent_t align_event = nullptr;  // marks the result copy of sdvl_image_align_begin
+  uint32_t align_ticket = 0;  // marks the result copy of sdvl_image_align_begin
   int align_pending = 0;
-  // sdvl_search_run_chain: the search results have landed at chain_event; the pose results follow at the stream's tail
-  hipEvent_t chain_event = nullptr;
+  // sdvl_search_run_chain: the search results have landed at chain_ticket; the pose results follow at the stream's tail
+  uint32_t chain_ticket = 0;
   int chain_pending = 0;             // trackers of the chained batch in flight
   size_t chain_host_off = 0;         // where its pose results start in h_out
   int chain_obs_total = 0;
@@ -79,7 +84,9 @@ struct sdvl_ctx {
   void *d_nits = nullptr;
   std::vector<int32_t> nits_host;
   int nits_points = -1, nits_its = -1, nits_max_size = -1;
-  hipEvent_t waiting_on = nullptr;   // the event a cooperative wait is polling (sdvl_ctx_wait_done / _block)
+  int waiting = 0;                   // a cooperative wait is polling `waiting_ticket` (sdvl_ctx_wait_done / _block)
+  uint32_t waiting_ticket = 0;
+  int waiting_kind = 0;
   void (*wait_hook)(void *user, sdvl_ctx *ctx) = nullptr;
   void *wait_user = nullptr;
   // per-kernel timing (HIP events on `stream`)
@@ -127,9 +134,11 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);
 int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d);
 // wait for everything queued on ctx->stream WITHOUT spinning: hipEventBlockingSync event + hipEventSynchronize.
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
-// wait (blocking or cooperative, like sdvl_stream_wait) for ONE event already recorded on the stream; work queued after the
-// event may still be running, so the staging ring is not recycled
-hipError_t sdvl_event_wait(sdvl_ctx *ctx, hipEvent_t ev);
+// a point of the stream to wait for later: everything queued before the mark has completed once the wait returns; work
+// queued after it may still be running.  kind: 0 = whole-stream waits, 1 = image alignment results, 2 = chained search
+enum { SDVL_MARK_STREAM = 0, SDVL_MARK_ALIGN = 1, SDVL_MARK_CHAIN = 2 };
+hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket);
+hipError_t sdvl_mark_wait(sdvl_ctx *ctx, int kind, uint32_t ticket);
 // host copy of a frame's corner count; fetches it (blocking) when only the device knows it
 int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n);
 // make the device corner header match the host view before a kernel reads it (after an image change without detection)

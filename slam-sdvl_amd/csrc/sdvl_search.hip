@@ -815,8 +815,7 @@ int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   size_t d_off = 0, h_off = 0;
   rc = search_enqueue(ctx, n, cam, p, jb + ob + hb + rb + nb + lb, rb + nb + lb, &d_off, &h_off);
   if (rc) return rc;
-  if (!ctx->chain_event) SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->chain_event, hipEventBlockingSync | hipEventDisableTiming));
-  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->chain_event, ctx->stream));  // the search results are on the host from here on
+  SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_CHAIN, &ctx->chain_ticket));  // the search results are on the host from here on
   // inputs of the selection + pose stage: one staged copy
   const size_t fb = (sizeof(ChainFrameDev) * n_frames + 255) / 256 * 256, cb = (sizeof(int32_t) * static_cast<size_t>(n_cand) + 255) / 256 * 256;
   const size_t pb = (sizeof(double) * 3 * static_cast<size_t>(n) + 255) / 256 * 256, rndb = (sizeof(int32_t) * static_cast<size_t>(n_rand) + 255) / 256 * 256;
@@ -864,7 +863,7 @@ int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   ctx->chain_pending = n_frames;
   ctx->chain_host_off = h_off;
   ctx->chain_obs_total = obs_total;
-  SDVL_HIP_CHECK(ctx, sdvl_event_wait(ctx, ctx->chain_event));
+  SDVL_HIP_CHECK(ctx, sdvl_mark_wait(ctx, SDVL_MARK_CHAIN, ctx->chain_ticket));
   memcpy(out, ctx->h_out, sizeof(sdvl_search_res) * static_cast<size_t>(n));
   return SDVL_OK;
 }

@@ -1017,7 +1017,18 @@ void FeatureAlign::PrepareReprojectImpl(const shared_ptr<Frame> &frame, const sh
     plan_begin_[i] = static_cast<int>(plan_.size());
     vector<CellEntry> &cell = grid_[cell_order_[i]];
     // cell->sort(CompareQuality): std::list::sort is a stable merge sort
-    if (cell.size() > 1) std::stable_sort(cell.begin(), cell.end(), [](const CellEntry &a, const CellEntry &b) { return a.score > b.score; });
+    // (a stable order is unique, so any stable algorithm gives the list's order; cells hold a handful of entries and
+    // std::stable_sort would malloc a merge buffer for each of them)
+    if (cell.size() > 32) {
+      std::stable_sort(cell.begin(), cell.end(), [](const CellEntry &a, const CellEntry &b) { return a.score > b.score; });
+    } else {
+      for (size_t a = 1; a < cell.size(); a++) {
+        const CellEntry e = cell[a];
+        size_t b = a;
+        while (b > 0 && cell[b - 1].score < e.score) { cell[b] = cell[b - 1]; b--; }
+        cell[b] = e;
+      }
+    }
     for (size_t ce = 0; ce < cell.size(); ce++) {
       const CellEntry &e = cell[ce];
       Point *point = features[e.src]->GetPointRaw();
@@ -1830,7 +1841,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
         if (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) {
           vector<shared_ptr<Feature>> &features = t.current_frame_->GetFeatures();
           for (auto it = features.begin(); it != features.end(); it++)
-            if ((*it)->GetPoint()) (*it)->GetPoint()->AddFeature(*it);
+            if (Point *p = (*it)->GetPointRaw()) p->AddFeature(*it);
           t.current_frame_->SetKeyframe();
           t.map_->AddKeyframe(t.current_frame_);
           t.last_kf_ = t.current_frame_;
