@@ -298,6 +298,7 @@ def main():
     thr0 = throttled()
     rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     flt0 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     barrier()
     t0 = time.perf_counter()
     stats = farm.run(ptrs[1 + Wm:], workers, stats_buf)  # the K timed steps: group-steps are scheduled onto the worker threads
@@ -306,6 +307,10 @@ def main():
     rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     flt1 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
     thr1 = throttled()
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+    sys.stderr.write("host CPU in the timed region: %.2f s user + %.2f s system over %.2f s wall = %.1f CPUs busy (%d usable)\n" %
+                     (ru1.ru_utime - ru0.ru_utime, ru1.ru_stime - ru0.ru_stime, elapsed, cpu_s / elapsed, ncpu))
     sys.stderr.write("host memory: max RSS %.0f -> %.0f MB, minor page faults in the timed region: %d; CPU quota throttling in the timed region: "
                      "%d periods, %.1f ms\n" % (rss0 / 1024, rss1 / 1024, flt1 - flt0, thr1[0] - thr0[0], (thr1[1] - thr0[1]) / 1e3))
     timers = {}
