@@ -132,7 +132,7 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);
 // last sdvl_stream_wait never overlap, so a call can fill its records while earlier copies are still in flight;
 // only when the ring is exhausted does this wait for the stream.
 int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d);
-// wait for everything queued on ctx->stream WITHOUT spinning: hipEventBlockingSync event + hipEventSynchronize.
+// wait for everything queued on ctx->stream WITHOUT spinning: a mark (sdvl_mark_record) + sleeping polls (sdvl_mark_wait).
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
 // a point of the stream to wait for later: everything queued before the mark has completed once the wait returns; work
 // queued after it may still be running.  kind: 0 = whole-stream waits, 1 = image alignment results, 2 = chained search

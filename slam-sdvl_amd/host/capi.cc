@@ -272,8 +272,8 @@ struct Farm {
 // ---- cooperative group-steps -------------------------------------------------------------------------------------
 // A group-step spends ~40 % of its time blocked on its own stream (alignment, search, pose, filter results).  With
 // fibers_per_worker > 1 a worker thread runs several group-steps on separate stacks (ucontext); the library's wait hook
-// (sdvl_ctx_set_wait_hook) switches to another fiber whenever a step would sleep, and the thread only sleeps — in
-// hipEventSynchronize, no spinning: the CPU quota is the scarce resource — when every fiber is waiting for the GPU.
+// (sdvl_ctx_set_wait_hook) switches to another fiber whenever a step would sleep, and the thread only sleeps — a 25 us
+// nanosleep between polls, no spinning: the CPU quota is the scarce resource — when every fiber is waiting for the GPU.
 namespace {
 struct Fiber {
   ucontext_t ctx;
