@@ -195,6 +195,11 @@ int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap,
  * (desc may be NULL), counts[n]. */
 int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
                        int32_t *counts);
+/* The same in two halves: _begin queues the kernels and the result copy, _end waits for exactly that and unpacks.  Between
+ * the two the caller may do host work, but no other call on this context that returns data to the host. */
+int sdvl_filter_inputs_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int with_desc);
+int sdvl_filter_inputs_end(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
+                           int32_t *counts);
 /* ORBDetector::GetDescriptor at arbitrary (x,y,level) points of one frame; out_angle_deg may be NULL */
 int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const int32_t *xyl, uint8_t *out_desc,
                              float *out_angle_deg);

@@ -69,14 +69,18 @@ struct sdvl_ctx {
   // pinned host memory, polled by the waiting thread with plain loads (SDVL_WAIT_EVENTS=1: HIP events + hipEventQuery)
   volatile uint32_t *h_flag = nullptr;
   uint32_t flag_seq = 0;
-  hipEvent_t mark_events[3] = {nullptr, nullptr, nullptr};  // event mode: one per kind of mark (stream, align, chain)
-  uint32_t mark_event_ticket[3] = {0, 0, 0};
+  hipEvent_t mark_events[4] = {nullptr, nullptr, nullptr, nullptr};  // event mode: one per kind of mark
+  uint32_t mark_event_ticket[4] = {0, 0, 0, 0};
   // cooperative waits: when set, sdvl_stream_wait polls the event and calls the hook while the stream is still busy, so a
   // host thread that drives several contexts can run another one's host stage instead of sleeping
   uint32_t align_ticket = 0;  // marks the result copy of sdvl_image_align_begin
   int align_pending = 0;
   // sdvl_search_run_chain: the search results have landed at chain_ticket; the pose results follow at the stream's tail
   uint32_t chain_ticket = 0;
+  // sdvl_filter_inputs_begin in flight: its mark and the row geometry _end needs
+  uint32_t filter_ticket = 0;
+  int filter_pending = 0, filter_ccap = 0, filter_desc = 0;
+  size_t filter_sc_bytes = 0, filter_row = 0;
   int chain_pending = 0;             // trackers of the chained batch in flight
   size_t chain_host_off = 0;         // where its pose results start in h_out
   int chain_obs_total = 0;
@@ -135,8 +139,9 @@ int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d);
 // wait for everything queued on ctx->stream WITHOUT spinning: a mark (sdvl_mark_record) + sleeping polls (sdvl_mark_wait).
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
 // a point of the stream to wait for later: everything queued before the mark has completed once the wait returns; work
-// queued after it may still be running.  kind: 0 = whole-stream waits, 1 = image alignment results, 2 = chained search
-enum { SDVL_MARK_STREAM = 0, SDVL_MARK_ALIGN = 1, SDVL_MARK_CHAIN = 2 };
+// queued after it may still be running.  kind: 0 = whole-stream waits, 1 = image alignment results, 2 = chained search,
+// 3 = keyframe filter inputs
+enum { SDVL_MARK_STREAM = 0, SDVL_MARK_ALIGN = 1, SDVL_MARK_CHAIN = 2, SDVL_MARK_FILTER = 3 };
 hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket);
 hipError_t sdvl_mark_wait(sdvl_ctx *ctx, int kind, uint32_t ticket);
 // host copy of a frame's corner count; fetches it (blocking) when only the device knows it

@@ -214,10 +214,11 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   return SDVL_OK;
 }
 
-int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
-                       int32_t *counts) {
-  if (!ctx || n < 0 || (n > 0 && (!frames || !xyl || !scores || !counts)) || cap <= 0) return SDVL_ERR_INVALID;
+int sdvl_filter_inputs_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int with_desc) {
+  if (!ctx || n < 0 || (n > 0 && !frames) || cap <= 0) return SDVL_ERR_INVALID;
+  ctx->filter_pending = 0;
   if (n == 0) return SDVL_OK;
+  const bool desc = with_desc != 0;
   for (int i = 0; i < n; i++) SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
   if (desc) {  // frames whose descriptors have not been computed yet (searches compute only what they compare) get them now
     std::vector<sdvl_frame *> missing;
@@ -261,7 +262,25 @@ int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap,
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   uint8_t *h = static_cast<uint8_t *>(ctx->h_out);
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_out, sc_bytes + row * n, hipMemcpyDeviceToHost, ctx->stream));
-  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_FILTER, &ctx->filter_ticket));
+  ctx->filter_pending = n;
+  ctx->filter_ccap = ccap;
+  ctx->filter_desc = desc ? 1 : 0;
+  ctx->filter_sc_bytes = sc_bytes;
+  ctx->filter_row = row;
+  return SDVL_OK;
+}
+
+int sdvl_filter_inputs_end(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
+                           int32_t *counts) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !xyl || !scores || !counts)) || cap <= 0) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, ctx->filter_pending == n && (desc != nullptr) == (ctx->filter_desc != 0), "sdvl_filter_inputs_end without a matching sdvl_filter_inputs_begin");
+  ctx->filter_pending = 0;
+  SDVL_HIP_CHECK(ctx, sdvl_mark_wait(ctx, SDVL_MARK_FILTER, ctx->filter_ticket));
+  const int ccap = ctx->filter_ccap;
+  const size_t sc_bytes = ctx->filter_sc_bytes, row = ctx->filter_row;
+  const uint8_t *h = static_cast<const uint8_t *>(ctx->h_out);
   for (int i = 0; i < n; i++) {
     const uint8_t *src = h + sc_bytes + row * i;
     const int32_t *hdr = reinterpret_cast<const int32_t *>(src);
@@ -281,6 +300,14 @@ int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap,
     if (desc) memcpy(desc + static_cast<size_t>(i) * cap * 32, src + sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1), static_cast<size_t>(cnt) * 32);
   }
   return SDVL_OK;
+}
+
+int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
+                       int32_t *counts) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !xyl || !scores || !counts)) || cap <= 0) return SDVL_ERR_INVALID;
+  const int rc = sdvl_filter_inputs_begin(ctx, n, frames, cap, desc ? 1 : 0);
+  if (rc) return rc;
+  return sdvl_filter_inputs_end(ctx, n, frames, cap, xyl, scores, desc, counts);
 }
 
 int sdvl_frame_download_descriptors(sdvl_ctx *ctx, const sdvl_frame *f, int cap, uint8_t *out) {

@@ -647,6 +647,22 @@ vector<vector<uchar>> &Frame::GetDescriptors() {
 void Frame::FilterCorners() { FilterCornersBatch({shared_from_this()}); }
 
 void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
+  FilterCornersBegin(frames);
+  FilterCornersEnd(frames);
+}
+
+// first half: the device side of FilterCorners for all frames (Shi-Tomasi scores, missing descriptors, one gather, one
+// copy) is queued; the caller may do host work that does not touch the device before FilterCornersEnd
+void Frame::FilterCornersBegin(const vector<shared_ptr<Frame>> &frames) {
+  const int n = static_cast<int>(frames.size());
+  if (n == 0) return;
+  Device *dev = Device::Current();
+  vector<sdvl_frame *> devs(n);
+  for (int i = 0; i < n; i++) devs[i] = frames[i]->dev_;
+  dev->Check(sdvl_filter_inputs_begin(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, Config::UseORB() ? 1 : 0), "sdvl_filter_inputs_begin");
+}
+
+void Frame::FilterCornersEnd(const vector<shared_ptr<Frame>> &frames) {
   const int n = static_cast<int>(frames.size());
   if (n == 0) return;
   Device *dev = Device::Current();
@@ -663,8 +679,8 @@ void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
   if (xyl.size() < n * cap * 3) xyl.resize(n * cap * 3);
   if (scores.size() < n * cap) scores.resize(n * cap);
   if (orb && desc.size() < n * cap * 32) desc.resize(n * cap * 32);
-  dev->Check(sdvl_filter_inputs(dev->ctx(), n, devs.data(), static_cast<int>(cap), xyl.data(), scores.data(), orb ? desc.data() : nullptr,
-                                counts.data()), "sdvl_filter_inputs");
+  dev->Check(sdvl_filter_inputs_end(dev->ctx(), n, devs.data(), static_cast<int>(cap), xyl.data(), scores.data(), orb ? desc.data() : nullptr,
+                                    counts.data()), "sdvl_filter_inputs_end");
   for (int i = 0; i < n; i++) {
     Frame &f = *frames[i];
     const int cnt = counts[i];
@@ -1675,6 +1691,21 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     }
   }
 
+  // fresh keyframes of plane-map trackers: their FilterCorners round trip is queued as soon as the keyframe decisions are
+  // known (stage 3b) and collected in stage 4, with the rest of the per-tracker bookkeeping in between
+  vector<shared_ptr<Frame>> kfs;
+  vector<int> kf_owner;
+  bool filter_begun = false;
+  // corner counts of this step's frames (they rode along with the detection kernels: no round trip once any wait on the
+  // stream has returned since): the statistics need them, and with them known the keyframe round trip returns rows of
+  // exactly the right length
+  const auto fetch_corner_counts = [&]() {
+    vector<sdvl_frame *> devs(B);
+    vector<int32_t> counts(B);
+    for (int i = 0; i < B; i++) devs[i] = frames[i]->device();
+    dev_->Check(sdvl_frames_corner_counts(dev_->ctx(), B, devs.data(), counts.data()), "sdvl_frames_corner_counts");
+    for (int i = 0; i < B; i++) stats[i].n_corners = counts[i];
+  };
   // ---- stage 2: FeatureAlign::Reproject, sdvl.cc:193 — all candidates of all trackers in one launch
   {
     clk.reset(new StageClock(ST_PREPARE));
@@ -1819,6 +1850,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
                                          static_cast<int>(all.nits.size()), all.nits.data(), &pp, pres.data(), lists.data()),
                   "sdvl_pose_from_matches");
     }
+    vector<char> decision(R, 0);  // 0 = tracking lost, 1 = ordinary frame, 2 = new keyframe
     ParallelFor(R, [&](int k) {
       const int i = run[k];
       SDVL &t = *trk_[i];
@@ -1837,8 +1869,32 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
         for (int c = 0; c < 6; c++) t.vel_[c] = 0.9 * (0.5 * vel[c] + 0.5 * t.vel_[c]);
       }
       t.CalcTrackingQuality(t.matches_, t.attempts_);
-      if (t.tracking_quality_ != SDVL::TRACKING_BAD) {
-        if (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) {
+      if (t.tracking_quality_ != SDVL::TRACKING_BAD)
+        decision[k] = (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) ? 2 : 1;
+    });
+    // the keyframes are known: queue their FilterCorners inputs (Shi-Tomasi, descriptors, one gather + copy) now; the
+    // bookkeeping below (feature lists of the points, keyframe graph, retiring the previous frames) runs meanwhile
+    if (threads_ <= 1) {
+      vector<char> fresh(B, 0);
+      for (int k = 0; k < R; k++)
+        if (decision[k] == 2 && !dynamic_cast<MapperMap *>(trk_[run[k]]->map_)) fresh[run[k]] = 1;
+      for (int i = 0; i < B; i++) {
+        if (trk_[i]->pending_kf_) { kfs.push_back(trk_[i]->pending_kf_); kf_owner.push_back(i); }
+        else if (fresh[i]) { kfs.push_back(trk_[i]->current_frame_); kf_owner.push_back(i); }
+      }
+      if (!kfs.empty()) {
+        StageClock fclk(ST_MAPPING);
+        fetch_corner_counts();  // before the filter round trip: it shares the context's result buffers
+        Frame::FilterCornersBegin(kfs);
+        filter_begun = true;
+      }
+    }
+    ParallelFor(R, [&](int k) {
+      const int i = run[k];
+      SDVL &t = *trk_[i];
+      FrameStats &st = stats[i];
+      if (decision[k] != 0) {
+        if (decision[k] == 2) {
           vector<shared_ptr<Feature>> &features = t.current_frame_->GetFeatures();
           for (auto it = features.begin(); it != features.end(); it++)
             if (Point *p = (*it)->GetPointRaw()) p->AddFeature(*it);
@@ -1858,23 +1914,19 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
 
   // ---- stage 4: mapper stand-in for fresh keyframes (sequential mode, main.cc:148-149): one K3 launch for all
   clk.reset(new StageClock(ST_MAPPING));
-  {  // corner counts of this step's frames (one small copy): the statistics need them, and with them known the keyframe
-     // round trip below returns rows of exactly the right length
-    vector<sdvl_frame *> devs(B);
-    vector<int32_t> counts(B);
-    for (int i = 0; i < B; i++) devs[i] = frames[i]->device();
-    dev_->Check(sdvl_frames_corner_counts(dev_->ctx(), B, devs.data(), counts.data()), "sdvl_frames_corner_counts");
-    for (int i = 0; i < B; i++) stats[i].n_corners = counts[i];
-  }
+  if (!filter_begun) fetch_corner_counts();
   {
-    vector<shared_ptr<Frame>> kfs;
-    vector<int> owner;
-    for (int i = 0; i < B; i++)
-      if (trk_[i]->pending_kf_) { kfs.push_back(trk_[i]->pending_kf_); owner.push_back(i); }
+    if (!filter_begun) {
+      kfs.clear();
+      kf_owner.clear();
+      for (int i = 0; i < B; i++)
+        if (trk_[i]->pending_kf_) { kfs.push_back(trk_[i]->pending_kf_); kf_owner.push_back(i); }
+      Frame::FilterCornersBegin(kfs);
+    }
     if (!kfs.empty()) {
-      Frame::FilterCornersBatch(kfs);
+      Frame::FilterCornersEnd(kfs);
       ParallelFor(static_cast<int>(kfs.size()), [&](int k) {
-        SDVL &t = *trk_[owner[k]];
+        SDVL &t = *trk_[kf_owner[k]];
         PlaneMap *pm = dynamic_cast<PlaneMap *>(t.map_);
         if (pm) pm->SeedFromFiltered(kfs[k]);  // other Map implementations run their own mapper on AddKeyframe
         t.pending_kf_ = nullptr;

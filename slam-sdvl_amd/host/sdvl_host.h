@@ -341,6 +341,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void SetKeyframe() { is_keyframe_ = true; }
   void FilterCorners();
   static void FilterCornersBatch(const std::vector<std::shared_ptr<Frame>> &frames);
+  static void FilterCornersBegin(const std::vector<std::shared_ptr<Frame>> &frames);  // the two halves of FilterCornersBatch
+  static void FilterCornersEnd(const std::vector<std::shared_ptr<Frame>> &frames);
   // corner detection + ORB for frames built with corners = false (CreateBatch): queues the kernels, returns at once
   static void DetectBatch(const std::vector<std::shared_ptr<Frame>> &frames, int nfeatures);
   const SE3 &GetPose() const { return pose_; }
