@@ -313,6 +313,9 @@ def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth)
             cells.append(c)
             k = c[-1] + 1 if c[-1] >= 0 else max(x for x in c if x >= 0) + 1
         trackers.append(dict(cells=cells, max_matches=cap, pose=T_cur, draws=rng.integers(0, 2**31 - 1, 100)))
+    # a tracker that projected nothing into the image (no candidates) and one whose only candidates have no request
+    trackers.append(dict(cells=[], max_matches=200, pose=T_ref, draws=rng.integers(0, 2**31 - 1, 100)))
+    trackers.append(dict(cells=[[-1], [-1, -1]], max_matches=200, pose=T_cur, draws=rng.integers(0, 2**31 - 1, 100)))
     res, got = ctx.search_chain(reqs, cam, sp, trackers, pts, fx=TUM_CAM[0])
     want_res = ctx.search_points(reqs, cam, sp)
     for a, b in zip(res, want_res):
@@ -334,9 +337,12 @@ def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth)
             nrm = np.sqrt(x * x + y * y + 1.0)
             v = np.array([x / nrm, y / nrm, 1.0 / nrm])          # Camera::Unproject
             obs.append([v[0] / v[2], v[1] / v[2], pts[r, 0], pts[r, 1], pts[r, 2], res[r].level])
-        jobs.append((np.array(obs).reshape(-1, 6), T_cur, t["draws"]))
+        jobs.append((np.array(obs).reshape(-1, 6), t["pose"], t["draws"]))
     want = ctx.pose_from_matches(jobs, fx=TUM_CAM[0])
     assert got[0]["n_obs"] == 40 and got[1]["n_obs"] > 60
+    for g, t in zip(got[2:], trackers[2:]):     # nothing to select: SelectInliers / OptimizePose leave the pose alone, draw nothing
+        assert g["n_obs"] == 0 and g["n_draws"] == 0 and g["refined"] == 0 and len(g["inliers"]) == 0 and len(g["outliers"]) == 0
+        assert np.array_equal(g["pose"], np.asarray(t["pose"], np.float64))
     for g, w, j in zip(got, want, jobs):
         assert g["n_obs"] == len(j[0])
         assert g["n_draws"] == w["n_draws"] and g["refined"] == w["refined"]
