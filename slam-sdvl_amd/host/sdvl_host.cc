@@ -1124,6 +1124,18 @@ void FeatureAlign::FinishSelect(const shared_ptr<Frame> &frame, const sdvl_searc
   const int size = static_cast<int>(plan_begin_.size()) - 1;
   if (!relocalizing_) frame->GetFeatures().reserve(frame->GetFeatures().size() + static_cast<size_t>(max_matches_));
   vector<shared_ptr<Feature>> &src_features = last_frame_->GetFeatures();
+  // the loop below touches, per candidate, the feature it came from and that feature's point — last used a whole batch of
+  // frames ago.  Two passes of prefetches first (features, then points): independent misses overlap, one dependent chain
+  // per candidate does not.
+  if (!relocalizing_) {
+    const int total = plan_begin_[size];
+    for (int k = 0; k < total; k++) __builtin_prefetch(src_features[plan_[k].src].get());
+    for (int k = 0; k < total; k++) {
+      const char *p = reinterpret_cast<const char *>(src_features[plan_[k].src]->GetPointRaw());
+      __builtin_prefetch(p, 1);
+      __builtin_prefetch(p + 64, 1);
+    }
+  }
   for (int i = 0; i < size && matches_ < max_matches_; i++) {
     bool found = false;
     for (int k = plan_begin_[i]; k < plan_begin_[i + 1] && !found; k++) {
