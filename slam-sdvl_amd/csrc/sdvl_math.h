@@ -30,6 +30,43 @@ SDVL_HD V3 vscale_l(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
 SDVL_HD double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 SDVL_HD double vnorm(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 
+// sin and cos of a double in [0, 2*pi + eps] (the ORB orientation angle, extra/orb_detector.cc:361-362), fdlibm style: quadrant by Cody-Waite reduction with a
+// 33-bit head of pi/2 (n <= 4, so n * head is exact), then the k_sin / k_cos kernels with the reduction's tail.  Within
+// 1 ulp (double) of the true value like libm's and ocml's, so the float the caller rounds to is the same (DESIGN.md "frozen
+// interpretations"); unlike ocml's sin()/cos() there is no large-argument path, which cost ~15 VGPRs in every kernel that
+// describes corners.  Plain IEEE double arithmetic: identical on host and device (tests/test_abi_cpu.py checks the host
+// build, sdvlh_sincos_2pi, against libm; every float in [0, 6.3] was compared once: no float differs).
+SDVL_HD void sincos_2pi(double x, double *sn, double *cs) {
+  const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+  const double r0 = x - n * 1.57079632673412561417e+00;  // exact product, (nearly always) exact difference
+  const double w = n * 6.07710050650619224932e-11;
+  const double y = r0 - w;
+  const double t = (r0 - y) - w;  // tail of the reduced argument
+  const double z = y * y;
+  // k_sin(y, t)
+  const double v = z * y;
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double ks = y - ((z * (0.5 * t - v * rs) - t) - v * -1.66666666666666324348e-01);
+  // k_cos(y, t), |y| <= pi/4 + eps
+  const double rc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double ay = y < 0 ? -y : y;
+  double kc;
+  if (ay < 0.3) {
+    kc = 1.0 - (0.5 * z - (z * rc - y * t));
+  } else {
+    const double qx = ay > 0.78125 ? 0.28125 : 0.25 * ay;  // fdlibm truncates |y|/4 to its high word; any qx near |y|/4 keeps the sum exact
+    const double hz = 0.5 * z - qx;
+    kc = (1.0 - qx) - (hz - (z * rc - y * t));
+  }
+  const int q = static_cast<int>(n) & 3;
+  const double s_ = (q & 1) ? kc : ks, c_ = (q & 1) ? ks : kc;
+  *sn = (q & 2) ? -s_ : s_;
+  *cs = (q == 1 || q == 2) ? -c_ : c_;
+}
+
 SDVL_HD V3 mvec(const M3 &R, V3 v) {
   return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
           R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};

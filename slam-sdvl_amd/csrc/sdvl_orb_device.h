@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "sdvl_math.h"
 
 namespace {
 
@@ -80,8 +81,10 @@ __device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W
   const float angle_deg = fast_atan2_deg(static_cast<float>(m01), static_cast<float>(m10));
   const float factorPI = static_cast<float>(M_PI / 180.f);
   const float angle = static_cast<float>(static_cast<double>(angle_deg) * factorPI);
-  const float a = static_cast<float>(cos(static_cast<double>(angle)));
-  const float b = static_cast<float>(sin(static_cast<double>(angle)));
+  double sn_d, cs_d;
+  sdvl::sincos_2pi(static_cast<double>(angle), &sn_d, &cs_d);
+  const float a = static_cast<float>(cs_d);
+  const float b = static_cast<float>(sn_d);
   // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..); its 16 pattern bytes come in one 128-bit load
   const uint4 pw = reinterpret_cast<const uint4 *>(c_orb_pattern)[lane];
   const uint32_t pq[4] = {pw.x, pw.y, pw.z, pw.w};

@@ -63,6 +63,9 @@ struct SearchPrep {
   int alive, slevel;
   double pxa[2], pxb[2];        // projected ends of the depth interval (pxb only for epipolar searches)
   double I00, I01, I10, I11;    // inverse of the affine warp (CreatePatch, matcher.cc:330)
+  // wave-uniform constants of GetCornersInRange (matcher.cc:139-148, 92-94), computed once by the request's lane; the wave
+  // kernel reads the record with scalar loads, so they live in SGPRs instead of 64 copies in VGPRs
+  double nx, ny, normdist, xdiff, ydiff, vline, range, range2;
 };
 
 struct PatchJob {  // sdvl_align_patches
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev 
   out.slevel = -1;
   out.pxa[0] = out.pxa[1] = out.pxb[0] = out.pxb[1] = 0.0;
   out.I00 = out.I01 = out.I10 = out.I11 = 0.0;
+  out.nx = out.ny = out.normdist = out.xdiff = out.ydiff = out.vline = out.range = out.range2 = 0.0;
   const int level = rq.level;
   const Rigid cur_pose = se3_from7(tcur.pose), ref_pose = se3_from7(tref.pose);
   const Rigid ref_world = se3_inverse(ref_pose);
@@ -275,10 +279,27 @@ __global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev 
   out.alive = 1;
   out.slevel = slevel;
   out.pxa[0] = pxa.x; out.pxa[1] = pxa.y; out.pxb[0] = pxb.x; out.pxb[1] = pxb.y;
+  {
+    double range = prm.search_size;
+    for (int i = 1; i <= slevel; i++) range *= 1.2;
+    out.range = range;
+    out.range2 = range * range;
+    // epipolar line constants (matcher.cc:139-148)
+    double ex = pxa.x - pxb.x, ey = pxa.y - pxb.y;
+    const double en = sqrt(ex * ex + ey * ey);
+    ex /= en;
+    ey /= en;
+    out.nx = ey;
+    out.ny = -ex;
+    out.normdist = pxa.x * out.nx + pxa.y * out.ny;
+    out.xdiff = pxb.x - pxa.x;
+    out.ydiff = pxb.y - pxa.y;
+    out.vline = (out.xdiff) * (out.xdiff) + (out.ydiff) * (out.ydiff);
+  }
   prep[ri] = out;
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
                                                                             const SearchFramePose *__restrict__ table,
                                                                             const SearchBlock *__restrict__ blocks,
                                                                             const SearchPrep *__restrict__ prep, Cam cam,
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
   // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
   __shared__ uint32_t s_corners[SDVL_MAX_CORNERS];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // wave-uniform: request, prep and frame-table loads become scalar loads
   // Workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is padded to a multiple of 8).  XCD x takes the x-th
   // eighth of the block table: blocks are ordered by current frame, so one frame's corner list, search-level image and
   // ORB windows are fetched into ONE L2 instead of all eight.
@@ -349,24 +370,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
     }
   }
   wave_sync();
-  double range = prm.search_size;
-  for (int i = 1; i <= slevel; i++) range *= 1.2;
-  const double range2 = range * range;
+  const double range = pr.range, range2 = pr.range2;
 
   // ---- GetCornersInRange + SearchFeatures
   const int threshold = prm.use_orb ? 100 : prm.patch_size * prm.patch_size * 500;
   unsigned long long best = ~0ull;
   {
     const SearchFrame &cf = tcur.f;
-    // epipolar line constants (matcher.cc:139-148)
-    double ex = pxa.x - pxb.x, ey = pxa.y - pxb.y;
-    const double en = sqrt(ex * ex + ey * ey);
-    ex /= en;
-    ey /= en;
-    const double nx = ey, ny = -ex;
-    const double normdist = pxa.x * nx + pxa.y * ny;
-    const double xdiff = pxb.x - pxa.x, ydiff = pxb.y - pxa.y;
-    const double vline = (xdiff) * (xdiff) + (ydiff) * (ydiff);
+    const double nx = pr.nx, ny = pr.ny, normdist = pr.normdist, xdiff = pr.xdiff, ydiff = pr.ydiff, vline = pr.vline;
     int sumA = 0, sumAA = 0;
     if (!prm.use_orb) {
       const int pv = L.patch[lane];
@@ -442,6 +453,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void search_points_kernel(cons
           // CompareZMSSDScore, matcher.cc:461-476 (integer arithmetic, integer division by 64)
           const uint8_t *cp = cf.level[cl] + static_cast<size_t>(cy - 4) * cf.lw[cl] + (cx - 4);
           unsigned sumB = 0, sumBB = 0, sumAB = 0;
+#pragma unroll 1
           for (int yy = 0, r = 0; yy < 8; yy++)
             for (int xx = 0; xx < 8; xx++, r++) {
               const unsigned pix = cp[yy * cf.lw[cl] + xx];

@@ -66,6 +66,8 @@ void *sdvlh_device_ctx(void *d) { return static_cast<Device *>(d)->ctx(); }
 int sdvlh_config_set(const char *key, double value) { return Config::GetInstance().SetParameter(key, value) ? 0 : -1; }
 int sdvlh_config_read(const char *filename) { return Config::GetInstance().ReadParameters(filename) ? 0 : -1; }
 void sdvlh_config_reset() { Config::GetInstance().Reset(); }
+// test hook: the host build of the sin/cos the ORB kernels use (csrc/sdvl_math.h), same IEEE arithmetic as on the device
+void sdvlh_sincos_2pi(double x, double *sn, double *cs) { sincos_2pi(x, sn, cs); }
 
 void *sdvlh_batch_create(void *device, int B, int w, int h, const double *cam4, const double *plane4, const double *first_poses7,
                          int host_threads) {

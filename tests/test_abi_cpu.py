@@ -56,3 +56,39 @@ def test_fast_num_cells_matches_survey(sdvl):
     for (w, h), want in {(640, 480): [300, 80, 20], (752, 480): [360, 96, 24], (1280, 960): [1200, 300, 80]}.items():
         assert lib.sdvl_fast_num_cells(w, h, C.byref(dp), cpl, C.byref(tot)) == 0
         assert [cpl[i] for i in range(3)] == want and tot.value == sum(want)      # SURVEY §8 header
+
+
+def test_orb_sincos_rounds_like_libm():
+    """The ORB kernels take cos/sin of the float orientation angle in double and round to float
+    (extra/orb_detector.cc:361-362).  The device uses csrc/sdvl_math.h `sincos_2pi` (plain IEEE double arithmetic, the
+    same on host and device); its host build must round to the same floats as libm does, on angles all over [0, 2 pi]
+    and hard against the quadrant boundaries."""
+    import math
+    import numpy as np
+    trk = importlib.import_module("slam-sdvl_amd.tracker")
+    lib = trk.load_host_library()
+    fn = lib.sdvlh_sincos_2pi
+    fn.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    fn.restype = None
+    rng = np.random.default_rng(20260400)
+    deg = np.concatenate([rng.uniform(0.0, 360.0, 60000), np.arange(0, 361, dtype=np.float64)]).astype(np.float32)
+    ang = (deg.astype(np.float64) * np.float32(math.pi / np.float32(180.0))).astype(np.float32)   # orb_detector.cc:360
+    near = []
+    for k in range(5):                     # floats either side of k * pi/2
+        c = np.float32(k * math.pi / 2)
+        x = c
+        for _ in range(200):
+            near.append(x)
+            x = np.nextafter(x, np.float32(10.0))
+        x = c
+        for _ in range(200):
+            near.append(x)
+            x = np.nextafter(x, np.float32(-1.0))
+    ang = np.concatenate([ang, np.array([a for a in near if a >= 0], np.float32)])
+    s, c = C.c_double(), C.c_double()
+    worst = 0.0
+    for a in ang.tolist():
+        fn(a, C.byref(s), C.byref(c))
+        assert np.float32(s.value) == np.float32(math.sin(a)) and np.float32(c.value) == np.float32(math.cos(a)), a
+        worst = max(worst, abs(s.value - math.sin(a)), abs(c.value - math.cos(a)))
+    assert worst < 3e-16
