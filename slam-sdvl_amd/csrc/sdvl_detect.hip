@@ -720,6 +720,108 @@ __device__ __forceinline__ int block_retain_best(uint32_t *v, int len, int n_poi
   return new_len;
 }
 
+
+// ---- the same retainBest by a GROUP of G consecutive lanes of one wave (G = 16: four cells per wave; G = 64: one wave for
+// the per-level list).  No s_barrier: the lanes of a wave execute their LDS instructions in order, a fence keeps the
+// compiler from moving them.  Groups of one wave may follow different control flow; inside a group every branch depends
+// on group-uniform values only, so __ballot (active lanes) always carries the whole group.
+__device__ __forceinline__ void sel_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int G>
+__device__ __forceinline__ unsigned long long group_ballot(bool p, int shift) {
+  const unsigned long long b = __ballot(p);
+  if (G == 64) return b;
+  return (b >> shift) & ((1ull << G) - 1ull);
+}
+
+constexpr int kSelGroupMin = 8;  // ranges shorter than this are finished by the group's first lane
+
+// block_two_pointer_partition for a group: left-stoppers ascending in Ls[0..nL), right-stoppers ASCENDING in Rs[0..nR) (the
+// k-th from the right is Rs[nR - 1 - k]); L[k] < R[k] is monotone in k, so K is a count.  Returns K; *cut = where the left
+// scan finally stops (the next original left-stopper or the slot the last swap filled from the left).
+template <int G, typename IDX, typename FL, typename FR>
+__device__ __forceinline__ int group_two_pointer_partition(uint32_t *v, int first, int last, IDX *Ls, IDX *Rs, int sub, int shift, FL is_left,
+                                                           FR is_right, int *out_nR, int *out_cut) {
+  const unsigned long long below = (1ull << sub) - 1ull;
+  int nL = 0, nR = 0;
+  for (int base = first; base < last; base += G) {
+    const int i = base + sub;
+    bool l = false, r = false;
+    if (i < last) {
+      const uint32_t x = v[i];
+      l = is_left(x);
+      r = is_right(x);
+    }
+    const unsigned long long bl = group_ballot<G>(l, shift), br = group_ballot<G>(r, shift);
+    if (l) Ls[nL + __popcll(bl & below)] = static_cast<IDX>(i);
+    if (r) Rs[nR + __popcll(br & below)] = static_cast<IDX>(i);
+    nL += __popcll(bl);
+    nR += __popcll(br);
+  }
+  sel_wave_sync();
+  const int m = min(nL, nR);
+  int K = 0;
+  for (int base = 0; base < m; base += G) {
+    const int k = base + sub;
+    const bool ok = k < m && Ls[k] < Rs[nR - 1 - k];
+    const int c = __popcll(group_ballot<G>(ok, shift));
+    K += c;
+    if (c < min(G, m - base)) break;
+  }
+  int cut = 0x7FFFFFFF;
+  if (K < nL) cut = Ls[K];
+  if (K > 0) cut = min(cut, static_cast<int>(Rs[nR - K]));
+  for (int k = sub; k < K; k += G) {
+    const int a = Ls[k], b = Rs[nR - 1 - k];
+    const uint32_t t = v[a];
+    v[a] = v[b];
+    v[b] = t;
+  }
+  sel_wave_sync();
+  *out_nR = nR;
+  *out_cut = cut;
+  return K;
+}
+
+// cv::KeyPointsFilter::retainBest(v[0..len), n_points) by a group; every lane of the group gets the new length
+template <int G, typename IDX>
+__device__ __forceinline__ int group_retain_best(uint32_t *v, int len, int n_points, IDX *Ls, IDX *Rs, int sub, int shift) {
+  if (!(n_points >= 0 && len > n_points)) return len;
+  if (n_points == 0) return 0;
+  {  // ---- std::nth_element(v, v + n_points, v + len)
+    int first = 0, last = len;
+    const int nth = n_points;
+    int depth_limit = (31 - __clz(len)) * 2;
+    while (last - first > 3 && last - first >= kSelGroupMin && depth_limit > 0) {
+      --depth_limit;
+      if (sub == 0) {
+        const int mid = first + (last - first) / 2;
+        sel_move_median_to_first(v, first, first + 1, mid, last - 1);
+      }
+      sel_wave_sync();
+      const uint32_t pv = v[first] >> 24;
+      int nR, cut;
+      group_two_pointer_partition<G, IDX>(
+          v, first + 1, last, Ls, Rs, sub, shift, [pv](uint32_t x) { return !((x >> 24) > pv); }, [pv](uint32_t x) { return !(pv > (x >> 24)); }, &nR,
+          &cut);
+      if (cut <= nth) first = cut;
+      else last = cut;
+    }
+    if (sub == 0) sel_introselect_from(v, first, nth, last, depth_limit);
+    sel_wave_sync();
+  }
+  // ---- std::partition(v + n_points, v + len, response >= amb)
+  const uint32_t amb = v[n_points - 1] >> 24;
+  int nR, cut;
+  group_two_pointer_partition<G, IDX>(
+      v, n_points, len, Ls, Rs, sub, shift, [amb](uint32_t x) { return !((x >> 24) >= amb); }, [amb](uint32_t x) { return (x >> 24) >= amb; }, &nR, &cut);
+  return n_points + nR;  // the elements that satisfy the predicate end up in front
+}
+
 // one workgroup per (level, frame)
 __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJob *__restrict__ jobs, SelLevels lv) {
   __shared__ uint32_t s_stage[kSelStage];
@@ -728,6 +830,8 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
   __shared__ int s_pre[kSelMaxCells + 1];  // exclusive prefix of the cell counts (level-wide)
   __shared__ int s_wave[kSelWaves];
   __shared__ int s_c1;
+  __shared__ uint8_t s_gl[kSelThreads / 16][SDVL_CELL_KP_CAP], s_gr[kSelThreads / 16][SDVL_CELL_KP_CAP];  // stopper lists of the 16-lane groups
+  static_assert(SDVL_CELL_KP_CAP <= 256, "cell positions are stored in a byte");
   const SelJob &job = jobs[blockIdx.y];
   const int l = blockIdx.x;
   const int tid = threadIdx.x;
@@ -830,10 +934,12 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
       for (int k = (tid & 3); k < cnt; k += 4) s_stage[s_pre[c] - base + k] = src[k];
     }
     __syncthreads();
-    {  // cell (c0 + w + 16*j) goes to lane j of wave w: consecutive cells land in different waves
-      const int w = tid >> 6, j = tid & 63;
-      const int c = c0 + w + kSelWaves * j;
-      if (c < c1) s_newlen[c] = static_cast<uint8_t>(sel_retain_best(&s_stage[s_pre[c] - base], s_cnt[c], s_nsel[c]));
+    {  // 16 lanes per cell, four cells per wave at a time
+      const int gid = tid >> 4, sub = tid & 15, shift = tid & 48;
+      for (int c = c0 + gid; c < c1; c += kSelThreads / 16) {
+        const int nl = group_retain_best<16, uint8_t>(&s_stage[s_pre[c] - base], s_cnt[c], s_nsel[c], s_gl[gid], s_gr[gid], sub, shift);
+        if (sub == 0) s_newlen[c] = static_cast<uint8_t>(nl);
+      }
     }
     __syncthreads();
     int my_len = 0;
@@ -863,7 +969,16 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
   int n = -1;
   if (!overflow) {
     uint16_t *Ls = reinterpret_cast<uint16_t *>(s_stage), *Rs = Ls + kSelFts;
-    n = (nfts > nfeatures) ? block_retain_best(s_fts, nfts, nfeatures, Ls, Rs, s_wave) : nfts;
+    n = nfts;
+    if (nfts > nfeatures) {  // one wave does it (no workgroup barriers inside); the others wait
+      __shared__ int s_final;
+      if (tid < 64) {
+        const int nl = group_retain_best<64, uint16_t>(s_fts, nfts, nfeatures, Ls, Rs, tid, 0);
+        if (tid == 0) s_final = nl;
+      }
+      __syncthreads();
+      n = s_final;
+    }
     n = min(n, SDVL_MAX_CORNERS);
   }
   __syncthreads();
@@ -901,14 +1016,33 @@ __global__ __launch_bounds__(kSelThreads) void retain_best_kernel(uint32_t *v, i
   __shared__ uint32_t s_v[kSelFts];
   __shared__ uint16_t s_l[kSelFts], s_r[kSelFts];
   __shared__ int s_wave[kSelWaves];
-  if (cooperative && len <= kSelFts) {  // the workgroup-cooperative form used for the per-level list
+  if (cooperative == 1 && len <= kSelFts) {  // the workgroup-cooperative form
     for (int i = threadIdx.x; i < len; i += kSelThreads) s_v[i] = v[i];
     __syncthreads();
     const int n = block_retain_best(s_v, len, n_points, s_l, s_r, s_wave);
     __syncthreads();
     for (int i = threadIdx.x; i < len; i += kSelThreads) v[i] = s_v[i];
     if (threadIdx.x == 0) *out_len = n;
-  } else if (threadIdx.x == 0) {        // the one-lane form used per cell
+  } else if (cooperative == 2 && len <= SDVL_CELL_KP_CAP) {  // the 16-lane form used per cell (run by lanes 16..31: shifted ballots)
+    uint8_t *gl = reinterpret_cast<uint8_t *>(s_l), *gr = reinterpret_cast<uint8_t *>(s_r);
+    for (int i = threadIdx.x; i < len; i += kSelThreads) s_v[i] = v[i];
+    __syncthreads();
+    if (threadIdx.x >= 16 && threadIdx.x < 32) {
+      const int n = group_retain_best<16, uint8_t>(s_v, len, n_points, gl, gr, threadIdx.x - 16, 16);
+      if (threadIdx.x == 16) *out_len = n;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += kSelThreads) v[i] = s_v[i];
+  } else if (cooperative == 3 && len <= kSelFts) {            // the one-wave form used for the per-level list
+    for (int i = threadIdx.x; i < len; i += kSelThreads) s_v[i] = v[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int n = group_retain_best<64, uint16_t>(s_v, len, n_points, s_l, s_r, threadIdx.x, 0);
+      if (threadIdx.x == 0) *out_len = n;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += kSelThreads) v[i] = s_v[i];
+  } else if (threadIdx.x == 0) {        // one lane
     *out_len = sel_retain_best(v, len, n_points);
   }
 }

@@ -97,7 +97,7 @@ def test_device_retain_best_is_libstdcxx_order(ctx, orc):
     """the device restatement of nth_element + partition leaves the list exactly as libstdc++ does"""
     rng = np.random.default_rng(42)
     cases = []
-    for n in [1, 2, 3, 4, 5, 7, 16, 33, 64, 169, 500, 1500, 4000]:
+    for n in [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 33, 40, 64, 100, 169, 176, 500, 1500, 4000]:
         for hi in (4, 30, 255):                      # few distinct responses -> many ties; many -> few ties
             sc = rng.integers(1, hi + 1, n).astype(np.uint32)
             xy = np.arange(n, dtype=np.uint32)
@@ -115,6 +115,10 @@ def test_device_retain_best_is_libstdcxx_order(ctx, orc):
         want = orc.retain_best(v, k)
         assert np.array_equal(ctx.retain_best(v, k), want), (len(v), k, "one lane")
         assert np.array_equal(ctx.retain_best(v, k, cooperative=True), want), (len(v), k, "workgroup")
+        if len(v) <= 176:     # a cell's list: 16 lanes of a wave (the form select_corners uses per cell)
+            assert np.array_equal(ctx.retain_best(v, k, cooperative=2), want), (len(v), k, "16 lanes")
+        if len(v) <= 4096:    # a level's list: one wave (the form select_corners uses per level)
+            assert np.array_equal(ctx.retain_best(v, k, cooperative=3), want), (len(v), k, "one wave")
 
 
 @pytest.mark.parametrize("shape,cam,ks", [((480, 640), TUM_CAM, [0, 3, 11]), ((480, 752), EUROC_CAM, [2])])
