@@ -2,10 +2,11 @@
 // FeatureAlign::OptimizePose / RescueOutliers (feature_align.cc:73-82,218-243) around ConvergePose (:341-421) and
 // CheckReprojectionError (:258-283), for a batch of frames.  SURVEY §8(f) "next" row 1.
 //
-//   pose_hypotheses_kernel : one LANE per (frame, RANSAC draw).  The reference evaluates draws one after the other and
-//       adapts the iteration budget as it goes; a draw's result does not depend on earlier draws, so all max_ransac_its
-//       draws are evaluated at once (the lanes of a wave share the frame: every observation load is a broadcast) and the
-//       sequential bookkeeping is replayed afterwards.
+//   pose_hypotheses_kernel : one workgroup per (frame, 128 RANSAC draws).  The reference evaluates draws one after the other
+//       and adapts the iteration budget as it goes; a draw's result does not depend on earlier draws, so all
+//       max_ransac_its draws are evaluated at once and the sequential bookkeeping is replayed afterwards.  Phase 1: one LANE
+//       per draw converges the 5-point pose in registers; phase 2: the (draw, match) pairs of the supporter counts are
+//       dealt to all 512 lanes (integer sums: order-free).
 //   pose_refine_kernel     : one WAVE per frame.  Replays the RANSAC loop over the draw results (iteration budget from a
 //       host-computed table, so no device log()), then inliers / Tukey-weighted Gauss-Newton / rescue / second pass.
 //       Per-observation work (projection, Jacobian, weight, 28 normal-equation terms) is lane-parallel; lanes 0..27 each
@@ -117,40 +118,69 @@ __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, in
   return true;
 }
 
-__global__ __launch_bounds__(64) void pose_hypotheses_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
-                                                             const int32_t *__restrict__ rand_idx, sdvl_pose_params prm,
-                                                             HypResult *__restrict__ hyp) {
+constexpr int kHypDraws = 128;    // draws of one workgroup
+constexpr int kHypThreads = 512;  // 2 waves converge the draws (a lane each), all 8 count the supporters
+
+__global__ __launch_bounds__(kHypThreads) void pose_hypotheses_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+                                                                      const int32_t *__restrict__ rand_idx, sdvl_pose_params prm,
+                                                                      HypResult *__restrict__ hyp) {
+  __shared__ double s_rt[kHypDraws][13];  // R (9) and t (3) of every converged draw (+1 pad)
+  __shared__ int s_ok[kHypDraws], s_sup[kHypDraws];
   const PoseJobDev &job = jobs[blockIdx.y];
-  const int h = blockIdx.x * 64 + threadIdx.x;
-  if (h >= prm.max_ransac_its) return;
-  HypResult r;
-  r.ok = 0;
-  r.supporters = 0;
-  for (int k = 0; k < 7; k++) r.se3[k] = job.pose[k];
+  const int tid = threadIdx.x;
+  const int h0 = blockIdx.x * kHypDraws;
+  const int nd = min(kHypDraws, prm.max_ransac_its - h0);  // draws of this workgroup
   const int size = job.n_obs;
-  if (size > 0) {
-    const sdvl_pose_obs *obs = obs_all + job.obs_begin;
-    const int npoints = min(prm.max_ransac_points, size);
-    int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180) ...
-    if (prm.pad_ & 1) index %= size;           // ... or the raw rand() value when the host could not know `size` yet
-    int sel[8];
-    for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
-    Rigid se3;
-    if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
-      r.ok = 1;
-      se3_to7(se3, r.se3);
-      const M3 R = se3_rot(se3);
-      int sup = 0;
-      for (int q = 0; q < size; q++) {  // CheckReprojectionError over every match: all lanes of the wave read the same obs
-        double ex, ey;
-        V3 pos;
-        reproj_error(obs[q], R, se3.t, &ex, &ey, &pos);
-        if (sqrt(ex * ex + ey * ey) <= prm.inlier_threshold) sup++;
+  const sdvl_pose_obs *obs = obs_all + job.obs_begin;
+  // ---- phase 1: ConvergePose of every draw, one lane each (feature_align.cc:176-197)
+  if (tid < nd) {
+    const int h = h0 + tid;
+    HypResult r;
+    r.ok = 0;
+    r.supporters = 0;
+    for (int k = 0; k < 7; k++) r.se3[k] = job.pose[k];
+    if (size > 0) {
+      const int npoints = min(prm.max_ransac_points, size);
+      int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180) ...
+      if (prm.pad_ & 1) index %= size;           // ... or the raw rand() value when the host could not know `size` yet
+      int sel[8];
+      for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
+      Rigid se3;
+      if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
+        r.ok = 1;
+        se3_to7(se3, r.se3);
+        const M3 R = se3_rot(se3);
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_rt[tid][k] = R.m[k];
+        s_rt[tid][9] = se3.t.x;
+        s_rt[tid][10] = se3.t.y;
+        s_rt[tid][11] = se3.t.z;
       }
-      r.supporters = sup;
     }
+    s_ok[tid] = r.ok;
+    s_sup[tid] = 0;
+    HypResult &dst = hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h];
+    for (int k = 0; k < 7; k++) dst.se3[k] = r.se3[k];
+    dst.ok = r.ok;
   }
-  hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h] = r;
+  __syncthreads();
+  // ---- phase 2: CheckReprojectionError of every draw over every match (feature_align.cc:190, 245-283): the (draw, match)
+  //      pairs are dealt to all lanes of the workgroup; a supporter count is an integer sum, so its order is free
+  const int pairs = nd * size;
+  for (int p = tid; p < pairs; p += kHypThreads) {
+    const int d = p / size, q = p - d * size;
+    if (!s_ok[d]) continue;
+    M3 R;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R.m[k] = s_rt[d][k];
+    const V3 t = {s_rt[d][9], s_rt[d][10], s_rt[d][11]};
+    double ex, ey;
+    V3 pos;
+    reproj_error(obs[q], R, t, &ex, &ey, &pos);
+    if (sqrt(ex * ex + ey * ey) <= prm.inlier_threshold) atomicAdd(&s_sup[d], 1);
+  }
+  __syncthreads();
+  if (tid < nd) hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h0 + tid].supporters = s_sup[tid];
 }
 
 // ---------------------------------------------------------------------------------------------- refinement (wave each)
@@ -404,7 +434,7 @@ size_t sdvl_pose_hyp_bytes() { return sizeof(HypResult); }
 
 int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
                              const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists) {
-  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + 63) / 64, n_jobs), dim3(64), d_jobs, d_obs, d_rand, *p,
+  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypThreads), d_jobs, d_obs, d_rand, *p,
               static_cast<HypResult *>(d_hyp));
   SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel, dim3(n_jobs), dim3(64), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
               d_lists);
