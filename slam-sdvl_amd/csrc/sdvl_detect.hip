@@ -738,7 +738,8 @@ __device__ __forceinline__ unsigned long long group_ballot(bool p, int shift) {
   return (b >> shift) & ((1ull << G) - 1ull);
 }
 
-constexpr int kSelGroupMin = 8;  // ranges shorter than this are finished by the group's first lane
+constexpr int kSelGroupMin = 4;  // ranges shorter than this are finished by the group's first lane (>= 4: the median-of-3 positions must differ)
+constexpr int kSelGroup = 8;     // lanes that share a cell's retainBest in select_corners_kernel
 
 // block_two_pointer_partition for a group: left-stoppers ascending in Ls[0..nL), right-stoppers ASCENDING in Rs[0..nR) (the
 // k-th from the right is Rs[nR - 1 - k]); L[k] < R[k] is monotone in k, so K is a count.  Returns K; *cut = where the left
@@ -765,10 +766,16 @@ __device__ __forceinline__ int group_two_pointer_partition(uint32_t *v, int firs
   sel_wave_sync();
   const int m = min(nL, nR);
   int K = 0;
+  int a0 = 0, b0 = 0;  // the lane's pair of the first chunk stays in registers for the swap
   for (int base = 0; base < m; base += G) {
     const int k = base + sub;
-    const bool ok = k < m && Ls[k] < Rs[nR - 1 - k];
-    const int c = __popcll(group_ballot<G>(ok, shift));
+    int a = 0, b = 0;
+    if (k < m) {
+      a = Ls[k];
+      b = Rs[nR - 1 - k];
+    }
+    if (base == 0) { a0 = a; b0 = b; }
+    const int c = __popcll(group_ballot<G>(k < m && a < b, shift));
     K += c;
     if (c < min(G, m - base)) break;
   }
@@ -776,7 +783,7 @@ __device__ __forceinline__ int group_two_pointer_partition(uint32_t *v, int firs
   if (K < nL) cut = Ls[K];
   if (K > 0) cut = min(cut, static_cast<int>(Rs[nR - K]));
   for (int k = sub; k < K; k += G) {
-    const int a = Ls[k], b = Rs[nR - 1 - k];
+    const int a = (k == sub) ? a0 : static_cast<int>(Ls[k]), b = (k == sub) ? b0 : static_cast<int>(Rs[nR - 1 - k]);
     const uint32_t t = v[a];
     v[a] = v[b];
     v[b] = t;
@@ -798,12 +805,21 @@ __device__ __forceinline__ int group_retain_best(uint32_t *v, int len, int n_poi
     int depth_limit = (31 - __clz(len)) * 2;
     while (last - first > 3 && last - first >= kSelGroupMin && depth_limit > 0) {
       --depth_limit;
+      // __move_median_to_first(first, first + 1, mid, last - 1): every lane reads the four values at once and decides; the
+      // group's first lane stores the exchange (the range holds >= kSelGroupMin elements: the four positions differ)
+      const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+      const uint32_t vf = v[first], va = v[ia], vb = v[ib], vc = v[ic];
+      int pick;
+      if (kp_gt(va, vb)) pick = kp_gt(vb, vc) ? ib : (kp_gt(va, vc) ? ic : ia);
+      else pick = kp_gt(va, vc) ? ia : (kp_gt(vb, vc) ? ic : ib);
+      const uint32_t vp = pick == ia ? va : (pick == ib ? vb : vc);
+      sel_wave_sync();  // all lanes have read before the exchange is stored
       if (sub == 0) {
-        const int mid = first + (last - first) / 2;
-        sel_move_median_to_first(v, first, first + 1, mid, last - 1);
+        v[first] = vp;
+        v[pick] = vf;
       }
       sel_wave_sync();
-      const uint32_t pv = v[first] >> 24;
+      const uint32_t pv = vp >> 24;
       int nR, cut;
       group_two_pointer_partition<G, IDX>(
           v, first + 1, last, Ls, Rs, sub, shift, [pv](uint32_t x) { return !((x >> 24) > pv); }, [pv](uint32_t x) { return !(pv > (x >> 24)); }, &nR,
@@ -830,7 +846,7 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
   __shared__ int s_pre[kSelMaxCells + 1];  // exclusive prefix of the cell counts (level-wide)
   __shared__ int s_wave[kSelWaves];
   __shared__ int s_c1;
-  __shared__ uint8_t s_gl[kSelThreads / 16][SDVL_CELL_KP_CAP], s_gr[kSelThreads / 16][SDVL_CELL_KP_CAP];  // stopper lists of the 16-lane groups
+  __shared__ uint8_t s_glr[2 * kSelStage];  // stopper lists of the lane groups: 2 x count bytes per staged cell
   static_assert(SDVL_CELL_KP_CAP <= 256, "cell positions are stored in a byte");
   const SelJob &job = jobs[blockIdx.y];
   const int l = blockIdx.x;
@@ -934,10 +950,11 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
       for (int k = (tid & 3); k < cnt; k += 4) s_stage[s_pre[c] - base + k] = src[k];
     }
     __syncthreads();
-    {  // 16 lanes per cell, four cells per wave at a time
-      const int gid = tid >> 4, sub = tid & 15, shift = tid & 48;
-      for (int c = c0 + gid; c < c1; c += kSelThreads / 16) {
-        const int nl = group_retain_best<16, uint8_t>(&s_stage[s_pre[c] - base], s_cnt[c], s_nsel[c], s_gl[gid], s_gr[gid], sub, shift);
+    {  // kSelGroup lanes per cell, 64 / kSelGroup cells per wave at a time
+      const int gid = tid / kSelGroup, sub = tid % kSelGroup, shift = (tid & 63) - sub;
+      for (int c = c0 + gid; c < c1; c += kSelThreads / kSelGroup) {
+        uint8_t *Ls = &s_glr[2 * (s_pre[c] - base)];
+        const int nl = group_retain_best<kSelGroup, uint8_t>(&s_stage[s_pre[c] - base], s_cnt[c], s_nsel[c], Ls, Ls + s_cnt[c], sub, shift);
         if (sub == 0) s_newlen[c] = static_cast<uint8_t>(nl);
       }
     }
@@ -1023,13 +1040,13 @@ __global__ __launch_bounds__(kSelThreads) void retain_best_kernel(uint32_t *v, i
     __syncthreads();
     for (int i = threadIdx.x; i < len; i += kSelThreads) v[i] = s_v[i];
     if (threadIdx.x == 0) *out_len = n;
-  } else if (cooperative == 2 && len <= SDVL_CELL_KP_CAP) {  // the 16-lane form used per cell (run by lanes 16..31: shifted ballots)
+  } else if (cooperative == 2 && len <= SDVL_CELL_KP_CAP) {  // the lane-group form used per cell (run by the wave's second group: shifted ballots)
     uint8_t *gl = reinterpret_cast<uint8_t *>(s_l), *gr = reinterpret_cast<uint8_t *>(s_r);
     for (int i = threadIdx.x; i < len; i += kSelThreads) s_v[i] = v[i];
     __syncthreads();
-    if (threadIdx.x >= 16 && threadIdx.x < 32) {
-      const int n = group_retain_best<16, uint8_t>(s_v, len, n_points, gl, gr, threadIdx.x - 16, 16);
-      if (threadIdx.x == 16) *out_len = n;
+    if (threadIdx.x >= kSelGroup && threadIdx.x < 2 * kSelGroup) {
+      const int n = group_retain_best<kSelGroup, uint8_t>(s_v, len, n_points, gl, gr, threadIdx.x - kSelGroup, kSelGroup);
+      if (threadIdx.x == kSelGroup) *out_len = n;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < len; i += kSelThreads) v[i] = s_v[i];
