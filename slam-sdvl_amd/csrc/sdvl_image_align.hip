@@ -42,6 +42,33 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 
 // Halving butterfly: on return the even lane 2j (and its odd partner) holds the wave-wide sum of value index
 // idx(2j) = lane bits (5,4,3,2,1) read as a 5-bit number.  32 values in, 32 DP shuffles.
+// The same for 8 values (10 DP shuffles): on return every lane holds the wave-wide sum of value index (lane >> 3) & 7.
+__device__ __forceinline__ double wave_reduce8(const double *v8, int lane) {
+  double v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = v8[i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool up = lane & 32;
+    const double keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+    v[i] = keep + shfl_xor_f64(send, 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const bool up = lane & 16;
+    const double keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+    v[i] = keep + shfl_xor_f64(send, 16);
+  }
+  {
+    const bool up = lane & 8;
+    const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = keep + shfl_xor_f64(send, 8);
+  }
+  v[0] += shfl_xor_f64(v[0], 4);
+  v[0] += shfl_xor_f64(v[0], 2);
+  return v[0] + shfl_xor_f64(v[0], 1);
+}
+
 __device__ __forceinline__ double wave_reduce32(double *v, int lane) {
 #pragma unroll
   for (int i = 0; i < 16; i++) {
@@ -308,9 +335,11 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
   int *s_ui = reinterpret_cast<int *>(s_item + static_cast<size_t>(max_f) * 16);
   int *s_vi = s_ui + max_f;
   float *s_w = reinterpret_cast<float *>(s_vi + max_f);                   // [4][max_f]
-  uint8_t *s_ok = reinterpret_cast<uint8_t *>(s_w + static_cast<size_t>(4) * max_f);
+  double *s_fpos = reinterpret_cast<double *>(s_w + static_cast<size_t>(4) * max_f);  // [max_f][5]: px, py, and f * depth (3)
+  uint8_t *s_ok = reinterpret_cast<uint8_t *>(s_fpos + static_cast<size_t>(5) * max_f);
   uint8_t *s_okprev = s_ok + max_f;
   uint8_t *s_vis = s_okprev + max_f;
+  uint8_t *s_valid = s_vis + max_f;
   __shared__ double s_red[kWaves][32];
   __shared__ double s_sum[32];
   __shared__ double s_H[21];
@@ -329,7 +358,18 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
   int n_meas = 0, iters_run = 0;
   int its0 = 0, its1 = 0, its2 = 0, its3 = 0, its4 = 0, its5 = 0, its6 = 0, its7 = 0;
 
-  for (int f = tid; f < nf; f += kThreads) s_vis[f] = 0;
+  // the feature records are read once: every level's PrecomputePatches and every iteration's projection use the LDS copy
+  for (int f = tid; f < nf; f += kThreads) {
+    const sdvl_align_feature ft = F[f];
+    const V3 xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+    s_fpos[f * 5 + 0] = ft.px;
+    s_fpos[f * 5 + 1] = ft.py;
+    s_fpos[f * 5 + 2] = xyz.x;
+    s_fpos[f * 5 + 3] = xyz.y;
+    s_fpos[f * 5 + 4] = xyz.z;
+    s_valid[f] = ft.valid ? 1 : 0;
+    s_vis[f] = 0;
+  }
   if (tid == 0) {
     T = se3_from7(job.T);
     se3_to7(T, s_T);
@@ -356,15 +396,14 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
         // ---- PrecomputePatches(level), image_align.cc:208-267
         for (int idx = tid; idx < n_items; idx += kThreads) {
           const int f = idx >> 4, p = idx & 15;
-          const sdvl_align_feature ft = F[f];
-          const float u_ref = static_cast<float>(ft.px * scale);
-          const float v_ref = static_cast<float>(ft.py * scale);
+          const float u_ref = static_cast<float>(s_fpos[f * 5 + 0] * scale);
+          const float v_ref = static_cast<float>(s_fpos[f * 5 + 1] * scale);
           const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
           const int border = 3;
-          if (!ft.valid || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) continue;
+          if (!s_valid[f] || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) continue;
           if (p == 0) {
             s_vis[f] = 1;
-            const V3 xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+            const V3 xyz = {s_fpos[f * 5 + 2], s_fpos[f * 5 + 3], s_fpos[f * 5 + 4]};
             double fj[12];
             jacobian_3d_to_plane(xyz, fj);
 #pragma unroll
@@ -394,8 +433,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
       for (int f = tid; f < nf; f += kThreads) {
         uint8_t ok = 0;
         if (s_vis[f]) {
-          const sdvl_align_feature ft = F[f];
-          const V3 xr = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+          const V3 xr = {s_fpos[f * 5 + 2], s_fpos[f * 5 + 3], s_fpos[f * 5 + 4]};
           const V3 xc = {s_R[0] * xr.x + s_R[1] * xr.y + s_R[2] * xr.z + s_T[4], s_R[3] * xr.x + s_R[4] * xr.y + s_R[5] * xr.z + s_T[5],
                          s_R[6] * xr.x + s_R[7] * xr.y + s_R[8] * xr.z + s_T[6]};
           const V2 pr = cam_project(cam, xc);
@@ -448,11 +486,16 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
         acc[27] += static_cast<double>(res * res);
         acc[28] += 1.0;
       }
-      const double tot = wave_reduce32(acc, lane);
-      if ((lane & 1) == 0) {
-        const int vidx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) |
-                         ((lane >> 1) & 1);
-        s_red[wave][vidx] = tot;
+      if (rebuild_h) {
+        const double tot = wave_reduce32(acc, lane);
+        if ((lane & 1) == 0) {
+          const int vidx = (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) |
+                           ((lane >> 1) & 1);
+          s_red[wave][vidx] = tot;
+        }
+      } else {  // H is reused: only Jres, chi2 and the count (values 21..28) are new
+        const double tot = wave_reduce8(acc + 21, lane);
+        if ((lane & 7) == 0) s_red[wave][21 + ((lane >> 3) & 7)] = tot;
       }
       __syncthreads();
       if (tid < 32) {
@@ -537,7 +580,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
 }
 
 size_t ia_lds_bytes(int max_f) {
-  return static_cast<size_t>(max_f) * (12 * sizeof(double) + 16 * sizeof(IaItem) + 2 * sizeof(int) + 4 * sizeof(float) + 3) + 64;
+  return static_cast<size_t>(max_f) * (12 * sizeof(double) + 16 * sizeof(IaItem) + 2 * sizeof(int) + 4 * sizeof(float) + 5 * sizeof(double) + 4) + 64;
 }
 
 }  // namespace
