@@ -342,7 +342,8 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
   uint8_t *s_valid = s_vis + max_f;
   __shared__ double s_red[kWaves][32];
   __shared__ double s_sum[32];
-  __shared__ double s_H[21];
+  __shared__ double s_H[21], s_L[36];
+  __shared__ int s_tr[6];
   __shared__ double s_T[7], s_R[9];
   __shared__ int s_break, s_abort, s_changed;
 
@@ -529,7 +530,23 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
         iters_run++;
         const double new_chi2 = static_cast<double>(static_cast<float>(s_sum[27]) / static_cast<float>(n_meas));
         if (n_meas == 0) stop = true;
-        ldlt_solve6_reg<true>(Hm, Jres, xs);
+        {  // H is the same for as long as the contributing set stays the same: so is its factorisation (kept in LDS)
+          double La[36];
+          int tr[6];
+          if (rebuild_h) {
+            ldlt_factor6_reg<true>(Hm, La, tr);
+#pragma unroll
+            for (int q = 0; q < 36; q++) s_L[q] = La[q];
+#pragma unroll
+            for (int q = 0; q < 6; q++) s_tr[q] = tr[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 36; q++) La[q] = s_L[q];
+#pragma unroll
+            for (int q = 0; q < 6; q++) tr[q] = s_tr[q];
+          }
+          ldlt_apply6_reg(La, tr, Jres, xs);
+        }
         if (xs[0] != xs[0]) stop = true;
         int brk = 0;
         if ((it > 0 && new_chi2 > chi2) || stop) {

@@ -314,10 +314,11 @@ SDVL_HD void ldlt_solve6(const double *Ain, const double *bin, double *x) {
 // ldlt_solve6 (sdvl_math.h) with compile-time indices only: swaps become predicated moves, so everything stays in registers
 // kUniform: every active lane of the wave solves the SAME system (or only one lane is active): the pivot index is then
 // made a scalar, the swap blocks become scalar branches and only the one that applies is executed.
+// Two halves, so that a caller that solves several right-hand sides with ONE matrix factorises once:
+// ldlt_factor6_reg leaves the factor (unit lower triangle + D on the diagonal) in a[36] and the transpositions in tr[6],
+// ldlt_apply6_reg solves with them.  ldlt_solve6_reg = factor + apply, operation for operation as before.
 template <bool kUniform = false>
-SDVL_HD void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
-  double a[36];
-  int tr[6];
+SDVL_HD void ldlt_factor6_reg(const double *Ain, double *a, int *tr) {
 #pragma unroll
   for (int i = 0; i < 36; i++) a[i] = Ain[i];
   bool alive = true;  // false once the k == 0 pivot is exactly zero (all-zero diagonal): nothing more to do
@@ -375,6 +376,9 @@ SDVL_HD void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
       }
     }
   }
+}
+
+SDVL_HD void ldlt_apply6_reg(const double *a, const int *tr, const double *bin, double *x) {
   double d[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) d[i] = bin[i];
@@ -412,6 +416,14 @@ SDVL_HD void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) x[i] = d[i];
+}
+
+template <bool kUniform = false>
+SDVL_HD void ldlt_solve6_reg(const double *Ain, const double *bin, double *x) {
+  double a[36];
+  int tr[6];
+  ldlt_factor6_reg<kUniform>(Ain, a, tr);
+  ldlt_apply6_reg(a, tr, bin, x);
 }
 #endif  // __HIPCC__
 
