@@ -284,17 +284,18 @@ __global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev 
     for (int i = 1; i <= slevel; i++) range *= 1.2;
     out.range = range;
     out.range2 = range * range;
-    // epipolar line constants (matcher.cc:139-148)
-    double ex = pxa.x - pxb.x, ey = pxa.y - pxb.y;
-    const double en = sqrt(ex * ex + ey * ey);
-    ex /= en;
-    ey /= en;
-    out.nx = ey;
-    out.ny = -ex;
-    out.normdist = pxa.x * out.nx + pxa.y * out.ny;
-    out.xdiff = pxb.x - pxa.x;
-    out.ydiff = pxb.y - pxa.y;
-    out.vline = (out.xdiff) * (out.xdiff) + (out.ydiff) * (out.ydiff);
+    if (!rq.fixed) {  // epipolar line constants (matcher.cc:139-148); a fixed search tests a circle around px0 only
+      double ex = pxa.x - pxb.x, ey = pxa.y - pxb.y;
+      const double en = sqrt(ex * ex + ey * ey);
+      ex /= en;
+      ey /= en;
+      out.nx = ey;
+      out.ny = -ex;
+      out.normdist = pxa.x * out.nx + pxa.y * out.ny;
+      out.xdiff = pxb.x - pxa.x;
+      out.ydiff = pxb.y - pxa.y;
+      out.vline = (out.xdiff) * (out.xdiff) + (out.ydiff) * (out.ydiff);
+    }
   }
   prep[ri] = out;
 }
