@@ -309,7 +309,7 @@ def main():
     farm.run(ptrs[:1 + Wm], workers)          # bootstrap + warmup (untimed)
     farm.stage_times(reset=True)
     for c in ctxs:
-        c.timing(True)
+        c.timing(not os.environ.get("SDVL_BENCH_NO_KERNEL_TIMING"))
     stats_buf = farm.alloc_stats(K)
     import resource
     def throttled():

@@ -503,6 +503,29 @@ def test_pose_from_matches_equals_oracle(ctx, orc, sizes):
     assert len(got[0]["outliers"]) >= 10 and len(got[0]["inliers"]) >= 90
 
 
+def test_pose_from_matches_many_draws(ctx, orc):
+    """max_ransac_its above one workgroup's 128 draws and not a multiple of it (300 = 128 + 128 + 44), with enough gross
+    outliers that the adaptive budget keeps drawing"""
+    cam = TUM_CAM
+    old = orc.params.max_ransac_its
+    orc.params.max_ransac_its = 300
+    try:
+        jobs, wants = [], []
+        for j, (n, frac) in enumerate([(180, 0.55), (90, 0.7), (40, 0.3)]):
+            obs, guess = make_matches(orc, n, seed=200 + j, outlier_frac=frac)
+            draws = orc.rand_stream(300, seed=5)
+            jobs.append((obs, guess, draws))
+            wants.append(orc.pose_from_matches(cam, obs, guess, rand_seed=5))
+        got = ctx.pose_from_matches(jobs, fx=cam[0], max_ransac_its=300)
+    finally:
+        orc.params.max_ransac_its = old
+    for j, (g, w) in enumerate(zip(got, wants)):
+        assert g["n_draws"] == w["n_draws"], j
+        assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["outliers"], w["outliers"]), j
+        assert np.abs(g["pose"] - w["pose"]).max() <= 1e-9, j
+    assert max(w["n_draws"] for w in wants) > 128   # the later workgroups' draws are really consumed
+
+
 def test_pose_from_matches_degenerate_inputs(ctx, orc):
     """all matches identical / all outliers / more matches than the device path takes"""
     cam = TUM_CAM
