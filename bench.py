@@ -10,7 +10,8 @@ max 200 matches).  All input frames are rendered into HBM before the timed regio
 
 Sequences shard across ranks with no data-path collective ("weak" scaling: B sequences per GPU); RCCL is used only
 for the barrier and the throughput reduction.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events
-on the kernel's own stream over the timed region) and `cpu_baseline` (the CPU oracle on one host core, bounded sample).
+on the kernel's own stream over the timed region) and `cpu_baseline` (the CPU oracle on one host core and on all usable host cores,
+bounded sample; N = 1 only).
 """
 import argparse
 import ctypes as C
@@ -288,7 +289,7 @@ def main():
     # it also keeps the timed region away from the start-up activity of the container (measured: the first seconds of a
     # fresh box cost the 16 host threads up to 40 % of their CPU share)
     cpu = None
-    if rank == 0 and args.cpu_frames > 0:
+    if rank == 0 and world == 1 and args.cpu_frames > 0:   # at N = 1 only: with more ranks the host cores belong to their farms
         n_cpu = args.cpu_frames
         cbuf = ctx.malloc(n_cpu * frame_bytes)
         views = [make_view(pkg, se3_exp(shard.sequence_twist(0) * k), shard.sequence_seed(0), k) for k in range(n_cpu)]
