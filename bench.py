@@ -31,6 +31,15 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 W_IMG, H_IMG = 640, 480
 TUM_CAM = np.array([517.3, 516.5, 318.6, 255.3])
+FEATS_LABEL = "~200 feats"
+ORACLE_PARAMS = {}      # fields of the oracle's parameter block that differ from its defaults (workload S-C)
+# S-A is the metric configuration; S-C (1280x960, num_features 4000, max_matches 1000, 64 sequences per GPU)
+# is BASELINE.json's roofline case, run with `--workload S-C`
+WORKLOADS = {
+    "S-A": dict(w=640, h=480, cam=[517.3, 516.5, 318.6, 255.3], seqs=1024, over={}, label="~200 feats", cpu_frames=300),
+    "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=64, label="~1000 feats", cpu_frames=60,
+                over={"SDVL.num_features": 4000, "SDVL.max_matches": 1000}),
+}
 XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])
 
 
@@ -175,6 +184,8 @@ def cpu_baseline(frames, mapper=False, threads=1):
     import threading
     import oraclelib as ol
     orc = ol.Oracle()
+    for k, v in ORACLE_PARAMS.items():
+        setattr(orc.params, k, v)
     out = [None] * threads
 
     def run(i):
@@ -210,7 +221,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "1024")), help="independent sequences per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S-A", help="S-A: the metric configuration (640x480); S-C: 1280x960, 4000 features")
+    ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "0")), help="independent sequences per GPU (0 = the workload's)")
     ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
     ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")
     ap.add_argument("--workers", type=int, default=0, help="host threads that execute group-steps (0 = auto)")
@@ -218,8 +230,16 @@ def main():
                     help="group-steps a worker thread interleaves, switching at GPU waits (1 = one at a time)")
     ap.add_argument("--mapper", action="store_true",
                     help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
-    ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip, -1 = the workload's)")
     args = ap.parse_args()
+    global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS
+    wl = WORKLOADS[args.workload]
+    W_IMG, H_IMG, TUM_CAM, FEATS_LABEL = wl["w"], wl["h"], np.array(wl["cam"]), wl["label"]
+    ORACLE_PARAMS = {k.split(".")[1]: v for k, v in wl["over"].items()}
+    if args.seqs <= 0:
+        args.seqs = wl["seqs"]
+    if args.cpu_frames < 0:
+        args.cpu_frames = wl["cpu_frames"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -238,7 +258,7 @@ def main():
     trk = importlib.import_module("slam-sdvl_amd.tracker")
     shard = importlib.import_module("slam-sdvl_amd.shard")
     numa_node = None if os.environ.get("SDVL_NO_NUMA_BIND") else trk.bind_to_gpu_numa_node(local_rank)
-    trk.configure()
+    trk.configure(dict(trk.TUM_OVERRIDES, **wl["over"]))
     ncpu = effective_cpus()
     B, K, Wm = args.seqs, args.steps, args.warmup
     # one group = one HIP stream + one host-side step at a time; workers = host threads.  With a full CPU share (16 per
@@ -375,15 +395,15 @@ def main():
                 bytes_per_launch = per_frame * frames_per_step / launches_per_step
                 achieved = bytes_per_launch / avg_s / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes(name, frames_per_step / launches_per_step),
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes(name, frames_per_step / launches_per_step) if args.workload == "S-A" else None,  # the PMC passes were taken on S-A
                             "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch)}
         value = tracked_all / elapsed_max
         out = {
-            "metric": "tracked frames/sec (640x480, 5-lvl pyr, ~200 feats)", "value": round(value, 2), "unit": "frames/s",
+            "metric": "tracked frames/sec (%dx%d, 5-lvl pyr, %s)" % (W_IMG, H_IMG, FEATS_LABEL), "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed_max / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
-            "config": {"workload": "S-A: synthetic TUM fr1-like 640x480 mono, textured plane z=2m, %d independent sequences per GPU, "
-                                   "one tracked frame per sequence per step%s" % (B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
+            "config": {"workload": "%s: synthetic TUM fr1-like %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
+                                   "one tracked frame per sequence per step%s" % (args.workload, W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "numa_node": numa_node, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),

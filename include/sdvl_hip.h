@@ -33,7 +33,7 @@ enum sdvl_status {
 };
 
 #define SDVL_MAX_LEVELS 8
-#define SDVL_MAX_CORNERS 4096        /* per frame; first frame detects 2*NumFeatures (sdvl.cc:135) */
+#define SDVL_MAX_CORNERS 6144        /* per frame: num_features plus the ties retainBest keeps (config C: 4000 + ~2 %) */
 #define SDVL_MAX_ALIGN_FEATURES 2048 /* features per image-alignment job */
 #define SDVL_CELL_KP_CAP 176         /* a 32x32 ROI holds at most 13*13 = 169 NMS-surviving corners */
 

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(CSRC, "libsdvl_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "host", "libsdvl_host.so")
 
 MAX_LEVELS = 8
-MAX_CORNERS = 4096
+MAX_CORNERS = 6144
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int32)
@@ -166,7 +166,7 @@ class Frame:
         self.ctx._check(self.ctx.lib.sdvl_frame_set_corners(self.ctx.h, self.h, len(xyl), _ptr(xyl, i32p)))
         return self
 
-    def descriptors(self, cap=4096):
+    def descriptors(self, cap=MAX_CORNERS):
         """host mirror of the frame's ORB descriptors, [n_corners][32] (computed now if they have not been)"""
         out = np.zeros((cap, 32), np.uint8)
         n = (C.c_int32 * 1)()

@@ -27,6 +27,8 @@ namespace {
 using namespace sdvl;
 
 constexpr int kWavesPerBlock = 4;  // requests of one workgroup; they all search the SAME current frame (block table)
+constexpr int kLdsCorners = 4096;  // corners of the current frame staged in LDS (16 KB: 8 workgroups per CU); a frame with
+                                   // more (up to SDVL_MAX_CORNERS) has the rest read from HBM / L2
 
 struct SearchBlock {
   int first, count;  // requests [first, first + count) of the launch, count <= kWavesPerBlock
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   __shared__ WaveLds s_lds[kWavesPerBlock];
   // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
-  __shared__ uint32_t s_corners[SDVL_MAX_CORNERS];
+  __shared__ uint32_t s_corners[kLdsCorners];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // wave-uniform: request, prep and frame-table loads become scalar loads
   // Workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is padded to a multiple of 8).  XCD x takes the x-th
   // eighth of the block table: blocks are ordered by current frame, so one frame's corner list, search-level image and
@@ -320,11 +322,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   const SearchBlock blk = blocks[bi];
   const SearchFramePose &tcur = table[reqs[blk.first].cur];
   const int n_corners = min(tcur.f.n_ptr[0], SDVL_MAX_CORNERS);
-  for (int ci = threadIdx.x; ci < n_corners; ci += 64 * kWavesPerBlock) {
-    const int4 c = reinterpret_cast<const int4 *>(tcur.f.corners)[ci];
-    s_corners[ci] = static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24);
-  }
+  const int4 *corners_g = reinterpret_cast<const int4 *>(tcur.f.corners);
+  const auto pack_corner = [](const int4 c) {
+    return static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24);
+  };
+  for (int ci = threadIdx.x; ci < min(n_corners, kLdsCorners); ci += 64 * kWavesPerBlock) s_corners[ci] = pack_corner(corners_g[ci]);
   __syncthreads();
+  const auto corner_at = [&](int ci) { return ci < kLdsCorners ? s_corners[ci] : pack_corner(corners_g[ci]); };
   if (wv >= blk.count) return;
   const int ri = blk.first + wv;
   WaveLds &L = s_lds[wv];
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
       bool inr = ci < n_corners;
       int cx = 0, cy = 0, cl = 0;
       if (inr) {
-        const uint32_t pk = s_corners[ci];
+        const uint32_t pk = corner_at(ci);
         cx = static_cast<int>(pk & 0xFFFu);
         cy = static_cast<int>((pk >> 12) & 0xFFFu);
         cl = static_cast<int>(pk >> 24);
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         while (m) {
           const int j = __ffsll(static_cast<long long>(m)) - 1;
           m &= m - 1;
-          const uint32_t pj = s_corners[c0 + j];
+          const uint32_t pj = corner_at(c0 + j);
           const int jx = static_cast<int>(pj & 0xFFFu), jy = static_cast<int>((pj >> 12) & 0xFFFu), jl = static_cast<int>(pj >> 24);
           const int Wj = cf.lw[jl], Hj = cf.lh[jl];
           uint32_t nib = 0;  // outside ORBDetector::IsInsideLimits the descriptor is all zeros (sdvl_orb.hip)
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     return;
   }
   res.best_corner = best_ci;
-  const uint32_t bpk = s_corners[best_ci];
+  const uint32_t bpk = corner_at(best_ci);
   const int bx = static_cast<int>(bpk & 0xFFFu), by = static_cast<int>((bpk >> 12) & 0xFFFu), bl = static_cast<int>(bpk >> 24);
   const double mpx = static_cast<double>(bx * (1 << bl)), mpy = static_cast<double>(by * (1 << bl));
   res.px[0] = mpx;

@@ -291,6 +291,34 @@ def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur
     f_ref.close(); f_cur.close()
 
 
+def test_search_points_frame_with_more_corners_than_the_lds_stage(ctx, sdvl, orc, synth):
+    """1280x960 with num_features 4600: the current frame holds more corners than search_points stages in LDS (4096), the
+    rest (coarse-level corners at the end of the list) are read from HBM — found flags, levels and offsets as the oracle's"""
+    cam4 = np.array(TUM_CAM) * 2.0
+    old = orc.params.num_features
+    orc.params.num_features = 4600
+    try:
+        img_ref, img_cur = frames_of(synth, orc, cam4, 1280, 960, [0, 3])
+        T_ref, T_cur = trajectory_pose(orc, 0), trajectory_pose(orc, 3)
+        reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, cam4, 400, 21, True, 0.0, False)
+    finally:
+        orc.params.num_features = old
+    assert 4096 < len(ccur) <= 6144
+    cam = sdvl.Camera(1280, 960, *cam4)
+    res = ctx.search_points(reqs, cam, sdvl.default_search_params())
+    beyond = 0
+    for r, m in zip(res, meta):
+        want = orc.search_point(img_ref, img_cur, cam4, T_ref, T_cur, m["px"], m["bearing"], m["level"], m["desc"],
+                                m["idepth"], m["istd"], True, ccur, m["px0"])
+        assert r.found == want["found"]
+        if want["found"]:
+            assert r.level == want["level"] and np.array_equal(np.array(r.px[:]), want["px"])
+        if r.best_corner >= 4096:
+            beyond += 1
+    assert beyond >= 5          # matches among the corners that live outside the LDS stage
+    f_ref.close(); f_cur.close()
+
+
 def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth):
     """sdvl_search_run_chain / _chain_end against the separate calls: the same search results, the matches the host replay of
     SelectPoints (first hit per cell, at most max_matches) picks, and bit-identical pose results from them"""
@@ -388,7 +416,7 @@ def test_errors_are_reported_not_swallowed(ctx, sdvl):
     with pytest.raises(sdvl.SdvlError):
         f.set_corners([[700, 10, 0]])                        # outside the level image
     with pytest.raises(sdvl.SdvlError):
-        f.set_corners(np.zeros((5000, 3), np.int32))         # capacity
+        f.set_corners(np.zeros((sdvl.MAX_CORNERS + 1, 3), np.int32))   # capacity
     f.close()
 
 
@@ -446,7 +474,7 @@ def test_detect_corners_config_c_size(ctx, sdvl, orc):
     img = (img.astype(np.float32) * 0.25 + 96).astype(np.uint8)      # lower contrast: fewer, less tied corners
     f = ctx.frame(img)
     got = ctx.detect_corners([f], sdvl.default_detect_params(), 4000)[0]
-    assert len(got) <= 4096
+    assert len(got) <= 6144
     want = orc.detect_pyramid(img, nfeatures=4000)
     assert np.array_equal(got, want)
     f.close()
