@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
 }
 
 // one workgroup per frame: level segments -> corners_ (fast_detector.cc:171-174 concatenates levels in order)
-__global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restrict__ jobs, int n_levels, int32_t *__restrict__ batch_counts) {
+__global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restrict__ jobs, int n_levels, int32_t *__restrict__ batch_counts,
+                                                           int32_t *__restrict__ host_counts) {
   const SelJob &job = jobs[blockIdx.x];
   int off = 0;
   bool bad = false;
@@ -1025,6 +1026,7 @@ __global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restr
     job.corner_hdr[0] = total < 0 ? 0 : total;
     job.corner_hdr[1] = total;
     if (batch_counts) batch_counts[blockIdx.x] = total;
+    if (host_counts) host_counts[blockIdx.x] = total;
   }
 }
 
@@ -1282,12 +1284,16 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   const SelJob *ds = reinterpret_cast<const SelJob *>(static_cast<uint8_t *>(dst) + fj_bytes);
   SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv);
   SDVL_LAUNCH(ctx, "select_corners", select_corners_kernel, dim3(lv.n_levels, n), dim3(kSelThreads), ds, sl);
-  SDVL_LAUNCH(ctx, "pack_corners", pack_corners_kernel, dim3(n), dim3(256), ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts));
+  // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
+  // writes them into device memory and, when results go direct, into the pinned host array as well
+  const bool direct = sdvl_direct_results() && sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK;
+  SDVL_LAUNCH(ctx, "pack_corners", pack_corners_kernel, dim3(n), dim3(256), ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts),
+              direct ? static_cast<int32_t *>(ctx->h_counts) : nullptr);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
-  // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts)
   ctx->counts_gen = ~0ull;
-  if (sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK &&
-      hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess)
+  if (direct) ctx->counts_gen = ctx->wait_gen;
+  else if (sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK &&
+           hipMemcpyAsync(ctx->h_counts, ctx->d_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess)
     ctx->counts_gen = ctx->wait_gen;
   return SDVL_OK;
 }

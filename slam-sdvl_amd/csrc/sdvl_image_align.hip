@@ -664,6 +664,7 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, job_bytes + feat_bytes, hipMemcpyHostToDevice, ctx->stream));
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   const bool use_lds = max_nf <= kLdsMaxF && !getenv("SDVL_IMAGE_ALIGN_GENERIC");
+  const bool direct = sdvl_direct_results();
   if (use_lds) {
     const int max_f = (max_nf + 7) / 8 * 8 + 8;
     const size_t lds = ia_lds_bytes(max_f);
@@ -677,14 +678,14 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
     sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
     hipExtLaunchKernelGGL(image_align_lds_kernel, dim3(n_jobs), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
                           reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p, max_f,
-                          static_cast<sdvl_align_result *>(ctx->d_out));
+                          static_cast<sdvl_align_result *>(direct ? ctx->h_out : ctx->d_out));
   } else {
     SDVL_LAUNCH(ctx, "image_align", image_align_kernel, dim3(n_jobs), dim3(kThreads), static_cast<const IaJob *>(dsx),
                 reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p,
-                static_cast<sdvl_align_result *>(ctx->d_out));
+                static_cast<sdvl_align_result *>(direct ? ctx->h_out : ctx->d_out));
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (!direct) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_ALIGN, &ctx->align_ticket));
   ctx->align_pending = n_jobs;
   return SDVL_OK;

@@ -3,6 +3,7 @@
 #define SDVL_INTERNAL_H_
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -153,6 +154,15 @@ int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f);
 // own AQL packet, so the measured span is the dispatch itself (what rocprofv3 --kernel-trace reports), not the queueing
 // behind other streams that share a hardware queue.
 bool sdvl_timer_events(sdvl_ctx *ctx, const char *name, hipEvent_t *a, hipEvent_t *b);
+// Small results go from the kernels straight into the context's pinned host buffers (host-coherent memory is mapped into
+// the device's address space; the stores are posted PCIe writes, visible to the host once the kernel has completed, i.e.
+// before the sequence number the stream writes behind it) instead of through a device buffer and a D2H copy packet.
+// SDVL_RESULT_COPIES=1 restores the copies (A/B measurements).
+inline bool sdvl_direct_results() {
+  static const bool off = getenv("SDVL_RESULT_COPIES") != nullptr;
+  return !off;
+}
+
 #define SDVL_LAUNCH(ctx, name, kernel, grid, block, ...)                                                   \
   do {                                                                                                     \
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;                                                           \

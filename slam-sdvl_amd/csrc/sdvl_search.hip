@@ -307,7 +307,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                                                                             const SearchBlock *__restrict__ blocks,
                                                                             const SearchPrep *__restrict__ prep, Cam cam,
                                                                             sdvl_search_params prm, int n_blocks,
-                                                                            sdvl_search_res *__restrict__ out) {
+                                                                            sdvl_search_res *__restrict__ out,
+                                                                            sdvl_search_res *__restrict__ out_host) {
   __shared__ WaveLds s_lds[kWavesPerBlock];
   // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   const int level = rq.level;
   const SearchPrep pr = prep[ri];
   if (!pr.alive) {
-    if (lane == 0) out[ri] = res;
+    if (lane == 0) { out[ri] = res; if (out_host) out_host[ri] = res; }
     return;
   }
   const V2 pxa = {pr.pxa[0], pr.pxa[1]}, pxb = {pr.pxb[0], pr.pxb[1]};
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     }
   }
   if (!matched) {
-    if (lane == 0) out[ri] = res;
+    if (lane == 0) { out[ri] = res; if (out_host) out_host[ri] = res; }
     return;
   }
   res.best_corner = best_ci;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     res.found = 1;
     res.stage = 3;
   }
-  if (lane == 0) out[ri] = res;
+  if (lane == 0) { out[ri] = res; if (out_host) out_host[ri] = res; }
 }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void align_patches_kernel(const PatchJob *__restrict__ jobs, const uint8_t *__restrict__ border,
@@ -745,9 +746,10 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
               *p, d_prep);
   SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
               static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
-              static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out));
+              static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
+              sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (!sdvl_direct_results()) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   return SDVL_OK;
 }
 
