@@ -524,21 +524,28 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
       const int index = fcorners[count];
       const Vector3i corner = corners[index];
       const int scale = (1 << corner(2));
+      // map.cc:345-351 constructs the candidate point and its feature before the search; a miss throws them away again. Here
+      // a miss only consumes the point id the constructor would have taken (ids stay those of the reference's order).
+      const sdvl_search_res &r = res[ic_req_[k * nc + count]];
+      if (!r.found) {
+        Point::ConsumeId();
+        continue;
+      }
       shared_ptr<Point> candidate = std::make_shared<Point>();
       shared_ptr<Feature> feature = std::make_shared<Feature>(cur_, Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
       if (Config::UseORB()) feature->SetDescriptor(cur_->HostDescriptor(index));
-      const sdvl_search_res &r = res[ic_req_[k * nc + count]];
-      if (!r.found) continue;
       const Vector2d imgpos(r.px[0], r.px[1]);
       const int level = r.level;
       bool mfound = false;
       vector<shared_ptr<Feature>> &features = cframe->GetFeatures();
       for (size_t q = 0; q < features.size() && !mfound; q++) {  // index loop: AddFeature below may grow the vector
-        if (!features[q]) continue;
-        shared_ptr<Point> point = features[q]->GetPoint();
-        if (!point || point->ToDelete()) continue;
-        const double d1 = imgpos(0) - features[q]->GetPosition()(0), d2 = imgpos(1) - features[q]->GetPosition()(1);
+        const Feature *fq = features[q].get();
+        if (!fq) continue;
+        const Point *praw = fq->GetPointRaw();
+        if (!praw || praw->ToDelete()) continue;
+        const double d1 = imgpos(0) - fq->GetPosition()(0), d2 = imgpos(1) - fq->GetPosition()(1);
         if (std::sqrt(d1 * d1 + d2 * d2) < 1.0) {  // Distance2D, extra/utils.cc:222-226
+          shared_ptr<Point> point = features[q]->GetPoint();
           feature->SetPoint(point);
           cur_->AddFeature(feature);
           point->AddFeature(feature);

@@ -424,6 +424,10 @@ Point::Point() {
   sigma2_ = 1.0;
   z_range_ = 6.0;
 }
+void Point::ConsumeId() {
+  if (g_current_device) g_current_device->next_point_id++;
+  else g_point_counter++;
+}
 double Point::GetStd() { return std::sqrt(sigma2_); }
 
 // point.cc:48-62

@@ -310,6 +310,7 @@ class Point {
   void Update(const std::shared_ptr<Frame> &frame, double depth, double px_error_angle);
   bool HasConverged();
   bool SeenFrom(const std::shared_ptr<Frame> &frame) const;
+  static void ConsumeId();  // what constructing and discarding a Point does to the id counter
   static double ComputeTau(const SE3 &pose, const Vector3d &v, double depth, double px_error_angle);
   static double PDFNormal(double mean, double sd, double x);
 
