@@ -168,7 +168,8 @@ int sdvl_frames_corner_counts(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, i
 /* host mirror of corners_ (GetCorners()): xyl = [n][3], *n_out = count */
 int sdvl_frame_download_corners(sdvl_ctx *ctx, sdvl_frame *f, int cap, int32_t *xyl, int *n_out);
 /* diagnostic: cv::KeyPointsFilter::retainBest on packed keypoints (response in the top byte) run by the device code;
- * cooperative = 0: the one-lane form used per cell, 1: the workgroup form used for a level's list (len <= 4096) */
+ * cooperative = 0: one lane, 1: the whole workgroup with barriers (len <= 4096), 2: a group of 8 lanes — the form the
+ * selection kernel uses per cell (len <= SDVL_CELL_KP_CAP), 3: one wave — the form it uses per level (len <= 4096) */
 int sdvl_retain_best(sdvl_ctx *ctx, uint32_t *packed, int len, int n_points, int cooperative, int *out_len);
 
 /* corners_ of a frame (x, y in level coordinates, level), fast_detector.cc:151 -> HBM; descriptors are invalidated */
