@@ -95,14 +95,19 @@ __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, in
 #pragma unroll
       for (int c = 0; c < 12; c++) J[c] *= ic;
       const double weight = tukey(sqrt(ex * ex + ey * ey) / scale);
+      // A is symmetric term by term (products commute), so only its upper triangle is accumulated; mirrored before the solve
 #pragma unroll
       for (int r = 0; r < 6; r++) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) A[6 * r + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+        for (int c = r; c < 6; c++) A[6 * r + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
         b[r] -= (J[r] * ex + J[6 + r] * ey) * weight;
       }
       new_chi2 += (ex * ex + ey * ey) * weight;
     }
+#pragma unroll
+    for (int r = 1; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < r; c++) A[6 * r + c] = A[6 * c + r];
     double dT[6];
     ldlt_solve6_reg(A, b, dT);
     if ((i > 0 && new_chi2 > chi2) || dT[0] != dT[0]) {
