@@ -308,22 +308,20 @@ def main():
     # CPU baseline first (rank 0, one core, bounded sample): it is independent of the GPU run, and on a freshly started box
     # it also keeps the timed region away from the start-up activity of the container (measured: the first seconds of a
     # fresh box cost the 16 host threads up to 40 % of their CPU share)
-    cpu = None
+    cpu, cpu_sample, cpu_one, cpu_all = None, None, None, None
     if rank == 0 and world == 1 and args.cpu_frames > 0:   # at N = 1 only: with more ranks the host cores belong to their farms
         n_cpu = args.cpu_frames
         cbuf = ctx.malloc(n_cpu * frame_bytes)
         views = [make_view(pkg, se3_exp(shard.sequence_twist(0) * k), shard.sequence_seed(0), k) for k in range(n_cpu)]
         ctx.render(views, cbuf)
         host = ctx.download(cbuf, n_cpu * frame_bytes).reshape(n_cpu, H_IMG, W_IMG)
-        sample = [host[k] for k in range(n_cpu)]
-        fps1, n_tracked1, secs1 = cpu_baseline(sample, args.mapper, 1)
-        n_thr = max(1, min(ncpu, 16))
-        fps, n_tracked, secs = cpu_baseline(sample, args.mapper, n_thr) if n_thr > 1 else (fps1, n_tracked1, secs1)
-        cpu = {"value": round(fps, 2), "unit": "tracked frames/s", "cores": n_thr, "kind": "port",
-               "sample": "sequence 0 of the same workload, %d tracked frames per tracker: one tracker on one host core (%.1f s), then %d "
-                         "independent trackers on %d host threads (%.1f s; %d usable CPUs)" % (n_tracked1, secs1, n_thr, n_thr, secs, ncpu),
-               "one_core": round(fps1, 2)}
+        cpu_sample = [host[k].copy() for k in range(n_cpu)]
+        cpu_one = cpu_baseline(cpu_sample, args.mapper, 1)
         del host
+        if os.environ.get("SDVL_BENCH_CPU_ORDER", "after") == "before":
+            cpu_all = cpu_baseline(cpu_sample, args.mapper, max(1, min(ncpu, 16)))
+    # (the all-core leg runs AFTER the timed region: 16 threads at full load right before it cost the GPU run ~5-10 % -
+    #  151 k against 170 k on the same box - whatever the host does to a process that has just used its whole CPU share)
 
     workers = args.workers or max(1, G // max(1, fibers))
     farm.reserve(reserve_frames)              # every keyframe keeps its HBM frame: no hipMalloc inside the run
@@ -377,6 +375,15 @@ def main():
         n_lk += st.lk_iters
 
     tracked_all, elapsed_max = shard.reduce_throughput(tracked, elapsed, dist if distributed else None, "cuda")
+    if cpu_sample is not None:
+        fps1, n_tracked1, secs1 = cpu_one
+        n_thr = max(1, min(ncpu, 16))
+        fps, n_tracked, secs = cpu_all if cpu_all else (cpu_baseline(cpu_sample, args.mapper, n_thr) if n_thr > 1 else cpu_one)
+        cpu = {"value": round(fps, 2), "unit": "tracked frames/s", "cores": n_thr, "kind": "port",
+               "sample": "sequence 0 of the same workload, %d tracked frames per tracker: one tracker on one host core before the GPU run "
+                         "(%.1f s), %d independent trackers on %d host threads after it (%.1f s; %d usable CPUs)"
+                         % (n_tracked1, secs1, n_thr, n_thr, secs, ncpu),
+               "one_core": round(fps1, 2)}
 
     if rank == 0:
         frames_rank = B * K
