@@ -36,7 +36,7 @@ ORACLE_PARAMS = {}      # fields of the oracle's parameter block that differ fro
 # S-A is the metric configuration; S-C (1280x960, num_features 4000, max_matches 1000, 64 sequences per GPU)
 # is BASELINE.json's roofline case, run with `--workload S-C`
 WORKLOADS = {
-    "S-A": dict(w=640, h=480, cam=[517.3, 516.5, 318.6, 255.3], seqs=1024, over={}, label="~200 feats", cpu_frames=300),
+    "S-A": dict(w=640, h=480, cam=[517.3, 516.5, 318.6, 255.3], seqs=2048, over={}, label="~200 feats", cpu_frames=300),
     "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=64, label="~1000 feats", cpu_frames=60,
                 over={"SDVL.num_features": 4000, "SDVL.max_matches": 1000}),
 }

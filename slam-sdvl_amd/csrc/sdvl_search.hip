@@ -645,7 +645,7 @@ struct SearchBatch {
   std::unordered_map<const sdvl_frame *, int> where;
   int last = -1;
 };
-constexpr size_t kSearchTabCap = 512;  // frame-table entries that fit the staging reserve (more go through d_work)
+constexpr size_t kSearchTabCap = 2048;  // frame-table entries that fit the staging reserve (more go through d_work)
 
 static SearchBatch &batch_of(sdvl_ctx *ctx) {
   static thread_local std::unordered_map<sdvl_ctx *, SearchBatch> batches;  // one builder per context

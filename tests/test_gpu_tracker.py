@@ -183,14 +183,14 @@ def test_farm_fibers_give_identical_results(trk, orc, synth):
 
 
 def test_farm_at_bench_size_replicas_agree_and_match_the_oracle(trk, orc, synth):
-    """The bench configuration (1024 sequences, 16 groups of 64, one worker per group) on 8 distinct sequences replicated
-    128 times: where a sequence sits in a group, which group and which stream it runs on must not matter — every replica
+    """The bench configuration (2048 sequences, 16 groups of 128, one worker per group) on 8 distinct sequences replicated
+    256 times: where a sequence sits in a group, which group and which stream it runs on must not matter — every replica
     gives the same per-frame record, bit for bit — and the 8 distinct ones equal the CPU oracle (decisions exact, poses
     within 1e-4)."""
     import importlib
     sdvl = importlib.import_module("slam-sdvl_amd")
     import bench as B
-    G, Bg, n_steps, distinct = 16, 64, 6, 8
+    G, Bg, n_steps, distinct = 16, 128, 6, 8
     n = G * Bg
     trk.configure()
     farm = trk.TrackerFarm(0, G, Bg, 640, 480, TUM_CAM)
