@@ -848,8 +848,12 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
   __shared__ int s_c1;
   __shared__ uint8_t s_glr[2 * kSelStage];  // stopper lists of the lane groups: 2 x count bytes per staged cell
   static_assert(SDVL_CELL_KP_CAP <= 256, "cell positions are stored in a byte");
-  const SelJob &job = jobs[blockIdx.y];
-  const int l = blockIdx.x;
+  // One workgroup fills a CU (LDS), so a batch of more than 256 / n_levels frames runs in rounds.  Workgroups start in
+  // linear order: the level is the SLOW index, i.e. every frame's level 0 — the longest job — starts first and the short
+  // coarse levels fill the CUs as they free up (longest first: ~30 % less for 128 frames than frame-major order).
+  const int lin = static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x);
+  const int l = lin / static_cast<int>(gridDim.y);
+  const SelJob &job = jobs[lin - l * static_cast<int>(gridDim.y)];
   const int tid = threadIdx.x;
   const int wc = lv.wcells[l], hc = lv.hcells[l];
   const int ncells = wc * hc;
