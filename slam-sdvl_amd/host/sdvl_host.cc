@@ -1739,7 +1739,9 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       for (int k = 0; k < R; k++) cap += static_cast<int>(trk_[run[k]]->last_frame_->GetFeatures().size());
       sink.ctx = dev_->ctx();
       sink.cap = cap;
-      sink.batch_id = ++search_batch_counter_;
+      // unique per DEVICE, not per SDVLBatch: frames remember the slot they got in a batch by its id, and SDVL::HandleFrame
+      // makes a fresh one-tracker SDVLBatch for every frame
+      sink.batch_id = ++dev_->search_batch_counter;
       // search -> match selection -> RANSAC + pose refinement as ONE submission (sdvl_search_run_chain): the device replays
       // the second half of SelectPoints itself, so the pose kernels run while this thread does the same replay for its
       // own bookkeeping (features, point statistics) instead of starting after it

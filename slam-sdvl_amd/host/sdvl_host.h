@@ -73,6 +73,7 @@ class Device {
   void Check(int rc, const char *what) const;
   static Device *Current();
   static void SetCurrent(Device *d);
+  uint64_t search_batch_counter = 0;  // ids of the packed search batches opened on this device's context
   std::vector<int32_t> scratch_xyl;  // Frame::FilterCornersBatch round-trip buffers
   std::vector<double> scratch_scores;
   std::vector<uint8_t> scratch_desc;
@@ -732,7 +733,6 @@ class SDVLBatch {
   Device *dev_;
   std::vector<SDVL *> trk_;
   int threads_;
-  uint64_t search_batch_counter_ = 0;
   std::vector<sdvl_search_req> scratch_reqs_;  // per-step request / pose batches, reused so that they never reallocate
   FeatureAlign::PoseBatch scratch_pose_;
   std::vector<double> scratch_points_;  // sdvl_search_run_chain inputs, same idea

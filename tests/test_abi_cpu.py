@@ -92,3 +92,15 @@ def test_orb_sincos_rounds_like_libm():
         assert np.float32(s.value) == np.float32(math.sin(a)) and np.float32(c.value) == np.float32(math.cos(a)), a
         worst = max(worst, abs(s.value - math.sin(a)), abs(c.value - math.cos(a)))
     assert worst < 3e-16
+
+
+def test_cpp_example_fails_loudly_without_a_gpu():
+    """the C++ example of the drop-in (host/track_sequence) has no CPU path either"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(ROOT, "slam-sdvl_amd", "host", "track_sequence")
+    assert os.path.exists(exe), "build() makes it (make -C slam-sdvl_amd/host)"
+    r = subprocess.run([exe, "--synthetic", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr

@@ -2,6 +2,7 @@
 sequences tracked on the MI355X through the host layer (sdvl::SDVLBatch) against the CPU oracle tracker run on
 the same frames.  Decisions (matches, attempts, inliers, keyframes) must be identical, poses within 1e-4."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -314,3 +315,33 @@ def test_mapper_mode_lost_and_relocalize(trk, orc, synth):
         relocs += g.relocalized
     assert relocs == 1
     batch.close(); ref.close(); dev.close()
+
+
+def test_cpp_example_track_sequence_matches_the_oracle(orc, synth, tmp_path):
+    """slam-sdvl_amd/host/track_sequence: the reference's main.cc loop written against sdvl_host.h (no Python, no ctypes in
+    the path) — on rendered frames and on the same frames read back from a PGM list it reports what the CPU oracle does"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam-sdvl_amd", "host", "track_sequence")
+    assert os.path.exists(exe), "build() makes it (make -C slam-sdvl_amd/host)"
+    n = 6
+    imgs = [synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, frame_id=k) for k in range(n)]
+    lst = tmp_path / "frames.txt"
+    with open(lst, "w") as fh:
+        for k, im in enumerate(imgs):
+            p = tmp_path / ("f%03d.pgm" % k)
+            with open(p, "wb") as out:
+                out.write(b"P5\n# frame %d\n640 480\n255\n" % k)
+                out.write(im.tobytes())
+            fh.write(str(p) + "\n")
+    ref = orc.tracker(640, 480, TUM_CAM)
+    wants = [ref.handle_frame(im) for im in imgs]
+    ref.close()
+    for args in (["--synthetic", str(n)], ["--list", str(lst)]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        rows = [l.split() for l in r.stdout.strip().splitlines()]
+        assert len(rows) == n
+        for k, (row, w) in enumerate(zip(rows, wants)):
+            assert [int(v) for v in row[:6]] == [k, w.state, w.quality, w.matches, w.attempts, w.inliers], (args[0], k)
+            assert np.abs(np.array([float(v) for v in row[6:13]]) - np.array(w.pose[:])).max() <= POSE_TOL
+        assert "tracked frames/s" in r.stderr
