@@ -345,3 +345,16 @@ def test_cpp_example_track_sequence_matches_the_oracle(orc, synth, tmp_path):
             assert [int(v) for v in row[:6]] == [k, w.state, w.quality, w.matches, w.attempts, w.inliers], (args[0], k)
             assert np.abs(np.array([float(v) for v in row[6:13]]) - np.array(w.pose[:])).max() <= POSE_TOL
         assert "tracked frames/s" in r.stderr
+
+
+def test_cpp_single_call_api_surface():
+    """slam-sdvl_amd/host/api_surface_check: the reference's per-object calls one at a time (Frame ctor and accessors,
+    FastDetector::DetectPyramid, ORBDetector::GetDescriptor / Distance, Frame::FilterCorners, ImageAlign::ComputePose,
+    Matcher::SearchPoint, FeatureAlign::Reproject / OptimizePose) agree with the batched path and recover the rendered motion"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam-sdvl_amd", "host", "api_surface_check")
+    assert os.path.exists(exe), "build() makes it (make -C slam-sdvl_amd/host)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) >= 16 and all(l.startswith("ok") for l in lines[:-1]) and lines[-1] == "0 check(s) failed"
