@@ -6,7 +6,8 @@ grid reprojection with SearchPoint/AlignPatch, RANSAC + pose refinement) over on
 640x480 sequences per GPU (workload S-A of SURVEY §8d, TUM intrinsics / TUM cfg parameters, 5-level pyramid,
 max 200 matches).  All input frames are rendered into HBM before the timed region starts.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU - started by torch.distributed.run, or by this
+                                                          file itself when it is launched directly; fewer GPUs than N = error)
 
 Sequences shard across ranks with no data-path collective ("weak" scaling: B sequences per GPU); RCCL is used only
 for the barrier and the throughput reduction.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events
@@ -216,6 +217,78 @@ def cpu_baseline(frames, mapper=False, threads=1):
     return tracked / wall, tracked, wall
 
 
+def launch_ranks(n, dry=False):
+    """`python bench.py --gpus N` without a distributed launcher: start the N ranks as child processes, one per GPU, BEFORE
+    anything in this process touches the GPU (a process that has initialised HIP must never exec or fork workers).  Every
+    rank gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like under torch.distributed.run and an equal share of the CPUs
+    (SDVL_BENCH_CPU_SHARE; inside the rank the share is bound to the NUMA node of its GPU).  Rank 0 prints the JSON line.
+    Returns the exit code: non-zero if the box has fewer GPUs than ranks or if any rank fails."""
+    import socket
+    import subprocess
+    if not dry:
+        have = torch.cuda.device_count()     # counting devices does not initialise the GPU
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but %d GPU(s) are visible on this box - refusing to measure fewer GPUs than asked for\n" % (n, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    share = max(1, effective_cpus() // n)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SDVL_BENCH_CPU_SHARE=str(share), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d - stopping the other ranks\n" % (r, code))
+                    for q in pending:
+                        procs[q].terminate()     # exactly the children started above, by handle
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_rank(args, rank, world):
+    """SDVL_BENCH_DRY=1: the N > 1 plumbing of this file without a GPU - sharding, gloo rendezvous, barrier, the one
+    reduction (shard.reduce_throughput) and rank 0's JSON line - so that the launcher is testable on CPU."""
+    shard = importlib.import_module("slam-sdvl_amd.shard")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, K = args.seqs, args.steps
+    my = shard.sequences_for_rank(rank, world, B)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.02 * (1 + rank))                      # ranks finish at different times: the job's time is the slowest rank's
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tracked_all, elapsed_max = shard.reduce_throughput(len(my) * K, elapsed, dist, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "tracked frames/sec (dry run, no GPU)", "value": round(tracked_all / elapsed_max, 2), "unit": "frames/s",
+                          "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed_max / K * 1e3, 3), "dry": True,
+                          "tracked": tracked_all, "cpu_share": int(os.environ.get("SDVL_BENCH_CPU_SHARE", "0")),
+                          "sequences": [my[0], my[-1]], "scaling": "weak"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,14 +314,27 @@ def main():
     if args.cpu_frames < 0:
         args.cpu_frames = wl["cpu_frames"]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "WORLD_SIZE must equal --gpus (launch with torch.distributed.run)"
+    dry = bool(os.environ.get("SDVL_BENCH_DRY"))   # test hook (tests/test_bench_launcher.py): ranks, barrier and reduction without a GPU
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # launched directly with --gpus N: this process only starts the N ranks (it never touches the GPU itself)
+            raise SystemExit(launch_ranks(args.gpus, dry))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: one rank per GPU (torch.distributed.run --nproc-per-node N bench.py "
+                             "--gpus N, or plain `python bench.py --gpus N`, which starts the ranks itself)" % (world, args.gpus))
     distributed = world > 1
     dist = None
+    if dry:
+        return dry_rank(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
@@ -264,7 +350,7 @@ def main():
     # one group = one HIP stream + one host-side step at a time; workers = host threads.  With a full CPU share (16 per
     # GPU on the MI355X boxes) one group per worker is best; with fewer CPUs every worker interleaves two groups (fibers),
     # which hides their GPU waits and is worth ~10 % there.
-    cpus_rank = max(1, ncpu // max(1, world))
+    cpus_rank = int(os.environ.get("SDVL_BENCH_CPU_SHARE", "0")) or max(1, ncpu // max(1, world))
     fibers = args.fibers
     if args.groups:
         G = args.groups

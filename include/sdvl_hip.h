@@ -125,6 +125,15 @@ int sdvl_ctx_create(int device, sdvl_ctx **out);
 int sdvl_ctx_destroy(sdvl_ctx *ctx);
 const char *sdvl_last_error(const sdvl_ctx *ctx);
 int sdvl_ctx_synchronize(sdvl_ctx *ctx);
+/* HIP's current device is per host thread (and starts at 0): a thread that did not create the context selects the context's
+ * GPU with this before its first call (the reference's mapper thread, map.cc:55-71; worker threads of a batch driver).
+ * Allocation sites inside the library select it themselves; this makes launches and copies of the thread follow. */
+int sdvl_ctx_bind_thread(sdvl_ctx *ctx);
+int sdvl_ctx_device(const sdvl_ctx *ctx);
+/* diagnostics: the GPU a device pointer lives on; the GPU the context's scratch buffers were allocated on (must equal
+ * sdvl_ctx_device for every thread that ever grew them) */
+int sdvl_pointer_device(sdvl_ctx *ctx, const void *p, int *device);
+int sdvl_ctx_scratch_device(sdvl_ctx *ctx, int *device);
 void *sdvl_ctx_stream(sdvl_ctx *ctx); /* the hipStream_t every launch of this context goes to */
 /* per-kernel device time (HIP events on the context stream) accumulated since the last reset; names/ms/launches */
 int sdvl_ctx_timing_enable(sdvl_ctx *ctx, int on);
@@ -259,6 +268,8 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
 int sdvl_ctx_set_wait_hook(sdvl_ctx *ctx, void (*hook)(void *user, sdvl_ctx *ctx), void *user);
 int sdvl_ctx_wait_done(sdvl_ctx *ctx);
 int sdvl_ctx_wait_block(sdvl_ctx *ctx);
+/* 0 while the stream is healthy (idle or busy), SDVL_ERR_HIP after a device fault: for schedulers that poll _wait_done */
+int sdvl_ctx_health(sdvl_ctx *ctx);
 
 /* ---- input stage: Camera::UndistortImage = cv::undistort(in, out, K, D) (camera.cc:39-67,100-105, main.cc:133) ----
  * d[0..4] = Camera.d1..d5 of the config = (k1, k2, p1, p2, k3).  As in the reference, d[0] == 0 means "no distortion":

@@ -4,8 +4,15 @@
 
 #include "sdvl_internal.h"
 
+// HIP's current device is per THREAD and starts at 0: every host thread that works for a context of GPU n (farm workers,
+// fibers, pool helpers, a user's mapper thread) must select that GPU before it allocates or launches, or its hipMalloc /
+// hipHostMalloc land on GPU 0.  Not cached: other code on the thread (torch) may select devices too; hipSetDevice is a
+// thread-local store and is only called where memory is allocated and once per step of a host thread.
+hipError_t sdvl_bind_device(const sdvl_ctx *ctx) { return hipSetDevice(ctx->device); }
+
 int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned) {
   if (*cur >= need && *p) return SDVL_OK;
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
   size_t want = need + need / 2 + 4096;
   if (*p) {
     SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
@@ -56,7 +63,9 @@ hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket) {
   }
   if (!ctx->h_flag) {
     void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, 64, hipHostMallocDefault);
+    hipError_t e = sdvl_bind_device(ctx);
+    if (e != hipSuccess) return e;
+    e = hipHostMalloc(&p, 64, hipHostMallocDefault);
     if (e != hipSuccess) return e;
     memset(p, 0, 64);
     ctx->h_flag = static_cast<volatile uint32_t *>(p);
@@ -137,6 +146,16 @@ extern "C" int sdvl_ctx_wait_done(sdvl_ctx *ctx) {
   if (!ctx || !ctx->waiting) return 1;
   hipError_t err;
   return mark_reached(ctx, ctx->waiting_kind, ctx->waiting_ticket, &err) != 0 ? 1 : 0;
+}
+
+// 0 while the context's stream is healthy (idle or busy), SDVL_ERR_HIP once it has reported a fault: a scheduler that polls
+// sdvl_ctx_wait_done asks this now and then, so that a faulted kernel ends the run instead of hanging it
+extern "C" int sdvl_ctx_health(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  const hipError_t q = hipStreamQuery(ctx->stream);
+  if (q == hipSuccess || q == hipErrorNotReady) return SDVL_OK;
+  ctx->err = std::string("stream fault: ") + hipGetErrorString(q);
+  return SDVL_ERR_HIP;
 }
 
 // sleep (no spinning) until the wait in flight has completed
@@ -221,7 +240,7 @@ int sdvl_ctx_create(int device, sdvl_ctx **out) {
   if (device < 0 || device >= count) return SDVL_ERR_INVALID;
   sdvl_ctx *ctx = new sdvl_ctx();
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (sdvl_bind_device(ctx) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return SDVL_ERR_HIP;
   }
@@ -231,7 +250,7 @@ int sdvl_ctx_create(int device, sdvl_ctx **out) {
 
 int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   if (!ctx) return SDVL_ERR_INVALID;
-  (void)hipSetDevice(ctx->device);
+  (void)sdvl_bind_device(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   sdvl_timer_collect(ctx);
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
@@ -240,6 +259,8 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   if (ctx->h_flag) (void)hipHostFree(const_cast<uint32_t *>(ctx->h_flag));
   if (ctx->d_nits) (void)hipFree(ctx->d_nits);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_search) (void)hipHostFree(ctx->h_search);
+  if (ctx->d_search) (void)hipFree(ctx->d_search);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
   if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -253,6 +274,29 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
 }
 
 const char *sdvl_last_error(const sdvl_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int sdvl_ctx_bind_thread(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  return SDVL_OK;
+}
+
+int sdvl_ctx_device(const sdvl_ctx *ctx) { return ctx ? ctx->device : SDVL_ERR_INVALID; }
+
+int sdvl_pointer_device(sdvl_ctx *ctx, const void *p, int *device) {
+  if (!ctx || !p || !device) return SDVL_ERR_INVALID;
+  hipPointerAttribute_t a;
+  SDVL_HIP_CHECK(ctx, hipPointerGetAttributes(&a, p));
+  *device = a.device;
+  return SDVL_OK;
+}
+
+int sdvl_ctx_scratch_device(sdvl_ctx *ctx, int *device) {
+  if (!ctx || !device) return SDVL_ERR_INVALID;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, 256, false);
+  if (rc) return rc;
+  return sdvl_pointer_device(ctx, ctx->d_out, device);
+}
 
 int sdvl_ctx_synchronize(sdvl_ctx *ctx) {
   if (!ctx) return SDVL_ERR_INVALID;
@@ -382,7 +426,7 @@ int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int
   SDVL_REQUIRE(ctx, levels >= 1 && levels <= SDVL_MAX_LEVELS, "pyramid levels out of range");
   FrameLayout L;
   SDVL_REQUIRE(ctx, frame_layout(width, height, levels, &L), "image too small for the pyramid depth");
-  SDVL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
   uint8_t *base = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), L.bytes * static_cast<size_t>(n));
   if (e != hipSuccess) {
@@ -560,7 +604,7 @@ int sdvl_frame_download_corners(sdvl_ctx *ctx, sdvl_frame *f, int cap, int32_t *
 
 int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out) {
   if (!ctx || !out || bytes <= 0) return SDVL_ERR_INVALID;
-  SDVL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
   SDVL_HIP_CHECK(ctx, hipMalloc(out, static_cast<size_t>(bytes)));
   return SDVL_OK;
 }

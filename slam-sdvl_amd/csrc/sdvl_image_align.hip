@@ -12,6 +12,8 @@
 // (double) and chi2 (float in the reference, accumulated in double here), hence tolerance-class parity (1e-4).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
 
@@ -668,11 +670,14 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
   if (use_lds) {
     const int max_f = (max_nf + 7) / 8 * 8 + 8;
     const size_t lds = ia_lds_bytes(max_f);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the kernel object of ONE device: set it once per device, whichever thread gets there first
+    static std::atomic<unsigned long long> attr_devices{0};
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
+      SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
       SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_lds_bytes(kLdsMaxF + 16))));
-      attr_set = true;
+      attr_devices.fetch_or(bit, std::memory_order_release);
     }
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);

@@ -58,6 +58,11 @@ struct sdvl_ctx {
   void *d_out = nullptr;   size_t d_out_bytes = 0;
   void *d_work = nullptr;  size_t d_work_bytes = 0;
   size_t stage_off = 0;  // bump pointer into h_stage/d_stage; reset by every sdvl_stream_wait
+  // A search batch (sdvl_search_begin .. sdvl_search_run) is filled by the caller over time and must survive every wait in
+  // between, so it does not live in the ring (whose bump pointer any sdvl_stream_wait resets) but in buffers of its own
+  void *h_search = nullptr; size_t h_search_bytes = 0;
+  void *d_search = nullptr; size_t d_search_bytes = 0;
+  uint64_t search_busy_gen = ~0ull;  // wait_gen when the last batch was queued: its buffers are in use until a later wait
   // corner counts of the last sdvl_detect_corners batch, written by the pack kernel: one D2H serves all frames
   void *d_counts = nullptr; size_t d_counts_bytes = 0;
   std::vector<sdvl_frame *> detect_frames;
@@ -132,6 +137,8 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
     }                                         \
   } while (0)
 
+// select the context's GPU on the calling thread (HIP's current device is per thread); cached, one compare when already bound
+hipError_t sdvl_bind_device(const sdvl_ctx *ctx);
 int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);
 // `bytes` of pinned host staging + its device mirror (same offset in h_stage / d_stage).  Allocations made since the
 // last sdvl_stream_wait never overlap, so a call can fill its records while earlier copies are still in flight;

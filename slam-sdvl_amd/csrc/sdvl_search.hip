@@ -662,8 +662,15 @@ int sdvl_search_begin(sdvl_ctx *ctx, int max_requests, sdvl_search_req_packed **
   B.last = -1;
   B.in_bytes = (sizeof(SearchReqDev) * static_cast<size_t>(max_requests) + 255) / 256 * 256;
   B.blk_cap_bytes = (sizeof(SearchBlock) * static_cast<size_t>(max_requests) + 255) / 256 * 256;
-  int rc = sdvl_stage_alloc(ctx, B.in_bytes + B.blk_cap_bytes + sizeof(SearchFramePose) * kSearchTabCap, &B.hs, &B.dsx);
+  // the batch's own pinned + device buffers, not the staging ring: the caller fills the records over time and every
+  // sdvl_stream_wait in between (buffer growth inside sdvl_search_run, a staging request that wraps) restarts the ring
+  if (ctx->search_busy_gen == ctx->wait_gen) SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // the previous batch may still be read
+  const size_t need = B.in_bytes + B.blk_cap_bytes + sizeof(SearchFramePose) * kSearchTabCap;
+  int rc = sdvl_ensure(ctx, &ctx->h_search, &ctx->h_search_bytes, need, true);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_search, &ctx->d_search_bytes, need, false);
   if (rc) return rc;
+  B.hs = ctx->h_search;
+  B.dsx = ctx->d_search;
   *reqs = static_cast<sdvl_search_req_packed *>(B.hs);
   return SDVL_OK;
 }
@@ -714,6 +721,7 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   if (extra_d_off) *extra_d_off = out_dev_bytes + prep_bytes;
   if (extra_h_off) *extra_h_off = out_dev_bytes;
   void *hs = B.hs, *dsx = B.dsx;
+  ctx->search_busy_gen = ctx->wait_gen;  // from here on the batch buffers are read by queued copies and kernels
   // workgroups: runs of up to kWavesPerBlock consecutive requests that search the same current frame
   SearchBlock *hblk = reinterpret_cast<SearchBlock *>(static_cast<uint8_t *>(hs) + in_bytes);
   int n_blocks = 0;
@@ -792,6 +800,7 @@ static int ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int ma
   SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // nobody may still be reading the old table
   if (ctx->d_nits) SDVL_HIP_CHECK(ctx, hipFree(ctx->d_nits));
   ctx->d_nits = nullptr;
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
   SDVL_HIP_CHECK(ctx, hipMalloc(&ctx->d_nits, entries * sizeof(int32_t)));
   SDVL_HIP_CHECK(ctx, hipMemcpy(ctx->d_nits, t.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
   ctx->nits_points = npoints_cfg;

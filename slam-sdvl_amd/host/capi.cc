@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <execinfo.h>
 #include <signal.h>
+#include <sys/mman.h>
 #include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <sys/time.h>
@@ -277,9 +278,27 @@ struct Farm {
 // (sdvl_ctx_set_wait_hook) switches to another fiber whenever a step would sleep, and the thread only sleeps — a 25 us
 // nanosleep between polls, no spinning: the CPU quota is the scarce resource — when every fiber is waiting for the GPU.
 namespace {
+// a fiber's stack: 1 MB with an inaccessible page below it, so that an overflow (deep recursion in the mapper or the HIP
+// runtime) faults instead of silently overwriting the heap
+struct FiberStack {
+  static constexpr size_t kBytes = 1 << 20, kGuard = 4096;
+  char *base = nullptr;
+  FiberStack() {
+    void *p = mmap(nullptr, kBytes + kGuard, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+    if (p == MAP_FAILED) throw std::bad_alloc();
+    base = static_cast<char *>(p);
+    mprotect(base, kGuard, PROT_NONE);
+  }
+  ~FiberStack() { if (base) munmap(base, kBytes + kGuard); }
+  FiberStack(const FiberStack &) = delete;
+  FiberStack &operator=(const FiberStack &) = delete;
+  char *data() const { return base + kGuard; }
+  size_t size() const { return kBytes; }
+};
+
 struct Fiber {
   ucontext_t ctx;
-  std::vector<char> stack;
+  FiberStack stack;
   Farm *farm = nullptr;
   int group = -1;      // -1 = free
   int rc = 0;
@@ -332,10 +351,8 @@ void Farm::RunShareFibers(int worker, int n_workers) {
   g_sched = &sched;
   prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);  // a 25 us nanosleep should cost ~30 us, not 25 + the default 50 us slack
   std::vector<Fiber> fibers(fibers_per_worker);
-  for (Fiber &f : fibers) {
-    f.stack.resize(1 << 20);
-    f.farm = this;
-  }
+  for (Fiber &f : fibers) f.farm = this;
+  int idle_polls = 0;
   auto start = [&](Fiber &f, int g, bool whole_run) {
     f.group = g;
     f.finished = false;
@@ -390,6 +407,19 @@ void Farm::RunShareFibers(int worker, int n_workers) {
     if (!progressed) {  // every fiber waits for the GPU: sleep a poll interval (any of their streams may finish first)
       const struct timespec ts = {0, 25000};
       nanosleep(&ts, nullptr);
+      if (++idle_polls % 2048 == 0) {  // ~every 100 ms without progress: a faulted stream never reaches its mark
+        for (Fiber &f : fibers)
+          if (f.group >= 0 && f.waiting_on && sdvl_ctx_health(f.waiting_on) != SDVL_OK) {
+            std::lock_guard<std::mutex> lk(m);
+            failed = true;
+            err = std::string("GPU fault while a group-step was waiting: ") + sdvl_last_error(f.waiting_on);
+          }
+        bool stop;
+        { std::lock_guard<std::mutex> lk(m); stop = failed; }
+        if (stop) break;  // the fibers' stacks are abandoned: the run is over
+      }
+    } else {
+      idle_polls = 0;
     }
   }
   g_sched = nullptr;

@@ -89,7 +89,12 @@ Device *Device::Current() {
   if (!g_current_device) throw std::runtime_error("no sdvl::Device bound to this thread (construct one, or Device::SetCurrent)");
   return g_current_device;
 }
-void Device::SetCurrent(Device *d) { g_current_device = d; }
+// binds the calling thread to the device object AND to its GPU: HIP's current device is per thread and starts at 0, so a
+// farm worker, fiber or pool helper that steps a group of GPU n must select n before anything it does allocates or launches
+void Device::SetCurrent(Device *d) {
+  g_current_device = d;
+  if (d) d->Check(sdvl_ctx_bind_thread(d->ctx()), "sdvl_ctx_bind_thread");
+}
 
 void Device::Check(int rc, const char *what) const {
   if (rc != SDVL_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + sdvl_last_error(ctx_));
@@ -1548,7 +1553,7 @@ class Pool {
         cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
         if (stop_) return;
         seen = gen_;
-        g_current_device = dev_;  // the helpers work for the caller's device (Point ids, scratch)
+        Device::SetCurrent(dev_);  // the helpers work for the caller's device (Point ids, scratch) and on its GPU
       }
       Drain();
       {

@@ -1,0 +1,58 @@
+"""bench.py's own rank launcher (`python bench.py --gpus N` without torch.distributed.run), driven on CPU: two ranks over
+gloo through the real sharding + shard.reduce_throughput path (SDVL_BENCH_DRY=1 replaces only the GPU work), and the
+refusal to measure fewer GPUs than asked for."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SDVL_BENCH_DRY")}
+    env.update(kw)
+    return env
+
+
+def test_launcher_runs_two_ranks_over_gloo():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--seqs", "8"], env=_env(SDVL_BENCH_DRY="1"),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["tracked"] == 2 * 8 * 3                         # SUM over ranks of (sequences per GPU x steps)
+    assert d["sequences"] == [0, 7]                          # rank 0 owns the first 8 global sequences
+    assert d["cpu_share"] >= 1
+    # MAX over ranks: rank 1 sleeps 40 ms, rank 0 20 ms
+    assert d["ms_per_step"] * 3 >= 39.0
+    assert abs(d["value"] - d["tracked"] / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 0.02
+
+
+def test_launcher_refuses_fewer_gpus_than_asked():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the refusal cannot be provoked")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=_env(), capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode != 0
+    assert "refusing" in out.stderr and not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_world_size_must_match_gpus():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "2", "--warmup", "1"],
+                         env=_env(SDVL_BENCH_DRY="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in out.stderr
+
+
+def test_a_failing_rank_fails_the_launch():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "0", "--warmup", "0", "--seqs", "8"], env=_env(SDVL_BENCH_DRY="1"),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0                               # steps = 0: every rank divides by zero -> the launcher reports it
+    assert "exited with" in out.stderr

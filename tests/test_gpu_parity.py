@@ -319,12 +319,11 @@ def test_search_points_frame_with_more_corners_than_the_lds_stage(ctx, sdvl, orc
     f_ref.close(); f_cur.close()
 
 
-def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth):
-    """sdvl_search_run_chain / _chain_end against the separate calls: the same search results, the matches the host replay of
-    SelectPoints (first hit per cell, at most max_matches) picks, and bit-identical pose results from them"""
+def chain_case(ctx, sdvl, orc, synth, n_req=300):
+    """requests of one frame pair + four trackers over them for sdvl_search_run_chain"""
     img_ref, img_cur = frames_of(synth, orc, TUM_CAM, 640, 480, [0, 5])
     T_ref, T_cur = trajectory_pose(orc, 0), trajectory_pose(orc, 5)
-    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, 300, 21, True, 0.0, describe=False)
+    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, n_req, 21, True, 0.0, describe=False)
     n = len(reqs)
     cam = sdvl.Camera(640, 480, *TUM_CAM)
     sp = sdvl.default_search_params()
@@ -348,6 +347,13 @@ def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth)
     # a tracker that projected nothing into the image (no candidates) and one whose only candidates have no request
     trackers.append(dict(cells=[], max_matches=200, pose=T_ref, draws=rng.integers(0, 2**31 - 1, 100)))
     trackers.append(dict(cells=[[-1], [-1, -1]], max_matches=200, pose=T_cur, draws=rng.integers(0, 2**31 - 1, 100)))
+    return reqs, cam, sp, trackers, pts, f_ref, f_cur
+
+
+def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth):
+    """sdvl_search_run_chain / _chain_end against the separate calls: the same search results, the matches the host replay of
+    SelectPoints (first hit per cell, at most max_matches) picks, and bit-identical pose results from them"""
+    reqs, cam, sp, trackers, pts, f_ref, f_cur = chain_case(ctx, sdvl, orc, synth)
     res, got = ctx.search_chain(reqs, cam, sp, trackers, pts, fx=TUM_CAM[0])
     want_res = ctx.search_points(reqs, cam, sp)
     for a, b in zip(res, want_res):
@@ -381,6 +387,74 @@ def test_search_chain_equals_search_then_select_then_pose(ctx, sdvl, orc, synth)
         assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["outliers"], w["outliers"])
         assert np.array_equal(g["pose"], w["pose"])
     f_ref.close(); f_cur.close()
+
+
+def test_search_chain_survives_buffer_growth_inside_the_call(ctx, sdvl, orc, synth):
+    """A request batch is filled between sdvl_search_begin and sdvl_search_run_chain; the run grows the context's result and
+    staging buffers when they are too small, and growing waits on the stream.  The batch must survive that (it used to live
+    in the staging ring, whose bump pointer every wait reset): a fresh context — first a small chain, then one that forces
+    every buffer to grow while its batch is open — returns what a warmed-up context returns."""
+    reqs, cam, sp, trackers, pts, f_ref, f_cur = chain_case(ctx, sdvl, orc, synth, 300)
+    ctx.search_chain(reqs, cam, sp, trackers, pts, fx=TUM_CAM[0])               # warm: nothing grows in the next call
+    want_res, want = ctx.search_chain(reqs, cam, sp, trackers, pts, fx=TUM_CAM[0])
+    fresh = sdvl.Context(0)
+    try:
+        small = chain_case(fresh, sdvl, orc, synth, 12)
+        fresh.search_chain(small[0], small[1], small[2], small[3], small[4], fx=TUM_CAM[0])
+        reqs2, cam2, sp2, trackers2, pts2, g_ref, g_cur = chain_case(fresh, sdvl, orc, synth, 300)
+        got_res, got = fresh.search_chain(reqs2, cam2, sp2, trackers2, pts2, fx=TUM_CAM[0])
+        for a, b in zip(got_res, want_res):
+            assert (a.found, a.level, a.best_corner, a.stage, a.lk_its, a.slevel, a.px[0], a.px[1]) == \
+                   (b.found, b.level, b.best_corner, b.stage, b.lk_its, b.slevel, b.px[0], b.px[1])
+        for g, w in zip(got, want):
+            assert g["n_obs"] == w["n_obs"] and g["n_draws"] == w["n_draws"]
+            assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["outliers"], w["outliers"]) and np.array_equal(g["pose"], w["pose"])
+        for f in (small[5], small[6], g_ref, g_cur):
+            f.close()
+    finally:
+        fresh.close()
+    f_ref.close(); f_cur.close()
+
+
+def test_context_of_a_fresh_thread_allocates_on_its_own_gpu(sdvl):
+    """HIP's current device is per thread and starts at 0: a context's scratch must land on the context's GPU whichever thread
+    grows it (farm workers, fibers, a mapper thread).  With one GPU the check is trivial but still runs the code path."""
+    import ctypes as C
+    import threading
+    import torch
+    lib = sdvl.load_library()
+    dev = torch.cuda.device_count() - 1
+    out = {}
+
+    def work():
+        h = C.c_void_p()
+        assert lib.sdvl_ctx_create(dev, C.byref(h)) == 0
+        d = C.c_int(-1)
+        rc = lib.sdvl_ctx_scratch_device(h, C.byref(d))
+        out["rc"], out["scratch"] = rc, d.value
+        out["ctx_dev"] = lib.sdvl_ctx_device(h)
+        lib.sdvl_ctx_destroy(h)
+
+    def grow_elsewhere():
+        # the context is created on this thread, its buffers grow on ANOTHER fresh thread (whose current device is 0)
+        h = C.c_void_p()
+        assert lib.sdvl_ctx_create(dev, C.byref(h)) == 0
+        res = {}
+
+        def grow():
+            d = C.c_int(-1)
+            res["rc"] = lib.sdvl_ctx_scratch_device(h, C.byref(d))
+            res["dev"] = d.value
+        t2 = threading.Thread(target=grow)
+        t2.start(); t2.join()
+        out["rc2"], out["scratch2"] = res["rc"], res["dev"]
+        lib.sdvl_ctx_destroy(h)
+
+    for fn in (work, grow_elsewhere):
+        t = threading.Thread(target=fn)
+        t.start(); t.join()
+    assert out["rc"] == 0 and out["rc2"] == 0
+    assert out["ctx_dev"] == dev and out["scratch"] == dev and out["scratch2"] == dev
 
 
 def test_align_patches_bit_exact_and_recovers_shift(ctx, sdvl, orc, synth):
