@@ -352,6 +352,114 @@ int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
                           const double *req_point, int n_rand, const int32_t *rand_raw, const sdvl_pose_params *pp);
 int sdvl_search_chain_end(sdvl_ctx *ctx, int n_frames, sdvl_pose_result *results, int32_t *n_obs, int32_t *lists);
 
+/* ---- device-resident tracking state: SDVL::ProcessFrame without the host in the loop (sdvl.cc:175-203) ----------------
+ * What FeatureAlign::Reproject reads every frame — the features of last_frame and the points behind them
+ * (feature_align.cc:296-339: position, score; :105-125: the point's first observation, inverse depth, descriptor) — lives in
+ * HBM, one table per tracker, and one submission does for n trackers what ProcessFrame does between the Frame constructor
+ * and the keyframe decision:
+ *   ImageAlign::ComputePose(last_frame, frame)                                        image_align.cc:46-84
+ *   FeatureAlign::Reproject: ProjectPoints, the shuffled cell order, the per-cell sort by Point::Score, SearchPoint for every
+ *     candidate, first hit per cell, max_matches, Promote / Unpromote / MaxFailed     feature_align.cc:59-150,285-339
+ *   SelectInliers + OptimizePose + RemoveOutliers                                      feature_align.cc:73-82,152-283
+ * and leaves the new frame's features (the matches) in the tracker's OTHER feature buffer; the caller decides afterwards
+ * whether the frame replaces last_frame (sdvl.cc:104-123) by naming the buffer in the next job.  rand() stays on the host:
+ * the caller passes the cell order it shuffled and the next max_ransac_its raw draws, and advances its stream by n_draws.
+ * Per tracker and frame ~1 KB goes to the device and ~100 B + the match list come back; no Feature / Point object is touched.
+ * A table is (re)built from host objects with sdvl_track_upload (keyframes: new points appear, bootstrap, relocalisation).
+ * All frames named by a table or a job must have been created on the table's context. */
+typedef struct sdvl_track_set sdvl_track_set;
+
+typedef struct sdvl_track_point { /* what the tracker reads of one Point (point.h) */
+  double position[3];     /* Point::GetPosition() */
+  double px[2];           /* GetInitFeature()->GetPosition() */
+  double bearing[3];      /* GetInitFeature()->GetVector() */
+  double idepth, idepth_std; /* GetInverseDepth(), GetStd() */
+  const sdvl_frame *ref;  /* GetInitFeature()->GetFrame(), registered with sdvl_frame_register */
+  int32_t level, fixed;   /* GetInitFeature()->GetLevel(), IsFixed() */
+  int32_t score, n_failed;/* n_successful_ (Score()), n_failed_ */
+  int32_t last_frame;     /* GetLastFrame() */
+  int32_t status;         /* GetStatus() as int */
+  uint8_t desc[32];       /* GetInitFeature()->GetDescriptor() */
+} sdvl_track_point;
+
+typedef struct sdvl_track_feature { /* one Feature of last_frame (feature.h) */
+  double px[2];       /* GetPosition() */
+  double bearing[3];  /* GetVector() */
+  int32_t level;
+  int32_t point;      /* index into the tracker's points, -1 = no point (or ToDelete); | SDVL_TRACK_DUPLICATE when an
+                         earlier feature of the list has the same point (ProjectPoints skips it, feature_align.cc:310) */
+} sdvl_track_feature;
+#define SDVL_TRACK_DUPLICATE 0x40000000
+
+typedef struct sdvl_track_params {
+  sdvl_align_params align;
+  sdvl_search_params search;
+  sdvl_pose_params pose;
+  int32_t cell_size;   /* Config::CellSize(): FeatureAlign's grid */
+  int32_t patch_size;  /* Config::PatchSize(): margin of ProjectPoint's IsInsideImage */
+  int32_t max_failed;  /* Config::MaxFailed(): Point::Unpromote */
+  int32_t pad_;
+} sdvl_track_params;
+
+typedef struct sdvl_track_job {
+  int32_t tracker;        /* table */
+  int32_t feat_buf;       /* which of the tracker's two feature buffers holds last_frame's features; results go to the other */
+  const sdvl_frame *last; /* last_frame */
+  sdvl_frame *cur;        /* the new frame: pyramid built; corners detected before sdvl_track_search */
+  double T[7];            /* start of the alignment, frame2.pose * frame1.pose^-1 (image_align.cc:66) */
+  double last_pose[7];    /* last_frame->GetPose() */
+  int32_t frame_id;       /* frame->GetID() (Point::SetLastFrame) */
+  int32_t max_matches;    /* FeatureAlign max_matches_ */
+} sdvl_track_job;
+
+typedef struct sdvl_track_result {
+  double pose[7];         /* frame->GetPose() after OptimizePose */
+  double align_error;     /* ImageAlign::GetError() */
+  int32_t align_meas, align_iters; /* ComputePose return value; ComputeResiduals evaluations */
+  int32_t n_features;     /* features of last_frame the alignment ran on */
+  int32_t n_requests;     /* SearchPoint evaluations (all candidates, speculatively) */
+  int32_t matches, attempts;       /* GetMatches(), GetAttempts() */
+  int32_t n_draws, n_inliers, n_outliers, refined; /* as sdvl_pose_result */
+  int32_t n_points;       /* Frame::GetNumPoints() of the new frame */
+  int32_t n_deleted;      /* points that crossed MaxFailed this frame (Map::DeletePoint) */
+  int32_t lk_iters;       /* AlignPatch iterations over all requests */
+  int32_t n_corners;      /* corners of the new frame (Frame::GetCorners().size()) */
+  int32_t status;         /* 0, or SDVL_ERR_CAPACITY if a table capacity was exceeded (results invalid) */
+} sdvl_track_result;
+
+typedef struct sdvl_track_feature_out { /* a feature of the new frame as the host needs it to build a Feature */
+  double px[2];
+  int32_t level;
+  int32_t point;   /* index into the tracker's points, -1 after RemoveOutliers */
+} sdvl_track_feature_out;
+
+typedef struct sdvl_track_point_stat { /* the mutable part of a point after the step */
+  int32_t score, n_failed, last_frame;
+  int32_t status;  /* Point::PointStatus | 0x100 when the point was deleted (crossed MaxFailed) */
+} sdvl_track_point_stat;
+
+int sdvl_track_create(sdvl_ctx *ctx, int n_trackers, int max_points, int max_features, int grid_cells, int max_matches,
+                      int max_ransac_its, sdvl_track_set **out);
+int sdvl_track_destroy(sdvl_ctx *ctx, sdvl_track_set *set);
+/* (frame, pose) becomes addressable by tables: keyframes when their pose is final, the bootstrap frame */
+int sdvl_frame_register(sdvl_ctx *ctx, const sdvl_frame *frame, const double *pose7);
+/* replaces the tables of n trackers: trackers[i] gets n_points[i] points and n_features[i] features (concatenated arrays),
+ * its features go to buffer feat_buf[i].  Asynchronous. */
+int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *set, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,
+                      const sdvl_track_point *points, const int32_t *n_features, const sdvl_track_feature *features);
+/* first third of a step: alignment of n_jobs frames against their last frames, queued.  cell_rank[j][grid_cells] = position
+ * of every grid cell in tracker j's shuffled cell_order_; rand_raw[j][max_ransac_its] = its next rand() values. */
+int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *set, int n_jobs, const sdvl_track_job *jobs, const uint16_t *cell_rank,
+                     const int32_t *rand_raw, const sdvl_camera *cam, const sdvl_track_params *p);
+/* second third: reprojection, search, match selection, pose, table update, queued behind whatever the caller queued in
+ * between (sdvl_detect_corners on the new frames) */
+int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *set);
+/* last third: wait, results[n_jobs].  Until the set's next sdvl_track_align, sdvl_track_features / _stats return the new
+ * frame's features (result.matches of them) and the tracker's point statistics (n_points of them) */
+int sdvl_track_collect(sdvl_ctx *ctx, sdvl_track_set *set, int n_jobs, sdvl_track_result *results);
+const sdvl_track_feature_out *sdvl_track_features(const sdvl_track_set *set, int job);
+const sdvl_track_point_stat *sdvl_track_stats(const sdvl_track_set *set, int job);
+
 /* ---- synthetic sequence generator (no dataset ships with the repo) ------------------------------- */
 struct sdvl_synth_view;
 /* renders n views of the textured plane straight into HBM: dev_out + i*frame_bytes, row stride = width */

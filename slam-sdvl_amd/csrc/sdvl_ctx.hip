@@ -3,6 +3,7 @@
 #include <time.h>
 
 #include "sdvl_internal.h"
+#include "sdvl_search_types.h"
 
 // HIP's current device is per THREAD and starts at 0: every host thread that works for a context of GPU n (farm workers,
 // fibers, pool helpers, a user's mapper thread) must select that GPU before it allocates or launches, or its hipMalloc /
@@ -24,6 +25,25 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned) 
   if (pinned) SDVL_HIP_CHECK(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
   else SDVL_HIP_CHECK(ctx, hipMalloc(p, want));
   *cur = want;
+  return SDVL_OK;
+}
+
+int sdvl_registry_reserve(sdvl_ctx *ctx, int extra) {
+  const int need = ctx->registry_next + extra - static_cast<int>(ctx->registry_free.size());
+  if (need <= ctx->registry_cap) return SDVL_OK;
+  int cap = ctx->registry_cap ? ctx->registry_cap : 1024;
+  while (cap < need) cap *= 2;
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  void *fresh = nullptr;
+  SDVL_HIP_CHECK(ctx, hipMalloc(&fresh, sizeof(SearchFramePose) * static_cast<size_t>(cap)));
+  if (ctx->d_registry) {
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(fresh, ctx->d_registry, sizeof(SearchFramePose) * static_cast<size_t>(ctx->registry_cap), hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // nothing queued may still read the old table
+    SDVL_HIP_CHECK(ctx, hipFree(ctx->d_registry));
+  }
+  ctx->d_registry = fresh;
+  ctx->registry_cap = cap;
   return SDVL_OK;
 }
 
@@ -258,6 +278,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->h_flag) (void)hipHostFree(const_cast<uint32_t *>(ctx->h_flag));
   if (ctx->d_nits) (void)hipFree(ctx->d_nits);
+  if (ctx->d_registry) (void)hipFree(ctx->d_registry);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_search) (void)hipHostFree(ctx->h_search);
   if (ctx->d_search) (void)hipFree(ctx->d_search);
@@ -403,6 +424,8 @@ sdvl_frame *frame_bind(const FrameLayout &L, int width, int height, int levels, 
   f->cell_kps = reinterpret_cast<uint32_t *>(base + L.kps_off);
   f->max_cells = L.max_cells;
   f->desc_valid = 0;
+  f->reg_id = -1;
+  f->home = nullptr;
   return f;
 }
 }  // namespace
@@ -427,6 +450,10 @@ int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int
   FrameLayout L;
   SDVL_REQUIRE(ctx, frame_layout(width, height, levels, &L), "image too small for the pyramid depth");
   SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  {
+    const int rc = sdvl_registry_reserve(ctx, n);
+    if (rc) return rc;
+  }
   uint8_t *base = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), L.bytes * static_cast<size_t>(n));
   if (e != hipSuccess) {
@@ -437,6 +464,13 @@ int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int
   if (in_slab) ctx->slabs.push_back(base);
   for (int i = 0; i < n; i++) {
     out[i] = frame_bind(L, width, height, levels, base + L.bytes * static_cast<size_t>(i), in_slab);
+    out[i]->home = ctx;
+    if (!ctx->registry_free.empty()) {
+      out[i]->reg_id = ctx->registry_free.back();
+      ctx->registry_free.pop_back();
+    } else {
+      out[i]->reg_id = ctx->registry_next++;
+    }
     e = hipMemsetAsync(out[i]->v.corner_hdr, 0, 16, ctx->stream);
     if (e != hipSuccess) {
       ctx->err = std::string("hipMemsetAsync(frame): ") + hipGetErrorString(e);
@@ -452,6 +486,7 @@ int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f) {
     SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
     SDVL_HIP_CHECK(ctx, hipFree(f->base));
   }
+  if (f->home == ctx && f->reg_id >= 0) ctx->registry_free.push_back(f->reg_id);
   delete f;
   return SDVL_OK;
 }

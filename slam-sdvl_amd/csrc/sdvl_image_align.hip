@@ -604,13 +604,12 @@ size_t ia_lds_bytes(int max_f) {
 
 }  // namespace
 
-// launch + result copy, no wait: the caller may queue more work on the context (kernels that neither read results nor use
-// the context's result buffers: sdvl_pyramid_build, sdvl_detect_corners, sdvl_orb_describe) before sdvl_image_align_end
-extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
-                                      const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p) {
-  if (!ctx || !cam || !p || n_jobs < 0 || (n_jobs > 0 && !jobs) || n_features < 0 || (n_features > 0 && !features)) return SDVL_ERR_INVALID;
-  ctx->align_pending = 0;
-  if (n_jobs == 0) return SDVL_OK;
+// Queues the alignment of n_jobs frame pairs (no wait).  The feature records come from the host (`features`, staged and
+// copied here) or already sit in HBM (`d_features`, written by sdvl_track.hip).  Results go to `d_results` when given (device
+// memory, nothing returns to the host), otherwise to the context's result buffers for sdvl_image_align_end.
+int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features, const sdvl_align_feature *features,
+                             const sdvl_align_feature *d_features, const sdvl_camera *cam, const sdvl_align_params *p,
+                             sdvl_align_result *d_results) {
   SDVL_REQUIRE(ctx, p->patch_size == 4, "only align_patch_size 4 is supported");
   SDVL_REQUIRE(ctx, p->min_level >= 0 && p->max_level >= p->min_level && p->max_level < SDVL_MAX_LEVELS, "bad align levels");
   SDVL_REQUIRE(ctx, p->max_its >= 0, "bad max_its");
@@ -628,16 +627,20 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
       return SDVL_ERR_CAPACITY;
     }
     if (a.feat_end - a.feat_begin > max_nf) max_nf = a.feat_end - a.feat_begin;
-    work += static_cast<size_t>(a.feat_end - a.feat_begin) * 16 * (sizeof(float) + 6 * sizeof(double));
-    work = (work + 255) / 256 * 256;
   }
+  const bool use_lds = max_nf <= kLdsMaxF && !getenv("SDVL_IMAGE_ALIGN_GENERIC");
+  if (!use_lds)  // the global-memory variant keeps its patch / Jacobian caches in the work buffer
+    for (int j = 0; j < n_jobs; j++) {
+      work += static_cast<size_t>(jobs[j].feat_end - jobs[j].feat_begin) * 16 * (sizeof(float) + 6 * sizeof(double));
+      work = (work + 255) / 256 * 256;
+    }
   const size_t job_bytes = (sizeof(IaJob) * n_jobs + 255) / 256 * 256;
-  const size_t feat_bytes = sizeof(sdvl_align_feature) * static_cast<size_t>(n_features);
+  const size_t feat_bytes = d_features ? 0 : sizeof(sdvl_align_feature) * static_cast<size_t>(n_features);
   const size_t res_bytes = sizeof(sdvl_align_result) * n_jobs;
   void *hs = nullptr, *dsx = nullptr;
   int rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, work + 256, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, res_bytes, false);
-  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, res_bytes, true);
+  if (!rc && !d_results) rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, res_bytes, false);
+  if (!rc && !d_results) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, res_bytes, true);
   if (!rc) rc = sdvl_stage_alloc(ctx, job_bytes + feat_bytes, &hs, &dsx);
   if (rc) return rc;
   IaJob *hj = static_cast<IaJob *>(hs);
@@ -656,17 +659,20 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
     d.feat_begin = a.feat_begin;
     d.n_feat = a.feat_end - a.feat_begin;
     for (int k = 0; k < 7; k++) d.T[k] = a.T[k];
-    const size_t items = static_cast<size_t>(d.n_feat) * 16;
-    d.jac_cache = reinterpret_cast<double *>(wbase + woff);
-    d.patch_cache = reinterpret_cast<float *>(wbase + woff + items * 6 * sizeof(double));
-    woff += items * (sizeof(float) + 6 * sizeof(double));
-    woff = (woff + 255) / 256 * 256;
+    if (!use_lds) {
+      const size_t items = static_cast<size_t>(d.n_feat) * 16;
+      d.jac_cache = reinterpret_cast<double *>(wbase + woff);
+      d.patch_cache = reinterpret_cast<float *>(wbase + woff + items * 6 * sizeof(double));
+      woff += items * (sizeof(float) + 6 * sizeof(double));
+      woff = (woff + 255) / 256 * 256;
+    }
   }
   if (feat_bytes) memcpy(static_cast<uint8_t *>(hs) + job_bytes, features, feat_bytes);
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, job_bytes + feat_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const sdvl_align_feature *feats_dev = d_features ? d_features : reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes);
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  const bool use_lds = max_nf <= kLdsMaxF && !getenv("SDVL_IMAGE_ALIGN_GENERIC");
   const bool direct = sdvl_direct_results();
+  sdvl_align_result *dst = d_results ? d_results : static_cast<sdvl_align_result *>(direct ? ctx->h_out : ctx->d_out);
   if (use_lds) {
     const int max_f = (max_nf + 7) / 8 * 8 + 8;
     const size_t lds = ia_lds_bytes(max_f);
@@ -682,15 +688,24 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
     hipExtLaunchKernelGGL(image_align_lds_kernel, dim3(n_jobs), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
-                          reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p, max_f,
-                          static_cast<sdvl_align_result *>(direct ? ctx->h_out : ctx->d_out));
+                          feats_dev, c, *p, max_f, dst);
   } else {
-    SDVL_LAUNCH(ctx, "image_align", image_align_kernel, dim3(n_jobs), dim3(kThreads), static_cast<const IaJob *>(dsx),
-                reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes), c, *p,
-                static_cast<sdvl_align_result *>(direct ? ctx->h_out : ctx->d_out));
+    SDVL_LAUNCH(ctx, "image_align", image_align_kernel, dim3(n_jobs), dim3(kThreads), static_cast<const IaJob *>(dsx), feats_dev, c, *p, dst);
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
-  if (!direct) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (!d_results && !direct) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return SDVL_OK;
+}
+
+// launch + result copy, no wait: the caller may queue more work on the context (kernels that neither read results nor use
+// the context's result buffers: sdvl_pyramid_build, sdvl_detect_corners, sdvl_orb_describe) before sdvl_image_align_end
+extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
+                                      const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p) {
+  if (!ctx || !cam || !p || n_jobs < 0 || (n_jobs > 0 && !jobs) || n_features < 0 || (n_features > 0 && !features)) return SDVL_ERR_INVALID;
+  ctx->align_pending = 0;
+  if (n_jobs == 0) return SDVL_OK;
+  const int rc = sdvl_image_align_enqueue(ctx, n_jobs, jobs, n_features, features, nullptr, cam, p, nullptr);
+  if (rc) return rc;
   SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_ALIGN, &ctx->align_ticket));
   ctx->align_pending = n_jobs;
   return SDVL_OK;

@@ -39,6 +39,10 @@ struct sdvl_frame {
   int in_slab;           // storage belongs to a slab owned by the context (sdvl_frame_create_many)
   int hdr_stale;         // device corner header still holds the count of a previous image (reset lazily)
   uint8_t *own_level0;   // the frame's own level-0 storage (level[0] may point at a borrowed caller image)
+  // slot of this frame in its creating context's device-resident (frame, pose) registry: device-resident tracking tables
+  // (sdvl_track.hip) name frames by this index instead of carrying their views through every launch
+  int reg_id;
+  sdvl_ctx *home;
 };
 
 struct KernelTimer {
@@ -63,6 +67,10 @@ struct sdvl_ctx {
   void *h_search = nullptr; size_t h_search_bytes = 0;
   void *d_search = nullptr; size_t d_search_bytes = 0;
   uint64_t search_busy_gen = ~0ull;  // wait_gen when the last batch was queued: its buffers are in use until a later wait
+  // (frame, pose) registry: one SearchFramePose record per frame created on this context, index = sdvl_frame::reg_id
+  void *d_registry = nullptr;
+  int registry_cap = 0, registry_next = 0;
+  std::vector<int> registry_free;
   // corner counts of the last sdvl_detect_corners batch, written by the pack kernel: one D2H serves all frames
   void *d_counts = nullptr; size_t d_counts_bytes = 0;
   std::vector<sdvl_frame *> detect_frames;
@@ -120,6 +128,12 @@ size_t sdvl_pose_hyp_bytes();
 int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
                              const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists);
 
+// sdvl_image_align.hip: queue the alignment of n_jobs pairs; features from the host (`features`) or resident (`d_features`);
+// results to `d_results` (device) or, when null, to the context's result buffers (see sdvl_image_align_begin)
+int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features, const sdvl_align_feature *features,
+                             const sdvl_align_feature *d_features, const sdvl_camera *cam, const sdvl_align_params *p,
+                             sdvl_align_result *d_results);
+
 #define SDVL_HIP_CHECK(ctx, expr)                                                            \
   do {                                                                                       \
     hipError_t e_ = (expr);                                                                  \
@@ -137,6 +151,8 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
     }                                         \
   } while (0)
 
+// room for `extra` more frames in the registry (grows by reallocation + device copy behind a stream wait)
+int sdvl_registry_reserve(sdvl_ctx *ctx, int extra);
 // select the context's GPU on the calling thread (HIP's current device is per thread); cached, one compare when already bound
 hipError_t sdvl_bind_device(const sdvl_ctx *ctx);
 int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);

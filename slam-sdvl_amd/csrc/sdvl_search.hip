@@ -21,54 +21,11 @@
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
 #include "sdvl_orb_device.h"
+#include "sdvl_search_types.h"
 
 namespace {
 
 using namespace sdvl;
-
-constexpr int kWavesPerBlock = 4;  // requests of one workgroup; they all search the SAME current frame (block table)
-constexpr int kLdsCorners = 4096;  // corners of the current frame staged in LDS (16 KB: 8 workgroups per CU); a frame with
-                                   // more (up to SDVL_MAX_CORNERS) has the rest read from HBM / L2
-
-struct SearchBlock {
-  int first, count;  // requests [first, first + count) of the launch, count <= kWavesPerBlock
-};
-
-struct SearchFrame {
-  const uint8_t *level[SDVL_MAX_LEVELS];
-  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
-  const int32_t *corners;
-  const uint8_t *desc;
-  const int32_t *n_ptr;  // device-resident corner count
-  int levels;
-  int pad_;
-};
-
-// (frame, pose) pairs are shared by many requests of a launch: they go into a table, requests carry two indices
-struct SearchFramePose {
-  SearchFrame f;
-  double pose[7];
-  double pad_;
-};
-
-struct SearchReqDev {
-  int cur, ref;  // indices into the SearchFramePose table of the launch
-  int level, fixed;
-  double px[2], bearing[3];
-  double idepth, idepth_std;
-  double px0[2];
-  uint32_t desc[8];
-};
-
-// what the scalar part of SearchPoint (matcher.cc:45-96) leaves for the wave part: one record per request
-struct SearchPrep {
-  int alive, slevel;
-  double pxa[2], pxb[2];        // projected ends of the depth interval (pxb only for epipolar searches)
-  double I00, I01, I10, I11;    // inverse of the affine warp (CreatePatch, matcher.cc:330)
-  // wave-uniform constants of GetCornersInRange (matcher.cc:139-148, 92-94), computed once by the request's lane; the wave
-  // kernel reads the record with scalar loads, so they live in SGPRs instead of 64 copies in VGPRs
-  double nx, ny, normdist, xdiff, ydiff, vline, range, range2;
-};
 
 struct PatchJob {  // sdvl_align_patches
   const uint8_t *img;
@@ -208,7 +165,6 @@ __global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev 
   const int ri = blockIdx.x * 256 + threadIdx.x;
   if (ri >= n) return;
   const SearchReqDev &rq = reqs[ri];
-  const SearchFramePose &tcur = table[rq.cur], &tref = table[rq.ref];
   SearchPrep out;
   out.alive = 0;
   out.slevel = -1;
@@ -216,6 +172,11 @@ __global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev 
   out.I00 = out.I01 = out.I10 = out.I11 = 0.0;
   out.nx = out.ny = out.normdist = out.xdiff = out.ydiff = out.vline = out.range = out.range2 = 0.0;
   const int level = rq.level;
+  if (level < 0) {  // a dead slot of a device-built batch (sdvl_track.hip): no request here
+    prep[ri] = out;
+    return;
+  }
+  const SearchFramePose &tcur = table[rq.cur], &tref = table[rq.ref];
   const Rigid cur_pose = se3_from7(tcur.pose), ref_pose = se3_from7(tref.pose);
   const Rigid ref_world = se3_inverse(ref_pose);
   const Rigid pose = se3_mul(cur_pose, ref_world);
@@ -321,6 +282,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   const int bi = static_cast<int>(blockIdx.x & 7u) * per_xcd + static_cast<int>(blockIdx.x >> 3);
   if (bi >= n_blocks) return;
   const SearchBlock blk = blocks[bi];
+  if (blk.count <= 0) return;  // device-built batches reserve blocks for the most requests a tracker can have
   const SearchFramePose &tcur = table[reqs[blk.first].cur];
   const int n_corners = min(tcur.f.n_ptr[0], SDVL_MAX_CORNERS);
   const int4 *corners_g = reinterpret_cast<const int4 *>(tcur.f.corners);
@@ -543,27 +505,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void align_patches_kernel(cons
 // candidates come cell by cell in the reference's order; a cell's first found candidate is a match; the first
 // max_matches matches are kept.  One workgroup per tracker; the matches leave as pose observations (feature_align.cc:132
 // creates the Feature — bearing = Camera::Unproject(px) — SelectInliers reads bearing/z, the point and 1/2^level).
-struct ChainFrameDev {
-  int cand_begin, cand_end;
-  int max_matches, rand_begin;
-  int obs_begin, pad_;
-  double pose[7];
-  double pad2_;
-};
 constexpr int kChainMaxCand = 16384;  // candidates of one tracker the kernel can flag in LDS
 
 __global__ __launch_bounds__(256) void select_matches_kernel(const ChainFrameDev *__restrict__ frames, const int32_t *__restrict__ cand_req,
                                                              const int32_t *__restrict__ cand_first, const sdvl_search_res *__restrict__ res,
                                                              const double *__restrict__ req_point, Cam cam, PoseJobDev *__restrict__ jobs,
-                                                             sdvl_pose_obs *__restrict__ obs, int32_t *__restrict__ n_obs_out) {
+                                                             sdvl_pose_obs *__restrict__ obs, int32_t *__restrict__ n_obs_out,
+                                                             int32_t *__restrict__ match_cand) {
   __shared__ uint8_t s_found[kChainMaxCand];
   __shared__ int s_wave[4];
   const ChainFrameDev &fr = frames[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = fr.cand_end - fr.cand_begin;
-  const int32_t *creq = cand_req + fr.cand_begin, *cfirst = cand_first + fr.cand_begin;
+  const int32_t *cfirst = cand_first + fr.cand_begin;
+  // cand_req == nullptr: candidate k was searched with request cand_begin + k (batches built on the device)
+  const auto req_of = [&](int k) { return cand_req ? cand_req[fr.cand_begin + k] : fr.cand_begin + k; };
   for (int k = tid; k < n; k += 256) {
-    const int r = creq[k];
+    const int r = req_of(k);
     s_found[k] = (r >= 0 && res[r].found != 0) ? 1 : 0;
   }
   __syncthreads();
@@ -585,12 +543,13 @@ __global__ __launch_bounds__(256) void select_matches_kernel(const ChainFrameDev
     for (int w = 0; w < wave; w++) base += s_wave[w];
     const int rank = base + below;
     if (sel && rank < fr.max_matches) {
-      const sdvl_search_res &r = res[creq[k]];
+      const sdvl_search_res &r = res[req_of(k)];
+      if (match_cand) match_cand[fr.obs_begin + rank] = k;
       const V3 v = cam_unproject(cam, {r.px[0], r.px[1]});
       sdvl_pose_obs o;
       o.ax = v.x / v.z;
       o.ay = v.y / v.z;
-      const double *P = req_point + 3 * static_cast<size_t>(creq[k]);
+      const double *P = req_point + 3 * static_cast<size_t>(req_of(k));
       o.px = P[0];
       o.py = P[1];
       o.pz = P[2];
@@ -627,6 +586,32 @@ void fill_frame(SearchFrame *d, const sdvl_frame *f) {
 }
 
 }  // namespace
+
+int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_reqs, const SearchFramePose *d_table,
+                              const SearchBlock *d_blocks, int n_blocks, const sdvl_camera *cam, const sdvl_search_params *p,
+                              SearchPrep *d_prep, sdvl_search_res *d_res, sdvl_search_res *h_res) {
+  SDVL_REQUIRE(ctx, p->patch_size == 8, "only patch_size 8 is supported (one wave64 per 8x8 patch)");
+  SDVL_REQUIRE(ctx, p->max_fast_levels >= 1 && p->max_fast_levels <= 4, "bad max_fast_levels");
+  SDVL_REQUIRE(ctx, p->max_align_its >= 0 && p->margin >= 4, "bad max_align_its / margin");
+  if (n_slots <= 0 || n_blocks <= 0) return SDVL_OK;
+  Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n_slots + 255) / 256), dim3(256), d_reqs, d_table, n_slots, c, *p, d_prep);
+  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock), d_reqs,
+              d_table, d_blocks, static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, d_res, h_res);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  return SDVL_OK;
+}
+
+int sdvl_select_matches_launch(sdvl_ctx *ctx, int n_frames, const ChainFrameDev *d_frames, const int32_t *d_cand_req,
+                               const int32_t *d_cand_first, const sdvl_search_res *d_res, const double *d_req_point,
+                               const sdvl_camera *cam, PoseJobDev *d_jobs, sdvl_pose_obs *d_obs, int32_t *d_nobs, int32_t *d_match_cand) {
+  if (n_frames <= 0) return SDVL_OK;
+  Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  SDVL_LAUNCH(ctx, "select_matches", select_matches_kernel, dim3(n_frames), dim3(256), d_frames, d_cand_req, d_cand_first, d_res, d_req_point, c,
+              d_jobs, d_obs, d_nobs, d_match_cand);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  return SDVL_OK;
+}
 
 extern "C" {
 
@@ -774,7 +759,7 @@ int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_sea
 // ---- sdvl_search_run_chain / sdvl_search_chain_end
 // SelectInliers' iteration budget as a function of the supporter count (feature_align.cc:199-207), for every match count
 // up to max_size: row s (s + 1 entries) starts at s*(s+1)/2.  Two libm log() per entry, computed once per configuration.
-static int ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int max_size) {
+int sdvl_ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int max_size) {
   if (ctx->d_nits && ctx->nits_points == npoints_cfg && ctx->nits_its == max_its && ctx->nits_max_size >= max_size) return SDVL_OK;
   const size_t entries = static_cast<size_t>(max_size + 1) * (max_size + 2) / 2;
   std::vector<int32_t> &t = ctx->nits_host;
@@ -833,7 +818,7 @@ int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
     SDVL_REQUIRE(ctx, cand_first[k] >= 0 && cand_first[k] <= k, "cand_first must point at or before the candidate");
   }
   for (int k = 0; k < n_rand; k++) SDVL_REQUIRE(ctx, rand_raw[k] >= 0, "rand() values are non-negative");
-  int rc = ensure_nits_table(ctx, pp->max_ransac_points, pp->max_ransac_its, max_size);
+  int rc = sdvl_ensure_nits_table(ctx, pp->max_ransac_points, pp->max_ransac_its, max_size);
   if (rc) return rc;
   // behind the search's buffers — device: jobs | obs | hypotheses | results | n_obs | lists ; host: results | n_obs | lists
   const size_t jb = (sizeof(PoseJobDev) * n_frames + 255) / 256 * 256, ob = (sizeof(sdvl_pose_obs) * static_cast<size_t>(obs_total) + 255) / 256 * 256;
@@ -881,7 +866,8 @@ int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   SDVL_LAUNCH(ctx, "select_matches", select_matches_kernel, dim3(n_frames), dim3(256), reinterpret_cast<const ChainFrameDev *>(d8),
               reinterpret_cast<const int32_t *>(d8 + fb), reinterpret_cast<const int32_t *>(d8 + fb + cb),
-              static_cast<const sdvl_search_res *>(ctx->d_out), reinterpret_cast<const double *>(d8 + fb + 2 * cb), c, d_jobs, d_obs, d_nobs);
+              static_cast<const sdvl_search_res *>(ctx->d_out), reinterpret_cast<const double *>(d8 + fb + 2 * cb), c, d_jobs, d_obs, d_nobs,
+              static_cast<int32_t *>(nullptr));
   sdvl_pose_params prm = *pp;
   prm.pad_ = 1;  // raw rand() values: the kernel reduces them modulo the match count it finds in the job
   rc = sdvl_pose_enqueue_device(ctx, n_frames, d_jobs, d_obs, reinterpret_cast<const int32_t *>(d8 + fb + 2 * cb + pb),

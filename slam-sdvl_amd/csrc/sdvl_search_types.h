@@ -1,0 +1,77 @@
+// sdvl_search_types.h — device records of the search stage (sdvl_search.hip), shared with the device-resident tracking
+// tables (sdvl_track.hip), which write them on the device instead of receiving them from the host.
+#ifndef SDVL_SEARCH_TYPES_H_
+#define SDVL_SEARCH_TYPES_H_
+
+#include "sdvl_internal.h"
+#include "sdvl_math.h"
+
+constexpr int kWavesPerBlock = 4;  // requests of one workgroup; they all search the SAME current frame (block table)
+constexpr int kLdsCorners = 4096;  // corners of the current frame staged in LDS (16 KB: 8 workgroups per CU); a frame with
+                                   // more (up to SDVL_MAX_CORNERS) has the rest read from HBM / L2
+
+struct SearchBlock {
+  int first, count;  // requests [first, first + count) of the launch, count <= kWavesPerBlock
+};
+
+struct SearchFrame {
+  const uint8_t *level[SDVL_MAX_LEVELS];
+  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
+  const int32_t *corners;
+  const uint8_t *desc;
+  const int32_t *n_ptr;  // device-resident corner count
+  int levels;
+  int pad_;
+};
+
+// (frame, pose) pairs are shared by many requests of a launch: they go into a table, requests carry two indices
+struct SearchFramePose {
+  SearchFrame f;
+  double pose[7];
+  double pad_;
+};
+
+struct SearchReqDev {
+  int cur, ref;  // indices into the SearchFramePose table of the launch
+  int level, fixed;
+  double px[2], bearing[3];
+  double idepth, idepth_std;
+  double px0[2];
+  uint32_t desc[8];
+};
+
+// what the scalar part of SearchPoint (matcher.cc:45-96) leaves for the wave part: one record per request
+struct SearchPrep {
+  int alive, slevel;
+  double pxa[2], pxb[2];        // projected ends of the depth interval (pxb only for epipolar searches)
+  double I00, I01, I10, I11;    // inverse of the affine warp (CreatePatch, matcher.cc:330)
+  // wave-uniform constants of GetCornersInRange (matcher.cc:139-148, 92-94), computed once by the request's lane; the wave
+  // kernel reads the record with scalar loads, so they live in SGPRs instead of 64 copies in VGPRs
+  double nx, ny, normdist, xdiff, ydiff, vline, range, range2;
+};
+
+struct ChainFrameDev {
+  int cand_begin, cand_end;
+  int max_matches, rand_begin;
+  int obs_begin, pad_;
+  double pose[7];
+  double pad2_;
+};
+
+// ---- launch helpers of sdvl_search.hip for callers whose records already live in HBM (no copies, no wait) --------------
+// search_prepare + search_points over n_slots request records (a record with level < 0 is a dead slot) dealt to workgroups
+// by the n_blocks entries of d_blocks (a block with count 0 is skipped); d_res receives one result per slot, h_res (may
+// be null) the same records in pinned host memory
+int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_reqs, const SearchFramePose *d_table,
+                              const SearchBlock *d_blocks, int n_blocks, const sdvl_camera *cam, const sdvl_search_params *p,
+                              SearchPrep *d_prep, sdvl_search_res *d_res, sdvl_search_res *h_res);
+// second half of SelectPoints for n_frames trackers (feature_align.cc:105-149): d_cand_req may be null (candidate k of a
+// tracker = request cand_begin + k); d_match_cand (may be null) receives, per selected match, its candidate index
+// relative to cand_begin, at obs_begin + rank
+int sdvl_select_matches_launch(sdvl_ctx *ctx, int n_frames, const ChainFrameDev *d_frames, const int32_t *d_cand_req,
+                               const int32_t *d_cand_first, const sdvl_search_res *d_res, const double *d_req_point,
+                               const sdvl_camera *cam, PoseJobDev *d_jobs, sdvl_pose_obs *d_obs, int32_t *d_nobs, int32_t *d_match_cand);
+// the iteration-budget table of SelectInliers for all match counts up to max_size, resident in HBM (ctx->d_nits)
+extern "C" int sdvl_ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int max_size);
+
+#endif  // SDVL_SEARCH_TYPES_H_

@@ -1,6 +1,7 @@
 // capi.cc — flat C entry points over the host layer (sdvl_host.h) for the Python harness (tests, smoke, bench):
 // B independent SDVL trackers on one MI355X stepping together through sdvl::SDVLBatch.
 #include <dlfcn.h>
+#include <malloc.h>
 #include <execinfo.h>
 #include <signal.h>
 #include <sys/mman.h>
@@ -151,6 +152,32 @@ int sdvlh_camera_undistort(void *device, int w, int h, const double *cam4, const
     g_err = e.what();
     return -1;
   }
+}
+
+// device-resident tracking tables on (default) / off for the batches stepping from now on; process-wide
+void sdvlh_set_track_tables(int on) { SDVLBatch::SetTrackTables(on != 0); }
+int sdvlh_track_tables() { return SDVLBatch::TrackTables() ? 1 : 0; }
+
+// test hook: a digest of the map state of tracker i after SyncHostState — the points reachable from its keyframes' features
+// (each once): count, sum of Score(), sum of failure counts, deleted ones, sum of inverse depths, sum of GetStd()
+int sdvlh_batch_point_digest(void *bp, int i, double *out6) {
+  Batch *b = static_cast<Batch *>(bp);
+  Device::SetCurrent(b->dev);
+  b->batch->SyncHostState();
+  std::set<Point *> seen;
+  for (int k = 0; k < 6; k++) out6[k] = 0.0;
+  for (auto &kf : b->maps[i]->GetKeyframes())
+    for (auto &ft : kf->GetFeatures()) {
+      Point *p = ft ? ft->GetPointRaw() : nullptr;
+      if (!p || !seen.insert(p).second) continue;
+      out6[0] += 1.0;
+      out6[1] += p->Score();
+      out6[2] += p->GetFailed();
+      out6[3] += p->ToDelete() ? 1.0 : 0.0;
+      out6[4] += p->GetInverseDepth();
+      out6[5] += p->GetStd();
+    }
+  return 0;
 }
 
 // pose stage on the device (default) or with the host implementation; process-wide
@@ -427,6 +454,12 @@ void Farm::RunShareFibers(int worker, int n_workers) {
 
 void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4, const double *plane4, const double *first_poses7,
                         int host_threads_per_group) {
+  // G host threads allocate and free small objects all the time while their keyframes keep ~100 KB each for good: with the
+  // default settings every per-thread malloc arena grows in 128 KB steps (one mprotect each, all serialised on the process's
+  // address-space lock together with the page faults) and gives memory back as eagerly.  Grow in 32 MB steps, never trim.
+  mallopt(M_TOP_PAD, 32 << 20);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_MMAP_THRESHOLD, 16 << 20);
   Farm *f = new Farm();
   f->gpu = gpu; f->G = G; f->Bg = Bg; f->w = w; f->h = h;
   for (int g = 0; g < G; g++) {

@@ -154,6 +154,10 @@ bool Point::SeenFrom(const shared_ptr<Frame> &frame) const {
 // frame.cc:70-92
 double Frame::GetSceneDepth() {
   vector<double> depth_vec;
+  if (flat_) {  // features still flat records of the tracking tables: same points in the same order, no objects needed
+    for (const sdvl_track_feature_out &f : flat_->feats)
+      if (f.point >= 0) depth_vec.push_back(GetRelativePos((*flat_->points)[f.point]->GetPosition())(2));
+  }
   for (auto it = features_.begin(); it != features_.end(); it++) {
     if (!(*it)) continue;
     Point *point = (*it)->GetPointRaw();

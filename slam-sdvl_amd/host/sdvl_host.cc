@@ -548,6 +548,7 @@ FrameArena *Frame::NewArena() const { return new FrameArena(owner_ ? owner_->chu
 
 Frame::~Frame() {
   features_.clear();
+  DropFlat();
   if (arena_) arena_->Release();  // the arena goes with the last object carved out of it
   if (dev_ && owner_) {
     sdvl_frame *f = dev_;  // hand the HBM frame back to the pool
@@ -699,7 +700,8 @@ void Frame::FilterCornersEnd(const vector<shared_ptr<Frame>> &frames) {
       f.corners_on_host_ = true;
     }
     FastDetector detector(f.width_, f.height_);
-    for (auto it = f.features_.begin(); it != f.features_.end(); it++) detector.LockCell((*it)->GetPosition());
+    vector<shared_ptr<Feature>> &kf_features = f.GetFeatures();
+    for (auto it = kf_features.begin(); it != kf_features.end(); it++) detector.LockCell((*it)->GetPosition());
     detector.FilterWithScores(f.pyramid_, f.corners_, scores.data() + i * cap, &f.filtered_corners_);
     // frame.cc:145-161 mirrors the descriptors of the filtered corners one std::vector each; here the frame's whole block
     if (orb) f.desc_flat_.assign(desc.begin() + i * cap * 32, desc.begin() + (i * cap + cnt) * 32);
@@ -709,6 +711,10 @@ void Frame::FilterCornersEnd(const vector<shared_ptr<Frame>> &frames) {
 // frame.cc:165-179
 int Frame::GetNumPoints() const {
   int count = 0;
+  if (flat_) {  // not materialised yet: a record with a point index is a feature with a point
+    for (const sdvl_track_feature_out &f : flat_->feats) count += f.point >= 0 ? 1 : 0;
+    return count;
+  }
   for (auto it = features_.begin(); it != features_.end(); it++) {
     if (!(*it)) continue;
     if (!(*it)->GetPointRaw()) continue;
@@ -723,6 +729,48 @@ bool Frame::Project(const Vector3d &p3D, Vector2d *p2D) {
   if (rel_p(2) < 0.0) return false;
   camera_->Project(rel_p, p2D);
   return true;
+}
+
+// features of a frame the device-resident tables tracked: flat records now, Feature objects on first use
+void Frame::SetFlatFeatures(const sdvl_track_feature_out *feats, int n, const shared_ptr<PointTable> &points) {
+  features_.clear();
+  DropFlat();
+  if (!arena_) arena_ = NewArena();
+  sdvl_track_feature_out *dst = nullptr;
+  if (n > 0) {
+    dst = static_cast<sdvl_track_feature_out *>(arena_->Allocate(sizeof(sdvl_track_feature_out) * static_cast<size_t>(n), alignof(sdvl_track_feature_out)));
+    std::memcpy(dst, feats, sizeof(sdvl_track_feature_out) * static_cast<size_t>(n));
+  }
+  flat_store_.feats.data = dst;
+  flat_store_.feats.n = n;
+  flat_store_.points = points;
+  flat_ = &flat_store_;
+}
+
+void Frame::DropFlat() {
+  if (!flat_) return;
+  if (flat_store_.feats.data) arena_->Release();  // the block counted as one object of the arena
+  flat_store_.feats.data = nullptr;
+  flat_store_.feats.n = 0;
+  flat_store_.points.reset();
+  flat_ = nullptr;
+}
+
+// what SelectPoints + RemoveOutliers leave on the frame (feature_align.cc:127-134,245-256): one Feature per match in match
+// order, linked to its point unless the pose stage called it an outlier (those positions also go to the outlier list)
+void Frame::MaterializeFeatures() {
+  const FlatSpan feats = flat_store_.feats;
+  const shared_ptr<PointTable> points = flat_store_.points;
+  flat_ = nullptr;  // GetFeatures() below must not come back here
+  features_.reserve(features_.size() + feats.size());
+  for (const sdvl_track_feature_out &f : feats) {
+    shared_ptr<Feature> feature = NewFeature(Vector2d(f.px[0], f.px[1]), f.level);
+    if (f.point >= 0) feature->SetPoint((*points)[f.point]);
+    else outliers_.push_back(feature->GetPosition());
+    features_.push_back(std::move(feature));
+  }
+  flat_ = &flat_store_;
+  DropFlat();
 }
 
 // ----------------------------------------------------------------------------------------------------- ImageAlign
@@ -1122,6 +1170,26 @@ void FeatureAlign::PeekRand(int n, vector<int32_t> *out) const {
   for (int h = 0; h < n; h++) out->push_back(peek.Next());
 }
 
+void FeatureAlign::ShuffleCellRanks(uint16_t *rank_of_cell) {
+  rng_->Shuffle(&cell_order_);
+  for (size_t i = 0; i < cell_order_.size(); i++) rank_of_cell[cell_order_[i]] = static_cast<uint16_t>(i);
+}
+
+void FeatureAlign::AdvanceRand(int n) {
+  for (int k = 0; k < n; k++) rng_->Next();
+}
+
+void FeatureAlign::SetTrackedCounts(int matches, int attempts, int inliers, int outliers) {
+  matches_ = matches;
+  num_attempts_ = attempts;
+  found_.clear();
+  obs_.clear();
+  plan_.clear();
+  last_frame_.reset();
+  inliers_.assign(inliers, 0);
+  outliers_.assign(outliers, 0);
+}
+
 // feature_align.cc:59-71 tail: SelectPoints replay, then SelectInliers
 void FeatureAlign::FinishReproject(const shared_ptr<Frame> &frame, const sdvl_search_res *res) {
   FinishSelect(frame, res);
@@ -1475,6 +1543,7 @@ void SDVL::CalcTrackingQuality(int matches, int attempts) {
 
 bool SDVL::HandleFrame(const Image &img) {
   SDVLBatch one(Device::Current(), {this}, 1);
+  one.persistent_ = false;  // a one-call batch: no device-resident tables to amortise
   FrameStats st;
   one.HandleFrames({img}, &st);
   return true;
@@ -1582,7 +1651,12 @@ static Pool *g_pool_of(void *&slot, int threads) {
 }
 
 SDVLBatch::SDVLBatch(Device *dev, const vector<SDVL *> &trackers, int host_threads) : dev_(dev), trk_(trackers), threads_(host_threads) {}
-SDVLBatch::~SDVLBatch() {}
+SDVLBatch::~SDVLBatch() {
+  if (track_) {
+    Device::SetCurrent(dev_);
+    sdvl_track_destroy(dev_->ctx(), track_);
+  }
+}
 
 static thread_local void *g_pool_slot = nullptr;
 static thread_local int g_pool_threads = 0;
@@ -1610,15 +1684,352 @@ bool SDVLBatch::DevicePose() {
   return g_device_pose != 0;
 }
 
-// SDVL::HandleFrame (sdvl.cc:55-130) for B trackers, stage by stage
+static int g_track_tables = -1;  // -1: not decided yet (environment)
+void SDVLBatch::SetTrackTables(bool on) { g_track_tables = on ? 1 : 0; }
+bool SDVLBatch::TrackTables() {
+  if (g_track_tables < 0) g_track_tables = std::getenv("SDVL_NO_TRACK_TABLES") ? 0 : 1;
+  return g_track_tables != 0;
+}
+
+// The counters the device advanced (Promote / Unpromote / SetLastFrame / status) reach the Point objects.
+void SDVLBatch::SyncStats(SDVL &t) {
+  SDVL::TrackState &ts = t.track_;
+  if (!ts.stats_dirty || !ts.points) return;
+  const size_t n = std::min(ts.stats.size(), ts.points->size());
+  for (size_t p = 0; p < n; p++) {
+    const sdvl_track_point_stat &s = ts.stats[p];
+    (*ts.points)[p]->SetTrackCounters(s.score, s.n_failed, s.last_frame, static_cast<Point::PointStatus>(s.status & 0xFF));
+  }
+  ts.stats_dirty = false;
+}
+
+void SDVLBatch::SyncHostState() {
+  for (SDVL *t : trk_) {
+    SyncStats(*t);
+    if (t->last_frame_ && t->last_frame_->HasFlatFeatures()) t->last_frame_->GetFeatures();
+  }
+}
+
+// last_frame's features and the points behind them as table rows (include/sdvl_hip.h: sdvl_track_point / _feature).
+// false: something the tables cannot express (a point without a first observation or whose keyframe is gone) — the step
+// then runs on the host path.
+bool SDVLBatch::BuildTable(SDVL &t, vector<sdvl_track_point> *points, vector<sdvl_track_feature> *feats) {
+  SyncStats(t);
+  vector<shared_ptr<Feature>> &features = t.last_frame_->GetFeatures();
+  if (static_cast<int>(features.size()) > track_cap_) return false;
+  auto table = std::make_shared<Frame::PointTable>();
+  table->reserve(features.size());
+  // a point may sit behind several features of a keyframe: ProjectPoints takes the first and skips the rest
+  // (feature_align.cc:310: the point already carries this frame's id)
+  struct Slot { Point *p; int idx; };
+  static thread_local vector<Slot> hash;
+  size_t hcap = 64;
+  while (hcap < features.size() * 2) hcap *= 2;
+  hash.assign(hcap, Slot{nullptr, -1});
+  const size_t p0 = points->size();
+  for (auto &ftp : features) {
+    Feature *ft = ftp.get();
+    sdvl_track_feature f;
+    if (!ft) return false;
+    f.px[0] = ft->GetPosition()(0); f.px[1] = ft->GetPosition()(1);
+    f.bearing[0] = ft->GetVector()(0); f.bearing[1] = ft->GetVector()(1); f.bearing[2] = ft->GetVector()(2);
+    f.level = ft->GetLevel();
+    f.point = -1;
+    Point *pt = ft->GetPointRaw();
+    if (pt && !pt->ToDelete()) {
+      size_t h = (reinterpret_cast<uintptr_t>(pt) >> 4) & (hcap - 1);
+      while (hash[h].p && hash[h].p != pt) h = (h + 1) & (hcap - 1);
+      if (hash[h].p) {
+        f.point = hash[h].idx | SDVL_TRACK_DUPLICATE;
+      } else {
+        Feature *init = pt->GetInitFeatureRaw();
+        Frame *ref = init ? init->GetFrameRaw() : nullptr;
+        if (!init || !ref || ref->owner() != dev_) return false;
+        const int idx = static_cast<int>(table->size());
+        hash[h] = Slot{pt, idx};
+        f.point = idx;
+        table->push_back(ft->GetPoint());
+        points->emplace_back();
+        sdvl_track_point &tp = points->back();
+        const Vector3d P = pt->GetPosition();
+        tp.position[0] = P(0); tp.position[1] = P(1); tp.position[2] = P(2);
+        tp.px[0] = init->GetPosition()(0); tp.px[1] = init->GetPosition()(1);
+        tp.bearing[0] = init->GetVector()(0); tp.bearing[1] = init->GetVector()(1); tp.bearing[2] = init->GetVector()(2);
+        tp.idepth = pt->GetInverseDepth();
+        tp.idepth_std = pt->GetStd();
+        tp.ref = ref->device();
+        tp.level = init->GetLevel();
+        tp.fixed = pt->IsFixed() ? 1 : 0;
+        tp.score = pt->Score();
+        tp.n_failed = pt->GetFailed();
+        tp.last_frame = pt->GetLastFrame();
+        tp.status = static_cast<int32_t>(pt->GetStatus());
+        if (init->HasDescriptor()) std::memcpy(tp.desc, init->GetDescriptor().data(), 32);
+        else std::memset(tp.desc, 0, 32);
+        if (!ref->IsRegistered()) {  // a keyframe that never was the current frame of a tracked step (bootstrap, host-path steps)
+          double pose[7];
+          ref->GetPose().ToArray(pose);
+          dev_->Check(sdvl_frame_register(dev_->ctx(), ref->device(), pose), "sdvl_frame_register");
+          ref->SetRegistered();
+        }
+      }
+    }
+    feats->push_back(f);
+  }
+  if (static_cast<int>(points->size() - p0) > track_cap_) return false;
+  t.track_.points = table;
+  t.track_.stats.clear();
+  t.track_.stats_dirty = false;
+  return true;
+}
+
+// One step of B trackers on the device-resident tables: ONE submission (alignment, detection, reprojection, search, match
+// selection, pose, table update) and ONE wait.  The host keeps what only it can do: rand() (cell shuffle, RANSAC draws), the
+// motion model, tracking quality, the keyframe decision and everything a keyframe sets off.
+bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats) {
+  static const bool chain_enabled = std::getenv("SDVL_NO_CHAIN") == nullptr;
+  if (!persistent_ || threads_ > 1 || !TrackTables() || !chain_enabled || !DevicePose() || Config::MaxRansacPoints() > 8) return false;
+  const int B = static_cast<int>(trk_.size());
+  for (int i = 0; i < B; i++) {
+    SDVL &t = *trk_[i];
+    if (t.feature_align_.MaxMatches() > FeatureAlign::kMaxDevicePoseObs || t.feature_align_.MaxMatches() < 1) return false;
+    if (t.state_ == SDVL::STATE_RUNNING && t.lost_frames_ >= 3) return false;  // Relocalize (sdvl.cc:205-238) runs on the host path
+    if (t.camera_ != trk_[0]->camera_) return false;
+  }
+  Camera &camera = *trk_[0]->camera_;
+  const int cells = trk_[0]->feature_align_.GridCells();
+  if (cells > 65535) return false;
+  if (!track_) {
+    // a keyframe holds its matches plus what the mapper adds (one seed per free grid cell with the plane map): twice that
+    // leaves room for the reference mapper's connection points; a frame that outgrows it is tracked on the host path
+    int mm = 1;
+    for (SDVL *t : trk_) mm = std::max(mm, t->feature_align_.MaxMatches());
+    track_cap_ = std::min(4096, 2 * (mm + cells));
+    track_cells_ = cells;
+    dev_->Check(sdvl_track_create(dev_->ctx(), B, track_cap_, track_cap_, cells, mm, Config::MaxRansacIts(), &track_), "sdvl_track_create");
+  }
+  if (cells != track_cells_) return false;
+
+  // ---- tables of the trackers whose last_frame changed behind the device's back (keyframes: seeded / mapped features).
+  // First of all: a frame that cannot be expressed as a table sends the whole step to the host path, untouched.
+  std::unique_ptr<StageClock> clk(new StageClock(ST_PREPARE));
+  {
+    vector<int32_t> up_trk, up_buf, up_np, up_nf;
+    tr_up_points_.clear();
+    tr_up_feats_.clear();
+    vector<int> built;
+    for (int i = 0; i < B; i++) {
+      SDVL &t = *trk_[i];
+      if (t.state_ != SDVL::STATE_RUNNING || t.track_.valid) continue;
+      const size_t p0 = tr_up_points_.size(), f0 = tr_up_feats_.size();
+      if (!BuildTable(t, &tr_up_points_, &tr_up_feats_)) return false;
+      built.push_back(i);
+      up_trk.push_back(i);
+      up_buf.push_back(0);
+      up_np.push_back(static_cast<int32_t>(tr_up_points_.size() - p0));
+      up_nf.push_back(static_cast<int32_t>(tr_up_feats_.size() - f0));
+    }
+    if (!up_trk.empty())
+      dev_->Check(sdvl_track_upload(dev_->ctx(), track_, static_cast<int>(up_trk.size()), up_trk.data(), up_buf.data(), up_np.data(), tr_up_points_.data(),
+                                    up_nf.data(), tr_up_feats_.data()), "sdvl_track_upload");
+    for (int i : built) {
+      trk_[i]->track_.feat_buf = 0;
+      trk_[i]->track_.valid = true;
+    }
+  }
+
+  // ---- stage 0: Frame construction, sdvl.cc:59 (pyramids now, detection behind the alignment)
+  vector<shared_ptr<Frame>> frames;
+  const std::function<void(int, std::function<void(int)>)> pfor = [this](int n, std::function<void(int)> fn) { ParallelFor(n, fn); };
+  Frame::CreateBatch(&camera, &trk_[0]->orb_detector_, imgs, false, Config::NumFeatures(), &frames, &pfor);
+  vector<int> run;
+  clk.reset(new StageClock(ST_PRELUDE));
+  for (int i = 0; i < B; i++) {
+    SDVL &t = *trk_[i];
+    FrameStats &st = stats[i];
+    st = FrameStats();
+    t.current_frame_ = frames[i];
+    t.current_frame_->SetID(t.frame_counter_++);
+    if (t.state_ != SDVL::STATE_RUNNING) {
+      // bootstrap replacement (SaveFirstFrame/SaveSecondFrame are out of scope): first frame = keyframe at first_pose
+      t.current_frame_->SetPose(t.first_pose_);
+      t.current_frame_->SetKeyframe();
+      t.map_->AddKeyframe(t.current_frame_, false);
+      t.pending_kf_ = t.current_frame_;
+      t.last_frame_ = t.current_frame_;
+      t.last_kf_ = t.current_frame_;
+      t.state_ = SDVL::STATE_RUNNING;
+      t.track_.valid = false;
+      st.state = 0;
+      st.keyframe = 1;
+    } else {
+      st.state = 2;
+      t.current_frame_->SetPose(SE3::Exp(t.vel_) * t.last_frame_->GetPose());  // SetMotionModel, sdvl.cc:278-281
+      run.push_back(i);
+    }
+  }
+  const int R = static_cast<int>(run.size());
+
+  vector<char> decision(R, 0);  // 0 = tracking lost, 1 = ordinary frame, 2 = new keyframe
+  vector<shared_ptr<Frame>> kfs;
+  vector<int> kf_owner;
+  bool filter_begun = false;
+  if (R > 0) {
+    // ---- the step: jobs, the cell order SelectPoints would shuffle (feature_align.cc:103), the draws SelectInliers would make
+    clk.reset(new StageClock(ST_IMAGE_ALIGN));
+    const int max_its = Config::MaxRansacIts();
+    tr_jobs_.resize(R);
+    tr_rank_.resize(static_cast<size_t>(R) * cells);
+    tr_rand_.clear();
+    for (int k = 0; k < R; k++) {
+      SDVL &t = *trk_[run[k]];
+      sdvl_track_job &jb = tr_jobs_[k];
+      jb.tracker = run[k];
+      jb.feat_buf = t.track_.feat_buf;
+      jb.last = t.last_frame_->device();
+      jb.cur = t.current_frame_->device();
+      const SE3 T = t.current_frame_->GetPose() * t.last_frame_->GetPose().Inverse();  // image_align.cc:66
+      T.ToArray(jb.T);
+      t.last_frame_->GetPose().ToArray(jb.last_pose);
+      jb.frame_id = t.current_frame_->GetID();
+      jb.max_matches = t.feature_align_.MaxMatches();
+      t.feature_align_.ShuffleCellRanks(tr_rank_.data() + static_cast<size_t>(k) * cells);
+      t.feature_align_.PeekRand(max_its, &tr_rand_);
+    }
+    sdvl_track_params prm;
+    prm.align = AlignParams(false);
+    prm.search = SearchParams();
+    prm.pose = FeatureAlign::PoseParams(camera);
+    prm.cell_size = Config::CellSize();
+    prm.patch_size = Config::PatchSize();
+    prm.max_failed = Config::MaxFailed();
+    prm.pad_ = 0;
+    const sdvl_camera cam = camera.abi();
+    dev_->Check(sdvl_track_align(dev_->ctx(), track_, R, tr_jobs_.data(), tr_rank_.data(), tr_rand_.data(), &cam, &prm), "sdvl_track_align");
+    Frame::DetectBatch(frames, Config::NumFeatures());  // FAST + selection run behind the alignment
+    clk.reset(new StageClock(ST_SEARCH));
+    dev_->Check(sdvl_track_search(dev_->ctx(), track_), "sdvl_track_search");
+    tr_res_.resize(R);
+    dev_->Check(sdvl_track_collect(dev_->ctx(), track_, R, tr_res_.data()), "sdvl_track_collect");
+
+    // ---- results: pose, counters, the rand() stream, deletions, motion model, tracking quality, keyframe decision
+    clk.reset(new StageClock(ST_FINISH));
+    for (int k = 0; k < R; k++) {
+      const int i = run[k];
+      SDVL &t = *trk_[i];
+      FrameStats &st = stats[i];
+      const sdvl_track_result &r = tr_res_[k];
+      if (r.status != 0) throw std::runtime_error("sdvl_track: a table capacity was exceeded on the device");
+      SDVL::TrackState &ts = t.track_;
+      st.align_meas = r.align_meas;
+      st.align_iters = r.align_iters;
+      st.align_features = r.n_features;
+      st.search_requests = r.n_requests;
+      st.lk_iters = r.lk_iters;
+      st.n_corners = r.n_corners;
+      t.current_frame_->SetPose(SE3::FromArray(r.pose));
+      t.current_frame_->SetRegistered();  // the step wrote (view, final pose) into the registry
+      t.current_frame_->SetFlatFeatures(sdvl_track_features(track_, k), r.matches, ts.points);
+      const sdvl_track_point_stat *ps = sdvl_track_stats(track_, k);
+      ts.stats.assign(ps, ps + ts.points->size());
+      ts.stats_dirty = true;
+      if (dynamic_cast<MapperMap *>(t.map_)) SyncStats(t);  // the mapper's depth filter reads and resets the failure counts
+      t.feature_align_.AdvanceRand(r.n_draws);
+      t.feature_align_.SetTrackedCounts(r.matches, r.attempts, r.n_inliers, r.n_outliers);
+      t.matches_ = r.matches;
+      t.attempts_ = r.attempts;
+      st.inliers = r.n_inliers;
+      st.outliers = r.n_outliers;
+      if (r.n_deleted > 0)  // points that crossed MaxFailed: Map::DeletePoint (feature_align.cc:141-142), emptied in the epilogue
+        for (size_t p = 0; p < ts.points->size(); p++)
+          if ((ts.stats[p].status & 0x100) && !(*ts.points)[p]->ToDelete()) t.map_->DeletePoint((*ts.points)[p]);
+      {  // GetMotionModel, sdvl.cc:266-276
+        const SE3 mov = t.current_frame_->GetPose() * t.last_frame_->GetPose().Inverse();
+        const Vector6d vel = SE3::Log(mov);
+        for (int c = 0; c < 6; c++) t.vel_[c] = 0.9 * (0.5 * vel[c] + 0.5 * t.vel_[c]);
+      }
+      t.CalcTrackingQuality(t.matches_, t.attempts_);
+      if (t.tracking_quality_ != SDVL::TRACKING_BAD)
+        decision[k] = (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) ? 2 : 1;
+    }
+    // the keyframes are known: queue their FilterCorners inputs now; the bookkeeping below runs meanwhile
+    clk.reset(new StageClock(ST_POSE));
+    {
+      vector<char> fresh(B, 0);
+      for (int k = 0; k < R; k++)
+        if (decision[k] == 2 && !dynamic_cast<MapperMap *>(trk_[run[k]]->map_)) fresh[run[k]] = 1;
+      for (int i = 0; i < B; i++) {
+        if (trk_[i]->pending_kf_) { kfs.push_back(trk_[i]->pending_kf_); kf_owner.push_back(i); }
+        else if (fresh[i]) { kfs.push_back(trk_[i]->current_frame_); kf_owner.push_back(i); }
+      }
+      if (!kfs.empty()) {
+        StageClock fclk(ST_MAPPING);
+        for (int i = 0; i < B; i++)
+          if (stats[i].state == 0) { FetchCornerCounts(frames, stats); break; }  // bootstrap frames: their counts did not ride along
+        Frame::FilterCornersBegin(kfs);
+        filter_begun = true;
+      }
+    }
+    for (int k = 0; k < R; k++) {
+      const int i = run[k];
+      SDVL &t = *trk_[i];
+      FrameStats &st = stats[i];
+      if (decision[k] == 0) continue;  // tracking lost: last_frame and its table stay
+      if (decision[k] == 2) {
+        // the frame becomes part of the map: its features and the points behind them turn into objects
+        SyncStats(t);
+        vector<shared_ptr<Feature>> &features = t.current_frame_->GetFeatures();
+        for (auto it = features.begin(); it != features.end(); it++)
+          if (Point *p = (*it)->GetPointRaw()) p->AddFeature(*it);
+        t.current_frame_->SetKeyframe();
+        t.map_->AddKeyframe(t.current_frame_);
+        t.last_kf_ = t.current_frame_;
+        t.map_->LimitKeyframes(t.current_frame_);  // sdvl.cc:114
+        if (!dynamic_cast<MapperMap *>(t.map_)) t.pending_kf_ = t.current_frame_;
+        st.keyframe = 1;
+        t.track_.valid = false;  // seeding / the mapper add features: the table is rebuilt from the keyframe
+      } else {
+        t.map_->AddFrame(t.current_frame_);
+        t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
+      }
+      t.last_frame_ = t.current_frame_;
+    }
+  }
+  clk.reset();
+  if (R == 0) Frame::DetectBatch(frames, Config::NumFeatures());  // bootstrap-only step: the new keyframes still need their corners
+  // a mapper that looks at the frames it was given (MapperMap: scene depth of every frame, feature lists of keyframes)
+  // materialises them on demand; a keyframe's table is rebuilt afterwards in any case
+  EpilogueAndMapper(frames, stats, &kfs, &kf_owner, filter_begun);
+  // With the reference's mapper the tracker follows CANDIDATES too (Map::InitCandidates links them to the keyframe at once,
+  // map.cc:379-390), and the depth filter rewrites their inverse depth, variance, position, failure count and finally
+  // `fixed` after every frame (point.cc:64-100,164-178): their rows are rebuilt from the objects before the next step.
+  // (The step itself still runs as one submission; what is lost is the saving on the host side.)
+  for (int i = 0; i < B; i++)
+    if (dynamic_cast<MapperMap *>(trk_[i]->map_)) trk_[i]->track_.valid = false;
+  return true;
+}
+
+// SDVL::HandleFrame (sdvl.cc:55-130) for B trackers
 void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
-  const bool device_pose = DevicePose();
   const int B = static_cast<int>(trk_.size());
   if (static_cast<int>(imgs.size()) != B) throw std::runtime_error("SDVLBatch::HandleFrames: one image per tracker");
   Device::SetCurrent(dev_);
   g_stage_times = &stage_times;
   stage_times.steps++;
   const auto t_begin = std::chrono::steady_clock::now();
+  if (!HandleFramesTracked(imgs, stats)) {
+    SyncHostState();  // Feature lists and Point counters catch up with the device; the tables are rebuilt when tracking returns
+    HandleFramesGeneric(imgs, stats);
+  }
+  stage_times.t[ST_TOTAL] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  g_stage_times = nullptr;
+}
+
+// the host-driven form, stage by stage: every request assembled here, results replayed here
+void SDVLBatch::HandleFramesGeneric(const vector<Image> &imgs, FrameStats *stats) {
+  const bool device_pose = DevicePose();
+  const int B = static_cast<int>(trk_.size());
+  for (SDVL *t : trk_) t->track_.valid = false;  // this step changes last_frame's features behind the tables' back
   const std::function<void(int, std::function<void(int)>)> pfor = [this](int n, std::function<void(int)> fn) { ParallelFor(n, fn); };
 
   // ---- stage 0: Frame construction (pyramid + FAST + selection + ORB), sdvl.cc:59
@@ -1717,16 +2128,6 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   vector<shared_ptr<Frame>> kfs;
   vector<int> kf_owner;
   bool filter_begun = false;
-  // corner counts of this step's frames (they rode along with the detection kernels: no round trip once any wait on the
-  // stream has returned since): the statistics need them, and with them known the keyframe round trip returns rows of
-  // exactly the right length
-  const auto fetch_corner_counts = [&]() {
-    vector<sdvl_frame *> devs(B);
-    vector<int32_t> counts(B);
-    for (int i = 0; i < B; i++) devs[i] = frames[i]->device();
-    dev_->Check(sdvl_frames_corner_counts(dev_->ctx(), B, devs.data(), counts.data()), "sdvl_frames_corner_counts");
-    for (int i = 0; i < B; i++) stats[i].n_corners = counts[i];
-  };
   // ---- stage 2: FeatureAlign::Reproject, sdvl.cc:193 — all candidates of all trackers in one launch
   {
     clk.reset(new StageClock(ST_PREPARE));
@@ -1907,7 +2308,7 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
       }
       if (!kfs.empty()) {
         StageClock fclk(ST_MAPPING);
-        fetch_corner_counts();  // before the filter round trip: it shares the context's result buffers
+        FetchCornerCounts(frames, stats);  // before the filter round trip: it shares the context's result buffers
         Frame::FilterCornersBegin(kfs);
         filter_begun = true;
       }
@@ -1935,9 +2336,32 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     });
   }
 
+  clk.reset();
+  EpilogueAndMapper(frames, stats, &kfs, &kf_owner, filter_begun);
+}
+
+// corner counts of this step's frames (they rode along with the detection kernels: no round trip once any wait on the stream
+// has returned since): the statistics need them, and with them known the keyframe round trip returns rows of exactly the
+// right length
+void SDVLBatch::FetchCornerCounts(const vector<shared_ptr<Frame>> &frames, FrameStats *stats) {
+  const int B = static_cast<int>(frames.size());
+  vector<sdvl_frame *> devs(B);
+  vector<int32_t> counts(B);
+  for (int i = 0; i < B; i++) devs[i] = frames[i]->device();
+  dev_->Check(sdvl_frames_corner_counts(dev_->ctx(), B, devs.data(), counts.data()), "sdvl_frames_corner_counts");
+  for (int i = 0; i < B; i++) stats[i].n_corners = counts[i];
+}
+
+// what follows the tracking decisions in both forms of a step: the keyframes' FilterCorners round trip + seeding, the
+// per-tracker epilogue, and SDVL::Mapping() of sequential mode
+void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, FrameStats *stats, vector<shared_ptr<Frame>> *kfs_io,
+                                  vector<int> *kf_owner_io, bool filter_begun) {
   // ---- stage 4: mapper stand-in for fresh keyframes (sequential mode, main.cc:148-149): one K3 launch for all
-  clk.reset(new StageClock(ST_MAPPING));
-  if (!filter_begun) fetch_corner_counts();
+  std::unique_ptr<StageClock> clk(new StageClock(ST_MAPPING));
+  const int B = static_cast<int>(trk_.size());
+  vector<shared_ptr<Frame>> &kfs = *kfs_io;
+  vector<int> &kf_owner = *kf_owner_io;
+  if (!filter_begun) FetchCornerCounts(frames, stats);
   {
     if (!filter_begun) {
       kfs.clear();
@@ -2042,8 +2466,6 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
     }
   }
   clk.reset();
-  stage_times.t[ST_TOTAL] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-  g_stage_times = nullptr;
 }
 
 }  // namespace sdvl

@@ -307,6 +307,14 @@ class Point {
   std::shared_ptr<Feature> GetLastFeature() { return features_.front(); }
   bool Promote();
   bool Unpromote();
+  // device-resident tracking tables (SDVLBatch): the counters the device advances while the point sits in a table
+  int GetFailed() const { return n_failed_; }
+  // (one failure more than before = one Unpromote on the device, which also counts in the depth filter's b_, point.cc:112;
+  //  exact as long as the counters are collected after every frame, which SDVLBatch does whenever a mapper filters points)
+  void SetTrackCounters(int n_successful, int n_failed, int last_frame, PointStatus status) {
+    if (n_failed == n_failed_ + 1) b_++;
+    n_successful_ = n_successful; n_failed_ = n_failed; last_frame_ = last_frame; status_ = status;
+  }
   // depth filter (point.cc:64-100,164-217): used by the mapper (MapperMap), not by the tracking path
   void Update(const std::shared_ptr<Frame> &frame, double depth, double px_error_angle);
   bool HasConverged();
@@ -350,7 +358,17 @@ class Frame : public std::enable_shared_from_this<Frame> {
   const SE3 &GetPose() const { return pose_; }
   void SetPose(const SE3 &se3) { pose_ = se3; world_valid_ = false; }
   std::vector<Image> &GetPyramid();  // host mirror is filled on first call
-  std::vector<std::shared_ptr<Feature>> &GetFeatures() { return features_; }
+  // Features of a frame that went through the device-resident tracking tables exist as flat records first (position, level,
+  // index of the point in the tracker's table) and become Feature objects the first time somebody asks for them
+  typedef std::vector<std::shared_ptr<Point>> PointTable;
+  std::vector<std::shared_ptr<Feature>> &GetFeatures() {
+    if (flat_) MaterializeFeatures();
+    return features_;
+  }
+  void SetFlatFeatures(const sdvl_track_feature_out *feats, int n, const std::shared_ptr<PointTable> &points);
+  bool HasFlatFeatures() const { return flat_ != nullptr; }
+  bool IsRegistered() const { return registered_; }
+  void SetRegistered() { registered_ = true; }
   std::vector<Vector3i> &GetCorners();  // host mirror of the HBM corner list, filled on first call
   int GetNumCorners();                  // corner count without mirroring the list
   std::vector<int> &GetFilteredCorners() { return filtered_corners_; }
@@ -372,7 +390,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   }
   Vector3d GetWorldPosition() const { return GetWorldPose().GetTranslation(); }
   Vector3d GetRelativePos(const Vector3d &pos) const { return pose_ * pos; }
-  void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_back(f); }
+  void AddFeature(const std::shared_ptr<Feature> &f) { GetFeatures().push_back(f); }
   // a Feature on this frame whose storage comes from the frame's arena (same object as make_shared<Feature>(frame, ...))
   std::shared_ptr<Feature> NewFeature(const Vector2d &p, int level) {
     if (!arena_) arena_ = NewArena();
@@ -384,11 +402,11 @@ class Frame : public std::enable_shared_from_this<Frame> {
     return std::allocate_shared<Point>(ArenaAllocator<Point>(arena_));
   }
   void AddOutlier(const Vector2d &p) { outliers_.push_back(p); }
-  int GetNumFeatures() const { return static_cast<int>(features_.size()); }
+  int GetNumFeatures() const { return flat_ ? static_cast<int>(flat_->feats.size()) : static_cast<int>(features_.size()); }
   int GetNumPoints() const;
   bool Project(const Vector3d &p3D, Vector2d *p2D);
   void CreateCorners(int levels, int nfeatures);
-  void RemoveFeatures() { features_.clear(); }
+  void RemoveFeatures() { features_.clear(); DropFlat(); }
   // mapper-side state and queries (frame.h:71-87,120-136; frame.cc:70-113,181-207)
   void SetKeyframeID(int id) { kf_id_ = id; }
   int GetKeyframeID() const { return kf_id_; }
@@ -432,6 +450,24 @@ class Frame : public std::enable_shared_from_this<Frame> {
   Device *owner_ = nullptr;
   FrameArena *arena_ = nullptr;
   FrameArena *NewArena() const;
+  // the records sit in the frame's arena (no malloc per frame: with 16 host threads the allocator's mprotect / page-fault
+  // traffic was the largest single cost of a step)
+  struct FlatSpan {
+    const sdvl_track_feature_out *data = nullptr;
+    int n = 0;
+    const sdvl_track_feature_out *begin() const { return data; }
+    const sdvl_track_feature_out *end() const { return data + n; }
+    size_t size() const { return static_cast<size_t>(n); }
+  };
+  struct FlatFeatures {
+    FlatSpan feats;
+    std::shared_ptr<PointTable> points;
+  };
+  FlatFeatures flat_store_;
+  FlatFeatures *flat_ = nullptr;  // &flat_store_ while the features are still flat records
+  void MaterializeFeatures();
+  void DropFlat();
+  bool registered_ = false;  // the context's (frame, pose) registry holds this frame with its current pose
   int search_slot_ = -1;
   uint64_t search_batch_ = 0;
   int kf_id_ = 0;
@@ -620,6 +656,11 @@ class FeatureAlign {
   bool EmitPoseJob(const std::shared_ptr<Frame> &frame, PoseBatch *batch);  // false: too many matches, use the host path
   void CommitPose(const std::shared_ptr<Frame> &frame, const sdvl_pose_result &r, const int32_t *lists);
   static sdvl_pose_params PoseParams(const Camera &cam);
+  // device-resident tables (SDVLBatch::HandleFramesTracked): the host keeps what only it can do — rand()
+  void ShuffleCellRanks(uint16_t *rank_of_cell);  // random_shuffle(cell_order_) of SelectPoints (feature_align.cc:103) -> rank per cell
+  int GridCells() const { return grid_width_ * grid_height_; }
+  void AdvanceRand(int n);                        // the draws SelectInliers made on the device
+  void SetTrackedCounts(int matches, int attempts, int inliers, int outliers);
   void SelectInliers(const std::shared_ptr<Frame> &frame);  // host RANSAC (feature_align.cc:152-216)
 
  private:
@@ -711,6 +752,14 @@ class SDVL {
   SE3 first_pose_;
   FrameStats stats_;
   bool relocalize_pending_ = false;
+  // device-resident tracking table of this tracker (SDVLBatch owns the set): valid = the table holds last_frame_'s features
+  struct TrackState {
+    bool valid = false;
+    int feat_buf = 0;
+    std::shared_ptr<Frame::PointTable> points;        // table index -> Point
+    std::vector<sdvl_track_point_stat> stats;         // newest counters of `points`; the Point objects lag behind
+    bool stats_dirty = false;
+  } track_;
 };
 
 // B independent trackers stepping together, one launch per kernel per stage (MI355X-first driver)
@@ -724,6 +773,13 @@ class SDVLBatch {
   // also set by SDVL_POSE_HOST=1 in the environment.  Both produce the same decisions (tests/test_gpu_tracker.py).
   static void SetDevicePose(bool on);
   static bool DevicePose();
+  // Device-resident tracking tables (default for a persistent batch on one host thread): last_frame's features and points
+  // stay in HBM, a step is ONE submission and ONE wait, the host keeps rand(), the motion model and the keyframe logic.
+  // Off (SDVL_NO_TRACK_TABLES=1 or SetTrackTables(false)): the host assembles every request as before.  Same results.
+  static void SetTrackTables(bool on);
+  static bool TrackTables();
+  // Point objects / Feature lists catch up with the device (called on its own whenever the batch leaves the tracked path)
+  void SyncHostState();
 
  private:
   void ParallelFor(int n, const std::function<void(int)> &fn);
@@ -737,6 +793,24 @@ class SDVLBatch {
   FeatureAlign::PoseBatch scratch_pose_;
   std::vector<double> scratch_points_;  // sdvl_search_run_chain inputs, same idea
   std::vector<int32_t> chain_cand_req_, chain_cand_first_, chain_rand_;
+  // ---- device-resident tables
+  bool HandleFramesTracked(const std::vector<Image> &imgs, FrameStats *stats);  // false: not applicable this step
+  void HandleFramesGeneric(const std::vector<Image> &imgs, FrameStats *stats);
+  bool BuildTable(SDVL &t, std::vector<sdvl_track_point> *points, std::vector<sdvl_track_feature> *feats);
+  void SyncStats(SDVL &t);
+  void FetchCornerCounts(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats);
+  void EpilogueAndMapper(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats, std::vector<std::shared_ptr<Frame>> *kfs,
+                         std::vector<int> *kf_owner, bool filter_begun);
+  sdvl_track_set *track_ = nullptr;
+  int track_cells_ = 0, track_cap_ = 0;
+  bool persistent_ = true;  // SDVL::HandleFrame's one-shot batches never build tables
+  friend class SDVL;
+  std::vector<sdvl_track_job> tr_jobs_;
+  std::vector<uint16_t> tr_rank_;
+  std::vector<int32_t> tr_rand_;
+  std::vector<sdvl_track_result> tr_res_;
+  std::vector<sdvl_track_point> tr_up_points_;
+  std::vector<sdvl_track_feature> tr_up_feats_;
 };
 
 }  // namespace sdvl
