@@ -37,8 +37,10 @@ ORACLE_PARAMS = {}      # fields of the oracle's parameter block that differ fro
 # S-A is the metric configuration; S-C (1280x960, num_features 4000, max_matches 1000, 64 sequences per GPU)
 # is BASELINE.json's roofline case, run with `--workload S-C`
 WORKLOADS = {
-    "S-A": dict(w=640, h=480, cam=[517.3, 516.5, 318.6, 255.3], seqs=2048, over={}, label="~200 feats", cpu_frames=300),
-    "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=64, label="~1000 feats", cpu_frames=60,
+    # seqs: tried in this order, the first whose resident input frames + keyframe pool fit the GPU is used (with the device-
+    # resident tracking tables the kernels are the limit, and 256 sequences per launch amortise their latency better than 128)
+    "S-A": dict(w=640, h=480, cam=[517.3, 516.5, 318.6, 255.3], seqs=[4096, 3072, 2048], over={}, label="~200 feats", cpu_frames=300),
+    "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=[64], label="~1000 feats", cpu_frames=60,
                 over={"SDVL.num_features": 4000, "SDVL.max_matches": 1000}),
 }
 XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])
@@ -304,13 +306,16 @@ def main():
     ap.add_argument("--mapper", action="store_true",
                     help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip, -1 = the workload's)")
+    ap.add_argument("--host-steps", type=int, default=8,
+                    help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
+                         "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip")
     args = ap.parse_args()
     global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS
     wl = WORKLOADS[args.workload]
     W_IMG, H_IMG, TUM_CAM, FEATS_LABEL = wl["w"], wl["h"], np.array(wl["cam"]), wl["label"]
     ORACLE_PARAMS = {k.split(".")[1]: v for k, v in wl["over"].items()}
-    if args.seqs <= 0:
-        args.seqs = wl["seqs"]
+    seq_choices = [args.seqs] if args.seqs > 0 else list(wl["seqs"])
+    args.seqs = seq_choices[0]
     if args.cpu_frames < 0:
         args.cpu_frames = wl["cpu_frames"]
 
@@ -346,22 +351,40 @@ def main():
     numa_node = None if os.environ.get("SDVL_NO_NUMA_BIND") else trk.bind_to_gpu_numa_node(local_rank)
     trk.configure(dict(trk.TUM_OVERRIDES, **wl["over"]))
     ncpu = effective_cpus()
-    B, K, Wm = args.seqs, args.steps, args.warmup
-    # one group = one HIP stream + one host-side step at a time; workers = host threads.  With a full CPU share (16 per
-    # GPU on the MI355X boxes) one group per worker is best; with fewer CPUs every worker interleaves two groups (fibers),
-    # which hides their GPU waits and is worth ~10 % there.
     cpus_rank = int(os.environ.get("SDVL_BENCH_CPU_SHARE", "0")) or max(1, ncpu // max(1, world))
+    K, Wm = args.steps, args.warmup
     fibers = args.fibers
-    if args.groups:
-        G = args.groups
-    else:
-        workers_auto = max(1, min(cpus_rank, 16))
-        if fibers <= 1 and cpus_rank < 12 and not args.workers:
-            fibers = 2
-        G = max(1, min(B // 8 if B >= 8 else 1, workers_auto * max(1, fibers)))
-    while B % G:
-        G -= 1
-    Bg = B // G
+    n_frames = 1 + Wm + K                     # bootstrap keyframe + warmup + timed
+    frame_bytes = W_IMG * H_IMG
+    pkg.load_library().sdvl_frame_footprint.restype = C.c_int64
+    footprint = pkg.load_library().sdvl_frame_footprint(W_IMG, H_IMG, 5)
+    free_b, total_b = torch.cuda.mem_get_info()
+    B = G = Bg = reserve_frames = need = None
+    for cand in seq_choices:
+        # one group = one HIP stream + one host-side step at a time; workers = host threads.  With a full CPU share (16 per
+        # GPU on the MI355X boxes) one group per worker is best; with fewer CPUs every worker interleaves two groups (fibers),
+        # which hides their GPU waits and is worth ~10 % there.
+        B = cand
+        fibers = args.fibers
+        if args.groups:
+            G = args.groups
+        else:
+            workers_auto = max(1, min(cpus_rank, 16))
+            if fibers <= 1 and cpus_rank < 12 and not args.workers:
+                fibers = 2
+            G = max(1, min(B // 8 if B >= 8 else 1, workers_auto * max(1, fibers)))
+        while B % G:
+            G -= 1
+        Bg = B // G
+        steps_all = Wm + K + max(0, args.host_steps)
+        reserve_frames = Bg * (4 + (steps_all + 3) // 4)   # keyframe budget: S-A turns about one frame in five into a keyframe
+        need = B * n_frames * frame_bytes + G * reserve_frames * footprint + B * 2 * footprint
+        if need <= 0.85 * free_b:
+            break
+    if need > 0.9 * free_b:
+        raise SystemExit("bench.py: %d sequences x %d steps need %.0f GB of HBM (input frames stay resident, keyframes keep their frame); "
+                         "%.0f GB are free - use fewer --steps or --seqs" % (B, K, need / 1e9, free_b / 1e9))
+    args.seqs = B
     threads = args.threads or 1
     trk.set_mapper(args.mapper)
     farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
@@ -370,15 +393,6 @@ def main():
     ctx = ctxs[0]
 
     my_seqs = shard.sequences_for_rank(rank, world, B)   # independent sequences: no data-path collective
-    n_frames = 1 + Wm + K                     # bootstrap keyframe + warmup + timed
-    frame_bytes = W_IMG * H_IMG
-    reserve_frames = Bg * (4 + (Wm + K + 3) // 4)   # keyframe budget: S-A turns about one frame in five into a keyframe
-    pkg.load_library().sdvl_frame_footprint.restype = C.c_int64
-    need = B * n_frames * frame_bytes + G * reserve_frames * pkg.load_library().sdvl_frame_footprint(W_IMG, H_IMG, 5)
-    free_b, total_b = torch.cuda.mem_get_info()
-    if need > 0.9 * free_b:
-        raise SystemExit("bench.py: %d sequences x %d steps need %.0f GB of HBM (input frames stay resident, keyframes keep their frame); "
-                         "%.0f GB are free - use fewer --steps or --seqs" % (B, K, need / 1e9, free_b / 1e9))
     buf = ctx.malloc(B * n_frames * frame_bytes)
     for k in range(n_frames):                 # frame-major layout: step k reads B consecutive frames
         views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * k), shard.sequence_seed(g), k) for g in my_seqs]
@@ -461,6 +475,39 @@ def main():
         n_lk += st.lk_iters
 
     tracked_all, elapsed_max = shard.reduce_throughput(tracked, elapsed, dist if distributed else None, "cuda")
+
+    # ---- second leg, HOST-FED: the same trackers continue, but their next frames come from pinned HOST memory and every group
+    # uploads them on its own stream inside the step — what SDVL::HandleFrame(const cv::Mat&) receives (sdvl.cc:55-59).  This is
+    # the end-to-end drop-in rate; `value` above is the contract's number (inputs resident when the timed region starts).
+    host_fed = None
+    Kh = max(0, args.host_steps)
+    if Kh > 0:
+        try:
+            hbuf = torch.empty(B * Kh * frame_bytes, dtype=torch.uint8, pin_memory=True)
+        except RuntimeError as e:
+            hbuf = None
+            sys.stderr.write("bench.py: host-fed leg skipped, cannot pin %.1f GB of host memory (%s)\n" % (B * Kh * frame_bytes / 1e9, e))
+        if hbuf is not None:
+            lib_hip = pkg.load_library()
+            for k in range(Kh):                       # the frames that follow the resident leg's last one, rendered into the (now free) input area
+                ka = n_frames + k
+                views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * ka), shard.sequence_seed(g), ka) for g in my_seqs]
+                ctx.render(views, buf)
+                ctx.check(lib_hip.sdvl_device_download(ctx.h, C.c_void_p(buf), C.c_int64(B * frame_bytes), C.c_void_p(hbuf.data_ptr() + k * B * frame_bytes)))
+            hptrs = (hbuf.data_ptr() + (np.arange(Kh, dtype=np.uint64)[:, None] * B + np.arange(B, dtype=np.uint64)[None, :]) * frame_bytes).astype(np.uint64)
+            farm.set_host_input(True)
+            hstats_buf = farm.alloc_stats(Kh)
+            barrier()
+            t0 = time.perf_counter()
+            hstats = farm.run(hptrs, workers, hstats_buf)
+            barrier()
+            elapsed_h = time.perf_counter() - t0
+            farm.set_host_input(False)
+            tracked_h = sum(int(st.quality != 2) for st in hstats)
+            th_all, eh_max = shard.reduce_throughput(tracked_h, elapsed_h, dist if distributed else None, "cuda")
+            host_fed = {"value": round(th_all / eh_max, 2), "unit": "frames/s", "steps": Kh, "ms_per_step": round(eh_max / Kh * 1e3, 3),
+                        "pcie_h2d_gb_per_s": round(world * B * Kh * frame_bytes / eh_max / 1e9, 2),
+                        "input": "pinned host memory, %d B per frame uploaded inside the step on the group's stream" % frame_bytes}
     if cpu_sample is not None:
         fps1, n_tracked1, secs1 = cpu_one
         n_thr = max(1, min(ncpu, 16))
@@ -495,8 +542,10 @@ def main():
             "metric": "tracked frames/sec (%dx%d, 5-lvl pyr, %s)" % (W_IMG, H_IMG, FEATS_LABEL), "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed_max / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
+            "value_host_fed": host_fed["value"] if host_fed else None, "host_fed": host_fed,
             "config": {"workload": "%s: synthetic TUM fr1-like %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step%s" % (args.workload, W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
+                       "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",
                        "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "numa_node": numa_node, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),

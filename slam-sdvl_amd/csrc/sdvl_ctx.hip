@@ -496,8 +496,10 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
   SDVL_REQUIRE(ctx, stride >= f->width, "stride smaller than width");
   // hipMemcpy2DAsync from pageable memory stages internally; it returns once the source has been consumed.
   f->v.level[0] = f->own_level0;
-  SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, img, stride, f->width, f->height, hipMemcpyHostToDevice,
-                                       ctx->stream));
+  if (stride == f->width)  // contiguous: one linear copy (pinned sources go out as a single DMA)
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(f->v.level[0], img, static_cast<size_t>(f->width) * f->height, hipMemcpyHostToDevice, ctx->stream));
+  else
+    SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], f->width, img, stride, f->width, f->height, hipMemcpyHostToDevice, ctx->stream));
   f->hdr_stale = 1;
   f->v.n_corners = 0;
   f->desc_valid = 0;

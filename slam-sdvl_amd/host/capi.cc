@@ -233,6 +233,7 @@ struct Farm {
   bool failed = false;
 
   int fibers_per_worker = 1;  // > 1: a worker interleaves that many group-steps, switching at every GPU wait
+  bool host_input = false;    // the frame pointers of a run are HOST pointers (pinned): every step uploads its frames
 
   // next (group, step) for a worker: the idle group that is furthest behind.  Returns -1 when nothing is left, -2 when
   // every remaining group is busy elsewhere (only with `may_block` false; otherwise it waits for one to come free).
@@ -256,6 +257,7 @@ struct Farm {
     const int total = G * Bg;
     const int s = done[g];  // only the owner of a busy group reads or writes its counter
     const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
+    if (host_input) return sdvlh_batch_step_host(batches[g], reinterpret_cast<const uint8_t *const *>(dev_frames + off), stride, out + off);
     return sdvlh_batch_step_device(batches[g], dev_frames + off, stride, out + off);
   }
 
@@ -480,6 +482,10 @@ void sdvlh_farm_set_fibers(void *fp, int n) {
   for (void *d : f->devices)
     sdvl_ctx_set_wait_hook(static_cast<Device *>(d)->ctx(), f->fibers_per_worker > 1 ? FiberWaitHook : nullptr, nullptr);
 }
+
+// the frame pointers handed to sdvlh_farm_run are host pointers (SDVL::HandleFrame(const cv::Mat&) takes a host image,
+// sdvl.cc:55-59): every group uploads its frames on its own stream inside the step
+void sdvlh_farm_set_host_input(void *fp, int on) { static_cast<Farm *>(fp)->host_input = on != 0; }
 
 void sdvlh_farm_destroy(void *fp) {
   Farm *f = static_cast<Farm *>(fp);

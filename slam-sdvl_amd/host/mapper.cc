@@ -10,6 +10,9 @@
 #include "config.h"
 #include "sdvl_host.h"
 
+#include <chrono>
+#include <thread>
+
 namespace sdvl {
 
 using std::shared_ptr;
@@ -64,7 +67,7 @@ void FillRequest(sdvl_search_req *rq, Frame *cur, Frame *ref, const Vector2d &px
 void FillRequestFromFeature(sdvl_search_req *rq, Frame *cur, Feature *feature, Frame *ref, double idepth, double idepth_std, bool fixed,
                             const Vector2d &px0) {
   FillRequest(rq, cur, ref, feature->GetPosition(), feature->GetVector(), feature->GetLevel(),
-              feature->HasDescriptor() ? feature->GetDescriptor().data() : nullptr, idepth, idepth_std, fixed, px0);
+              feature->HasDescriptor() ? feature->DescriptorData().data() : nullptr, idepth, idepth_std, fixed, px0);
 }
 
 }  // namespace
@@ -277,6 +280,7 @@ bool MapperMap::BeginUpdate() {
     cur_ = frame_queue_.front();
     frame_queue_.pop_front();
   }
+  updates_++;
   depth_mean_ = cur_->GetSceneDepth();
   pass_ = 0;
   occurrence_.assign(candidates_.size(), 0);
@@ -634,6 +638,41 @@ void MapperMap::FinishUpdate() {
 }
 
 // Map::UpdateMap for ONE tracker (one K7 launch per phase); SDVLBatch runs the same phases for many trackers at once
+// map.cc:49-71
+MapperMap::~MapperMap() { Stop(); }
+
+void MapperMap::Start() {
+  if (running_) return;
+  tracker_device_ = Device::CurrentOrNull();
+  running_ = true;
+  thread_ = std::thread(&MapperMap::Run, this);
+}
+
+void MapperMap::Stop() {
+  running_ = false;
+  if (thread_.joinable()) thread_.join();
+}
+
+void MapperMap::Run() {
+  // one context (= HIP stream, staging, result buffers) per host thread; the tracker's frames are shared read-only, and
+  // the points this thread creates continue the tracker's id sequence
+  Device dev(tracker_device_ ? tracker_device_->gpu() : 0);
+  if (tracker_device_) dev.point_ids = tracker_device_->point_ids;
+  Device::SetCurrent(&dev);
+  while (running_) {
+    {
+      std::unique_lock<std::mutex> lock(mutex_map_);
+      UpdateMap();
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));  // map.cc:68
+  }
+  {
+    std::unique_lock<std::mutex> lock(mutex_map_);
+    cur_.reset();
+  }
+  Device::SetCurrent(nullptr);
+}
+
 void MapperMap::UpdateMap() {
   if (!BeginUpdate()) return;
   Device *dev = Device::Current();

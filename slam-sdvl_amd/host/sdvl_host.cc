@@ -49,7 +49,7 @@ struct StageClock {
 };
 }  // namespace
 
-Device::Device(int gpu) {
+Device::Device(int gpu) : gpu_(gpu) {
   const int rc = sdvl_ctx_create(gpu, &ctx_);
   if (rc != SDVL_OK) throw std::runtime_error("sdvl_ctx_create failed (" + std::to_string(rc) + "): no MI355X visible; there is no CPU fallback");
   if (!g_current_device) g_current_device = this;
@@ -84,6 +84,8 @@ void ChunkPool::Put(char *c) {
   std::lock_guard<std::mutex> lk(m_);
   free_.push_back(c);
 }
+
+Device *Device::CurrentOrNull() { return g_current_device; }
 
 Device *Device::Current() {
   if (!g_current_device) throw std::runtime_error("no sdvl::Device bound to this thread (construct one, or Device::SetCurrent)");
@@ -417,7 +419,7 @@ static std::atomic<int> g_point_counter{0};
 
 // point.cc:32-43
 Point::Point() {
-  id_ = g_current_device ? g_current_device->next_point_id++ : g_point_counter++;
+  id_ = g_current_device ? (*g_current_device->point_ids)++ : g_point_counter++;
   status_ = P_NOT_FOUND;
   last_frame_ = -1;
   n_failed_ = 0;
@@ -430,7 +432,7 @@ Point::Point() {
   z_range_ = 6.0;
 }
 void Point::ConsumeId() {
-  if (g_current_device) g_current_device->next_point_id++;
+  if (g_current_device) (*g_current_device->point_ids)++;
   else g_point_counter++;
 }
 double Point::GetStd() { return std::sqrt(sigma2_); }
@@ -458,6 +460,20 @@ Vector3d Point::GetPosition() const {
   const Vector3d &v = feature_->GetVector();
   const double s = 1.0 / rho_;
   return se3 * Vector3d(s * v(0), s * v(1), s * v(2));
+}
+
+// point.cc:144-162
+void Point::SetPosition(const Vector3d &pos) {
+  if (fixed_) {
+    p3d_ = pos;
+    return;
+  }
+  shared_ptr<Frame> frame = feature_->GetFrame();
+  Vector2d p2d;
+  frame->Project(pos, &p2d);
+  Vector3d v3d = frame->GetCamera()->Unproject(p2d);
+  feature_->SetVector(v3d);
+  rho_ = 1.0 / frame->DistanceTo(pos);
 }
 
 // point.cc:105-118
@@ -897,7 +913,7 @@ bool Matcher::MakeRequest(const shared_ptr<Frame> &frame, const shared_ptr<Featu
   req->px0[0] = px(0); req->px0[1] = px(1);
   req->level = feature->GetLevel();
   req->fixed = fixed ? 1 : 0;
-  if (feature->HasDescriptor()) std::memcpy(req->desc, feature->GetDescriptor().data(), 32);
+  if (feature->HasDescriptor()) std::memcpy(req->desc, feature->DescriptorData().data(), 32);
   else std::memset(req->desc, 0, 32);
   return true;
 }
@@ -987,7 +1003,15 @@ void PlaneMap::SeedFromFiltered(const shared_ptr<Frame> &kf) {
 
 // --------------------------------------------------------------------------------------------------- FeatureAlign
 // feature_align.cc:33-54
+// feature_align.h:46: the reference draws from the process-wide rand(); a FeatureAlign built with its signature owns the
+// stream a lone reference process would see (glibc TYPE_3, seed 1)
+FeatureAlign::FeatureAlign(Map *map, Camera *camera, int max_matches) : FeatureAlign(map, camera, max_matches, nullptr) {}
+
 FeatureAlign::FeatureAlign(Map *map, Camera *camera, int max_matches, RandStream *rng) {
+  if (!rng) {
+    own_rng_.reset(new RandStream(1));
+    rng = own_rng_.get();
+  }
   map_ = map;
   camera_ = camera;
   rng_ = rng;
@@ -1122,7 +1146,7 @@ void FeatureAlign::PrepareReprojectImpl(const shared_ptr<Frame> &frame, const sh
         rq.px0[0] = e.p(0); rq.px0[1] = e.p(1);
         rq.level = feature->GetLevel();
         rq.fixed = point->IsFixed() ? 1 : 0;
-        if (feature->HasDescriptor()) std::memcpy(rq.desc, feature->GetDescriptor().data(), 32);
+        if (feature->HasDescriptor()) std::memcpy(rq.desc, feature->DescriptorData().data(), 32);
         else std::memset(rq.desc, 0, 32);
         if (sink->points) {
           const Vector3d P = point->GetPosition();
@@ -1144,7 +1168,7 @@ void FeatureAlign::PrepareReprojectImpl(const shared_ptr<Frame> &frame, const sh
         rq.px0[0] = e.p(0); rq.px0[1] = e.p(1);
         rq.level = feature->GetLevel();
         rq.fixed = point->IsFixed() ? 1 : 0;
-        if (feature->HasDescriptor()) std::memcpy(rq.desc, feature->GetDescriptor().data(), 32);
+        if (feature->HasDescriptor()) std::memcpy(rq.desc, feature->DescriptorData().data(), 32);
         else std::memset(rq.desc, 0, 32);
         c.req = static_cast<int>(reqs->size()) - 1 - req_base_;  // relative: FinishReproject gets res + req_base
       }
@@ -1517,7 +1541,88 @@ SDVL::SDVL(Camera *camera, Map *map, const SE3 &first_pose)
   frame_counter_ = 0;
 }
 
-SDVL::~SDVL() {}
+static Device *OwnDeviceIfNone() {
+  if (Device::CurrentOrNull()) return nullptr;
+  const char *g = std::getenv("SDVL_GPU");
+  return new Device(g ? std::atoi(g) : 0);  // binds itself to the thread
+}
+
+// sdvl.cc:36-50
+SDVL::SDVL(Camera *camera)
+    : own_device_(OwnDeviceIfNone()),
+      own_map_(new MapperMap(Vector3d(0.0, 0.0, 1.0), Config::MapScale(), camera)),
+      camera_(camera),
+      map_(own_map_.get()),
+      rng_(1),
+      feature_align_(map_, camera, Config::MaxMatches(), &rng_),
+      first_pose_(SE3()) {
+  state_ = STATE_FIRST_FRAME;
+  tracking_quality_ = TRACKING_GOOD;
+  lost_frames_ = 0;
+  matches_ = attempts_ = 0;
+  frame_counter_ = 0;
+}
+
+SDVL::~SDVL() {
+  if (own_map_) own_map_->Stop();
+  current_frame_.reset();
+  last_frame_.reset();
+  last_kf_.reset();
+  pending_kf_.reset();
+  own_map_.reset();     // frames go back to the device's pool before the device does
+}
+
+void SDVL::SetBootstrapPlane(const Vector3d &n, double d) {
+  if (PlaneMap *pm = dynamic_cast<PlaneMap *>(map_)) pm->SetPlane(n, d);
+}
+
+// sdvl.cc:283-291
+void SDVL::GetCameraTrail(vector<std::pair<SE3, bool>> *positions) {
+  std::unique_lock<std::mutex> lock(map_->GetMutex());
+  positions->clear();
+  for (auto it = map_->GetKeyframes().begin(); it != map_->GetKeyframes().end(); it++)
+    positions->push_back(std::make_pair((*it)->GetWorldPose(), (*it)->IsSelected()));
+}
+
+// sdvl.cc:293-324: converged points twice, the others as the two ends of their depth interval
+void SDVL::GetPoints(vector<Vector3d> *positions) {
+  std::unique_lock<std::mutex> lock(map_->GetMutex());
+  positions->clear();
+  for (auto it = map_->GetKeyframes().begin(); it != map_->GetKeyframes().end(); it++) {
+    for (auto feature = (*it)->GetFeatures().begin(); feature != (*it)->GetFeatures().end(); feature++) {
+      shared_ptr<Point> p = (*feature)->GetPoint();
+      if (!p || p->ToDelete()) continue;
+      if (p->HasConverged()) {
+        positions->push_back(p->GetPosition());
+        positions->push_back(p->GetPosition());
+      } else {
+        const double zmin = 1.0 / (p->GetInverseDepth() + 2.0 * p->GetStd());
+        const double zmax = 1.0 / (std::max(p->GetInverseDepth() - 2.0 * p->GetStd(), 0.00000001));
+        const Vector3d &v = p->GetInitFeature()->GetVector();
+        const SE3 pose = p->GetInitFeature()->GetFrame()->GetWorldPose();
+        positions->push_back(pose * Vector3d(v(0) * zmin, v(1) * zmin, v(2) * zmin));
+        positions->push_back(pose * Vector3d(v(0) * zmax, v(1) * zmax, v(2) * zmax));
+      }
+    }
+  }
+}
+
+// sdvl.cc:326-349: (x, y, Point status) of the last frame's features, then its outliers as status P_OUTLIER
+void SDVL::GetLastFeatures(vector<Vector3i> *positions) {
+  std::unique_lock<std::mutex> lock(map_->GetMutex());
+  positions->clear();
+  if (!last_frame_) return;
+  vector<shared_ptr<Feature>> &features = last_frame_->GetFeatures();
+  for (auto feature = features.begin(); feature != features.end(); feature++) {
+    shared_ptr<Point> point = (*feature)->GetPoint();
+    if (!point || point->ToDelete()) continue;
+    const Vector2d &pos = (*feature)->GetPosition();
+    positions->push_back(Vector3i(static_cast<int>(pos(0)), static_cast<int>(pos(1)), static_cast<int>(point->GetStatus())));
+  }
+  vector<Vector2d> &outliers = last_frame_->GetOutliers();
+  for (auto it = outliers.begin(); it != outliers.end(); it++)
+    positions->push_back(Vector3i(static_cast<int>((*it)(0)), static_cast<int>((*it)(1)), static_cast<int>(Point::P_OUTLIER)));
+}
 
 SE3 SDVL::GetPose() const {
   if (last_frame_) return last_frame_->GetWorldPose();
@@ -1542,6 +1647,7 @@ void SDVL::CalcTrackingQuality(int matches, int attempts) {
 }
 
 bool SDVL::HandleFrame(const Image &img) {
+  std::unique_lock<std::mutex> lock(map_->GetMutex());  // the mapper thread of threaded mode stays out meanwhile
   SDVLBatch one(Device::Current(), {this}, 1);
   one.persistent_ = false;  // a one-call batch: no device-resident tables to amortise
   FrameStats st;
@@ -1550,6 +1656,7 @@ bool SDVL::HandleFrame(const Image &img) {
 }
 
 void SDVL::Mapping() {
+  std::unique_lock<std::mutex> lock(map_->GetMutex());
   if (pending_kf_) {
     PlaneMap *pm = dynamic_cast<PlaneMap *>(map_);
     if (pm) {
@@ -1764,7 +1871,7 @@ bool SDVLBatch::BuildTable(SDVL &t, vector<sdvl_track_point> *points, vector<sdv
         tp.n_failed = pt->GetFailed();
         tp.last_frame = pt->GetLastFrame();
         tp.status = static_cast<int32_t>(pt->GetStatus());
-        if (init->HasDescriptor()) std::memcpy(tp.desc, init->GetDescriptor().data(), 32);
+        if (init->HasDescriptor()) std::memcpy(tp.desc, init->DescriptorData().data(), 32);
         else std::memset(tp.desc, 0, 32);
         if (!ref->IsRegistered()) {  // a keyframe that never was the current frame of a tracked step (bootstrap, host-path steps)
           double pose[7];
@@ -2400,7 +2507,7 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
     vector<MapperMap *> mm;
     for (int i = 0; i < B; i++) {
       MapperMap *m = dynamic_cast<MapperMap *>(trk_[i]->map_);
-      if (m && m->BeginUpdate()) mm.push_back(m);
+      if (m && !m->IsThreaded() && m->BeginUpdate()) mm.push_back(m);  // a started mapper thread does its own UpdateMap
     }
     const int M = static_cast<int>(mm.size());
     if (M > 0) {

@@ -25,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -72,6 +73,7 @@ class Device {
   void Reserve(int w, int h, int levels, int frames);
   void Check(int rc, const char *what) const;
   static Device *Current();
+  static Device *CurrentOrNull();
   static void SetCurrent(Device *d);
   uint64_t search_batch_counter = 0;  // ids of the packed search batches opened on this device's context
   std::vector<int32_t> scratch_xyl;  // Frame::FilterCornersBatch round-trip buffers
@@ -80,12 +82,17 @@ class Device {
   // source of Point ids for the trackers stepping on this device: ids only have to grow along one tracker's own history
   // (the mapper orders by id), and a counter shared by every group would bounce between their cores
   std::atomic<int> next_point_id{0};
+  // the counter Point() draws from on threads bound to this device: its own, or another device's (a tracker's mapper thread
+  // works on its own Device = its own stream, but its points belong to the tracker's id sequence)
+  std::atomic<int> *point_ids = &next_point_id;
+  int gpu() const { return gpu_; }
   // chunks for the frame arenas (features, points) of the trackers on this device; shared with the arenas, which may
   // outlive the device object
   std::shared_ptr<ChunkPool> chunks = std::make_shared<ChunkPool>();
 
  private:
   sdvl_ctx *ctx_ = nullptr;
+  int gpu_ = 0;
   struct Pooled { sdvl_frame *f; int w, h, levels; };
   std::vector<Pooled> pool_;
   std::mutex pool_mutex_;
@@ -195,9 +202,15 @@ class Feature {
   const Vector3d &GetVector() const { return v_; }
   void SetVector(Vector3d &v) { v_ = v; }
   int GetLevel() const { return level_; }
-  // the 32 descriptor bytes live inside the feature (the reference keeps a std::vector<uchar>: one more heap block and
-  // one more cache miss per search candidate)
-  const std::array<uchar, 32> &GetDescriptor() const { return descriptor_; }
+  // feature.h:78.  The 32 descriptor bytes live inside the feature (DescriptorData(): what the request loops read — the
+  // reference's std::vector<uchar> is one more heap block and one more cache miss per search candidate); the vector the
+  // reference's signature returns is made from them the first time somebody asks for it.
+  const std::vector<uchar> &GetDescriptor() const {
+    if (!descriptor_vec_) descriptor_vec_.reset(new std::vector<uchar>(32, 0));
+    if (has_descriptor_) std::memcpy(descriptor_vec_->data(), descriptor_.data(), 32);
+    return *descriptor_vec_;
+  }
+  const std::array<uchar, 32> &DescriptorData() const { return descriptor_; }
   void SetDescriptor(const std::vector<uchar> &d) {
     descriptor_.fill(0);
     std::memcpy(descriptor_.data(), d.data(), d.size() < 32 ? d.size() : 32);
@@ -220,6 +233,7 @@ class Feature {
   int level_;
   bool has_descriptor_;
   std::array<uchar, 32> descriptor_;
+  mutable std::unique_ptr<std::vector<uchar>> descriptor_vec_;
 };
 
 // Bump allocator for the many small objects that live and die with one frame (its features, the points it seeds): one
@@ -291,6 +305,7 @@ class Point {
   void SetInitFeature(const std::shared_ptr<Feature> &f) { feature_ = f; }
   int GetID() const { return id_; }
   Vector3d GetPosition() const;
+  void SetPosition(const Vector3d &pos);  // point.cc:144-162
   void InitFixed(const std::shared_ptr<Feature> &f, double depth, double sigma2, const Vector3d &p3d);
   void InitCandidate(const std::shared_ptr<Feature> &f, double depth);
   std::list<std::shared_ptr<Feature>> &GetFeatures() { return features_; }
@@ -355,8 +370,9 @@ class Frame : public std::enable_shared_from_this<Frame> {
   static void FilterCornersEnd(const std::vector<std::shared_ptr<Frame>> &frames);
   // corner detection + ORB for frames built with corners = false (CreateBatch): queues the kernels, returns at once
   static void DetectBatch(const std::vector<std::shared_ptr<Frame>> &frames, int nfeatures);
+  SE3 &GetPose() { return pose_; }  // frame.h:52: callers may write through it, so the cached inverse is checked by value
   const SE3 &GetPose() const { return pose_; }
-  void SetPose(const SE3 &se3) { pose_ = se3; world_valid_ = false; }
+  void SetPose(const SE3 &se3) { pose_ = se3; }
   std::vector<Image> &GetPyramid();  // host mirror is filled on first call
   // Features of a frame that went through the device-resident tracking tables exist as flat records first (position, level,
   // index of the point in the tracker's table) and become Feature objects the first time somebody asks for them
@@ -385,7 +401,11 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void SetID(int id) { id_ = id; }
   // pose_.Inverse(), computed once per SetPose (the mapper asks for it for every candidate of every frame)
   const SE3 &GetWorldPose() const {
-    if (!world_valid_) { world_ = pose_.Inverse(); world_valid_ = true; }
+    if (!world_valid_ || std::memcmp(&world_of_, &pose_, sizeof(SE3)) != 0) {
+      world_ = pose_.Inverse();
+      world_of_ = pose_;
+      world_valid_ = true;
+    }
     return world_;
   }
   Vector3d GetWorldPosition() const { return GetWorldPose().GetTranslation(); }
@@ -436,7 +456,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   bool pyramid_on_host_ = false;
   int width_ = 0, height_ = 0;
   SE3 pose_;
-  mutable SE3 world_;
+  mutable SE3 world_, world_of_;
   mutable bool world_valid_ = false;
   std::vector<std::shared_ptr<Feature>> features_;
   std::vector<Vector3i> corners_;
@@ -515,6 +535,13 @@ class Matcher {
 class Map {
  public:
   virtual ~Map() {}
+  // map.h:49-55,61.  The mapper thread (threaded mode, main.cc:97,120) and the tracker meet on this mutex.  It is held more
+  // coarsely than in the reference — by the tracker for a whole HandleFrame, by the mapper for a whole UpdateMap — so the two
+  // threads alternate on the shared objects while each drives its own sdvl_ctx / HIP stream.
+  std::mutex &GetMutex() { return mutex_map_; }
+  virtual void UpdateMap() {}
+  virtual void Start() {}
+  virtual void Stop() {}
   void DeletePoint(const std::shared_ptr<Point> &p) { points_trash_.push_back(p); }
   bool NeedKeyframe(const std::shared_ptr<Frame> &frame, int matches);  // map.cc:170-188
   virtual void AddKeyframe(const std::shared_ptr<Frame> &frame, bool search = true);
@@ -531,6 +558,7 @@ class Map {
   std::vector<std::shared_ptr<Point>> points_trash_;
   std::shared_ptr<Frame> last_kf_;
   int last_matches_ = 0;
+  std::mutex mutex_map_;
 };
 
 // Map stand-in for synthetic scenes: seeds one FIXED point per FilterCorners() corner of a keyframe, depth from a
@@ -540,6 +568,7 @@ class PlaneMap : public Map {
   PlaneMap(const Vector3d &n, double d) : n_(n), d_(d) {}
   void InitCandidates(const std::shared_ptr<Frame> &kf) override;
   void SeedFromFiltered(const std::shared_ptr<Frame> &kf);  // after Frame::FilterCorners()
+  void SetPlane(const Vector3d &n, double d) { n_ = n; d_ = d; }
 
  private:
   Vector3d n_;
@@ -577,7 +606,15 @@ class MapperMap : public PlaneMap {
   void ApplyInitCandidates(const sdvl_search_res *res);
   void FinishUpdate();                                           // CheckRedundantKeyframes + trash for ordinary frames
   // the whole of it for one tracker (one launch per phase)
-  void UpdateMap();
+  void UpdateMap() override;
+  // map.cc:49-71: the mapper thread of threaded mode.  It works on a Device of its own (one sdvl_ctx = one HIP stream per
+  // host thread, include/sdvl_hip.h) on the tracker's GPU and shares the tracker's frames read-only.
+  ~MapperMap() override;
+  void Start() override;
+  void Stop() override;
+  void Run();
+  long Updates() const { return updates_; }  // UpdateMap calls that found a frame to work on
+  bool IsThreaded() const { return running_; }
 
   struct Stats { int candidates = 0, converged = 0, initialized = 0, linked = 0, connected = 0, keyframes = 0; };
   Stats GetStats() const;
@@ -603,6 +640,10 @@ class MapperMap : public PlaneMap {
   std::vector<std::shared_ptr<Frame>> best_kfs_;
   std::vector<int> ic_req_;                                // InitCandidates: request of (kf k, filtered corner c) or -1
   std::vector<std::shared_ptr<Feature>> ic_feature_;
+  std::thread thread_;
+  std::atomic<bool> running_{false};
+  std::atomic<long> updates_{0};
+  Device *tracker_device_ = nullptr;  // whose GPU and point-id sequence the mapper thread joins
 };
 
 typedef std::pair<std::shared_ptr<Point>, Vector2d> PointInfo;
@@ -613,6 +654,8 @@ typedef std::list<PointInfo> GridCell;
 // its time on once the kernels are batched.
 class FeatureAlign {
  public:
+  FeatureAlign(Map *map, Camera *camera, int max_matches);  // feature_align.h:46: draws from a rand() stream of its own
+  // the same with the caller's stream (B trackers in one process each own the stream a lone reference process would see)
   FeatureAlign(Map *map, Camera *camera, int max_matches, RandStream *rng);
   ~FeatureAlign();
   void Reproject(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, const std::shared_ptr<Frame> &last_kf,
@@ -683,6 +726,7 @@ class FeatureAlign {
 
   Map *map_;
   Camera *camera_;
+  std::unique_ptr<RandStream> own_rng_;
   RandStream *rng_;
   int cell_size_, max_matches_, grid_width_, grid_height_;
   std::vector<std::vector<CellEntry>> grid_;
@@ -726,18 +770,35 @@ class SDVL {
  public:
   enum State { STATE_FIRST_FRAME, STATE_SECOND_FRAME, STATE_RUNNING };
   enum TrackingQuality { TRACKING_GOOD, TRACKING_INSUFFICIENT, TRACKING_BAD };
+  // sdvl.h:49: the tracker owns its map (the reference's mapper, MapperMap).  The two-frame homography bootstrap is out of
+  // scope, so the first keyframe's points come from a scene plane: z = Config::MapScale() in the first camera's frame (the
+  // depth the reference's initialisation normalises the map to) unless SetBootstrapPlane says otherwise.  A Device for the
+  // calling thread is created if none is bound yet (GPU 0, or SDVL_GPU).
+  explicit SDVL(Camera *camera);
+  // additions: a caller-owned map (PlaneMap stub or MapperMap) and first pose — what SDVLBatch's trackers are built with
   SDVL(Camera *camera, Map *map, const SE3 &first_pose = SE3());
   ~SDVL();
+  void SetBootstrapPlane(const Vector3d &n, double d);
+  // sdvl.h:52-54 (the UI's queries)
+  void GetCameraTrail(std::vector<std::pair<SE3, bool>> *positions);
+  void GetPoints(std::vector<Vector3d> *positions);
+  void GetLastFeatures(std::vector<Vector3i> *positions);
+  // sdvl.h:58-60: Start / Stop the mapper thread (threaded mode, main.cc:120); Mapping() = one mapper step (sequential mode)
+  void Start() { map_->Start(); }
+  void Stop() { map_->Stop(); }
+  void Mapping();
   bool HandleFrame(const Image &img);
   SE3 GetPose() const;
   TrackingQuality GetTrackingQuality() const { return tracking_quality_; }
   bool HasMap() { return state_ == STATE_RUNNING; }
   const FrameStats &LastStats() const { return stats_; }
-  void Mapping();  // sequential-mode mapper step (main.cc:148-149): seeds points on a fresh keyframe
+  Map *GetMap() { return map_; }
 
  private:
   friend class SDVLBatch;
   void CalcTrackingQuality(int matches, int attempts);
+  std::unique_ptr<Device> own_device_;  // SDVL(Camera*) on a thread without a Device
+  std::unique_ptr<Map> own_map_;        // SDVL(Camera*): the reference's `Map map_` member
   Camera *camera_;
   Map *map_;
   ORBDetector orb_detector_;

@@ -38,9 +38,15 @@ typedef Vec<double, 6> Vector6d;
 
 // cv::Mat (CV_8UC1) subset.  `data` is a host mirror (may be null until HostData() is called on the owning
 // Frame); dev/level bind the image to an HBM-resident pyramid level.
+enum { CV_8UC1 = 0 };  // the only cv::Mat type the tracking front-end sees (frame.cc:38-41 converts to grey)
+
 struct Image {
   const uint8_t *data = nullptr;
   int cols = 0, rows = 0, step = 0;
+  Image() {}
+  // cv::Mat(rows, cols, type, data, step): a header over caller-owned pixels
+  Image(int rows_, int cols_, int /*type*/, const void *pixels, size_t step_ = 0)
+      : data(static_cast<const uint8_t *>(pixels)), cols(cols_), rows(rows_), step(step_ ? static_cast<int>(step_) : cols_) {}
   sdvl_frame *dev = nullptr;
   int level = 0;
   std::shared_ptr<std::vector<uint8_t>> owner;  // keeps a host copy alive (cv::Mat ref-count analogue)

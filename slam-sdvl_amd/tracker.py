@@ -200,6 +200,11 @@ class TrackerFarm:
         self.lib.sdvlh_farm_set_fibers.argtypes = [C.c_void_p, C.c_int]
         self.lib.sdvlh_farm_set_fibers(self.h, int(n))
 
+    def set_host_input(self, on):
+        """the pointers of run() are HOST pointers (pinned memory): every step uploads its frames inside the step"""
+        self.lib.sdvlh_farm_set_host_input.argtypes = [C.c_void_p, C.c_int]
+        self.lib.sdvlh_farm_set_host_input(self.h, int(bool(on)))
+
     def alloc_stats(self, n_steps):
         """output records for run(); touched here so that the workers do not take the first-touch page faults"""
         out = (FrameStats * (n_steps * self.G * self.Bg))()

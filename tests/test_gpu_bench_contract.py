@@ -27,6 +27,10 @@ def check(d, steps=4, warmup=1):
     assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["input"].startswith("hbm_resident")
+    # the host-fed leg (frames uploaded inside the step) rides along and is never the headline value
+    assert d["value_host_fed"] == d["host_fed"]["value"] and d["value_host_fed"] > 0
+    assert d["host_fed"]["pcie_h2d_gb_per_s"] > 0 and d["host_fed"]["steps"] >= 1
     assert d["value"] > 0 and abs(d["value"] - 32 * steps / (d["ms_per_step"] * steps / 1e3)) / d["value"] < 0.02   # every frame tracked
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0

@@ -358,3 +358,18 @@ def test_cpp_single_call_api_surface():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
     assert len(lines) >= 16 and all(l.startswith("ok") for l in lines[:-1]) and lines[-1] == "0 check(s) failed"
+
+
+def test_cpp_threaded_mode_tracker_and_mapper_on_two_threads():
+    """slam-sdvl_amd/host/threaded_mode_check: main.cc's default mode (handler->Start(): the mapper runs on its own thread,
+    map.cc:49-71) — two host threads inside the path, each with its own sdvl_ctx / stream, frames shared read-only.  The
+    reference is not deterministic there, so: every frame tracked, pose on the rendered trajectory, the mapper thread did
+    its work, the map is comparable to sequential mode's (the program prints both and checks)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam-sdvl_amd", "host", "threaded_mode_check")
+    assert os.path.exists(exe), "build() makes it (make -C slam-sdvl_amd/host)"
+    r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("sequential") and lines[1].startswith("threaded")
+    assert len(lines) >= 8 and all(l.startswith("ok") for l in lines[2:])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU occupancy of the timed part of a traced bench run, from rocprofv3's kernel_trace.csv:
 busy = union of the dispatch intervals / wall, overlap = sum of the dispatch durations / union.
-    python tools/trace_overlap.py <kernel_trace.csv> [skip_fraction]"""
+    python tools/trace_overlap.py <kernel_trace.csv> [skip_fraction] [anchor kernel: window = its dispatches after the skip]"""
 import csv
 import sys
 
@@ -11,9 +11,15 @@ with open(sys.argv[1]) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
+anchor = sys.argv[3] if len(sys.argv) > 3 else None
 t0, t1 = rows[0][0], max(r[1] for r in rows)
-lo = t0 + (t1 - t0) * skip                       # drop rendering + warm-up at the front
-rows = [r for r in rows if r[0] >= lo and "synth_render" not in r[2]]
+if anchor:   # window = from the dispatch of `anchor` at fraction `skip` of its dispatches to its last one (the timed steps)
+    a = [r for r in rows if anchor in r[2]]
+    lo, hi = a[int(len(a) * skip)][0], a[-1][1]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= hi and "synth_render" not in r[2]]
+else:
+    lo = t0 + (t1 - t0) * skip                       # drop rendering + warm-up at the front
+    rows = [r for r in rows if r[0] >= lo and "synth_render" not in r[2]]
 wall = max(r[1] for r in rows) - rows[0][0]
 union, cur_s, cur_e, total = 0, None, None, 0
 for s, e, _ in rows:
