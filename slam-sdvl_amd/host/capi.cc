@@ -68,6 +68,17 @@ void *sdvlh_device_ctx(void *d) { return static_cast<Device *>(d)->ctx(); }
 int sdvlh_config_set(const char *key, double value) { return Config::GetInstance().SetParameter(key, value) ? 0 : -1; }
 int sdvlh_config_read(const char *filename) { return Config::GetInstance().ReadParameters(filename) ? 0 : -1; }
 void sdvlh_config_reset() { Config::GetInstance().Reset(); }
+// the values a test compares with its own copies of the reference's configuration files: camera block (11) followed by the
+// SDVL.* keys those files set: cell_size, min_avg_shift, max_matches, max_keyframes, use_orb, fast_threshold, lost_ratio,
+// num_features, min_matches
+void sdvlh_config_snapshot(double *out20) {
+  const CameraParameters &c = Config::GetCameraParameters();
+  const double v[20] = {static_cast<double>(c.width), static_cast<double>(c.height), c.fx, c.fy, c.u0, c.v0, c.d1, c.d2, c.d3, c.d4, c.d5,
+                        static_cast<double>(Config::CellSize()), static_cast<double>(Config::MinAvgShift()), static_cast<double>(Config::MaxMatches()),
+                        static_cast<double>(Config::MaxKeyframes()), Config::UseORB() ? 1.0 : 0.0, static_cast<double>(Config::FastThreshold()),
+                        Config::LostRatio(), static_cast<double>(Config::NumFeatures()), static_cast<double>(Config::MinMatches())};
+  for (int i = 0; i < 20; i++) out20[i] = v[i];
+}
 // test hook: the host build of the sin/cos the ORB kernels use (csrc/sdvl_math.h), same IEEE arithmetic as on the device
 void sdvlh_sincos_2pi(double x, double *sn, double *cs) { sincos_2pi(x, sn, cs); }
 

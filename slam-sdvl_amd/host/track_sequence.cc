@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
   unsigned seed = 20260001;
   double cam4[4] = {517.3, 516.5, 318.6, 255.3}, dist[5] = {0, 0, 0, 0, 0}, plane[4] = {0, 0, 1, 2.0};
   std::string list, cfg;
-  bool mapper = false;
+  bool mapper = false, size_given = false, cam_given = false, dist_given = false;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto need = [&](int k) { if (i + k >= argc) { std::cerr << "missing value after " << a << std::endl; std::exit(2); } };
@@ -65,9 +65,9 @@ int main(int argc, char **argv) {
     else if (a == "--seed") { need(1); seed = static_cast<unsigned>(std::strtoul(argv[++i], nullptr, 10)); }
     else if (a == "--list") { need(1); list = argv[++i]; }
     else if (a == "--config") { need(1); cfg = argv[++i]; }
-    else if (a == "--size") { need(2); W = std::atoi(argv[++i]); H = std::atoi(argv[++i]); }
-    else if (a == "--cam") { need(4); for (int k = 0; k < 4; k++) cam4[k] = std::atof(argv[++i]); }
-    else if (a == "--dist") { need(5); for (int k = 0; k < 5; k++) dist[k] = std::atof(argv[++i]); }
+    else if (a == "--size") { need(2); W = std::atoi(argv[++i]); H = std::atoi(argv[++i]); size_given = true; }
+    else if (a == "--cam") { need(4); for (int k = 0; k < 4; k++) cam4[k] = std::atof(argv[++i]); cam_given = true; }
+    else if (a == "--dist") { need(5); for (int k = 0; k < 5; k++) dist[k] = std::atof(argv[++i]); dist_given = true; }
     else if (a == "--plane") { need(4); for (int k = 0; k < 4; k++) plane[k] = std::atof(argv[++i]); }
     else if (a == "--mapper") mapper = true;
     else { std::cerr << "unknown argument " << a << std::endl; return 2; }
@@ -79,7 +79,14 @@ int main(int argc, char **argv) {
   c.SetParameter("SDVL.cell_size", 32); c.SetParameter("SDVL.max_matches", 200); c.SetParameter("SDVL.use_orb", 1);
   c.SetParameter("SDVL.fast_threshold", 10); c.SetParameter("SDVL.num_features", 1000); c.SetParameter("SDVL.min_avg_shift", 5);
   c.SetParameter("SDVL.max_keyframes", 1000); c.SetParameter("SDVL.lost_ratio", 0.7);
-  if (!cfg.empty() && !c.ReadParameters(cfg)) { std::cerr << "cannot read " << cfg << std::endl; return 2; }
+  if (!cfg.empty()) {
+    if (!c.ReadParameters(cfg)) { std::cerr << "cannot read " << cfg << std::endl; return 2; }
+    // the camera block of the file (main.cc:72: Camera() reads it) unless --size / --cam / --dist said otherwise
+    const CameraParameters &cp = Config::GetCameraParameters();
+    if (!size_given) { W = cp.width; H = cp.height; }
+    if (!cam_given) { cam4[0] = cp.fx; cam4[1] = cp.fy; cam4[2] = cp.u0; cam4[3] = cp.v0; }
+    if (!dist_given) { dist[0] = cp.d1; dist[1] = cp.d2; dist[2] = cp.d3; dist[3] = cp.d4; dist[4] = cp.d5; }
+  }
 
   std::vector<std::string> files;
   if (!list.empty()) {

@@ -65,6 +65,8 @@ def ptr(a, t):
 TUM_DIST = np.array([0.2624, -0.9531, -0.0054, 0.0026, 1.1633])   # config/config_tum_f1.cfg:15-19
 EUROC_DIST = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0])  # config/config_euroc.cfg:15-19
 TUM_CAM = np.array([517.3, 516.5, 318.6, 255.3])          # config/config_tum_f1.cfg:11-14
+TUM2_CAM = np.array([520.9, 521.0, 325.1, 249.7])         # config/config_tum_f2.cfg:11-14
+TUM2_DIST = np.array([0.2312, -0.7849, -0.0033, -0.0001, 0.9172])  # config/config_tum_f2.cfg:15-19
 EUROC_CAM = np.array([458.654, 457.296, 367.215, 248.375])  # config/config_euroc.cfg
 XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])  # SURVEY §8d trajectory twist per frame
 

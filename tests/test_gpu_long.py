@@ -1,0 +1,193 @@
+"""The long end of the closed-loop parity suite: whole S-A sequences (300 frames) against the CPU oracle with and
+without the reference's mapper — long enough for keyframe culling, LimitKeyframes and MaxFailed deletions to happen —,
+relocalisation over dozens of keyframes of which the newest fail, and BASELINE's configuration C on the 64-sequence farm."""
+import importlib
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from oraclelib import TUM_CAM, TUM2_CAM, TUM2_DIST, XI, trajectory_pose
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def trk():
+    importlib.import_module("slam-sdvl_amd")
+    return importlib.import_module("slam-sdvl_amd.tracker")
+
+
+def same(g, w, k, with_reloc=False):
+    a = (g.state, g.quality, g.keyframe, g.n_corners, g.matches, g.attempts, g.inliers, g.outliers, g.align_meas)
+    b = (w.state, w.quality, w.keyframe, w.n_corners, w.matches, w.attempts, w.inliers, w.outliers, w.align_meas)
+    assert a == b, (k, a, b)
+    if with_reloc:
+        assert g.relocalized == w.relocalized, k
+
+
+def test_s_a_300_frames_then_relocalisation_over_many_keyframes(trk, orc, synth):
+    """S-A as SURVEY §8d defines it: 300 frames, device-resident tracking tables, plane map — every per-frame decision equals
+    the oracle's, poses within 1e-4.  The sequence leaves ~60 keyframes behind.  Then the camera is covered for four frames
+    and uncovered looking at where it was around frame 120: Relocalize (sdvl.cc:205-238) walks the keyframes newest first,
+    the newest dozens fail (alignment error or too few matches; `fast` stops them early, image_align.cc:75-77), an old one
+    succeeds — the first success in the reference's order, as the oracle finds it."""
+    trk.configure()
+    dev = trk.HostDevice(0)
+    batch = trk.TrackerBatch(dev, 1, 640, 480, TUM_CAM)
+    ref = orc.tracker(640, 480, TUM_CAM)
+    n_kf, worst, deleted_seen = 0, 0.0, 0
+    for k in range(300):
+        img = synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, frame_id=k)
+        g, w = batch.step_host([img])[0], ref.handle_frame(img)
+        same(g, w, k)
+        d = np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max()
+        worst = max(worst, d)
+        assert d <= POSE_TOL, (k, d)
+        if k > 0:
+            assert g.quality == 0 and g.matches >= 100
+        n_kf += g.keyframe
+    assert n_kf >= 50, n_kf
+    relocs = 0
+    seq = [-1, -1, -1, -1, 120, 121, 122, 123, 124]
+    for j, idx in enumerate(seq):
+        img = np.full((480, 640), 127, np.uint8) if idx < 0 else synth.render(trajectory_pose(orc, idx), TUM_CAM, 640, 480, frame_id=idx)
+        g, w = batch.step_host([img])[0], ref.handle_frame(img)
+        a = (g.quality, g.matches, g.attempts, g.inliers, g.keyframe, g.relocalized)
+        b = (w.quality, w.matches, w.attempts, w.inliers, w.keyframe, w.relocalized)
+        if idx < 0:   # a featureless frame: the alignment is degenerate (the Gauss-Newton steps amplify rounding differences of the
+            a, b = a[:2] + a[3:], b[:2] + b[3:]   # sums), so how many points the garbage pose projects into the image is not comparable
+        assert a == b, (j, idx, a, b)
+        if idx >= 0:
+            assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, (j, idx)
+        relocs += g.relocalized
+    assert relocs == 1 and g.quality == 0 and g.matches >= 100      # found an old keyframe and tracks again from there
+    batch.close(); ref.close(); dev.close()
+
+
+def test_s_a_300_frames_with_the_reference_mapper(trk, orc, synth):
+    """the same 300 frames with the reference's mapper inside every step (sequential mode): decisions, poses AND the map's
+    bookkeeping (candidates alive / converged / initialised / linked, connections, keyframes after CheckRedundantKeyframes and
+    LimitKeyframes) equal the oracle's frame by frame; candidates that fail MaxFailed times are deleted on both sides"""
+    trk.configure()
+    trk.set_mapper(True)
+    try:
+        dev = trk.HostDevice(0)
+        batch = trk.TrackerBatch(dev, 1, 640, 480, TUM_CAM)
+    finally:
+        trk.set_mapper(False)
+    ref = orc.tracker(640, 480, TUM_CAM)
+    ref.use_mapper(True)
+    peak_kf, last = 0, None
+    for k in range(300):
+        img = synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, frame_id=k)
+        g, w = batch.step_host([img])[0], ref.handle_frame(img)
+        same(g, w, k)
+        assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, k
+        last = batch.map_stats(0)
+        assert last == ref.map_stats(), (k, last, ref.map_stats())
+        peak_kf = max(peak_kf, last["keyframes"])
+    assert last["converged"] > 200 and last["initialized"] > last["candidates"] // 2 and peak_kf >= 10
+    batch.close(); ref.close(); dev.close()
+
+
+def test_config_c_farm_of_64_sequences(trk, orc, synth):
+    """BASELINE configuration C as SURVEY §8d sizes it — 1280x960, num_features 4000, max_matches 1000, 64 independent
+    sequences per GPU — on the farm (8 groups of 8, one stream each) for 10 steps: every sequence equals its CPU oracle."""
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    cam = np.array([1034.6, 1033.0, 637.2, 510.6])
+    W, H, G, Bg, n_steps = 1280, 960, 8, 8, 11
+    n = G * Bg
+    over = dict(trk.TUM_OVERRIDES)
+    over.update({"SDVL.num_features": 4000, "SDVL.max_matches": 1000})
+    trk.configure(over)
+    saved = (orc.params.num_features, orc.params.max_matches)
+    orc.params.num_features, orc.params.max_matches = 4000, 1000
+    try:
+        farm = trk.TrackerFarm(0, G, Bg, W, H, cam)
+        ctx = B.CtxView(sdvl, farm.ctx_handle(0))
+        fb = W * H
+        xis = [XI * (1.0 + 0.05 * (i % 7)) * (1 if (i // 7) % 2 == 0 else -1) for i in range(n)]
+        buf = ctx.malloc(n * n_steps * fb)
+        old = (B.W_IMG, B.H_IMG, B.TUM_CAM)
+        B.W_IMG, B.H_IMG, B.TUM_CAM = W, H, cam
+        try:
+            for k in range(n_steps):
+                views = [B.make_view(sdvl, trajectory_pose(orc, k, xis[i]), 20260100 + i, k) for i in range(n)]
+                ctx.render(views, buf + k * n * fb)
+        finally:
+            B.W_IMG, B.H_IMG, B.TUM_CAM = old
+        ptrs = (buf + (np.arange(n_steps, dtype=np.uint64)[:, None] * n + np.arange(n, dtype=np.uint64)[None, :]) * fb).astype(np.uint64)
+        farm.reserve(Bg * 8)
+        st = farm.run(ptrs, G)
+
+        def check(i):
+            o = orc.tracker(W, H, cam)
+            worst = 0.0
+            for k in range(n_steps):
+                img = ctx_dl[i][k]
+                w = o.handle_frame(img)
+                g = st[k * n + i]
+                a = (g.state, g.quality, g.keyframe, g.n_corners, g.matches, g.attempts, g.inliers, g.outliers, g.align_meas)
+                b = (w.state, w.quality, w.keyframe, w.n_corners, w.matches, w.attempts, w.inliers, w.outliers, w.align_meas)
+                assert a == b, (i, k, a, b)
+                worst = max(worst, float(np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max()))
+            o.close()
+            return worst
+
+        ctx_dl = [[ctx.download(buf + (k * n + i) * fb, fb).reshape(H, W) for k in range(n_steps)] for i in range(n)]
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:      # the oracle calls release the GIL
+            worst = max(ex.map(check, range(n)))
+        assert worst <= POSE_TOL
+        assert min(st[(n_steps - 1) * n + i].matches for i in range(n)) > 256
+        farm.close()
+    finally:
+        orc.params.num_features, orc.params.max_matches = saved
+        trk.configure()
+
+
+def test_pgm_list_with_tum_f2_intrinsics_and_distortion(orc, synth, tmp_path):
+    """How a real TUM / EuRoC sequence goes through the C++ front-end and the oracle (no dataset ships with the repo): grey
+    frames as a list of binary PGMs + the dataset's own configuration file.  Here: frames rendered with the intrinsics of
+    config_tum_f2.cfg and distorted-camera coefficients of the same file, so Camera::UndistortImage (camera.cc:100-105) is
+    inside the loop on both sides.
+        host/track_sequence --list frames.txt --config config_tum_f2.cfg
+    prints what tools/oracle_pgm_list.py (the CPU oracle on the same list) prints."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "slam-sdvl_amd", "host", "track_sequence")
+    n = 8
+    imgs = [synth.render(trajectory_pose(orc, k), TUM2_CAM, 640, 480, frame_id=k) for k in range(n)]
+    lst = tmp_path / "frames.txt"
+    with open(lst, "w") as fh:
+        for k, im in enumerate(imgs):
+            p = tmp_path / ("f%03d.pgm" % k)
+            with open(p, "wb") as out:
+                out.write(b"P5\n640 480\n255\n")
+                out.write(im.tobytes())
+            fh.write(str(p) + "\n")
+    cfg = tmp_path / "config_tum_f2.cfg"
+    with open(cfg, "w") as fh:      # the camera block + SDVL block of the reference's config/config_tum_f2.cfg
+        fh.write("%YAML:1.0\nCamera.width: 640\nCamera.height: 480\n")
+        for key, v in zip(("fx", "fy", "u0", "v0"), TUM2_CAM):
+            fh.write("Camera.%s: %r\n" % (key, float(v)))
+        for i, v in enumerate(TUM2_DIST):
+            fh.write("Camera.d%d: %r\n" % (i + 1, float(v)))
+        fh.write('Video.type: 1\nVideo.path: "/../tum/f2_kidnap/rgb/"\nSDVL.cell_size: 32\nSDVL.min_avg_shift: 5\nSDVL.max_matches: 200\n'
+                 "SDVL.max_keyframes: 1000\nSDVL.use_orb: 1\nSDVL.fast_threshold: 10\nSDVL.lost_ratio: 0.7\nSDVL.num_features: 1000\n")
+    r = subprocess.run([exe, "--list", str(lst), "--config", str(cfg)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    o = subprocess.run([sys.executable, os.path.join(root, "tools", "oracle_pgm_list.py"), "--list", str(lst), "--config", str(cfg)],
+                       capture_output=True, text=True, timeout=300)
+    assert o.returncode == 0, o.stderr
+    got = [l.split() for l in r.stdout.strip().splitlines()]
+    want = [l.split() for l in o.stdout.strip().splitlines()]
+    assert len(got) == n and len(want) == n
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert a[:6] == b[:6], (k, a[:6], b[:6])                   # frame, state, quality, matches, attempts, inliers
+        assert np.abs(np.array([float(v) for v in a[6:13]]) - np.array([float(v) for v in b[6:13]])).max() <= POSE_TOL, k
+    assert int(got[-1][3]) >= 100                                    # tracked, through the undistortion
