@@ -136,6 +136,14 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
         "search_prepare": n_s * (120 + 80),                            # request records read, scalar-phase records written
         "pose_hypotheses": 48 * n_m + 100 * 64,                      # match records read once + one result per RANSAC draw
         "pose_refine": 48 * n_m + 100 * 64 + 4 * n_m + 80,           # matches + draw results read, index lists + pose written
+        # device-resident tracking tables (sdvl_track.hip): feature + point rows read, alignment records / requests / new rows written
+        "track_align_prep": n_f * (48 + 24 + 56),
+        "track_project": n_f * (48 + 144) + n_s * (136 + 24 + 8),
+        "track_commit": n_s * (40 + 8) + n_m * (48 + 24) + n_f * 16,
+        # keyframes only: Shi-Tomasi scores + corner records read, one record + one 31x31 ORB window per kept corner (~1 in 4)
+        "filter_select": n_c * (16 + 8) + 0.25 * n_c * 56,
+        "filter_describe": 0.25 * n_c * (961 + 32),
+        "shi_tomasi": n_c * (100 + 8),
     }.get(kernel)
 
 
@@ -369,7 +377,7 @@ def main():
         if args.groups:
             G = args.groups
         else:
-            workers_auto = max(1, min(cpus_rank, 16))
+            workers_auto = max(1, min(cpus_rank, 16) // max(1, args.threads))   # a group's helper threads come out of the same share
             if fibers <= 1 and cpus_rank < 12 and not args.workers:
                 fibers = 2
             G = max(1, min(B // 8 if B >= 8 else 1, workers_auto * max(1, fibers)))
@@ -520,7 +528,8 @@ def main():
 
     if rank == 0:
         frames_rank = B * K
-        dom = max(timers.items(), key=lambda kv: kv[1][0]) if timers else None
+        priced = {k: v for k, v in timers.items() if algorithmic_bytes_per_frame(k, 1, 1, 1, 1, 1) is not None}
+        dom = max(priced.items(), key=lambda kv: kv[1][0]) if priced else None   # the kernel with the most dispatch time
         roofline = None
         if dom:
             name, (ms, launches) = dom
@@ -531,7 +540,7 @@ def main():
             launches_per_step = launches / K          # all groups together
             if per_frame is not None:
                 # descriptors of whole frames, Shi-Tomasi scores and the filter gather run on the frames that become keyframes only
-                frames_per_step = n_kf / K if name in ("orb_describe", "shi_tomasi", "filter_gather") else B
+                frames_per_step = n_kf / K if name in ("orb_describe", "shi_tomasi", "filter_gather", "filter_select", "filter_describe") else B
                 bytes_per_launch = per_frame * frames_per_step / launches_per_step
                 achieved = bytes_per_launch / avg_s / 1e9
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -210,6 +210,24 @@ int sdvl_filter_inputs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap,
 int sdvl_filter_inputs_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int with_desc);
 int sdvl_filter_inputs_end(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, int32_t *xyl, double *scores, uint8_t *desc,
                            int32_t *counts);
+/* Frame::FilterCorners (frame.cc:133-163) for n frames INCLUDING the selection of FastDetector::FilterCorners
+ * (fast_detector.cc:177-218): per frame the corners outside the margin or in a locked cell are dropped, every other cell
+ * keeps the corner the reference's sequential scan would keep (a later corner wins when its Shi-Tomasi score exceeds the
+ * TRUNCATED score stored for the cell), cells whose score stays <= min_feature_score are dropped, and the survivors come
+ * back in cell order with their ORB descriptors (the reference computes descriptors for the filtered corners only).
+ * locked_cells[i][mask_words]: bit c of frame i's mask = grid cell c already holds a feature (FastDetector::LockCell on the
+ * frame's features, frame.cc:139-142); grid = ceil(width / cell_size) x ceil(height / cell_size), at most 4096 cells.
+ * _begin queues everything, _end waits and returns counts[n] and records out[n][cap] (cap >= the cell count is always enough). */
+typedef struct sdvl_filtered_corner {
+  int32_t index;        /* position in the frame's corner list (Frame::GetFilteredCorners() holds these) */
+  int32_t x, y, level;  /* the corner, level coordinates */
+  int32_t score;        /* the cell's stored score: (int) Shi-Tomasi score */
+  int32_t pad_;
+  uint8_t desc[32];
+} sdvl_filtered_corner;
+int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const uint32_t *locked_cells, int mask_words, int cell_size,
+                              int margin, int min_feature_score, int with_desc);
+int sdvl_filter_corners_end(sdvl_ctx *ctx, int n, int cap, int32_t *counts, sdvl_filtered_corner *out);
 /* ORBDetector::GetDescriptor at arbitrary (x,y,level) points of one frame; out_angle_deg may be NULL */
 int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const int32_t *xyl, uint8_t *out_desc,
                              float *out_angle_deg);

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <vector>
 
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
@@ -30,6 +31,7 @@ struct IaJob {
   const uint8_t *cur_level[SDVL_MAX_LEVELS];
   int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
   int feat_begin, n_feat;
+  int out_index, pad_;  // slot of this job's result (jobs are regrouped by size before the launch)
   double T[7];
   float *patch_cache;  // [n_feat*16]
   double *jac_cache;   // [n_feat*16][6]
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void image_align_kernel(const IaJob *__re
     r.stop = stop ? 1 : 0;
     r.iters_run = iters_run;
     r.pad_ = 0;
-    out[blockIdx.x] = r;
+    out[job.out_index] = r;
   }
 }
 
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
     r.stop = stop ? 1 : 0;
     r.iters_run = iters_run;
     r.pad_ = 0;
-    out[blockIdx.x] = r;
+    out[job.out_index] = r;
   }
 }
 
@@ -613,8 +615,13 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   SDVL_REQUIRE(ctx, p->patch_size == 4, "only align_patch_size 4 is supported");
   SDVL_REQUIRE(ctx, p->min_level >= 0 && p->max_level >= p->min_level && p->max_level < SDVL_MAX_LEVELS, "bad align levels");
   SDVL_REQUIRE(ctx, p->max_its >= 0, "bad max_its");
+  // Jobs whose features fit the LDS-resident kernel run there; the (few) larger ones of the same call go to the global-memory
+  // kernel in a second launch.  One oversized job used to send the whole batch to the slow kernel: with 256 trackers per
+  // launch there is almost always a fresh keyframe with more than 384 features among them.
+  const bool force_generic = getenv("SDVL_IMAGE_ALIGN_GENERIC") != nullptr;
+  std::vector<int> order(n_jobs);
+  int n_lds = 0, max_nf_lds = 0;
   size_t work = 0;
-  int max_nf = 0;
   for (int j = 0; j < n_jobs; j++) {
     const sdvl_align_job &a = jobs[j];
     SDVL_REQUIRE(ctx, a.ref && a.cur, "null frame in alignment job");
@@ -626,14 +633,23 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
       ctx->err = "too many features in one alignment job (SDVL_MAX_ALIGN_FEATURES)";
       return SDVL_ERR_CAPACITY;
     }
-    if (a.feat_end - a.feat_begin > max_nf) max_nf = a.feat_end - a.feat_begin;
   }
-  const bool use_lds = max_nf <= kLdsMaxF && !getenv("SDVL_IMAGE_ALIGN_GENERIC");
-  if (!use_lds)  // the global-memory variant keeps its patch / Jacobian caches in the work buffer
+  {  // LDS-sized jobs first, the others behind them; results are written to each job's own slot, so the order is free
+    int lo = 0, hi = n_jobs;
     for (int j = 0; j < n_jobs; j++) {
-      work += static_cast<size_t>(jobs[j].feat_end - jobs[j].feat_begin) * 16 * (sizeof(float) + 6 * sizeof(double));
-      work = (work + 255) / 256 * 256;
+      const int nf = jobs[j].feat_end - jobs[j].feat_begin;
+      if (!force_generic && nf <= kLdsMaxF) {
+        order[lo++] = j;
+        if (nf > max_nf_lds) max_nf_lds = nf;
+      } else {
+        order[--hi] = j;
+        work += static_cast<size_t>(nf) * 16 * (sizeof(float) + 6 * sizeof(double));
+        work = (work + 255) / 256 * 256;
+      }
     }
+    n_lds = lo;
+  }
+  const int n_gen = n_jobs - n_lds;
   const size_t job_bytes = (sizeof(IaJob) * n_jobs + 255) / 256 * 256;
   const size_t feat_bytes = d_features ? 0 : sizeof(sdvl_align_feature) * static_cast<size_t>(n_features);
   const size_t res_bytes = sizeof(sdvl_align_result) * n_jobs;
@@ -646,9 +662,9 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   IaJob *hj = static_cast<IaJob *>(hs);
   uint8_t *wbase = static_cast<uint8_t *>(ctx->d_work);
   size_t woff = 0;
-  for (int j = 0; j < n_jobs; j++) {
-    const sdvl_align_job &a = jobs[j];
-    IaJob &d = hj[j];
+  for (int q = 0; q < n_jobs; q++) {
+    const sdvl_align_job &a = jobs[order[q]];
+    IaJob &d = hj[q];
     memset(&d, 0, sizeof(IaJob));
     for (int l = 0; l < a.ref->v.levels; l++) {
       d.ref_level[l] = a.ref->v.level[l];
@@ -658,8 +674,9 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     }
     d.feat_begin = a.feat_begin;
     d.n_feat = a.feat_end - a.feat_begin;
+    d.out_index = order[q];
     for (int k = 0; k < 7; k++) d.T[k] = a.T[k];
-    if (!use_lds) {
+    if (q >= n_lds) {
       const size_t items = static_cast<size_t>(d.n_feat) * 16;
       d.jac_cache = reinterpret_cast<double *>(wbase + woff);
       d.patch_cache = reinterpret_cast<float *>(wbase + woff + items * 6 * sizeof(double));
@@ -673,8 +690,8 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   const bool direct = sdvl_direct_results();
   sdvl_align_result *dst = d_results ? d_results : static_cast<sdvl_align_result *>(direct ? ctx->h_out : ctx->d_out);
-  if (use_lds) {
-    const int max_f = (max_nf + 7) / 8 * 8 + 8;
+  if (n_lds > 0) {
+    const int max_f = (max_nf_lds + 7) / 8 * 8 + 8;
     const size_t lds = ia_lds_bytes(max_f);
     // the attribute belongs to the kernel object of ONE device: set it once per device, whichever thread gets there first
     static std::atomic<unsigned long long> attr_devices{0};
@@ -687,11 +704,11 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     }
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
-    hipExtLaunchKernelGGL(image_align_lds_kernel, dim3(n_jobs), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+    hipExtLaunchKernelGGL(image_align_lds_kernel, dim3(n_lds), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
                           feats_dev, c, *p, max_f, dst);
-  } else {
-    SDVL_LAUNCH(ctx, "image_align", image_align_kernel, dim3(n_jobs), dim3(kThreads), static_cast<const IaJob *>(dsx), feats_dev, c, *p, dst);
   }
+  if (n_gen > 0)
+    SDVL_LAUNCH(ctx, "image_align_big", image_align_kernel, dim3(n_gen), dim3(kThreads), static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, dst);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   if (!d_results && !direct) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   return SDVL_OK;

@@ -3,6 +3,7 @@
 //        arithmetic is orb_wave_nibble() in sdvl_orb_device.h; here nibbles are merged pairwise into bytes and stored.
 //   K3  shi_tomasi_kernel   : FindShiTomasiScoreAtPoint, extra/utils.cc:61-97 — lane = pixel of the 8x8 box,
 //        exact int32 sums (every partial sum < 2^24 so the reference's float loop is exact too), float/double tail.
+#include <algorithm>
 #include <vector>
 
 #include "sdvl_internal.h"
@@ -84,6 +85,107 @@ __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restric
     const float disc = (dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY);
     job.out_score[ci] = 0.5 * (dXX + dYY - sqrt(static_cast<double>(disc)));
   }
+  }
+}
+
+
+// ---- Frame::FilterCorners on the device (frame.cc:133-163, FastDetector::FilterCorners fast_detector.cc:177-218) ----------
+// After shi_tomasi_kernel has scored every corner: one workgroup per frame walks the corner list cell by cell in the
+// reference's order (a later corner of a cell replaces the cell's choice when its score exceeds the TRUNCATED score stored
+// for it: order matters, so a cell is scanned sequentially by its own thread), drops corners in locked cells or inside the
+// margin, lists the survivors in cell order, and one wave per survivor computes its ORB descriptor (frame.cc:148-161 asks
+// for the descriptors of the filtered corners only).  Output per frame: count + records {index, x, y, level, score, desc}.
+struct FilterJob {
+  const uint8_t *level[SDVL_MAX_LEVELS];
+  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS];
+  const int32_t *corners;   // [n][4]
+  const int32_t *n_ptr;     // device-resident corner count
+  const double *scores;     // [ccap] Shi-Tomasi scores of this frame's corners
+  const uint32_t *locked;   // [mask_words] bit c = cell c holds a feature already (FastDetector::LockCell)
+  sdvl_filtered_corner *out;  // [max_out] records; out_count[0] = how many
+  int32_t *out_count;
+  int levels, ccap;
+};
+
+constexpr int kFilterMaxCorners = SDVL_MAX_CORNERS;
+
+__global__ __launch_bounds__(256) void filter_select_kernel(const FilterJob *__restrict__ jobs, int cell_size, int grid_w, int n_cells, int margin,
+                                                            int min_score, int max_out) {
+  __shared__ uint16_t s_cell[kFilterMaxCorners];  // cell of corner i, 0xFFFF = not eligible
+  __shared__ int s_sel[4096];                     // per cell: chosen corner or -1
+  __shared__ int s_wave[4];
+  const FilterJob &job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(min(job.n_ptr[0], job.ccap), kFilterMaxCorners);
+  for (int i = tid; i < n; i += 256) {
+    const int px = job.corners[4 * i], py = job.corners[4 * i + 1], level = job.corners[4 * i + 2];
+    uint16_t c = 0xFFFFu;
+    if (level >= 0 && level < job.levels && !(px < margin || py < margin || px >= job.lw[level] - margin || py >= job.lh[level] - margin)) {
+      const int scale = 1 << level;
+      const int pos = ((py * scale) / cell_size) * grid_w + (px * scale) / cell_size;
+      if (pos >= 0 && pos < n_cells && !((job.locked[pos >> 5] >> (pos & 31)) & 1u)) c = static_cast<uint16_t>(pos);
+    }
+    s_cell[i] = c;
+  }
+  __syncthreads();
+  for (int c = tid; c < n_cells; c += 256) {
+    int best_idx = 0, best = min_score;  // cgrid_ starts as (0, MinFeatureScore), fast_detector.cc:40
+    for (int i = 0; i < n; i++) {
+      if (s_cell[i] != c) continue;
+      const double score = job.scores[i];
+      if (score > best) {
+        best_idx = i;
+        best = static_cast<int>(score);
+      }
+    }
+    s_sel[c] = best > min_score ? best_idx : -1;
+  }
+  __syncthreads();
+  // survivors in cell order (fast_detector.cc:213-217)
+  int running = 0;
+  for (int c0 = 0; c0 < n_cells; c0 += 256) {
+    const int c = c0 + tid;
+    const bool ok = c < n_cells && s_sel[c] >= 0;
+    const unsigned long long m = __ballot(ok);
+    const int below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int pos = running + below;
+    for (int w = 0; w < wave; w++) pos += s_wave[w];
+    if (ok && pos < max_out) {
+      const int i = s_sel[c];
+      sdvl_filtered_corner r;
+      r.index = i;
+      r.x = job.corners[4 * i]; r.y = job.corners[4 * i + 1]; r.level = job.corners[4 * i + 2];
+      r.score = static_cast<int>(job.scores[i]);
+      r.pad_ = 0;
+      // descriptor filled below
+      sdvl_filtered_corner *dst = job.out + pos;
+      dst->index = r.index; dst->x = r.x; dst->y = r.y; dst->level = r.level; dst->score = r.score; dst->pad_ = 0;
+    }
+    running += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  }
+  if (tid == 0) job.out_count[0] = running;  // the host checks it against max_out
+}
+
+// ORB descriptors of the corners filter_select_kernel kept, one wave each: grid.x covers max_out / 4 workgroups, grid.y = frames
+__global__ __launch_bounds__(256) void filter_describe_kernel(const FilterJob *__restrict__ jobs, int max_out) {
+  const FilterJob &job = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int total = min(job.out_count[0], max_out);
+  for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < total; k += gridDim.x * 4) {
+    sdvl_filtered_corner *dst = job.out + k;
+    const int cx = dst->x, cy = dst->y, cl = dst->level;
+    const int W = job.lw[cl], H = job.lh[cl];
+    uint8_t byte = 0;
+    if (cx >= 19 && cx < W - 19 && cy >= 19 && cy < H - 19) {  // ORBDetector::IsInsideLimits; zeros outside, as orb_describe_kernel
+      float angle_deg;
+      const uint32_t nib = orb_wave_nibble(job.level[cl] + static_cast<size_t>(cy) * W + cx, W, lane, &angle_deg);
+      const uint32_t hi = __shfl_down(nib, 1, 64);
+      byte = static_cast<uint8_t>(nib | (hi << 4));
+    }
+    if ((lane & 1) == 0) dst->desc[lane >> 1] = byte;
   }
 }
 
@@ -298,6 +400,91 @@ int sdvl_filter_inputs_end(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int 
     }
     memcpy(scores + static_cast<size_t>(i) * cap, reinterpret_cast<const double *>(h) + static_cast<size_t>(i) * ccap, sizeof(double) * cnt);
     if (desc) memcpy(desc + static_cast<size_t>(i) * cap * 32, src + sizeof(int32_t) * 4 * (static_cast<size_t>(ccap) + 1), static_cast<size_t>(cnt) * 32);
+  }
+  return SDVL_OK;
+}
+
+
+// ---- sdvl_filter_corners_begin / _end: Frame::FilterCorners for n frames, selection included --------------------------------
+int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const uint32_t *locked_cells, int mask_words, int cell_size,
+                              int margin, int min_feature_score, int with_desc) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !locked_cells)) || mask_words <= 0 || cell_size <= 0) return SDVL_ERR_INVALID;
+  ctx->filter_pending = 0;
+  if (n == 0) return SDVL_OK;
+  (void)with_desc;  // descriptors of the selected corners always ride along (32 B each)
+  const int W = frames[0]->width, H = frames[0]->height;
+  const int grid_w = (W + cell_size - 1) / cell_size, grid_h = (H + cell_size - 1) / cell_size, n_cells = grid_w * grid_h;
+  SDVL_REQUIRE(ctx, n_cells <= 4096 && n_cells <= mask_words * 32, "filter grid too large (4096 cells) or lock mask too short");
+  int ccap = 1;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] && frames[i]->width == W && frames[i]->height == H, "frames of one batch must share their size");
+    const int c = frames[i]->hdr_stale ? 0 : frames[i]->v.n_corners;
+    ccap = std::max(ccap, c < 0 ? SDVL_MAX_CORNERS : c);
+  }
+  const int max_out = n_cells;
+  // device: scores[n][ccap] | counts[n] | records[n][max_out] ; host mirror of counts + records
+  const size_t sc_bytes = (sizeof(double) * static_cast<size_t>(n) * ccap + 255) / 256 * 256;
+  const size_t cnt_bytes = (sizeof(int32_t) * n + 255) / 256 * 256, rec_bytes = sizeof(sdvl_filtered_corner) * static_cast<size_t>(n) * max_out;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, sc_bytes + cnt_bytes + rec_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, cnt_bytes + rec_bytes, true);
+  if (rc) return rc;
+  OrbJob *d_jobs = nullptr;
+  int max_n = 0;
+  rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
+  if (rc) return rc;
+  max_n = max_n > ccap ? ccap : max_n;
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
+  const size_t jb = (sizeof(FilterJob) * n + 255) / 256 * 256, mb = sizeof(uint32_t) * static_cast<size_t>(n) * mask_words;
+  void *hs = nullptr, *dsx = nullptr;
+  rc = sdvl_stage_alloc(ctx, jb + mb, &hs, &dsx);
+  if (rc) return rc;
+  FilterJob *hj = static_cast<FilterJob *>(hs);
+  uint8_t *d8 = static_cast<uint8_t *>(ctx->d_out);
+  for (int i = 0; i < n; i++) {
+    const FrameView &v = frames[i]->v;
+    memset(&hj[i], 0, sizeof(FilterJob));
+    for (int l = 0; l < v.levels; l++) { hj[i].level[l] = v.level[l]; hj[i].lw[l] = v.lw[l]; hj[i].lh[l] = v.lh[l]; }
+    hj[i].corners = v.corners;
+    hj[i].n_ptr = v.corner_hdr;
+    hj[i].scores = reinterpret_cast<const double *>(d8) + static_cast<size_t>(i) * ccap;
+    hj[i].locked = reinterpret_cast<const uint32_t *>(static_cast<uint8_t *>(dsx) + jb) + static_cast<size_t>(i) * mask_words;
+    hj[i].out = reinterpret_cast<sdvl_filtered_corner *>(d8 + sc_bytes + cnt_bytes) + static_cast<size_t>(i) * max_out;
+    hj[i].out_count = reinterpret_cast<int32_t *>(d8 + sc_bytes) + i;
+    hj[i].levels = v.levels;
+    hj[i].ccap = ccap;
+  }
+  memcpy(static_cast<uint8_t *>(hs) + jb, locked_cells, mb);
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, jb + mb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_LAUNCH(ctx, "filter_select", filter_select_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells, margin,
+              min_feature_score, max_out);
+  SDVL_LAUNCH(ctx, "filter_describe", filter_describe_kernel, dim3((std::min(max_out, 512) + 3) / 4, n), dim3(256), static_cast<const FilterJob *>(dsx),
+              max_out);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, d8 + sc_bytes, cnt_bytes + rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_FILTER, &ctx->filter_ticket));
+  ctx->filter_pending = n;
+  ctx->filter_ccap = max_out;
+  ctx->filter_sc_bytes = cnt_bytes;
+  return SDVL_OK;
+}
+
+int sdvl_filter_corners_end(sdvl_ctx *ctx, int n, int cap, int32_t *counts, sdvl_filtered_corner *out) {
+  if (!ctx || n < 0 || (n > 0 && (!counts || !out)) || cap <= 0) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, ctx->filter_pending == n, "sdvl_filter_corners_end without a matching sdvl_filter_corners_begin");
+  ctx->filter_pending = 0;
+  SDVL_HIP_CHECK(ctx, sdvl_mark_wait(ctx, SDVL_MARK_FILTER, ctx->filter_ticket));
+  const int max_out = ctx->filter_ccap;
+  const uint8_t *h = static_cast<const uint8_t *>(ctx->h_out);
+  const int32_t *hc = reinterpret_cast<const int32_t *>(h);
+  const sdvl_filtered_corner *hr = reinterpret_cast<const sdvl_filtered_corner *>(h + ctx->filter_sc_bytes);
+  for (int i = 0; i < n; i++) {
+    if (hc[i] > max_out || hc[i] > cap) {
+      ctx->err = "more filtered corners than the output holds";
+      return SDVL_ERR_CAPACITY;
+    }
+    counts[i] = hc[i];
+    memcpy(out + static_cast<size_t>(i) * cap, hr + static_cast<size_t>(i) * max_out, sizeof(sdvl_filtered_corner) * static_cast<size_t>(hc[i]));
   }
   return SDVL_OK;
 }

@@ -493,7 +493,6 @@ void MapperMap::EmitInitCandidates(vector<sdvl_search_req> *reqs) {
   req_base_ = static_cast<int>(reqs->size());
   if (best_kfs_.empty()) return;
   depth_mean_ = cur_->GetSceneDepth();
-  vector<Vector3i> &corners = cur_->GetCorners();
   vector<int> &fcorners = cur_->GetFilteredCorners();
   const int nc = static_cast<int>(fcorners.size());
   ic_req_.assign(best_kfs_.size() * static_cast<size_t>(nc), -1);
@@ -502,12 +501,12 @@ void MapperMap::EmitInitCandidates(vector<sdvl_search_req> *reqs) {
     const double distance = cur_->DistanceTo(*cframe);
     if (distance / depth_mean_ < 0.01) continue;
     for (int c = 0; c < nc; c++) {
-      const Vector3i corner = corners[fcorners[c]];
+      const Vector3i corner = cur_->FilteredCorner(c);
       const int scale = (1 << corner(2));
       const Vector2d px(corner(0) * scale, corner(1) * scale);
       const Vector3d bearing = camera_->Unproject(px);
       reqs->emplace_back();
-      FillRequest(&reqs->back(), cframe, cur_.get(), px, bearing, corner(2), Config::UseORB() ? cur_->HostDescriptor(fcorners[c]) : nullptr,
+      FillRequest(&reqs->back(), cframe, cur_.get(), px, bearing, corner(2), Config::UseORB() ? cur_->FilteredDescriptor(c) : nullptr,
                   1.0 / depth_mean_, 1.0, false, Vector2d(0, 0));
       ic_req_[k * nc + c] = static_cast<int>(reqs->size()) - 1 - req_base_;
     }
@@ -518,7 +517,6 @@ void MapperMap::EmitInitCandidates(vector<sdvl_search_req> *reqs) {
 void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
   if (best_kfs_.empty()) return;
   const sdvl_search_res *res = res_all + req_base_;
-  vector<Vector3i> &corners = cur_->GetCorners();
   vector<int> &fcorners = cur_->GetFilteredCorners();
   const int nc = static_cast<int>(fcorners.size());
   vector<bool> imatches(fcorners.size(), false);
@@ -529,8 +527,7 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
     if (distance / depth_mean_ < 0.01) continue;
     for (int count = 0; count < nc; count++) {
       if (imatches[count]) continue;
-      const int index = fcorners[count];
-      const Vector3i corner = corners[index];
+      const Vector3i corner = cur_->FilteredCorner(count);
       const int scale = (1 << corner(2));
       // map.cc:345-351 constructs the candidate point and its feature before the search; a miss throws them away again. Here
       // a miss only consumes the point id the constructor would have taken (ids stay those of the reference's order).
@@ -541,7 +538,7 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
       }
       shared_ptr<Point> candidate = std::make_shared<Point>();
       shared_ptr<Feature> feature = std::make_shared<Feature>(cur_, Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
-      if (Config::UseORB()) feature->SetDescriptor(cur_->HostDescriptor(index));
+      if (Config::UseORB()) feature->SetDescriptor(cur_->FilteredDescriptor(count));
       const Vector2d imgpos(r.px[0], r.px[1]);
       const int level = r.level;
       bool mfound = false;

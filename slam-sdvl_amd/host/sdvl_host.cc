@@ -596,7 +596,7 @@ void Frame::DetectBatch(const vector<shared_ptr<Frame>> &frames, int nfeatures) 
     devs[i] = f.dev_;
     f.corners_.clear();
     f.descriptors_.clear();
-    f.desc_flat_.clear();
+    f.filt_.clear();
     f.descriptors_on_host_ = false;
     f.corners_on_host_ = false;
   }
@@ -615,7 +615,7 @@ void Frame::CreateCorners(int, int nfeatures) {
   const sdvl_detect_params dp = DetectParams();
   corners_.clear();
   descriptors_.clear();
-  desc_flat_.clear();
+  filt_.clear();
   descriptors_on_host_ = false;
   dev->Check(sdvl_detect_corners(dev->ctx(), 1, &dev_, &dp, nfeatures), "sdvl_detect_corners");
   corners_on_host_ = false;
@@ -677,50 +677,52 @@ void Frame::FilterCornersBatch(const vector<shared_ptr<Frame>> &frames) {
   FilterCornersEnd(frames);
 }
 
-// first half: the device side of FilterCorners for all frames (Shi-Tomasi scores, missing descriptors, one gather, one
-// copy) is queued; the caller may do host work that does not touch the device before FilterCornersEnd
+// first half: the device side of FilterCorners for all frames — Shi-Tomasi scores, the per-cell selection of
+// FastDetector::FilterCorners (fast_detector.cc:177-218) with the cells of the frame's features locked (frame.cc:139-142),
+// ORB descriptors of the corners that survive — is queued; the caller may do host work that does not touch the device
+// before FilterCornersEnd
 void Frame::FilterCornersBegin(const vector<shared_ptr<Frame>> &frames) {
   const int n = static_cast<int>(frames.size());
   if (n == 0) return;
   Device *dev = Device::Current();
+  const int cell = Config::CellSize();
+  const int gw = static_cast<int>(std::ceil(static_cast<double>(frames[0]->width_) / cell));
+  const int gh = static_cast<int>(std::ceil(static_cast<double>(frames[0]->height_) / cell));
+  const int words = (gw * gh + 31) / 32;
   vector<sdvl_frame *> devs(n);
-  for (int i = 0; i < n; i++) devs[i] = frames[i]->dev_;
-  dev->Check(sdvl_filter_inputs_begin(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, Config::UseORB() ? 1 : 0), "sdvl_filter_inputs_begin");
+  vector<uint32_t> locked(static_cast<size_t>(n) * words, 0u);
+  for (int i = 0; i < n; i++) {
+    Frame &f = *frames[i];
+    devs[i] = f.dev_;
+    vector<shared_ptr<Feature>> &kf_features = f.GetFeatures();
+    for (auto it = kf_features.begin(); it != kf_features.end(); it++) {  // FastDetector::LockCell, fast_detector.cc:48-51
+      const Vector2d &p = (*it)->GetPosition();
+      const int index = static_cast<int>(p(1) / cell) * gw + static_cast<int>(p(0) / cell);
+      if (index >= 0 && index < gw * gh) locked[static_cast<size_t>(i) * words + (index >> 5)] |= 1u << (index & 31);
+    }
+  }
+  dev->Check(sdvl_filter_corners_begin(dev->ctx(), n, devs.data(), locked.data(), words, cell, DetectMargin(), Config::MinFeatureScore(),
+                                       Config::UseORB() ? 1 : 0), "sdvl_filter_corners_begin");
 }
 
-void Frame::FilterCornersEnd(const vector<shared_ptr<Frame>> &frames) {
+void Frame::FilterCornersEnd(const vector<shared_ptr<Frame>> &frames, const std::function<void(int, const std::function<void(int)> &)> *pfor) {
   const int n = static_cast<int>(frames.size());
   if (n == 0) return;
   Device *dev = Device::Current();
-  const bool orb = Config::UseORB();
-  vector<sdvl_frame *> devs(n);
-  for (int i = 0; i < n; i++) devs[i] = frames[i]->dev_;
-  // corners + Shi-Tomasi scores + descriptors of all frames in one round trip
-  // scratch owned by the Device (= one group): a host thread may interleave several groups, so nothing here is per thread
-  vector<int32_t> &xyl = dev->scratch_xyl;
-  vector<double> &scores = dev->scratch_scores;
-  vector<uint8_t> &desc = dev->scratch_desc;
+  const int cell = Config::CellSize();
+  const int gw = static_cast<int>(std::ceil(static_cast<double>(frames[0]->width_) / cell));
+  const int gh = static_cast<int>(std::ceil(static_cast<double>(frames[0]->height_) / cell));
+  const int cap = gw * gh;
   vector<int32_t> counts(n);
-  const size_t cap = SDVL_MAX_CORNERS;
-  if (xyl.size() < n * cap * 3) xyl.resize(n * cap * 3);
-  if (scores.size() < n * cap) scores.resize(n * cap);
-  if (orb && desc.size() < n * cap * 32) desc.resize(n * cap * 32);
-  dev->Check(sdvl_filter_inputs_end(dev->ctx(), n, devs.data(), static_cast<int>(cap), xyl.data(), scores.data(), orb ? desc.data() : nullptr,
-                                    counts.data()), "sdvl_filter_inputs_end");
+  vector<sdvl_filtered_corner> &recs = dev->scratch_filtered;  // one row of `cap` records per frame
+  if (recs.size() < static_cast<size_t>(n) * cap) recs.resize(static_cast<size_t>(n) * cap);
+  dev->Check(sdvl_filter_corners_end(dev->ctx(), n, cap, counts.data(), recs.data()), "sdvl_filter_corners_end");
+  (void)pfor;  // a frame's share is a copy of <= one record per grid cell: not worth spreading
   for (int i = 0; i < n; i++) {
     Frame &f = *frames[i];
-    const int cnt = counts[i];
-    if (!f.corners_on_host_) {
-      f.corners_.resize(cnt);
-      for (int k = 0; k < cnt; k++) f.corners_[k] = Vector3i(xyl[(i * cap + k) * 3], xyl[(i * cap + k) * 3 + 1], xyl[(i * cap + k) * 3 + 2]);
-      f.corners_on_host_ = true;
-    }
-    FastDetector detector(f.width_, f.height_);
-    vector<shared_ptr<Feature>> &kf_features = f.GetFeatures();
-    for (auto it = kf_features.begin(); it != kf_features.end(); it++) detector.LockCell((*it)->GetPosition());
-    detector.FilterWithScores(f.pyramid_, f.corners_, scores.data() + i * cap, &f.filtered_corners_);
-    // frame.cc:145-161 mirrors the descriptors of the filtered corners one std::vector each; here the frame's whole block
-    if (orb) f.desc_flat_.assign(desc.begin() + i * cap * 32, desc.begin() + (i * cap + cnt) * 32);
+    f.filt_.assign(recs.begin() + static_cast<size_t>(i) * cap, recs.begin() + static_cast<size_t>(i) * cap + counts[i]);
+    f.filtered_corners_.resize(counts[i]);
+    for (int k = 0; k < counts[i]; k++) f.filtered_corners_[k] = f.filt_[k].index;
   }
 }
 
@@ -980,12 +982,12 @@ void PlaneMap::SeedFromFiltered(const shared_ptr<Frame> &kf) {
   const SE3 world = kf->GetWorldPose();
   const M3 Rw = world.GetRotation();
   const Vector3d tw = world.GetTranslation();
-  vector<Vector3i> &corners = kf->GetCorners();
-  for (int index : kf->GetFilteredCorners()) {
-    const Vector3i corner = corners[index];
+  const int n_filtered = kf->NumFiltered();
+  for (int k = 0; k < n_filtered; k++) {
+    const Vector3i corner = kf->FilteredCorner(k);
     const int scale = (1 << corner(2));
     shared_ptr<Feature> feature = kf->NewFeature(Vector2d(corner(0) * scale, corner(1) * scale), corner(2));
-    if (Config::UseORB()) feature->SetDescriptor(kf->HostDescriptor(index));  // filled by FilterCorners (frame.cc:145-161)
+    if (Config::UseORB()) feature->SetDescriptor(kf->FilteredDescriptor(k));  // filled by FilterCorners (frame.cc:145-161)
     const Vector3d &v = feature->GetVector();
     const V3 ray = mvec(Rw, {v(0), v(1), v(2)});
     const double denom = n_(0) * ray.x + n_(1) * ray.y + n_(2) * ray.z;
@@ -1192,6 +1194,11 @@ void FeatureAlign::EmitChainCandidates(int req_offset, vector<int32_t> *cand_req
 void FeatureAlign::PeekRand(int n, vector<int32_t> *out) const {
   RandStream peek = *rng_;
   for (int h = 0; h < n; h++) out->push_back(peek.Next());
+}
+
+void FeatureAlign::PeekRand(int n, int32_t *out) const {
+  RandStream peek = *rng_;
+  for (int h = 0; h < n; h++) out[h] = peek.Next();
 }
 
 void FeatureAlign::ShuffleCellRanks(uint16_t *rank_of_cell) {
@@ -1820,8 +1827,13 @@ void SDVLBatch::SyncHostState() {
 // last_frame's features and the points behind them as table rows (include/sdvl_hip.h: sdvl_track_point / _feature).
 // false: something the tables cannot express (a point without a first observation or whose keyframe is gone) — the step
 // then runs on the host path.
-bool SDVLBatch::BuildTable(SDVL &t, vector<sdvl_track_point> *points, vector<sdvl_track_feature> *feats) {
+bool SDVLBatch::BuildTable(SDVL &t) {
   SyncStats(t);
+  vector<sdvl_track_point> *points = &t.track_.up_points;
+  vector<sdvl_track_feature> *feats = &t.track_.up_feats;
+  points->clear();
+  feats->clear();
+  t.track_.up_register.clear();
   vector<shared_ptr<Feature>> &features = t.last_frame_->GetFeatures();
   if (static_cast<int>(features.size()) > track_cap_) return false;
   auto table = std::make_shared<Frame::PointTable>();
@@ -1833,7 +1845,6 @@ bool SDVLBatch::BuildTable(SDVL &t, vector<sdvl_track_point> *points, vector<sdv
   size_t hcap = 64;
   while (hcap < features.size() * 2) hcap *= 2;
   hash.assign(hcap, Slot{nullptr, -1});
-  const size_t p0 = points->size();
   for (auto &ftp : features) {
     Feature *ft = ftp.get();
     sdvl_track_feature f;
@@ -1873,17 +1884,14 @@ bool SDVLBatch::BuildTable(SDVL &t, vector<sdvl_track_point> *points, vector<sdv
         tp.status = static_cast<int32_t>(pt->GetStatus());
         if (init->HasDescriptor()) std::memcpy(tp.desc, init->DescriptorData().data(), 32);
         else std::memset(tp.desc, 0, 32);
-        if (!ref->IsRegistered()) {  // a keyframe that never was the current frame of a tracked step (bootstrap, host-path steps)
-          double pose[7];
-          ref->GetPose().ToArray(pose);
-          dev_->Check(sdvl_frame_register(dev_->ctx(), ref->device(), pose), "sdvl_frame_register");
-          ref->SetRegistered();
-        }
+        // a keyframe that never was the current frame of a tracked step (bootstrap, host-path steps): the caller registers
+        // it (device calls of one context come from one thread)
+        if (!ref->IsRegistered()) t.track_.up_register.push_back(ref);
       }
     }
     feats->push_back(f);
   }
-  if (static_cast<int>(points->size() - p0) > track_cap_) return false;
+  if (static_cast<int>(points->size()) > track_cap_) return false;
   t.track_.points = table;
   t.track_.stats.clear();
   t.track_.stats_dirty = false;
@@ -1895,7 +1903,7 @@ bool SDVLBatch::BuildTable(SDVL &t, vector<sdvl_track_point> *points, vector<sdv
 // motion model, tracking quality, the keyframe decision and everything a keyframe sets off.
 bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats) {
   static const bool chain_enabled = std::getenv("SDVL_NO_CHAIN") == nullptr;
-  if (!persistent_ || threads_ > 1 || !TrackTables() || !chain_enabled || !DevicePose() || Config::MaxRansacPoints() > 8) return false;
+  if (!persistent_ || !TrackTables() || !chain_enabled || !DevicePose() || Config::MaxRansacPoints() > 8) return false;
   const int B = static_cast<int>(trk_.size());
   for (int i = 0; i < B; i++) {
     SDVL &t = *trk_[i];
@@ -1921,27 +1929,39 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
   // First of all: a frame that cannot be expressed as a table sends the whole step to the host path, untouched.
   std::unique_ptr<StageClock> clk(new StageClock(ST_PREPARE));
   {
-    vector<int32_t> up_trk, up_buf, up_np, up_nf;
-    tr_up_points_.clear();
-    tr_up_feats_.clear();
-    vector<int> built;
-    for (int i = 0; i < B; i++) {
-      SDVL &t = *trk_[i];
-      if (t.state_ != SDVL::STATE_RUNNING || t.track_.valid) continue;
-      const size_t p0 = tr_up_points_.size(), f0 = tr_up_feats_.size();
-      if (!BuildTable(t, &tr_up_points_, &tr_up_feats_)) return false;
-      built.push_back(i);
-      up_trk.push_back(i);
-      up_buf.push_back(0);
-      up_np.push_back(static_cast<int32_t>(tr_up_points_.size() - p0));
-      up_nf.push_back(static_cast<int32_t>(tr_up_feats_.size() - f0));
-    }
-    if (!up_trk.empty())
+    vector<int> need;
+    for (int i = 0; i < B; i++)
+      if (trk_[i]->state_ == SDVL::STATE_RUNNING && !trk_[i]->track_.valid) need.push_back(i);
+    if (!need.empty()) {
+      vector<char> ok(need.size(), 0);
+      ParallelFor(static_cast<int>(need.size()), [&](int q) { ok[q] = BuildTable(*trk_[need[q]]) ? 1 : 0; });
+      for (char o : ok)
+        if (!o) return false;
+      vector<int32_t> up_trk, up_buf, up_np, up_nf;
+      tr_up_points_.clear();
+      tr_up_feats_.clear();
+      for (int i : need) {
+        SDVL::TrackState &ts = trk_[i]->track_;
+        for (Frame *ref : ts.up_register)
+          if (!ref->IsRegistered()) {
+            double pose[7];
+            ref->GetPose().ToArray(pose);
+            dev_->Check(sdvl_frame_register(dev_->ctx(), ref->device(), pose), "sdvl_frame_register");
+            ref->SetRegistered();
+          }
+        up_trk.push_back(i);
+        up_buf.push_back(0);
+        up_np.push_back(static_cast<int32_t>(ts.up_points.size()));
+        up_nf.push_back(static_cast<int32_t>(ts.up_feats.size()));
+        tr_up_points_.insert(tr_up_points_.end(), ts.up_points.begin(), ts.up_points.end());
+        tr_up_feats_.insert(tr_up_feats_.end(), ts.up_feats.begin(), ts.up_feats.end());
+      }
       dev_->Check(sdvl_track_upload(dev_->ctx(), track_, static_cast<int>(up_trk.size()), up_trk.data(), up_buf.data(), up_np.data(), tr_up_points_.data(),
                                     up_nf.data(), tr_up_feats_.data()), "sdvl_track_upload");
-    for (int i : built) {
-      trk_[i]->track_.feat_buf = 0;
-      trk_[i]->track_.valid = true;
+      for (int i : need) {
+        trk_[i]->track_.feat_buf = 0;
+        trk_[i]->track_.valid = true;
+      }
     }
   }
 
@@ -1987,8 +2007,8 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     const int max_its = Config::MaxRansacIts();
     tr_jobs_.resize(R);
     tr_rank_.resize(static_cast<size_t>(R) * cells);
-    tr_rand_.clear();
-    for (int k = 0; k < R; k++) {
+    tr_rand_.resize(static_cast<size_t>(R) * max_its);
+    ParallelFor(R, [&](int k) {
       SDVL &t = *trk_[run[k]];
       sdvl_track_job &jb = tr_jobs_[k];
       jb.tracker = run[k];
@@ -2001,8 +2021,8 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
       jb.frame_id = t.current_frame_->GetID();
       jb.max_matches = t.feature_align_.MaxMatches();
       t.feature_align_.ShuffleCellRanks(tr_rank_.data() + static_cast<size_t>(k) * cells);
-      t.feature_align_.PeekRand(max_its, &tr_rand_);
-    }
+      t.feature_align_.PeekRand(max_its, tr_rand_.data() + static_cast<size_t>(k) * max_its);
+    });
     sdvl_track_params prm;
     prm.align = AlignParams(false);
     prm.search = SearchParams();
@@ -2021,12 +2041,13 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
 
     // ---- results: pose, counters, the rand() stream, deletions, motion model, tracking quality, keyframe decision
     clk.reset(new StageClock(ST_FINISH));
-    for (int k = 0; k < R; k++) {
+    for (int k = 0; k < R; k++)
+      if (tr_res_[k].status != 0) throw std::runtime_error("sdvl_track: a table capacity was exceeded on the device");
+    ParallelFor(R, [&](int k) {
       const int i = run[k];
       SDVL &t = *trk_[i];
       FrameStats &st = stats[i];
       const sdvl_track_result &r = tr_res_[k];
-      if (r.status != 0) throw std::runtime_error("sdvl_track: a table capacity was exceeded on the device");
       SDVL::TrackState &ts = t.track_;
       st.align_meas = r.align_meas;
       st.align_iters = r.align_iters;
@@ -2058,7 +2079,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
       t.CalcTrackingQuality(t.matches_, t.attempts_);
       if (t.tracking_quality_ != SDVL::TRACKING_BAD)
         decision[k] = (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) ? 2 : 1;
-    }
+    });
     // the keyframes are known: queue their FilterCorners inputs now; the bookkeeping below runs meanwhile
     clk.reset(new StageClock(ST_POSE));
     {
@@ -2077,11 +2098,11 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         filter_begun = true;
       }
     }
-    for (int k = 0; k < R; k++) {
+    ParallelFor(R, [&](int k) {
       const int i = run[k];
       SDVL &t = *trk_[i];
       FrameStats &st = stats[i];
-      if (decision[k] == 0) continue;  // tracking lost: last_frame and its table stay
+      if (decision[k] == 0) return;  // tracking lost: last_frame and its table stay
       if (decision[k] == 2) {
         // the frame becomes part of the map: its features and the points behind them turn into objects
         SyncStats(t);
@@ -2100,7 +2121,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
       }
       t.last_frame_ = t.current_frame_;
-    }
+    });
   }
   clk.reset();
   if (R == 0) Frame::DetectBatch(frames, Config::NumFeatures());  // bootstrap-only step: the new keyframes still need their corners
@@ -2478,7 +2499,8 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
       Frame::FilterCornersBegin(kfs);
     }
     if (!kfs.empty()) {
-      Frame::FilterCornersEnd(kfs);
+      const std::function<void(int, const std::function<void(int)> &)> pfor = [this](int n, const std::function<void(int)> &fn) { ParallelFor(n, fn); };
+      Frame::FilterCornersEnd(kfs, &pfor);
       ParallelFor(static_cast<int>(kfs.size()), [&](int k) {
         SDVL &t = *trk_[kf_owner[k]];
         PlaneMap *pm = dynamic_cast<PlaneMap *>(t.map_);
@@ -2489,7 +2511,7 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
   }
 
   clk.reset(new StageClock(ST_EPILOGUE));
-  for (int i = 0; i < B; i++) {
+  ParallelFor(B, [&](int i) {
     SDVL &t = *trk_[i];
     FrameStats &st = stats[i];
     st.quality = static_cast<int>(t.tracking_quality_);
@@ -2499,7 +2521,7 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
     t.stats_ = st;
     t.current_frame_ = nullptr;
     t.map_->EmptyTrash();  // sdvl.cc:127
-  }
+  });
   // ---- stage 5: SDVL::Mapping() of sequential mode (main.cc:148-149) for the trackers that own a real mapper: the phases of
   // Map::UpdateMap run in lock step, every phase's SearchPoint requests of ALL trackers in one K7 launch
   clk.reset(new StageClock(ST_MAPPER));

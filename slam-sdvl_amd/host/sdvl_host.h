@@ -76,9 +76,9 @@ class Device {
   static Device *CurrentOrNull();
   static void SetCurrent(Device *d);
   uint64_t search_batch_counter = 0;  // ids of the packed search batches opened on this device's context
-  std::vector<int32_t> scratch_xyl;  // Frame::FilterCornersBatch round-trip buffers
-  std::vector<double> scratch_scores;
-  std::vector<uint8_t> scratch_desc;
+  // Frame::FilterCornersEnd's round-trip buffer: owned by the Device (= one group), because a host thread may interleave
+  // several groups (fibers switch at the wait inside the call), so nothing there can be per thread
+  std::vector<sdvl_filtered_corner> scratch_filtered;
   // source of Point ids for the trackers stepping on this device: ids only have to grow along one tracker's own history
   // (the mapper orders by id), and a counter shared by every group would bounce between their cores
   std::atomic<int> next_point_id{0};
@@ -367,7 +367,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void FilterCorners();
   static void FilterCornersBatch(const std::vector<std::shared_ptr<Frame>> &frames);
   static void FilterCornersBegin(const std::vector<std::shared_ptr<Frame>> &frames);  // the two halves of FilterCornersBatch
-  static void FilterCornersEnd(const std::vector<std::shared_ptr<Frame>> &frames);
+  static void FilterCornersEnd(const std::vector<std::shared_ptr<Frame>> &frames,
+                               const std::function<void(int, const std::function<void(int)> &)> *pfor = nullptr);
   // corner detection + ORB for frames built with corners = false (CreateBatch): queues the kernels, returns at once
   static void DetectBatch(const std::vector<std::shared_ptr<Frame>> &frames, int nfeatures);
   SE3 &GetPose() { return pose_; }  // frame.h:52: callers may write through it, so the cached inverse is checked by value
@@ -390,9 +391,16 @@ class Frame : public std::enable_shared_from_this<Frame> {
   std::vector<int> &GetFilteredCorners() { return filtered_corners_; }
   std::vector<Vector2d> &GetOutliers() { return outliers_; }
   std::vector<std::vector<uchar>> &GetDescriptors();  // host mirror of the HBM descriptors
-  // descriptor of corner `index` as FilterCorners mirrored it (one flat block per frame), null before FilterCorners
+  // What FilterCorners brought back from the device: the k-th filtered corner (x, y in level coordinates, level) and its
+  // ORB descriptor (frame.cc:148-161 computes descriptors for exactly these), in the order of GetFilteredCorners()
+  int NumFiltered() const { return static_cast<int>(filt_.size()); }
+  Vector3i FilteredCorner(int k) const { return Vector3i(filt_[k].x, filt_[k].y, filt_[k].level); }
+  const uchar *FilteredDescriptor(int k) const { return filt_[k].desc; }
+  // descriptor of corner `index` (an entry of GetFilteredCorners()), null for corners FilterCorners did not keep
   const uchar *HostDescriptor(int index) const {
-    return static_cast<size_t>(index) * 32 + 32 <= desc_flat_.size() ? desc_flat_.data() + static_cast<size_t>(index) * 32 : nullptr;
+    for (const sdvl_filtered_corner &c : filt_)
+      if (c.index == index) return c.desc;
+    return nullptr;
   }
   Camera *GetCamera() const { return camera_; }
   int GetWidth() const { return width_; }
@@ -463,7 +471,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   std::vector<int> filtered_corners_;
   std::vector<Vector2d> outliers_;
   std::vector<std::vector<uchar>> descriptors_;
-  std::vector<uchar> desc_flat_;
+  std::vector<sdvl_filtered_corner> filt_;
   bool descriptors_on_host_ = false;
   bool corners_on_host_ = true;  // false after a device-side DetectPyramid until GetCorners() mirrors the list
   sdvl_frame *dev_ = nullptr;
@@ -685,6 +693,7 @@ class FeatureAlign {
   int FoundCount() const { return static_cast<int>(found_.size()); }
   // the next `n` values of the tracker's rand() stream, without advancing it
   void PeekRand(int n, std::vector<int32_t> *out) const;
+  void PeekRand(int n, int32_t *out) const;
   void PrepareReprojectPacked(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Frame> &last_frame, bool reloc, PackedSink *sink);
   // FinishReproject without SelectInliers: the pose stage then runs either on the host (SelectInliers + OptimizePose)
   // or batched on the device: EmitPoseJob for every tracker, ONE sdvl_pose_from_matches, CommitPose for every tracker.
@@ -820,6 +829,10 @@ class SDVL {
     std::shared_ptr<Frame::PointTable> points;        // table index -> Point
     std::vector<sdvl_track_point_stat> stats;         // newest counters of `points`; the Point objects lag behind
     bool stats_dirty = false;
+    // rows of a rebuilt table on their way to the device (every tracker fills its own: the rebuilds of a step run in parallel)
+    std::vector<sdvl_track_point> up_points;
+    std::vector<sdvl_track_feature> up_feats;
+    std::vector<Frame *> up_register;                 // keyframes the registry does not know yet
   } track_;
 };
 
@@ -857,7 +870,7 @@ class SDVLBatch {
   // ---- device-resident tables
   bool HandleFramesTracked(const std::vector<Image> &imgs, FrameStats *stats);  // false: not applicable this step
   void HandleFramesGeneric(const std::vector<Image> &imgs, FrameStats *stats);
-  bool BuildTable(SDVL &t, std::vector<sdvl_track_point> *points, std::vector<sdvl_track_feature> *feats);
+  bool BuildTable(SDVL &t);
   void SyncStats(SDVL &t);
   void FetchCornerCounts(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats);
   void EpilogueAndMapper(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats, std::vector<std::shared_ptr<Frame>> *kfs,

@@ -65,7 +65,15 @@ def test_closed_loop_with_host_pose_stage(trk, orc, synth):
 
 
 def test_batch_of_sequences_closed_loop_threaded(trk, orc, synth):
-    worst = run_case(trk, orc, synth, B=5, n_frames=9, threads=4)
+    """several host threads per batch: on the device-resident tables (table rebuilds, results, keyframes spread over the
+    threads) and on the host-driven path (requests assembled by the threads)"""
+    worst = run_case(trk, orc, synth, B=5, n_frames=12, threads=4)
+    assert worst <= POSE_TOL
+    trk.set_track_tables(False)
+    try:
+        worst = run_case(trk, orc, synth, B=5, n_frames=9, threads=4)
+    finally:
+        trk.set_track_tables(True)
     assert worst <= POSE_TOL
 
 

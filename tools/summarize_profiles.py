@@ -65,4 +65,29 @@ with open(os.path.join(dst, "pmc_hbm_traffic.csv"), "w") as out:
         fa = a["FETCH_SIZE"][0] / a["FETCH_SIZE"][1] if a["FETCH_SIZE"][1] else float("nan")
         wa = a["WRITE_SIZE"][0] / a["WRITE_SIZE"][1] if a["WRITE_SIZE"][1] else float("nan")
         out.write("%s,%d,%.2f,%.2f,%s\n" % (k, n, fa, wa, note))
+
+# SQ pass (LDS activity / bank conflicts, wave counts, VALU issue): per kernel averages per dispatch, every counter one column
+f = biggest("prof_sq/**/*counter_collection.csv")
+if f:
+    sq, names = {}, []
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k, c = short(row["Kernel_Name"]), row["Counter_Name"]
+            if c not in names:
+                names.append(c)
+            a = sq.setdefault(k, {})
+            v = a.setdefault(c, [0.0, 0])
+            v[0] += float(row["Counter_Value"])
+            v[1] += 1
+    with open(os.path.join(dst, "pmc_sq_lds.csv"), "w") as out:
+        out.write("kernel,dispatches," + ",".join(n + "_avg" for n in names) + ",lds_conflict_share,valu_insts_per_wave,note\n")
+        for k in sorted(sq):
+            a = sq[k]
+            avg = {n: (a[n][0] / a[n][1] if n in a and a[n][1] else float("nan")) for n in names}
+            disp = max(v[1] for v in a.values())
+            conf = avg.get("SQ_LDS_BANK_CONFLICT", float("nan")) / avg["SQ_LDS_IDX_ACTIVE"] if avg.get("SQ_LDS_IDX_ACTIVE") else float("nan")
+            ipw = avg.get("SQ_INSTS_VALU", float("nan")) / avg["SQ_WAVES"] if avg.get("SQ_WAVES") else float("nan")
+            out.write("%s,%d,%s,%.4f,%.1f,%s\n" % (k, disp, ",".join("%.1f" % avg[n] for n in names), conf, ipw,
+                                                  "one --pmc pass of SQ counters; %s; lds_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE "
+                                                  "(extra LDS cycles per LDS-array cycle)" % cfg))
 print("wrote", sorted(os.listdir(dst)))
