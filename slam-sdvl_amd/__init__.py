@@ -335,6 +335,31 @@ class Context:
         self._check(self.lib.sdvl_orb_describe(self.h, n, arr, cap, _ptr(out, u8p)))
         return [out[i, :self.lib.sdvl_frame_num_corners(frames[i].h)].copy() for i in range(n)]
 
+    def filter_corners(self, frames, locked_px, cell_size=32, margin=19, min_feature_score=50):
+        """sdvl_filter_corners_begin / _end: Frame::FilterCorners for the frames, selection on the device.  locked_px[i] = (k, 2)
+        positions whose cells are locked (FastDetector::LockCell).  Returns per frame (indices, xyl, scores, descriptors)."""
+        n = len(frames)
+        w, h = frames[0].width, frames[0].height
+        gw, gh = (w + cell_size - 1) // cell_size, (h + cell_size - 1) // cell_size
+        words = (gw * gh + 31) // 32
+        mask = np.zeros((n, words), np.uint32)
+        for i, pts in enumerate(locked_px):
+            for x, y in np.asarray(pts, np.float64).reshape(-1, 2):
+                c = int(y / cell_size) * gw + int(x / cell_size)
+                mask[i, c >> 5] |= np.uint32(1 << (c & 31))
+        arr = (C.c_void_p * n)(*[f.h for f in frames])
+        self._check(self.lib.sdvl_filter_corners_begin(self.h, n, arr, mask.ctypes.data_as(C.POINTER(C.c_uint32)), words, cell_size, margin,
+                                                       min_feature_score, 1))
+        cap = gw * gh
+        counts = np.zeros(n, np.int32)
+        rec = np.zeros((n, cap, 14), np.int32)      # 56-byte records: index, x, y, level, score, pad, desc[32]
+        self._check(self.lib.sdvl_filter_corners_end(self.h, n, cap, _ptr(counts, i32p), rec.ctypes.data_as(C.c_void_p)))
+        out = []
+        for i in range(n):
+            r = rec[i, :counts[i]]
+            out.append((r[:, 0].copy(), r[:, 1:4].copy(), r[:, 4].copy(), r[:, 6:].copy().view(np.uint8).reshape(-1, 32)))
+        return out
+
     def orb_describe_points(self, frame, xyl):
         xyl = np.ascontiguousarray(xyl, np.int32).reshape(-1, 3)
         desc = np.zeros((len(xyl), 32), np.uint8)

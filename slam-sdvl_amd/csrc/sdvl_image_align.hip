@@ -329,14 +329,20 @@ constexpr int kLdsMaxF = 384;
 
 struct IaItem { float patch, dx, dy; };
 
+// kSpill: the two big per-feature caches (the 2x6 Jacobians and the 16 reference items of every feature, 288 B per feature)
+// live in the job's slice of the context's work buffer (L2-resident: a job touches nothing else) instead of LDS, so that
+// jobs of up to SDVL_MAX_ALIGN_FEATURES features run the same kernel — configuration C aligns ~850 features per frame.
+// Same statements, same order: results are those of the LDS-resident form.
+template <bool kSpill>
 __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *__restrict__ jobs,
                                                                    const sdvl_align_feature *__restrict__ feats_all, Cam cam,
                                                                    sdvl_align_params prm, int max_f, sdvl_align_result *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-  // carve: items[max_f*16] | fjac[max_f*12] doubles | ui, vi ints | w[4] floats | ok, okprev, vis bytes
-  double *s_fj = reinterpret_cast<double *>(s_dyn);                       // [max_f][12], already multiplied by nothing (raw 2x6)
-  IaItem *s_item = reinterpret_cast<IaItem *>(s_fj + static_cast<size_t>(max_f) * 12);  // [max_f*16]
-  int *s_ui = reinterpret_cast<int *>(s_item + static_cast<size_t>(max_f) * 16);
+  // carve: fjac[max_f*12] doubles | items[max_f*16] (both only when not spilled) | ui, vi ints | w[4] floats | fpos | flag bytes
+  double *s_fj = kSpill ? jobs[blockIdx.x].jac_cache : reinterpret_cast<double *>(s_dyn);  // [max_f][12] raw 2x6 Jacobians
+  IaItem *s_item = kSpill ? reinterpret_cast<IaItem *>(jobs[blockIdx.x].patch_cache)
+                          : reinterpret_cast<IaItem *>(reinterpret_cast<double *>(s_dyn) + static_cast<size_t>(max_f) * 12);  // [max_f*16]
+  int *s_ui = kSpill ? reinterpret_cast<int *>(s_dyn) : reinterpret_cast<int *>(s_item + static_cast<size_t>(max_f) * 16);
   int *s_vi = s_ui + max_f;
   float *s_w = reinterpret_cast<float *>(s_vi + max_f);                   // [4][max_f]
   double *s_fpos = reinterpret_cast<double *>(s_w + static_cast<size_t>(4) * max_f);  // [max_f][5]: px, py, and f * depth (3)
@@ -603,6 +609,8 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
 size_t ia_lds_bytes(int max_f) {
   return static_cast<size_t>(max_f) * (12 * sizeof(double) + 16 * sizeof(IaItem) + 2 * sizeof(int) + 4 * sizeof(float) + 5 * sizeof(double) + 4) + 64;
 }
+size_t ia_spill_lds_bytes(int max_f) { return static_cast<size_t>(max_f) * (2 * sizeof(int) + 4 * sizeof(float) + 5 * sizeof(double) + 4) + 64; }
+size_t ia_spill_work_bytes(int nf) { return (static_cast<size_t>(nf) * (12 * sizeof(double) + 16 * sizeof(IaItem)) + 255) / 256 * 256; }
 
 }  // namespace
 
@@ -619,8 +627,9 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   // kernel in a second launch.  One oversized job used to send the whole batch to the slow kernel: with 256 trackers per
   // launch there is almost always a fresh keyframe with more than 384 features among them.
   const bool force_generic = getenv("SDVL_IMAGE_ALIGN_GENERIC") != nullptr;
+  const bool legacy = force_generic || getenv("SDVL_IMAGE_ALIGN_LEGACY_BIG") != nullptr;  // the round-1 global-memory kernel for the big jobs
   std::vector<int> order(n_jobs);
-  int n_lds = 0, max_nf_lds = 0;
+  int n_lds = 0, max_nf_lds = 0, max_nf_big = 0;
   size_t work = 0;
   for (int j = 0; j < n_jobs; j++) {
     const sdvl_align_job &a = jobs[j];
@@ -643,8 +652,8 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
         if (nf > max_nf_lds) max_nf_lds = nf;
       } else {
         order[--hi] = j;
-        work += static_cast<size_t>(nf) * 16 * (sizeof(float) + 6 * sizeof(double));
-        work = (work + 255) / 256 * 256;
+        work += legacy ? (static_cast<size_t>(nf) * 16 * (sizeof(float) + 6 * sizeof(double)) + 255) / 256 * 256 : ia_spill_work_bytes(nf);
+        if (nf > max_nf_big) max_nf_big = nf;
       }
     }
     n_lds = lo;
@@ -676,12 +685,16 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     d.n_feat = a.feat_end - a.feat_begin;
     d.out_index = order[q];
     for (int k = 0; k < 7; k++) d.T[k] = a.T[k];
-    if (q >= n_lds) {
+    if (q >= n_lds && legacy) {
       const size_t items = static_cast<size_t>(d.n_feat) * 16;
       d.jac_cache = reinterpret_cast<double *>(wbase + woff);
       d.patch_cache = reinterpret_cast<float *>(wbase + woff + items * 6 * sizeof(double));
       woff += items * (sizeof(float) + 6 * sizeof(double));
       woff = (woff + 255) / 256 * 256;
+    } else if (q >= n_lds) {  // Jacobians [n_feat][12] doubles, then the items [n_feat][16] {patch, dx, dy}
+      d.jac_cache = reinterpret_cast<double *>(wbase + woff);
+      d.patch_cache = reinterpret_cast<float *>(wbase + woff + static_cast<size_t>(d.n_feat) * 12 * sizeof(double));
+      woff += ia_spill_work_bytes(d.n_feat);
     }
   }
   if (feat_bytes) memcpy(static_cast<uint8_t *>(hs) + job_bytes, features, feat_bytes);
@@ -690,25 +703,36 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   const bool direct = sdvl_direct_results();
   sdvl_align_result *dst = d_results ? d_results : static_cast<sdvl_align_result *>(direct ? ctx->h_out : ctx->d_out);
-  if (n_lds > 0) {
-    const int max_f = (max_nf_lds + 7) / 8 * 8 + 8;
-    const size_t lds = ia_lds_bytes(max_f);
+  {
     // the attribute belongs to the kernel object of ONE device: set it once per device, whichever thread gets there first
     static std::atomic<unsigned long long> attr_devices{0};
     const unsigned long long bit = 1ull << (ctx->device & 63);
     if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
       SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
-      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_lds_bytes(kLdsMaxF + 16))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_spill_lds_bytes(kMaxF + 16))));
       attr_devices.fetch_or(bit, std::memory_order_release);
     }
+  }
+  if (n_lds > 0) {
+    const int max_f = (max_nf_lds + 7) / 8 * 8 + 8;
+    const size_t lds = ia_lds_bytes(max_f);
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
-    hipExtLaunchKernelGGL(image_align_lds_kernel, dim3(n_lds), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+    hipExtLaunchKernelGGL(image_align_lds_kernel<false>, dim3(n_lds), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
                           feats_dev, c, *p, max_f, dst);
   }
-  if (n_gen > 0)
+  if (n_gen > 0 && legacy) {
     SDVL_LAUNCH(ctx, "image_align_big", image_align_kernel, dim3(n_gen), dim3(kThreads), static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, dst);
+  } else if (n_gen > 0) {
+    const int max_f = (max_nf_big + 7) / 8 * 8 + 8;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    sdvl_timer_events(ctx, "image_align_big", &ev_a, &ev_b);
+    hipExtLaunchKernelGGL(image_align_lds_kernel<true>, dim3(n_gen), dim3(kThreads), ia_spill_lds_bytes(max_f), ctx->stream, ev_a, ev_b, 0,
+                          static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, max_f, dst);
+  }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   if (!d_results && !direct) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   return SDVL_OK;

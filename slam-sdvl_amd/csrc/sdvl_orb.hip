@@ -169,6 +169,100 @@ __global__ __launch_bounds__(256) void filter_select_kernel(const FilterJob *__r
   if (tid == 0) job.out_count[0] = running;  // the host checks it against max_out
 }
 
+// The same selection for grids of up to 2048 cells with the corners binned first: every corner appends itself to its cell's
+// short list (LDS atomics, arrival order), the cell's thread puts the handful of entries back into list order and runs the
+// reference's sequential comparison over them.  Work ~ corners instead of cells x corners (configuration C: 1200 cells x
+// 4050 corners).  A cell with more than kBinSlots corners falls back to the scan over all corners.
+constexpr int kBinCells = 2048, kBinSlots = 10;
+
+__global__ __launch_bounds__(256) void filter_select_binned_kernel(const FilterJob *__restrict__ jobs, int cell_size, int grid_w, int n_cells,
+                                                                   int margin, int min_score, int max_out) {
+  __shared__ uint16_t s_cell[kFilterMaxCorners];
+  __shared__ uint16_t s_list[kBinCells * kBinSlots];
+  __shared__ int s_cnt[kBinCells];  // corners of the cell; afterwards the chosen corner or -1
+  __shared__ int s_wave[4];
+  const FilterJob &job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(min(job.n_ptr[0], job.ccap), kFilterMaxCorners);
+  for (int c = tid; c < n_cells; c += 256) s_cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int px = job.corners[4 * i], py = job.corners[4 * i + 1], level = job.corners[4 * i + 2];
+    uint16_t c = 0xFFFFu;
+    if (level >= 0 && level < job.levels && !(px < margin || py < margin || px >= job.lw[level] - margin || py >= job.lh[level] - margin)) {
+      const int scale = 1 << level;
+      const int pos = ((py * scale) / cell_size) * grid_w + (px * scale) / cell_size;
+      if (pos >= 0 && pos < n_cells && !((job.locked[pos >> 5] >> (pos & 31)) & 1u)) {
+        c = static_cast<uint16_t>(pos);
+        const int slot = atomicAdd(&s_cnt[pos], 1);
+        if (slot < kBinSlots) s_list[pos * kBinSlots + slot] = static_cast<uint16_t>(i);
+      }
+    }
+    s_cell[i] = c;
+  }
+  __syncthreads();
+  for (int c = tid; c < n_cells; c += 256) {
+    const int cnt = s_cnt[c];
+    int best_idx = 0, best = min_score;  // cgrid_ starts as (0, MinFeatureScore), fast_detector.cc:40
+    if (cnt <= kBinSlots) {
+      int idx[kBinSlots];
+#pragma unroll
+      for (int q = 0; q < kBinSlots; q++) idx[q] = q < cnt ? s_list[c * kBinSlots + q] : 0x7FFFFFFF;
+      // list order = ascending corner index: a fixed compare-exchange network over the (at most 10) entries
+#pragma unroll
+      for (int a = 0; a < kBinSlots; a++)
+#pragma unroll
+        for (int b = 0; b + 1 < kBinSlots - a; b++) {
+          const int lo = min(idx[b], idx[b + 1]), hi = max(idx[b], idx[b + 1]);
+          idx[b] = lo;
+          idx[b + 1] = hi;
+        }
+#pragma unroll
+      for (int q = 0; q < kBinSlots; q++) {
+        if (q >= cnt) break;
+        const double score = job.scores[idx[q]];
+        if (score > best) {
+          best_idx = idx[q];
+          best = static_cast<int>(score);
+        }
+      }
+    } else {
+      for (int i = 0; i < n; i++) {
+        if (s_cell[i] != c) continue;
+        const double score = job.scores[i];
+        if (score > best) {
+          best_idx = i;
+          best = static_cast<int>(score);
+        }
+      }
+    }
+    s_cnt[c] = best > min_score ? best_idx : -1;
+  }
+  __syncthreads();
+  int running = 0;
+  for (int c0 = 0; c0 < n_cells; c0 += 256) {
+    const int c = c0 + tid;
+    const bool ok = c < n_cells && s_cnt[c] >= 0;
+    const unsigned long long m = __ballot(ok);
+    const int below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int pos = running + below;
+    for (int w = 0; w < wave; w++) pos += s_wave[w];
+    if (ok && pos < max_out) {
+      const int i = s_cnt[c];
+      sdvl_filtered_corner *dst = job.out + pos;
+      dst->index = i;
+      dst->x = job.corners[4 * i]; dst->y = job.corners[4 * i + 1]; dst->level = job.corners[4 * i + 2];
+      dst->score = static_cast<int>(job.scores[i]);
+      dst->pad_ = 0;
+    }
+    running += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  }
+  if (tid == 0) job.out_count[0] = running;
+}
+
 // ORB descriptors of the corners filter_select_kernel kept, one wave each: grid.x covers max_out / 4 workgroups, grid.y = frames
 __global__ __launch_bounds__(256) void filter_describe_kernel(const FilterJob *__restrict__ jobs, int max_out) {
   const FilterJob &job = jobs[blockIdx.y];
@@ -455,8 +549,13 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   }
   memcpy(static_cast<uint8_t *>(hs) + jb, locked_cells, mb);
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, jb + mb, hipMemcpyHostToDevice, ctx->stream));
-  SDVL_LAUNCH(ctx, "filter_select", filter_select_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells, margin,
-              min_feature_score, max_out);
+  static const bool scan_only = getenv("SDVL_FILTER_SCAN") != nullptr;  // A/B: the cells x corners scan for every grid
+  if (n_cells <= kBinCells && !scan_only)
+    SDVL_LAUNCH(ctx, "filter_select", filter_select_binned_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells,
+                margin, min_feature_score, max_out);
+  else
+    SDVL_LAUNCH(ctx, "filter_select", filter_select_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells, margin,
+                min_feature_score, max_out);
   SDVL_LAUNCH(ctx, "filter_describe", filter_describe_kernel, dim3((std::min(max_out, 512) + 3) / 4, n), dim3(256), static_cast<const FilterJob *>(dsx),
               max_out);
   SDVL_HIP_CHECK(ctx, hipGetLastError());

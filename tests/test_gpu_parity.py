@@ -213,6 +213,39 @@ def test_image_align_batch_of_jobs_and_empty(ctx, sdvl, orc, synth):
         f.close()
 
 
+def test_filter_corners_selection_on_the_device(ctx, sdvl, orc, synth):
+    """sdvl_filter_corners_begin / _end = Frame::FilterCorners with the per-cell selection of FastDetector::FilterCorners done
+    on the device: the kept corner indices (cell order), their truncated scores and ORB descriptors equal the oracle's, with
+    some cells locked; on a frame whose corners crowd into few cells (more than the kernel's per-cell bins hold: the scan
+    fallback) and on a normal frame"""
+    img = frames_of(synth, orc, TUM_CAM, 640, 480, [2])[0]
+    corners = orc.detect_pyramid(img)
+    # a second corner list of the same image: every level-0 corner of a few cells (FAST without the quota), > 10 per cell
+    dense = orc.fast(img, thr=10, nonmax=True)
+    dense = dense[(dense[:, 0] >= 64) & (dense[:, 0] < 160) & (dense[:, 1] >= 64) & (dense[:, 1] < 128)][:600]
+    dense = np.concatenate([dense[:, :2], np.zeros((len(dense), 1), np.int32)], 1).astype(np.int32)
+    assert len(dense) > 100
+    pyr = orc.pyramid(img, 5)
+    for clist, locked in ((corners, [[100.0, 100.0], [333.3, 250.1], [620.0, 470.0]]), (dense, [[70.0, 70.0]]), (corners, [])):
+        f = ctx.frame(img)
+        f.set_corners(clist)
+        idx, xyl, score, desc = ctx.filter_corners([f], [locked])[0]
+        want = orc.filter_corners(img, clist, locked if locked else None)
+        assert np.array_equal(idx, want), (len(idx), len(want))
+        assert np.array_equal(xyl, clist[want])
+        for k in range(0, len(idx), 7):
+            x, y, l = xyl[k]
+            assert score[k] == int(orc.shi_tomasi(pyr[l], x, y))
+            d, _ = orc.orb_describe(pyr[l], [[x, y]])
+            inside = 19 <= x < pyr[l].shape[1] - 19 and 19 <= y < pyr[l].shape[0] - 19
+            assert np.array_equal(desc[k], d[0] if inside else np.zeros(32, np.uint8))
+        f.close()
+    cells = {}
+    for x, y, _ in dense:
+        cells[(x // 32, y // 32)] = cells.get((x // 32, y // 32), 0) + 1
+    assert max(cells.values()) > 10      # the dense list really overflows a bin
+
+
 # ------------------------------------------------------------------------------------------------ K7
 def search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, cam4, n_req, seed, fixed, noise=0.0, describe=True):
     """points seeded on the reference frame's corners (plane z=2 in world = camera 0), searched in the current frame"""
