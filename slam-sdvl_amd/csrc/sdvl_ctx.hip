@@ -424,6 +424,14 @@ sdvl_frame *frame_bind(const FrameLayout &L, int width, int height, int levels, 
   f->cell_kps = reinterpret_cast<uint32_t *>(base + L.kps_off);
   f->max_cells = L.max_cells;
   f->desc_valid = 0;
+  f->bins_valid = 0;
+  {  // bins live in the selection scratch: [cells + 1] offsets, then 8-byte entries (the scratch holds 4 x 6144 x 16 B)
+    f->bin_gw = (width + 31) / 32;
+    const int cells = f->bin_gw * ((height + 31) / 32);
+    f->bin_cells = cells <= 4096 ? cells : 0;
+    f->bin_start = f->level_corners;
+    f->bin_entries = reinterpret_cast<uint2 *>(f->level_corners + ((cells + 1 + 3) / 4 * 4));
+  }
   f->reg_id = -1;
   f->home = nullptr;
   return f;
@@ -503,6 +511,7 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
   f->hdr_stale = 1;
   f->v.n_corners = 0;
   f->desc_valid = 0;
+  f->bins_valid = 0;
   return SDVL_OK;
 }
 
@@ -515,6 +524,7 @@ int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_im
   f->hdr_stale = 1;
   f->v.n_corners = 0;
   f->desc_valid = 0;
+  f->bins_valid = 0;
   return SDVL_OK;
 }
 
@@ -524,6 +534,7 @@ int sdvl_frame_borrow_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev
   f->hdr_stale = 1;
   f->v.n_corners = 0;
   f->desc_valid = 0;
+  f->bins_valid = 0;
   return SDVL_OK;
 }
 
@@ -565,6 +576,7 @@ int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *x
   f->hdr_stale = 0;
   f->v.n_corners = n;
   f->desc_valid = 0;
+  f->bins_valid = 0;
   return SDVL_OK;
 }
 
@@ -608,6 +620,7 @@ int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, con
     frames[i]->v.n_corners = counts[i];
     frames[i]->hdr_stale = 0;
     frames[i]->desc_valid = 0;
+    frames[i]->bins_valid = 0;
     w += counts[i] + 1;
   }
   // no synchronisation: later launches on the same stream are ordered behind the copies; the pinned staging

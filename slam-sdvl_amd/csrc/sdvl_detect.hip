@@ -553,6 +553,9 @@ struct SelJob {
   int32_t *level_counts;   // [4]
   int32_t *corner_hdr;     // {count,0,0,0} + corners
   int lw[4], lh[4];
+  int32_t *bin_start;      // [bin_cells + 1] (pack_corners_kernel)
+  uint2 *bin_entries;
+  int bin_gw, bin_cells;
 };
 
 constexpr int kSelThreads = 1024;  // 16 waves: one lane per cell leaves <= ~20 divergent lanes per wave
@@ -1012,8 +1015,13 @@ __global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJo
 }
 
 // one workgroup per frame: level segments -> corners_ (fast_detector.cc:171-174 concatenates levels in order)
+// levels concatenated into corners_ (fast_detector.cc:151) + the count, then the list binned by 32-px cell of level-0
+// coordinates for the searches (GetCornersInRange scans ALL corners of the frame for every point, matcher.cc:123-230: with
+// the bins a search reads the handful of cells around its point).  The bins go into the selection scratch, dead by now.
 __global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restrict__ jobs, int n_levels, int32_t *__restrict__ batch_counts,
                                                            int32_t *__restrict__ host_counts) {
+  __shared__ int s_hist[4096];
+  __shared__ int s_part[256];
   const SelJob &job = jobs[blockIdx.x];
   int off = 0;
   bool bad = false;
@@ -1031,6 +1039,47 @@ __global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restr
     job.corner_hdr[1] = total;
     if (batch_counts) batch_counts[blockIdx.x] = total;
     if (host_counts) host_counts[blockIdx.x] = total;
+  }
+  const int cells = job.bin_cells;
+  if (cells <= 0) return;
+  const int n = bad ? 0 : off;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < cells; c += 256) s_hist[c] = 0;
+  __syncthreads();  // also: every thread has finished copying out of the scratch the bins are about to overwrite
+  const int4 *list = reinterpret_cast<const int4 *>(job.corner_hdr + 4);
+  const auto cell_of = [&](const int4 c) {
+    const int x = min(c.x << c.z, job.lw[0] - 1), y = min(c.y << c.z, job.lh[0] - 1);
+    return (y >> 5) * job.bin_gw + (x >> 5);
+  };
+  for (int k = tid; k < n; k += 256) atomicAdd(&s_hist[cell_of(list[k])], 1);
+  __syncthreads();
+  // exclusive scan of the histogram: every thread owns a run of consecutive cells
+  const int per = (cells + 255) / 256, c0 = tid * per, c1 = min(cells, c0 + per);
+  int sum = 0;
+  for (int c = c0; c < c1; c++) sum += s_hist[c];
+  s_part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; t++) { const int v = s_part[t]; s_part[t] = run; run += v; }
+  }
+  __syncthreads();
+  {
+    int run = s_part[tid];
+    for (int c = c0; c < c1; c++) {
+      const int v = s_hist[c];
+      job.bin_start[c] = run;
+      s_hist[c] = run;  // becomes the fill cursor of the cell
+      run += v;
+    }
+    if (tid == 0) job.bin_start[cells] = n;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const int4 c = list[k];
+    const int slot = atomicAdd(&s_hist[cell_of(c)], 1);
+    job.bin_entries[slot] = make_uint2(static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24),
+                                       static_cast<uint32_t>(k));
   }
 }
 
@@ -1279,6 +1328,11 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
     hs[i].level_corners = frames[i]->level_corners;
     hs[i].level_counts = frames[i]->level_counts;
     hs[i].corner_hdr = frames[i]->v.corner_hdr;
+    hs[i].bin_start = frames[i]->bin_start;
+    hs[i].bin_entries = frames[i]->bin_entries;
+    hs[i].bin_gw = frames[i]->bin_gw;
+    hs[i].bin_cells = frames[i]->bin_cells;
+    frames[i]->bins_valid = frames[i]->bin_cells > 0 ? 1 : 0;
     frames[i]->v.n_corners = -1;  // known on the device only
     frames[i]->hdr_stale = 0;     // the pack kernel rewrites the header
     frames[i]->desc_valid = 0;

@@ -36,6 +36,12 @@ struct sdvl_frame {
   int32_t *level_counts;   // [4]
   int max_cells;
   int desc_valid;
+  // the corner list binned by 32-px cell of level-0 coordinates (written by the detection's pack kernel into the selection
+  // scratch, which is dead by then): searches visit the cells around a point instead of scanning every corner
+  int32_t *bin_start;    // [bin_cells + 1]
+  uint2 *bin_entries;    // [n_corners] {packed corner x | y<<12 | level<<24, index in the corner list}
+  int bin_gw, bin_cells; // grid; bin_cells == 0: the frame size does not fit the binning kernel
+  int bins_valid;        // the bins describe the current corner list (sdvl_detect_corners); cleared with the corners
   int in_slab;           // storage belongs to a slab owned by the context (sdvl_frame_create_many)
   int hdr_stale;         // device corner header still holds the count of a previous image (reset lazily)
   uint8_t *own_level0;   // the frame's own level-0 storage (level[0] may point at a borrowed caller image)

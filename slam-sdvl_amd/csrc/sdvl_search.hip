@@ -289,9 +289,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   const auto pack_corner = [](const int4 c) {
     return static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24);
   };
-  for (int ci = threadIdx.x; ci < min(n_corners, kLdsCorners); ci += 64 * kWavesPerBlock) s_corners[ci] = pack_corner(corners_g[ci]);
-  __syncthreads();
-  const auto corner_at = [&](int ci) { return ci < kLdsCorners ? s_corners[ci] : pack_corner(corners_g[ci]); };
+  // A frame whose corners are binned by cell (sdvl_detect_corners) is searched through its bins: no staging, no barrier.
+  // (workgroup-uniform: the workgroup's requests share the current frame)
+  const bool binned = tcur.f.bin_start != nullptr;
+  if (!binned) {
+    for (int ci = threadIdx.x; ci < min(n_corners, kLdsCorners); ci += 64 * kWavesPerBlock) s_corners[ci] = pack_corner(corners_g[ci]);
+    __syncthreads();
+  }
+  const auto corner_at = [&](int ci) { return (!binned && ci < kLdsCorners) ? s_corners[ci] : pack_corner(corners_g[ci]); };
   if (wv >= blk.count) return;
   const int ri = blk.first + wv;
   WaveLds &L = s_lds[wv];
@@ -355,12 +360,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     // a current frame without descriptors (sdvl_orb_describe not run): the wave computes the descriptor of every corner
     // that falls in range on the spot — same arithmetic, same values; a tracking step compares ~200 of ~1000 corners
     const bool lazy_desc = prm.use_orb && cf.desc == nullptr;
-    for (int c0 = 0; c0 < n_corners; c0 += 64) {
-      const int ci = c0 + lane;
-      bool inr = ci < n_corners;
+    // one round of GetCornersInRange + SearchFeatures: lane's corner (packed `pk`, list index `ci`; `have` = the lane holds one)
+    const auto scan_round = [&](bool have, uint32_t pk, int ci) {
+      bool inr = have;
       int cx = 0, cy = 0, cl = 0;
       if (inr) {
-        const uint32_t pk = corner_at(ci);
         cx = static_cast<int>(pk & 0xFFFu);
         cy = static_cast<int>((pk >> 12) & 0xFFFu);
         cl = static_cast<int>(pk >> 24);
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         while (m) {
           const int j = __ffsll(static_cast<long long>(m)) - 1;
           m &= m - 1;
-          const uint32_t pj = corner_at(c0 + j);
+          const uint32_t pj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pk), j));
           const int jx = static_cast<int>(pj & 0xFFFu), jy = static_cast<int>((pj >> 12) & 0xFFFu), jl = static_cast<int>(pj >> 24);
           const int Wj = cf.lw[jl], Hj = cf.lh[jl];
           uint32_t nib = 0;  // outside ORBDetector::IsInsideLimits the descriptor is all zeros (sdvl_orb.hip)
@@ -436,6 +440,44 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         const unsigned long long key =
             (static_cast<unsigned long long>(static_cast<unsigned>(score + 0x40000000)) << 20) | static_cast<unsigned>(ci);
         best = key < best ? key : best;
+      }
+    };
+    // which corners to look at: with bins, the cells the search region touches (a superset of the corners in range: the
+    // exact tests above decide); otherwise, or for regions spanning many cells, the whole list
+    bool scanned = false;
+    if (binned) {
+      double bx0, bx1, by0, by1;
+      if (rq.fixed) {
+        bx0 = rq.px0[0] - range; bx1 = rq.px0[0] + range; by0 = rq.px0[1] - range; by1 = rq.px0[1] + range;
+      } else {
+        bx0 = fmin(pxa.x, pxb.x) - range; bx1 = fmax(pxa.x, pxb.x) + range; by0 = fmin(pxa.y, pxb.y) - range; by1 = fmax(pxa.y, pxb.y) + range;
+      }
+      const int gw = cf.bin_gw, gh = cf.bin_cells / cf.bin_gw;
+      // NaN or absurd coordinates fail the comparisons below and fall through to the full scan
+      if (bx0 > -1.0e6 && bx1 < 1.0e6 && by0 > -1.0e6 && by1 < 1.0e6) {
+        const int cx0 = max(0, static_cast<int>(floor(bx0)) >> 5), cx1 = min(gw - 1, static_cast<int>(floor(bx1)) >> 5);
+        const int cy0 = max(0, static_cast<int>(floor(by0)) >> 5), cy1 = min(gh - 1, static_cast<int>(floor(by1)) >> 5);
+        if (cx1 < cx0 || cy1 < cy0) {
+          scanned = true;  // the region lies outside the image: no corner can be in range
+        } else if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 48) {
+          scanned = true;
+          for (int cyi = cy0; cyi <= cy1; cyi++) {
+            const int e0 = cf.bin_start[cyi * gw + cx0], e1 = cf.bin_start[cyi * gw + cx1 + 1];  // cells of a row are consecutive
+            for (int e = e0; e < e1; e += 64) {
+              const bool have = e + lane < e1;
+              uint2 ent = make_uint2(0u, 0u);
+              if (have) ent = cf.bin_entries[e + lane];
+              scan_round(have, ent.x, static_cast<int>(ent.y));
+            }
+          }
+        }
+      }
+    }
+    if (!scanned) {
+      for (int c0 = 0; c0 < n_corners; c0 += 64) {
+        const int ci = c0 + lane;
+        const bool have = ci < n_corners;
+        scan_round(have, have ? corner_at(ci) : 0u, ci);
       }
     }
     best = wave_min_u64(best);
@@ -583,6 +625,12 @@ void fill_frame(SearchFrame *d, const sdvl_frame *f) {
   d->desc = f->desc_valid ? f->v.desc : nullptr;  // null: the search computes what it compares (search_points_kernel)
   d->n_ptr = f->v.corner_hdr;
   d->levels = f->v.levels;
+  if (f->bins_valid) {
+    d->bin_start = f->bin_start;
+    d->bin_entries = f->bin_entries;
+    d->bin_gw = f->bin_gw;
+    d->bin_cells = f->bin_cells;
+  }
 }
 
 }  // namespace

@@ -85,6 +85,12 @@ void fill_view(SearchFrame *d, const sdvl_frame *f) {
   d->desc = f->desc_valid ? f->v.desc : nullptr;  // null: a search computes the descriptors it compares (search_points_kernel)
   d->n_ptr = f->v.corner_hdr;
   d->levels = f->v.levels;
+  if (f->bins_valid) {
+    d->bin_start = f->bin_start;
+    d->bin_entries = f->bin_entries;
+    d->bin_gw = f->bin_gw;
+    d->bin_cells = f->bin_cells;
+  }
 }
 
 __global__ __launch_bounds__(64) void registry_write_kernel(const RegisterRec *__restrict__ recs, int n, SearchFramePose *__restrict__ registry) {

@@ -177,6 +177,7 @@ int sdvl_frames_upload_undistorted(sdvl_ctx *ctx, int n, sdvl_frame *const *fram
     frames[i]->hdr_stale = 1;
     frames[i]->v.n_corners = 0;
     frames[i]->desc_valid = 0;
+    frames[i]->bins_valid = 0;
   }
   return run_undistort(ctx, n, src, src_stride, src_on_device, frames[0]->width, frames[0]->height, cam, dist, dst.data(), frames[0]->width);
 }
