@@ -302,7 +302,7 @@ def dry_rank(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S-A", help="S-A: the metric configuration (640x480); S-C: 1280x960, 4000 features")
     ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "0")), help="independent sequences per GPU (0 = the workload's)")
