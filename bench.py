@@ -150,13 +150,15 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
 def pmc_traffic_bytes(kernel, frames_per_launch):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN/pmc_hbm_traffic.csv, newest round):
     (FETCH_SIZE + WRITE_SIZE) * 1024 as the CDNA guide prices it, scaled to this run's frames per launch.  The counters
-    need their own rocprofv3 passes (tools/profile_round.sh), so they cannot be sampled inside the timed region."""
+    need their own rocprofv3 passes (tools/profile_round.sh), so they cannot be sampled inside the timed region.
+    Returns (bytes or None, where the figure came from)."""
     import csv
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "pmc_hbm_traffic.csv")))
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "pmc_hbm_traffic.csv")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as fh:
         for row in csv.DictReader(fh):
             if row["kernel"].startswith(kernel):
@@ -165,11 +167,13 @@ def pmc_traffic_bytes(kernel, frames_per_launch):
                 try:
                     total = (float(row["FETCH_SIZE_avg_KB"]) + float(row["WRITE_SIZE_avg_KB"])) * 1024.0
                 except ValueError:
-                    return None
+                    return None, None
                 if not per or total != total:
-                    return None
-                return int(total * frames_per_launch / per)
-    return None
+                    return None, None
+                src = "%s row '%s': (FETCH_SIZE_avg_KB %s + WRITE_SIZE_avg_KB %s) * 1024 per %d-frame dispatch, scaled to %.0f frames" % (
+                    os.path.relpath(files[-1], root), row["kernel"], row["FETCH_SIZE_avg_KB"], row["WRITE_SIZE_avg_KB"], int(per), frames_per_launch)
+                return int(total * frames_per_launch / per), src
+    return None, None
 
 
 def effective_cpus():
@@ -543,8 +547,9 @@ def main():
                 frames_per_step = n_kf / K if name in ("orb_describe", "shi_tomasi", "filter_gather", "filter_select", "filter_describe") else B
                 bytes_per_launch = per_frame * frames_per_step / launches_per_step
                 achieved = bytes_per_launch / avg_s / 1e9
+                traffic, traffic_src = pmc_traffic_bytes(name, frames_per_step / launches_per_step) if args.workload == "S-A" else (None, None)  # the PMC passes were taken on S-A
                 roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes(name, frames_per_step / launches_per_step) if args.workload == "S-A" else None,  # the PMC passes were taken on S-A
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                             "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch)}
         value = tracked_all / elapsed_max
         out = {

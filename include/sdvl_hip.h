@@ -95,6 +95,10 @@ typedef struct sdvl_search_params { /* Config getters used by Matcher */
   int max_fast_levels; /* MaxFastLevels 3 */
   int margin;          /* corner margin, matcher.cc:131-134 */
   int use_orb;         /* UseORB (1: Hamming on ORB descriptors; 0: ZMSSD on 8x8 patches) */
+  int lk_tree_sums;    /* 0: AlignPatch's three 64-term sums in the reference's sequential order (offsets bit-identical to the
+                          CPU path); 1: wave butterfly sums (__shfl_xor tree): same iteration, different rounding order —
+                          offsets agree within the path's 1e-4 tolerance, convergence decisions may differ on borderline patches */
+  int pad_;
 } sdvl_search_params;
 
 typedef struct sdvl_search_req { /* arguments of Matcher::SearchPoint, matcher.cc:45-46 */

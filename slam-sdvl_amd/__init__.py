@@ -67,7 +67,7 @@ class AlignResult(C.Structure):
 
 
 class SearchParams(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("patch_size", "max_align_its", "search_size", "max_fast_levels", "margin", "use_orb")]
+    _fields_ = [(n, C.c_int) for n in ("patch_size", "max_align_its", "search_size", "max_fast_levels", "margin", "use_orb", "lk_tree_sums", "pad_")]
 
 
 class SearchReq(C.Structure):

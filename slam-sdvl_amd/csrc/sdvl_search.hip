@@ -77,8 +77,14 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 }
 
 // Matcher::AlignPatch, matcher.cc:359-445.  border/patch in this wave's LDS.  Returns converged; *u,*v updated.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, int max_its, int lane, float *u_io, float *v_io,
-                                 int *its_out) {
+                                 int *its_out, bool tree_sums = false) {
   const int y = lane >> 3, x = lane & 7;
   const uint8_t *it = &L.border[(y + 1) * 10 + 1 + x];
   const int jx = static_cast<int>(it[1]) - static_cast<int>(it[-1]);
@@ -129,18 +135,25 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
     const uint8_t *ip = img + static_cast<size_t>(v_r + y - 4) * W + (u_r + x - 4);
     const float search_pixel = wTL * ip[0] + wTR * ip[1] + wBL * ip[W] + wBR * ip[W + 1];
     const float res = search_pixel - ref + mean_diff;
-    L.prod[0][lane] = res * dx;
-    L.prod[1][lane] = res * dy;
-    L.prod[2][lane] = res;
-    wave_sync();
-    // sequential accumulation (matcher.cc:427-429): lanes 0..2 own one component each
-    float acc = 0.f;
-    if (lane < 3) {
+    float J0, J1, J2;
+    if (tree_sums) {  // tolerance class: the same 64 terms summed as a butterfly (18 shuffles instead of a 64-step chain)
+      J0 = -wave_sum_f32(res * dx);
+      J1 = -wave_sum_f32(res * dy);
+      J2 = -wave_sum_f32(res);
+    } else {
+      L.prod[0][lane] = res * dx;
+      L.prod[1][lane] = res * dy;
+      L.prod[2][lane] = res;
+      wave_sync();
+      // sequential accumulation (matcher.cc:427-429): lanes 0..2 own one component each
+      float acc = 0.f;
+      if (lane < 3) {
 #pragma unroll 8
-      for (int k = 0; k < 64; k++) acc -= L.prod[lane][k];
+        for (int k = 0; k < 64; k++) acc -= L.prod[lane][k];
+      }
+      J0 = __shfl(acc, 0, 64); J1 = __shfl(acc, 1, 64); J2 = __shfl(acc, 2, 64);
+      wave_sync();
     }
-    const float J0 = __shfl(acc, 0, 64), J1 = __shfl(acc, 1, 64), J2 = __shfl(acc, 2, 64);
-    wave_sync();
     const float up0 = inv[0][0] * J0 + inv[0][1] * J1 + inv[0][2] * J2;
     const float up1 = inv[1][0] * J0 + inv[1][1] * J1 + inv[1][2] * J2;
     const float up2 = inv[2][0] * J0 + inv[2][1] * J1 + inv[2][2] * J2;
@@ -506,7 +519,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   // ---- AlignPatch at the search level
   float u = static_cast<float>(mpx / (1 << slevel)), v = static_cast<float>(mpy / (1 << slevel));
   int its = 0;
-  const bool conv = align_patch_wave(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v, &its);
+  const bool conv = align_patch_wave(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v, &its,
+                                     prm.lk_tree_sums != 0);
   res.lk_its = its;
   res.stage = 2;
   if (conv) {

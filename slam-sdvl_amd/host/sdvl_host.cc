@@ -897,6 +897,9 @@ static sdvl_search_params SearchParams() {
   sp.max_fast_levels = Config::MaxFastLevels();
   sp.margin = DetectMargin();
   sp.use_orb = Config::UseORB() ? 1 : 0;
+  static const bool tree = std::getenv("SDVL_LK_TREE_SUMS") != nullptr;  // A/B: tolerance-class LK sums (include/sdvl_hip.h)
+  sp.lk_tree_sums = tree ? 1 : 0;
+  sp.pad_ = 0;
   return sp;
 }
 

@@ -324,6 +324,29 @@ def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur
     f_ref.close(); f_cur.close()
 
 
+def test_search_points_tree_sums_within_tolerance(ctx, sdvl, orc, synth):
+    """sdvl_search_params.lk_tree_sums = 1: AlignPatch's three 64-term sums as a wave butterfly instead of the reference's
+    sequential chain.  Tolerance class, not bit class: found flags equal for (almost) every request, offsets within 1e-4."""
+    img_ref, img_cur = frames_of(synth, orc, TUM_CAM, 640, 480, [0, 4])
+    T_ref, T_cur = trajectory_pose(orc, 0), trajectory_pose(orc, 4)
+    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, 400, 31, True, 0.0, False)
+    cam = sdvl.Camera(640, 480, *TUM_CAM)
+    exact = ctx.search_points(reqs, cam, sdvl.default_search_params())
+    sp = sdvl.default_search_params()
+    sp.lk_tree_sums = 1
+    tree = ctx.search_points(reqs, cam, sp)
+    both, flipped, worst = 0, 0, 0.0
+    for a, b in zip(exact, tree):
+        assert a.best_corner == b.best_corner and a.slevel == b.slevel      # everything before AlignPatch is untouched
+        if a.found != b.found:
+            flipped += 1
+        elif a.found:
+            both += 1
+            worst = max(worst, abs(a.px[0] - b.px[0]), abs(a.px[1] - b.px[1]))
+    assert both >= 150 and flipped <= 2 and worst <= 1e-4, (both, flipped, worst)
+    f_ref.close(); f_cur.close()
+
+
 def test_search_points_frame_with_more_corners_than_the_lds_stage(ctx, sdvl, orc, synth):
     """1280x960 with num_features 4600: the current frame holds more corners than search_points stages in LDS (4096), the
     rest (coarse-level corners at the end of the list) are read from HBM — found flags, levels and offsets as the oracle's"""

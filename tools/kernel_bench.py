@@ -117,6 +117,17 @@ t_b = ctx.timing_get().get("search_points", (0.0, 0))
 assert [r.found for r in sres2] == [r.found for r in sres] and [tuple(r.px) for r in sres2] == [tuple(r.px) for r in sres]
 print("search_points, descriptors on demand: %.1f us/launch (descriptors in HBM: %.1f us/launch)" %
       ((t_b[0] - t_a[0]) / max(1, t_b[1] - t_a[1]) * 1e3, t_a[0] / max(1, t_a[1]) * 1e3))
+# tolerance-class LK sums (sdvl_search_params.lk_tree_sums)
+sp_tree = sdvl.default_search_params()
+sp_tree.lk_tree_sums = 1
+ctx.synchronize()
+t_c = ctx.timing_get().get("search_points", (0.0, 0))
+for _ in range(max(1, reps // 3)):
+    sres3 = ctx.search_points(sreqs, cam, sp_tree)
+ctx.synchronize()
+t_d = ctx.timing_get().get("search_points", (0.0, 0))
+print("search_points, LK sums as a wave butterfly (tolerance class): %.1f us/launch; found flags that differ from the sequential sums: %d of %d" %
+      ((t_d[0] - t_c[0]) / max(1, t_d[1] - t_c[1]) * 1e3, sum(a.found != b.found for a, b in zip(sres2, sres3)), nreq))
 # pose stage: n jobs of 190 matches (20 % gross outliers) of a small camera motion; rand() draws from numpy (timing only)
 prng = np.random.default_rng(7)
 pose_jobs = []
