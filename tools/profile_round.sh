@@ -20,5 +20,10 @@ find $O/prof_sq -name "*kernel_trace.csv" -delete
 # the stats files are small; the raw traces are not needed back
 find $O/prof_kt -name "*kernel_trace.csv" -delete
 find $O/prof_fetch $O/prof_write -name "*kernel_trace.csv" -delete
+# the other two configurations DESIGN §7 quotes: the reference's mapper inside every step, and BASELINE's configuration C
+python3 bench.py --mapper --steps 20 --warmup 4 --cpu-frames 0 --host-steps 0 > $O/bench_mapper.json 2> $O/bench_mapper.err
+python3 bench.py --workload S-C --seqs 512 --steps 30 --warmup 4 --cpu-frames 60 --host-steps 0 > $O/bench_config_c.json 2> $O/bench_config_c.err
+python3 tools/kernel_bench.py 256 6 > $O/kernel_bench_isolated.txt 2>&1
 python3 tools/summarize_profiles.py $O $O/summary_r
+cp $O/bench_mapper.json $O/bench_config_c.json $O/kernel_bench_isolated.txt $O/summary_r/
 ls -la $O/summary_r
