@@ -276,6 +276,60 @@ int sdvl_search_begin(sdvl_ctx *ctx, int max_requests, sdvl_search_req_packed **
 int sdvl_search_slot(sdvl_ctx *ctx, const sdvl_frame *frame, const double *pose7);
 int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, sdvl_search_res *out);
 
+/* ---- the mapper's depth filter behind the search (Map::UpdateCandidates, map.cc:402-498) ------------------------------
+ * One request per candidate that passed the visibility / baseline tests (map.cc:421-452).  After search_points the device
+ * does, per request, what the body of the loop does with the result (map.cc:454-497):
+ *   not found                -> Point::Unpromote (point.cc:109-118): n_failed + 1, b + 1, deleted when n_failed > max_failed
+ *   found                    -> GetDepthFromTriangulation (extra/utils.cc:193-205), the point's world position, GetParallax
+ *                               (utils.cc:207-213; >= 0.999999 skips), the two minimum-depth tests (map.cc:476-479),
+ *                               Point::Update (point.cc:64-100: ComputeTau, the Gaussian x uniform posterior of inverse depth,
+ *                               parallax and distance of the new estimate) and Point::HasConverged (point.cc:164-178)
+ * and returns the point's new filter state.  With a tracking table set, the row of a point that a tracker follows
+ * (track_row >= 0) is patched in place — position, inverse depth and its deviation, fixed, n_failed, and "deleted after the next
+ * step" (Map::DeletePoint takes effect in the next frame's EmptyTrash, sdvl.cc:127) — so the table stays valid across the
+ * mapper's update.  acos / sin / exp are the device library's: results agree with the host arithmetic to the last bits, not
+ * bit for bit (tolerance class of the poses, 1e-4). */
+struct sdvl_track_set; /* the tracking tables, below */
+typedef struct sdvl_depth_state { /* the Point behind a request (point.h:136-150) */
+  double rho, sigma2, a, b, z_range;
+  double depth_mean;   /* Frame::GetSceneDepth() of the map's current frame (map.cc:92) */
+  double position[3];  /* p3d_ of a point that is fixed already (the second list entry of a point that converged in the first
+                          pass of this frame, map.cc:381,389: Update and HasConverged still run on it) */
+  int32_t fixed;
+  int32_t n_failed;
+  int32_t track_row;   /* tracker * max_points + index of the point's row in the tracking tables, -1: none */
+  int32_t pad_;
+} sdvl_depth_state;
+
+typedef struct sdvl_depth_params {
+  double px_error_angle;  /* Camera::GetPixelErrorAngle, camera.h:104-107 */
+  double min_depth;       /* Config::MapScale() * Config::ScaleMinDist(), map.cc:476 */
+  double scale_min_dist;  /* Config::ScaleMinDist(), map.cc:478 */
+  int32_t max_failed;     /* Config::MaxFailed() */
+  int32_t pad_;
+} sdvl_depth_params;
+
+#define SDVL_DEPTH_NOT_FOUND 0 /* Unpromote */
+#define SDVL_DEPTH_SKIPPED 1   /* found, but no triangulation / no parallax / too close: the point is left alone */
+#define SDVL_DEPTH_UPDATED 2   /* Point::Update ran */
+#define SDVL_DEPTH_CONVERGED 3 /* ... and Point::HasConverged fixed the point at `position` */
+#define SDVL_DEPTH_DELETED 0x100 /* | NOT_FOUND: n_failed crossed max_failed (Map::DeletePoint) */
+typedef struct sdvl_depth_out {
+  int32_t outcome;
+  int32_t n_failed;
+  double rho, sigma2, a, b;
+  double cos_alpha, last_distance; /* valid when UPDATED / CONVERGED */
+  double position[3];              /* Point::GetPosition() after the update (UPDATED / CONVERGED) */
+} sdvl_depth_out;
+
+/* requests as for sdvl_search_points; state[n]; set may be NULL (no table to patch); out[n], fout[n] */
+int sdvl_search_points_filter(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam, const sdvl_search_params *p,
+                              const sdvl_depth_state *state, const sdvl_depth_params *fp, struct sdvl_track_set *set,
+                              sdvl_search_res *out, sdvl_depth_out *fout);
+/* the same behind sdvl_search_begin / sdvl_search_slot */
+int sdvl_search_run_filter(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, const sdvl_depth_state *state,
+                           const sdvl_depth_params *fp, struct sdvl_track_set *set, sdvl_search_res *out, sdvl_depth_out *fout);
+
 /* Matcher::AlignPatch alone, matcher.cc:359-445: n patches against level images of frames.
  * border[n][100], patch[n][64], uv_io[n][2] (level coordinates), converged[n], its[n] (may be NULL) */
 int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const int32_t *levels,

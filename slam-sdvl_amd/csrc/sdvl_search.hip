@@ -647,6 +647,153 @@ void fill_frame(SearchFrame *d, const sdvl_frame *f) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- the mapper's depth filter
+// extra/utils.cc:193-205: A = [R v_ref | v_cur], depth2 = -(A^T A)^-1 A^T t, |depth2[0]|
+__device__ __forceinline__ bool depth_from_triangulation(const Rigid &pose, V3 v_ref, V3 v_cur, double *depth) {
+  const M3 R = se3_rot(pose);
+  const V3 a0 = mvec(R, v_ref);
+  const V3 a1 = v_cur;
+  const double m00 = vdot(a0, a0), m01 = vdot(a0, a1), m11 = vdot(a1, a1);
+  const double det = m00 * m11 - m01 * m01;
+  if (det < 0.000001) return false;
+  const double invdet = 1.0 / det;
+  const double i00 = m11 * invdet, i01 = -m01 * invdet;
+  const double n00 = -i00, n01 = -i01;
+  const double r0x = n00 * a0.x + n01 * a1.x, r0y = n00 * a0.y + n01 * a1.y, r0z = n00 * a0.z + n01 * a1.z;
+  const double d0 = r0x * pose.t.x + r0y * pose.t.y + r0z * pose.t.z;
+  *depth = fabs(d0);
+  return true;
+}
+
+// extra/utils.cc:207-213
+__device__ __forceinline__ double parallax_of(V3 src1, V3 src2, V3 p3d) {
+  V3 v1 = vsub(src1, p3d), v2 = vsub(src2, p3d);
+  const double n1 = vnorm(v1), n2 = vnorm(v2);
+  v1 = {v1.x / n1, v1.y / n1, v1.z / n1};
+  v2 = {v2.x / n2, v2.y / n2, v2.z / n2};
+  return vdot(v1, v2);
+}
+
+// point.cc:189-201
+__device__ __forceinline__ double compute_tau(const Rigid &pose, V3 v, double depth, double px_error_angle) {
+  const double PI = 3.14159265;
+  const V3 t = pose.t;
+  const V3 a = {v.x * depth - t.x, v.y * depth - t.y, v.z * depth - t.z};
+  const double t_norm = vnorm(t), a_norm = vnorm(a);
+  const double alpha = acos((v.x * t.x + v.y * t.y + v.z * t.z) / t_norm);
+  const double beta = acos((a.x * -t.x + a.y * -t.y + a.z * -t.z) / (t_norm * a_norm));
+  const double beta_plus = beta + px_error_angle;
+  const double gamma_plus = PI - alpha - beta_plus;
+  const double depth_plus = t_norm * sin(beta_plus) / sin(gamma_plus);
+  return depth_plus - depth;
+}
+
+// point.cc:203-217
+__device__ __forceinline__ double pdf_normal(double mean, double sd, double x) {
+  const double PI = 3.14159265;
+  double result = 0.0;
+  if (sd <= 0) return result;
+  double exponent = x - mean;
+  exponent *= -exponent;
+  exponent /= 2 * sd * sd;
+  result = exp(exponent);
+  result /= sd * sqrt(2.0 * PI);
+  return result;
+}
+
+// The body of Map::UpdateCandidates' loop behind SearchPoint (map.cc:454-497), one lane per request: Unpromote for a miss;
+// triangulation, parallax, the minimum-depth tests, Point::Update (point.cc:64-100) and Point::HasConverged (:164-178) for a
+// hit.  The point's row in the tracking tables (if it has one) receives what the tracker reads of it.
+__global__ __launch_bounds__(128) void depth_filter_kernel(const SearchReqDev *__restrict__ reqs, const SearchFramePose *__restrict__ table,
+                                                           const sdvl_search_res *__restrict__ res, const sdvl_depth_state *__restrict__ state,
+                                                           int n, Cam cam, sdvl_depth_params fp, TrackPoint *__restrict__ rows, int n_rows,
+                                                           sdvl_depth_out *__restrict__ out, sdvl_depth_out *__restrict__ out_host) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  const SearchReqDev &rq = reqs[i];
+  const sdvl_depth_state st = state[i];
+  const sdvl_search_res r = res[i];
+  TrackPoint *row = (rows && st.track_row >= 0 && st.track_row < n_rows) ? rows + st.track_row : nullptr;
+  sdvl_depth_out o;
+  o.outcome = SDVL_DEPTH_SKIPPED;
+  o.n_failed = st.n_failed;
+  o.rho = st.rho; o.sigma2 = st.sigma2; o.a = st.a; o.b = st.b;
+  o.cos_alpha = 0.0; o.last_distance = 0.0;
+  o.position[0] = o.position[1] = o.position[2] = 0.0;
+  if (!r.found) {
+    // Point::Unpromote, point.cc:109-118
+    o.n_failed = st.n_failed + 1;
+    o.b = st.b + 1.0;
+    o.outcome = SDVL_DEPTH_NOT_FOUND | (o.n_failed > fp.max_failed ? SDVL_DEPTH_DELETED : 0);
+    if (row) {
+      row->n_failed = o.n_failed;
+      if (o.outcome & SDVL_DEPTH_DELETED) row->status |= kTrash;
+    }
+  } else {
+    const Rigid cur = se3_from7(table[rq.cur].pose), ref = se3_from7(table[rq.ref].pose);
+    const V3 fv = {rq.bearing[0], rq.bearing[1], rq.bearing[2]};
+    const Rigid pose = se3_mul(cur, se3_inverse(ref));  // map.cc:459
+    const V3 v3d = cam_unproject(cam, {r.px[0], r.px[1]});
+    double depth = 0.0;
+    bool go = depth_from_triangulation(pose, fv, v3d, &depth);
+    const Rigid ref_world = se3_inverse(ref), cur_world = se3_inverse(cur);  // Frame::GetWorldPose
+    if (go) {
+      const V3 p3d = se3_apply(ref_world, {depth * fv.x, depth * fv.y, depth * fv.z});
+      const double cos_alpha = parallax_of(ref_world.t, cur_world.t, p3d);
+      if (cos_alpha >= 0.999999) go = false;
+    }
+    if (go && (depth < fp.min_depth || depth < st.depth_mean * fp.scale_min_dist)) go = false;
+    if (go) {
+      // Point::Update, point.cc:64-100
+      const Rigid pose2 = se3_mul(ref, se3_inverse(cur));
+      const double tau = compute_tau(pose2, fv, depth, fp.px_error_angle);
+      const double tau_inverse = 0.5 * (1.0 / fmax(0.0000001, depth - tau) - 1.0 / (depth + tau));
+      const double tau2 = tau_inverse * tau_inverse;
+      const double x = 1. / depth;
+      const double norm_scale = sqrt(st.sigma2 + tau2);
+      if (!(norm_scale != norm_scale)) {  // std::isnan(norm_scale) -> return: the point keeps its state
+        const double s2 = 1. / (1. / st.sigma2 + 1. / tau2);
+        const double m = s2 * (st.rho / st.sigma2 + x / tau2);
+        double C1 = st.a / (st.a + st.b) * pdf_normal(st.rho, norm_scale, x);
+        double C2 = st.b / (st.a + st.b) * 1. / st.z_range;
+        const double normalization_constant = C1 + C2;
+        C1 /= normalization_constant;
+        C2 /= normalization_constant;
+        const double f = C1 * (st.a + 1.) / (st.a + st.b + 1.) + C2 * st.a / (st.a + st.b + 1.);
+        const double e = C1 * (st.a + 1.) * (st.a + 2.) / ((st.a + st.b + 1.) * (st.a + st.b + 2.)) +
+                         C2 * st.a * (st.a + 1.0) / ((st.a + st.b + 1.0) * (st.a + st.b + 2.0));
+        const double rho_new = C1 * m + C2 * st.rho;
+        o.sigma2 = C1 * (s2 + m * m) + C2 * (st.sigma2 + st.rho * st.rho) - rho_new * rho_new;
+        o.rho = rho_new;
+        o.a = (e - f) / (f - e / f);
+        o.b = o.a * (1.0 - f) / f;
+        // Point::GetPosition (point.cc:128-142) of the candidate: the first observation's ray at the new inverse depth
+        const double sc = 1.0 / o.rho;
+        const V3 pos = st.fixed ? V3{st.position[0], st.position[1], st.position[2]} : se3_apply(ref_world, {sc * fv.x, sc * fv.y, sc * fv.z});
+        o.cos_alpha = parallax_of(ref_world.t, cur_world.t, pos);
+        o.last_distance = vnorm(vsub(cur_world.t, pos));  // Frame::DistanceTo, frame.h:133-136
+        o.n_failed = 0;
+        o.position[0] = pos.x; o.position[1] = pos.y; o.position[2] = pos.z;
+        o.outcome = SDVL_DEPTH_UPDATED;
+        // Point::HasConverged, point.cc:164-178
+        const double std_d = sqrt(o.sigma2) / (o.rho * o.rho);
+        const double l = 4 * std_d * o.cos_alpha / o.last_distance;
+        if (st.fixed || l < 0.1) o.outcome = SDVL_DEPTH_CONVERGED;
+        if (row) {
+          row->P[0] = pos.x; row->P[1] = pos.y; row->P[2] = pos.z;
+          row->idepth = o.rho;
+          row->idepth_std = sqrt(o.sigma2);  // Point::GetStd
+          row->n_failed = 0;
+          if (o.outcome == SDVL_DEPTH_CONVERGED) row->fixed = 1;
+        }
+      }
+    }
+  }
+  out[i] = o;
+  if (out_host) out_host[i] = o;
+}
+
 }  // namespace
 
 int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_reqs, const SearchFramePose *d_table,
@@ -743,7 +890,8 @@ int sdvl_search_slot(sdvl_ctx *ctx, const sdvl_frame *f, const double *pose) {
 // everything of sdvl_search_run up to and including the queued copy of the results into h_out[0 .. n records); the caller
 // waits.  extra_d / extra_h: room the caller wants behind the search's own use of d_out / h_out (offsets returned).
 static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, size_t extra_d, size_t extra_h,
-                          size_t *extra_d_off, size_t *extra_h_off) {
+                          size_t *extra_d_off, size_t *extra_h_off, const SearchReqDev **d_reqs_out = nullptr,
+                          const SearchFramePose **d_table_out = nullptr) {
   SearchBatch &B = batch_of(ctx);
   SDVL_REQUIRE(ctx, B.hs && n <= B.cap, "sdvl_search_run without a matching sdvl_search_begin");
   SDVL_REQUIRE(ctx, p->patch_size == 8, "only patch_size 8 is supported (one wave64 per 8x8 patch)");
@@ -794,6 +942,8 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
     SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `table` is pageable and reused by the next batch
     d_table = static_cast<const SearchFramePose *>(ctx->d_work);
   }
+  if (d_reqs_out) *d_reqs_out = static_cast<const SearchReqDev *>(dsx);
+  if (d_table_out) *d_table_out = d_table;
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   // d_out: results | per-request records of the scalar phase
   SearchPrep *d_prep = reinterpret_cast<SearchPrep *>(static_cast<uint8_t *>(ctx->d_out) + out_dev_bytes);
@@ -958,10 +1108,7 @@ int sdvl_search_chain_end(sdvl_ctx *ctx, int n_frames, sdvl_pose_result *results
 }
 
 
-int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
-                       const sdvl_search_params *p, sdvl_search_res *out) {
-  if (!ctx || !cam || !p || n < 0 || (n > 0 && (!reqs || !out))) return SDVL_ERR_INVALID;
-  if (n == 0) return SDVL_OK;
+static int pack_requests(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs) {
   sdvl_search_req_packed *packed = nullptr;
   int rc = sdvl_search_begin(ctx, n, &packed);
   if (rc) return rc;
@@ -979,7 +1126,68 @@ int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const 
     d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
     memcpy(d.desc, r.desc, 32);
   }
+  return SDVL_OK;
+}
+
+int sdvl_search_points(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam,
+                       const sdvl_search_params *p, sdvl_search_res *out) {
+  if (!ctx || !cam || !p || n < 0 || (n > 0 && (!reqs || !out))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  const int rc = pack_requests(ctx, n, reqs);
+  if (rc) return rc;
   return sdvl_search_run(ctx, n, cam, p, out);
+}
+
+// ---- search + depth filter (Map::UpdateCandidates, map.cc:402-498): one submission, one wait
+int sdvl_search_run_filter(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_search_params *p, const sdvl_depth_state *state,
+                           const sdvl_depth_params *fp, sdvl_track_set *set, sdvl_search_res *out, sdvl_depth_out *fout) {
+  if (!ctx || !cam || !p || !fp || n < 0 || (n > 0 && (!state || !out || !fout))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  TrackPoint *rows = nullptr;
+  int n_rows = 0;
+  if (set) {
+    int np = 0, nt = 0;
+    rows = sdvl_track_points_device(set, &np, &nt);
+    n_rows = np * nt;
+  }
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, state[i].track_row >= -1 && (state[i].track_row < n_rows || !set), "depth filter: track_row outside the tables");
+    SDVL_REQUIRE(ctx, state[i].sigma2 > 0.0 && state[i].z_range > 0.0, "depth filter: sigma2 and z_range must be positive");
+  }
+  const size_t sb = (sizeof(sdvl_depth_state) * static_cast<size_t>(n) + 255) / 256 * 256;
+  const size_t ob = (sizeof(sdvl_depth_out) * static_cast<size_t>(n) + 255) / 256 * 256;
+  size_t d_off = 0, h_off = 0;
+  const SearchReqDev *d_reqs = nullptr;
+  const SearchFramePose *d_table = nullptr;
+  int rc = search_enqueue(ctx, n, cam, p, ob, ob, &d_off, &h_off, &d_reqs, &d_table);
+  if (rc) return rc;
+  void *hs = nullptr, *dsx = nullptr;
+  rc = sdvl_stage_alloc(ctx, sb, &hs, &dsx);
+  if (rc) return rc;
+  memcpy(hs, state, sizeof(sdvl_depth_state) * static_cast<size_t>(n));
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, sb, hipMemcpyHostToDevice, ctx->stream));
+  Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  sdvl_depth_out *d_fout = reinterpret_cast<sdvl_depth_out *>(static_cast<uint8_t *>(ctx->d_out) + d_off);
+  sdvl_depth_out *h_fout = reinterpret_cast<sdvl_depth_out *>(static_cast<uint8_t *>(ctx->h_out) + h_off);
+  SDVL_LAUNCH(ctx, "depth_filter", depth_filter_kernel, dim3((n + 127) / 128), dim3(128), d_reqs, d_table,
+              static_cast<const sdvl_search_res *>(ctx->d_out), static_cast<const sdvl_depth_state *>(dsx), n, c, *fp, rows, n_rows, d_fout,
+              sdvl_direct_results() ? h_fout : nullptr);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  if (!sdvl_direct_results()) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h_fout, d_fout, sizeof(sdvl_depth_out) * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  memcpy(out, ctx->h_out, sizeof(sdvl_search_res) * static_cast<size_t>(n));
+  memcpy(fout, h_fout, sizeof(sdvl_depth_out) * static_cast<size_t>(n));
+  return SDVL_OK;
+}
+
+int sdvl_search_points_filter(sdvl_ctx *ctx, int n, const sdvl_search_req *reqs, const sdvl_camera *cam, const sdvl_search_params *p,
+                              const sdvl_depth_state *state, const sdvl_depth_params *fp, sdvl_track_set *set, sdvl_search_res *out,
+                              sdvl_depth_out *fout) {
+  if (!ctx || !cam || !p || !fp || n < 0 || (n > 0 && (!reqs || !state || !out || !fout))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  const int rc = pack_requests(ctx, n, reqs);
+  if (rc) return rc;
+  return sdvl_search_run_filter(ctx, n, cam, p, state, fp, set, out, fout);
 }
 
 int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const int32_t *levels, const uint8_t *border,

@@ -62,6 +62,30 @@ struct ChainFrameDev {
   double pad2_;
 };
 
+// ---- rows of the device-resident tracking tables (sdvl_track.hip); the depth filter (sdvl_search.hip) patches them in place
+constexpr int kDeleted = 0x100;                 // sdvl_track_point_stat::status bit
+constexpr int kTrash = 0x200;                   // deleted by the mapper: becomes kDeleted at the end of the next step's commit
+constexpr int kKeepBits = kDeleted | kTrash;
+enum { kFound = 0, kNotFound = 1, kSeen = 2, kUnseen = 3 };  // Point::PointStatus (point.h)
+constexpr int kPointMask = SDVL_TRACK_DUPLICATE - 1;
+
+struct TrackPoint {  // device form of sdvl_track_point: the frame pointer replaced by its registry slot
+  double P[3];
+  double ipx[2];
+  double ibearing[3];
+  double idepth, idepth_std;
+  int32_t ref, pad_;
+  int32_t ilevel, fixed;
+  int32_t score, n_failed;
+  int32_t last_frame;
+  int32_t status;  // Point::PointStatus | kDeleted | kTrash
+  uint32_t desc[8];
+};
+static_assert(sizeof(TrackPoint) == sizeof(sdvl_track_point), "upload converts in place");
+static_assert(sizeof(sdvl_track_point) == 144, "layout");
+// the set's point rows and the row count per tracker (sdvl_track.hip)
+extern "C" TrackPoint *sdvl_track_points_device(sdvl_track_set *set, int *max_points, int *n_trackers);
+
 // ---- launch helpers of sdvl_search.hip for callers whose records already live in HBM (no copies, no wait) --------------
 // search_prepare + search_points over n_slots request records (a record with level < 0 is a dead slot) dealt to workgroups
 // by the n_blocks entries of d_blocks (a block with count 0 is skipped); d_res receives one result per slot, h_res (may

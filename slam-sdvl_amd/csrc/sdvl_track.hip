@@ -26,25 +26,6 @@ namespace {
 
 using namespace sdvl;
 
-constexpr int kDeleted = 0x100;                 // sdvl_track_point_stat::status bit
-enum { kFound = 0, kNotFound = 1, kSeen = 2, kUnseen = 3 };  // Point::PointStatus (point.h)
-constexpr int kPointMask = SDVL_TRACK_DUPLICATE - 1;
-
-struct TrackPoint {  // device form of sdvl_track_point: the frame pointer replaced by its registry slot
-  double P[3];
-  double ipx[2];
-  double ibearing[3];
-  double idepth, idepth_std;
-  int32_t ref, pad_;
-  int32_t ilevel, fixed;
-  int32_t score, n_failed;
-  int32_t last_frame;
-  int32_t status;  // Point::PointStatus | kDeleted
-  uint32_t desc[8];
-};
-static_assert(sizeof(TrackPoint) == sizeof(sdvl_track_point), "upload converts in place");
-static_assert(sizeof(sdvl_track_point) == 144, "layout");
-
 struct TrackFeat {
   double px[2];
   double bearing[3];
@@ -193,7 +174,7 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
           ok = cam_inside(cam, static_cast<int>(px.x), static_cast<int>(px.y), patch);
         }
         if (!ok) {
-          p.status = kUnseen;
+          p.status = (p.status & kTrash) | kUnseen;
         } else {
           const int k = static_cast<int>(px.y / cell_size) * gw + static_cast<int>(px.x / cell_size);
           const unsigned sc = static_cast<unsigned>(p.score < 0 ? 0 : (p.score > 0xFFFFFF ? 0xFFFFFF : p.score));
@@ -202,7 +183,7 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
                 (static_cast<unsigned long long>(0xFFFFFFu - sc) << 24) | static_cast<unsigned>(i);
           s_px[2 * i] = px.x;
           s_px[2 * i + 1] = px.y;
-          p.status = kSeen;
+          p.status = (p.status & kTrash) | kSeen;
         }
         p.last_frame = jb.frame_id;  // not relocalising (the tables are only used for ordinary tracking)
       }
@@ -337,7 +318,7 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
       const sdvl_search_res &r = res[base + k];
       p.score += 1;      // Point::Promote
       p.n_failed = 0;
-      p.status = (p.status & kDeleted) | kFound;
+      p.status = (p.status & kKeepBits) | kFound;
       TrackFeat nf_;
       nf_.px[0] = r.px[0]; nf_.px[1] = r.px[1];
       const V3 v = cam_unproject(cam, {r.px[0], r.px[1]});  // Feature::Feature, feature.cc:28-35
@@ -349,10 +330,10 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
       p.n_failed += 1;   // Point::Unpromote; beyond MaxFailed the map deletes the point (feature_align.cc:141-142)
       int st = kNotFound;
       if (p.n_failed > max_failed && !(p.status & kDeleted)) {
-        st |= kDeleted;
+        st |= kDeleted | (p.status & kTrash);
         atomicAdd(&s_deleted, 1);
       } else {
-        st |= p.status & kDeleted;
+        st |= p.status & kKeepBits;
       }
       p.status = st;
     }
@@ -366,7 +347,7 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
     const int pt = N[r].point;
     if (pt >= 0) {
       N[r].point = -1;
-      P[pt].status = (P[pt].status & kDeleted) | kNotFound;
+      P[pt].status = (P[pt].status & kKeepBits) | kNotFound;
     }
   }
   __syncthreads();
@@ -382,7 +363,10 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
   }
   if (kept) atomicAdd(&s_npoints, kept);
   for (int q = tid; q < jb.n_points; q += 256) {
-    const TrackPoint &p = P[q];
+    TrackPoint &p = P[q];
+    // a point the mapper deleted during the previous frame's update dies now: Map::DeletePoint only queues it, the queue is
+    // emptied after the next frame has been tracked (sdvl.cc:127) — this frame still saw it
+    if (p.status & kTrash) p.status = (p.status & ~kTrash) | kDeleted;
     sdvl_track_point_stat s;
     s.score = p.score; s.n_failed = p.n_failed; s.last_frame = p.last_frame; s.status = p.status;
     h_stats[static_cast<size_t>(j) * np + q] = s;
@@ -540,6 +524,12 @@ int sdvl_track_create(sdvl_ctx *ctx, int n, int max_points, int max_features, in
   s->n_feat[1].assign(n, 0);
   *out = s;
   return SDVL_OK;
+}
+
+TrackPoint *sdvl_track_points_device(sdvl_track_set *set, int *max_points, int *n_trackers) {
+  if (max_points) *max_points = set->np;
+  if (n_trackers) *n_trackers = set->n;
+  return set->d_points;
 }
 
 int sdvl_track_destroy(sdvl_ctx *ctx, sdvl_track_set *s) {

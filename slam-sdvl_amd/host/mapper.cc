@@ -293,7 +293,27 @@ bool MapperMap::BeginUpdate() {
 
 // Map::UpdateCandidates, map.cc:402-498, one pass = the `pass_`-th occurrence of every point in the list.  Points do not
 // interact, so processing the list occurrence by occurrence leaves every point in the state the sequential loop does.
-bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs) {
+static int g_device_filter = -1;  // -1: not decided yet (environment)
+void MapperMap::SetDeviceFilter(bool on) { g_device_filter = on ? 1 : 0; }
+bool MapperMap::DeviceFilter() {
+  if (g_device_filter < 0) {
+    const char *e = std::getenv("SDVL_HOST_DEPTH_FILTER");
+    g_device_filter = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_device_filter != 0;
+}
+
+sdvl_depth_params MapperMap::FilterParams() const {
+  sdvl_depth_params fp;
+  fp.px_error_angle = std::atan(1.0 / (2.0 * camera_->GetFx())) * 2.0;  // Camera::GetPixelErrorAngle, camera.h:104-107
+  fp.min_depth = Config::MapScale() * Config::ScaleMinDist();
+  fp.scale_min_dist = Config::ScaleMinDist();
+  fp.max_failed = Config::MaxFailed();
+  fp.pad_ = 0;
+  return fp;
+}
+
+bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs, vector<sdvl_depth_state> *states) {
   cand_work_.clear();
   if (!cur_) return false;
   req_base_ = static_cast<int>(reqs->size());
@@ -320,6 +340,11 @@ bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs) {
           reqs->emplace_back();
           FillRequestFromFeature(&reqs->back(), cur_.get(), feature, f0, point->GetInverseDepth(), point->GetStd(), false, Vector2d(0, 0));
           w.req = static_cast<int>(reqs->size()) - 1 - req_base_;
+          if (states) {
+            states->emplace_back();
+            point->GetFilterState(&states->back());
+            states->back().depth_mean = depth_mean_;
+          }
         }
       }
     }
@@ -328,9 +353,10 @@ bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs) {
   return any;
 }
 
-void MapperMap::ApplyCandidates(const sdvl_search_res *res_all) {
+void MapperMap::ApplyCandidates(const sdvl_search_res *res_all, const sdvl_depth_out *fout_all) {
   if (!cur_) return;
   const sdvl_search_res *res = res_all + req_base_;
+  const sdvl_depth_out *fout = fout_all ? fout_all + req_base_ : nullptr;
   const double px_error_angle = std::atan(1.0 / (2.0 * camera_->GetFx())) * 2.0;  // Camera::GetPixelErrorAngle, camera.h:104-107
   const int min_kf_id = last_kf_->GetKeyframeID() - 2 * Config::MaxSearchKeyframes();
   vector<char> erase(candidates_.size(), 0);
@@ -353,6 +379,18 @@ void MapperMap::ApplyCandidates(const sdvl_search_res *res_all) {
     Feature *feature = point->GetInitFeatureRaw();
     Frame *f0 = feature->GetFrameRaw();
     const sdvl_search_res &r = res[w.req];
+    if (fout) {  // the loop body ran on the device (depth_filter_kernel): book what it decided
+      const sdvl_depth_out &o = fout[w.req];
+      point->ApplyFilterOut(o);
+      if (o.outcome & SDVL_DEPTH_DELETED) {
+        if (point->TrackRow() >= 0) point->SetDeviceTrashed();  // its table row carries the deletion already
+        DeletePoint(point);
+      } else if ((o.outcome & 0xFF) == SDVL_DEPTH_CONVERGED) {
+        erase[w.index] = 1;
+        stats_.converged++;
+      }
+      continue;
+    }
     if (!r.found) {
       if (point->Unpromote()) DeletePoint(point);
       continue;
@@ -675,12 +713,25 @@ void MapperMap::UpdateMap() {
   Device *dev = Device::Current();
   vector<sdvl_search_req> reqs;
   vector<sdvl_search_res> res;
+  vector<sdvl_depth_state> states;
+  vector<sdvl_depth_out> fout;
+  const bool on_device = DeviceFilter();
+  const sdvl_depth_params fp = FilterParams();
   for (;;) {
     reqs.clear();
-    if (!EmitCandidates(&reqs)) break;
+    states.clear();
+    if (!EmitCandidates(&reqs, on_device ? &states : nullptr)) break;
     res.clear();
-    Matcher::SearchPoints(dev, reqs, *camera_, &res);
-    ApplyCandidates(res.data());
+    if (on_device) {
+      // no table patching from here: in threaded mode this runs on the mapper's own context, concurrently with the tracker's
+      for (sdvl_depth_state &st : states) st.track_row = -1;
+      Matcher::SearchPointsFilter(dev, reqs, states, *camera_, fp, nullptr, &res, &fout);
+      if (fout.empty()) fout.resize(1);
+      ApplyCandidates(res.data(), fout.data());
+    } else {
+      Matcher::SearchPoints(dev, reqs, *camera_, &res);
+      ApplyCandidates(res.data());
+    }
   }
   if (IsKeyframeUpdate()) {
     CheckConnections();

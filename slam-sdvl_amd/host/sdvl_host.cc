@@ -452,6 +452,32 @@ void Point::InitFixed(const shared_ptr<Feature> &f, double depth, double sigma2,
   p3d_ = p3d;
 }
 
+void Point::GetFilterState(sdvl_depth_state *st) const {
+  st->rho = rho_; st->sigma2 = sigma2_; st->a = a_; st->b = b_; st->z_range = z_range_;
+  st->position[0] = p3d_(0); st->position[1] = p3d_(1); st->position[2] = p3d_(2);
+  st->fixed = fixed_ ? 1 : 0;
+  st->n_failed = n_failed_;
+  st->track_row = track_row_;
+  st->pad_ = 0;
+}
+
+// what Map::UpdateCandidates' loop body (map.cc:454-497) left of the point, computed by depth_filter_kernel
+void Point::ApplyFilterOut(const sdvl_depth_out &o) {
+  const int what = o.outcome & 0xFF;
+  if (what == SDVL_DEPTH_NOT_FOUND) {  // Unpromote
+    n_failed_ = o.n_failed;
+    b_ = o.b;
+  } else if (what == SDVL_DEPTH_UPDATED || what == SDVL_DEPTH_CONVERGED) {  // Update (+ HasConverged)
+    rho_ = o.rho; sigma2_ = o.sigma2; a_ = o.a; b_ = o.b;
+    cos_alpha_ = o.cos_alpha; last_distance_ = o.last_distance;
+    n_failed_ = 0;
+    if (what == SDVL_DEPTH_CONVERGED && !fixed_) {
+      p3d_ = Vector3d(o.position[0], o.position[1], o.position[2]);
+      fixed_ = true;
+    }
+  }
+}
+
 // point.cc:128-142
 Vector3d Point::GetPosition() const {
   if (fixed_) return p3d_;
@@ -931,6 +957,19 @@ void Matcher::SearchPoints(Device *dev, const vector<sdvl_search_req> &reqs, con
   dev->Check(sdvl_search_points(dev->ctx(), static_cast<int>(reqs.size()), reqs.data(), &c, &sp, res->data()), "sdvl_search_points");
 }
 
+void Matcher::SearchPointsFilter(Device *dev, const vector<sdvl_search_req> &reqs, const vector<sdvl_depth_state> &states, const Camera &cam,
+                                 const sdvl_depth_params &fp, sdvl_track_set *set, vector<sdvl_search_res> *res, vector<sdvl_depth_out> *fout) {
+  res->resize(reqs.size());
+  fout->resize(reqs.size());
+  if (reqs.empty()) return;
+  if (states.size() != reqs.size()) throw std::runtime_error("SearchPointsFilter: one filter state per request");
+  const sdvl_camera c = cam.abi();
+  const sdvl_search_params sp = SearchParams();
+  dev->Check(sdvl_search_points_filter(dev->ctx(), static_cast<int>(reqs.size()), reqs.data(), &c, &sp, states.data(), &fp, set, res->data(),
+                                       fout->data()),
+             "sdvl_search_points_filter");
+}
+
 // matcher.cc:45-121
 bool Matcher::SearchPoint(const shared_ptr<Frame> &frame, const shared_ptr<Feature> &feature, double idepth, double idepth_std, bool fixed,
                           Vector2d *px, int *flevel) {
@@ -968,6 +1007,7 @@ void Map::AddKeyframe(const shared_ptr<Frame> &frame, bool) {
 // map.cc:207-259 (points)
 void Map::EmptyTrash() {
   for (auto &p : points_trash_) {
+    if (!p->ToDelete() && p->TrackRow() >= 0 && !p->DeviceTrashed()) tables_dirty_ = true;
     std::list<shared_ptr<Feature>> &features = p->GetFeatures();
     for (auto it = features.begin(); it != features.end(); it++) (*it)->SetPoint(nullptr);
     features.clear();
@@ -1767,7 +1807,9 @@ static Pool *g_pool_of(void *&slot, int threads) {
   return static_cast<Pool *>(slot);
 }
 
-SDVLBatch::SDVLBatch(Device *dev, const vector<SDVL *> &trackers, int host_threads) : dev_(dev), trk_(trackers), threads_(host_threads) {}
+SDVLBatch::SDVLBatch(Device *dev, const vector<SDVL *> &trackers, int host_threads) : dev_(dev), trk_(trackers), threads_(host_threads) {
+  for (size_t i = 0; i < trk_.size(); i++) trk_[i]->track_.slot = static_cast<int>(i);
+}
 SDVLBatch::~SDVLBatch() {
   if (track_) {
     Device::SetCurrent(dev_);
@@ -1839,6 +1881,9 @@ bool SDVLBatch::BuildTable(SDVL &t) {
   t.track_.up_register.clear();
   vector<shared_ptr<Feature>> &features = t.last_frame_->GetFeatures();
   if (static_cast<int>(features.size()) > track_cap_) return false;
+  if (t.track_.points)
+    for (const shared_ptr<Point> &old : *t.track_.points) old->SetTrackRow(-1);
+  const int row_base = t.track_.slot * track_cap_;
   auto table = std::make_shared<Frame::PointTable>();
   table->reserve(features.size());
   // a point may sit behind several features of a keyframe: ProjectPoints takes the first and skips the rest
@@ -1870,6 +1915,7 @@ bool SDVLBatch::BuildTable(SDVL &t) {
         hash[h] = Slot{pt, idx};
         f.point = idx;
         table->push_back(ft->GetPoint());
+        pt->SetTrackRow(row_base + idx);
         points->emplace_back();
         sdvl_track_point &tp = points->back();
         const Vector3d P = pt->GetPosition();
@@ -2530,9 +2576,12 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
   clk.reset(new StageClock(ST_MAPPER));
   {
     vector<MapperMap *> mm;
-    for (int i = 0; i < B; i++) {
-      MapperMap *m = dynamic_cast<MapperMap *>(trk_[i]->map_);
-      if (m && !m->IsThreaded() && m->BeginUpdate()) mm.push_back(m);  // a started mapper thread does its own UpdateMap
+    {
+      StageClock begin_clk(ST_MAP_BEGIN);
+      for (int i = 0; i < B; i++) {
+        MapperMap *m = dynamic_cast<MapperMap *>(trk_[i]->map_);
+        if (m && !m->IsThreaded() && m->BeginUpdate()) mm.push_back(m);  // a started mapper thread does its own UpdateMap
+      }
     }
     const int M = static_cast<int>(mm.size());
     if (M > 0) {
@@ -2541,27 +2590,51 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
       vector<sdvl_search_req> reqs;
       vector<sdvl_search_res> res;
       vector<size_t> begin(M + 1, 0);
-      auto launch = [&]() {  // concatenate, search, leave the offsets in `begin`
+      // UpdateCandidates with the depth filter on the device: one filter state per request, outcomes beside the search results;
+      // the rows of the points the trackers follow are patched in the same submission (same context, same stream)
+      const bool dev_filter = MapperMap::DeviceFilter();
+      vector<vector<sdvl_depth_state>> per_st(M);
+      vector<sdvl_depth_state> states;
+      vector<sdvl_depth_out> fout;
+      const sdvl_depth_params fparams = mm[0]->FilterParams();
+      auto launch = [&](bool filter = false) {  // concatenate, search, leave the offsets in `begin`
         reqs.clear();
+        states.clear();
         for (int k = 0; k < M; k++) {
           begin[k] = reqs.size();
           reqs.insert(reqs.end(), per[k].begin(), per[k].end());
           per[k].clear();
+          if (filter) {
+            states.insert(states.end(), per_st[k].begin(), per_st[k].end());
+            per_st[k].clear();
+          }
         }
         begin[M] = reqs.size();
         res.clear();
-        if (!reqs.empty()) Matcher::SearchPoints(dev_, reqs, cam, &res);
+        fout.clear();
+        if (!reqs.empty()) {
+          if (filter) Matcher::SearchPointsFilter(dev_, reqs, states, cam, fparams, track_, &res, &fout);
+          else Matcher::SearchPoints(dev_, reqs, cam, &res);
+        }
         if (res.empty()) res.resize(1);
+        if (fout.empty()) fout.resize(1);
       };
       std::unique_ptr<StageClock> sub(new StageClock(ST_MAP_CANDIDATES));
       for (;;) {  // UpdateCandidates, one occurrence pass at a time
         vector<char> more(M, 0);
-        ParallelFor(M, [&](int k) { more[k] = mm[k]->EmitCandidates(&per[k]) ? 1 : 0; });
+        {
+          StageClock c(ST_MAP_EMIT);
+          ParallelFor(M, [&](int k) { more[k] = mm[k]->EmitCandidates(&per[k], dev_filter ? &per_st[k] : nullptr) ? 1 : 0; });
+        }
         bool any = false;
         for (int k = 0; k < M; k++) any = any || more[k];
         if (!any) break;
-        launch();
-        ParallelFor(M, [&](int k) { if (more[k]) mm[k]->ApplyCandidates(res.data() + begin[k]); });
+        {
+          StageClock c(ST_MAP_SEARCH);
+          launch(dev_filter);
+        }
+        StageClock c(ST_MAP_APPLY);
+        ParallelFor(M, [&](int k) { if (more[k]) mm[k]->ApplyCandidates(res.data() + begin[k], dev_filter ? fout.data() + begin[k] : nullptr); });
       }
       vector<int> kf_idx;
       for (int k = 0; k < M; k++)

@@ -330,6 +330,15 @@ class Point {
     if (n_failed == n_failed_ + 1) b_++;
     n_successful_ = n_successful; n_failed_ = n_failed; last_frame_ = last_frame; status_ = status;
   }
+  // the depth filter's state as the device kernel takes and returns it (sdvl_search_points_filter)
+  void GetFilterState(sdvl_depth_state *st) const;
+  void ApplyFilterOut(const sdvl_depth_out &o);
+  // row of the point in the device-resident tracking tables (tracker * capacity + index), -1: none
+  int TrackRow() const { return track_row_; }
+  void SetTrackRow(int r) { track_row_ = r; }
+  // the device knows the point is deleted (or will be after the next step): nothing to tell it when the trash is emptied
+  bool DeviceTrashed() const { return dev_trashed_; }
+  void SetDeviceTrashed() { dev_trashed_ = true; }
   // depth filter (point.cc:64-100,164-217): used by the mapper (MapperMap), not by the tracking path
   void Update(const std::shared_ptr<Frame> &frame, double depth, double px_error_angle);
   bool HasConverged();
@@ -350,6 +359,8 @@ class Point {
   std::shared_ptr<Feature> feature_;
   double sigma2_, a_, b_, z_range_;
   double cos_alpha_ = 1.0, last_distance_ = 1.0;
+  int track_row_ = -1;
+  bool dev_trashed_ = false;
   std::list<std::shared_ptr<Feature>> features_;
 };
 
@@ -534,6 +545,11 @@ class Matcher {
   static bool MakeRequest(const std::shared_ptr<Frame> &frame, const std::shared_ptr<Feature> &feature, double idepth,
                           double idepth_std, bool fixed, const Vector2d &px, sdvl_search_req *req);
   static void SearchPoints(Device *dev, const std::vector<sdvl_search_req> &reqs, const Camera &cam, std::vector<sdvl_search_res> *res);
+  // the same with the mapper's depth filter behind the search (Map::UpdateCandidates); `set` (may be null) = the tracking tables
+  // whose rows the filter patches
+  static void SearchPointsFilter(Device *dev, const std::vector<sdvl_search_req> &reqs, const std::vector<sdvl_depth_state> &states,
+                                 const Camera &cam, const sdvl_depth_params &fp, sdvl_track_set *set, std::vector<sdvl_search_res> *res,
+                                 std::vector<sdvl_depth_out> *fout);
 
  private:
   int patch_size_;
@@ -564,6 +580,7 @@ class Map {
  protected:
   std::vector<std::shared_ptr<Frame>> keyframes_;
   std::vector<std::shared_ptr<Point>> points_trash_;
+  bool tables_dirty_ = false;
   std::shared_ptr<Frame> last_kf_;
   int last_matches_ = 0;
   std::mutex mutex_map_;
@@ -602,8 +619,14 @@ class MapperMap : public PlaneMap {
 
   // ---- Map::UpdateMap (map.cc:75-141) cut into phases; a driver calls them in this order for all its trackers
   bool BeginUpdate();                                            // pops the next frame; false = nothing to do
-  bool EmitCandidates(std::vector<sdvl_search_req> *reqs);       // UpdateCandidates, one pass; false = no more passes
-  void ApplyCandidates(const sdvl_search_res *res);
+  // UpdateCandidates, one pass; false = no more passes.  states / fout: the depth filter runs on the device behind the search
+  // (sdvl_search_points_filter) and Apply only books its outcomes; without them Apply does the arithmetic itself
+  bool EmitCandidates(std::vector<sdvl_search_req> *reqs, std::vector<sdvl_depth_state> *states = nullptr);
+  void ApplyCandidates(const sdvl_search_res *res, const sdvl_depth_out *fout = nullptr);
+  static bool DeviceFilter();             // env SDVL_HOST_DEPTH_FILTER=1 turns it off
+  static void SetDeviceFilter(bool on);
+  sdvl_depth_params FilterParams() const;
+
   bool IsKeyframeUpdate() const { return cur_ && cur_->IsKeyframe(); }
   void CheckConnections();                                       // map.cc:500-558
   void EmitConnectionsPoints(std::vector<sdvl_search_req> *reqs);  // AddConnectionsPoints, map.cc:560-617
@@ -756,7 +779,7 @@ class FeatureAlign {
 
 // wall-clock per stage of SDVLBatch::HandleFrames, accumulated (seconds); index = StageId
 enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_POSE, ST_MAPPING,
-               ST_EPILOGUE, ST_MAPPER, ST_TOTAL, ST_MAP_CANDIDATES, ST_MAP_CONNECTIONS, ST_MAP_INIT, ST_MAP_FINISH, ST_COUNT };
+               ST_EPILOGUE, ST_MAPPER, ST_TOTAL, ST_MAP_CANDIDATES, ST_MAP_CONNECTIONS, ST_MAP_INIT, ST_MAP_FINISH, ST_MAP_BEGIN, ST_MAP_EMIT, ST_MAP_SEARCH, ST_MAP_APPLY, ST_COUNT };
 struct StageTimes {
   double t[ST_COUNT] = {0};
   long steps = 0;
@@ -826,6 +849,7 @@ class SDVL {
   struct TrackState {
     bool valid = false;
     int feat_buf = 0;
+    int slot = 0;                                     // the tracker's index in its batch = which table of the set is its own
     std::shared_ptr<Frame::PointTable> points;        // table index -> Point
     std::vector<sdvl_track_point_stat> stats;         // newest counters of `points`; the Point objects lag behind
     bool stats_dirty = false;

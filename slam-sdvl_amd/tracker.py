@@ -142,7 +142,8 @@ class TrackerBatch:
         return self._stats
 
     STAGES = ["upload_pyr", "fast", "select", "corners_orb", "prelude", "image_align", "prepare", "search", "finish", "pose", "mapping",
-              "epilogue", "mapper", "total", "map_candidates", "map_connections", "map_init", "map_finish"]
+              "epilogue", "mapper", "total", "map_candidates", "map_connections", "map_init", "map_finish",
+              "map_begin", "map_emit", "map_search", "map_apply"]
 
     def map_stats(self, i):
         """mapper mode only: candidates, converged, initialized, linked, connected, keyframes of tracker i"""
