@@ -292,6 +292,7 @@ int sdvl_search_run(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sdvl_sea
 struct sdvl_track_set; /* the tracking tables, below */
 typedef struct sdvl_depth_state { /* the Point behind a request (point.h:136-150) */
   double rho, sigma2, a, b, z_range;
+  double cos_alpha, last_distance; /* of the previous update: HasConverged reads them when Update returns early (NaN) */
   double depth_mean;   /* Frame::GetSceneDepth() of the map's current frame (map.cc:92) */
   double position[3];  /* p3d_ of a point that is fixed already (the second list entry of a point that converged in the first
                           pass of this frame, map.cc:381,389: Update and HasConverged still run on it) */
@@ -313,6 +314,8 @@ typedef struct sdvl_depth_params {
 #define SDVL_DEPTH_SKIPPED 1   /* found, but no triangulation / no parallax / too close: the point is left alone */
 #define SDVL_DEPTH_UPDATED 2   /* Point::Update ran */
 #define SDVL_DEPTH_CONVERGED 3 /* ... and Point::HasConverged fixed the point at `position` */
+#define SDVL_DEPTH_FIXED_STALE 4 /* Update returned early (norm_scale is NaN, point.cc:76) and HasConverged fixed the point at
+                                    the position of its unchanged estimate */
 #define SDVL_DEPTH_DELETED 0x100 /* | NOT_FOUND: n_failed crossed max_failed (Map::DeletePoint) */
 typedef struct sdvl_depth_out {
   int32_t outcome;
@@ -491,6 +494,7 @@ typedef struct sdvl_track_job {
 typedef struct sdvl_track_result {
   double pose[7];         /* frame->GetPose() after OptimizePose */
   double align_error;     /* ImageAlign::GetError() */
+  double scene_depth;     /* Frame::GetSceneDepth() of the new frame (frame.cc:70-92): median camera-frame depth of its points */
   int32_t align_meas, align_iters; /* ComputePose return value; ComputeResiduals evaluations */
   int32_t n_features;     /* features of last_frame the alignment ran on */
   int32_t n_requests;     /* SearchPoint evaluations (all candidates, speculatively) */

@@ -303,6 +303,50 @@ double sdvl_ref_pdf_normal(double mean, double sd, double x) { return Tracker::P
 double sdvl_ref_compute_tau(const double *pose7, const double *v3, double depth, double px_error_angle) {
   return Tracker::ComputeTau(ToSE3(pose7), Vec3{v3[0], v3[1], v3[2]}, depth, px_error_angle);
 }
+int sdvl_ref_depth_filter(void *t, const double *cur_pose7, const double *ref_pose7, const double *bearing3, int found, const double *px2,
+                          double depth_mean, double *st) {
+  Tracker *tr = static_cast<Tracker *>(t);
+  // the objects the loop body touches: the candidate, its first observation on the reference keyframe, the current frame
+  RFrame ref_frame, cur_frame;
+  ref_frame.pose = ToSE3(ref_pose7);
+  cur_frame.pose = ToSE3(cur_pose7);
+  auto feature = std::make_shared<RFeature>();
+  feature->frame = &ref_frame;
+  feature->v = Vec3{bearing3[0], bearing3[1], bearing3[2]};
+  RPoint point;
+  point.init_feature = feature;
+  point.rho = st[0]; point.sigma2 = st[1]; point.a = st[2]; point.b = st[3]; point.z_range = st[4];
+  point.cos_alpha = st[5]; point.last_distance = st[6];
+  point.p3d = Vec3{st[7], st[8], st[9]};
+  point.fixed = st[10] != 0.0;
+  point.n_failed = static_cast<int>(st[11]);
+  int outcome = 1;
+  const double px_error_angle = std::atan(1.0 / (2.0 * tr->cam.fx)) * 2.0;
+  if (!found) {  // map.cc:454-458
+    outcome = tr->PointUnpromote(&point) ? 0x100 : 0;
+  } else {       // map.cc:459-497, statement for statement as Tracker::UpdateCandidates has it
+    const SE3 pose = cur_frame.pose * feature->frame->pose.Inverse();
+    const Vec3 v3d = tr->cam.Unproject(Vec2{px2[0], px2[1]});
+    double depth = 0.0;
+    bool go = Tracker::DepthFromTriangulation(pose, feature->v, v3d, &depth);
+    if (go) {
+      const Vec3 p3d = feature->frame->pose.Inverse() * (depth * feature->v);
+      const double cos_alpha = Tracker::Parallax(feature->frame->WorldPosition(), cur_frame.WorldPosition(), p3d);
+      if (cos_alpha >= 0.999999) go = false;
+    }
+    if (go && (depth < tr->map_scale * tr->scale_min_dist || depth < depth_mean * tr->scale_min_dist)) go = false;
+    if (go) {
+      tr->PointUpdate(&point, cur_frame, depth, px_error_angle);
+      outcome = Tracker::PointHasConverged(&point) ? 3 : 2;
+    }
+  }
+  st[0] = point.rho; st[1] = point.sigma2; st[2] = point.a; st[3] = point.b; st[4] = point.z_range;
+  st[5] = point.cos_alpha; st[6] = point.last_distance;
+  st[7] = point.p3d.x; st[8] = point.p3d.y; st[9] = point.p3d.z;
+  st[10] = point.fixed ? 1.0 : 0.0;
+  st[11] = point.n_failed;
+  return outcome;
+}
 int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_ref_frame_stats *out) {
   Tracker *tr = static_cast<Tracker *>(t);
   const FrameStats s = tr->HandleFrame(img, stride);

@@ -91,6 +91,11 @@ int sdvl_ref_tracker_mapper_points(void *t, int cap, double *out_xyzc);
 int sdvl_ref_triangulate(const double *pose7, const double *v_ref3, const double *v_cur3, double *depth);
 double sdvl_ref_pdf_normal(double mean, double sd, double x);
 double sdvl_ref_compute_tau(const double *pose7, const double *v3, double depth, double px_error_angle);
+/* the body of Map::UpdateCandidates' loop behind SearchPoint (map.cc:454-497) for ONE candidate, with the tracker's camera and
+ * configuration: state = {rho, sigma2, a, b, z_range, cos_alpha, last_distance, p3d[3], fixed, n_failed} in / out (12 doubles);
+ * returns 0 not found (Unpromote; | 0x100 deleted), 1 skipped, 2 updated, 3 updated and converged */
+int sdvl_ref_depth_filter(void *t, const double *cur_pose7, const double *ref_pose7, const double *bearing3, int found, const double *px2,
+                          double depth_mean, double *state12);
 int sdvl_ref_tracker_handle_frame(void *t, const uint8_t *img, int stride, sdvl_ref_frame_stats *out);
 
 #ifdef __cplusplus

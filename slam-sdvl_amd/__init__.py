@@ -93,6 +93,23 @@ class SearchRes(C.Structure):
                 ("stage", C.c_int32), ("lk_its", C.c_int32), ("slevel", C.c_int32)]
 
 
+class DepthState(C.Structure):
+    """sdvl_depth_state: the depth-filter state of the Point behind a candidate request (point.h:136-150)"""
+    _fields_ = [("rho", C.c_double), ("sigma2", C.c_double), ("a", C.c_double), ("b", C.c_double), ("z_range", C.c_double),
+                ("cos_alpha", C.c_double), ("last_distance", C.c_double), ("depth_mean", C.c_double), ("position", C.c_double * 3),
+                ("fixed", C.c_int32), ("n_failed", C.c_int32), ("track_row", C.c_int32), ("pad_", C.c_int32)]
+
+
+class DepthParams(C.Structure):
+    _fields_ = [("px_error_angle", C.c_double), ("min_depth", C.c_double), ("scale_min_dist", C.c_double),
+                ("max_failed", C.c_int32), ("pad_", C.c_int32)]
+
+
+class DepthOut(C.Structure):
+    _fields_ = [("outcome", C.c_int32), ("n_failed", C.c_int32), ("rho", C.c_double), ("sigma2", C.c_double), ("a", C.c_double),
+                ("b", C.c_double), ("cos_alpha", C.c_double), ("last_distance", C.c_double), ("position", C.c_double * 3)]
+
+
 class SynthView(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
                 ("R", C.c_double * 9), ("t", C.c_double * 3), ("plane", C.c_double * 4),
@@ -386,6 +403,14 @@ class Context:
         res = (SearchRes * n)()
         self._check(self.lib.sdvl_search_points(self.h, n, reqs, C.byref(cam), C.byref(sp), res))
         return res
+
+    def search_points_filter(self, reqs, cam, sp, states, fparams):
+        """sdvl_search_points_filter without tracking tables: (search results, depth-filter outcomes)"""
+        n = len(reqs)
+        res = (SearchRes * n)()
+        fout = (DepthOut * n)()
+        self._check(self.lib.sdvl_search_points_filter(self.h, n, reqs, C.byref(cam), C.byref(sp), states, C.byref(fparams), None, res, fout))
+        return res, fout
 
     def search_chain(self, reqs, cam, sp, trackers, req_points, fx, max_ransac_points=5, max_ransac_its=100, max_optim_pose_its=10,
                      inlier_error_threshold=2.0):

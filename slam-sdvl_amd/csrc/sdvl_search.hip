@@ -752,7 +752,22 @@ __global__ __launch_bounds__(128) void depth_filter_kernel(const SearchReqDev *_
       const double tau2 = tau_inverse * tau_inverse;
       const double x = 1. / depth;
       const double norm_scale = sqrt(st.sigma2 + tau2);
-      if (!(norm_scale != norm_scale)) {  // std::isnan(norm_scale) -> return: the point keeps its state
+      if (norm_scale != norm_scale) {
+        // std::isnan(norm_scale) -> Update returns with the point untouched (point.cc:76); HasConverged still runs
+        const double std_d = sqrt(st.sigma2) / (st.rho * st.rho);
+        const double l = 4 * std_d * st.cos_alpha / st.last_distance;
+        if (st.fixed || l < 0.1) {
+          const double sc = 1.0 / st.rho;
+          const V3 pos = st.fixed ? V3{st.position[0], st.position[1], st.position[2]} : se3_apply(ref_world, {sc * fv.x, sc * fv.y, sc * fv.z});
+          o.position[0] = pos.x; o.position[1] = pos.y; o.position[2] = pos.z;
+          o.cos_alpha = st.cos_alpha; o.last_distance = st.last_distance;
+          o.outcome = SDVL_DEPTH_FIXED_STALE;
+          if (row) {
+            row->P[0] = pos.x; row->P[1] = pos.y; row->P[2] = pos.z;
+            row->fixed = 1;
+          }
+        }
+      } else {
         const double s2 = 1. / (1. / st.sigma2 + 1. / tau2);
         const double m = s2 * (st.rho / st.sigma2 + x / tau2);
         double C1 = st.a / (st.a + st.b) * pdf_normal(st.rho, norm_scale, x);

@@ -263,8 +263,10 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   uint16_t *s_before = reinterpret_cast<uint16_t *>(s_dyn);  // [stride + 1] matches selected among the candidates before k
   uint8_t *s_found = reinterpret_cast<uint8_t *>(s_before + stride + 1);  // [stride]
+  double *s_depth = reinterpret_cast<double *>(s_dyn + (static_cast<size_t>(stride + 1) * 2 + stride + 64 + 7) / 8 * 8);  // [mm]
   __shared__ int s_wave[4];
   __shared__ int s_attempts, s_deleted, s_lk, s_npoints;
+  __shared__ double s_median;
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const TrackJobDev &jb = jobs[j];
   const ChainFrameDev &fr = chain[j];
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
   }
   __syncthreads();
   int kept = 0;
+  const Rigid final_pose = se3_from7(pr.pose);
   for (int r = tid; r < matches; r += 256) {
     const TrackFeat f = N[r];
     sdvl_track_feature_out o;
@@ -360,8 +363,30 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
     o.point = f.point;
     h_feats[static_cast<size_t>(j) * nf + r] = o;
     kept += f.point >= 0 ? 1 : 0;
+    // Frame::GetSceneDepth, frame.cc:70-92: GetRelativePos(point position)(2) of every feature that has a point
+    double z = __builtin_nan("");  // no point: compares false with everything below
+    if (f.point >= 0) z = se3_apply(final_pose, {P[f.point].P[0], P[f.point].P[1], P[f.point].P[2]}).z;
+    s_depth[r] = z;
   }
   if (kept) atomicAdd(&s_npoints, kept);
+  if (tid == 0) s_median = 0.0;
+  __syncthreads();
+  {
+    // GetMedianVector (extra/utils.cc:215-220): nth_element at floor(n / 2) = the value of sorted rank n / 2; a value v sits
+    // there when fewer than or exactly n / 2 values are smaller and more than n / 2 are smaller or equal
+    const int n_pts = s_npoints, mid = n_pts / 2;
+    for (int r = tid; r < matches; r += 256) {
+      const double v = s_depth[r];
+      if (v != v) continue;
+      int less = 0, leq = 0;
+      for (int q = 0; q < matches; q++) {
+        const double u = s_depth[q];
+        less += u < v ? 1 : 0;
+        leq += u <= v ? 1 : 0;
+      }
+      if (less <= mid && mid < leq) s_median = v;  // every writer holds the same value
+    }
+  }
   for (int q = tid; q < jb.n_points; q += 256) {
     TrackPoint &p = P[q];
     // a point the mapper deleted during the previous frame's update dies now: Map::DeletePoint only queues it, the queue is
@@ -377,6 +402,7 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
 #pragma unroll
     for (int q = 0; q < 7; q++) out.pose[q] = pr.pose[q];
     out.align_error = ares[j].error;
+    out.scene_depth = s_median;
     out.align_meas = ares[j].n_meas;
     out.align_iters = ares[j].iters_run;
     out.n_features = jb.n_feat;
@@ -739,7 +765,8 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
                                 s->d_lists);
   if (rc) return rc;
   {
-    const size_t lds = static_cast<size_t>(stride + 1) * 2 + stride + 64;
+    // s_before | s_found | (8-byte aligned) depths of the new frame's points, at most mm of them
+    const size_t lds = (static_cast<size_t>(stride + 1) * 2 + stride + 64 + 7) / 8 * 8 + static_cast<size_t>(s->mm) * 8;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "track_commit", &ev_a, &ev_b);
     hipExtLaunchKernelGGL(track_commit_kernel, dim3(n_jobs), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const TrackJobDev *>(s->d_jobs),

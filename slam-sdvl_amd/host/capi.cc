@@ -168,6 +168,9 @@ int sdvlh_camera_undistort(void *device, int w, int h, const double *cam4, const
 // device-resident tracking tables on (default) / off for the batches stepping from now on; process-wide
 void sdvlh_set_track_tables(int on) { SDVLBatch::SetTrackTables(on != 0); }
 int sdvlh_track_tables() { return SDVLBatch::TrackTables() ? 1 : 0; }
+// the mapper's depth filter on the device (default) or on the host, for the mapper updates from now on; process-wide
+void sdvlh_set_device_filter(int on) { MapperMap::SetDeviceFilter(on != 0); }
+int sdvlh_device_filter() { return MapperMap::DeviceFilter() ? 1 : 0; }
 
 // test hook: a digest of the map state of tracker i after SyncHostState — the points reachable from its keyframes' features
 // (each once): count, sum of Score(), sum of failure counts, deleted ones, sum of inverse depths, sum of GetStd()

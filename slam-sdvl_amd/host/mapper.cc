@@ -156,6 +156,7 @@ bool Point::SeenFrom(const shared_ptr<Frame> &frame) const {
 // ----------------------------------------------------------------------------------------------------- Frame (map side)
 // frame.cc:70-92
 double Frame::GetSceneDepth() {
+  if (scene_depth_hint_valid_) return scene_depth_hint_;
   vector<double> depth_vec;
   if (flat_) {  // features still flat records of the tracking tables: same points in the same order, no objects needed
     for (const sdvl_track_feature_out &f : flat_->feats)
@@ -284,10 +285,10 @@ bool MapperMap::BeginUpdate() {
   depth_mean_ = cur_->GetSceneDepth();
   pass_ = 0;
   occurrence_.assign(candidates_.size(), 0);
-  {  // the reference pushes every new candidate twice (map.cc:381,389): entry k is the occurrence_[k]-th of its point
-    std::map<Point *, int> seen;
-    for (size_t k = 0; k < candidates_.size(); k++) occurrence_[k] = seen[candidates_[k].get()]++;
-  }
+  // the reference pushes every new candidate twice (map.cc:381,389): entry k is the occurrence_[k]-th of its point.  The two
+  // entries are pushed back to back and erasures keep the order, so the entries of a point stay neighbours.
+  for (size_t k = 1; k < candidates_.size(); k++)
+    if (candidates_[k] == candidates_[k - 1]) occurrence_[k] = occurrence_[k - 1] + 1;
   return true;
 }
 
@@ -385,7 +386,7 @@ void MapperMap::ApplyCandidates(const sdvl_search_res *res_all, const sdvl_depth
       if (o.outcome & SDVL_DEPTH_DELETED) {
         if (point->TrackRow() >= 0) point->SetDeviceTrashed();  // its table row carries the deletion already
         DeletePoint(point);
-      } else if ((o.outcome & 0xFF) == SDVL_DEPTH_CONVERGED) {
+      } else if ((o.outcome & 0xFF) == SDVL_DEPTH_CONVERGED || (o.outcome & 0xFF) == SDVL_DEPTH_FIXED_STALE) {
         erase[w.index] = 1;
         stats_.converged++;
       }

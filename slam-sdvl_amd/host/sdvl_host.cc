@@ -454,6 +454,7 @@ void Point::InitFixed(const shared_ptr<Feature> &f, double depth, double sigma2,
 
 void Point::GetFilterState(sdvl_depth_state *st) const {
   st->rho = rho_; st->sigma2 = sigma2_; st->a = a_; st->b = b_; st->z_range = z_range_;
+  st->cos_alpha = cos_alpha_; st->last_distance = last_distance_;
   st->position[0] = p3d_(0); st->position[1] = p3d_(1); st->position[2] = p3d_(2);
   st->fixed = fixed_ ? 1 : 0;
   st->n_failed = n_failed_;
@@ -475,6 +476,9 @@ void Point::ApplyFilterOut(const sdvl_depth_out &o) {
       p3d_ = Vector3d(o.position[0], o.position[1], o.position[2]);
       fixed_ = true;
     }
+  } else if (what == SDVL_DEPTH_FIXED_STALE && !fixed_) {  // Update returned early, HasConverged fixed the old estimate
+    p3d_ = Vector3d(o.position[0], o.position[1], o.position[2]);
+    fixed_ = true;
   }
 }
 
@@ -2107,6 +2111,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
       t.current_frame_->SetPose(SE3::FromArray(r.pose));
       t.current_frame_->SetRegistered();  // the step wrote (view, final pose) into the registry
       t.current_frame_->SetFlatFeatures(sdvl_track_features(track_, k), r.matches, ts.points);
+      t.current_frame_->SetSceneDepthHint(r.scene_depth);
       const sdvl_track_point_stat *ps = sdvl_track_stats(track_, k);
       ts.stats.assign(ps, ps + ts.points->size());
       ts.stats_dirty = true;
@@ -2119,7 +2124,10 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
       st.outliers = r.n_outliers;
       if (r.n_deleted > 0)  // points that crossed MaxFailed: Map::DeletePoint (feature_align.cc:141-142), emptied in the epilogue
         for (size_t p = 0; p < ts.points->size(); p++)
-          if ((ts.stats[p].status & 0x100) && !(*ts.points)[p]->ToDelete()) t.map_->DeletePoint((*ts.points)[p]);
+          if ((ts.stats[p].status & 0x100) && !(*ts.points)[p]->ToDelete()) {
+            (*ts.points)[p]->SetDeviceTrashed();  // the row carries the deletion: nothing to rebuild when the trash is emptied
+            t.map_->DeletePoint((*ts.points)[p]);
+          }
       {  // GetMotionModel, sdvl.cc:266-276
         const SE3 mov = t.current_frame_->GetPose() * t.last_frame_->GetPose().Inverse();
         const Vector6d vel = SE3::Log(mov);
@@ -2158,6 +2166,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         vector<shared_ptr<Feature>> &features = t.current_frame_->GetFeatures();
         for (auto it = features.begin(); it != features.end(); it++)
           if (Point *p = (*it)->GetPointRaw()) p->AddFeature(*it);
+        t.current_frame_->ClearSceneDepthHint();  // a keyframe's features lose the points EmptyTrash deletes (map.cc:207-259)
         t.current_frame_->SetKeyframe();
         t.map_->AddKeyframe(t.current_frame_);
         t.last_kf_ = t.current_frame_;
@@ -2179,10 +2188,18 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
   EpilogueAndMapper(frames, stats, &kfs, &kf_owner, filter_begun);
   // With the reference's mapper the tracker follows CANDIDATES too (Map::InitCandidates links them to the keyframe at once,
   // map.cc:379-390), and the depth filter rewrites their inverse depth, variance, position, failure count and finally
-  // `fixed` after every frame (point.cc:64-100,164-178): their rows are rebuilt from the objects before the next step.
-  // (The step itself still runs as one submission; what is lost is the saving on the host side.)
-  for (int i = 0; i < B; i++)
-    if (dynamic_cast<MapperMap *>(trk_[i]->map_)) trk_[i]->track_.valid = false;
+  // `fixed` after every frame (point.cc:64-100,164-178).  With the filter on the device (depth_filter_kernel) the rows are
+  // patched where they lie, in the same stream, and the table stays valid; it is rebuilt from the objects when the filter ran
+  // on the host or on another context (threaded mode), and whenever a point with a row died behind the device's back.
+  for (int i = 0; i < B; i++) {
+    SDVL &t = *trk_[i];
+    MapperMap *m = dynamic_cast<MapperMap *>(t.map_);
+    if (m && (m->IsThreaded() || !MapperMap::DeviceFilter())) t.track_.valid = false;
+    if (t.map_->TakeTablesDirty()) t.track_.valid = false;
+    // tracking lost: last_frame stays, but the mapper has had it and trashed it — its features are gone from the host
+    // (MapperMap::EmptyTrash, map.cc:207-259) and the next step must not find them in the table either
+    if (t.last_frame_ && t.last_frame_->FeaturesRemoved()) t.track_.valid = false;
+  }
   return true;
 }
 

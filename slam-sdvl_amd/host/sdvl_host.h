@@ -429,7 +429,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   }
   Vector3d GetWorldPosition() const { return GetWorldPose().GetTranslation(); }
   Vector3d GetRelativePos(const Vector3d &pos) const { return pose_ * pos; }
-  void AddFeature(const std::shared_ptr<Feature> &f) { GetFeatures().push_back(f); }
+  void AddFeature(const std::shared_ptr<Feature> &f) { GetFeatures().push_back(f); scene_depth_hint_valid_ = false; }
   // a Feature on this frame whose storage comes from the frame's arena (same object as make_shared<Feature>(frame, ...))
   std::shared_ptr<Feature> NewFeature(const Vector2d &p, int level) {
     if (!arena_) arena_ = NewArena();
@@ -445,7 +445,8 @@ class Frame : public std::enable_shared_from_this<Frame> {
   int GetNumPoints() const;
   bool Project(const Vector3d &p3D, Vector2d *p2D);
   void CreateCorners(int levels, int nfeatures);
-  void RemoveFeatures() { features_.clear(); DropFlat(); }
+  void RemoveFeatures() { features_.clear(); DropFlat(); features_removed_ = true; scene_depth_hint_valid_ = false; }
+  bool FeaturesRemoved() const { return features_removed_; }  // the mapper emptied the frame (Map::EmptyTrash, map.cc:207-259)
   // mapper-side state and queries (frame.h:71-87,120-136; frame.cc:70-113,181-207)
   void SetKeyframeID(int id) { kf_id_ = id; }
   int GetKeyframeID() const { return kf_id_; }
@@ -454,6 +455,9 @@ class Frame : public std::enable_shared_from_this<Frame> {
   bool ToDelete() const { return delete_; }
   void SetDelete() { delete_ = true; }
   double GetSceneDepth();
+  // the step computed it on the device (sdvl_track_result.scene_depth); valid until the feature list changes
+  void SetSceneDepthHint(double d) { scene_depth_hint_ = d; scene_depth_hint_valid_ = true; }
+  void ClearSceneDepthHint() { scene_depth_hint_valid_ = false; }
   bool IsPointVisible(const Vector3d &p);
   double DistanceTo(const Frame &frame) const;
   double DistanceTo(const Vector3d &p) const;
@@ -507,6 +511,9 @@ class Frame : public std::enable_shared_from_this<Frame> {
   void MaterializeFeatures();
   void DropFlat();
   bool registered_ = false;  // the context's (frame, pose) registry holds this frame with its current pose
+  bool features_removed_ = false;
+  double scene_depth_hint_ = 0.0;
+  bool scene_depth_hint_valid_ = false;
   int search_slot_ = -1;
   uint64_t search_batch_ = 0;
   int kf_id_ = 0;
@@ -573,6 +580,9 @@ class Map {
   virtual void LimitKeyframes(const std::shared_ptr<Frame> &) {}
   virtual void SetRelocalizing(bool) {}
   virtual void EmptyTrash();  // map.cc:207-259
+  // a point with a row in the device-resident tracking tables died without the device having been told (EmptyTrash): the
+  // tracker's table must be rebuilt before the next step
+  bool TakeTablesDirty() { const bool d = tables_dirty_; tables_dirty_ = false; return d; }
   std::vector<std::shared_ptr<Frame>> &GetKeyframes() { return keyframes_; }
   // mapper work for a fresh keyframe (Map::InitCandidates stand-in); called outside the tracking stages
   virtual void InitCandidates(const std::shared_ptr<Frame> &) {}

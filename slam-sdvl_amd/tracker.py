@@ -62,6 +62,11 @@ def set_track_tables(on):
     load_host_library().sdvlh_set_track_tables(int(bool(on)))
 
 
+def set_device_filter(on):
+    """the mapper's depth filter (Point::Update / HasConverged behind the candidate search) on the device (default) / on the host"""
+    load_host_library().sdvlh_set_device_filter(int(bool(on)))
+
+
 def bind_to_gpu_numa_node(gpu=0):
     """Restrict this process (and the threads it creates later) to the CPUs of the NUMA node the GPU hangs off: the host
     objects of the trackers, the pinned staging buffers and the doorbell writes then stay on that socket.  Returns the

@@ -252,6 +252,16 @@ class OracleTracker:
         self.lib.sdvl_ref_tracker_use_mapper(C.c_void_p(self.h_), int(on), int(max_search_keyframes), int(max_keyframes),
                                              C.c_double(map_scale), C.c_double(scale_min_dist))
 
+    def depth_filter(self, cur_pose, ref_pose, bearing, found, px, depth_mean, state12):
+        """the body of Map::UpdateCandidates' loop behind SearchPoint (map.cc:454-497) for one candidate -> (outcome, new state)"""
+        st = np.array(state12, np.float64)
+        cp, rp, bv, pp = (np.ascontiguousarray(a, np.float64) for a in (cur_pose, ref_pose, bearing, px))
+        self.lib.sdvl_ref_depth_filter.restype = C.c_int
+        self.lib.sdvl_ref_depth_filter.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_double, C.c_void_p]
+        rc = self.lib.sdvl_ref_depth_filter(C.c_void_p(self.h_), cp.ctypes.data, rp.ctypes.data, bv.ctypes.data, int(found), pp.ctypes.data,
+                                            float(depth_mean), st.ctypes.data)
+        return rc, st
+
     def map_stats(self):
         out = np.zeros(6, np.int32)
         self.lib.sdvl_ref_tracker_map_stats(C.c_void_p(self.h_), ptr(out, i32p))

@@ -324,6 +324,62 @@ def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur
     f_ref.close(); f_cur.close()
 
 
+@pytest.mark.parametrize("k_cur,noise", [(6, 0.02), (30, 0.05), (60, 0.2)])
+def test_depth_filter_behind_the_search_matches_oracle(ctx, sdvl, orc, synth, k_cur, noise):
+    """sdvl_search_points_filter: the mapper's depth filter (triangulation, parallax, the minimum-depth tests, Point::Update,
+    HasConverged; Unpromote for a miss: map.cc:454-497, point.cc:64-118,164-178) on the device behind the candidate search,
+    against the oracle's statement-level restatement fed with the same search results.  Decisions and counters exact; the
+    filter state within 1e-11 relative (acos / sin / exp are the device library's, not glibc's)."""
+    import math
+    img_ref, img_cur = frames_of(synth, orc, TUM_CAM, 640, 480, [0, k_cur])
+    T_ref, T_cur = trajectory_pose(orc, 0), trajectory_pose(orc, k_cur)
+    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img_ref, img_cur, T_ref, T_cur, TUM_CAM, 300, 17 + k_cur, False, noise, False)
+    n = len(reqs)
+    rng = np.random.default_rng(5)
+    ref = orc.tracker(640, 480, TUM_CAM)
+    ref.use_mapper(True)
+    max_failed = 15
+    states = (sdvl.DepthState * n)()
+    for i, m in enumerate(meta):
+        s = states[i]
+        s.rho, s.sigma2 = m["idepth"], m["istd"] ** 2
+        s.a, s.b = 10.0 + 5.0 * rng.random(), 10.0 + 8.0 * rng.random()
+        s.z_range = math.sqrt(36.0)
+        s.cos_alpha, s.last_distance = 1.0, 1.0
+        s.depth_mean = 2.0 if i % 7 else 40.0          # a scene so deep that the candidate fails the minimum-depth test
+        s.fixed = 1 if i % 11 == 3 else 0
+        for k in range(3):
+            s.position[k] = [0.1 * (i % 5), -0.05 * (i % 3), 2.0][k]
+        s.n_failed = int(rng.integers(0, max_failed + 1))
+        s.track_row = -1
+    fp = sdvl.DepthParams()
+    fp.px_error_angle = math.atan(1.0 / (2.0 * TUM_CAM[0])) * 2.0
+    fp.min_depth, fp.scale_min_dist, fp.max_failed = 1.0 * 0.25, 0.25, max_failed
+    cam = sdvl.Camera(640, 480, *TUM_CAM)
+    res, fout = ctx.search_points_filter(reqs, cam, sdvl.default_search_params(), states, fp)
+    plain = ctx.search_points(reqs, cam, sdvl.default_search_params())
+    seen = {}
+    for i in range(n):
+        r, o, s = res[i], fout[i], states[i]
+        assert (r.found, tuple(r.px)) == (plain[i].found, tuple(plain[i].px))      # the search itself is untouched
+        st0 = [s.rho, s.sigma2, s.a, s.b, s.z_range, s.cos_alpha, s.last_distance, s.position[0], s.position[1], s.position[2], s.fixed, s.n_failed]
+        want, st1 = ref.depth_filter(T_cur, T_ref, meta[i]["bearing"], r.found, r.px[:], s.depth_mean, st0)
+        assert o.outcome == want, (i, o.outcome, want)
+        assert o.n_failed == int(st1[11])
+        seen[want & 0xFF] = seen.get(want & 0xFF, 0) + 1
+        if want & 0x100:
+            seen["deleted"] = seen.get("deleted", 0) + 1
+        got = np.array([o.rho, o.sigma2, o.a, o.b])
+        assert np.all(np.abs(got - st1[:4]) <= 1e-11 * np.abs(st1[:4])), (i, got, st1[:4])
+        if (want & 0xFF) in (2, 3):
+            assert abs(o.cos_alpha - st1[5]) <= 1e-11 and abs(o.last_distance - st1[6]) <= 1e-11 * st1[6]
+            if (want & 0xFF) == 3:      # the position HasConverged froze (p3d_)
+                assert np.abs(np.array(o.position[:]) - st1[7:10]).max() <= 1e-11
+    # every branch of the loop body was exercised
+    assert seen.get(0, 0) > 5 and seen.get(1, 0) > 5 and seen.get(2, 0) + seen.get(3, 0) > 20 and seen.get(3, 0) > 0 and seen.get("deleted", 0) > 0, seen
+    f_ref.close(); f_cur.close()
+
+
 def test_search_points_tree_sums_within_tolerance(ctx, sdvl, orc, synth):
     """sdvl_search_params.lk_tree_sums = 1: AlignPatch's three 64-term sums as a wave butterfly instead of the reference's
     sequential chain.  Tolerance class, not bit class: found flags equal for (almost) every request, offsets within 1e-4."""

@@ -155,6 +155,17 @@ def test_closed_loop_with_reference_mapper(trk, orc, synth):
     assert stats["initialized"] >= 100 and stats["converged"] >= 50 and stats["linked"] >= 200 and stats["connected"] >= 10
 
 
+def test_closed_loop_with_reference_mapper_depth_filter_on_the_host(trk, orc, synth):
+    """the same with Point::Update / HasConverged computed by the host layer (SDVL_HOST_DEPTH_FILTER=1): the tracking tables are
+    rebuilt from the objects after every mapper update instead of being patched by depth_filter_kernel"""
+    trk.set_device_filter(False)
+    try:
+        worst, stats = run_mapper_case(trk, orc, synth, B=2, n_frames=24, threads=1)
+    finally:
+        trk.set_device_filter(True)
+    assert worst <= POSE_TOL and stats["converged"] >= 20
+
+
 def test_closed_loop_with_reference_mapper_batched(trk, orc, synth):
     worst, _ = run_mapper_case(trk, orc, synth, B=4, n_frames=16, threads=3)
     assert worst <= POSE_TOL
