@@ -382,7 +382,9 @@ def main():
             G = args.groups
         else:
             workers_auto = max(1, min(cpus_rank, 16) // max(1, args.threads))   # a group's helper threads come out of the same share
-            if fibers <= 1 and cpus_rank < 12 and not args.workers:
+            # (with the reference's mapper in the step the host is the limiter and a step has four more GPU waits — candidate,
+            #  connection and seed searches, FilterCorners: two groups per worker keep the core busy across them, +5 %)
+            if fibers <= 1 and (cpus_rank < 12 or args.mapper) and not args.workers:
                 fibers = 2
             G = max(1, min(B // 8 if B >= 8 else 1, workers_auto * max(1, fibers)))
         while B % G:

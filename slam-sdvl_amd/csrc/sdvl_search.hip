@@ -852,7 +852,7 @@ struct SearchBatch {
   std::vector<SearchFramePose> table;
   std::vector<const sdvl_frame *> frames;  // parallel to `table`
   std::unordered_map<const sdvl_frame *, int> where;
-  int last = -1;
+  int last = -1, last2 = -1;  // the two most recent slots: requests alternate between their current and reference frame
 };
 constexpr size_t kSearchTabCap = 2048;  // frame-table entries that fit the staging reserve (more go through d_work)
 
@@ -869,6 +869,7 @@ int sdvl_search_begin(sdvl_ctx *ctx, int max_requests, sdvl_search_req_packed **
   B.frames.clear();
   B.where.clear();
   B.last = -1;
+  B.last2 = -1;
   B.in_bytes = (sizeof(SearchReqDev) * static_cast<size_t>(max_requests) + 255) / 256 * 256;
   B.blk_cap_bytes = (sizeof(SearchBlock) * static_cast<size_t>(max_requests) + 255) / 256 * 256;
   // the batch's own pinned + device buffers, not the staging ring: the caller fills the records over time and every
@@ -888,7 +889,12 @@ int sdvl_search_slot(sdvl_ctx *ctx, const sdvl_frame *f, const double *pose) {
   if (!ctx || !f || !pose) return SDVL_ERR_INVALID;
   SearchBatch &B = batch_of(ctx);
   std::vector<SearchFramePose> &table = B.table;
-  if (B.last >= 0 && table[B.last].f.corners == f->v.corners && memcmp(table[B.last].pose, pose, sizeof(double) * 7) == 0) return B.last;
+  if (B.last >= 0 && B.frames[B.last] == f && memcmp(table[B.last].pose, pose, sizeof(double) * 7) == 0) return B.last;
+  if (B.last2 >= 0 && B.frames[B.last2] == f && memcmp(table[B.last2].pose, pose, sizeof(double) * 7) == 0) {
+    std::swap(B.last, B.last2);
+    return B.last;
+  }
+  B.last2 = B.last;
   auto it = B.where.find(f);
   if (it != B.where.end() && memcmp(table[it->second].pose, pose, sizeof(double) * 7) == 0) { B.last = it->second; return B.last; }
   SearchFramePose e;

@@ -319,7 +319,16 @@ bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs, vector<sdvl_depth_
   if (!cur_) return false;
   req_base_ = static_cast<int>(reqs->size());
   bool any = false;
-  for (size_t k = 0; k < candidates_.size(); k++) {
+  const size_t n_cand = candidates_.size();
+  for (size_t k = 0; k < n_cand; k++) {
+    // the loop walks Point -> first Feature -> its keyframe, three dependent loads per candidate scattered over the heap:
+    // ask for them a few candidates ahead
+    if (k + 8 < n_cand) __builtin_prefetch(candidates_[k + 8].get());
+    if (k + 4 < n_cand) {
+      const Feature *f4 = candidates_[k + 4]->GetInitFeatureRaw();
+      __builtin_prefetch(f4);
+      __builtin_prefetch(reinterpret_cast<const char *>(f4) + 64);
+    }
     if (occurrence_[k] != pass_) continue;
     any = true;
     Point *point = candidates_[k].get();
@@ -361,7 +370,9 @@ void MapperMap::ApplyCandidates(const sdvl_search_res *res_all, const sdvl_depth
   const double px_error_angle = std::atan(1.0 / (2.0 * camera_->GetFx())) * 2.0;  // Camera::GetPixelErrorAngle, camera.h:104-107
   const int min_kf_id = last_kf_->GetKeyframeID() - 2 * Config::MaxSearchKeyframes();
   vector<char> erase(candidates_.size(), 0);
-  for (const CandWork &w : cand_work_) {
+  for (size_t wi = 0; wi < cand_work_.size(); wi++) {
+    const CandWork &w = cand_work_[wi];
+    if (wi + 6 < cand_work_.size()) __builtin_prefetch(candidates_[cand_work_[wi + 6].index].get());
     const shared_ptr<Point> &point = candidates_[w.index];
     if (w.state == kDeleted) {
       DeletePoint(point);
@@ -535,19 +546,31 @@ void MapperMap::EmitInitCandidates(vector<sdvl_search_req> *reqs) {
   vector<int> &fcorners = cur_->GetFilteredCorners();
   const int nc = static_cast<int>(fcorners.size());
   ic_req_.assign(best_kfs_.size() * static_cast<size_t>(nc), -1);
+  // what a request says about the corner is the same for every connected keyframe: position, bearing, level, descriptor
+  // and the current frame's side are filled once per corner, the keyframe's side per pair
+  ic_proto_.resize(nc);
+  for (int c = 0; c < nc; c++) {
+    const Vector3i corner = cur_->FilteredCorner(c);
+    const int scale = (1 << corner(2));
+    const Vector2d px(corner(0) * scale, corner(1) * scale);
+    const Vector3d bearing = camera_->Unproject(px);
+    FillRequest(&ic_proto_[c], cur_.get(), cur_.get(), px, bearing, corner(2), Config::UseORB() ? cur_->FilteredDescriptor(c) : nullptr,
+                1.0 / depth_mean_, 1.0, false, Vector2d(0, 0));
+  }
   for (size_t k = 0; k < best_kfs_.size(); k++) {
     Frame *cframe = best_kfs_[k].get();
     const double distance = cur_->DistanceTo(*cframe);
     if (distance / depth_mean_ < 0.01) continue;
+    double cpose[7];
+    cframe->GetPose().ToArray(cpose);
+    const sdvl_frame *cdev = cframe->device();
+    const size_t first = reqs->size();
+    reqs->insert(reqs->end(), ic_proto_.begin(), ic_proto_.end());
     for (int c = 0; c < nc; c++) {
-      const Vector3i corner = cur_->FilteredCorner(c);
-      const int scale = (1 << corner(2));
-      const Vector2d px(corner(0) * scale, corner(1) * scale);
-      const Vector3d bearing = camera_->Unproject(px);
-      reqs->emplace_back();
-      FillRequest(&reqs->back(), cframe, cur_.get(), px, bearing, corner(2), Config::UseORB() ? cur_->FilteredDescriptor(c) : nullptr,
-                  1.0 / depth_mean_, 1.0, false, Vector2d(0, 0));
-      ic_req_[k * nc + c] = static_cast<int>(reqs->size()) - 1 - req_base_;
+      sdvl_search_req &rq = (*reqs)[first + c];
+      rq.cur = cdev;  // the search runs IN the connected keyframe, from the new keyframe's corner (map.cc:352)
+      std::memcpy(rq.cur_pose, cpose, sizeof(cpose));
+      ic_req_[k * nc + c] = static_cast<int>(first) + c - req_base_;
     }
   }
 }

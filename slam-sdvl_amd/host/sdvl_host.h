@@ -681,6 +681,7 @@ class MapperMap : public PlaneMap {
   std::vector<std::shared_ptr<Frame>> best_kfs_;
   std::vector<int> ic_req_;                                // InitCandidates: request of (kf k, filtered corner c) or -1
   std::vector<std::shared_ptr<Feature>> ic_feature_;
+  std::vector<sdvl_search_req> ic_proto_;                  // InitCandidates: the request of filtered corner c without its keyframe
   std::thread thread_;
   std::atomic<bool> running_{false};
   std::atomic<long> updates_{0};
