@@ -2614,27 +2614,51 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
       vector<sdvl_depth_state> states;
       vector<sdvl_depth_out> fout;
       const sdvl_depth_params fparams = mm[0]->FilterParams();
-      auto launch = [&](bool filter = false) {  // concatenate, search, leave the offsets in `begin`
-        reqs.clear();
-        states.clear();
+      auto launch = [&](bool filter = false) {  // search everything the maps emitted, leave the offsets in `begin`
+        // the requests go from the maps' lists straight into the context's pinned batch (device layout, frames by slot)
+        size_t total = 0;
         for (int k = 0; k < M; k++) {
-          begin[k] = reqs.size();
-          reqs.insert(reqs.end(), per[k].begin(), per[k].end());
-          per[k].clear();
+          begin[k] = total;
+          total += per[k].size();
+        }
+        begin[M] = total;
+        states.clear();
+        res.assign(std::max<size_t>(total, 1), sdvl_search_res());
+        fout.assign(std::max<size_t>(filter ? total : 0, 1), sdvl_depth_out());
+        if (total > 0) {
+          sdvl_ctx *ctx = dev_->ctx();
+          sdvl_search_req_packed *packed = nullptr;
+          dev_->Check(sdvl_search_begin(ctx, static_cast<int>(total), &packed), "sdvl_search_begin");
+          size_t o = 0;
+          for (int k = 0; k < M; k++) {
+            for (const sdvl_search_req &r : per[k]) {
+              sdvl_search_req_packed &d = packed[o++];
+              d.cur = sdvl_search_slot(ctx, r.cur, r.cur_pose);
+              d.ref = sdvl_search_slot(ctx, r.ref, r.ref_pose);
+              if (d.cur < 0 || d.ref < 0) dev_->Check(d.cur < 0 ? d.cur : d.ref, "sdvl_search_slot");
+              d.level = r.level; d.fixed = r.fixed;
+              d.px[0] = r.px[0]; d.px[1] = r.px[1];
+              d.bearing[0] = r.bearing[0]; d.bearing[1] = r.bearing[1]; d.bearing[2] = r.bearing[2];
+              d.idepth = r.idepth; d.idepth_std = r.idepth_std;
+              d.px0[0] = r.px0[0]; d.px0[1] = r.px0[1];
+              std::memcpy(d.desc, r.desc, 32);
+            }
+            per[k].clear();
+            if (filter) {
+              states.insert(states.end(), per_st[k].begin(), per_st[k].end());
+              per_st[k].clear();
+            }
+          }
+          const sdvl_camera c = cam.abi();
+          const sdvl_search_params sp = SearchParams();
           if (filter) {
-            states.insert(states.end(), per_st[k].begin(), per_st[k].end());
-            per_st[k].clear();
+            if (states.size() != total) throw std::runtime_error("mapper: one filter state per candidate request");
+            dev_->Check(sdvl_search_run_filter(ctx, static_cast<int>(total), &c, &sp, states.data(), &fparams, track_, res.data(), fout.data()),
+                        "sdvl_search_run_filter");
+          } else {
+            dev_->Check(sdvl_search_run(ctx, static_cast<int>(total), &c, &sp, res.data()), "sdvl_search_run");
           }
         }
-        begin[M] = reqs.size();
-        res.clear();
-        fout.clear();
-        if (!reqs.empty()) {
-          if (filter) Matcher::SearchPointsFilter(dev_, reqs, states, cam, fparams, track_, &res, &fout);
-          else Matcher::SearchPoints(dev_, reqs, cam, &res);
-        }
-        if (res.empty()) res.resize(1);
-        if (fout.empty()) fout.resize(1);
       };
       std::unique_ptr<StageClock> sub(new StageClock(ST_MAP_CANDIDATES));
       for (;;) {  // UpdateCandidates, one occurrence pass at a time
