@@ -387,6 +387,8 @@ def main():
             if fibers <= 1 and (cpus_rank < 12 or args.mapper) and not args.workers:
                 fibers = 2
             G = max(1, min(B // 8 if B >= 8 else 1, workers_auto * max(1, fibers)))
+            if args.workload == "S-C":   # 4x the pixels and features per frame: 64 frames per launch fill the chip, more streams only
+                G = max(1, min(G, B // 64 if B >= 64 else G))   # stretch the latency-bound kernels (512 sequences: 8 groups 33k, 16 groups 31k, 4 groups 28k frames/s)
         while B % G:
             G -= 1
         Bg = B // G

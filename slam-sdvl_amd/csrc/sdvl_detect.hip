@@ -161,19 +161,21 @@ __device__ __forceinline__ bool fast_compass_pass(int v, int p_dn, int p_rt, int
 #define SDVL_MIN2(a, b) min((a), (b))
 #define SDVL_MAX2(a, b) max((a), (b))
 
-// cornerScore<16> of the pixel at byte address (row, x) of the padded LDS tile in closed form, by min doubling:
+// cornerScore<16> of the pixel at byte address (row, x) of the padded LDS tile in closed form:
 // best = max(t, max_arcs min9(v-p), max_arcs min9(p-v)); OpenCV's score is best - 1.  The segment test itself falls out
 // of the same number: a 9-arc with every |difference| > t exists  <=>  best > t  (cv::FAST_t / cornerScore<16>).
+// v is the same in all 16 differences, so min9(v-p) = v - max9(p) and min9(p-v) = min9(p) - v: the windows run on the raw
+// ring bytes (no subtraction per ring pixel), best = max(t, v - min_arcs max9(p), max_arcs min9(p) - v).  Integers: exact.
 __device__ __forceinline__ int fast_corner_best(const uint8_t *tile, int pitch_bytes, int t) {
   const int v = tile[0];
-  // e_k = v - p_k over the Bresenham circle, cv::FAST offsets16:
+  // p_k over the Bresenham circle, cv::FAST offsets16:
   // (dx,dy) = (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-#define SDVL_E(K, DX, DY) const int e##K = v - static_cast<int>(tile[(DY) * pitch_bytes + (DX)]);
+#define SDVL_E(K, DX, DY) const int e##K = static_cast<int>(tile[(DY) * pitch_bytes + (DX)]);
   SDVL_E(0, 0, 3) SDVL_E(1, 1, 3) SDVL_E(2, 2, 2) SDVL_E(3, 3, 1) SDVL_E(4, 3, 0) SDVL_E(5, 3, -1) SDVL_E(6, 2, -2) SDVL_E(7, 1, -3)
   SDVL_E(8, 0, -3) SDVL_E(9, -1, -3) SDVL_E(10, -2, -2) SDVL_E(11, -3, -1) SDVL_E(12, -3, 0) SDVL_E(13, -3, 1) SDVL_E(14, -2, 2) SDVL_E(15, -1, 3)
 #undef SDVL_E
   // sliding windows on the ring with 3-input min / max (v_min3_i32 / v_max3_i32): 3-windows, then 9-windows = three
-  // 3-windows.  Darker ring: max over arcs of min9(e); brighter ring: max over arcs of min9(-e) = -min over arcs of max9(e).
+  // 3-windows.  (Packed 16-bit min / max are 2-input: a 3-window costs two of them for two pixels — the same count per pixel.)
 #define SDVL_MIN3(a, b, c) min(min((a), (b)), (c))
 #define SDVL_MAX3(a, b, c) max(max((a), (b)), (c))
 #define SDVL_W3(K, A, B, C) const int n##K = SDVL_MIN3(e##A, e##B, e##C), x##K = SDVL_MAX3(e##A, e##B, e##C);
@@ -186,11 +188,11 @@ __device__ __forceinline__ int fast_corner_best(const uint8_t *tile, int pitch_b
   SDVL_W9(6, 6, 9, 12) SDVL_W9(7, 7, 10, 13) SDVL_W9(8, 8, 11, 14) SDVL_W9(9, 9, 12, 15) SDVL_W9(10, 10, 13, 0) SDVL_W9(11, 11, 14, 1)
   SDVL_W9(12, 12, 15, 2) SDVL_W9(13, 13, 0, 3) SDVL_W9(14, 14, 1, 4) SDVL_W9(15, 15, 2, 5)
 #undef SDVL_W9
-  const int dark = SDVL_MAX3(SDVL_MAX3(N0, N1, N2), SDVL_MAX3(N3, N4, N5), SDVL_MAX3(SDVL_MAX3(N6, N7, N8), SDVL_MAX3(N9, N10, N11), SDVL_MAX3(N12, N13, SDVL_MAX2(N14, N15))));
-  const int brig = SDVL_MIN3(SDVL_MIN3(X0, X1, X2), SDVL_MIN3(X3, X4, X5), SDVL_MIN3(SDVL_MIN3(X6, X7, X8), SDVL_MIN3(X9, X10, X11), SDVL_MIN3(X12, X13, SDVL_MIN2(X14, X15))));
+  const int max_n = SDVL_MAX3(SDVL_MAX3(N0, N1, N2), SDVL_MAX3(N3, N4, N5), SDVL_MAX3(SDVL_MAX3(N6, N7, N8), SDVL_MAX3(N9, N10, N11), SDVL_MAX3(N12, N13, SDVL_MAX2(N14, N15))));
+  const int min_x = SDVL_MIN3(SDVL_MIN3(X0, X1, X2), SDVL_MIN3(X3, X4, X5), SDVL_MIN3(SDVL_MIN3(X6, X7, X8), SDVL_MIN3(X9, X10, X11), SDVL_MIN3(X12, X13, SDVL_MIN2(X14, X15))));
 #undef SDVL_MIN3
 #undef SDVL_MAX3
-  return max(max(t, dark), -brig);
+  return max(max(t, v - min_x), max_n - v);
 }
 
 // exclusive rank of (lane, bit k) in lane-major order over the wave for the 4-bit flag sets `flags`, and the wave total
@@ -254,38 +256,68 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   }
   __syncthreads();
   const int t = lv.threshold;
-  // ---- phase A: compass pre-test of the thread's 4 pixels
-  uint32_t cflags = 0;
-  if (row >= 3 && row < rh - 3) {
-    const uint32_t *qz = &s_img[(row + kPadRows) * kPitchW + wq];
-    const uint32_t rz0 = qz[0], rz1 = qz[1], rz2 = qz[2];
-    const uint32_t up = s_img[(row + kPadRows - 3) * kPitchW + wq + 1], dn = s_img[(row + kPadRows + 3) * kPitchW + wq + 1];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int x = cg + k;
-      if (x < 3 || x >= rw - 3) continue;
-      const int v = static_cast<int>((rz1 >> (8 * k)) & 0xFFu);
-      if (fast_compass_pass(v, static_cast<int>((dn >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 7 + k),
-                            static_cast<int>((up >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 1 + k), t))
-        cflags |= 1u << k;
-    }
-  }
-  // ---- phase B: candidates listed densely in scan order (thread order == row-major pixel order)
   const int lane = tid & 63, wave = tid >> 6;
-  int wtot;
-  const int wrank = wave_rank4(cflags, &wtot);
-  if (lane == 0) s_wave_tot[wave] = wtot;
-  __syncthreads();
-  int cbase = 0;
-  for (int w = 0; w < wave; w++) cbase += s_wave_tot[w];
-  const int ncand = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+  // ---- density probe: the compass pre-test on ONE pixel per thread (a quarter of the tile, the column rotating with the row).
+  // Where most pixels pass it — dense texture: on the synthetic plane 83 % of the tested pixels pass and 48 % are corners —
+  // listing the survivors buys nothing, and the tile is scored densely instead (phases A and B skipped).  Both paths yield the
+  // same corners and scores; the probe only chooses the cheaper one.
+  bool dense;
   {
-    int cpos = cbase + wrank;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (cflags & (1u << k)) s_list[cpos++] = static_cast<uint16_t>((row << 5) | (cg + k));
+    bool probed = false, passed = false;
+    const int x = cg + (row & 3);
+    if (row >= 3 && row < rh - 3 && x >= 3 && x < rw - 3) {
+      probed = true;
+      const uint8_t *q = reinterpret_cast<const uint8_t *>(s_img) + (row + kPadRows) * (kPitchW * 4) + 4 + x;
+      passed = fast_compass_pass(q[0], q[3 * kPitchW * 4], q[3], q[-3 * kPitchW * 4], q[-3], t);
+    }
+    const unsigned long long mp = __ballot(probed), mq = __ballot(passed);
+    if (lane == 0) s_wave_tot[wave] = (__popcll(mp) << 16) | __popcll(mq);
+    __syncthreads();
+    const int sum = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    dense = 2 * (sum & 0xFFFF) > (sum >> 16);
+    __syncthreads();  // s_wave_tot is written again below
   }
-  __syncthreads();
+  int ncand;
+  int dense_tw = 1, dense_inv = 0;
+  if (dense) {
+    // every tested pixel (rows 3 .. rh-4, columns 3 .. rw-4) is a candidate, in scan order: candidate q = (q / tw, q % tw)
+    dense_tw = rw - 6;
+    ncand = dense_tw > 0 && rh > 6 ? dense_tw * (rh - 6) : 0;
+    dense_tw = dense_tw > 0 ? dense_tw : 1;
+    dense_inv = (65536 + dense_tw - 1) / dense_tw;  // q / tw == (q * inv) >> 16 for q < 1024, tw <= 26
+  } else {
+    // ---- phase A: compass pre-test of the thread's 4 pixels
+    uint32_t cflags = 0;
+    if (row >= 3 && row < rh - 3) {
+      const uint32_t *qz = &s_img[(row + kPadRows) * kPitchW + wq];
+      const uint32_t rz0 = qz[0], rz1 = qz[1], rz2 = qz[2];
+      const uint32_t up = s_img[(row + kPadRows - 3) * kPitchW + wq + 1], dn = s_img[(row + kPadRows + 3) * kPitchW + wq + 1];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = cg + k;
+        if (x < 3 || x >= rw - 3) continue;
+        const int v = static_cast<int>((rz1 >> (8 * k)) & 0xFFu);
+        if (fast_compass_pass(v, static_cast<int>((dn >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 7 + k),
+                              static_cast<int>((up >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 1 + k), t))
+          cflags |= 1u << k;
+      }
+    }
+    // ---- phase B: candidates listed densely in scan order (thread order == row-major pixel order)
+    int wtot;
+    const int wrank = wave_rank4(cflags, &wtot);
+    if (lane == 0) s_wave_tot[wave] = wtot;
+    __syncthreads();
+    int cbase = 0;
+    for (int w = 0; w < wave; w++) cbase += s_wave_tot[w];
+    ncand = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    {
+      int cpos = cbase + wrank;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (cflags & (1u << k)) s_list[cpos++] = static_cast<uint16_t>((row << 5) | (cg + k));
+    }
+    __syncthreads();
+  }
   // ---- phase C: one candidate per lane gets the 16-pixel arithmetic, which yields the segment test AND the score
   uint8_t *score_bytes = reinterpret_cast<uint8_t *>(s_score);
   const uint8_t *img_bytes = reinterpret_cast<const uint8_t *>(s_img);
@@ -298,12 +330,21 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     if (ps < npass) {
       const int i = ps * 256 + tid;
       if (i < ncand) {
-        const int rc = s_list[i], r = rc >> 5, x = rc & 31;
+        int r, x;
+        if (dense) {
+          const int qr = (i * dense_inv) >> 16;
+          r = qr + 3;
+          x = i - qr * dense_tw + 3;
+        } else {
+          const int rc = s_list[i];
+          r = rc >> 5;
+          x = rc & 31;
+        }
         const int best = fast_corner_best(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
         if (best > t) {
           const int sc = (best - 1) & 0xFF;  // uchar like OpenCV's score buffer
           score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>(sc);
-          rc_of[ps] = rc;
+          rc_of[ps] = (r << 5) | x;
           sc_of[ps] = sc;
         }
       }
