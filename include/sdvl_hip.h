@@ -153,6 +153,11 @@ int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f);
 /* HBM bytes one frame of this shape occupies (pyramid + corner / descriptor / cell lists); -1 for an invalid shape */
 int64_t sdvl_frame_footprint(int width, int height, int levels);
 int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stride);
+/* the same for n frames of one shape in ONE submission.  Images in pinned (device-mapped) host memory — hipHostMalloc,
+ * hipHostRegister, torch pin_memory — are pulled over the bus by one gather kernel that reads the host pages directly (no DMA
+ * descriptor per image: 256 images of 300 KB each cost 256 copy launches otherwise and reach about half the link rate);
+ * pageable images fall back to one staged copy each.  The images must stay valid until the stream has passed this point. */
+int sdvl_frames_upload(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const uint8_t *const *imgs, int stride);
 /* same, image already in HBM (device pointer) */
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride);
 /* same without the copy: level 0 aliases the caller's HBM image (row stride == width), which must stay valid and

@@ -121,7 +121,7 @@ ABI_SYMBOLS = [
     "sdvl_ctx_create", "sdvl_ctx_destroy", "sdvl_last_error", "sdvl_ctx_synchronize", "sdvl_ctx_stream",
     "sdvl_ctx_bind_thread", "sdvl_ctx_device", "sdvl_pointer_device", "sdvl_ctx_scratch_device",
     "sdvl_ctx_timing_enable", "sdvl_ctx_timing_get", "sdvl_ctx_timing_reset",
-    "sdvl_frame_create", "sdvl_frame_create_many", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frame_set_image_device", "sdvl_frame_borrow_image_device",
+    "sdvl_frame_create", "sdvl_frame_create_many", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frames_upload", "sdvl_frame_set_image_device", "sdvl_frame_borrow_image_device",
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
     "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
     "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
@@ -403,6 +403,14 @@ class Context:
         res = (SearchRes * n)()
         self._check(self.lib.sdvl_search_points(self.h, n, reqs, C.byref(cam), C.byref(sp), res))
         return res
+
+    def frames_upload(self, frames, addresses, stride):
+        """sdvl_frames_upload: images at host `addresses` (ints; pinned memory is read by one gather kernel, pageable memory is
+        copied image by image) become level 0 of `frames`; the memory must stay alive until the stream has passed"""
+        n = len(frames)
+        fr = (C.c_void_p * n)(*[f.h for f in frames])
+        im = (C.c_void_p * n)(*[int(a) for a in addresses])
+        self._check(self.lib.sdvl_frames_upload(self.h, n, fr, im, int(stride)))
 
     def search_points_filter(self, reqs, cam, sp, states, fparams):
         """sdvl_search_points_filter without tracking tables: (search results, depth-filter outcomes)"""

@@ -250,6 +250,44 @@ static void sdvl_timer_collect(sdvl_ctx *ctx) {
   ctx->pending.clear();
 }
 
+// ---- batched upload: the GPU pulls the images out of pinned host memory itself ---------------------------------------------
+namespace {
+struct UploadJob {
+  const uint8_t *src;  // device-visible address of the image in pinned host memory
+  uint8_t *dst;        // level 0 of the frame
+};
+constexpr int kUploadChunks = 30;  // workgroups per image: 256 images x 30 = 7680 workgroups, every lane keeps 4 x 16 B reads in flight
+
+__global__ __launch_bounds__(256) void frames_upload_kernel(const UploadJob *__restrict__ jobs, int width, int height, int stride) {
+  const UploadJob job = jobs[blockIdx.y];
+  const int tid = threadIdx.x + blockIdx.x * 256, nthr = 256 * gridDim.x;
+  if (stride == width && (reinterpret_cast<uintptr_t>(job.src) & 15u) == 0 && ((static_cast<size_t>(width) * height) & 15u) == 0) {
+    // contiguous image: 16-byte units, four independent loads per lane and round (reads cross the bus: latency is long)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *s = reinterpret_cast<const u32x4 *>(job.src);
+    u32x4 *d = reinterpret_cast<u32x4 *>(job.dst);
+    const int n16 = static_cast<int>((static_cast<size_t>(width) * height) >> 4);
+    int i = tid;
+    for (; i + 3 * nthr < n16; i += 4 * nthr) {
+      const u32x4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + nthr);
+      const u32x4 c = __builtin_nontemporal_load(s + i + 2 * nthr), e = __builtin_nontemporal_load(s + i + 3 * nthr);
+      d[i] = a; d[i + nthr] = b; d[i + 2 * nthr] = c; d[i + 3 * nthr] = e;
+    }
+    for (; i < n16; i += nthr) d[i] = __builtin_nontemporal_load(s + i);
+  } else {  // padded rows or odd alignment: row by row, 4-byte units where the row allows it
+    for (int r = blockIdx.x; r < height; r += gridDim.x) {
+      const uint8_t *s = job.src + static_cast<size_t>(r) * stride;
+      uint8_t *d = job.dst + static_cast<size_t>(r) * width;
+      if ((reinterpret_cast<uintptr_t>(s) & 3u) == 0 && (reinterpret_cast<uintptr_t>(d) & 3u) == 0 && (width & 3) == 0) {
+        for (int x = threadIdx.x; x < (width >> 2); x += 256) reinterpret_cast<uint32_t *>(d)[x] = reinterpret_cast<const uint32_t *>(s)[x];
+      } else {
+        for (int x = threadIdx.x; x < width; x += 256) d[x] = s[x];
+      }
+    }
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int sdvl_ctx_create(int device, sdvl_ctx **out) {
@@ -512,6 +550,56 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
   f->v.n_corners = 0;
   f->desc_valid = 0;
   f->bins_valid = 0;
+  return SDVL_OK;
+}
+
+int sdvl_frames_upload(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const uint8_t *const *imgs, int stride) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !imgs))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  const int width = frames[0]->width, height = frames[0]->height;
+  SDVL_REQUIRE(ctx, stride >= width, "stride smaller than width");
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  // which images can the GPU read where they are?
+  std::vector<const uint8_t *> mapped(n, nullptr);
+  int n_mapped = 0;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] && imgs[i], "null frame or image");
+    SDVL_REQUIRE(ctx, frames[i]->width == width && frames[i]->height == height, "sdvl_frames_upload: frames of one shape");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, imgs[i]) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+      mapped[i] = static_cast<const uint8_t *>(attr.devicePointer);
+      n_mapped++;
+    } else {
+      (void)hipGetLastError();  // an unregistered pointer is not an error here
+    }
+  }
+  if (n_mapped > 0) {
+    void *hs = nullptr, *ds = nullptr;
+    const int rc = sdvl_stage_alloc(ctx, sizeof(UploadJob) * static_cast<size_t>(n_mapped), &hs, &ds);
+    if (rc) return rc;
+    UploadJob *hj = static_cast<UploadJob *>(hs);
+    int k = 0;
+    for (int i = 0; i < n; i++)
+      if (mapped[i]) hj[k++] = UploadJob{mapped[i], frames[i]->own_level0};
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, sizeof(UploadJob) * static_cast<size_t>(n_mapped), hipMemcpyHostToDevice, ctx->stream));
+    SDVL_LAUNCH(ctx, "frames_upload", frames_upload_kernel, dim3(kUploadChunks, n_mapped), dim3(256), static_cast<const UploadJob *>(ds), width,
+                height, stride);
+    SDVL_HIP_CHECK(ctx, hipGetLastError());
+  }
+  for (int i = 0; i < n; i++) {
+    sdvl_frame *f = frames[i];
+    f->v.level[0] = f->own_level0;
+    if (!mapped[i]) {
+      if (stride == width)
+        SDVL_HIP_CHECK(ctx, hipMemcpyAsync(f->v.level[0], imgs[i], static_cast<size_t>(width) * height, hipMemcpyHostToDevice, ctx->stream));
+      else
+        SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(f->v.level[0], width, imgs[i], stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    }
+    f->hdr_stale = 1;
+    f->v.n_corners = 0;
+    f->desc_valid = 0;
+    f->bins_valid = 0;
+  }
   return SDVL_OK;
 }
 

@@ -546,12 +546,29 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
   const int n = static_cast<int>(frames.size());
   if (n == 0) return;
   std::unique_ptr<StageClock> clk(new StageClock(ST_UPLOAD_PYR));
+  // host images of one shape and row pitch go up together (one gather kernel over pinned memory instead of a copy per image)
+  vector<sdvl_frame *> up_f;
+  vector<const uint8_t *> up_i;
+  int up_step = 0;
+  auto flush = [&]() {
+    if (up_f.empty()) return;
+    dev->Check(sdvl_frames_upload(dev->ctx(), static_cast<int>(up_f.size()), up_f.data(), up_i.data(), up_step), "sdvl_frames_upload");
+    up_f.clear();
+    up_i.clear();
+  };
   for (int i = 0; i < n; i++) {
     if (imgs[i].dev_src && imgs[i].step == imgs[i].cols && imgs[i].borrow)
       dev->Check(sdvl_frame_borrow_image_device(dev->ctx(), devs[i], imgs[i].dev_src), "sdvl_frame_borrow_image_device");
     else if (imgs[i].dev_src) dev->Check(sdvl_frame_set_image_device(dev->ctx(), devs[i], imgs[i].dev_src, imgs[i].step), "sdvl_frame_set_image_device");
-    else dev->Check(sdvl_frame_upload(dev->ctx(), devs[i], imgs[i].data, imgs[i].step), "sdvl_frame_upload");
+    else {
+      if (!up_f.empty() && (imgs[i].step != up_step || frames[i]->GetWidth() != frames[0]->GetWidth() || frames[i]->GetHeight() != frames[0]->GetHeight()))
+        flush();
+      up_step = imgs[i].step;
+      up_f.push_back(devs[i]);
+      up_i.push_back(imgs[i].data);
+    }
   }
+  flush();
   dev->Check(sdvl_pyramid_build(dev->ctx(), n, devs.data()), "sdvl_pyramid_build");
   if (!corners) return;
   // FastDetector::DetectPyramid on the device (FAST + quota + retainBest in libstdc++ order); nothing returns to the host

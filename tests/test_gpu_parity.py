@@ -569,6 +569,44 @@ def test_context_of_a_fresh_thread_allocates_on_its_own_gpu(sdvl):
     assert out["ctx_dev"] == dev and out["scratch"] == dev and out["scratch2"] == dev
 
 
+def test_frames_upload_from_pinned_and_pageable_memory(ctx, sdvl, orc):
+    """sdvl_frames_upload: pinned images are pulled by the gather kernel (contiguous and padded rows), pageable ones go through
+    staged copies; either way level 0 is the image and the pyramid built from it is the oracle's"""
+    import torch
+    rng = np.random.default_rng(9)
+    n, w, h = 5, 640, 480
+    frames = [sdvl.Frame(ctx, w, h) for _ in range(n)]
+    pinned = torch.empty((n, h, w), dtype=torch.uint8, pin_memory=True)
+    imgs = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    pinned.numpy()[:] = imgs
+    ctx.frames_upload(frames, [pinned.data_ptr() + i * w * h for i in range(n)], w)
+    ctx._check(ctx.lib.sdvl_pyramid_build(ctx.h, n, (C.c_void_p * n)(*[f.h for f in frames])))
+    for i in range(n):
+        assert np.array_equal(frames[i].level(0), imgs[i])
+        assert np.array_equal(frames[i].level(2), orc.pyramid(imgs[i], 5)[2])
+    # padded rows (pitch 656) in pinned memory, and a mix of pinned and pageable sources in one call
+    pitch = 656
+    padded = torch.zeros((n, h, pitch), dtype=torch.uint8, pin_memory=True)
+    imgs2 = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    padded.numpy()[:, :, :w] = imgs2
+    pageable = np.zeros((h, pitch), np.uint8)
+    imgs2[3] = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    pageable[:, :w] = imgs2[3]
+    addrs = [padded.data_ptr() + i * pitch * h for i in range(n)]
+    addrs[3] = pageable.ctypes.data
+    ctx.frames_upload(frames, addrs, pitch)
+    ctx.synchronize()
+    for i in range(n):
+        assert np.array_equal(frames[i].level(0), imgs2[i]), i
+    # an odd source address (not 16-byte aligned) takes the row path
+    odd = torch.zeros(w * h + 64, dtype=torch.uint8, pin_memory=True)
+    odd.numpy()[3:3 + w * h] = imgs[1].reshape(-1)
+    ctx.frames_upload(frames[:1], [odd.data_ptr() + 3], w)
+    assert np.array_equal(frames[0].level(0), imgs[1])
+    for f in frames:
+        f.close()
+
+
 def test_align_patches_bit_exact_and_recovers_shift(ctx, sdvl, orc, synth):
     img = frames_of(synth, orc, TUM_CAM, 640, 480, [0])[0]
     corners = orc.detect_pyramid(img)
