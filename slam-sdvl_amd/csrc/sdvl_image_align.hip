@@ -628,6 +628,12 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   // launch there is almost always a fresh keyframe with more than 384 features among them.
   const bool force_generic = getenv("SDVL_IMAGE_ALIGN_GENERIC") != nullptr;
   const bool legacy = force_generic || getenv("SDVL_IMAGE_ALIGN_LEGACY_BIG") != nullptr;  // the round-1 global-memory kernel for the big jobs
+  // jobs up to this many features keep their caches in LDS (SDVL_IA_LDS_MAX_F: experiments with the LDS / L2 trade-off)
+  static const int lds_max_f = [] {
+    const char *e = getenv("SDVL_IA_LDS_MAX_F");
+    const int v = e ? atoi(e) : kLdsMaxF;
+    return v < 0 ? 0 : (v > kLdsMaxF ? kLdsMaxF : v);
+  }();
   std::vector<int> order(n_jobs);
   int n_lds = 0, max_nf_lds = 0, max_nf_big = 0;
   size_t work = 0;
@@ -647,7 +653,7 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     int lo = 0, hi = n_jobs;
     for (int j = 0; j < n_jobs; j++) {
       const int nf = jobs[j].feat_end - jobs[j].feat_begin;
-      if (!force_generic && nf <= kLdsMaxF) {
+      if (!force_generic && nf <= lds_max_f) {
         order[lo++] = j;
         if (nf > max_nf_lds) max_nf_lds = nf;
       } else {

@@ -23,7 +23,15 @@ find $O/prof_fetch $O/prof_write -name "*kernel_trace.csv" -delete
 # the other two configurations DESIGN §7 quotes: the reference's mapper inside every step, and BASELINE's configuration C
 python3 bench.py --mapper --steps 20 --warmup 4 --cpu-frames 0 --host-steps 0 > $O/bench_mapper.json 2> $O/bench_mapper.err
 python3 bench.py --workload S-C --seqs 512 --steps 30 --warmup 4 --cpu-frames 60 --host-steps 0 > $O/bench_config_c.json 2> $O/bench_config_c.err
+python3 bench.py --workload S-C --steps 30 --warmup 4 --cpu-frames 0 --host-steps 0 > $O/bench_config_c_64seq.json 2> $O/bench_config_c_64seq.err
+# kernel stats of configuration C (the workload whose dominant kernel VERDICT r01 asked to halve)
+rm -rf $O/sc_kt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/sc_kt -- python3 bench.py --workload S-C --seqs 512 --steps 10 --warmup 3 --cpu-frames 0 --host-steps 0 > $O/sc_kt.json 2> $O/sc_kt.err
+find $O/sc_kt -name "*kernel_trace.csv" -delete
 python3 tools/kernel_bench.py 256 6 > $O/kernel_bench_isolated.txt 2>&1
+python3 tools/pcie_probe.py > $O/pcie_probe.txt 2>&1
 python3 tools/summarize_profiles.py $O $O/summary_r
-cp $O/bench_mapper.json $O/bench_config_c.json $O/kernel_bench_isolated.txt $O/summary_r/
+cp $O/bench_mapper.json $O/bench_config_c.json $O/bench_config_c_64seq.json $O/kernel_bench_isolated.txt $O/pcie_probe.txt $O/summary_r/
+ks=$(ls -S $O/sc_kt/*/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$ks" ] && cp "$ks" $O/summary_r/kernel_stats_config_c.csv
 ls -la $O/summary_r
