@@ -318,7 +318,7 @@ def main():
     ap.add_argument("--mapper", action="store_true",
                     help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip, -1 = the workload's)")
-    ap.add_argument("--host-steps", type=int, default=8,
+    ap.add_argument("--host-steps", type=int, default=16,
                     help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip")
     args = ap.parse_args()
@@ -512,6 +512,7 @@ def main():
                 ctx.check(lib_hip.sdvl_device_download(ctx.h, C.c_void_p(buf), C.c_int64(B * frame_bytes), C.c_void_p(hbuf.data_ptr() + k * B * frame_bytes)))
             hptrs = (hbuf.data_ptr() + (np.arange(Kh, dtype=np.uint64)[:, None] * B + np.arange(B, dtype=np.uint64)[None, :]) * frame_bytes).astype(np.uint64)
             farm.set_host_input(True)
+            farm.set_input_ring(not os.environ.get("SDVL_BENCH_NO_INPUT_RING"))
             hstats_buf = farm.alloc_stats(Kh)
             barrier()
             t0 = time.perf_counter()
@@ -523,7 +524,8 @@ def main():
             th_all, eh_max = shard.reduce_throughput(tracked_h, elapsed_h, dist if distributed else None, "cuda")
             host_fed = {"value": round(th_all / eh_max, 2), "unit": "frames/s", "steps": Kh, "ms_per_step": round(eh_max / Kh * 1e3, 3),
                         "pcie_h2d_gb_per_s": round(world * B * Kh * frame_bytes / eh_max / 1e9, 2),
-                        "input": "pinned host memory, %d B per frame uploaded inside the step on the group's stream" % frame_bytes}
+                        "input": "pinned host memory, %d B per frame; the images of step s + 1 travel on the group's copy stream into a "
+                                 "2-step input ring in HBM while step s computes (SDVL_BENCH_NO_INPUT_RING=1: uploaded inside the step)" % frame_bytes}
     if cpu_sample is not None:
         fps1, n_tracked1, secs1 = cpu_one
         n_thr = max(1, min(ncpu, 16))

@@ -158,6 +158,14 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
  * descriptor per image: 256 images of 300 KB each cost 256 copy launches otherwise and reach about half the link rate);
  * pageable images fall back to one staged copy each.  The images must stay valid until the stream has passed this point. */
 int sdvl_frames_upload(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const uint8_t *const *imgs, int stride);
+/* Input ring for callers that know their next images early (a camera driver's queue, a farm of sequences): the images travel
+ * on a second stream of the context while the current step computes.
+ *   sdvl_ctx_prefetch_images  n host images (pinned: one gather kernel; pageable: staged copies) -> dev_dst[i] (width x height,
+ *                             dense rows), queued on the context's copy stream; returns at once
+ *   sdvl_ctx_prefetch_fence   work queued on the context's stream from now on starts after everything prefetched so far
+ * The caller owns the destination buffers and must not prefetch into one that queued work may still read. */
+int sdvl_ctx_prefetch_images(sdvl_ctx *ctx, int n, const uint8_t *const *imgs, int stride, int width, int height, void *const *dev_dst);
+int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx);
 /* same, image already in HBM (device pointer) */
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride);
 /* same without the copy: level 0 aliases the caller's HBM image (row stride == width), which must stay valid and

@@ -121,7 +121,7 @@ ABI_SYMBOLS = [
     "sdvl_ctx_create", "sdvl_ctx_destroy", "sdvl_last_error", "sdvl_ctx_synchronize", "sdvl_ctx_stream",
     "sdvl_ctx_bind_thread", "sdvl_ctx_device", "sdvl_pointer_device", "sdvl_ctx_scratch_device",
     "sdvl_ctx_timing_enable", "sdvl_ctx_timing_get", "sdvl_ctx_timing_reset",
-    "sdvl_frame_create", "sdvl_frame_create_many", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frames_upload", "sdvl_frame_set_image_device", "sdvl_frame_borrow_image_device",
+    "sdvl_frame_create", "sdvl_frame_create_many", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frames_upload", "sdvl_ctx_prefetch_images", "sdvl_ctx_prefetch_fence", "sdvl_frame_set_image_device", "sdvl_frame_borrow_image_device",
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
     "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
     "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",

@@ -60,6 +60,12 @@ struct KernelTimer {
 struct sdvl_ctx {
   int device;
   hipStream_t stream;
+  // input ring (sdvl_ctx_prefetch_images / _fence): a second stream that carries the NEXT step's images while this one computes
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_event = nullptr;
+  void *h_prefetch_jobs[2] = {nullptr, nullptr};  // pinned job lists, read by the gather kernel where they are
+  size_t prefetch_jobs_cap = 0;
+  unsigned prefetch_count = 0;
   std::string err;
   // pinned + device staging, grown on demand
   void *h_stage = nullptr; size_t h_stage_bytes = 0;

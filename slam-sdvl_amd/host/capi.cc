@@ -225,6 +225,14 @@ int sdvlh_batch_step_device(void *bp, const void *const *dev_imgs, int stride, s
   return step(b, v, out);
 }
 
+// the same for images in a buffer the caller will overwrite (an input ring): every frame copies its image into its own level 0
+int sdvlh_batch_step_device_copy(void *bp, const void *const *dev_imgs, int stride, sdvlh_frame_stats *out) {
+  Batch *b = static_cast<Batch *>(bp);
+  std::vector<Image> v;
+  for (size_t i = 0; i < b->trackers.size(); i++) v.push_back(Image::WrapDevice(dev_imgs[i], b->w, b->h, stride, false));
+  return step(b, v, out);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Farm: G groups x Bg sequences on ONE GPU.  Every group owns a host thread, an sdvl::Device (= sdvl_ctx = HIP stream
 // + staging + frame pool) and an SDVLBatch; groups free-run through their steps, so the host stages of one group
@@ -248,6 +256,10 @@ struct Farm {
 
   int fibers_per_worker = 1;  // > 1: a worker interleaves that many group-steps, switching at every GPU wait
   bool host_input = false;    // the frame pointers of a run are HOST pointers (pinned): every step uploads its frames
+  // host input travels one step ahead: while a group computes step s, its copy stream carries the images of step s + 1 into the
+  // other half of the group's input ring (2 x Bg frames of HBM); the frames then copy their image out of the ring (HBM -> HBM)
+  bool input_ring = true;
+  std::vector<void *> ring;
 
   // next (group, step) for a worker: the idle group that is furthest behind.  Returns -1 when nothing is left, -2 when
   // every remaining group is busy elsewhere (only with `may_block` false; otherwise it waits for one to come free).
@@ -271,6 +283,32 @@ struct Farm {
     const int total = G * Bg;
     const int s = done[g];  // only the owner of a busy group reads or writes its counter
     const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
+    if (host_input && input_ring && stride == w) {
+      sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(devices[g]));
+      const size_t fb = static_cast<size_t>(w) * h;
+      if (!ring[g] && sdvl_device_malloc(ctx, static_cast<int64_t>(2 * fb * Bg), &ring[g]) != SDVL_OK) {
+        g_err = std::string("input ring: ") + sdvl_last_error(ctx);
+        return -1;
+      }
+      std::vector<void *> dst(Bg);
+      auto prefetch = [&](int step) {
+        uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(step & 1) * Bg * fb;
+        for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
+        const size_t o = static_cast<size_t>(step) * total + static_cast<size_t>(g) * Bg;
+        return sdvl_ctx_prefetch_images(ctx, Bg, reinterpret_cast<const uint8_t *const *>(dev_frames + o), stride, w, h, dst.data());
+      };
+      int rc = SDVL_OK;
+      if (s == 0) rc = prefetch(0);                   // nothing is under way yet
+      if (rc == SDVL_OK) rc = sdvl_ctx_prefetch_fence(ctx);  // this step's kernels start behind its images
+      if (rc == SDVL_OK && s + 1 < n_steps) rc = prefetch(s + 1);  // the half that step s - 1 read: that step is complete
+      if (rc != SDVL_OK) {
+        g_err = std::string("input ring: ") + sdvl_last_error(ctx);
+        return -1;
+      }
+      uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(s & 1) * Bg * fb;
+      for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
+      return sdvlh_batch_step_device_copy(batches[g], dst.data(), stride, out + off);
+    }
     if (host_input) return sdvlh_batch_step_host(batches[g], reinterpret_cast<const uint8_t *const *>(dev_frames + off), stride, out + off);
     return sdvlh_batch_step_device(batches[g], dev_frames + off, stride, out + off);
   }
@@ -478,6 +516,7 @@ void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4
   mallopt(M_MMAP_THRESHOLD, 16 << 20);
   Farm *f = new Farm();
   f->gpu = gpu; f->G = G; f->Bg = Bg; f->w = w; f->h = h;
+  f->ring.assign(G, nullptr);
   for (int g = 0; g < G; g++) {
     void *d = sdvlh_device_create(gpu);
     if (!d) { sdvlh_farm_destroy(f); return nullptr; }
@@ -500,11 +539,15 @@ void sdvlh_farm_set_fibers(void *fp, int n) {
 // the frame pointers handed to sdvlh_farm_run are host pointers (SDVL::HandleFrame(const cv::Mat&) takes a host image,
 // sdvl.cc:55-59): every group uploads its frames on its own stream inside the step
 void sdvlh_farm_set_host_input(void *fp, int on) { static_cast<Farm *>(fp)->host_input = on != 0; }
+// the input ring of host-fed runs on (default) / off (every step uploads its own frames on its own stream before it computes)
+void sdvlh_farm_set_input_ring(void *fp, int on) { static_cast<Farm *>(fp)->input_ring = on != 0; }
 
 void sdvlh_farm_destroy(void *fp) {
   Farm *f = static_cast<Farm *>(fp);
   if (!f) return;
   for (void *b : f->batches) sdvlh_batch_destroy(b);
+  for (size_t g = 0; g < f->ring.size() && g < f->devices.size(); g++)
+    if (f->ring[g]) sdvl_device_free(static_cast<sdvl_ctx *>(sdvlh_device_ctx(f->devices[g])), f->ring[g]);
   for (void *d : f->devices) sdvlh_device_destroy(d);
   delete f;
 }

@@ -559,13 +559,12 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
   for (int i = 0; i < n; i++) {
     if (imgs[i].dev_src && imgs[i].step == imgs[i].cols && imgs[i].borrow)
       dev->Check(sdvl_frame_borrow_image_device(dev->ctx(), devs[i], imgs[i].dev_src), "sdvl_frame_borrow_image_device");
-    else if (imgs[i].dev_src) dev->Check(sdvl_frame_set_image_device(dev->ctx(), devs[i], imgs[i].dev_src, imgs[i].step), "sdvl_frame_set_image_device");
-    else {
+    else {  // host images, and images in HBM that the frame must own a copy of (an input ring the caller overwrites)
       if (!up_f.empty() && (imgs[i].step != up_step || frames[i]->GetWidth() != frames[0]->GetWidth() || frames[i]->GetHeight() != frames[0]->GetHeight()))
         flush();
       up_step = imgs[i].step;
       up_f.push_back(devs[i]);
-      up_i.push_back(imgs[i].data);
+      up_i.push_back(imgs[i].dev_src ? static_cast<const uint8_t *>(imgs[i].dev_src) : imgs[i].data);
     }
   }
   flush();

@@ -235,6 +235,11 @@ class TrackerFarm:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return out
 
+    def set_input_ring(self, on):
+        """host-fed runs: the images of step s + 1 travel on the group's copy stream while step s computes (default on)"""
+        self.lib.sdvlh_farm_set_input_ring.argtypes = [C.c_void_p, C.c_int]
+        self.lib.sdvlh_farm_set_input_ring(self.h, int(bool(on)))
+
     def stage_times(self, reset=False):
         tot, steps = None, 0
         self.lib.sdvlh_batch_stage_times.restype = C.c_long

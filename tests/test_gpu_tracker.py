@@ -202,6 +202,46 @@ def test_farm_fibers_give_identical_results(trk, orc, synth):
     assert all(r[1] == 0 and r[4] >= 100 for r in plain[n:])      # tracking, not idling
 
 
+def test_farm_host_input_ring_gives_identical_results(trk, orc, synth):
+    """host-fed farm: frames in pinned host memory.  With the input ring (the images of step s + 1 travel on the group's copy
+    stream while step s computes; contiguous runs as one DMA, the rest per image) and without it (every step uploads its own
+    frames first) the per-frame results are those of the HBM-resident run"""
+    import importlib
+    import torch
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    G, Bg, n_steps = 3, 4, 6
+    n = G * Bg
+    fb = 640 * 480
+    trk.configure()
+    pinned = torch.empty(n * n_steps * fb + 4096, dtype=torch.uint8, pin_memory=True)
+
+    def run(mode):
+        farm = trk.TrackerFarm(0, G, Bg, 640, 480, TUM_CAM)
+        ctx = B.CtxView(sdvl, farm.ctx_handle(0))
+        buf = ctx.malloc(n * n_steps * fb)
+        for k in range(n_steps):
+            views = [B.make_view(sdvl, trajectory_pose(orc, k, XI * (1.0 + 0.1 * i)), 20260001 + i, k) for i in range(n)]
+            ctx.render(views, buf + k * n * fb)
+        idx = (np.arange(n_steps, dtype=np.uint64)[:, None] * n + np.arange(n, dtype=np.uint64)[None, :])
+        if mode == "resident":
+            ptrs = (buf + idx * fb).astype(np.uint64)
+        else:
+            pinned.numpy()[:n * n_steps * fb] = ctx.download(buf, n * n_steps * fb)
+            ptrs = (pinned.data_ptr() + idx * fb).astype(np.uint64)
+            farm.set_host_input(True)
+            farm.set_input_ring(mode != "no-ring")
+        st = farm.run(ptrs, G)
+        out = [(s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas, tuple(s.pose[:])) for s in st]
+        farm.close()
+        return out
+
+    resident = run("resident")
+    assert run("ring") == resident
+    assert run("no-ring") == resident
+    assert all(r[1] == 0 and r[4] >= 100 for r in resident[n:])
+
+
 def test_farm_at_bench_size_replicas_agree_and_match_the_oracle(trk, orc, synth):
     """The bench configuration (2048 sequences, 16 groups of 128, one worker per group) on 8 distinct sequences replicated
     256 times: where a sequence sits in a group, which group and which stream it runs on must not matter — every replica
