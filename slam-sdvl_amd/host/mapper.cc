@@ -488,13 +488,22 @@ void MapperMap::EmitConnectionsPoints(vector<sdvl_search_req> *reqs) {
   if (best_kfs.empty()) return;
   // the reference collects into a std::set keyed by pointer; here: by point id, unique (see the class comment)
   vector<std::pair<int, shared_ptr<Point>>> ids;
+  // Point::SeenFrom(cur_) (point.cc:180-187) walks the point's feature list; the points cur_ sees are exactly those behind its
+  // own features, so they are stamped once and the test below is one load
+  const int cur_id = cur_->GetID();
+  {
+    vector<shared_ptr<Feature>> &own = cur_->GetFeatures();
+    for (auto it = own.begin(); it != own.end(); it++)
+      if (*it)
+        if (Point *p = (*it)->GetPointRaw()) p->SetSeenStamp(cur_id);
+  }
   for (auto it_kf = best_kfs.begin(); it_kf != best_kfs.end(); it_kf++) {
     vector<shared_ptr<Feature>> &features = (*it_kf)->GetFeatures();
     for (auto it = features.begin(); it != features.end(); it++) {
       if (!*it) continue;
       Point *point = (*it)->GetPointRaw();
       if (!point || point->ToDelete()) continue;
-      if (point->SeenFrom(cur_)) continue;
+      if (point->SeenStamp() == cur_id) continue;
       ids.push_back({point->GetID(), (*it)->GetPoint()});
     }
   }

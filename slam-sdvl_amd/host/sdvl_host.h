@@ -343,6 +343,10 @@ class Point {
   void Update(const std::shared_ptr<Frame> &frame, double depth, double px_error_angle);
   bool HasConverged();
   bool SeenFrom(const std::shared_ptr<Frame> &frame) const;
+  // AddConnectionsPoints asks SeenFrom(current keyframe) for every point of the connected keyframes: the keyframe stamps its own
+  // points once instead (a feature of the keyframe is in its point's list and vice versa)
+  int SeenStamp() const { return seen_stamp_; }
+  void SetSeenStamp(int frame_id) { seen_stamp_ = frame_id; }
   static void ConsumeId();  // what constructing and discarding a Point does to the id counter
   static double ComputeTau(const SE3 &pose, const Vector3d &v, double depth, double px_error_angle);
   static double PDFNormal(double mean, double sd, double x);
@@ -360,6 +364,7 @@ class Point {
   double sigma2_, a_, b_, z_range_;
   double cos_alpha_ = 1.0, last_distance_ = 1.0;
   int track_row_ = -1;
+  int seen_stamp_ = -1;
   bool dev_trashed_ = false;
   std::list<std::shared_ptr<Feature>> features_;
 };
