@@ -160,12 +160,14 @@ int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stri
 int sdvl_frames_upload(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const uint8_t *const *imgs, int stride);
 /* Input ring for callers that know their next images early (a camera driver's queue, a farm of sequences): the images travel
  * on a second stream of the context while the current step computes.
- *   sdvl_ctx_prefetch_images  n host images (pinned: one gather kernel; pageable: staged copies) -> dev_dst[i] (width x height,
- *                             dense rows), queued on the context's copy stream; returns at once
- *   sdvl_ctx_prefetch_fence   work queued on the context's stream from now on starts after everything prefetched so far
+ *   sdvl_ctx_prefetch_images  n host images (dense rows that follow each other in memory on both sides: ONE DMA per run; padded
+ *                             rows in pinned memory: a gather kernel; pageable: staged copies) -> dev_dst[i] (width x height, dense
+ *                             rows), queued on the context's copy stream; returns at once with a ticket (>= 0) or a negative status
+ *   sdvl_ctx_prefetch_fence   work queued on the context's stream from now on starts after the prefetch with this ticket (one of
+ *                             the last four)
  * The caller owns the destination buffers and must not prefetch into one that queued work may still read. */
 int sdvl_ctx_prefetch_images(sdvl_ctx *ctx, int n, const uint8_t *const *imgs, int stride, int width, int height, void *const *dev_dst);
-int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx);
+int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx, int ticket);
 /* same, image already in HBM (device pointer) */
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride);
 /* same without the copy: level 0 aliases the caller's HBM image (row stride == width), which must stay valid and

@@ -332,7 +332,8 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
   }
-  if (ctx->copy_event) (void)hipEventDestroy(ctx->copy_event);
+  for (hipEvent_t e : ctx->copy_event)
+    if (e) (void)hipEventDestroy(e);
   for (void *j : ctx->h_prefetch_jobs)
     if (j) (void)hipHostFree(j);
   (void)hipStreamDestroy(ctx->stream);
@@ -614,13 +615,12 @@ int sdvl_frames_upload(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const ui
 
 // ---- input ring -----------------------------------------------------------------------------------------------------------
 int sdvl_ctx_prefetch_images(sdvl_ctx *ctx, int n, const uint8_t *const *imgs, int stride, int width, int height, void *const *dev_dst) {
-  if (!ctx || n < 0 || (n > 0 && (!imgs || !dev_dst)) || width <= 0 || height <= 0) return SDVL_ERR_INVALID;
-  if (n == 0) return SDVL_OK;
+  if (!ctx || n <= 0 || !imgs || !dev_dst || width <= 0 || height <= 0) return SDVL_ERR_INVALID;
   SDVL_REQUIRE(ctx, stride >= width, "stride smaller than width");
   SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
   if (!ctx->copy_stream) {
     SDVL_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming));
+    for (hipEvent_t &e : ctx->copy_event) SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   if (ctx->prefetch_jobs_cap < static_cast<size_t>(n)) {
     SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));  // nobody reads the old lists any more
@@ -635,8 +635,8 @@ int sdvl_ctx_prefetch_images(sdvl_ctx *ctx, int n, const uint8_t *const *imgs, i
   // ONE copy per run: the DMA engines reach the link rate with transfers of tens of MB (57 GB/s measured against ~30 GB/s for
   // 300 KB pieces or for a kernel pulling the bytes itself), and they take no compute unit from the step that is running.
   const size_t fb = static_cast<size_t>(width) * height;
-  UploadJob *hj = static_cast<UploadJob *>(ctx->h_prefetch_jobs[ctx->prefetch_count & 1u]);  // the list of the call before last: consumed
-  ctx->prefetch_count++;
+  const unsigned ticket = ctx->prefetch_count++;
+  UploadJob *hj = static_cast<UploadJob *>(ctx->h_prefetch_jobs[ticket & 3u]);  // the list of four calls ago: its copy was fenced long since
   int n_mapped = 0;
   for (int i = 0; i < n;) {
     SDVL_REQUIRE(ctx, imgs[i] && dev_dst[i], "null image or destination");
@@ -663,14 +663,16 @@ int sdvl_ctx_prefetch_images(sdvl_ctx *ctx, int n, const uint8_t *const *imgs, i
                        static_cast<const UploadJob *>(ja.devicePointer), width, height, stride);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
   }
-  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->copy_event, ctx->copy_stream));
-  return SDVL_OK;
+  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->copy_event[ticket & 3u], ctx->copy_stream));
+  return static_cast<int>(ticket & 0x3FFFFFFFu);
 }
 
-int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx) {
-  if (!ctx) return SDVL_ERR_INVALID;
-  if (!ctx->copy_event) return SDVL_OK;  // nothing was ever prefetched
-  SDVL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_event, 0));
+int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx, int ticket) {
+  if (!ctx || ticket < 0) return SDVL_ERR_INVALID;
+  const unsigned next = ctx->prefetch_count & 0x3FFFFFFFu, t = static_cast<unsigned>(ticket);
+  SDVL_REQUIRE(ctx, ctx->copy_stream && ((next - t) & 0x3FFFFFFFu) >= 1 && ((next - t) & 0x3FFFFFFFu) <= 4,
+               "sdvl_ctx_prefetch_fence: ticket is not one of the last four prefetches");
+  SDVL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_event[t & 3u], 0));
   return SDVL_OK;
 }
 

@@ -62,8 +62,8 @@ struct sdvl_ctx {
   hipStream_t stream;
   // input ring (sdvl_ctx_prefetch_images / _fence): a second stream that carries the NEXT step's images while this one computes
   hipStream_t copy_stream = nullptr;
-  hipEvent_t copy_event = nullptr;
-  void *h_prefetch_jobs[2] = {nullptr, nullptr};  // pinned job lists, read by the gather kernel where they are
+  hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};  // one per prefetch in flight (ticket & 3)
+  void *h_prefetch_jobs[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned job lists, read by the gather kernel where they are
   size_t prefetch_jobs_cap = 0;
   unsigned prefetch_count = 0;
   std::string err;

@@ -256,10 +256,12 @@ struct Farm {
 
   int fibers_per_worker = 1;  // > 1: a worker interleaves that many group-steps, switching at every GPU wait
   bool host_input = false;    // the frame pointers of a run are HOST pointers (pinned): every step uploads its frames
-  // host input travels one step ahead: while a group computes step s, its copy stream carries the images of step s + 1 into the
-  // other half of the group's input ring (2 x Bg frames of HBM); the frames then copy their image out of the ring (HBM -> HBM)
+  // host input travels ahead: while a group computes step s, its copy stream carries the images of the next steps into the free
+  // slots of the group's input ring (kRingSlots x Bg frames of HBM); the frames then copy their image out of the ring (HBM -> HBM)
   bool input_ring = true;
+  static constexpr int kRingSlots = 2;  // 3 (two steps ahead) measured slower: the transfers of step s + 2 share the link with those of s + 1, which the next step waits for (116 k against 133-145 k frames/s)
   std::vector<void *> ring;
+  std::vector<int> ring_ticket;  // [group][slot]: the prefetch that filled the slot
 
   // next (group, step) for a worker: the idle group that is furthest behind.  Returns -1 when nothing is left, -2 when
   // every remaining group is busy elsewhere (only with `may_block` false; otherwise it waits for one to come free).
@@ -284,29 +286,36 @@ struct Farm {
     const int s = done[g];  // only the owner of a busy group reads or writes its counter
     const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
     if (host_input && input_ring && stride == w) {
+      // a ring of kRingSlots steps: while step s computes, the images of the following kRingSlots - 1 steps are under way
       sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(devices[g]));
       const size_t fb = static_cast<size_t>(w) * h;
-      if (!ring[g] && sdvl_device_malloc(ctx, static_cast<int64_t>(2 * fb * Bg), &ring[g]) != SDVL_OK) {
+      if (!ring[g] && sdvl_device_malloc(ctx, static_cast<int64_t>(kRingSlots * fb * Bg), &ring[g]) != SDVL_OK) {
         g_err = std::string("input ring: ") + sdvl_last_error(ctx);
         return -1;
       }
       std::vector<void *> dst(Bg);
-      auto prefetch = [&](int step) {
-        uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(step & 1) * Bg * fb;
+      auto slot_ptrs = [&](int step) {
+        uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(step % kRingSlots) * Bg * fb;
         for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
+      };
+      auto prefetch = [&](int step) {  // -> ticket, or a negative status
+        slot_ptrs(step);
         const size_t o = static_cast<size_t>(step) * total + static_cast<size_t>(g) * Bg;
-        return sdvl_ctx_prefetch_images(ctx, Bg, reinterpret_cast<const uint8_t *const *>(dev_frames + o), stride, w, h, dst.data());
+        const int t = sdvl_ctx_prefetch_images(ctx, Bg, reinterpret_cast<const uint8_t *const *>(dev_frames + o), stride, w, h, dst.data());
+        if (t >= 0) ring_ticket[static_cast<size_t>(g) * kRingSlots + step % kRingSlots] = t;
+        return t;
       };
       int rc = SDVL_OK;
-      if (s == 0) rc = prefetch(0);                   // nothing is under way yet
-      if (rc == SDVL_OK) rc = sdvl_ctx_prefetch_fence(ctx);  // this step's kernels start behind its images
-      if (rc == SDVL_OK && s + 1 < n_steps) rc = prefetch(s + 1);  // the half that step s - 1 read: that step is complete
-      if (rc != SDVL_OK) {
+      if (s == 0)  // nothing is under way yet
+        for (int a = 0; a < kRingSlots - 1 && a < n_steps && rc >= 0; a++) rc = prefetch(a);
+      // the slot that step s - 1 read is free (that step is complete): the images of step s + kRingSlots - 1 go there
+      if (rc >= 0 && s + kRingSlots - 1 < n_steps) rc = prefetch(s + kRingSlots - 1);
+      if (rc >= 0) rc = sdvl_ctx_prefetch_fence(ctx, ring_ticket[static_cast<size_t>(g) * kRingSlots + s % kRingSlots]);  // this step's kernels start behind its images
+      if (rc < 0) {
         g_err = std::string("input ring: ") + sdvl_last_error(ctx);
         return -1;
       }
-      uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(s & 1) * Bg * fb;
-      for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
+      slot_ptrs(s);
       return sdvlh_batch_step_device_copy(batches[g], dst.data(), stride, out + off);
     }
     if (host_input) return sdvlh_batch_step_host(batches[g], reinterpret_cast<const uint8_t *const *>(dev_frames + off), stride, out + off);
@@ -517,6 +526,7 @@ void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4
   Farm *f = new Farm();
   f->gpu = gpu; f->G = G; f->Bg = Bg; f->w = w; f->h = h;
   f->ring.assign(G, nullptr);
+  f->ring_ticket.assign(static_cast<size_t>(G) * Farm::kRingSlots, -1);
   for (int g = 0; g < G; g++) {
     void *d = sdvlh_device_create(gpu);
     if (!d) { sdvlh_farm_destroy(f); return nullptr; }
