@@ -318,9 +318,10 @@ def main():
     ap.add_argument("--mapper", action="store_true",
                     help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip, -1 = the workload's)")
-    ap.add_argument("--host-steps", type=int, default=16,
+    ap.add_argument("--host-steps", type=int, default=-1,
                     help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
-                         "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip")
+                         "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
+                         "default 16 on one GPU, 0 on several (every rank would pin 20 GB of host memory)")
     args = ap.parse_args()
     global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS
     wl = WORKLOADS[args.workload]
@@ -345,6 +346,8 @@ def main():
             raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: one rank per GPU (torch.distributed.run --nproc-per-node N bench.py "
                              "--gpus N, or plain `python bench.py --gpus N`, which starts the ranks itself)" % (world, args.gpus))
     distributed = world > 1
+    if args.host_steps < 0:
+        args.host_steps = 16 if world == 1 else 0
     dist = None
     if dry:
         return dry_rank(args, rank, world)
