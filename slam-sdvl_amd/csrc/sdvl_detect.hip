@@ -195,6 +195,61 @@ __device__ __forceinline__ int fast_corner_best(const uint8_t *tile, int pitch_b
   return max(max(t, v - min_x), max_n - v);
 }
 
+
+// ---- the score of TWO horizontally adjacent pixels per lane on packed halves -------------------------------------------------
+// gfx950 has three-input packed min / max on f16 pairs (v_pk_minimum3_f16 / v_pk_maximum3_f16).  Grey levels 0..255 and their
+// differences are exact in f16, so the ring windows of fast_corner_best run on pixel PAIRS: the tile is kept a second time
+// as halves (kPitchHW words per row, pixel x at half 4 + x), the pair (x, x+1) with x odd reads its ring as 20 aligned words
+// — position (dx, dy) of both pixels is the word at half x + dx for odd dx, and two neighbouring words funnel-shifted by 16
+// bits for even dx — and every min3 / max3 serves two pixels: 32 + 32 + 16 packed operations instead of 2 x 88 scalar ones.
+constexpr int kPitchHW = 26;  // LDS row pitch of the half tile in 32-bit words: 4 + 32 + 16 halves (26: the 13 pairs of a row and the rows below them fall on different banks; 24 cost 29 % extra LDS cycles)
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 pk_min3(h2 a, h2 b, h2 c) {
+  h2 d;
+  asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ h2 pk_max3(h2 a, h2 b, h2 c) {
+  h2 d;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ h2 as_h2(uint32_t w) { return __builtin_bit_cast(h2, w); }
+// the two halves that straddle the words lo | hi: (hi : lo) >> 16
+__device__ __forceinline__ h2 mid_h2(uint32_t hi, uint32_t lo) { return as_h2(__builtin_amdgcn_alignbit(hi, lo, 16)); }
+
+// w = word of the half tile at (tile row of ring row -3, halves x-3 | x-2) for the pair (x, x+1), x odd; t2 = (t, t).
+// Returns (best(x), best(x+1)) with best as in fast_corner_best.
+__device__ __forceinline__ h2 fast_pair_best(const uint32_t *w, h2 t2) {
+#define SDVL_HW(DY, K) w[((DY) + 3) * kPitchHW + (K)]  // K = (dx + 3) / 2 for odd dx: halves (x + dx, x + dx + 1)
+  const uint32_t a1 = SDVL_HW(3, 1), a2 = SDVL_HW(3, 2), b1 = SDVL_HW(-3, 1), b2 = SDVL_HW(-3, 2);
+  const uint32_t c0 = SDVL_HW(2, 0), c1 = SDVL_HW(2, 1), c2 = SDVL_HW(2, 2), c3 = SDVL_HW(2, 3);
+  const uint32_t d0 = SDVL_HW(-2, 0), d1 = SDVL_HW(-2, 1), d2 = SDVL_HW(-2, 2), d3 = SDVL_HW(-2, 3);
+  const uint32_t z1 = SDVL_HW(0, 1), z2 = SDVL_HW(0, 2);
+  // cv::FAST offsets16: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+  const h2 e0 = mid_h2(a2, a1), e1 = as_h2(a2), e2 = mid_h2(c3, c2), e3 = as_h2(SDVL_HW(1, 3)), e4 = as_h2(SDVL_HW(0, 3)),
+           e5 = as_h2(SDVL_HW(-1, 3)), e6 = mid_h2(d3, d2), e7 = as_h2(b2), e8 = mid_h2(b2, b1), e9 = as_h2(b1), e10 = mid_h2(d1, d0),
+           e11 = as_h2(SDVL_HW(-1, 0)), e12 = as_h2(SDVL_HW(0, 0)), e13 = as_h2(SDVL_HW(1, 0)), e14 = mid_h2(c1, c0), e15 = as_h2(a1);
+  const h2 v = mid_h2(z2, z1);
+#undef SDVL_HW
+#define SDVL_W3(K, A, B, C) const h2 n##K = pk_min3(e##A, e##B, e##C), x##K = pk_max3(e##A, e##B, e##C);
+  SDVL_W3(0, 0, 1, 2) SDVL_W3(1, 1, 2, 3) SDVL_W3(2, 2, 3, 4) SDVL_W3(3, 3, 4, 5) SDVL_W3(4, 4, 5, 6) SDVL_W3(5, 5, 6, 7)
+  SDVL_W3(6, 6, 7, 8) SDVL_W3(7, 7, 8, 9) SDVL_W3(8, 8, 9, 10) SDVL_W3(9, 9, 10, 11) SDVL_W3(10, 10, 11, 12) SDVL_W3(11, 11, 12, 13)
+  SDVL_W3(12, 12, 13, 14) SDVL_W3(13, 13, 14, 15) SDVL_W3(14, 14, 15, 0) SDVL_W3(15, 15, 0, 1)
+#undef SDVL_W3
+#define SDVL_W9(K, A, B, C) const h2 N##K = pk_min3(n##A, n##B, n##C), X##K = pk_max3(x##A, x##B, x##C);
+  SDVL_W9(0, 0, 3, 6) SDVL_W9(1, 1, 4, 7) SDVL_W9(2, 2, 5, 8) SDVL_W9(3, 3, 6, 9) SDVL_W9(4, 4, 7, 10) SDVL_W9(5, 5, 8, 11)
+  SDVL_W9(6, 6, 9, 12) SDVL_W9(7, 7, 10, 13) SDVL_W9(8, 8, 11, 14) SDVL_W9(9, 9, 12, 15) SDVL_W9(10, 10, 13, 0) SDVL_W9(11, 11, 14, 1)
+  SDVL_W9(12, 12, 15, 2) SDVL_W9(13, 13, 0, 3) SDVL_W9(14, 14, 1, 4) SDVL_W9(15, 15, 2, 5)
+#undef SDVL_W9
+  const h2 max_n = pk_max3(pk_max3(pk_max3(N0, N1, N2), pk_max3(N3, N4, N5), pk_max3(N6, N7, N8)),
+                           pk_max3(pk_max3(N9, N10, N11), pk_max3(N12, N13, N14), N15), N15);
+  const h2 min_x = pk_min3(pk_min3(pk_min3(X0, X1, X2), pk_min3(X3, X4, X5), pk_min3(X6, X7, X8)),
+                           pk_min3(pk_min3(X9, X10, X11), pk_min3(X12, X13, X14), X15), X15);
+  return pk_max3(t2, v - min_x, max_n - v);
+}
+
 // exclusive rank of (lane, bit k) in lane-major order over the wave for the 4-bit flag sets `flags`, and the wave total
 __device__ __forceinline__ int wave_rank4(uint32_t flags, int *wave_total) {
   int below = 0, total = 0;
@@ -212,7 +267,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   // ROI tile with room for a 3-row / 4-byte halo.  The halo is never initialised: every value that decides something
   // is read within 3 px of a tested pixel, i.e. inside the ROI; halo bytes only flow into results that are masked out.
   __shared__ uint32_t s_img[(kTile + 2 * kPadRows) * kPitchW];
+  __shared__ uint32_t s_imgh[(kTile + 2 * kPadRows) * kPitchHW];  // the same tile as halves, for the pair path
   __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // scores of the corners, 0 elsewhere inside the ROI
+  __shared__ uint32_t s_scoreh[(kTile + 2) * kPitchHW];  // the same as halves (pair path: the 3x3 suppression runs on pairs too)
   __shared__ uint16_t s_list[kTile * kTile];           // (row << 5 | x) of the pixels that pass the compass pre-test
   __shared__ int s_wave_tot[4];
   __shared__ int s_keep_tot[3][4];
@@ -220,7 +277,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   // Workgroups go to the 8 XCDs round-robin by linear id; gridDim.x is a multiple of 32, so XCD = blockIdx.x % 8.  Within
   // every run of 32 cells an XCD gets 4 horizontally adjacent ones: a cell row is 32 bytes, so the 4 cells share their
   // 128-byte lines and find them in ONE L2 instead of fetching them once per XCD — and every XCD still sees the same mix
-  // of full and margin-clipped cells.
+  // of full and margin-clipped cells.  (One workgroup looping over its 4 cells was measured: 385 µs against 318 per 256
+  // frames — the cells of a workgroup then run one after the other with barriers in between, and nothing hides them.)
   const int total_cells = lv.cell_begin[lv.n_levels];
   const int gcell = static_cast<int>(blockIdx.x & ~31u) + static_cast<int>(blockIdx.x & 7u) * 4 + static_cast<int>((blockIdx.x >> 3) & 3u);
   if (gcell >= total_cells) return;
@@ -253,6 +311,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     }
     s_img[(row + kPadRows) * kPitchW + 1 + wq] = pack;
     s_score[(row + 1) * kPitchW + 1 + wq] = 0;
+    for (int z = tid; z < (kTile + 2) * kPitchHW; z += 256) s_scoreh[z] = 0;
+    {  // pixels cg .. cg+3 as halves 4 + cg .. : words 2 + 2 wq and the next (round-toward-zero is exact for 0..255)
+      const auto lo = __builtin_amdgcn_cvt_pkrtz(static_cast<float>(pack & 0xFFu), static_cast<float>((pack >> 8) & 0xFFu));
+      const auto hi = __builtin_amdgcn_cvt_pkrtz(static_cast<float>((pack >> 16) & 0xFFu), static_cast<float>(pack >> 24));
+      uint2 hw;
+      hw.x = __builtin_bit_cast(uint32_t, lo);
+      hw.y = __builtin_bit_cast(uint32_t, hi);
+      *reinterpret_cast<uint2 *>(&s_imgh[(row + kPadRows) * kPitchHW + 2 + 2 * wq]) = hw;
+    }
   }
   __syncthreads();
   const int t = lv.threshold;
@@ -277,14 +344,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     dense = 2 * (sum & 0xFFFF) > (sum >> 16);
     __syncthreads();  // s_wave_tot is written again below
   }
-  int ncand;
-  int dense_tw = 1, dense_inv = 0;
+  int ncand;                 // candidates of phase C: pixels (sparse path) or pixel pairs (dense path)
+  int dense_npr = 1, dense_inv = 0;
   if (dense) {
-    // every tested pixel (rows 3 .. rh-4, columns 3 .. rw-4) is a candidate, in scan order: candidate q = (q / tw, q % tw)
-    dense_tw = rw - 6;
-    ncand = dense_tw > 0 && rh > 6 ? dense_tw * (rh - 6) : 0;
-    dense_tw = dense_tw > 0 ? dense_tw : 1;
-    dense_inv = (65536 + dense_tw - 1) / dense_tw;  // q / tw == (q * inv) >> 16 for q < 1024, tw <= 26
+    // every tested pixel (rows 3 .. rh-4, columns 3 .. rw-4) is a candidate, two per lane: pair q = (row q / npr, columns
+    // 3 + 2 (q % npr) and the next), in scan order
+    const int tw = rw - 6;
+    dense_npr = tw > 0 ? (tw + 1) >> 1 : 1;
+    ncand = tw > 0 && rh > 6 ? dense_npr * (rh - 6) : 0;
+    dense_inv = (65536 + dense_npr - 1) / dense_npr;  // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13
   } else {
     // ---- phase A: compass pre-test of the thread's 4 pixels
     uint32_t cflags = 0;
@@ -318,34 +386,48 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     }
     __syncthreads();
   }
-  // ---- phase C: one candidate per lane gets the 16-pixel arithmetic, which yields the segment test AND the score
+  // ---- phase C: the 16-pixel arithmetic, which yields the segment test AND the score — one candidate pixel per lane and
+  // pass (sparse), or one pixel PAIR per lane and pass on packed halves (dense).  Slot (ps, k): pass ps, pixel k of the pair.
   uint8_t *score_bytes = reinterpret_cast<uint8_t *>(s_score);
   const uint8_t *img_bytes = reinterpret_cast<const uint8_t *>(s_img);
-  const int npass = (ncand + 255) >> 8;  // <= 3 (26 x 26 tested pixels)
-  int rc_of[3], sc_of[3];
+  const int npass = (ncand + 255) >> 8;  // <= 3 (sparse: 26 x 26 tested pixels; dense: 13 x 26 pairs -> 2)
+  int rc_of[3][2], sc_of[3][2];
 #pragma unroll
   for (int ps = 0; ps < 3; ps++) {
-    rc_of[ps] = 0;
-    sc_of[ps] = 0;
+    rc_of[ps][0] = rc_of[ps][1] = 0;
+    sc_of[ps][0] = sc_of[ps][1] = 0;
     if (ps < npass) {
       const int i = ps * 256 + tid;
       if (i < ncand) {
-        int r, x;
         if (dense) {
-          const int qr = (i * dense_inv) >> 16;
-          r = qr + 3;
-          x = i - qr * dense_tw + 3;
+          const int qr = (i * dense_inv) >> 16, j = i - qr * dense_npr;
+          const int r = qr + 3, x = 3 + 2 * j;
+          const _Float16 th = static_cast<_Float16>(t);
+          const h2 best2 = fast_pair_best(&s_imgh[r * kPitchHW + 2 + j], h2{th, th});  // tile row r = ring row -3 of image row r
+          const int b0 = static_cast<int>(static_cast<float>(best2.x)), b1 = static_cast<int>(static_cast<float>(best2.y));
+          _Float16 *score_halves = reinterpret_cast<_Float16 *>(s_scoreh) + (r + 1) * (kPitchHW * 2) + 4 + x;
+          if (b0 > t) {
+            const int sc = (b0 - 1) & 0xFF;  // uchar like OpenCV's score buffer
+            score_halves[0] = static_cast<_Float16>(sc);
+            rc_of[ps][0] = (r << 5) | x;
+            sc_of[ps][0] = sc;
+          }
+          if (b1 > t && x + 1 < rw - 3) {
+            const int sc = (b1 - 1) & 0xFF;
+            score_halves[1] = static_cast<_Float16>(sc);
+            rc_of[ps][1] = (r << 5) | (x + 1);
+            sc_of[ps][1] = sc;
+          }
         } else {
           const int rc = s_list[i];
-          r = rc >> 5;
-          x = rc & 31;
-        }
-        const int best = fast_corner_best(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
-        if (best > t) {
-          const int sc = (best - 1) & 0xFF;  // uchar like OpenCV's score buffer
-          score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>(sc);
-          rc_of[ps] = (r << 5) | x;
-          sc_of[ps] = sc;
+          const int r = rc >> 5, x = rc & 31;
+          const int best = fast_corner_best(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
+          if (best > t) {
+            const int sc = (best - 1) & 0xFF;
+            score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>(sc);
+            rc_of[ps][0] = rc;
+            sc_of[ps][0] = sc;
+          }
         }
       }
     }
@@ -356,33 +438,55 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
 #pragma unroll
   for (int ps = 0; ps < 3; ps++) {
     if (ps < npass) {
-      const int sc = sc_of[ps];
-      bool ok = false;
-      if (sc) {
-        const int r = rc_of[ps] >> 5, x = rc_of[ps] & 31;
-        const uint8_t *q = score_bytes + (r + 1) * (kPitchW * 4) + 4 + x;
-        const int pb = kPitchW * 4;
-        ok = sc > q[-1] && sc > q[1] && sc > q[-pb - 1] && sc > q[-pb] && sc > q[-pb + 1] && sc > q[pb - 1] && sc > q[pb] && sc > q[pb + 1];
+      bool ok0 = false, ok1 = false;
+      if (dense) {
+        // both pixels of the pair at once: the maximum over the 8 neighbours of each, three packed max3 per row of neighbours
+        const int sc0 = sc_of[ps][0], sc1 = sc_of[ps][1];
+        if (sc0 | sc1) {
+          const int rc = sc0 ? rc_of[ps][0] : rc_of[ps][1] - 1;  // (row, x of the pair's first pixel)
+          const int r = rc >> 5, x = rc & 31;
+          const uint32_t *sw = &s_scoreh[(r + 1) * kPitchHW + ((x + 3) >> 1)];  // halves (x-1 | x); the next word (x+1 | x+2)
+          const uint32_t u0 = sw[-kPitchHW], u1 = sw[-kPitchHW + 1], c0 = sw[0], c1 = sw[1], d0 = sw[kPitchHW], d1 = sw[kPitchHW + 1];
+          const h2 up = pk_max3(as_h2(u0), mid_h2(u1, u0), as_h2(u1)), dn = pk_max3(as_h2(d0), mid_h2(d1, d0), as_h2(d1));
+          const h2 m = pk_max3(up, dn, pk_max3(as_h2(c0), as_h2(c1), as_h2(c1)));  // same row: left neighbours (x-1 | x), right (x+1 | x+2)
+          ok0 = sc0 > static_cast<int>(static_cast<float>(m.x));
+          ok1 = sc1 > static_cast<int>(static_cast<float>(m.y));
+        }
+      } else {
+        const int sc = sc_of[ps][0];
+        if (sc) {
+          const int r = rc_of[ps][0] >> 5, x = rc_of[ps][0] & 31;
+          const uint8_t *q = score_bytes + (r + 1) * (kPitchW * 4) + 4 + x;
+          const int pb = kPitchW * 4;
+          ok0 = sc > q[-1] && sc > q[1] && sc > q[-pb - 1] && sc > q[-pb] && sc > q[-pb + 1] && sc > q[pb - 1] && sc > q[pb] && sc > q[pb + 1];
+        }
       }
-      if (ok) keep |= 1u << ps;
-      const unsigned long long m = __ballot(ok);
-      if (lane == 0) s_keep_tot[ps][wave] = __popcll(m);
+      if (ok0) keep |= 1u << (2 * ps);
+      if (ok1) keep |= 1u << (2 * ps + 1);
+      const int cnt = __popcll(__ballot(ok0)) + __popcll(__ballot(ok1));
+      if (lane == 0) s_keep_tot[ps][wave] = cnt;
     }
   }
   __syncthreads();
-  // survivors in list order = row-major order = cv::FAST's output order
+  // survivors in candidate order (pass, lane, pixel of the pair) = row-major order = cv::FAST's output order
   uint32_t *out = job.cell_kps + static_cast<size_t>(gcell) * SDVL_CELL_KP_CAP;
   int base = 0;
 #pragma unroll
   for (int ps = 0; ps < 3; ps++) {
     if (ps < npass) {
-      const bool ok = (keep >> ps) & 1u;
-      const unsigned long long m = __ballot(ok);
-      int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+      const bool ok0 = (keep >> (2 * ps)) & 1u, ok1 = (keep >> (2 * ps + 1)) & 1u;
+      const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+      int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m0 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m0), 0)) +
+                __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m1 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m1), 0));
       for (int w = 0; w < wave; w++) pos += s_keep_tot[ps][w];
-      if (ok && pos < SDVL_CELL_KP_CAP) {
-        const int r = rc_of[ps] >> 5, x = rc_of[ps] & 31;
-        out[pos] = static_cast<uint32_t>(x0 + x) | (static_cast<uint32_t>(y0 + r) << 12) | (static_cast<uint32_t>(sc_of[ps]) << 24);
+      if (ok0 && pos < SDVL_CELL_KP_CAP) {
+        const int r = rc_of[ps][0] >> 5, x = rc_of[ps][0] & 31;
+        out[pos] = static_cast<uint32_t>(x0 + x) | (static_cast<uint32_t>(y0 + r) << 12) | (static_cast<uint32_t>(sc_of[ps][0]) << 24);
+      }
+      pos += ok0 ? 1 : 0;
+      if (ok1 && pos < SDVL_CELL_KP_CAP) {
+        const int r = rc_of[ps][1] >> 5, x = rc_of[ps][1] & 31;
+        out[pos] = static_cast<uint32_t>(x0 + x) | (static_cast<uint32_t>(y0 + r) << 12) | (static_cast<uint32_t>(sc_of[ps][1]) << 24);
       }
       base += s_keep_tot[ps][0] + s_keep_tot[ps][1] + s_keep_tot[ps][2] + s_keep_tot[ps][3];
     }
