@@ -271,14 +271,15 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // scores of the corners, 0 elsewhere inside the ROI
   __shared__ uint32_t s_scoreh[(kTile + 2) * kPitchHW];  // the same as halves (pair path: the 3x3 suppression runs on pairs too)
   __shared__ uint16_t s_list[kTile * kTile];           // (row << 5 | x) of the pixels that pass the compass pre-test
-  __shared__ int s_wave_tot[4];
+  __shared__ int s_wave_tot[4], s_probe[4];
   __shared__ int s_keep_tot[3][4];
   const FastJob &job = jobs[blockIdx.y];  // by reference: a by-value copy indexed with the runtime level lands in scratch
   // Workgroups go to the 8 XCDs round-robin by linear id; gridDim.x is a multiple of 32, so XCD = blockIdx.x % 8.  Within
   // every run of 32 cells an XCD gets 4 horizontally adjacent ones: a cell row is 32 bytes, so the 4 cells share their
   // 128-byte lines and find them in ONE L2 instead of fetching them once per XCD — and every XCD still sees the same mix
-  // of full and margin-clipped cells.  (One workgroup looping over its 4 cells was measured: 385 µs against 318 per 256
-  // frames — the cells of a workgroup then run one after the other with barriers in between, and nothing hides them.)
+  // of full and margin-clipped cells.  (One workgroup looping over its 4 cells was measured, also with the next cell's tile
+  // prefetched into registers: 385-392 µs against 318 per 256 frames — the cells of a workgroup then run one after the other
+  // with barriers in between, and independent workgroups fill those gaps better than a loop does.)
   const int total_cells = lv.cell_begin[lv.n_levels];
   const int gcell = static_cast<int>(blockIdx.x & ~31u) + static_cast<int>(blockIdx.x & 7u) * 4 + static_cast<int>((blockIdx.x >> 3) & 3u);
   if (gcell >= total_cells) return;
@@ -338,11 +339,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
       passed = fast_compass_pass(q[0], q[3 * kPitchW * 4], q[3], q[-3 * kPitchW * 4], q[-3], t);
     }
     const unsigned long long mp = __ballot(probed), mq = __ballot(passed);
-    if (lane == 0) s_wave_tot[wave] = (__popcll(mp) << 16) | __popcll(mq);
+    if (lane == 0) s_probe[wave] = (__popcll(mp) << 16) | __popcll(mq);
     __syncthreads();
-    const int sum = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    const int sum = s_probe[0] + s_probe[1] + s_probe[2] + s_probe[3];
     dense = 2 * (sum & 0xFFFF) > (sum >> 16);
-    __syncthreads();  // s_wave_tot is written again below
   }
   int ncand;                 // candidates of phase C: pixels (sparse path) or pixel pairs (dense path)
   int dense_npr = 1, dense_inv = 0;
