@@ -73,11 +73,23 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrJob *__restrict_
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < rows * kPyrTW; idx += 256) {
-    const int r = idx / kPyrTW, x = idx - r * kPyrTW;
-    if (x < nx) {
-      const uint8_t *s = s_bytes + r * kPyrPitch + 2 + 2 * x;  // source columns 2*(tx0+x) - 2 .. + 2
-      s_h[r][x] = static_cast<uint16_t>(s[0] + s[4] + 4 * (s[1] + s[3]) + 6 * s[2]);
+  // horizontal 1-4-6-4-1 for two adjacent outputs per lane on packed 16-bit lanes (sums <= 255 * 16): outputs x, x+1 read source
+  // bytes 2x .. 2x+6 of the row = the last two bytes of word x/2, word x/2 + 1, the first byte of word x/2 + 2
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  for (int idx = tid; idx < rows * (kPyrTW / 2); idx += 256) {
+    const int r = idx / (kPyrTW / 2), xp = idx - r * (kPyrTW / 2);
+    if (2 * xp < nx) {
+      const uint32_t *w = &s_srcw[r * (kPyrSWW + 1) + xp];
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+      // v_perm_b32: selector bytes 0-3 name bytes of the second operand, 4-7 of the first, 0x0c a zero byte
+      const u16x2 p02 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c040c02u));
+      const u16x2 p13 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c050c03u));
+      const u16x2 p24 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c060c04u));
+      const u16x2 p35 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c070c05u));
+      const u16x2 p46 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w2, w1, 0x0c040c02u));
+      const u16x2 four = {4, 4}, six = {6, 6};
+      const u16x2 h = p02 + p46 + four * (p13 + p35) + six * p24;
+      *reinterpret_cast<uint32_t *>(&s_h[r][2 * xp]) = __builtin_bit_cast(uint32_t, h);
     }
   }
   __syncthreads();
@@ -85,26 +97,27 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrJob *__restrict_
     const int y = tid >> 4, x = (tid & 15) * 4;
     const int oy = ty0 + y, ox = tx0 + x;
     if (oy < job.dh && ox < job.dw) {
-      int acc[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) acc[k] = 0;
+      // vertical pass on the same packed lanes: sums <= 4080 * 16 = 65280, + 128 still fits 16 bits
+      u16x2 a01 = {0, 0}, a23 = {0, 0};
 #pragma unroll
       for (int t = 0; t < 5; t++) {
-        const int wgt = (t == 0 || t == 4) ? 1 : (t == 2 ? 6 : 4);
+        const unsigned short wg = (t == 0 || t == 4) ? 1 : (t == 2 ? 6 : 4);
+        const u16x2 wgt = {wg, wg};
         const uint2 hv = *reinterpret_cast<const uint2 *>(&s_h[2 * y + t][x]);
-        acc[0] += wgt * static_cast<int>(hv.x & 0xFFFFu);
-        acc[1] += wgt * static_cast<int>(hv.x >> 16);
-        acc[2] += wgt * static_cast<int>(hv.y & 0xFFFFu);
-        acc[3] += wgt * static_cast<int>(hv.y >> 16);
+        a01 += wgt * __builtin_bit_cast(u16x2, hv.x);
+        a23 += wgt * __builtin_bit_cast(u16x2, hv.y);
       }
+      const u16x2 half = {128, 128};
+      a01 = (a01 + half) >> 8;
+      a23 = (a23 + half) >> 8;
+      int acc[4] = {a01.x, a01.y, a23.x, a23.y};
       uint8_t *d = job.dst + static_cast<size_t>(oy) * job.dw + ox;
       if (ox + 3 < job.dw && (reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
-        *reinterpret_cast<uint32_t *>(d) = static_cast<uint32_t>((acc[0] + 128) >> 8) | (static_cast<uint32_t>((acc[1] + 128) >> 8) << 8) |
-                                           (static_cast<uint32_t>((acc[2] + 128) >> 8) << 16) | (static_cast<uint32_t>((acc[3] + 128) >> 8) << 24);
+        *reinterpret_cast<uint32_t *>(d) = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, a23), __builtin_bit_cast(uint32_t, a01), 0x06040200u);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          if (ox + k < job.dw) d[k] = static_cast<uint8_t>((acc[k] + 128) >> 8);
+          if (ox + k < job.dw) d[k] = static_cast<uint8_t>(acc[k]);
       }
     }
   }
