@@ -318,6 +318,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   if (ctx->h_flag) (void)hipHostFree(const_cast<uint32_t *>(ctx->h_flag));
   if (ctx->d_nits) (void)hipFree(ctx->d_nits);
   if (ctx->d_registry) (void)hipFree(ctx->d_registry);
+  if (ctx->d_fast_table) (void)hipFree(ctx->d_fast_table);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_search) (void)hipHostFree(ctx->h_search);
   if (ctx->d_search) (void)hipFree(ctx->d_search);

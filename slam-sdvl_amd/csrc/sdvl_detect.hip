@@ -131,6 +131,11 @@ struct FastLevels {
   int cell_size, margin, threshold;
 };
 
+struct CellGeo {  // one cell of the detection grid: pyramid level and the ROI left after the image margin (fast_detector.cc:84-92)
+  int16_t x0, y0, rw, rh;  // rw <= 0: the margin swallows the cell
+  int32_t level;
+};
+
 struct FastJob {
   const uint8_t *level[4];
   int lw[4], lh[4];
@@ -276,13 +281,13 @@ __device__ __forceinline__ int wave_rank4(uint32_t flags, int *wave_total) {
   return below;
 }
 
-__global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restrict__ jobs, FastLevels lv) {
+__global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restrict__ jobs, FastLevels lv, const CellGeo *__restrict__ cells) {
   // ROI tile with room for a 3-row / 4-byte halo.  The halo is never initialised: every value that decides something
   // is read within 3 px of a tested pixel, i.e. inside the ROI; halo bytes only flow into results that are masked out.
   __shared__ uint32_t s_img[(kTile + 2 * kPadRows) * kPitchW];
   __shared__ uint32_t s_imgh[(kTile + 2 * kPadRows) * kPitchHW];  // the same tile as halves, for the pair path
   __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // scores of the corners, 0 elsewhere inside the ROI
-  __shared__ uint32_t s_scoreh[(kTile + 2) * kPitchHW];  // the same as halves (pair path: the 3x3 suppression runs on pairs too)
+  __shared__ __attribute__((aligned(16))) uint32_t s_scoreh[(kTile + 2) * kPitchHW];  // the same as halves (pair path: the 3x3 suppression runs on pairs too)
   __shared__ uint16_t s_list[kTile * kTile];           // (row << 5 | x) of the pixels that pass the compass pre-test
   __shared__ int s_wave_tot[4], s_probe[4];
   __shared__ int s_keep_tot[3][4];
@@ -296,19 +301,18 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   const int total_cells = lv.cell_begin[lv.n_levels];
   const int gcell = static_cast<int>(blockIdx.x & ~31u) + static_cast<int>(blockIdx.x & 7u) * 4 + static_cast<int>((blockIdx.x >> 3) & 3u);
   if (gcell >= total_cells) return;
-  int l = 0;
-  while (l + 1 < lv.n_levels && gcell >= lv.cell_begin[l + 1]) l++;
-  const int c = gcell - lv.cell_begin[l];
-  const int ci = c / lv.wcells[l], cj = c - ci * lv.wcells[l];
-  const int W = job.lw[l], H = job.lh[l];
-  const int y0 = max(lv.margin, ci * lv.cell_size), y1 = min(H - lv.margin, ci * lv.cell_size + lv.cell_size);
-  const int x0 = max(lv.margin, cj * lv.cell_size), x1 = min(W - lv.margin, cj * lv.cell_size + lv.cell_size);
+  // level and clipped ROI of the cell come from a table computed once per frame shape on the host: the level search, the
+  // division by the grid width and the margin clipping were ~100 dependent scalar instructions at the head of every workgroup
+  const CellGeo geo = cells[gcell];
   const int tid = threadIdx.x;
-  if (y1 <= y0 || x1 <= x0) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
+  if (geo.rw <= 0) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
     if (tid == 0) job.cell_counts[gcell] = 0;
     return;
   }
-  const int rw = x1 - x0, rh = y1 - y0;  // <= 32
+  const int l = geo.level;
+  const int W = job.lw[l];
+  const int x0 = geo.x0, y0 = geo.y0;
+  const int rw = geo.rw, rh = geo.rh;  // <= 32
   const uint8_t *img = job.level[l];
   const int row = tid >> 3, wq = tid & 7, cg = wq * 4;
   {
@@ -324,8 +328,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
       }
     }
     s_img[(row + kPadRows) * kPitchW + 1 + wq] = pack;
-    s_score[(row + 1) * kPitchW + 1 + wq] = 0;
-    for (int z = tid; z < (kTile + 2) * kPitchHW; z += 256) s_scoreh[z] = 0;
+    static_assert(((kTile + 2) * kPitchHW) % 4 == 0 && (kTile + 2) * kPitchHW / 4 <= 256, "one 16-byte store per thread clears the plane");
+    if (tid < (kTile + 2) * kPitchHW / 4) reinterpret_cast<uint4 *>(s_scoreh)[tid] = make_uint4(0u, 0u, 0u, 0u);
     {  // pixels cg .. cg+3 as halves 4 + cg .. : words 2 + 2 wq and the next (round-toward-zero is exact for 0..255)
       const auto lo = __builtin_amdgcn_cvt_pkrtz(static_cast<float>(pack & 0xFFu), static_cast<float>((pack >> 8) & 0xFFu));
       const auto hi = __builtin_amdgcn_cvt_pkrtz(static_cast<float>((pack >> 16) & 0xFFu), static_cast<float>(pack >> 24));
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     ncand = tw > 0 && rh > 6 ? dense_npr * (rh - 6) : 0;
     dense_inv = (65536 + dense_npr - 1) / dense_npr;  // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13
   } else {
+    s_score[(row + 1) * kPitchW + 1 + wq] = 0;  // the byte score plane of this path; two barriers lie between here and its first use
     // ---- phase A: compass pre-test of the thread's 4 pixels
     uint32_t cflags = 0;
     if (row >= 3 && row < rh - 3) {
@@ -1325,6 +1330,44 @@ int sdvl_fast_num_cells(int width, int height, const sdvl_detect_params *p, int 
   return SDVL_OK;
 }
 
+// the per-cell geometry table of fast_cells_kernel for this frame shape and grid, built once and kept in HBM
+static int fast_cell_table(sdvl_ctx *ctx, const FastLevels &lv, const sdvl_frame *f0, const CellGeo **out) {
+  const int total = lv.cell_begin[lv.n_levels];
+  long long key = f0->width;
+  key = key * 8191 + f0->height;
+  key = key * 8191 + lv.n_levels;
+  key = key * 8191 + lv.cell_size;
+  key = key * 8191 + lv.margin;
+  if (ctx->d_fast_table && ctx->fast_table_key == key && ctx->fast_table_cells == total) {
+    *out = static_cast<const CellGeo *>(ctx->d_fast_table);
+    return SDVL_OK;
+  }
+  std::vector<CellGeo> t(total);
+  for (int l = 0; l < lv.n_levels; l++) {
+    const int W = f0->v.lw[l], H = f0->v.lh[l];
+    for (int c = 0; c < lv.cell_begin[l + 1] - lv.cell_begin[l]; c++) {
+      const int ci = c / lv.wcells[l], cj = c - ci * lv.wcells[l];
+      const int y0 = std::max(lv.margin, ci * lv.cell_size), y1 = std::min(H - lv.margin, ci * lv.cell_size + lv.cell_size);
+      const int x0 = std::max(lv.margin, cj * lv.cell_size), x1 = std::min(W - lv.margin, cj * lv.cell_size + lv.cell_size);
+      CellGeo &g = t[lv.cell_begin[l] + c];
+      const bool empty = y1 <= y0 || x1 <= x0;
+      g.x0 = static_cast<int16_t>(x0); g.y0 = static_cast<int16_t>(y0);
+      g.rw = static_cast<int16_t>(empty ? 0 : x1 - x0); g.rh = static_cast<int16_t>(empty ? 0 : y1 - y0);
+      g.level = l;
+    }
+  }
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a launch in flight may still read the old table
+  if (ctx->d_fast_table) (void)hipFree(ctx->d_fast_table);
+  ctx->d_fast_table = nullptr;
+  SDVL_HIP_CHECK(ctx, hipMalloc(&ctx->d_fast_table, sizeof(CellGeo) * static_cast<size_t>(total > 0 ? total : 1)));
+  if (total > 0) SDVL_HIP_CHECK(ctx, hipMemcpy(ctx->d_fast_table, t.data(), sizeof(CellGeo) * static_cast<size_t>(total), hipMemcpyHostToDevice));
+  ctx->fast_table_key = key;
+  ctx->fast_table_cells = total;
+  *out = static_cast<const CellGeo *>(ctx->d_fast_table);
+  return SDVL_OK;
+}
+
 int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_detect_params *p, int cap,
                     sdvl_keypoint *out_kps, int32_t *out_cell_offsets) {
   if (!ctx || !p || n < 0 || (n > 0 && (!frames || !out_kps || !out_cell_offsets))) return SDVL_ERR_INVALID;
@@ -1378,7 +1421,12 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, job_bytes, hipMemcpyHostToDevice, ctx->stream));
   int32_t *d_offs = static_cast<int32_t *>(ctx->d_out);
   uint32_t *d_kps = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->d_out) + offs_bytes);
-  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv);
+  const CellGeo *d_cells = nullptr;
+  {
+    const int rc_t = fast_cell_table(ctx, lv, frames[0], &d_cells);
+    if (rc_t) return rc_t;
+  }
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv, d_cells);
   SDVL_LAUNCH(ctx, "compact_cells", compact_cells_kernel, dim3(n), dim3(256), static_cast<const FastJob *>(dsx), total_cells, cap, d_kps, d_offs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   int32_t *h_offs = static_cast<int32_t *>(ctx->h_out);
@@ -1498,7 +1546,12 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst, hst, fj_bytes + sj_bytes, hipMemcpyHostToDevice, ctx->stream));
   const FastJob *df = static_cast<const FastJob *>(dst);
   const SelJob *ds = reinterpret_cast<const SelJob *>(static_cast<uint8_t *>(dst) + fj_bytes);
-  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv);
+  const CellGeo *d_cells = nullptr;
+  {
+    const int rc_t = fast_cell_table(ctx, lv, frames[0], &d_cells);
+    if (rc_t) return rc_t;
+  }
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv, d_cells);
   SDVL_LAUNCH(ctx, "select_corners", select_corners_kernel, dim3(lv.n_levels, n), dim3(kSelThreads), ds, sl);
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
   // writes them into device memory and, when results go direct, into the pinned host array as well

@@ -60,6 +60,10 @@ struct KernelTimer {
 struct sdvl_ctx {
   int device;
   hipStream_t stream;
+  // fast_cells_kernel's per-cell geometry (level, clipped ROI) for the last frame shape / grid seen, resident in HBM
+  void *d_fast_table = nullptr;
+  long long fast_table_key = -1;
+  int fast_table_cells = 0;
   // input ring (sdvl_ctx_prefetch_images / _fence): a second stream that carries the NEXT step's images while this one computes
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};  // one per prefetch in flight (ticket & 3)
