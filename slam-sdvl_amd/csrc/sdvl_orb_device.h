@@ -18,6 +18,40 @@ __constant__ __attribute__((aligned(16))) int8_t c_orb_pattern[256 * 4] = {
 };
 
 
+// the same pattern as floats: the steered sample coordinates are float products of these (no int8 -> float conversion per test)
+__constant__ __attribute__((aligned(16))) float c_orb_pattern_f[256 * 4] = {
+#include "orb_pattern_31.inc"
+};
+
+// Intensity centroid: task t = (row v = t / 8 - 15, four-pixel segment u0 = -16 + 4 (t % 8)) of the radius-15 disc.  Per task
+// two byte-coefficient words for v_dot4_u32_u8: `m` = 1 where the pixel lies inside the disc (|u| <= umax[|v|],
+// orb_detector.cc:325-348), `a` = (u + 16) there — sum u p = dot(p, a) - 16 dot(p, m), sum v p = v dot(p, m): exact int32
+struct OrbMomentTable {
+  uint32_t a[256], m[256];
+};
+constexpr OrbMomentTable make_orb_moment_table() {
+  OrbMomentTable t{};
+  constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  for (int task = 0; task < 256; task++) {
+    uint32_t a = 0, m = 0;
+    if (task < 248) {
+      const int v = (task >> 3) - 15, u0 = -16 + 4 * (task & 7);
+      const int um = umax[v < 0 ? -v : v];
+      for (int k = 0; k < 4; k++) {
+        const int u = u0 + k;
+        if ((u < 0 ? -u : u) <= um) {
+          a |= static_cast<uint32_t>(u + 16) << (8 * k);
+          m |= 1u << (8 * k);
+        }
+      }
+    }
+    t.a[task] = a;
+    t.m[task] = m;
+  }
+  return t;
+}
+__constant__ OrbMomentTable c_orb_moments = make_orb_moment_table();
+
 __device__ __forceinline__ int orb_wave_sum_i32(int v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -60,20 +94,12 @@ __device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W
     const int task = lane + 64 * r;
     if (task < 248) {
       const int v = (task >> 3) - 15, u0 = -16 + 4 * (task & 7);
-      const int av = v < 0 ? -v : v;
-      // umax = {15,15,15,15,14,14,14,13, 13,12,11,10,9,8,6,3}
-      const int um = static_cast<int>(((av < 8 ? 0xDEEEFFFFu : 0x3689ABCDu) >> (4 * (av & 7))) & 15u);
       uint32_t w;
       __builtin_memcpy(&w, center + v * W + u0, 4);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int u = u0 + k;
-        if ((u < 0 ? -u : u) <= um) {
-          const int p = static_cast<int>((w >> (8 * k)) & 0xFFu);
-          m10 += u * p;
-          m01 += v * p;
-        }
-      }
+      const int sp = static_cast<int>(__builtin_amdgcn_udot4(w, c_orb_moments.m[task], 0u, false));   // sum of the pixels inside the disc
+      const int sup = static_cast<int>(__builtin_amdgcn_udot4(w, c_orb_moments.a[task], 0u, false));  // sum of (u + 16) p
+      m10 += sup - 16 * sp;
+      m01 += v * sp;
     }
   }
   m10 = orb_wave_sum_i32(m10);
@@ -86,15 +112,13 @@ __device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W
   const float a = static_cast<float>(cs_d);
   const float b = static_cast<float>(sn_d);
   // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..); its 16 pattern bytes come in one 128-bit load
-  const uint4 pw = reinterpret_cast<const uint4 *>(c_orb_pattern)[lane];
-  const uint32_t pq[4] = {pw.x, pw.y, pw.z, pw.w};
+  const float4 *pf = reinterpret_cast<const float4 *>(c_orb_pattern_f) + 4 * lane;
   uint32_t nib = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int x0 = static_cast<int8_t>(pq[q] & 0xFF), y0 = static_cast<int8_t>((pq[q] >> 8) & 0xFF);
-    const int x1 = static_cast<int8_t>((pq[q] >> 16) & 0xFF), y1 = static_cast<int8_t>(pq[q] >> 24);
-    const int t0 = center[cv_round_f(x0 * b + y0 * a) * W + cv_round_f(x0 * a - y0 * b)];
-    const int t1 = center[cv_round_f(x1 * b + y1 * a) * W + cv_round_f(x1 * a - y1 * b)];
+    const float4 t = pf[q];  // x0, y0, x1, y1 of test 4 lane + q
+    const int t0 = center[cv_round_f(t.x * b + t.y * a) * W + cv_round_f(t.x * a - t.y * b)];
+    const int t1 = center[cv_round_f(t.z * b + t.w * a) * W + cv_round_f(t.z * a - t.w * b)];
     nib |= (t0 < t1 ? 1u : 0u) << q;
   }
   *angle_deg_out = angle_deg;
