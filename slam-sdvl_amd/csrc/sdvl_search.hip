@@ -58,11 +58,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ int wave_sum_i32(int v) { return orb_wave_sum_i32(v); }  // DPP row adds + row broadcasts (sdvl_orb_device.h)
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
