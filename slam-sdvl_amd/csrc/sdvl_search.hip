@@ -147,7 +147,10 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
 #pragma unroll 8
         for (int k = 0; k < 64; k++) acc -= L.prod[lane][k];
       }
-      J0 = __shfl(acc, 0, 64); J1 = __shfl(acc, 1, 64); J2 = __shfl(acc, 2, 64);
+      const int acc_bits = __builtin_bit_cast(int, acc);  // lanes 0..2 hold the three sums: one v_readlane each
+      J0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(acc_bits, 0));
+      J1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(acc_bits, 1));
+      J2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(acc_bits, 2));
       wave_sync();
     }
     const float up0 = inv[0][0] * J0 + inv[0][1] * J1 + inv[0][2] * J2;
