@@ -320,6 +320,13 @@ bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs, vector<sdvl_depth_
   req_base_ = static_cast<int>(reqs->size());
   bool any = false;
   const size_t n_cand = candidates_.size();
+  const Rigid &cp = cur_->GetPose().pod();
+  const M3 cur_R = se3_rot(cp);
+  const V3 cur_t = cp.t;
+  const V3 cur_w = cur_->GetWorldPose().pod().t;
+  const Frame *ref_cached = nullptr;
+  M3 ref_R = cur_R;
+  V3 ref_t = cur_t;
   for (size_t k = 0; k < n_cand; k++) {
     // the loop walks Point -> first Feature -> its keyframe, three dependent loads per candidate scattered over the heap:
     // ask for them a few candidates ahead
@@ -336,13 +343,41 @@ bool MapperMap::EmitCandidates(vector<sdvl_search_req> *reqs, vector<sdvl_depth_
     // the checks that precede SearchPoint (map.cc:421-452): decided here, acted upon in ApplyCandidates — nothing the
     // decision depends on can change in between (a point appears once per pass)
     if (!point->ToDelete()) {
-      const Vector3d pos = point->GetPosition();
-      if (!cur_->IsPointVisible(pos)) {
+      Feature *feature = point->GetInitFeatureRaw();
+      Frame *f0 = feature->GetFrameRaw();
+      // Point::GetPosition (point.cc:128-142) with the rotation matrix of the first observation's keyframe kept from the
+      // previous candidate (neighbouring candidates share their keyframe), Frame::IsPointVisible (frame.cc:105-113) with the
+      // current frame's: the same statements (se3_apply = R p + t), the quaternion -> matrix conversion once instead of twice
+      // per candidate
+      if (f0 != ref_cached) {
+        const Rigid &wp = f0->GetWorldPose().pod();
+        ref_R = se3_rot(wp);
+        ref_t = wp.t;
+        ref_cached = f0;
+      }
+      V3 pos;
+      if (point->IsFixed()) {
+        const Vector3d p = point->GetPosition();
+        pos = {p(0), p(1), p(2)};
+      } else {
+        const Vector3d &v = feature->GetVector();
+        const double sc = 1.0 / point->GetInverseDepth();
+        pos = vadd(mvec(ref_R, {sc * v(0), sc * v(1), sc * v(2)}), ref_t);
+      }
+      bool visible = false;
+      {
+        const V3 rel = vadd(mvec(cur_R, pos), cur_t);
+        if (!(rel.z < 0.0)) {
+          Vector2d image_p;
+          camera_->Project(Vector3d(rel.x, rel.y, rel.z), &image_p);
+          visible = camera_->IsInsideImage(Vector2i(static_cast<int>(image_p(0)), static_cast<int>(image_p(1))));
+        }
+      }
+      if (!visible) {
         w.state = kInvisible;
       } else {
-        Feature *feature = point->GetInitFeatureRaw();
-        Frame *f0 = feature->GetFrameRaw();
-        const double distance = cur_->DistanceTo(*f0);
+        const V3 dw = {cur_w.x - ref_t.x, cur_w.y - ref_t.y, cur_w.z - ref_t.z};  // Frame::DistanceTo(frame), frame.h:129-131
+        const double distance = vnorm(dw);
         if (distance / depth_mean_ < 0.01) {
           w.state = kTooClose;
         } else {

@@ -2639,8 +2639,8 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
         }
         begin[M] = total;
         states.clear();
-        res.assign(std::max<size_t>(total, 1), sdvl_search_res());
-        fout.assign(std::max<size_t>(filter ? total : 0, 1), sdvl_depth_out());
+        res.resize(std::max<size_t>(total, 1));   // every record is written by the call below (no clearing pass over MBs)
+        fout.resize(std::max<size_t>(filter ? total : 0, 1));
         if (total > 0) {
           sdvl_ctx *ctx = dev_->ctx();
           sdvl_search_req_packed *packed = nullptr;
