@@ -629,6 +629,7 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
   for (size_t k = 0; k < best_kfs_.size(); k++) {
     shared_ptr<Frame> cframe = best_kfs_[k];
     cframe->SetSelected(true);
+    kf_scan_.clear();
     const double distance = cur_->DistanceTo(*cframe);
     if (distance / depth_mean_ < 0.01) continue;
     for (int count = 0; count < nc; count++) {
@@ -649,12 +650,23 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
       const int level = r.level;
       bool mfound = false;
       vector<shared_ptr<Feature>> &features = cframe->GetFeatures();
+      // positions and liveness of the keyframe's features in one contiguous array (built once per keyframe, extended when a
+      // feature is added below): the scan runs for every found seed, and walking Feature -> Point each time is a cache miss apiece
+      if (kf_scan_.empty() && !features.empty()) {
+        kf_scan_.reserve(features.size() + 64);
+        for (size_t q = 0; q < features.size(); q++) {
+          const Feature *fq = features[q].get();
+          const Point *praw = fq ? fq->GetPointRaw() : nullptr;
+          KfScan e;
+          e.x = fq ? fq->GetPosition()(0) : 0.0;
+          e.y = fq ? fq->GetPosition()(1) : 0.0;
+          e.live = praw && !praw->ToDelete();
+          kf_scan_.push_back(e);
+        }
+      }
       for (size_t q = 0; q < features.size() && !mfound; q++) {  // index loop: AddFeature below may grow the vector
-        const Feature *fq = features[q].get();
-        if (!fq) continue;
-        const Point *praw = fq->GetPointRaw();
-        if (!praw || praw->ToDelete()) continue;
-        const double d1 = imgpos(0) - fq->GetPosition()(0), d2 = imgpos(1) - fq->GetPosition()(1);
+        if (!kf_scan_[q].live) continue;
+        const double d1 = imgpos(0) - kf_scan_[q].x, d2 = imgpos(1) - kf_scan_[q].y;
         if (std::sqrt(d1 * d1 + d2 * d2) < 1.0) {  // Distance2D, extra/utils.cc:222-226
           shared_ptr<Point> point = features[q]->GetPoint();
           feature->SetPoint(point);
@@ -679,6 +691,7 @@ void MapperMap::ApplyInitCandidates(const sdvl_search_res *res_all) {
       candidate->AddFeature(feature);
       feature->SetPoint(candidate);
       cframe->AddFeature(feature2);
+      kf_scan_.push_back(KfScan{feature2->GetPosition()(0), feature2->GetPosition()(1), true});
       candidate->AddFeature(feature2);
       feature2->SetPoint(candidate);
       imatches[count] = true;

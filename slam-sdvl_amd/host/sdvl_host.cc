@@ -1913,7 +1913,20 @@ bool SDVLBatch::BuildTable(SDVL &t) {
   size_t hcap = 64;
   while (hcap < features.size() * 2) hcap *= 2;
   hash.assign(hcap, Slot{nullptr, -1});
-  for (auto &ftp : features) {
+  const size_t n_features = features.size();
+  for (size_t fi = 0; fi < n_features; fi++) {
+    // Feature -> Point -> first Feature -> keyframe: four dependent loads per row, asked for a few features ahead
+    if (fi + 8 < n_features) __builtin_prefetch(features[fi + 8].get());
+    if (fi + 4 < n_features && features[fi + 4]) {
+      const Point *p4 = features[fi + 4]->GetPointRaw();
+      __builtin_prefetch(p4);
+      if (p4) __builtin_prefetch(reinterpret_cast<const char *>(p4) + 64);
+    }
+    if (fi + 2 < n_features && features[fi + 2]) {
+      const Point *p2 = features[fi + 2]->GetPointRaw();
+      if (p2) __builtin_prefetch(p2->GetInitFeatureRaw());
+    }
+    const shared_ptr<Feature> &ftp = features[fi];
     Feature *ft = ftp.get();
     sdvl_track_feature f;
     if (!ft) return false;

@@ -686,6 +686,8 @@ class MapperMap : public PlaneMap {
   std::vector<std::shared_ptr<Frame>> best_kfs_;
   std::vector<int> ic_req_;                                // InitCandidates: request of (kf k, filtered corner c) or -1
   std::vector<std::shared_ptr<Feature>> ic_feature_;
+  struct KfScan { double x, y; bool live; };
+  std::vector<KfScan> kf_scan_;                            // InitCandidates: a connected keyframe's features as the seed loop scans them
   std::vector<sdvl_search_req> ic_proto_;                  // InitCandidates: the request of filtered corner c without its keyframe
   std::thread thread_;
   std::atomic<bool> running_{false};
