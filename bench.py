@@ -514,8 +514,8 @@ def main():
                 ctx.render(views, buf)
                 ctx.check(lib_hip.sdvl_device_download(ctx.h, C.c_void_p(buf), C.c_int64(B * frame_bytes), C.c_void_p(hbuf.data_ptr() + k * B * frame_bytes)))
             hptrs = (hbuf.data_ptr() + (np.arange(Kh, dtype=np.uint64)[:, None] * B + np.arange(B, dtype=np.uint64)[None, :]) * frame_bytes).astype(np.uint64)
-            farm.set_host_input(True)
             farm.set_input_ring(not os.environ.get("SDVL_BENCH_NO_INPUT_RING"))
+            farm.set_host_input(True)     # allocates the groups' input rings
             hstats_buf = farm.alloc_stats(Kh)
             barrier()
             t0 = time.perf_counter()

@@ -548,7 +548,18 @@ void sdvlh_farm_set_fibers(void *fp, int n) {
 
 // the frame pointers handed to sdvlh_farm_run are host pointers (SDVL::HandleFrame(const cv::Mat&) takes a host image,
 // sdvl.cc:55-59): every group uploads its frames on its own stream inside the step
-void sdvlh_farm_set_host_input(void *fp, int on) { static_cast<Farm *>(fp)->host_input = on != 0; }
+void sdvlh_farm_set_host_input(void *fp, int on) {
+  Farm *f = static_cast<Farm *>(fp);
+  f->host_input = on != 0;
+  if (!f->host_input || !f->input_ring) return;
+  // the input rings are allocated here, not inside the first host-fed step (hipMalloc synchronises the device)
+  const size_t fb = static_cast<size_t>(f->w) * f->h;
+  for (int g = 0; g < f->G; g++)
+    if (!f->ring[g]) {
+      sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(f->devices[g]));
+      if (sdvl_device_malloc(ctx, static_cast<int64_t>(Farm::kRingSlots * fb * f->Bg), &f->ring[g]) != SDVL_OK) f->ring[g] = nullptr;  // StepGroup retries and reports
+    }
+}
 // the input ring of host-fed runs on (default) / off (every step uploads its own frames on its own stream before it computes)
 void sdvlh_farm_set_input_ring(void *fp, int on) { static_cast<Farm *>(fp)->input_ring = on != 0; }
 
