@@ -50,10 +50,11 @@ def test_pyramid_bit_exact(ctx, orc, shape):
 
 
 # ------------------------------------------------------------------------------------------------ K2
-def check_fast(ctx, sdvl, orc, imgs, margin=19, thr=10):
+def check_fast(ctx, sdvl, orc, imgs, margin=19, thr=10, cell=32):
     dp = sdvl.default_detect_params()
-    dp.margin, dp.fast_threshold = margin, thr
+    dp.margin, dp.fast_threshold, dp.cell_size = margin, thr, cell
     orc.params.fast_threshold = thr
+    orc.params.cell_size = cell
     orc.params.use_orb = 1 if margin == 19 else 0
     try:
         fr = [ctx.frame(im) for im in imgs]
@@ -73,7 +74,39 @@ def check_fast(ctx, sdvl, orc, imgs, margin=19, thr=10):
         return total
     finally:
         orc.params.fast_threshold = 10
+        orc.params.cell_size = 32
         orc.params.use_orb = 1
+
+
+def sparse_corner_image(seed, h, w):
+    """a smooth ramp with a few hundred small bright / dark squares and discs: corners on a few % of the pixels at most, the
+    regime of a real camera frame (the synthetic plane and white noise put a corner on every second pixel)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (60 + 0.1 * xx + 0.08 * yy).astype(np.float64)
+    for _ in range(500):
+        x, y, r = int(rng.integers(4, w - 12)), int(rng.integers(4, h - 12)), int(rng.integers(2, 7))
+        val = float(rng.choice([-45, -30, 30, 45, 70]))
+        if rng.random() < 0.5:
+            img[y:y + r, x:x + r] += val
+        else:
+            img[(yy - y) ** 2 + (xx - x) ** 2 <= r * r] += val
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_fast_cells_sparse_corners_and_other_cell_sizes(ctx, sdvl, orc):
+    """the two paths of fast_cells_kernel — candidate list (few corners) and pixel pairs on packed halves (dense texture) —
+    on images of both kinds and on cell sizes other than 32 (odd tested widths, pairs whose second pixel is not tested)"""
+    sparse = sparse_corner_image(3, 480, 640)
+    dense = rand_img(8, 480, 640)
+    n_sparse = check_fast(ctx, sdvl, orc, [sparse])
+    assert 200 < n_sparse < 30000, n_sparse                      # a few corners per cell, not hundreds
+    mixed = sparse.copy()
+    mixed[:, 320:] = dense[:, 320:]                                # cells of both kinds in one frame, and cells that straddle the seam
+    assert check_fast(ctx, sdvl, orc, [mixed, sparse], margin=5, thr=20) > 1000
+    for cell in (30, 31):      # what the per-frame cell-list capacity admits at 640x480 besides 32 (smaller cells: SDVL_ERR_CAPACITY)
+        assert check_fast(ctx, sdvl, orc, [mixed], cell=cell) > 1000, cell
+        assert check_fast(ctx, sdvl, orc, [dense], margin=5, thr=30, cell=cell) > 1000, cell
 
 
 def test_fast_cells_bit_exact_synthetic(ctx, sdvl, orc, synth):
