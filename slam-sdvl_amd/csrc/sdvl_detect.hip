@@ -339,28 +339,27 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
       *reinterpret_cast<uint2 *>(&s_imgh[(row + kPadRows) * kPitchHW + 2 + 2 * wq]) = hw;
     }
   }
-  __syncthreads();
   const int t = lv.threshold;
   const int lane = tid & 63, wave = tid >> 6;
-  // ---- density probe: the compass pre-test on ONE pixel per thread (a quarter of the tile, the column rotating with the row).
+  if (wave == 0) {
+    const int tw = rw - 6, th = rh - 6;
+    bool probed = false, passed = false;
+    if (tw > 0 && th > 0) {
+      const int pr = 3 + ((lane >> 3) * th >> 3), px = 3 + ((lane & 7) * tw >> 3);
+      const uint8_t *q = img + static_cast<size_t>(y0 + pr) * W + x0 + px;
+      probed = true;
+      passed = fast_compass_pass(q[0], q[3 * W], q[3], q[-3 * W], q[-3], t);
+    }
+    const unsigned long long mp = __ballot(probed), mq = __ballot(passed);
+    if (lane == 0) s_probe[0] = 2 * __popcll(mq) > __popcll(mp) ? 1 : 0;
+  }
+  __syncthreads();
+  // ---- density probe (wave 0, before the barrier above): the compass pre-test on an 8 x 8 sample of the tested pixels, read
+  // straight from the image while the tile is on its way, so the vote rides on the tile's barrier instead of costing one.
   // Where most pixels pass it — dense texture: on the synthetic plane 83 % of the tested pixels pass and 48 % are corners —
   // listing the survivors buys nothing, and the tile is scored densely instead (phases A and B skipped).  Both paths yield the
   // same corners and scores; the probe only chooses the cheaper one.
-  bool dense;
-  {
-    bool probed = false, passed = false;
-    const int x = cg + (row & 3);
-    if (row >= 3 && row < rh - 3 && x >= 3 && x < rw - 3) {
-      probed = true;
-      const uint8_t *q = reinterpret_cast<const uint8_t *>(s_img) + (row + kPadRows) * (kPitchW * 4) + 4 + x;
-      passed = fast_compass_pass(q[0], q[3 * kPitchW * 4], q[3], q[-3 * kPitchW * 4], q[-3], t);
-    }
-    const unsigned long long mp = __ballot(probed), mq = __ballot(passed);
-    if (lane == 0) s_probe[wave] = (__popcll(mp) << 16) | __popcll(mq);
-    __syncthreads();
-    const int sum = s_probe[0] + s_probe[1] + s_probe[2] + s_probe[3];
-    dense = 2 * (sum & 0xFFFF) > (sum >> 16);
-  }
+  const bool dense = s_probe[0] != 0;
   int ncand;                 // candidates of phase C: pixels (sparse path) or pixel pairs (dense path)
   int dense_npr = 1, dense_inv = 0;
   if (dense) {
