@@ -510,6 +510,243 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   }
   if (tid == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
 }
+
+// ---- one WAVE per cell ---------------------------------------------------------------------------------------------------
+// The same work as fast_cells_kernel with a 64-lane workgroup: no s_barrier anywhere (the lanes of one wave hand data over
+// through LDS behind a wave fence), no cross-wave prefix sums (ranks come from ballots and a running base), the probe's vote
+// is a ballot, and only the tile / score planes of the chosen path are written: 7.5 KB of LDS per cell instead of 13 KB and
+// four wave slots.  A workgroup of four waves spent most of its life waiting — job record, geometry, tile, four barriers —
+// and held four wave slots while it did; one wave per cell holds one, so four times as many cells are in flight per CU.
+__device__ __forceinline__ void fc_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kFcDenseWords = (kTile + 2 * kPadRows) * kPitchHW + (kTile + 2) * kPitchHW;          // half tile + half scores: 1872
+constexpr int kFcSparseWords = (kTile + 2 * kPadRows) * kPitchW + (kTile + 2) * kPitchW + kTile * kTile / 2;  // byte tile + byte scores + list
+static_assert(kFcSparseWords <= kFcDenseWords, "the sparse layout lives inside the dense one");
+static_assert(((kTile + 2 * kPadRows) * kPitchHW * 4) % 16 == 0, "the half score plane is cleared with 16-byte stores");
+
+__global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__restrict__ jobs, FastLevels lv, const CellGeo *__restrict__ cells) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_mem[kFcDenseWords];
+  const FastJob &job = jobs[blockIdx.y];
+  const int total_cells = lv.cell_begin[lv.n_levels];
+  // XCD placement as in fast_cells_kernel: 4 horizontally adjacent cells per XCD and run of 32
+  const int gcell = static_cast<int>(blockIdx.x & ~31u) + static_cast<int>(blockIdx.x & 7u) * 4 + static_cast<int>((blockIdx.x >> 3) & 3u);
+  if (gcell >= total_cells) return;
+  const CellGeo geo = cells[gcell];
+  const int lane = threadIdx.x;
+  if (geo.rw <= 0) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
+    if (lane == 0) job.cell_counts[gcell] = 0;
+    return;
+  }
+  const int l = geo.level;
+  const int W = job.lw[l];
+  const int x0 = geo.x0, y0 = geo.y0;
+  const int rw = geo.rw, rh = geo.rh;  // <= 32
+  const uint8_t *img = job.level[l];
+  const int t = lv.threshold;
+  // ---- density probe: compass pre-test on an 8 x 8 sample of the tested pixels, straight from the image
+  bool dense;
+  {
+    const int tw = rw - 6, th = rh - 6;
+    bool probed = false, passed = false;
+    if (tw > 0 && th > 0) {
+      const int pr = 3 + ((lane >> 3) * th >> 3), px = 3 + ((lane & 7) * tw >> 3);
+      const uint8_t *q = img + static_cast<size_t>(y0 + pr) * W + x0 + px;
+      probed = true;
+      passed = fast_compass_pass(q[0], q[3 * W], q[3], q[-3 * W], q[-3], t);
+    }
+    dense = 2 * __popcll(__ballot(passed)) > __popcll(__ballot(probed));
+  }
+  // ---- the tile: lane = (row, half row): 16 pixels = 4 words, so that (lane, word, byte) order is scan order
+  const int row = lane >> 1, wbase = (lane & 1) * 4;
+  uint32_t pk[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int cg = (wbase + k) * 4;
+    uint32_t pack = 0;
+    if (row < rh && cg < rw) {
+      const uint8_t *src = img + static_cast<size_t>(y0 + row) * W + x0 + cg;
+      if (cg + 4 <= rw && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {
+        pack = *reinterpret_cast<const uint32_t *>(src);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (cg + b < rw) pack |= static_cast<uint32_t>(src[b]) << (8 * b);
+      }
+    }
+    pk[k] = pack;
+  }
+  uint32_t *out = job.cell_kps + static_cast<size_t>(gcell) * SDVL_CELL_KP_CAP;
+  int base = 0;  // survivors written so far, in cv::FAST's output order (row-major)
+  if (dense) {
+    uint32_t *s_imgh = s_mem;
+    uint32_t *s_scoreh = s_mem + (kTile + 2 * kPadRows) * kPitchHW;
+    for (int z = lane; z < (kTile + 2) * kPitchHW / 4; z += 64) reinterpret_cast<uint4 *>(s_scoreh)[z] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // pixels as halves: pixel x at half 4 + x
+      const uint32_t pack = pk[k];
+      const auto lo = __builtin_amdgcn_cvt_pkrtz(static_cast<float>(pack & 0xFFu), static_cast<float>((pack >> 8) & 0xFFu));
+      const auto hi = __builtin_amdgcn_cvt_pkrtz(static_cast<float>((pack >> 16) & 0xFFu), static_cast<float>(pack >> 24));
+      uint2 hw;
+      hw.x = __builtin_bit_cast(uint32_t, lo);
+      hw.y = __builtin_bit_cast(uint32_t, hi);
+      *reinterpret_cast<uint2 *>(&s_imgh[(row + kPadRows) * kPitchHW + 2 + 2 * (wbase + k)]) = hw;
+    }
+    fc_wave_sync();
+    const int tw = rw - 6;
+    const int npr = tw > 0 ? (tw + 1) >> 1 : 1;
+    const int ncand = tw > 0 && rh > 6 ? npr * (rh - 6) : 0;   // pixel pairs, <= 13 x 26 = 338
+    const int inv = (65536 + npr - 1) / npr;                   // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13
+    const int npass = (ncand + 63) >> 6;                       // <= 6
+    const _Float16 th = static_cast<_Float16>(t);
+    uint32_t found[6][2];  // corner of slot (pass, pixel of the pair): score << 10 | row << 5 | x, 0 = none
+#pragma unroll
+    for (int ps = 0; ps < 6; ps++) {
+      found[ps][0] = found[ps][1] = 0u;
+      if (ps < npass) {
+        const int i = ps * 64 + lane;
+        if (i < ncand) {
+          const int qr = (i * inv) >> 16, j = i - qr * npr;
+          const int r = qr + 3, x = 3 + 2 * j;
+          const h2 best2 = fast_pair_best(&s_imgh[r * kPitchHW + 2 + j], h2{th, th});
+          const int b0 = static_cast<int>(static_cast<float>(best2.x)), b1 = static_cast<int>(static_cast<float>(best2.y));
+          _Float16 *score_halves = reinterpret_cast<_Float16 *>(s_scoreh) + (r + 1) * (kPitchHW * 2) + 4 + x;
+          if (b0 > t) {
+            const int sc = (b0 - 1) & 0xFF;  // uchar like OpenCV's score buffer
+            score_halves[0] = static_cast<_Float16>(sc);
+            found[ps][0] = static_cast<uint32_t>((sc << 10) | (r << 5) | x);
+          }
+          if (b1 > t && x + 1 < rw - 3) {
+            const int sc = (b1 - 1) & 0xFF;
+            score_halves[1] = static_cast<_Float16>(sc);
+            found[ps][1] = static_cast<uint32_t>((sc << 10) | (r << 5) | (x + 1));
+          }
+        }
+      }
+    }
+    fc_wave_sync();
+    // 3x3 strict non-max suppression on the pairs and ordered output, pass by pass
+#pragma unroll
+    for (int ps = 0; ps < 6; ps++) {
+      if (ps < npass) {
+        const uint32_t f0 = found[ps][0], f1 = found[ps][1];
+        bool ok0 = false, ok1 = false;
+        if (f0 | f1) {
+          const int rc = f0 ? static_cast<int>(f0 & 1023u) : static_cast<int>(f1 & 1023u) - 1;  // (row, x of the pair's first pixel)
+          const int r = rc >> 5, x = rc & 31;
+          const uint32_t *sw = &s_scoreh[(r + 1) * kPitchHW + ((x + 3) >> 1)];  // halves (x-1 | x); the next word (x+1 | x+2)
+          const uint32_t u0 = sw[-kPitchHW], u1 = sw[-kPitchHW + 1], c0 = sw[0], c1 = sw[1], d0 = sw[kPitchHW], d1 = sw[kPitchHW + 1];
+          const h2 up = pk_max3(as_h2(u0), mid_h2(u1, u0), as_h2(u1)), dn = pk_max3(as_h2(d0), mid_h2(d1, d0), as_h2(d1));
+          const h2 m = pk_max3(up, dn, pk_max3(as_h2(c0), as_h2(c1), as_h2(c1)));
+          ok0 = static_cast<int>(f0 >> 10) > static_cast<int>(static_cast<float>(m.x));
+          ok1 = static_cast<int>(f1 >> 10) > static_cast<int>(static_cast<float>(m.y));
+        }
+        const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+        int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m0 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m0), 0)) +
+                  __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m1 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m1), 0));
+        if (ok0 && pos < SDVL_CELL_KP_CAP)
+          out[pos] = static_cast<uint32_t>(x0 + static_cast<int>(f0 & 31u)) | (static_cast<uint32_t>(y0 + static_cast<int>((f0 >> 5) & 31u)) << 12) | ((f0 >> 10) << 24);
+        pos += ok0 ? 1 : 0;
+        if (ok1 && pos < SDVL_CELL_KP_CAP)
+          out[pos] = static_cast<uint32_t>(x0 + static_cast<int>(f1 & 31u)) | (static_cast<uint32_t>(y0 + static_cast<int>((f1 >> 5) & 31u)) << 12) | ((f1 >> 10) << 24);
+        base += __popcll(m0) + __popcll(m1);
+      }
+    }
+  } else {
+    uint32_t *s_img = s_mem;
+    uint32_t *s_score = s_mem + (kTile + 2 * kPadRows) * kPitchW;
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_mem + (kTile + 2 * kPadRows) * kPitchW + (kTile + 2) * kPitchW);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      s_img[(row + kPadRows) * kPitchW + 1 + wbase + k] = pk[k];
+      s_score[(row + 1) * kPitchW + 1 + wbase + k] = 0;
+    }
+    fc_wave_sync();
+    // ---- phase A: compass pre-test of the lane's 16 pixels (row `row`, columns 16 (lane & 1) ..)
+    uint32_t cflags = 0;
+    if (row >= 3 && row < rh - 3) {
+      const uint32_t *qz = &s_img[(row + kPadRows) * kPitchW + wbase];  // words wbase-1 .. wbase+4 of the row (word 0 is the left pad)
+      uint32_t rz[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) rz[k] = qz[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t up = s_img[(row + kPadRows - 3) * kPitchW + 1 + wbase + k], dn = s_img[(row + kPadRows + 3) * kPitchW + 1 + wbase + k];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int x = (wbase + k) * 4 + b;
+          if (x < 3 || x >= rw - 3) continue;
+          const int v = static_cast<int>((rz[k + 1] >> (8 * b)) & 0xFFu);
+          if (fast_compass_pass(v, static_cast<int>((dn >> (8 * b)) & 0xFFu), byte_of(rz[k], rz[k + 1], rz[k + 2], 7 + b),
+                                static_cast<int>((up >> (8 * b)) & 0xFFu), byte_of(rz[k], rz[k + 1], rz[k + 2], 1 + b), t))
+            cflags |= 1u << (4 * k + b);
+        }
+      }
+    }
+    // ---- phase B: candidates listed in scan order: rank of (lane, bit) = bits of lower lanes + lower bits of this lane
+    int below = 0, ncand = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const unsigned long long m = __ballot((cflags >> k) & 1u);
+      below += __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+      ncand += __popcll(m);
+    }
+    {
+      int cpos = below;
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (cflags & (1u << k)) s_list[cpos++] = static_cast<uint16_t>((row << 5) | (wbase * 4 + k));
+    }
+    fc_wave_sync();
+    // ---- phase C: one candidate per lane and round; the corners are compacted in place at the head of the list (a corner's
+    // slot never lies behind the candidate it came from), their scores go to the score plane
+    uint8_t *score_bytes = reinterpret_cast<uint8_t *>(s_score);
+    const uint8_t *img_bytes = reinterpret_cast<const uint8_t *>(s_img);
+    int ncorner = 0;
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+      const int i = c0 + lane;
+      int rc = 0;
+      bool is = false;
+      if (i < ncand) {
+        rc = s_list[i];
+        const int r = rc >> 5, x = rc & 31;
+        const int best = fast_corner_best(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
+        if (best > t) {
+          is = true;
+          score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>((best - 1) & 0xFF);  // uchar like OpenCV's score buffer
+        }
+      }
+      const unsigned long long m = __ballot(is);
+      fc_wave_sync();  // every lane has read its candidate
+      if (is) s_list[ncorner + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] = static_cast<uint16_t>(rc);
+      ncorner += __popcll(m);
+    }
+    fc_wave_sync();
+    // ---- 3x3 strict non-max suppression of the corners and ordered output
+    for (int j0 = 0; j0 < ncorner; j0 += 64) {
+      const int j = j0 + lane;
+      bool ok = false;
+      int rc = 0, sc = 0;
+      if (j < ncorner) {
+        rc = s_list[j];
+        const int r = rc >> 5, x = rc & 31;
+        const uint8_t *q = score_bytes + (r + 1) * (kPitchW * 4) + 4 + x;
+        const int pb = kPitchW * 4;
+        sc = q[0];
+        ok = sc > q[-1] && sc > q[1] && sc > q[-pb - 1] && sc > q[-pb] && sc > q[-pb + 1] && sc > q[pb - 1] && sc > q[pb] && sc > q[pb + 1];
+      }
+      const unsigned long long m = __ballot(ok);
+      const int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+      if (ok && pos < SDVL_CELL_KP_CAP)
+        out[pos] = static_cast<uint32_t>(x0 + (rc & 31)) | (static_cast<uint32_t>(y0 + (rc >> 5)) << 12) | (static_cast<uint32_t>(sc) << 24);
+      base += __popcll(m);
+    }
+  }
+  if (lane == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
+}
 #undef SDVL_MIN2
 #undef SDVL_MAX2
 
@@ -1329,6 +1566,12 @@ int sdvl_fast_num_cells(int width, int height, const sdvl_detect_params *p, int 
   return SDVL_OK;
 }
 
+// SDVL_FAST_WG4=1: the four-wave workgroup per cell (fast_cells_kernel) instead of one wave per cell (A/B measurements, tests)
+static bool fast_cells_four_waves() {
+  static const bool v = getenv("SDVL_FAST_WG4") != nullptr;
+  return v;
+}
+
 // the per-cell geometry table of fast_cells_kernel for this frame shape and grid, built once and kept in HBM
 static int fast_cell_table(sdvl_ctx *ctx, const FastLevels &lv, const sdvl_frame *f0, const CellGeo **out) {
   const int total = lv.cell_begin[lv.n_levels];
@@ -1425,7 +1668,11 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
     const int rc_t = fast_cell_table(ctx, lv, frames[0], &d_cells);
     if (rc_t) return rc_t;
   }
-  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv, d_cells);
+  if (fast_cells_four_waves()) {
+    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv, d_cells);
+  } else {
+    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
+  }
   SDVL_LAUNCH(ctx, "compact_cells", compact_cells_kernel, dim3(n), dim3(256), static_cast<const FastJob *>(dsx), total_cells, cap, d_kps, d_offs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   int32_t *h_offs = static_cast<int32_t *>(ctx->h_out);
@@ -1550,7 +1797,11 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
     const int rc_t = fast_cell_table(ctx, lv, frames[0], &d_cells);
     if (rc_t) return rc_t;
   }
-  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv, d_cells);
+  if (fast_cells_four_waves()) {
+    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv, d_cells);
+  } else {
+    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
+  }
   SDVL_LAUNCH(ctx, "select_corners", select_corners_kernel, dim3(lv.n_levels, n), dim3(kSelThreads), ds, sl);
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
   // writes them into device memory and, when results go direct, into the pinned host array as well
