@@ -220,7 +220,7 @@ __device__ __forceinline__ int fast_corner_best(const uint8_t *tile, int pitch_b
 // as halves (kPitchHW words per row, pixel x at half 4 + x), the pair (x, x+1) with x odd reads its ring as 20 aligned words
 // — position (dx, dy) of both pixels is the word at half x + dx for odd dx, and two neighbouring words funnel-shifted by 16
 // bits for even dx — and every min3 / max3 serves two pixels: 32 + 32 + 16 packed operations instead of 2 x 88 scalar ones.
-constexpr int kPitchHW = 26;  // LDS row pitch of the half tile in 32-bit words: 4 + 32 + 16 halves (26: the 13 pairs of a row and the rows below them fall on different banks; 24 cost 29 % extra LDS cycles)
+constexpr int kPitchHW = 20;  // LDS row pitch of the half tile in 32-bit words: 4 + 32 + 4 halves
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2 pk_min3(h2 a, h2 b, h2 c) {
