@@ -542,13 +542,14 @@ def main():
     if rank == 0:
         frames_rank = B * K
         priced = {k: v for k, v in timers.items() if algorithmic_bytes_per_frame(k, 1, 1, 1, 1, 1) is not None}
-        # the dominant kernel = the one with the most dispatch time; with 16 streams in flight the dispatch times of the top two
-        # (fast_cells: VALU work; select_corners: one 1024-thread workgroup per level that mostly waits) lie within a few % and
-        # swap from run to run, so among the kernels within 10 % of the maximum the one that moves the most bytes is taken
+        # the dominant kernel = the one with the most dispatch time; with 16 streams in flight the dispatch times of the top ones
+        # (search_points: the most work; select_corners: one 1024-thread workgroup per level that mostly waits for the chip's LDS
+        # — 104 us alone, 430-500 us among the other streams' kernels) lie within 10-15 % of each other and swap from run to
+        # run, so among the kernels within 20 % of the maximum the one that moves the most bytes is taken
         dom = None
         if priced:
             top = max(v[0] for v in priced.values())
-            near = {k: v for k, v in priced.items() if v[0] >= 0.9 * top}
+            near = {k: v for k, v in priced.items() if v[0] >= 0.8 * top}
             dom = max(near.items(), key=lambda kv: algorithmic_bytes_per_frame(kv[0], 1007, 190, 190, 6, 2.5) or 0)
         roofline = None
         if dom:
