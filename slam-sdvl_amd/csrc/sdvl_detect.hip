@@ -11,10 +11,17 @@
 
 namespace {
 
-constexpr int kPyrTW = 64, kPyrTH = 16;  // output tile of one 256-thread workgroup
-constexpr int kPyrSH = 2 * kPyrTH + 3;   // source rows of a tile: 35
-constexpr int kPyrSWW = kPyrTW / 2 + 2;  // source words of a tile row: bytes [2*tx0 - 4, 2*tx0 + 132)
-constexpr int kPyrPitch = (kPyrSWW + 1) * 4;  // LDS row pitch in bytes (odd number of words: rows start in different banks)
+// Output tile of one workgroup: 32 x 8 outputs for ONE WAVE (the form the launches use: no s_barrier — the lanes hand the
+// source tile and the horizontal sums over through LDS behind a wave fence; among the other streams' kernels the 64 x 16 tile
+// of a four-wave workgroup with its three barriers ran 3.5x longer than alone, a wave that never waits for another wave does not),
+// 64 x 16 for 256 threads (kept for A/B: SDVL_PYR_WG4=1).
+constexpr int kPyrTW = 32, kPyrTH = 8;
+
+__device__ __forceinline__ void pyr_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 struct PyrJob {
   const uint8_t *src;
@@ -32,7 +39,16 @@ __device__ __forceinline__ int reflect101_clamped(int p, int n) {
 // is source column 2*tx0 - 4 + b); the columns that fall off the image are patched afterwards from their BORDER_REFLECT_101
 // mirror inside the same row.  Horizontal 1-4-6-4-1 pass into 16-bit sums, then every thread finishes 4 adjacent outputs
 // and stores them as one word.
-__global__ __launch_bounds__(256) void pyr_down_kernel(const PyrJob *__restrict__ jobs) {
+template <int kPyrTW, int kPyrTH>
+__global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const PyrJob *__restrict__ jobs) {
+  constexpr int kThreads = kPyrTW * kPyrTH / 4;  // every thread finishes 4 adjacent outputs
+  constexpr int kPyrSH = 2 * kPyrTH + 3;         // source rows of a tile
+  constexpr int kPyrSWW = kPyrTW / 2 + 2;        // source words of a tile row: bytes [2*tx0 - 4, 2*tx0 + 2*TW + 4)
+  constexpr int kPyrPitch = (kPyrSWW + 1) * 4;   // LDS row pitch in bytes (odd number of words: rows start in different banks)
+  const auto sync = [] {
+    if (kThreads == 64) pyr_wave_sync();
+    else __syncthreads();
+  };
   __shared__ uint32_t s_srcw[kPyrSH * (kPyrSWW + 1)];
   __shared__ __attribute__((aligned(8))) uint16_t s_h[kPyrSH][kPyrTW];
   const PyrJob job = jobs[blockIdx.z];
@@ -47,14 +63,14 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrJob *__restrict_
   if ((job.sw & 3) == 0 && (reinterpret_cast<uintptr_t>(job.src) & 3u) == 0) {
     const int words_row = job.sw >> 2, w0 = xb >> 2;  // w0 = -1 for the leftmost tile
     const int nwords = last_byte / 4 + 1;
-    for (int idx = tid; idx < rows * kPyrSWW; idx += 256) {
+    for (int idx = tid; idx < rows * kPyrSWW; idx += kThreads) {
       const int r = idx / kPyrSWW, c = idx - r * kPyrSWW;  // constant divisor; narrow tiles skip the words they do not need
       if (c >= nwords) continue;
       const int sy = reflect101_clamped(2 * ty0 - 2 + r, job.sh);
       const int wi = min(max(w0 + c, 0), words_row - 1);
       s_srcw[r * (kPyrSWW + 1) + c] = reinterpret_cast<const uint32_t *>(job.src + static_cast<size_t>(sy) * job.sw)[wi];
     }
-    __syncthreads();
+    sync();
     if (tid < rows && (xb < 0 || xb + last_byte >= job.sw)) {  // border tiles: one thread mends one row
       uint8_t *row = s_bytes + tid * kPyrPitch;
       if (xb < 0) {  // columns -2, -1 mirror columns 2, 1
@@ -65,18 +81,18 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrJob *__restrict_
     }
   } else {  // odd widths: byte by byte
     const int ncols = last_byte - 1;
-    for (int idx = tid; idx < rows * ncols; idx += 256) {
+    for (int idx = tid; idx < rows * ncols; idx += kThreads) {
       const int r = idx / ncols, c = idx - r * ncols;
       const int sy = reflect101_clamped(2 * ty0 - 2 + r, job.sh);
       const int sx = reflect101_clamped(2 * tx0 - 2 + c, job.sw);
       s_bytes[r * kPyrPitch + 2 + c] = job.src[static_cast<size_t>(sy) * job.sw + sx];
     }
   }
-  __syncthreads();
+  sync();
   // horizontal 1-4-6-4-1 for two adjacent outputs per lane on packed 16-bit lanes (sums <= 255 * 16): outputs x, x+1 read source
   // bytes 2x .. 2x+6 of the row = the last two bytes of word x/2, word x/2 + 1, the first byte of word x/2 + 2
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  for (int idx = tid; idx < rows * (kPyrTW / 2); idx += 256) {
+  for (int idx = tid; idx < rows * (kPyrTW / 2); idx += kThreads) {
     const int r = idx / (kPyrTW / 2), xp = idx - r * (kPyrTW / 2);
     if (2 * xp < nx) {
       const uint32_t *w = &s_srcw[r * (kPyrSWW + 1) + xp];
@@ -92,9 +108,9 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrJob *__restrict_
       *reinterpret_cast<uint32_t *>(&s_h[r][2 * xp]) = __builtin_bit_cast(uint32_t, h);
     }
   }
-  __syncthreads();
+  sync();
   {
-    const int y = tid >> 4, x = (tid & 15) * 4;
+    const int y = tid / (kPyrTW / 4), x = (tid % (kPyrTW / 4)) * 4;
     const int oy = ty0 + y, ox = tx0 + x;
     if (oy < job.dh && ox < job.dw) {
       // vertical pass on the same packed lanes: sums <= 4080 * 16 = 65280, + 128 still fits 16 bits
@@ -1545,8 +1561,14 @@ int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
   for (int l = 1; l < levels; l++) {
     const FrameView &v = frames[0]->v;
-    dim3 grid((v.lw[l] + kPyrTW - 1) / kPyrTW, (v.lh[l] + kPyrTH - 1) / kPyrTH, n);
-    SDVL_LAUNCH(ctx, "pyr_down", pyr_down_kernel, grid, dim3(256), static_cast<const PyrJob *>(dsx) + (l - 1) * n);
+    static const bool four_waves = getenv("SDVL_PYR_WG4") != nullptr;
+    if (four_waves) {
+      dim3 grid((v.lw[l] + 63) / 64, (v.lh[l] + 15) / 16, n);
+      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<64, 16>), grid, dim3(256), static_cast<const PyrJob *>(dsx) + (l - 1) * n);
+    } else {
+      dim3 grid((v.lw[l] + kPyrTW - 1) / kPyrTW, (v.lh[l] + kPyrTH - 1) / kPyrTH, n);
+      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<kPyrTW, kPyrTH>), grid, dim3(64), static_cast<const PyrJob *>(dsx) + (l - 1) * n);
+    }
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
