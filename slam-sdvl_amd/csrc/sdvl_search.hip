@@ -275,6 +275,10 @@ __global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev 
   prep[ri] = out;
 }
 
+// kStage: frames without corner bins get their corner list staged in LDS (16 KB per workgroup).  Launches whose frames all
+// carry bins (every frame that went through sdvl_detect_corners: the tracking path) use the form without the stage: 3.7 KB of
+// LDS per workgroup, so its workgroups fit beside the LDS-heavy kernels of the other streams.
+template <bool kStage>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
                                                                             const SearchFramePose *__restrict__ table,
                                                                             const SearchBlock *__restrict__ blocks,
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   __shared__ WaveLds s_lds[kWavesPerBlock];
   // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
-  __shared__ uint32_t s_corners[kLdsCorners];
+  __shared__ uint32_t s_corners[kStage ? kLdsCorners : 1];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // wave-uniform: request, prep and frame-table loads become scalar loads
   // Workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is padded to a multiple of 8).  XCD x takes the x-th
   // eighth of the block table: blocks are ordered by current frame, so one frame's corner list, search-level image and
@@ -304,11 +308,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   // A frame whose corners are binned by cell (sdvl_detect_corners) is searched through its bins: no staging, no barrier.
   // (workgroup-uniform: the workgroup's requests share the current frame)
   const bool binned = tcur.f.bin_start != nullptr;
-  if (!binned) {
+  if (kStage && !binned) {
     for (int ci = threadIdx.x; ci < min(n_corners, kLdsCorners); ci += 64 * kWavesPerBlock) s_corners[ci] = pack_corner(corners_g[ci]);
     __syncthreads();
   }
-  const auto corner_at = [&](int ci) { return (!binned && ci < kLdsCorners) ? s_corners[ci] : pack_corner(corners_g[ci]); };
+  const auto corner_at = [&](int ci) { return (kStage && !binned && ci < kLdsCorners) ? s_corners[ci] : pack_corner(corners_g[ci]); };
   if (wv >= blk.count) return;
   const int ri = blk.first + wv;
   WaveLds &L = s_lds[wv];
@@ -819,7 +823,9 @@ int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_
   if (n_slots <= 0 || n_blocks <= 0) return SDVL_OK;
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n_slots + 255) / 256), dim3(256), d_reqs, d_table, n_slots, c, *p, d_prep);
-  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock), d_reqs,
+  // device-built batches search frames that came out of sdvl_detect_corners: binned (a frame without bins would still be
+  // searched correctly, its corner list read from HBM)
+  SDVL_LAUNCH(ctx, "search_points", search_points_kernel<false>, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock), d_reqs,
               d_table, d_blocks, static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, d_res, h_res);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
@@ -969,10 +975,19 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   SearchPrep *d_prep = reinterpret_cast<SearchPrep *>(static_cast<uint8_t *>(ctx->d_out) + out_dev_bytes);
   SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n + 255) / 256), dim3(256), static_cast<const SearchReqDev *>(dsx), d_table, n, c,
               *p, d_prep);
-  SDVL_LAUNCH(ctx, "search_points", search_points_kernel, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
-              static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
-              static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
-              sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
+  bool all_binned = true;
+  for (const sdvl_frame *f : B.frames) all_binned = all_binned && f->bins_valid;
+  if (all_binned) {
+    SDVL_LAUNCH(ctx, "search_points", search_points_kernel<false>, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
+                static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
+                static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
+                sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
+  } else {
+    SDVL_LAUNCH(ctx, "search_points", search_points_kernel<true>, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
+                static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
+                static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
+                sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
+  }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   if (!sdvl_direct_results()) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   return SDVL_OK;
