@@ -124,8 +124,10 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
     """SURVEY §8(d) per-frame algorithmic bytes, split by kernel (640x480, 5 levels, 3 FAST levels)."""
     P = [(W_IMG >> l) * (H_IMG >> l) for l in range(5)]
     return {
-        "select_corners": 4 * n_kp + 16 * n_c,                       # per-cell keypoint lists read once + corner records written
-        "pack_corners": 32 * n_c,
+        # per-cell retainBest: every keypoint list read once, the surviving heads (~1.5 n_c) and one length per cell written back
+        "select_cells": 4 * n_kp + 4 * 1.5 * n_c + 4 * 400,
+        # per-level retainBest + corners_ + bins: lengths and surviving heads read, corner records + bin entries written
+        "select_pack": 4 * 400 + 4 * 1.5 * n_c + (16 + 8) * n_c,
         "pyr_down": sum(P[:4]) + sum(P[1:]),                         # pyramid read + write (4 launches per frame batch)
         "fast_cells": sum(P[:3]) + 16 * n_c,                         # FAST read + keypoint write
         "orb_describe": n_c * (961 + 32),                            # 31x31 window + descriptor
@@ -144,36 +146,97 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
         "filter_select": n_c * (16 + 8) + 0.25 * n_c * 56,
         "filter_describe": 0.25 * n_c * (961 + 32),
         "shi_tomasi": n_c * (100 + 8),
+        "filter_gather": n_c * (16 + 8 + 32),
+        "image_align_big": 3 * n_f * 49 + i_ia * n_f * 25,          # the same kernel with its caches in HBM (> 384 features per job)
+        "select_matches": 40 * n_s + 48 * n_m,
+        "depth_filter": 184 * n_s,                                   # mapper: filter state in (104 B) and out (80 B) per candidate request
+        "align_patches": n_s * (164 + i_fa * 81),
+        "frames_upload": 2 * P[0], "undistort": 2 * P[0],            # image read + level 0 written
+        "compact_cells": 8 * n_kp, "registry_write": 128, "track_upload": n_f * (144 + 48),
     }.get(kernel)
 
 
-def pmc_traffic_bytes(kernel, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN/pmc_hbm_traffic.csv, newest round):
-    (FETCH_SIZE + WRITE_SIZE) * 1024 as the CDNA guide prices it, scaled to this run's frames per launch.  The counters
-    need their own rocprofv3 passes (tools/profile_round.sh), so they cannot be sampled inside the timed region.
-    Returns (bytes or None, where the figure came from)."""
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz
+
+
+def _pmc_rows(fname):
+    """rows of the newest committed profiles/rNN/<fname> (written by tools/summarize_profiles.py from separate --pmc passes)"""
     import csv
     import glob
-    import re
     root = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "pmc_hbm_traffic.csv")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", fname)))
     if not files:
-        return None, None
+        return [], None
     with open(files[-1]) as fh:
-        for row in csv.DictReader(fh):
-            if row["kernel"].startswith(kernel):
-                m = re.search(r"-> (\d+) frames per dispatch", row.get("note", ""))
-                per = float(m.group(1)) if m else None
-                try:
-                    total = (float(row["FETCH_SIZE_avg_KB"]) + float(row["WRITE_SIZE_avg_KB"])) * 1024.0
-                except ValueError:
-                    return None, None
-                if not per or total != total:
-                    return None, None
-                src = "%s row '%s': (FETCH_SIZE_avg_KB %s + WRITE_SIZE_avg_KB %s) * 1024 per %d-frame dispatch, scaled to %.0f frames" % (
-                    os.path.relpath(files[-1], root), row["kernel"], row["FETCH_SIZE_avg_KB"], row["WRITE_SIZE_avg_KB"], int(per), frames_per_launch)
-                return int(total * frames_per_launch / per), src
-    return None, None
+        return list(csv.DictReader(fh)), os.path.relpath(files[-1], root)
+
+
+def _pmc_row(rows, kernel):
+    """the row of timer name `kernel` (rocprofv3 names look like 'fast_cells_wave_kernel' or 'void image_align_lds_kernel<false>')"""
+    for row in rows:
+        name = row["kernel"].replace("void ", "")
+        if name.startswith(kernel + "_") or name.startswith(kernel + "<"):
+            return row
+    return None
+
+
+def _frames_per_dispatch(row):
+    import re
+    m = re.search(r"-> (\d+) frames per dispatch", row.get("note", ""))
+    return float(m.group(1)) if m else None
+
+
+def pmc_traffic_bytes(kernel, frames_per_launch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN/pmc_hbm_traffic.csv, newest round), scaled to
+    this run's frames per launch.  The counters need their own rocprofv3 passes (tools/profile_round.sh), so they cannot be
+    sampled inside the timed region.  FETCH_SIZE on gfx950 tallies a 128-B request as 64 B (MI355X_MICROARCH.md, HBM): the guide
+    calibrates the x2 for 16-B-per-lane streams; summarize_profiles.py marks per row whether the kernel's loads are of that kind
+    (column fetch_x2) and the figure here applies it.  Returns (bytes or None, where the figure came from)."""
+    rows, src_file = _pmc_rows("pmc_hbm_traffic.csv")
+    row = _pmc_row(rows, kernel)
+    if row is None:
+        return None, None
+    per = _frames_per_dispatch(row)
+    try:
+        fx = 2.0 if row.get("fetch_x2", "0") in ("1", "2", "2.0") else 1.0
+        total = (float(row["FETCH_SIZE_avg_KB"]) * fx + float(row["WRITE_SIZE_avg_KB"])) * 1024.0
+    except ValueError:
+        return None, None
+    if not per or total != total:
+        return None, None
+    src = "%s row '%s': (FETCH_SIZE_avg_KB %s x %g + WRITE_SIZE_avg_KB %s) * 1024 per %d-frame dispatch, scaled to %.0f frames" % (
+        src_file, row["kernel"], row["FETCH_SIZE_avg_KB"], fx, row["WRITE_SIZE_avg_KB"], int(per), frames_per_launch)
+    return int(total * frames_per_launch / per), src
+
+
+def pmc_valu(timers_ms_per_step, frames_per_step):
+    """wave-level VALU instructions from the committed SQ pass (profiles/rNN/pmc_sq_lds.csv, SQ_INSTS_VALU per dispatch):
+    per kernel {insts per dispatch, frames per dispatch, dispatches} and the whole path's instructions per tracked frame
+    (every kernel's instructions x its dispatches / the frames the run processed).  None when no SQ pass is committed."""
+    rows, src_file = _pmc_rows("pmc_sq_lds.csv")
+    if not rows:
+        return None
+    out, ref_frames = {}, None
+    fast = _pmc_row(rows, "fast_cells")
+    if fast is None:
+        return None
+    per = _frames_per_dispatch(fast)
+    if not per:
+        return None
+    ref_frames = per * float(fast["dispatches"])          # fast_cells runs once per frame batch: frames the profiled run processed
+    path = 0.0
+    for name in timers_ms_per_step:
+        row = _pmc_row(rows, name)
+        if row is None:
+            continue
+        try:
+            insts = float(row["SQ_INSTS_VALU_avg"])
+            disp = float(row["dispatches"])
+        except (KeyError, ValueError):
+            continue
+        out[name] = {"insts_per_dispatch": insts, "insts_per_frame": insts * disp / ref_frames}
+        path += insts * disp / ref_frames
+    return {"kernels": out, "path_insts_per_frame": path, "source": src_file, "frames_per_dispatch": per}
 
 
 def effective_cpus():
@@ -231,48 +294,92 @@ def cpu_baseline(frames, mapper=False, threads=1):
     return tracked / wall, tracked, wall
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT initialising HIP/HSA in it (a process that has touched the GPU must never
+    start rank children): the KFD topology in sysfs lists every node, GPUs are the ones with SIMDs; ROCR_/HIP_/CUDA_VISIBLE_DEVICES
+    narrow the set.  Returns None when sysfs has no KFD topology (then a throw-away child asks the runtime)."""
+    import glob
+    import subprocess
+    n = None
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if nodes:
+        n = 0
+        for f in nodes:
+            try:
+                props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+                n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            except (OSError, ValueError):
+                pass
+    if n is None or n == 0:
+        try:   # the runtime's answer, from a child that exits again: this process stays clean
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+            n = int(out.stdout.strip().splitlines()[-1])
+        except (subprocess.SubprocessError, ValueError, IndexError):
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n, dry=False):
-    """`python bench.py --gpus N` without a distributed launcher: start the N ranks as child processes, one per GPU, BEFORE
-    anything in this process touches the GPU (a process that has initialised HIP must never exec or fork workers).  Every
-    rank gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like under torch.distributed.run and an equal share of the CPUs
-    (SDVL_BENCH_CPU_SHARE; inside the rank the share is bound to the NUMA node of its GPU).  Rank 0 prints the JSON line.
+    """`python bench.py --gpus N` without a distributed launcher: start the N ranks as child processes, one per GPU.  This process
+    never touches the GPU — not even to count devices (visible_gpus reads sysfs) — because a process that has initialised HIP must
+    not start workers.  Every rank gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like under torch.distributed.run and an equal share
+    of the CPUs (SDVL_BENCH_CPU_SHARE; inside the rank the share is bound to the NUMA node of its GPU).  Rank 0 prints the JSON
+    line.  The rendezvous port is found by bind-and-close, so another process can take it before rank 0 listens: when the ranks die
+    of exactly that (EADDRINUSE in rank 0's stderr) they are started again on a fresh port, up to three times.
     Returns the exit code: non-zero if the box has fewer GPUs than ranks or if any rank fails."""
     import socket
     import subprocess
+    import tempfile
     if not dry:
-        have = torch.cuda.device_count()     # counting devices does not initialise the GPU
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             sys.stderr.write("bench.py: --gpus %d but %d GPU(s) are visible on this box - refusing to measure fewer GPUs than asked for\n" % (n, have))
             return 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+        # have is None: nothing could be counted here; every rank checks its own GPU and fails loudly ("rank r wants GPU r ...")
     share = max(1, effective_cpus() // n)
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), SDVL_BENCH_CPU_SHARE=str(share), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
-    try:
-        pending = set(range(n))
-        while pending:
-            for r in sorted(pending):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                pending.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code if code > 0 else 1
-                    sys.stderr.write("bench.py: rank %d exited with %d - stopping the other ranks\n" % (r, code))
-                    for q in pending:
-                        procs[q].terminate()     # exactly the children started above, by handle
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        err0 = tempfile.TemporaryFile()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), SDVL_BENCH_CPU_SHARE=str(share), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=err0 if r == 0 else None))
+        rc = 0
+        try:
+            pending = set(range(n))
+            while pending:
+                for r in sorted(pending):
+                    code = procs[r].poll()
+                    if code is None:
+                        continue
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+                        sys.stderr.write("bench.py: rank %d exited with %d - stopping the other ranks\n" % (r, code))
+                        for q in pending:
+                            procs[q].terminate()     # exactly the children started above, by handle
+                time.sleep(0.05)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        err0.seek(0)
+        text = err0.read().decode(errors="replace")
+        err0.close()
+        sys.stderr.write(text)
+        if rc != 0 and ("EADDRINUSE" in text or "ddress already in use" in text) and attempt < 2:
+            sys.stderr.write("bench.py: the rendezvous port %d was taken before rank 0 could listen - starting the ranks again\n" % port)
+            continue
+        break
     return rc
 
 
@@ -371,8 +478,14 @@ def main():
     fibers = args.fibers
     n_frames = 1 + Wm + K                     # bootstrap keyframe + warmup + timed
     frame_bytes = W_IMG * H_IMG
-    pkg.load_library().sdvl_frame_footprint.restype = C.c_int64
-    footprint = pkg.load_library().sdvl_frame_footprint(W_IMG, H_IMG, 5)
+    lib0 = pkg.load_library()
+    lib0.sdvl_frame_footprint_cap.restype = C.c_int64
+    lib0.sdvl_detect_scratch_bytes.restype = C.c_int64
+    n_feat_cfg = int(wl["over"].get("SDVL.num_features", 1000))
+    corner_cap = min(6144, max(1024, (2 * n_feat_cfg + 63) // 64 * 64))      # Device::CornerCap (host/sdvl_host.cc)
+    footprint = lib0.sdvl_frame_footprint_cap(W_IMG, H_IMG, 5, corner_cap)   # what a frame keeps for as long as it lives
+    det_params = pkg.default_detect_params()
+    scratch_per_frame = lib0.sdvl_detect_scratch_bytes(W_IMG, H_IMG, C.byref(det_params))   # per frame of a group's batch, per context
     free_b, total_b = torch.cuda.mem_get_info()
     B = G = Bg = reserve_frames = need = None
     for cand in seq_choices:
@@ -397,7 +510,7 @@ def main():
         Bg = B // G
         steps_all = Wm + K + max(0, args.host_steps)
         reserve_frames = Bg * (4 + (steps_all + 3) // 4)   # keyframe budget: S-A turns about one frame in five into a keyframe
-        need = B * n_frames * frame_bytes + G * reserve_frames * footprint + B * 2 * footprint
+        need = B * n_frames * frame_bytes + G * reserve_frames * footprint + B * 2 * footprint + B * scratch_per_frame
         if need <= 0.85 * free_b:
             break
     if need > 0.9 * free_b:
@@ -441,6 +554,24 @@ def main():
             cpu_all = cpu_baseline(cpu_sample, args.mapper, max(1, min(ncpu, 16)))
     # (the all-core leg runs AFTER the timed region: 16 threads at full load right before it cost the GPU run ~5-10 % -
     #  151 k against 170 k on the same box - whatever the host does to a process that has just used its whole CPU share)
+
+    # FAST keypoints per frame (the byte model of the selection kernels reads every per-cell list once): counted on four frames
+    # of this workload before anything is timed
+    n_kp_measured = 10000
+    try:
+        probe = pkg.Context(local_rank)
+        counts = []
+        for k in (0, 1):
+            for q in (0, min(B - 1, 7)):
+                img = ctx.download(int(ptrs[k, q]), frame_bytes).reshape(H_IMG, W_IMG)
+                pf_ = probe.frame(img)
+                got, _ = probe.fast_cells([pf_], det_params)
+                counts.append(len(got[0][0]))
+                pf_.close()
+        probe.close()
+        n_kp_measured = int(round(sum(counts) / len(counts)))
+    except Exception as e:   # the probe is a measurement aid; the byte model then keeps its round-2 constant
+        sys.stderr.write("bench.py: keypoint-count probe failed (%s); using %d\n" % (e, n_kp_measured))
 
     workers = args.workers or max(1, G // max(1, fibers))
     farm.reserve(reserve_frames)              # every keyframe keeps its HBM frame: no hipMalloc inside the run
@@ -541,33 +672,57 @@ def main():
 
     if rank == 0:
         frames_rank = B * K
-        priced = {k: v for k, v in timers.items() if algorithmic_bytes_per_frame(k, 1, 1, 1, 1, 1) is not None}
-        # the dominant kernel = the one with the most dispatch time; with 16 streams in flight the dispatch times of the top ones
-        # (search_points: the most work; select_corners: one 1024-thread workgroup per level that mostly waits for the chip's LDS
-        # — 104 us alone, 430-500 us among the other streams' kernels) lie within 10-15 % of each other and swap from run to
-        # run, so among the kernels within 20 % of the maximum the one that moves the most bytes is taken
-        dom = None
-        if priced:
-            top = max(v[0] for v in priced.values())
-            near = {k: v for k, v in priced.items() if v[0] >= 0.8 * top}
-            dom = max(near.items(), key=lambda kv: algorithmic_bytes_per_frame(kv[0], 1007, 190, 190, 6, 2.5) or 0)
+        # the dominant kernel = the one with the most dispatch time in the timed region, nothing else (round 2 broke near-ties by
+        # byte count, which named the kernel with the larger fraction: VERDICT r02)
+        dom = max(timers.items(), key=lambda kv: kv[1][0]) if timers else None
         roofline = None
+        valu = pmc_valu({k: v[0] / K for k, v in timers.items()}, B)
         if dom:
             name, (ms, launches) = dom
             avg_s = ms / max(1, launches) * 1e-3
-            # measured per-frame averages (corners, features, requests, GN evaluations, LK iterations) feed the §8(d) formula
+            # measured per-frame averages (corners, features, requests, GN evaluations, LK iterations, FAST keypoints) feed the
+            # §8(d) formula
             per_frame = algorithmic_bytes_per_frame(name, n_c / frames_rank, n_f / frames_rank, n_s / frames_rank,
-                                                    n_ia / frames_rank, n_lk / max(1, n_s), n_m / frames_rank)
+                                                    n_ia / frames_rank, n_lk / max(1, n_s), n_m / frames_rank, n_kp_measured)
             launches_per_step = launches / K          # all groups together
+            # descriptors of whole frames, Shi-Tomasi scores and the filter gather run on the frames that become keyframes only
+            frames_per_step = n_kf / K if name in ("orb_describe", "shi_tomasi", "filter_gather", "filter_select", "filter_describe") else B
+            frames_per_launch = frames_per_step / launches_per_step
+            roofline = {"bound": "hbm", "kernel": name, "selection_rule": "argmax of kernel_ms_per_step (dispatch time, HIP events on the kernel's own stream)",
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_us": round(avg_s * 1e6, 2), "frames_per_launch": round(frames_per_launch, 1),
+                        "achieved": None, "frac": None, "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": None}
             if per_frame is not None:
-                # descriptors of whole frames, Shi-Tomasi scores and the filter gather run on the frames that become keyframes only
-                frames_per_step = n_kf / K if name in ("orb_describe", "shi_tomasi", "filter_gather", "filter_select", "filter_describe") else B
-                bytes_per_launch = per_frame * frames_per_step / launches_per_step
+                bytes_per_launch = per_frame * frames_per_launch
                 achieved = bytes_per_launch / avg_s / 1e9
-                traffic, traffic_src = pmc_traffic_bytes(name, frames_per_step / launches_per_step) if args.workload == "S-A" else (None, None)  # the PMC passes were taken on S-A
-                roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                            "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+                traffic, traffic_src = pmc_traffic_bytes(name, frames_per_launch) if args.workload == "S-A" else (None, None)  # the PMC passes were taken on S-A
+                roofline.update({"achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                                 "algorithmic_bytes_note": "SURVEY §8(d) per-frame bytes of this kernel x frames per launch; search_points adds the 31x31 ORB window of "
+                                                           "every compared corner (961 B x matches): descriptors are computed inside the search" if name == "search_points" else
+                                                           "SURVEY §8(d) per-frame bytes of this kernel x frames per launch (FAST keypoints per frame measured: %d)" % n_kp_measured})
+            # the roof that governs: none of these kernels streams, they issue tens to hundreds of VALU instructions per byte.  Wave-level
+            # VALU instructions per launch (SQ_INSTS_VALU of the committed SQ pass, scaled to this run's frames per launch) over the
+            # launch's duration, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave instruction
+            if valu and args.workload == "S-A":
+                vk = valu["kernels"].get(name)
+                roofline["valu"] = {
+                    "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS, "source": valu["source"] + " (SQ_INSTS_VALU, own --pmc pass)",
+                    "kernel_insts_per_launch": int(vk["insts_per_dispatch"] * frames_per_launch / valu["frames_per_dispatch"]) if vk else None,
+                    "kernel_frac": round(vk["insts_per_dispatch"] * frames_per_launch / valu["frames_per_dispatch"] / avg_s / VALU_PEAK_WAVE_INSTS, 4) if vk else None,
+                    "path_insts_per_frame": int(valu["path_insts_per_frame"]),
+                    "path_frac": round(valu["path_insts_per_frame"] * (tracked_all / elapsed_max / world) / VALU_PEAK_WAVE_INSTS, 4),
+                    "insts_per_frame": {k: int(v["insts_per_frame"]) for k, v in sorted(valu["kernels"].items(), key=lambda kv: -kv[1]["insts_per_frame"])[:8]}}
+            # the whole path against HBM: all kernels' algorithmic bytes per tracked frame x frames/s
+            path_bytes = 0.0
+            for k, (kms, kl) in timers.items():
+                pf = algorithmic_bytes_per_frame(k, n_c / frames_rank, n_f / frames_rank, n_s / frames_rank, n_ia / frames_rank, n_lk / max(1, n_s),
+                                                 n_m / frames_rank, n_kp_measured)
+                if pf is None:
+                    continue
+                share = (n_kf / frames_rank) if k in ("orb_describe", "shi_tomasi", "filter_gather", "filter_select", "filter_describe") else 1.0
+                path_bytes += pf * share      # (pyr_down's figure already covers its four launches)
+            roofline["path_hbm"] = {"algorithmic_bytes_per_frame": int(path_bytes), "achieved": round(path_bytes * (tracked_all / elapsed_max / world) / 1e9, 1),
+                                    "frac": round(path_bytes * (tracked_all / elapsed_max / world) / 1e9 / HBM_PEAK_GBS, 5)}
         value = tracked_all / elapsed_max
         out = {
             "metric": "tracked frames/sec (%dx%d, 5-lvl pyr, %s)" % (W_IMG, H_IMG, FEATS_LABEL), "value": round(value, 2), "unit": "frames/s",
@@ -580,7 +735,7 @@ def main():
                        "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "numa_node": numa_node, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
-                       "lk_iterations_per_request": round(n_lk / max(1, n_s), 2),
+                       "lk_iterations_per_request": round(n_lk / max(1, n_s), 2), "fast_keypoints_per_frame": n_kp_measured,
                        "matches_per_frame": round(n_m / frames_rank, 1), "keyframes_per_frame": round(n_kf / frames_rank, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: round(v[0] / K, 4) for k, v in sorted(timers.items())},

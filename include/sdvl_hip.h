@@ -150,8 +150,16 @@ int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_fra
 int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int n, sdvl_frame **out);
 int sdvl_frame_destroy(sdvl_ctx *ctx, sdvl_frame *f);
 /* pyramid_[0] = img (frame.cc:116): host image -> HBM (async on the context stream, staged through pinned memory) */
-/* HBM bytes one frame of this shape occupies (pyramid + corner / descriptor / cell lists); -1 for an invalid shape */
-int64_t sdvl_frame_footprint(int width, int height, int levels);
+/* HBM bytes one frame of this shape occupies for as long as it lives (pyramid + corner list + descriptors + corner bins); -1 for
+ * an invalid shape.  Round 3: the detection's per-cell lists are scratch of the context (sdvl_detect_scratch_bytes per frame of the
+ * largest batch), no longer part of every frame: a keyframe keeps 0.76 MB at 640x480 instead of 1.43 MB, 0.50 MB with a corner
+ * capacity of 1536. */
+int64_t sdvl_frame_footprint(int width, int height, int levels);                       /* at the default capacity, SDVL_MAX_CORNERS */
+int64_t sdvl_frame_footprint_cap(int width, int height, int levels, int max_corners);
+/* corners_ capacity of the frames this context creates from now on (Frame::corners_ holds num_features plus the ties retainBest
+ * keeps, fast_detector.cc:147-148: 2 x num_features is ample); detection into a frame whose list overflows reports
+ * SDVL_ERR_CAPACITY through sdvl_frames_corner_counts, as for SDVL_MAX_CORNERS */
+int sdvl_ctx_set_corner_capacity(sdvl_ctx *ctx, int max_corners);
 int sdvl_frame_upload(sdvl_ctx *ctx, sdvl_frame *f, const uint8_t *img, int stride);
 /* the same for n frames of one shape in ONE submission.  Images in pinned (device-mapped) host memory — hipHostMalloc,
  * hipHostRegister, torch pin_memory — are pulled over the bus by one gather kernel that reads the host pages directly (no DMA
@@ -184,6 +192,8 @@ int sdvl_frame_download_level(sdvl_ctx *ctx, const sdvl_frame *f, int level, uin
  * are exclusive offsets over the frame's concatenated cells (ncells = sum over levels, see sdvl_fast_num_cells).
  * The quota / retainBest selection (fast_detector.cc:108-151) stays on the host. */
 int sdvl_fast_num_cells(int width, int height, const sdvl_detect_params *p, int *cells_per_level, int *total);
+/* bytes of context scratch one frame of a detection batch needs while the batch is in flight (per-cell lists, selection lists) */
+int64_t sdvl_detect_scratch_bytes(int width, int height, const sdvl_detect_params *p);
 int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_detect_params *p, int cap,
                     sdvl_keypoint *out_kps, int32_t *out_cell_offsets);
 
@@ -205,6 +215,7 @@ int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *x
 /* same for n frames in one transfer: counts[i] corners of frame i, concatenated in xyl */
 int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const int32_t *counts, const int32_t *xyl);
 int sdvl_frame_num_corners(const sdvl_frame *f);
+int sdvl_frame_corner_capacity(const sdvl_frame *f); /* corners its resident list holds (sdvl_ctx_set_corner_capacity) */
 
 /* FindShiTomasiScoreAtPoint for every corner of n frames (extra/utils.cc:61-97, called from
  * FastDetector::FilterCorners fast_detector.cc:205); out_scores[i*cap + k]; the grid logic stays on the host */

@@ -327,6 +327,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   if (ctx->d_stage) (void)hipFree(ctx->d_stage);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
+  if (ctx->d_detect) (void)hipFree(ctx->d_detect);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
   for (void *sl : ctx->slabs) (void)hipFree(sl);
   if (ctx->copy_stream) {
@@ -411,12 +412,17 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 
 namespace {
+// Round 3: a frame holds only what stays useful for as long as the frame lives — a keyframe lives for the rest of the run:
+//   level0 | level1 | ... (u8, 256-B aligned, 64 B slack) | corner header {count,0,0,0} + corners[cap] (x,y,level,pad int32)
+//   | descriptors[cap][32] | bin offsets [bin_cells + 1] | bin entries [cap] (8 B)
+// cap = the context's corner capacity when the frame was created (SDVL_MAX_CORNERS unless sdvl_ctx_set_corner_capacity says less).
+// 640x480, cap 6144: 0.76 MB (1.43 MB in round 2, which kept 0.7 MB of detection scratch per frame); cap 1536: 0.50 MB.
 struct FrameLayout {
-  size_t level_off[SDVL_MAX_LEVELS], corners_off, lvl_off, desc_off, counts_off, kps_off, bytes;
-  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS], max_cells;
+  size_t level_off[SDVL_MAX_LEVELS], corners_off, desc_off, bin_start_off, bin_entries_off, bytes;
+  int lw[SDVL_MAX_LEVELS], lh[SDVL_MAX_LEVELS], bin_gw, bin_cells, corner_cap;
 };
 
-bool frame_layout(int width, int height, int levels, FrameLayout *L) {
+bool frame_layout(int width, int height, int levels, int corner_cap, FrameLayout *L) {
   size_t off = 0;
   int w = width, h = height;
   for (int l = 0; l < levels; l++) {
@@ -428,20 +434,18 @@ bool frame_layout(int width, int height, int levels, FrameLayout *L) {
     w /= 2;
     h /= 2;
   }
+  L->corner_cap = corner_cap;
   L->corners_off = off;  // 16-byte header {count,0,0,0} + corner records, written by ONE copy
-  off = align_up(off + sizeof(int32_t) * 4 * (SDVL_MAX_CORNERS + 1), 256);
-  L->lvl_off = off;      // selection-kernel scratch: per-level segments + counts
-  off = align_up(off + sizeof(int32_t) * 4 * SDVL_MAX_CORNERS * 4 + 64, 256);
+  off = align_up(off + sizeof(int32_t) * 4 * (static_cast<size_t>(corner_cap) + 1), 256);
   L->desc_off = off;
-  off = align_up(off + 32 * SDVL_MAX_CORNERS, 256);
-  // per-cell FAST lists: cell_size >= 32 on the 4 finest levels (smaller cells hold fewer corners each)
-  int max_cells = 0;
-  for (int l = 0; l < levels && l < 4; l++) max_cells += ((L->lw[l] + 15) / 16) * ((L->lh[l] + 15) / 16);
-  L->max_cells = max_cells / 4 + 64;
-  L->counts_off = off;
-  off = align_up(off + sizeof(int32_t) * (max_cells + 1), 256);
-  L->kps_off = off;
-  off = align_up(off + sizeof(uint32_t) * SDVL_CELL_KP_CAP * L->max_cells, 256);
+  off = align_up(off + static_cast<size_t>(32) * corner_cap, 256);
+  L->bin_gw = (width + 31) / 32;
+  const int cells = L->bin_gw * ((height + 31) / 32);
+  L->bin_cells = cells <= 4096 ? cells : 0;  // larger grids: no bins, the searches scan the list
+  L->bin_start_off = off;
+  off = align_up(off + sizeof(int32_t) * (static_cast<size_t>(L->bin_cells) + 1), 256);
+  L->bin_entries_off = off;
+  off = align_up(off + sizeof(uint2) * static_cast<size_t>(L->bin_cells > 0 ? corner_cap : 0), 256);
   L->bytes = off;
   return true;
 }
@@ -465,38 +469,43 @@ sdvl_frame *frame_bind(const FrameLayout &L, int width, int height, int levels, 
   f->v.n_corners = 0;
   f->v.corner_hdr = reinterpret_cast<int32_t *>(base + L.corners_off);
   f->v.corners = f->v.corner_hdr + 4;
-  f->level_corners = reinterpret_cast<int32_t *>(base + L.lvl_off);
-  f->level_counts = f->level_corners + static_cast<size_t>(4) * SDVL_MAX_CORNERS * 4;
   f->v.desc = base + L.desc_off;
-  f->cell_counts = reinterpret_cast<int32_t *>(base + L.counts_off);
-  f->cell_kps = reinterpret_cast<uint32_t *>(base + L.kps_off);
-  f->max_cells = L.max_cells;
+  f->corner_cap = L.corner_cap;
   f->desc_valid = 0;
   f->bins_valid = 0;
-  {  // bins live in the selection scratch: [cells + 1] offsets, then 8-byte entries (the scratch holds 4 x 6144 x 16 B)
-    f->bin_gw = (width + 31) / 32;
-    const int cells = f->bin_gw * ((height + 31) / 32);
-    f->bin_cells = cells <= 4096 ? cells : 0;
-    f->bin_start = f->level_corners;
-    f->bin_entries = reinterpret_cast<uint2 *>(f->level_corners + ((cells + 1 + 3) / 4 * 4));
-  }
+  f->bin_gw = L.bin_gw;
+  f->bin_cells = L.bin_cells;
+  f->bin_start = reinterpret_cast<int32_t *>(base + L.bin_start_off);
+  f->bin_entries = reinterpret_cast<uint2 *>(base + L.bin_entries_off);
   f->reg_id = -1;
   f->home = nullptr;
   return f;
 }
 }  // namespace
 
+int sdvl_ctx_set_corner_capacity(sdvl_ctx *ctx, int max_corners) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, max_corners >= 64 && max_corners <= SDVL_MAX_CORNERS, "corner capacity must lie in [64, SDVL_MAX_CORNERS]");
+  ctx->corner_cap = max_corners;
+  return SDVL_OK;
+}
+
+int64_t sdvl_frame_footprint_cap(int width, int height, int levels, int max_corners) {
+  FrameLayout L;
+  if (width < 16 || height < 16 || levels < 1 || levels > SDVL_MAX_LEVELS || max_corners < 64 || max_corners > SDVL_MAX_CORNERS ||
+      !frame_layout(width, height, levels, max_corners, &L))
+    return -1;
+  return static_cast<int64_t>(L.bytes);
+}
+
 int sdvl_frame_create(sdvl_ctx *ctx, int width, int height, int levels, sdvl_frame **out) {
   return sdvl_frame_create_many(ctx, width, height, levels, 1, out);
 }
 
+int64_t sdvl_frame_footprint(int width, int height, int levels) { return sdvl_frame_footprint_cap(width, height, levels, SDVL_MAX_CORNERS); }
+
 // n frames out of ONE allocation (hipMalloc costs ~0.2 ms and synchronises; a tracker farm turns frames into keyframes
 // all the time).  The slab belongs to the context and is released with it; sdvl_frame_destroy only drops the handle.
-int64_t sdvl_frame_footprint(int width, int height, int levels) {
-  FrameLayout L;
-  if (width < 16 || height < 16 || levels < 1 || levels > SDVL_MAX_LEVELS || !frame_layout(width, height, levels, &L)) return -1;
-  return static_cast<int64_t>(L.bytes);
-}
 
 int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int n, sdvl_frame **out) {
   if (!ctx || !out || n <= 0) return SDVL_ERR_INVALID;
@@ -504,7 +513,7 @@ int sdvl_frame_create_many(sdvl_ctx *ctx, int width, int height, int levels, int
   SDVL_REQUIRE(ctx, width >= 16 && height >= 16 && width <= 4095 && height <= 4095, "frame size out of range");
   SDVL_REQUIRE(ctx, levels >= 1 && levels <= SDVL_MAX_LEVELS, "pyramid levels out of range");
   FrameLayout L;
-  SDVL_REQUIRE(ctx, frame_layout(width, height, levels, &L), "image too small for the pyramid depth");
+  SDVL_REQUIRE(ctx, frame_layout(width, height, levels, ctx->corner_cap, &L), "image too small for the pyramid depth");
   SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
   {
     const int rc = sdvl_registry_reserve(ctx, n);
@@ -712,8 +721,8 @@ int sdvl_frame_download_level(sdvl_ctx *ctx, const sdvl_frame *f, int level, uin
 
 int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *xyl) {
   if (!ctx || !f || (n > 0 && !xyl)) return SDVL_ERR_INVALID;
-  if (n < 0 || n > SDVL_MAX_CORNERS) {
-    ctx->err = "too many corners for one frame (SDVL_MAX_CORNERS)";
+  if (n < 0 || n > f->corner_cap) {
+    ctx->err = "too many corners for one frame (its corner capacity, at most SDVL_MAX_CORNERS)";
     return SDVL_ERR_CAPACITY;
   }
   // validate on the host: every corner must lie inside its level image (kernels index with it)
@@ -747,8 +756,8 @@ int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, con
   size_t total = 0;
   for (int i = 0; i < n; i++) {
     SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
-    if (counts[i] < 0 || counts[i] > SDVL_MAX_CORNERS) {
-      ctx->err = "too many corners for one frame (SDVL_MAX_CORNERS)";
+    if (counts[i] < 0 || counts[i] > frames[i]->corner_cap) {
+      ctx->err = "too many corners for one frame (its corner capacity, at most SDVL_MAX_CORNERS)";
       return SDVL_ERR_CAPACITY;
     }
     total += counts[i];
@@ -791,6 +800,7 @@ int sdvl_frames_set_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, con
 }
 
 int sdvl_frame_num_corners(const sdvl_frame *f) { return f ? f->v.n_corners : SDVL_ERR_INVALID; }
+int sdvl_frame_corner_capacity(const sdvl_frame *f) { return f ? f->corner_cap : SDVL_ERR_INVALID; }
 
 int sdvl_frame_download_corners(sdvl_ctx *ctx, sdvl_frame *f, int cap, int32_t *xyl, int *n_out) {
   if (!ctx || !f || !n_out) return SDVL_ERR_INVALID;

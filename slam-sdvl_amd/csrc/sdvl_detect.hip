@@ -950,32 +950,40 @@ __device__ __forceinline__ int sel_retain_best(uint32_t *v, int len, int n_point
 }
 
 constexpr int kSelMaxCells = 2048;  // cells of one level
-constexpr int kSelStage = 16384;    // keypoints staged in LDS per round (a 640x480 level 0 holds ~12k: one round).  128 KB of LDS per workgroup; rounds of 4608 (56 KB, room for the other streams' kernels beside it) were measured: this kernel 8.3 -> 6.8 ms of dispatch time per step, its neighbours slower by as much, throughput -0.5 %
 constexpr int kSelFts = 4096;       // concatenated selection of one level before the final retainBest
 
+// Round 3: the selection is two launches of NARROW workgroups instead of one 1024-thread workgroup per (frame, level) that held
+// 128 KB of LDS (a whole CU's worth: among the other streams' kernels it waited for a CU to drain, 104 us alone -> 460 us):
+//   select_cells_kernel  one WAVE per (frame, level, 8 consecutive cells): the level's quota (one number, below), then the cells'
+//                        retainBest by groups of 8 lanes; 11 KB of LDS, no workgroup barrier
+//   select_pack_kernel   one 256-thread workgroup per frame: wave l concatenates level l's surviving lists and runs the level's
+//                        retainBest (one wave, no barrier inside), then all four waves write corners_ and the 32-px bins
 struct SelLevels {
   int n_levels;
   int cell_begin[5];
   int wcells[4], hcells[4];
   int quota[4];
   int cell_size, margin;
+  int not_run[4];      // cells of the level whose ROI the margin swallows: cv::FAST is not called there (fast_detector.cc:84-94)
+  int slice_begin[5];  // select_cells: first 8-cell slice of each level among the slices of one frame
+  int fts_cap[4];      // select_pack: LDS entries for each level's concatenated list (longer lists go through HBM)
 };
 
 struct SelJob {
-  const uint32_t *cell_kps;
+  uint32_t *cell_kps;          // detection scratch of the frame's batch slot: per-cell lists, rewritten in place by select_cells
   const int32_t *cell_counts;
-  int32_t *level_corners;  // [4][SDVL_MAX_CORNERS][4]
-  int32_t *level_counts;   // [4]
-  int32_t *corner_hdr;     // {count,0,0,0} + corners
+  int32_t *cell_newlen;        // [total_cells] length of every cell's list after its retainBest
+  uint32_t *spill;             // [n_levels][2 * kSelFts] words: a level's list + stopper lists when they outgrow the LDS share
+  int32_t *corner_hdr;         // {count,0,0,0} + corners
   int lw[4], lh[4];
-  int32_t *bin_start;      // [bin_cells + 1] (pack_corners_kernel)
+  int32_t *bin_start;          // [bin_cells + 1]
   uint2 *bin_entries;
   int bin_gw, bin_cells;
+  int corner_cap;              // corners the frame's resident list holds
 };
 
 constexpr int kSelThreads = 1024;  // 16 waves: one lane per cell leaves <= ~20 divergent lanes per wave
 constexpr int kSelWaves = kSelThreads / 64;
-constexpr int kSelCellsPerThread = kSelMaxCells / kSelThreads;  // 2 consecutive cells per thread
 constexpr int kSelParMin = 96;     // ranges shorter than this are finished by one lane
 
 // block-wide exclusive prefix sum of one int per thread; returns the exclusive prefix, *total = block sum
@@ -1256,227 +1264,221 @@ __device__ __forceinline__ int group_retain_best(uint32_t *v, int len, int n_poi
   return n_points + nR;  // the elements that satisfy the predicate end up in front
 }
 
-// one workgroup per (level, frame)
-__global__ __launch_bounds__(kSelThreads) void select_corners_kernel(const SelJob *__restrict__ jobs, SelLevels lv) {
-  __shared__ uint32_t s_stage[kSelStage];
-  __shared__ uint32_t s_fts[kSelFts];
-  __shared__ uint8_t s_cnt[kSelMaxCells], s_nleft[kSelMaxCells], s_nsel[kSelMaxCells], s_newlen[kSelMaxCells];
-  __shared__ int s_pre[kSelMaxCells + 1];  // exclusive prefix of the cell counts (level-wide)
-  __shared__ int s_wave[kSelWaves];
-  __shared__ int s_c1;
-  __shared__ uint8_t s_glr[2 * kSelStage];  // stopper lists of the lane groups: 2 x count bytes per staged cell
-  static_assert(SDVL_CELL_KP_CAP <= 256, "cell positions are stored in a byte");
-  // One workgroup fills a CU (LDS), so a batch of more than 256 / n_levels frames runs in rounds.  Workgroups start in
-  // linear order: the level is the SLOW index, i.e. every frame's level 0 — the longest job — starts first and the short
-  // coarse levels fill the CUs as they free up (longest first: ~30 % less for 128 frames than frame-major order).
-  const int lin = static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x);
-  const int l = lin / static_cast<int>(gridDim.y);
-  const SelJob &job = jobs[lin - l * static_cast<int>(gridDim.y)];
-  const int tid = threadIdx.x;
-  const int wc = lv.wcells[l], hc = lv.hcells[l];
-  const int ncells = wc * hc;
-  const int cbeg = lv.cell_begin[l];
-  const int nfeatures = lv.quota[l];
-  const int cfirst = tid * kSelCellsPerThread;
-  // ---- load the cell counts, count the cells where cv::FAST ran but found nothing (fast_detector.cc:104-105)
-  int my_empty = 0, my_sum = 0;
-#pragma unroll
-  for (int k = 0; k < kSelCellsPerThread; k++) {
-    const int c = cfirst + k;
-    if (c < ncells) {
-      const int cnt = job.cell_counts[cbeg + c];
-      s_cnt[c] = static_cast<uint8_t>(cnt);
-      s_nleft[c] = static_cast<uint8_t>(cnt);
-      s_nsel[c] = 0;
-      my_sum += cnt;
-      const int i = c / wc, j = c - i * wc;
-      const bool ran = (min(job.lh[l] - lv.margin, i * lv.cell_size + lv.cell_size) > max(lv.margin, i * lv.cell_size)) &&
-                       (min(job.lw[l] - lv.margin, j * lv.cell_size + lv.cell_size) > max(lv.margin, j * lv.cell_size));
-      if (ran && cnt == 0) my_empty++;
-    }
-  }
-  int total_kps = 0;
-  {
-    int run = block_exclusive_scan(my_sum, s_wave, &total_kps);
-#pragma unroll
-    for (int k = 0; k < kSelCellsPerThread; k++) {
-      const int c = cfirst + k;
-      if (c < ncells) {
-        s_pre[c] = run;
-        run += s_cnt[c];
-      }
-    }
-    if (cfirst < ncells && cfirst + kSelCellsPerThread >= ncells) s_pre[ncells] = run;  // the thread that owns the last cell
-  }
-  int nempty = 0;
-  block_exclusive_scan(my_empty, s_wave, &nempty);
-  // ---- quota loop, fast_detector.cc:108-135: every pass is a map over the cells + two sums (order-free)
-  int selected = 0;
-  int cells_left = ncells - nempty;
-  while ((nfeatures - selected) > 0 && cells_left > 0) {
-    const int rem = nfeatures - selected;
-    const int npercell = (rem + cells_left - 1) / cells_left;  // ceil(double(rem) / double(cells_left))
-    int d_sel = 0, d_left = 0;
-#pragma unroll
-    for (int k = 0; k < kSelCellsPerThread; k++) {
-      const int c = cfirst + k;
-      if (c < ncells) {
-        const int nl = s_nleft[c];
-        if (nl > 0) {
-          if (nl > npercell) {
-            s_nsel[c] = static_cast<uint8_t>(s_nsel[c] + npercell);
-            d_sel += npercell;
-            s_nleft[c] = static_cast<uint8_t>(nl - npercell);
-            d_left++;
-          } else {
-            s_nsel[c] = static_cast<uint8_t>(s_nsel[c] + nl);
-            d_sel += nl;
-            s_nleft[c] = 0;
-          }
-        }
-      }
-    }
-    int tsel = 0, tleft = 0;
-    block_exclusive_scan(d_sel, s_wave, &tsel);
-    block_exclusive_scan(d_left, s_wave, &tleft);
-    selected += tsel;
-    cells_left = tleft;
-  }
-  __syncthreads();
-  // ---- per-cell retainBest (fast_detector.cc:138-145): cells staged into LDS in rounds, one lane per cell (the lanes
-  //      of a wave follow different control flow, hence 16 waves: few active lanes per wave);
-  //      survivors appended to s_fts in cell order through a prefix sum of the surviving lengths
-  int nfts = 0;
-  bool overflow = false;
-  int c0 = 0;
-  while (c0 < ncells) {
-    if (tid == 0) s_c1 = ncells;
-    __syncthreads();
-    {  // c1 = first cell whose list no longer fits the staging buffer
-      const int base = s_pre[c0];
-      int mine = ncells;
-#pragma unroll
-      for (int k = kSelCellsPerThread - 1; k >= 0; k--) {
-        const int c = cfirst + k;
-        if (c >= c0 && c < ncells && s_pre[c + 1] - base > kSelStage) mine = c;
-      }
-      if (mine < ncells) atomicMin(&s_c1, mine);
-    }
-    __syncthreads();
-    const int c1 = s_c1;
-    if (c1 == c0) { overflow = true; break; }  // a single cell larger than the staging buffer: impossible (<= 176)
-    const int base = s_pre[c0];
-    for (int c = c0 + (tid >> 2); c < c1; c += kSelThreads / 4) {  // 4 lanes copy one cell
-      const int cnt = s_cnt[c];
-      const uint32_t *src = job.cell_kps + static_cast<size_t>(cbeg + c) * SDVL_CELL_KP_CAP;
-      for (int k = (tid & 3); k < cnt; k += 4) s_stage[s_pre[c] - base + k] = src[k];
-    }
-    __syncthreads();
-    {  // kSelGroup lanes per cell, 64 / kSelGroup cells per wave at a time
-      const int gid = tid / kSelGroup, sub = tid % kSelGroup, shift = (tid & 63) - sub;
-      for (int c = c0 + gid; c < c1; c += kSelThreads / kSelGroup) {
-        uint8_t *Ls = &s_glr[2 * (s_pre[c] - base)];
-        const int nl = group_retain_best<kSelGroup, uint8_t>(&s_stage[s_pre[c] - base], s_cnt[c], s_nsel[c], Ls, Ls + s_cnt[c], sub, shift);
-        if (sub == 0) s_newlen[c] = static_cast<uint8_t>(nl);
-      }
-    }
-    __syncthreads();
-    int my_len = 0;
-#pragma unroll
-    for (int k = 0; k < kSelCellsPerThread; k++) {
-      const int c = cfirst + k;
-      if (c >= c0 && c < c1) my_len += s_newlen[c];
-    }
-    int round_total = 0;
-    int dst = nfts + block_exclusive_scan(my_len, s_wave, &round_total);
-    if (nfts + round_total > kSelFts) { overflow = true; break; }
-#pragma unroll
-    for (int k = 0; k < kSelCellsPerThread; k++) {
-      const int c = cfirst + k;
-      if (c >= c0 && c < c1) {
-        const int len = s_newlen[c];
-        const uint32_t *src = &s_stage[s_pre[c] - base];
-        for (int q = 0; q < len; q++) s_fts[dst + q] = src[q];
-        dst += len;
-      }
-    }
-    nfts += round_total;
-    __syncthreads();
-    c0 = c1;
-  }
-  // ---- final retainBest over the level (fast_detector.cc:147-148), cooperatively; s_stage is free now
-  int n = -1;
-  if (!overflow) {
-    uint16_t *Ls = reinterpret_cast<uint16_t *>(s_stage), *Rs = Ls + kSelFts;
-    n = nfts;
-    if (nfts > nfeatures) {  // one wave does it (no workgroup barriers inside); the others wait
-      __shared__ int s_final;
-      if (tid < 64) {
-        const int nl = group_retain_best<64, uint16_t>(s_fts, nfts, nfeatures, Ls, Rs, tid, 0);
-        if (tid == 0) s_final = nl;
-      }
-      __syncthreads();
-      n = s_final;
-    }
-    n = min(n, SDVL_MAX_CORNERS);
-  }
-  __syncthreads();
-  int32_t *dst = job.level_corners + static_cast<size_t>(l) * SDVL_MAX_CORNERS * 4;
-  for (int k = tid; k < n; k += kSelThreads) {
-    const uint32_t v = s_fts[k];
-    reinterpret_cast<int4 *>(dst)[k] = make_int4(static_cast<int>(v & 0xFFF), static_cast<int>((v >> 12) & 0xFFF), l, 0);
-  }
-  if (tid == 0) job.level_counts[l] = n;
+constexpr int kSelCellsPerWave = 64 / kSelGroup;  // 8 cells per wave
+
+// sum over the 64 lanes (all active), result in every lane: DPP adds inside the 16-lane rows, two row broadcasts, one readlane
+__device__ __forceinline__ int sel_wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
-// one workgroup per frame: level segments -> corners_ (fast_detector.cc:171-174 concatenates levels in order)
-// levels concatenated into corners_ (fast_detector.cc:151) + the count, then the list binned by 32-px cell of level-0
-// coordinates for the searches (GetCornersInRange scans ALL corners of the frame for every point, matcher.cc:123-230: with
-// the bins a search reads the handful of cells around its point).  The bins go into the selection scratch, dead by now.
-__global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restrict__ jobs, int n_levels, int32_t *__restrict__ batch_counts,
-                                                           int32_t *__restrict__ host_counts) {
-  __shared__ int s_hist[4096];
+// The quota loop of FastDetector::SelectPixels (fast_detector.cc:108-135) for one level, by one wave.  Every pass hands each cell that
+// still has keypoints left min(left, npercell) more, so after any pass a cell holds min(count, S) with S = the npercell values summed
+// so far, and the loop's two running sums are sum(min(count, S)) and #(count > S): ONE number per level describes the outcome for
+// every cell.  Returns S; cnt = the level's cell counts (bytes, LDS).
+__device__ __forceinline__ int sel_level_quota(const uint8_t *cnt, int ncells, int cells_left, int nfeatures, int lane) {
+  int S = 0, selected = 0;
+  while ((nfeatures - selected) > 0 && cells_left > 0) {
+    const int rem = nfeatures - selected;
+    S += (rem + cells_left - 1) / cells_left;  // ceil(double(rem) / double(cells_left))
+    int sel = 0, left = 0;
+    for (int c = lane; c < ncells; c += 64) {
+      const int n = cnt[c];
+      sel += min(n, S);
+      left += n > S ? 1 : 0;
+    }
+    selected = sel_wave_sum(sel);
+    cells_left = sel_wave_sum(left);
+  }
+  return S;
+}
+
+// one wave per (frame, level, 8 consecutive cells): per-cell retainBest, fast_detector.cc:138-145.  The surviving list replaces the
+// head of the cell's list in the detection scratch, its length goes to cell_newlen.
+__global__ __launch_bounds__(64) void select_cells_kernel(const SelJob *__restrict__ jobs, SelLevels lv, int n_frames) {
+  __shared__ uint8_t s_cnt[kSelMaxCells];
+  __shared__ uint32_t s_list[kSelCellsPerWave][SDVL_CELL_KP_CAP];
+  __shared__ uint8_t s_glr[kSelCellsPerWave][2 * SDVL_CELL_KP_CAP];  // stopper lists of the lane groups
+  static_assert(SDVL_CELL_KP_CAP <= 255, "cell positions and counts are stored in a byte");
+  // blocks b and b + 8 share an XCD (observed placement, used for speed only): all waves of a frame run on one, so the level's count
+  // array and the neighbouring cells' lists come out of one L2
+  const int slices = lv.slice_begin[lv.n_levels];
+  const int b = static_cast<int>(blockIdx.x), q = b >> 3;
+  const int fq = q / slices, s = q - fq * slices;
+  const int f = fq * 8 + (b & 7);
+  if (f >= n_frames) return;
+  int l = 0;
+  while (l + 1 < lv.n_levels && s >= lv.slice_begin[l + 1]) l++;
+  const SelJob &job = jobs[f];
+  const int lane = threadIdx.x;
+  const int ncells = lv.wcells[l] * lv.hcells[l], cbeg = lv.cell_begin[l];
+  // ---- the level's counts; cells where cv::FAST ran and found nothing (fast_detector.cc:104-105) = empty cells - cells it never ran on
+  int zeros = 0;
+  for (int c = lane; c < ncells; c += 64) {
+    const int n = job.cell_counts[cbeg + c];
+    s_cnt[c] = static_cast<uint8_t>(n);
+    zeros += n == 0 ? 1 : 0;
+  }
+  const int nempty = sel_wave_sum(zeros) - lv.not_run[l];
+  sel_wave_sync();
+  const int S = sel_level_quota(s_cnt, ncells, ncells - nempty, lv.quota[l], lane);
+  // ---- kSelGroup lanes per cell
+  const int g = lane / kSelGroup, sub = lane % kSelGroup, shift = lane - sub;
+  const int c = (s - lv.slice_begin[l]) * kSelCellsPerWave + g;
+  if (c >= ncells) return;
+  const int cnt = s_cnt[c];
+  const int nsel = min(cnt, S);
+  int nl = cnt;
+  if (cnt > nsel) {
+    uint32_t *list = job.cell_kps + static_cast<size_t>(cbeg + c) * SDVL_CELL_KP_CAP;
+    uint32_t *v = s_list[g];
+    for (int k = sub; k < cnt; k += kSelGroup) v[k] = list[k];
+    sel_wave_sync();
+    nl = group_retain_best<kSelGroup, uint8_t>(v, cnt, nsel, s_glr[g], s_glr[g] + cnt, sub, shift);
+    sel_wave_sync();
+    for (int k = sub; k < nl; k += kSelGroup) list[k] = v[k];
+  }
+  if (sub == 0) job.cell_newlen[cbeg + c] = nl;
+}
+
+// one workgroup per frame.  Wave l: the surviving lists of level l concatenated in cell order (fast_detector.cc:141-145), the level's
+// retainBest (:147-148).  Then all waves: levels concatenated into corners_ (:151, 171-174) + the count, and the list binned by 32-px
+// cell of level-0 coordinates for the searches (GetCornersInRange scans ALL corners of the frame for every point,
+// matcher.cc:123-230: with the bins a search reads the handful of cells around its point).
+// Dynamic LDS: [bin_cells] histogram | per level: list[fts_cap] (u32) | left-stoppers[fts_cap] (u16) | right-stoppers[fts_cap] (u16)
+__global__ __launch_bounds__(256) void select_pack_kernel(const SelJob *__restrict__ jobs, SelLevels lv, int32_t *__restrict__ batch_counts,
+                                                          int32_t *__restrict__ host_counts) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  __shared__ int s_n[4];
   __shared__ int s_part[256];
   const SelJob &job = jobs[blockIdx.x];
-  int off = 0;
-  bool bad = false;
-  for (int l = 0; l < n_levels; l++) {
-    const int cnt = job.level_counts[l];
-    if (cnt < 0 || off + cnt > SDVL_MAX_CORNERS) { bad = true; break; }
-    const int4 *src = reinterpret_cast<const int4 *>(job.level_corners + static_cast<size_t>(l) * SDVL_MAX_CORNERS * 4);
-    int4 *dst = reinterpret_cast<int4 *>(job.corner_hdr + 4) + off;
-    for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
-    off += cnt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cells = job.bin_cells;
+  int *s_hist = reinterpret_cast<int *>(s_dyn);
+  uint32_t *lists[4];
+  {
+    size_t off = (static_cast<size_t>(cells > 0 ? cells : 1) * 4 + 15) / 16 * 16;
+    for (int l = 0; l < 4; l++) {
+      lists[l] = reinterpret_cast<uint32_t *>(s_dyn + off);
+      if (l < lv.n_levels) off += static_cast<size_t>(lv.fts_cap[l]) * 8;
+    }
   }
-  if (threadIdx.x == 0) {
-    const int total = bad ? -1 : off;  // -1: a capacity overflowed; reported by sdvl_frames_corner_counts
-    job.corner_hdr[0] = total < 0 ? 0 : total;
+  if (wave < lv.n_levels) {
+    const int l = wave;
+    const int ncells = lv.wcells[l] * lv.hcells[l], cbeg = lv.cell_begin[l];
+    const int per = (ncells + 63) / 64;
+    const int c_lo = min(ncells, lane * per), c_hi = min(ncells, c_lo + per);
+    int mine = 0;
+    for (int c = c_lo; c < c_hi; c++) mine += job.cell_newlen[cbeg + c];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    const int nfts = __shfl(incl, 63, 64);
+    int dst = incl - mine;
+    int n = -1;  // a level of more than kSelFts candidates: reported as a capacity error, as before
+    if (nfts <= kSelFts) {
+      const bool fits = nfts <= lv.fts_cap[l];
+      uint32_t *spill = job.spill + static_cast<size_t>(l) * 2 * kSelFts;
+      // the gather: every lane copies the heads of its cells' lists
+      if (fits) {
+        uint32_t *v = lists[l];
+        for (int c = c_lo; c < c_hi; c++) {
+          const int len = job.cell_newlen[cbeg + c];
+          const uint32_t *src = job.cell_kps + static_cast<size_t>(cbeg + c) * SDVL_CELL_KP_CAP;
+          for (int k = 0; k < len; k++) v[dst++] = src[k];
+        }
+        sel_wave_sync();
+        n = nfts;
+        if (nfts > lv.quota[l]) {
+          uint16_t *Ls = reinterpret_cast<uint16_t *>(v + lv.fts_cap[l]);
+          n = group_retain_best<64, uint16_t>(v, nfts, lv.quota[l], Ls, Ls + lv.fts_cap[l], lane, 0);
+        }
+      } else {  // same statements on the frame's spill area in HBM (a wave's own stores and loads stay in order)
+        uint32_t *v = spill;
+        for (int c = c_lo; c < c_hi; c++) {
+          const int len = job.cell_newlen[cbeg + c];
+          const uint32_t *src = job.cell_kps + static_cast<size_t>(cbeg + c) * SDVL_CELL_KP_CAP;
+          for (int k = 0; k < len; k++) v[dst++] = src[k];
+        }
+        sel_wave_sync();
+        n = nfts;
+        if (nfts > lv.quota[l]) {
+          uint16_t *Ls = reinterpret_cast<uint16_t *>(v + kSelFts);
+          n = group_retain_best<64, uint16_t>(v, nfts, lv.quota[l], Ls, Ls + kSelFts, lane, 0);
+        }
+        sel_wave_sync();
+      }
+      if (lane == 0) s_n[l] = fits ? n : (n | 0x40000000);  // bit 30: the list lies in the spill area
+    } else if (lane == 0) {
+      s_n[l] = -1;
+    }
+  }
+  for (int c = tid; c < cells; c += 256) s_hist[c] = 0;
+  __syncthreads();
+  // ---- concatenation
+  int lvl_off[5];
+  bool bad = false;
+  lvl_off[0] = 0;
+  for (int l = 0; l < lv.n_levels; l++) {
+    const int raw = s_n[l];
+    if (raw < 0) { bad = true; lvl_off[l + 1] = lvl_off[l]; continue; }
+    if (raw & 0x40000000) lists[l] = job.spill + static_cast<size_t>(l) * 2 * kSelFts;
+    lvl_off[l + 1] = lvl_off[l] + (raw & 0x3FFFFFFF);
+  }
+  if (lvl_off[lv.n_levels] > job.corner_cap) bad = true;
+  const int n = bad ? 0 : lvl_off[lv.n_levels];
+  if (tid == 0) {
+    const int total = bad ? -1 : n;  // -1: a capacity overflowed; reported by sdvl_frames_corner_counts
+    job.corner_hdr[0] = n;
     job.corner_hdr[1] = total;
     if (batch_counts) batch_counts[blockIdx.x] = total;
     if (host_counts) host_counts[blockIdx.x] = total;
   }
-  const int cells = job.bin_cells;
-  if (cells <= 0) return;
-  const int n = bad ? 0 : off;
-  const int tid = threadIdx.x;
-  for (int c = tid; c < cells; c += 256) s_hist[c] = 0;
-  __syncthreads();  // also: every thread has finished copying out of the scratch the bins are about to overwrite
-  const int4 *list = reinterpret_cast<const int4 *>(job.corner_hdr + 4);
-  const auto cell_of = [&](const int4 c) {
-    const int x = min(c.x << c.z, job.lw[0] - 1), y = min(c.y << c.z, job.lh[0] - 1);
+  if (bad) return;
+  int4 *out = reinterpret_cast<int4 *>(job.corner_hdr + 4);
+  const auto cell_of = [&](uint32_t v, int l) {
+    const int x = min(static_cast<int>(v & 0xFFF) << l, job.lw[0] - 1), y = min(static_cast<int>((v >> 12) & 0xFFF) << l, job.lh[0] - 1);
     return (y >> 5) * job.bin_gw + (x >> 5);
   };
-  for (int k = tid; k < n; k += 256) atomicAdd(&s_hist[cell_of(list[k])], 1);
+  for (int l = 0; l < lv.n_levels; l++) {
+    const int nl = lvl_off[l + 1] - lvl_off[l];
+    const uint32_t *v = lists[l];
+    for (int k = tid; k < nl; k += 256) {
+      const uint32_t e = v[k];
+      out[lvl_off[l] + k] = make_int4(static_cast<int>(e & 0xFFF), static_cast<int>((e >> 12) & 0xFFF), l, 0);
+      if (cells > 0) atomicAdd(&s_hist[cell_of(e, l)], 1);
+    }
+  }
+  if (cells <= 0) return;
   __syncthreads();
   // exclusive scan of the histogram: every thread owns a run of consecutive cells
-  const int per = (cells + 255) / 256, c0 = tid * per, c1 = min(cells, c0 + per);
+  const int per = (cells + 255) / 256, c0 = min(cells, tid * per), c1 = min(cells, c0 + per);
   int sum = 0;
   for (int c = c0; c < c1; c++) sum += s_hist[c];
   s_part[tid] = sum;
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < 256; t++) { const int v = s_part[t]; s_part[t] = run; run += v; }
+  if (tid < 64) {  // one wave scans the 256 partial sums (4 per lane)
+    const int a0 = s_part[4 * tid], a1 = s_part[4 * tid + 1], a2 = s_part[4 * tid + 2], a3 = s_part[4 * tid + 3];
+    int incl = a0 + a1 + a2 + a3;
+    const int own = incl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (tid >= o) incl += t;
+    }
+    const int ex = incl - own;
+    s_part[4 * tid] = ex;
+    s_part[4 * tid + 1] = ex + a0;
+    s_part[4 * tid + 2] = ex + a0 + a1;
+    s_part[4 * tid + 3] = ex + a0 + a1 + a2;
   }
   __syncthreads();
   {
@@ -1490,11 +1492,14 @@ __global__ __launch_bounds__(256) void pack_corners_kernel(const SelJob *__restr
     if (tid == 0) job.bin_start[cells] = n;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
-    const int4 c = list[k];
-    const int slot = atomicAdd(&s_hist[cell_of(c)], 1);
-    job.bin_entries[slot] = make_uint2(static_cast<uint32_t>(c.x) | (static_cast<uint32_t>(c.y) << 12) | (static_cast<uint32_t>(c.z) << 24),
-                                       static_cast<uint32_t>(k));
+  for (int l = 0; l < lv.n_levels; l++) {
+    const int nl = lvl_off[l + 1] - lvl_off[l];
+    const uint32_t *v = lists[l];
+    for (int k = tid; k < nl; k += 256) {
+      const uint32_t e = v[k];
+      const int slot = atomicAdd(&s_hist[cell_of(e, l)], 1);
+      job.bin_entries[slot] = make_uint2((e & 0xFFFFFFu) | (static_cast<uint32_t>(l) << 24), static_cast<uint32_t>(lvl_off[l] + k));
+    }
   }
 }
 
@@ -1588,6 +1593,36 @@ int sdvl_fast_num_cells(int width, int height, const sdvl_detect_params *p, int 
   return SDVL_OK;
 }
 
+// Detection scratch of one batch slot: the per-cell FAST lists and counts, the lengths after the per-cell retainBest and the spill area
+// of the per-level lists.  A pool of the CONTEXT sized by its largest batch, alive between fast_cells and select_pack of one
+// submission only (round 3; it used to be part of every frame and stayed with a keyframe for good: 0.7 of its 1.43 MB).
+struct DetectSlot {
+  size_t counts_off, newlen_off, kps_off, spill_off, bytes;
+};
+static DetectSlot detect_slot_layout(int total_cells, int n_levels) {
+  DetectSlot L;
+  size_t off = 0;
+  const auto take = [&off](size_t bytes) { const size_t at = off; off = (off + bytes + 255) / 256 * 256; return at; };
+  L.counts_off = take(sizeof(int32_t) * (static_cast<size_t>(total_cells) + 1));
+  L.newlen_off = take(sizeof(int32_t) * static_cast<size_t>(total_cells));
+  L.kps_off = take(sizeof(uint32_t) * SDVL_CELL_KP_CAP * static_cast<size_t>(total_cells));
+  L.spill_off = take(sizeof(uint32_t) * 2 * kSelFts * static_cast<size_t>(n_levels));
+  L.bytes = off;
+  return L;
+}
+static int detect_scratch(sdvl_ctx *ctx, int n, const DetectSlot &L, uint8_t **base) {
+  const int rc = sdvl_ensure(ctx, &ctx->d_detect, &ctx->d_detect_bytes, L.bytes * static_cast<size_t>(n), false);
+  if (rc) return rc;
+  *base = static_cast<uint8_t *>(ctx->d_detect);
+  return SDVL_OK;
+}
+
+int64_t sdvl_detect_scratch_bytes(int width, int height, const sdvl_detect_params *p) {
+  int total = 0;
+  if (sdvl_fast_num_cells(width, height, p, nullptr, &total) != SDVL_OK) return -1;
+  return static_cast<int64_t>(detect_slot_layout(total, p->max_fast_levels).bytes);
+}
+
 // SDVL_FAST_WG4=1: the four-wave workgroup per cell (fast_cells_kernel) instead of one wave per cell (A/B measurements, tests)
 static bool fast_cells_four_waves() {
   static const bool v = getenv("SDVL_FAST_WG4") != nullptr;
@@ -1655,13 +1690,14 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
     total_cells += lv.wcells[l] * ((h + p->cell_size - 1) / p->cell_size);
   }
   lv.cell_begin[lv.n_levels] = total_cells;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n; i++)
     SDVL_REQUIRE(ctx, frames[i] && frames[i]->width == W && frames[i]->height == H && frames[i]->v.levels == frames[0]->v.levels,
                  "frames of one batch must share size and pyramid depth");
-    if (total_cells > frames[i]->max_cells) {
-      ctx->err = "cell grid larger than the frame's per-cell list capacity";
-      return SDVL_ERR_CAPACITY;
-    }
+  const DetectSlot slot = detect_slot_layout(total_cells, lv.n_levels);
+  uint8_t *scratch = nullptr;
+  {
+    const int rc_s = detect_scratch(ctx, n, slot, &scratch);
+    if (rc_s) return rc_s;
   }
   const size_t job_bytes = sizeof(FastJob) * n;
   const size_t offs_bytes = sizeof(int32_t) * static_cast<size_t>(n) * (total_cells + 1);
@@ -1679,8 +1715,8 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
       hj[i].lw[l] = frames[i]->v.lw[l];
       hj[i].lh[l] = frames[i]->v.lh[l];
     }
-    hj[i].cell_kps = frames[i]->cell_kps;
-    hj[i].cell_counts = frames[i]->cell_counts;
+    hj[i].cell_kps = reinterpret_cast<uint32_t *>(scratch + slot.bytes * i + slot.kps_off);
+    hj[i].cell_counts = reinterpret_cast<int32_t *>(scratch + slot.bytes * i + slot.counts_off);
   }
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, job_bytes, hipMemcpyHostToDevice, ctx->stream));
   int32_t *d_offs = static_cast<int32_t *>(ctx->d_out);
@@ -1758,27 +1794,47 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   double factor = 1.0, val = 0.0;
   for (int i = 0; i < p->max_fast_levels; i++) { val += factor; factor /= scale; }
   int levelfeatures = static_cast<int>(nfeatures / val);
-  int total_cells = 0;
+  int total_cells = 0, n_slices = 0;
+  size_t pack_lds = 0;
   for (int l = 0; l < lv.n_levels; l++) {
     SDVL_REQUIRE(ctx, l < frames[0]->v.levels, "max_fast_levels exceeds the pyramid depth");
     const int w = frames[0]->v.lw[l], h = frames[0]->v.lh[l];
     lv.cell_begin[l] = sl.cell_begin[l] = total_cells;
     lv.wcells[l] = sl.wcells[l] = (w + p->cell_size - 1) / p->cell_size;
     sl.hcells[l] = (h + p->cell_size - 1) / p->cell_size;
-    SDVL_REQUIRE(ctx, sl.wcells[l] * sl.hcells[l] <= kSelMaxCells, "too many cells in one level for the selection kernel");
-    total_cells += sl.wcells[l] * sl.hcells[l];
+    const int ncells = sl.wcells[l] * sl.hcells[l];
+    SDVL_REQUIRE(ctx, ncells <= kSelMaxCells, "too many cells in one level for the selection kernel");
+    total_cells += ncells;
     sl.quota[l] = levelfeatures;
     levelfeatures = static_cast<int>(levelfeatures / scale);
+    // cells whose ROI the margin swallows (cv::FAST is never called on them, fast_detector.cc:84-94)
+    int not_run = 0;
+    for (int ci = 0; ci < sl.hcells[l]; ci++)
+      for (int cj = 0; cj < sl.wcells[l]; cj++) {
+        const bool ran = std::min(h - p->margin, ci * p->cell_size + p->cell_size) > std::max(p->margin, ci * p->cell_size) &&
+                         std::min(w - p->margin, cj * p->cell_size + p->cell_size) > std::max(p->margin, cj * p->cell_size);
+        not_run += ran ? 0 : 1;
+      }
+    sl.not_run[l] = not_run;
+    sl.slice_begin[l] = n_slices;
+    n_slices += (ncells + kSelCellsPerWave - 1) / kSelCellsPerWave;
+    // LDS entries of the level's concatenated list in select_pack: the quota loop selects < quota + cells, ties that the per-cell
+    // retainBest keeps come on top (half as many again; a longer list is worked on in HBM)
+    sl.fts_cap[l] = std::min(kSelFts, ((sl.quota[l] + ncells) * 3 / 2 + 63) / 64 * 64);
+    pack_lds += static_cast<size_t>(sl.fts_cap[l]) * 8;
   }
   lv.cell_begin[lv.n_levels] = sl.cell_begin[sl.n_levels] = total_cells;
-  for (int i = 0; i < n; i++) {
+  sl.slice_begin[sl.n_levels] = n_slices;
+  for (int i = 0; i < n; i++)
     SDVL_REQUIRE(ctx, frames[i] && frames[i]->width == W && frames[i]->height == H && frames[i]->v.levels == frames[0]->v.levels,
                  "frames of one batch must share size and pyramid depth");
-    if (total_cells > frames[i]->max_cells) {
-      ctx->err = "cell grid larger than the frame's per-cell list capacity";
-      return SDVL_ERR_CAPACITY;
-    }
+  const DetectSlot slot = detect_slot_layout(total_cells, lv.n_levels);
+  uint8_t *scratch = nullptr;
+  {
+    const int rc_s = detect_scratch(ctx, n, slot, &scratch);
+    if (rc_s) return rc_s;
   }
+  pack_lds += (static_cast<size_t>(std::max(1, frames[0]->bin_cells)) * 4 + 15) / 16 * 16;
   const size_t fj_bytes = (sizeof(FastJob) * n + 255) / 256 * 256, sj_bytes = sizeof(SelJob) * n;
   void *hst = nullptr, *dst = nullptr;
   int rc = sdvl_ensure(ctx, &ctx->d_counts, &ctx->d_counts_bytes, sizeof(int32_t) * n, false);
@@ -1795,12 +1851,13 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
       hf[i].lw[l] = hs[i].lw[l] = frames[i]->v.lw[l];
       hf[i].lh[l] = hs[i].lh[l] = frames[i]->v.lh[l];
     }
-    hf[i].cell_kps = frames[i]->cell_kps;
-    hf[i].cell_counts = frames[i]->cell_counts;
-    hs[i].cell_kps = frames[i]->cell_kps;
-    hs[i].cell_counts = frames[i]->cell_counts;
-    hs[i].level_corners = frames[i]->level_corners;
-    hs[i].level_counts = frames[i]->level_counts;
+    uint8_t *sb = scratch + slot.bytes * i;
+    hf[i].cell_kps = hs[i].cell_kps = reinterpret_cast<uint32_t *>(sb + slot.kps_off);
+    hf[i].cell_counts = reinterpret_cast<int32_t *>(sb + slot.counts_off);
+    hs[i].cell_counts = hf[i].cell_counts;
+    hs[i].cell_newlen = reinterpret_cast<int32_t *>(sb + slot.newlen_off);
+    hs[i].spill = reinterpret_cast<uint32_t *>(sb + slot.spill_off);
+    hs[i].corner_cap = frames[i]->corner_cap;
     hs[i].corner_hdr = frames[i]->v.corner_hdr;
     hs[i].bin_start = frames[i]->bin_start;
     hs[i].bin_entries = frames[i]->bin_entries;
@@ -1824,12 +1881,21 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   } else {
     SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
   }
-  SDVL_LAUNCH(ctx, "select_corners", select_corners_kernel, dim3(lv.n_levels, n), dim3(kSelThreads), ds, sl);
+  SDVL_LAUNCH(ctx, "select_cells", select_cells_kernel, dim3(static_cast<unsigned>((n + 7) / 8 * 8 * n_slices)), dim3(64), ds, sl, n);
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
   // writes them into device memory and, when results go direct, into the pinned host array as well
   const bool direct = sdvl_direct_results() && sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK;
-  SDVL_LAUNCH(ctx, "pack_corners", pack_corners_kernel, dim3(n), dim3(256), ds, lv.n_levels, static_cast<int32_t *>(ctx->d_counts),
-              direct ? static_cast<int32_t *>(ctx->h_counts) : nullptr);
+  if (pack_lds > (48u << 10) && ctx->pack_lds_limit < pack_lds) {  // beyond the default dynamic-LDS limit: raise it once for this size
+    SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(select_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(pack_lds)));
+    ctx->pack_lds_limit = pack_lds;
+  }
+  {
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    sdvl_timer_events(ctx, "select_pack", &ev_a, &ev_b);
+    hipExtLaunchKernelGGL(select_pack_kernel, dim3(n), dim3(256), static_cast<unsigned>(pack_lds), ctx->stream, ev_a, ev_b, 0, ds, sl,
+                          static_cast<int32_t *>(ctx->d_counts), direct ? static_cast<int32_t *>(ctx->h_counts) : nullptr);
+  }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   ctx->counts_gen = ~0ull;
   if (direct) ctx->counts_gen = ctx->wait_gen;

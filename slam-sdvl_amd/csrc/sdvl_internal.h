@@ -21,23 +21,20 @@ struct FrameView {
   int32_t levels;
   int32_t n_corners;    // host copy of the corner count, -1 = only known on the device (after sdvl_detect_corners)
   int32_t *corner_hdr;  // device: [4] = {count, 0, 0, 0}, immediately followed by `corners`
-  int32_t *corners;     // device: [SDVL_MAX_CORNERS][4]: x, y, level, pad
-  uint8_t *desc;        // device: [SDVL_MAX_CORNERS][32]
+  int32_t *corners;     // device: [corner_cap][4]: x, y, level, pad
+  uint8_t *desc;        // device: [corner_cap][32]
 };
 
 struct sdvl_frame {
   FrameView v;
-  uint8_t *base;      // one allocation: pyramid | corners | descriptors | cell lists
+  uint8_t *base;      // one allocation: pyramid | corner header + list | descriptors | bin offsets | bin entries
   size_t bytes;
   int width, height;
-  uint32_t *cell_kps;    // [total_cells][SDVL_CELL_KP_CAP] packed (x | y<<12 | score<<24), level coordinates
-  int32_t *cell_counts;  // [total_cells]
-  int32_t *level_corners;  // [4][SDVL_MAX_CORNERS][4] per-level output segments of the selection kernel
-  int32_t *level_counts;   // [4]
-  int max_cells;
+  int corner_cap;        // corners the resident list / descriptor block / bin entries hold (sdvl_ctx_set_corner_capacity)
   int desc_valid;
-  // the corner list binned by 32-px cell of level-0 coordinates (written by the detection's pack kernel into the selection
-  // scratch, which is dead by then): searches visit the cells around a point instead of scanning every corner
+  // the corner list binned by 32-px cell of level-0 coordinates (written by the detection's pack kernel): searches visit the
+  // cells around a point instead of scanning every corner.  Round 3: part of the RESIDENT block; the detection's per-cell lists
+  // are scratch of the context (sdvl_ctx::d_detect), no longer part of a frame
   int32_t *bin_start;    // [bin_cells + 1]
   uint2 *bin_entries;    // [n_corners] {packed corner x | y<<12 | level<<24, index in the corner list}
   int bin_gw, bin_cells; // grid; bin_cells == 0: the frame size does not fit the binning kernel
@@ -77,6 +74,11 @@ struct sdvl_ctx {
   void *h_out = nullptr;   size_t h_out_bytes = 0;
   void *d_out = nullptr;   size_t d_out_bytes = 0;
   void *d_work = nullptr;  size_t d_work_bytes = 0;
+  // detection scratch (sdvl_detect.hip): per batch slot the per-cell FAST lists, counts and the selection's intermediate lists;
+  // dead once the batch's select_pack kernel has run
+  void *d_detect = nullptr; size_t d_detect_bytes = 0;
+  size_t pack_lds_limit = 0;            // dynamic LDS select_pack_kernel has been allowed so far
+  int corner_cap = SDVL_MAX_CORNERS;    // capacity of the corner list of frames created from now on
   size_t stage_off = 0;  // bump pointer into h_stage/d_stage; reset by every sdvl_stream_wait
   // A search batch (sdvl_search_begin .. sdvl_search_run) is filled by the caller over time and must survive every wait in
   // between, so it does not live in the ring (whose bump pointer any sdvl_stream_wait resets) but in buffers of its own

@@ -102,10 +102,18 @@ void Device::Check(int rc, const char *what) const {
   if (rc != SDVL_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + sdvl_last_error(ctx_));
 }
 
+// corners_ capacity of the frames this device creates: num_features plus the ties retainBest keeps (fast_detector.cc:147-148) fit
+// twice num_features with room to spare; a keyframe keeps its frame for good, so the list is not sized for the largest configuration
+int Device::CornerCap() const {
+  const int want = (2 * Config::NumFeatures() + 63) / 64 * 64;
+  return std::min(SDVL_MAX_CORNERS, std::max(1024, want));
+}
+
 sdvl_frame *Device::AcquireFrame(int w, int h, int levels) {
   std::lock_guard<std::mutex> lk(pool_mutex_);
+  const int cap = CornerCap();
   for (size_t i = 0; i < pool_.size(); i++) {
-    if (pool_[i].w == w && pool_[i].h == h && pool_[i].levels == levels) {
+    if (pool_[i].w == w && pool_[i].h == h && pool_[i].levels == levels && pool_[i].cap == cap) {
       sdvl_frame *f = pool_[i].f;
       pool_[i] = pool_.back();
       pool_.pop_back();
@@ -116,22 +124,25 @@ sdvl_frame *Device::AcquireFrame(int w, int h, int levels) {
   // milliseconds, so the slabs grow geometrically; callers that know their keyframe budget call Reserve() up front.
   const int chunk = std::min(512, std::max(32, total_frames_ / 2));
   std::vector<sdvl_frame *> fresh(chunk);
+  Check(sdvl_ctx_set_corner_capacity(ctx_, cap), "sdvl_ctx_set_corner_capacity");
   Check(sdvl_frame_create_many(ctx_, w, h, levels, chunk, fresh.data()), "sdvl_frame_create_many");
   total_frames_ += chunk;
-  for (int i = 1; i < chunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels});
+  for (int i = 1; i < chunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels, cap});
   return fresh[0];
 }
 
 void Device::Reserve(int w, int h, int levels, int frames) {
   std::lock_guard<std::mutex> lk(pool_mutex_);
+  const int cap = CornerCap();
   int have = 0;
-  for (const Pooled &p : pool_) have += (p.w == w && p.h == h && p.levels == levels) ? 1 : 0;
+  for (const Pooled &p : pool_) have += (p.w == w && p.h == h && p.levels == levels && p.cap == cap) ? 1 : 0;
+  Check(sdvl_ctx_set_corner_capacity(ctx_, cap), "sdvl_ctx_set_corner_capacity");
   while (have < frames) {
     const int chunk = std::min(512, frames - have);
     std::vector<sdvl_frame *> fresh(chunk);
     Check(sdvl_frame_create_many(ctx_, w, h, levels, chunk, fresh.data()), "sdvl_frame_create_many");
     total_frames_ += chunk;
-    for (int i = 0; i < chunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels});
+    for (int i = 0; i < chunk; i++) pool_.push_back(Pooled{fresh[i], w, h, levels, cap});
     have += chunk;
   }
 }
@@ -139,7 +150,7 @@ void Device::Reserve(int w, int h, int levels, int frames) {
 // frames die wherever their last shared_ptr is dropped, including the host worker threads
 void Device::ReleaseFrame(sdvl_frame *f, int w, int h, int levels) {
   std::lock_guard<std::mutex> lk(pool_mutex_);
-  pool_.push_back(Pooled{f, w, h, levels});
+  pool_.push_back(Pooled{f, w, h, levels, sdvl_frame_corner_capacity(f)});
 }
 
 // ---------------------------------------------------------------------------------------------------- RandStream

@@ -71,6 +71,7 @@ class Device {
   // make sure `frames` free HBM frames of this shape are pooled (keyframes keep theirs for good: size it from the
   // keyframe budget so that no hipMalloc lands on the tracking path)
   void Reserve(int w, int h, int levels, int frames);
+  int CornerCap() const;  // corners_ capacity of the frames created under the current Config
   void Check(int rc, const char *what) const;
   static Device *Current();
   static Device *CurrentOrNull();
@@ -93,7 +94,7 @@ class Device {
  private:
   sdvl_ctx *ctx_ = nullptr;
   int gpu_ = 0;
-  struct Pooled { sdvl_frame *f; int w, h, levels; };
+  struct Pooled { sdvl_frame *f; int w, h, levels, cap; };
   std::vector<Pooled> pool_;
   std::mutex pool_mutex_;
   int total_frames_ = 0;

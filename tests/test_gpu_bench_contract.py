@@ -36,10 +36,17 @@ def check(d, steps=4, warmup=1):
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["traffic"] is None or r["traffic"] > 0
+    # the roofline names THE dominant kernel: the one with the most dispatch time in the timed region, whatever its byte count
+    ms = d["kernel_ms_per_step"]
+    assert r["kernel"] == max(ms, key=ms.get), (r["kernel"], ms)
+    assert abs(r["avg_launch_us"] * 1e-6 * r["achieved"] * 1e9 - r["algorithmic_bytes_per_launch"]) / r["algorithmic_bytes_per_launch"] < 0.01
+    assert r["path_hbm"]["frac"] > 0
+    if "valu" in r:   # present when an SQ pass is committed under profiles/
+        assert r["valu"]["peak_wave_insts_per_s"] == 256 * 4 * 2.4e9 / 2 and 0 < r["valu"]["path_frac"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "tracked frames/s" and "sample" in c
     assert 0 < c["one_core"] <= c["value"] * 1.05   # the all-core figure is at least the one-core figure
-    assert d["value"] > 30 * c["value"] * 0.0 and d["value"] > c["value"]      # even this tiny batch beats one CPU core
+    assert d["value"] > 2 * c["one_core"]      # even this tiny batch (32 sequences, launch-latency bound) beats a CPU core several times over
 
 
 def test_bench_line_contract():
