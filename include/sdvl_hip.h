@@ -181,6 +181,11 @@ int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_im
 /* same without the copy: level 0 aliases the caller's HBM image (row stride == width), which must stay valid and
  * unmodified for as long as the frame is used; the next upload / set_image returns the frame to its own storage */
 int sdvl_frame_borrow_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img);
+/* n frames (one shape) whose level 0 aliases a caller image take the image into their own storage: one gather launch, queued on the
+ * context's stream.  For frames that must outlive the caller's buffer — a frame that has become a keyframe while its image sat in
+ * an input ring (Map::AddKeyframe keeps the Frame, map.cc:143-158; SearchPoint reads its pyramid for as long as its points live).
+ * Frames that own their image already are skipped. */
+int sdvl_frames_own_images(sdvl_ctx *ctx, int n, sdvl_frame *const *frames);
 /* Frame::CreatePyramid, frame.cc:114-120: levels 1..L-1 by cv::pyrDown for n frames */
 int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames);
 /* host mirror of GetPyramid()[level] (read by the mapper / UI) */

@@ -287,6 +287,15 @@ __global__ __launch_bounds__(256) void frames_upload_kernel(const UploadJob *__r
     }
   }
 }
+struct OwnRec {
+  int32_t id, pad_;
+  const uint8_t *level0;
+};
+// the registry record of a frame that has taken its image into its own storage: level 0 points there from now on
+__global__ __launch_bounds__(64) void registry_level0_kernel(const OwnRec *__restrict__ recs, int n, SearchFramePose *__restrict__ registry) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) registry[recs[i].id].f.level[0] = recs[i].level0;
+}
 }  // namespace
 
 extern "C" {
@@ -336,6 +345,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   }
   for (hipEvent_t e : ctx->copy_event)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
   for (void *j : ctx->h_prefetch_jobs)
     if (j) (void)hipHostFree(j);
   (void)hipStreamDestroy(ctx->stream);
@@ -646,7 +656,15 @@ int sdvl_ctx_prefetch_images(sdvl_ctx *ctx, int n, const uint8_t *const *imgs, i
   // 300 KB pieces or for a kernel pulling the bytes itself), and they take no compute unit from the step that is running.
   const size_t fb = static_cast<size_t>(width) * height;
   const unsigned ticket = ctx->prefetch_count++;
-  UploadJob *hj = static_cast<UploadJob *>(ctx->h_prefetch_jobs[ticket & 3u]);  // the list of four calls ago: its copy was fenced long since
+  // the job list and the event of four calls ago are reused: that prefetch must have completed (nothing obliges a caller to fence
+  // every prefetch, and the gather kernel reads its list in place from host memory)
+  if (ticket >= 4u) SDVL_HIP_CHECK(ctx, hipEventSynchronize(ctx->copy_event[ticket & 3u]));
+  UploadJob *hj = static_cast<UploadJob *>(ctx->h_prefetch_jobs[ticket & 3u]);
+  // the destinations may still be read by work queued on the context's stream (frames that alias an input-ring slot, and the
+  // keyframes' copy out of it, sdvl_frames_own_images): the prefetch starts behind everything queued there so far
+  if (!ctx->order_event) SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
+  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->order_event, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->order_event, 0));
   int n_mapped = 0;
   for (int i = 0; i < n;) {
     SDVL_REQUIRE(ctx, imgs[i] && dev_dst[i], "null image or destination");
@@ -706,6 +724,43 @@ int sdvl_frame_borrow_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev
   f->v.n_corners = 0;
   f->desc_valid = 0;
   f->bins_valid = 0;
+  return SDVL_OK;
+}
+
+// Frames whose level 0 aliases a caller image (sdvl_frame_borrow_image_device: an input-ring slot, a capture buffer) and that must
+// outlive it — the frames that have just become keyframes (reference patches for SearchPoint come from the keyframe of a point's
+// first observation, matcher.cc:52,87) — copy the image into their own level 0: ONE gather launch, and the level-0 pointer of
+// their registry records follows.  Frames that already own their image are skipped.
+int sdvl_frames_own_images(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
+  if (!ctx || n < 0 || (n > 0 && !frames)) return SDVL_ERR_INVALID;
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    SDVL_REQUIRE(ctx, frames[i] != nullptr, "null frame");
+    SDVL_REQUIRE(ctx, frames[i]->width == frames[0]->width && frames[i]->height == frames[0]->height, "sdvl_frames_own_images: frames of one shape");
+    if (frames[i]->v.level[0] != frames[i]->own_level0) m++;
+  }
+  if (m == 0) return SDVL_OK;
+  void *hs = nullptr, *ds = nullptr;
+  const size_t jb = (sizeof(UploadJob) * static_cast<size_t>(m) + 255) / 256 * 256;
+  const int rc = sdvl_stage_alloc(ctx, jb + sizeof(OwnRec) * static_cast<size_t>(m), &hs, &ds);
+  if (rc) return rc;
+  UploadJob *hj = static_cast<UploadJob *>(hs);
+  OwnRec *hr = reinterpret_cast<OwnRec *>(static_cast<uint8_t *>(hs) + jb);
+  int k = 0, n_reg = 0;
+  for (int i = 0; i < n; i++) {
+    sdvl_frame *f = frames[i];
+    if (f->v.level[0] == f->own_level0) continue;
+    hj[k++] = UploadJob{f->v.level[0], f->own_level0};
+    if (f->home == ctx && f->reg_id >= 0) hr[n_reg++] = OwnRec{f->reg_id, 0, f->own_level0};
+    f->v.level[0] = f->own_level0;
+  }
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, jb + sizeof(OwnRec) * static_cast<size_t>(m), hipMemcpyHostToDevice, ctx->stream));
+  SDVL_LAUNCH(ctx, "frames_own", frames_upload_kernel, dim3(kUploadChunks, m), dim3(256), static_cast<const UploadJob *>(ds), frames[0]->width,
+              frames[0]->height, frames[0]->width);
+  if (n_reg > 0 && ctx->d_registry)
+    hipLaunchKernelGGL(registry_level0_kernel, dim3((n_reg + 63) / 64), dim3(64), 0, ctx->stream,
+                       reinterpret_cast<const OwnRec *>(static_cast<uint8_t *>(ds) + jb), n_reg, static_cast<SearchFramePose *>(ctx->d_registry));
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
 }
 

@@ -1165,7 +1165,7 @@ __device__ __forceinline__ unsigned long long group_ballot(bool p, int shift) {
 }
 
 constexpr int kSelGroupMin = 4;  // ranges shorter than this are finished by the group's first lane (>= 4: the median-of-3 positions must differ)
-constexpr int kSelGroup = 8;     // lanes that share a cell's retainBest in select_corners_kernel
+constexpr int kSelGroup = 8;     // lanes that share a cell's retainBest in select_cells_kernel
 
 // block_two_pointer_partition for a group: left-stoppers ascending in Ls[0..nL), right-stoppers ASCENDING in Rs[0..nR) (the
 // k-th from the right is Rs[nR - 1 - k]); L[k] < R[k] is monotone in k, so K is a count.  Returns K; *cut = where the left

@@ -64,6 +64,7 @@ struct sdvl_ctx {
   // input ring (sdvl_ctx_prefetch_images / _fence): a second stream that carries the NEXT step's images while this one computes
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};  // one per prefetch in flight (ticket & 3)
+  hipEvent_t order_event = nullptr;  // marks the compute stream when a prefetch is issued: the copy stream starts behind it
   void *h_prefetch_jobs[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned job lists, read by the gather kernel where they are
   size_t prefetch_jobs_cap = 0;
   unsigned prefetch_count = 0;

@@ -21,7 +21,7 @@ struct SearchFrame {
   const uint8_t *desc;
   const int32_t *n_ptr;  // device-resident corner count
   int levels;
-  int bin_gw;            // corners binned by 32-px cell of level-0 coordinates (pack_corners_kernel), bin_start == null: none
+  int bin_gw;            // corners binned by 32-px cell of level-0 coordinates (select_pack_kernel), bin_start == null: none
   const int32_t *bin_start;
   const uint2 *bin_entries;
   int bin_cells, pad_;

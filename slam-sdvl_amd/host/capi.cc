@@ -233,6 +233,16 @@ int sdvlh_batch_step_device_copy(void *bp, const void *const *dev_imgs, int stri
   return step(b, v, out);
 }
 
+// the same without the copy for the frames that never need one (round 3): the frames alias the ring slot for the step that tracks
+// them; those that become keyframes copy their image out at the end of the step (Frame::OwnImages).  The caller must not refill
+// the slot before work queued on the batch's stream has passed (sdvl_ctx_prefetch_images orders itself behind that stream).
+int sdvlh_batch_step_device_transient(void *bp, const void *const *dev_imgs, int stride, sdvlh_frame_stats *out) {
+  Batch *b = static_cast<Batch *>(bp);
+  std::vector<Image> v;
+  for (size_t i = 0; i < b->trackers.size(); i++) v.push_back(Image::WrapDevice(dev_imgs[i], b->w, b->h, stride, true, true));
+  return step(b, v, out);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Farm: G groups x Bg sequences on ONE GPU.  Every group owns a host thread, an sdvl::Device (= sdvl_ctx = HIP stream
 // + staging + frame pool) and an SDVLBatch; groups free-run through their steps, so the host stages of one group
@@ -316,7 +326,9 @@ struct Farm {
         return -1;
       }
       slot_ptrs(s);
-      return sdvlh_batch_step_device_copy(batches[g], dst.data(), stride, out + off);
+      static const bool copy_all = getenv("SDVL_RING_COPY_ALL") != nullptr;  // round 2's behaviour: every frame copies its image out of the ring (A/B)
+      return copy_all ? sdvlh_batch_step_device_copy(batches[g], dst.data(), stride, out + off)
+                      : sdvlh_batch_step_device_transient(batches[g], dst.data(), stride, out + off);
     }
     if (host_input) return sdvlh_batch_step_host(batches[g], reinterpret_cast<const uint8_t *const *>(dev_frames + off), stride, out + off);
     return sdvlh_batch_step_device(batches[g], dev_frames + off, stride, out + off);

@@ -568,9 +568,11 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
     up_i.clear();
   };
   for (int i = 0; i < n; i++) {
-    if (imgs[i].dev_src && imgs[i].step == imgs[i].cols && imgs[i].borrow)
+    frames[i]->SetImageTransient(false);
+    if (imgs[i].dev_src && imgs[i].step == imgs[i].cols && imgs[i].borrow) {
       dev->Check(sdvl_frame_borrow_image_device(dev->ctx(), devs[i], imgs[i].dev_src), "sdvl_frame_borrow_image_device");
-    else {  // host images, and images in HBM that the frame must own a copy of (an input ring the caller overwrites)
+      frames[i]->SetImageTransient(imgs[i].transient);
+    } else {  // host images, and images in HBM that the frame must own a copy of (an input ring the caller overwrites)
       if (!up_f.empty() && (imgs[i].step != up_step || frames[i]->GetWidth() != frames[0]->GetWidth() || frames[i]->GetHeight() != frames[0]->GetHeight()))
         flush();
       up_step = imgs[i].step;
@@ -615,6 +617,18 @@ void Frame::CreateBatch(Camera *camera, ORBDetector *detector, const vector<Imag
   (void)pfor;
   clk.reset();
   BuildFrames(raw, devs, imgs, corners, nfeatures);
+}
+
+void Frame::OwnImages(const vector<shared_ptr<Frame>> &frames) {
+  vector<sdvl_frame *> devs;
+  Device *dev = nullptr;
+  for (const shared_ptr<Frame> &f : frames)
+    if (f && f->image_transient_ && f->dev_) {
+      devs.push_back(f->dev_);
+      f->image_transient_ = false;
+      dev = f->owner_;
+    }
+  if (!devs.empty()) dev->Check(sdvl_frames_own_images(dev->ctx(), static_cast<int>(devs.size()), devs.data()), "sdvl_frames_own_images");
 }
 
 FrameArena *Frame::NewArena() const { return new FrameArena(owner_ ? owner_->chunks : nullptr); }
@@ -2254,6 +2268,13 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   if (!HandleFramesTracked(imgs, stats)) {
     SyncHostState();  // Feature lists and Point counters catch up with the device; the tables are rebuilt when tracking returns
     HandleFramesGeneric(imgs, stats);
+  }
+  {  // frames that became keyframes while their image sat in an input-ring slot keep a copy; everybody else never copied level 0
+     // (the step's own frame pointer is gone by now: a fresh keyframe is the tracker's last_kf_, sdvl.cc:113)
+    vector<shared_ptr<Frame>> keep;
+    for (SDVL *t : trk_)
+      if (t->last_kf_ && t->last_kf_->ImageTransient()) keep.push_back(t->last_kf_);
+    if (!keep.empty()) Frame::OwnImages(keep);
   }
   stage_times.t[ST_TOTAL] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
   g_stage_times = nullptr;

@@ -381,6 +381,11 @@ class Frame : public std::enable_shared_from_this<Frame> {
 
   bool IsKeyframe() { return is_keyframe_; }
   void SetKeyframe() { is_keyframe_ = true; }
+  // level 0 aliases an HBM image that is valid during the frame's own step only (Image::transient)
+  bool ImageTransient() const { return image_transient_; }
+  void SetImageTransient(bool on) { image_transient_ = on; }
+  // the frames among `frames` whose image is transient copy it into their own level 0 (one launch): keyframes outlive the ring
+  static void OwnImages(const std::vector<std::shared_ptr<Frame>> &frames);
   void FilterCorners();
   static void FilterCornersBatch(const std::vector<std::shared_ptr<Frame>> &frames);
   static void FilterCornersBegin(const std::vector<std::shared_ptr<Frame>> &frames);  // the two halves of FilterCornersBatch
@@ -481,6 +486,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   ORBDetector *orb_detector_ = nullptr;
   int pyramid_levels_ = 0;
   bool is_keyframe_ = false;
+  bool image_transient_ = false;
   std::vector<Image> pyramid_;
   bool pyramid_on_host_ = false;
   int width_ = 0, height_ = 0;

@@ -71,9 +71,12 @@ struct Image {
   const void *dev_src = nullptr;
   std::shared_ptr<void> dev_owner;  // keeps an HBM image produced by this layer alive (Camera::UndistortImage)
   bool borrow = false;  // the HBM image outlives every Frame built from it: alias it instead of copying
-  static Image WrapDevice(const void *dev_ptr, int w, int h, int stride, bool borrow_storage = false) {
+  // borrow + transient: the HBM image stays valid for the step that tracks it only (a slot of an input ring): the Frame aliases it
+  // and takes a copy if it becomes a keyframe (Frame::OwnImages) — one frame in five in S-A, the other four never copy
+  bool transient = false;
+  static Image WrapDevice(const void *dev_ptr, int w, int h, int stride, bool borrow_storage = false, bool transient_storage = false) {
     Image r;
-    r.dev_src = dev_ptr; r.cols = w; r.rows = h; r.step = stride; r.borrow = borrow_storage;
+    r.dev_src = dev_ptr; r.cols = w; r.rows = h; r.step = stride; r.borrow = borrow_storage; r.transient = borrow_storage && transient_storage;
     return r;
   }
 };

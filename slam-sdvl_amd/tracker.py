@@ -34,6 +34,7 @@ def load_host_library():
         lib.sdvlh_batch_destroy.argtypes = [C.c_void_p]
         lib.sdvlh_batch_step_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.sdvlh_batch_step_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.sdvlh_batch_step_device_transient.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.sdvlh_config_set.argtypes = [C.c_char_p, C.c_double]
         _lib = lib
     return _lib
@@ -143,6 +144,14 @@ class TrackerBatch:
     def step_device(self, dev_ptrs):
         ptrs = (C.c_void_p * self.B)(*[int(p) for p in dev_ptrs])
         if self.lib.sdvlh_batch_step_device(self.h, ptrs, self.w, self._stats) != 0:
+            raise RuntimeError(self.lib.sdvlh_last_error().decode())
+        return self._stats
+
+    def step_device_transient(self, dev_ptrs):
+        """frames in HBM that stay valid for THIS step only (a slot of an input ring): aliased while tracked, frames that become
+        keyframes take a copy at the end of the step"""
+        ptrs = (C.c_void_p * self.B)(*[int(p) for p in dev_ptrs])
+        if self.lib.sdvlh_batch_step_device_transient(self.h, ptrs, self.w, self._stats) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return self._stats
 

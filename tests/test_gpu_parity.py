@@ -148,9 +148,9 @@ def test_device_retain_best_is_libstdcxx_order(ctx, orc):
         want = orc.retain_best(v, k)
         assert np.array_equal(ctx.retain_best(v, k), want), (len(v), k, "one lane")
         assert np.array_equal(ctx.retain_best(v, k, cooperative=True), want), (len(v), k, "workgroup")
-        if len(v) <= 176:     # a cell's list: 16 lanes of a wave (the form select_corners uses per cell)
+        if len(v) <= 176:     # a cell's list: 16 lanes of a wave (the form select_cells uses per cell)
             assert np.array_equal(ctx.retain_best(v, k, cooperative=2), want), (len(v), k, "16 lanes")
-        if len(v) <= 4096:    # a level's list: one wave (the form select_corners uses per level)
+        if len(v) <= 4096:    # a level's list: one wave (the form select_pack uses per level)
             assert np.array_equal(ctx.retain_best(v, k, cooperative=3), want), (len(v), k, "one wave")
 
 

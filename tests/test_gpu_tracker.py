@@ -202,6 +202,50 @@ def test_farm_fibers_give_identical_results(trk, orc, synth):
     assert all(r[1] == 0 and r[4] >= 100 for r in plain[n:])      # tracking, not idling
 
 
+def test_transient_ring_images_equal_resident_images(trk, orc, synth):
+    """frames that alias a 2-slot ring for the step that tracks them (sdvlh_batch_step_device_transient: the slot is overwritten two
+    steps later; only the frames that became keyframes copied their image out, Frame::OwnImages) give the per-frame results of frames
+    that alias images resident for good — every decision and every pose bit, over enough steps for keyframes to be created, searched
+    against and outlive several rewrites of their slot"""
+    import ctypes as C
+    import importlib
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    n, n_steps = 4, 12
+    fb = 640 * 480
+    trk.configure()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def run(mode):
+        dev = trk.HostDevice(0)
+        batch = trk.TrackerBatch(dev, n, 640, 480, TUM_CAM)
+        ctx = B.CtxView(sdvl, dev.ctx_handle())
+        buf = ctx.malloc(n * n_steps * fb)
+        ring = ctx.malloc(2 * n * fb)
+        for k in range(n_steps):
+            views = [B.make_view(sdvl, trajectory_pose(orc, k, XI * (1.0 + 0.1 * i)), 20260001 + i, k) for i in range(n)]
+            ctx.render(views, buf + k * n * fb)
+        stream = C.c_void_p(ctx.lib.sdvl_ctx_stream(ctx.h))
+        out = []
+        for k in range(n_steps):
+            if mode == "resident":
+                st = batch.step_device([buf + (k * n + i) * fb for i in range(n)])
+            else:
+                slot = ring + (k % 2) * n * fb
+                assert hip.hipMemcpyAsync(slot, buf + k * n * fb, n * fb, 3, stream) == 0   # device to device, on the batch's stream
+                st = batch.step_device_transient([slot + i * fb for i in range(n)])
+            out += [(s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas, tuple(s.pose[:])) for s in st]
+        batch.close()
+        dev.close()
+        return out
+
+    resident = run("resident")
+    assert run("ring") == resident
+    assert sum(r[2] for r in resident[n:]) >= n           # keyframes were created after the bootstrap
+    assert all(r[1] == 0 and r[4] >= 100 for r in resident[n:])
+
+
 def test_farm_host_input_ring_gives_identical_results(trk, orc, synth):
     """host-fed farm: frames in pinned host memory.  With the input ring (the images of step s + 1 travel on the group's copy
     stream while step s computes; contiguous runs as one DMA, the rest per image) and without it (every step uploads its own

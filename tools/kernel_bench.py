@@ -154,7 +154,7 @@ ctx._check(lib.sdvl_frames_corner_counts(ctx.h, n, arr0, counts.ctypes.data_as(C
 nc = float(counts.mean())
 i_ia = its / (reps * n)
 P = [(W >> l) * (H >> l) for l in range(5)]
-alg = {"pyr_down": (sum(P[:4]) + sum(P[1:])) / 4.0, "fast_cells": sum(P[:3]) + 16 * nc, "select_corners": 4 * 10000 + 16 * nc, "pack_corners": 32 * nc,
+alg = {"pyr_down": (sum(P[:4]) + sum(P[1:])) / 4.0, "fast_cells": sum(P[:3]) + 16 * nc, "select_cells": 4 * 10000 + 6 * nc + 1600, "select_pack": 1600 + 30 * nc,
        "orb_describe": 993 * nc, "image_align": 147 * nf + 25 * nf * i_ia, "pose_hypotheses": 48 * nf + 6400, "undistort": 2 * W * H,
        "search_points": 12 * nc + nf * (121 + 164 + lk * 81), "search_prepare": nf * (120 + 80),
        "pose_refine": 52 * nf + 6480}

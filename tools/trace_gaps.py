@@ -23,8 +23,8 @@ queues = defaultdict(set)
 for r in rows:
     queues[r[4]].add(r[3])
 print("streams %d, hardware queues %d (streams per queue: %s)" % (len(by_stream), len(queues), sorted(len(v) for v in queues.values())))
-pairs = [("pyr_down_kernel", "pyr_down_kernel"), ("pyr_down_kernel", "image_align_lds_kernel"), ("fast_cells_kernel", "select_corners_kernel"),
-         ("select_corners_kernel", "pack_corners_kernel"), ("search_prepare_kernel", "search_points_kernel"),
+pairs = [("pyr_down_kernel", "pyr_down_kernel"), ("pyr_down_kernel", "image_align_lds_kernel"), ("fast_cells_wave_kernel", "select_cells_kernel"),
+         ("select_cells_kernel", "select_pack_kernel"), ("search_prepare_kernel", "search_points_kernel"),
          ("select_matches_kernel", "pose_hypotheses_kernel"), ("pose_hypotheses_kernel", "pose_refine_kernel"),
          ("shi_tomasi_kernel", "orb_describe_kernel"), ("orb_describe_kernel", "filter_gather_kernel"), ("shi_tomasi_kernel", "filter_gather_kernel")]
 gaps = defaultdict(list)
