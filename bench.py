@@ -648,16 +648,30 @@ def main():
             farm.set_input_ring(not os.environ.get("SDVL_BENCH_NO_INPUT_RING"))
             farm.set_host_input(True)     # allocates the groups' input rings
             hstats_buf = farm.alloc_stats(Kh)
+            farm.stage_times(reset=True)
+            for c in ctxs:
+                c.timing(not os.environ.get("SDVL_BENCH_NO_KERNEL_TIMING"))
             barrier()
             t0 = time.perf_counter()
             hstats = farm.run(hptrs, workers, hstats_buf)
             barrier()
             elapsed_h = time.perf_counter() - t0
             farm.set_host_input(False)
+            h_timers = {}
+            for c in ctxs:
+                for name, (ms, n_l) in c.timing_get().items():
+                    a = h_timers.get(name, (0.0, 0))
+                    h_timers[name] = (a[0] + ms, a[1] + n_l)
+                c.timing(False)
+            h_stage_s, h_stage_n = farm.stage_times()
+            feed_call_s, feed_wait_s, feed_calls = farm.feed_stats()
             tracked_h = sum(int(st.quality != 2) for st in hstats)
             th_all, eh_max = shard.reduce_throughput(tracked_h, elapsed_h, dist if distributed else None, "cuda")
             host_fed = {"value": round(th_all / eh_max, 2), "unit": "frames/s", "steps": Kh, "ms_per_step": round(eh_max / Kh * 1e3, 3),
                         "pcie_h2d_gb_per_s": round(world * B * Kh * frame_bytes / eh_max / 1e9, 2),
+                        "feeder": {"transfers": feed_calls, "s_in_transfer_calls": round(feed_call_s, 4), "s_waiting_for_a_free_slot": round(feed_wait_s, 4), "wall_s": round(elapsed_h, 4)},
+                        "kernel_ms_per_step": {k: round(v[0] / Kh, 4) for k, v in sorted(h_timers.items())},
+                        "host_stage_ms_per_group_step": {k: round(v / max(1, h_stage_n) * 1e3, 3) for k, v in h_stage_s.items() if v > 0},
                         "input": "pinned host memory, %d B per frame; the images of step s + 1 travel on the group's copy stream into a "
                                  "2-step input ring in HBM while step s computes (SDVL_BENCH_NO_INPUT_RING=1: uploaded inside the step)" % frame_bytes}
     if cpu_sample is not None:

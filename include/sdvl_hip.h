@@ -176,6 +176,22 @@ int sdvl_frames_upload(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const ui
  * The caller owns the destination buffers and must not prefetch into one that queued work may still read. */
 int sdvl_ctx_prefetch_images(sdvl_ctx *ctx, int n, const uint8_t *const *imgs, int stride, int width, int height, void *const *dev_dst);
 int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx, int ticket);
+/* Feed: ONE copy stream for several contexts of a GPU (a farm of tracker groups, one context per host thread), filled by ONE thread
+ * of the caller's in the order the images will be needed.  hipMemcpyAsync of tens of MB keeps its calling thread for much of the
+ * transfer, and transfers issued by 16 threads onto 16 streams share the link — in one queue they follow each other at the link's
+ * rate.  n_slots buffers sets (caller-owned HBM) take turns:
+ *   sdvl_feed_images       feeder thread: n host images -> dev_dst[i] (dense rows that follow each other on both sides: one DMA per
+ *                          run), behind the slot's last sdvl_ctx_feed_release
+ *   sdvl_ctx_feed_acquire  consumer (the thread that drives ctx): ctx's stream waits for the slot's transfer
+ *   sdvl_ctx_feed_release  consumer: the work ctx has queued so far is the last reader of the slot's buffers
+ * The caller orders the three calls of a slot among its threads; the library orders the streams. */
+typedef struct sdvl_feed sdvl_feed;
+int sdvl_feed_create(int device, int n_slots, sdvl_feed **out);
+int sdvl_feed_destroy(sdvl_feed *f);
+const char *sdvl_feed_last_error(const sdvl_feed *f);
+int sdvl_feed_images(sdvl_feed *f, int slot, int n, const uint8_t *const *imgs, int stride, int width, int height, void *const *dev_dst);
+int sdvl_ctx_feed_acquire(sdvl_ctx *ctx, sdvl_feed *f, int slot);
+int sdvl_ctx_feed_release(sdvl_ctx *ctx, sdvl_feed *f, int slot);
 /* same, image already in HBM (device pointer) */
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride);
 /* same without the copy: level 0 aliases the caller's HBM image (row stride == width), which must stay valid and

@@ -129,7 +129,7 @@ ABI_SYMBOLS = [
     "sdvl_track_create", "sdvl_track_destroy", "sdvl_frame_register", "sdvl_track_upload", "sdvl_track_align", "sdvl_track_search",
     "sdvl_track_collect", "sdvl_track_features", "sdvl_track_stats",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
-    "sdvl_frames_own_images", "sdvl_frame_footprint_cap", "sdvl_ctx_set_corner_capacity", "sdvl_frame_corner_capacity", "sdvl_detect_scratch_bytes",
+    "sdvl_frames_own_images", "sdvl_feed_create", "sdvl_feed_destroy", "sdvl_feed_last_error", "sdvl_feed_images", "sdvl_ctx_feed_acquire", "sdvl_ctx_feed_release", "sdvl_frame_footprint_cap", "sdvl_ctx_set_corner_capacity", "sdvl_frame_corner_capacity", "sdvl_detect_scratch_bytes",
 ]
 
 _lib = None

@@ -704,6 +704,98 @@ int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx, int ticket) {
   return SDVL_OK;
 }
 
+// ---- feed: a copy stream of its own, driven by a thread of its own ---------------------------------------------------------
+// A feed is ONE stream that ONE caller thread (a farm's feeder) fills in the order the images will be needed; consumers (contexts,
+// each on its own thread) only exchange events with it:
+//   feeder    sdvl_feed_images(slot, ...)       transfer into the slot's buffers, behind the slot's last release
+//   consumer  sdvl_ctx_feed_acquire(ctx, slot)  ctx's stream waits for that transfer
+//             sdvl_ctx_feed_release(ctx, slot)  what ctx has queued so far was the last reader of the slot's buffers
+// The caller orders the three calls of a slot among its threads (a mutex / condition variable); the library orders the streams.
+struct sdvl_feed {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> ready, released;
+  std::string err;
+};
+
+int sdvl_feed_create(int device, int n_slots, sdvl_feed **out) {
+  if (!out || n_slots <= 0) return SDVL_ERR_INVALID;
+  *out = nullptr;
+  if (hipSetDevice(device) != hipSuccess) return SDVL_ERR_NO_DEVICE;
+  sdvl_feed *f = new sdvl_feed();
+  f->device = device;
+  bool ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
+  f->ready.assign(n_slots, nullptr);
+  f->released.assign(n_slots, nullptr);
+  for (int i = 0; i < n_slots && ok; i++)
+    ok = hipEventCreateWithFlags(&f->ready[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&f->released[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    sdvl_feed_destroy(f);
+    return SDVL_ERR_HIP;
+  }
+  *out = f;
+  return SDVL_OK;
+}
+
+int sdvl_feed_destroy(sdvl_feed *f) {
+  if (!f) return SDVL_ERR_INVALID;
+  (void)hipSetDevice(f->device);
+  if (f->stream) {
+    (void)hipStreamSynchronize(f->stream);
+    (void)hipStreamDestroy(f->stream);
+  }
+  for (hipEvent_t e : f->ready)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : f->released)
+    if (e) (void)hipEventDestroy(e);
+  delete f;
+  return SDVL_OK;
+}
+
+const char *sdvl_feed_last_error(const sdvl_feed *f) { return f ? f->err.c_str() : "null feed"; }
+
+#define SDVL_FEED_CHECK(f, expr)                                        \
+  do {                                                                  \
+    hipError_t e_ = (expr);                                             \
+    if (e_ != hipSuccess) {                                             \
+      (f)->err = std::string(#expr) + ": " + hipGetErrorString(e_);     \
+      return SDVL_ERR_HIP;                                              \
+    }                                                                   \
+  } while (0)
+
+int sdvl_feed_images(sdvl_feed *f, int slot, int n, const uint8_t *const *imgs, int stride, int width, int height, void *const *dev_dst) {
+  if (!f || n <= 0 || !imgs || !dev_dst || width <= 0 || height <= 0 || stride < width) return SDVL_ERR_INVALID;
+  if (slot < 0 || slot >= static_cast<int>(f->ready.size())) return SDVL_ERR_INVALID;
+  SDVL_FEED_CHECK(f, hipSetDevice(f->device));
+  SDVL_FEED_CHECK(f, hipStreamWaitEvent(f->stream, f->released[slot], 0));  // never recorded yet: no wait
+  const size_t fb = static_cast<size_t>(width) * height;
+  for (int i = 0; i < n;) {
+    if (!imgs[i] || !dev_dst[i]) { f->err = "null image or destination"; return SDVL_ERR_INVALID; }
+    int run = 1;  // dense images that follow each other on both sides travel as ONE transfer
+    if (stride == width)
+      while (i + run < n && imgs[i + run] == imgs[i] + run * fb && dev_dst[i + run] == static_cast<uint8_t *>(dev_dst[i]) + run * fb) run++;
+    if (stride == width) SDVL_FEED_CHECK(f, hipMemcpyAsync(dev_dst[i], imgs[i], fb * run, hipMemcpyHostToDevice, f->stream));
+    else SDVL_FEED_CHECK(f, hipMemcpy2DAsync(dev_dst[i], width, imgs[i], stride, width, height, hipMemcpyHostToDevice, f->stream));
+    i += run;
+  }
+  SDVL_FEED_CHECK(f, hipEventRecord(f->ready[slot], f->stream));
+  return SDVL_OK;
+}
+
+int sdvl_ctx_feed_acquire(sdvl_ctx *ctx, sdvl_feed *f, int slot) {
+  if (!ctx || !f || slot < 0 || slot >= static_cast<int>(f->ready.size())) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, ctx->device == f->device, "feed and context of one GPU");
+  SDVL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, f->ready[slot], 0));
+  return SDVL_OK;
+}
+
+int sdvl_ctx_feed_release(sdvl_ctx *ctx, sdvl_feed *f, int slot) {
+  if (!ctx || !f || slot < 0 || slot >= static_cast<int>(f->released.size())) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, hipEventRecord(f->released[slot], ctx->stream));
+  return SDVL_OK;
+}
+
 int sdvl_frame_set_image_device(sdvl_ctx *ctx, sdvl_frame *f, const void *dev_img, int stride) {
   if (!ctx || !f || !dev_img) return SDVL_ERR_INVALID;
   SDVL_REQUIRE(ctx, stride >= f->width, "stride smaller than width");

@@ -269,7 +269,20 @@ struct Farm {
   // host input travels ahead: while a group computes step s, its copy stream carries the images of the next steps into the free
   // slots of the group's input ring (kRingSlots x Bg frames of HBM); the frames then copy their image out of the ring (HBM -> HBM)
   bool input_ring = true;
-  static constexpr int kRingSlots = 2;  // 3 (two steps ahead) measured slower: the transfers of step s + 2 share the link with those of s + 1, which the next step waits for (116 k against 133-145 k frames/s)
+  // Round 3: ONE copy stream for the whole farm, filled by a feeder thread of its own (sdvl_feed), and a ring of three steps per
+  // group.  Before, every group's worker thread issued its own prefetch on its own copy stream: hipMemcpyAsync of 79 MB kept the
+  // worker for a good part of the transfer (15 of the 34 ms of a group-step were spent outside HandleFrames), and the 16 groups'
+  // transfers ran side by side and shared the link, so the one a group was waiting for was slowed by the ones nobody needed yet
+  // (38-47 GB/s of the 57 the link gives; a ring of three was slower still).  The feeder issues the transfers one after the
+  // other, the group that is furthest behind first; the workers only exchange events with it.
+  // SDVL_RING_PRIVATE_STREAMS=1: round 2's form (the worker prefetches on its context's copy stream, two slots).
+  bool use_feeder = true;
+  int kRingSlots = 3;
+  sdvl_feed *feed = nullptr;
+  double feed_call_s = 0.0, feed_wait_s = 0.0;  // the feeder's time inside sdvl_feed_images / waiting for a free slot, last run
+  long feed_calls = 0;
+  std::vector<int> issued;          // [group] steps whose images the feeder has queued
+  std::condition_variable cv_feed;  // feeder <-> workers (under m)
   std::vector<void *> ring;
   std::vector<int> ring_ticket;  // [group][slot]: the prefetch that filled the slot
 
@@ -295,6 +308,30 @@ struct Farm {
     const int total = G * Bg;
     const int s = done[g];  // only the owner of a busy group reads or writes its counter
     const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
+    if (host_input && input_ring && use_feeder && feed) {
+      sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(devices[g]));
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_feed.wait(lk, [&] { return issued[g] > s || failed; });
+        if (failed) return -1;
+      }
+      const int slot = g * kRingSlots + s % kRingSlots;
+      if (sdvl_ctx_feed_acquire(ctx, feed, slot) != SDVL_OK) {  // this step's kernels start behind its images
+        g_err = std::string("input ring: ") + sdvl_last_error(ctx);
+        return -1;
+      }
+      const size_t fb = static_cast<size_t>(w) * h;
+      std::vector<void *> dst(Bg);
+      uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(s % kRingSlots) * Bg * fb;
+      for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
+      const int rc = sdvlh_batch_step_device_transient(batches[g], dst.data(), w, out + off);
+      // the kernels queued up to here (the keyframes' copy out of the slot included) are the slot's last readers
+      if (rc == 0 && sdvl_ctx_feed_release(ctx, feed, slot) != SDVL_OK) {
+        g_err = std::string("input ring: ") + sdvl_last_error(ctx);
+        return -1;
+      }
+      return rc;
+    }
     if (host_input && input_ring && stride == w) {
       // a ring of kRingSlots steps: while step s computes, the images of the following kRingSlots - 1 steps are under way
       sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(devices[g]));
@@ -342,6 +379,52 @@ struct Farm {
       busy[g] = 0;
     }
     cv_work.notify_all();
+    cv_feed.notify_all();
+  }
+
+  // The feeder: queues the images of (group, step) pairs on the farm's one copy stream, always for the group whose next step is
+  // the earliest among those with a free ring slot (step s may go into its slot once step s - kRingSlots is complete).
+  void RunFeeder() {
+    const size_t fb = static_cast<size_t>(w) * h;
+    const int total = G * Bg;
+    std::vector<void *> dst(Bg);
+    for (;;) {
+      int g = -1, s = 0;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          if (failed) return;
+          bool left = false;
+          g = -1;
+          for (int k = 0; k < G; k++) {
+            if (issued[k] >= n_steps) continue;
+            left = true;
+            if (issued[k] - done[k] < kRingSlots && (g < 0 || issued[k] < issued[g])) g = k;
+          }
+          if (!left) return;
+          if (g >= 0) break;
+          const auto tw = std::chrono::steady_clock::now();
+          cv_feed.wait(lk);
+          feed_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+        }
+        s = issued[g];
+      }
+      const auto tc = std::chrono::steady_clock::now();
+      uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(s % kRingSlots) * Bg * fb;
+      for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
+      const size_t o = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
+      const int rc = sdvl_feed_images(feed, g * kRingSlots + s % kRingSlots, Bg, reinterpret_cast<const uint8_t *const *>(dev_frames + o), stride, w, h,
+                                      dst.data());
+      feed_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+      feed_calls++;
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (rc != SDVL_OK) { failed = true; err = std::string("input ring: ") + sdvl_feed_last_error(feed); }
+        issued[g]++;
+      }
+      cv_feed.notify_all();
+      cv_work.notify_all();
+    }
   }
 
   // A worker repeatedly takes the idle group that is furthest behind and executes its next step, so a descheduled or
@@ -358,9 +441,13 @@ struct Farm {
           if (failed) return;
         }
         const int rc = StepGroup(worker);
-        std::lock_guard<std::mutex> lk(m);
-        done[worker]++;
-        if (rc != 0) { failed = true; err = sdvlh_last_error(); return; }
+        {
+          std::lock_guard<std::mutex> lk(m);
+          done[worker]++;
+          if (rc != 0) { failed = true; err = sdvlh_last_error(); }
+        }
+        cv_feed.notify_all();
+        if (rc != 0) return;
       }
       return;
     }
@@ -438,7 +525,11 @@ void FiberMain(unsigned lo, unsigned hi) {
     f->rc = 0;
     for (int s = 0; s < f->farm->n_steps && f->rc == 0; s++) {
       f->rc = f->farm->StepGroup(f->group);
-      f->farm->done[f->group]++;
+      {
+        std::lock_guard<std::mutex> lk(f->farm->m);
+        f->farm->done[f->group]++;
+      }
+      f->farm->cv_feed.notify_all();
     }
   } else {
     f->rc = f->farm->StepGroup(f->group);
@@ -538,7 +629,8 @@ void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4
   Farm *f = new Farm();
   f->gpu = gpu; f->G = G; f->Bg = Bg; f->w = w; f->h = h;
   f->ring.assign(G, nullptr);
-  f->ring_ticket.assign(static_cast<size_t>(G) * Farm::kRingSlots, -1);
+  if (getenv("SDVL_RING_PRIVATE_STREAMS")) { f->use_feeder = false; f->kRingSlots = 2; }
+  f->ring_ticket.assign(static_cast<size_t>(G) * f->kRingSlots, -1);
   for (int g = 0; g < G; g++) {
     void *d = sdvlh_device_create(gpu);
     if (!d) { sdvlh_farm_destroy(f); return nullptr; }
@@ -569,16 +661,26 @@ void sdvlh_farm_set_host_input(void *fp, int on) {
   for (int g = 0; g < f->G; g++)
     if (!f->ring[g]) {
       sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(f->devices[g]));
-      if (sdvl_device_malloc(ctx, static_cast<int64_t>(Farm::kRingSlots * fb * f->Bg), &f->ring[g]) != SDVL_OK) f->ring[g] = nullptr;  // StepGroup retries and reports
+      if (sdvl_device_malloc(ctx, static_cast<int64_t>(f->kRingSlots * fb * f->Bg), &f->ring[g]) != SDVL_OK) f->ring[g] = nullptr;  // StepGroup retries and reports
     }
 }
+// (the feed itself is created by the first host-fed run)
 // the input ring of host-fed runs on (default) / off (every step uploads its own frames on its own stream before it computes)
 void sdvlh_farm_set_input_ring(void *fp, int on) { static_cast<Farm *>(fp)->input_ring = on != 0; }
+
+// the feeder thread of the last host-fed run: seconds inside sdvl_feed_images, seconds waiting for a free ring slot, transfers
+void sdvlh_farm_feed_stats(void *fp, double *out3) {
+  Farm *f = static_cast<Farm *>(fp);
+  out3[0] = f->feed_call_s;
+  out3[1] = f->feed_wait_s;
+  out3[2] = static_cast<double>(f->feed_calls);
+}
 
 void sdvlh_farm_destroy(void *fp) {
   Farm *f = static_cast<Farm *>(fp);
   if (!f) return;
   for (void *b : f->batches) sdvlh_batch_destroy(b);
+  if (f->feed) sdvl_feed_destroy(f->feed);  // waits for its stream: nothing writes the rings after this
   for (size_t g = 0; g < f->ring.size() && g < f->devices.size(); g++)
     if (f->ring[g]) sdvl_device_free(static_cast<sdvl_ctx *>(sdvlh_device_ctx(f->devices[g])), f->ring[g]);
   for (void *d : f->devices) sdvlh_device_destroy(d);
@@ -702,7 +804,18 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
     f->n_steps = n_steps; f->stride = stride; f->dev_frames = dev_frames; f->out = out;
     f->done.assign(f->G, 0);
     f->busy.assign(f->G, 0);
+    f->issued.assign(f->G, 0);
+    f->feed_call_s = f->feed_wait_s = 0.0;
+    f->feed_calls = 0;
     f->failed = false;
+  }
+  std::thread feeder;
+  if (f->host_input && f->input_ring && f->use_feeder) {
+    bool rings = true;
+    for (int g = 0; g < f->G; g++) rings = rings && f->ring[g] != nullptr;
+    if (!rings) { g_err = "input ring: the rings were not allocated (sdvlh_farm_set_host_input)"; return -1; }
+    if (!f->feed && sdvl_feed_create(f->gpu, f->G * f->kRingSlots, &f->feed) != SDVL_OK) { g_err = "input ring: sdvl_feed_create failed"; return -1; }
+    feeder = std::thread([f] { f->RunFeeder(); });
   }
   static const bool profile = std::getenv("SDVL_PROFILE") != nullptr;
   if (profile) ProfStart();
@@ -715,6 +828,10 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
       ProfThreadStop(pt);
     });
   for (auto &t : threads) t.join();
+  if (feeder.joinable()) {
+    f->cv_feed.notify_all();
+    feeder.join();
+  }
   if (profile) ProfStop();
   if (f->failed) { g_err = f->err; return -1; }
   return 0;

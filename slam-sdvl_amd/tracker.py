@@ -244,6 +244,13 @@ class TrackerFarm:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return out
 
+    def feed_stats(self):
+        """feeder thread of the last host-fed run -> (seconds inside the transfer calls, seconds waiting for a free ring slot, transfers)"""
+        out = (C.c_double * 3)()
+        self.lib.sdvlh_farm_feed_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.sdvlh_farm_feed_stats(self.h, out)
+        return out[0], out[1], int(out[2])
+
     def set_input_ring(self, on):
         """host-fed runs: the images of step s + 1 travel on the group's copy stream while step s computes (default on)"""
         self.lib.sdvlh_farm_set_input_ring.argtypes = [C.c_void_p, C.c_int]
