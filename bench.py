@@ -425,6 +425,10 @@ def main():
     ap.add_argument("--mapper", action="store_true",
                     help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip, -1 = the workload's)")
+    ap.add_argument("--sustained-frames", type=int, default=-1,
+                    help="frames per sequence of the third, SUSTAINED leg: fresh trackers run a whole sequence of SURVEY §8d's S-A (300 frames, "
+                         "~60 keyframes each, every keyframe keeps its HBM frame) host-fed from a pool of distinct sequences; reported as "
+                         "value_sustained with keyframes per sequence and the HBM / RSS peaks; 0 = skip; default 300 for S-A on one GPU")
     ap.add_argument("--host-steps", type=int, default=-1,
                     help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
@@ -455,6 +459,8 @@ def main():
     distributed = world > 1
     if args.host_steps < 0:
         args.host_steps = 16 if world == 1 else 0
+    if args.sustained_frames < 0:
+        args.sustained_frames = 300 if (world == 1 and args.workload == "S-A" and not args.mapper and not dry) else 0
     dist = None
     if dry:
         return dry_rank(args, rank, world)
@@ -674,6 +680,63 @@ def main():
                         "host_stage_ms_per_group_step": {k: round(v / max(1, h_stage_n) * 1e3, 3) for k, v in h_stage_s.items() if v > 0},
                         "input": "pinned host memory, %d B per frame; the images of step s + 1 travel on the group's copy stream into a "
                                  "2-step input ring in HBM while step s computes (SDVL_BENCH_NO_INPUT_RING=1: uploaded inside the step)" % frame_bytes}
+    # ---- third leg, SUSTAINED: S-A is 300 frames per sequence (main.cc:126-159 loops over the whole sequence).  The
+    # first leg keeps every input frame resident (B x frames x 307 KB) and so measures a burst of a few dozen frames; here FRESH
+    # trackers run whole sequences.  What stays resident is what the path itself retains: every keyframe keeps its HBM frame
+    # (pyramid + corner list + descriptors + bins; the detection scratch left the frame in round 3) and its host-side features.
+    # Input: a pool of D distinct sequences in pinned host memory (tracker i follows sequence i mod D; D x frames x 307 KB), fed
+    # through the farm's input ring like the host-fed leg — every tracker's frames cross the link, nothing is shared on the device.
+    sustained = None
+    NF = args.sustained_frames
+    if NF > Wm + 2:
+        import resource as _res
+        lib_hip = pkg.load_library()
+        ctx.check(lib_hip.sdvl_device_free(ctx.h, C.c_void_p(buf)))
+        farm.close()                        # the first legs' trackers, keyframes and rings go
+        farm = None
+        torch.cuda.synchronize()
+        free0, total0 = torch.cuda.mem_get_info()
+        D = min(B, int(os.environ.get("SDVL_BENCH_SUSTAINED_DISTINCT", "32")))
+        kf_budget = NF // 4 + 8             # S-A turns about one frame in five into a keyframe
+        need2 = G * Bg * kf_budget * footprint + 3 * B * frame_bytes + B * scratch_per_frame
+        if need2 > 0.9 * free0:
+            sys.stderr.write("bench.py: sustained leg skipped: %d sequences x ~%d keyframes x %.2f MB = %.0f GB of HBM, %.0f GB free\n" %
+                             (B, kf_budget, footprint / 1e6, need2 / 1e9, free0 / 1e9))
+        else:
+            farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
+            farm.set_fibers(fibers)
+            ctx2 = CtxView(pkg, farm.ctx_handle(0))
+            spool = torch.empty(D * NF * frame_bytes, dtype=torch.uint8, pin_memory=True)
+            tmp = ctx2.malloc(D * frame_bytes)
+            for k in range(NF):
+                views = [make_view(pkg, se3_exp(shard.sequence_twist(d) * k), shard.sequence_seed(d), k) for d in range(D)]
+                ctx2.render(views, tmp)
+                ctx2.check(lib_hip.sdvl_device_download(ctx2.h, C.c_void_p(tmp), C.c_int64(D * frame_bytes), C.c_void_p(spool.data_ptr() + k * D * frame_bytes)))
+            ctx2.check(lib_hip.sdvl_device_free(ctx2.h, C.c_void_p(tmp)))
+            sptrs = (spool.data_ptr() + (np.arange(NF, dtype=np.uint64)[:, None] * D + (np.arange(B, dtype=np.uint64) % D)[None, :]) * frame_bytes).astype(np.uint64)
+            farm.set_input_ring(True)
+            farm.set_host_input(True)
+            farm.reserve(Bg * kf_budget)
+            farm.run(sptrs[:1 + Wm], workers)                      # bootstrap keyframe + warm-up, untimed
+            Ks = NF - 1 - Wm
+            sbuf = farm.alloc_stats(Ks)
+            barrier()
+            t0 = time.perf_counter()
+            sstats = farm.run(sptrs[1 + Wm:], workers, sbuf)
+            barrier()
+            elapsed_s = time.perf_counter() - t0
+            free1, _ = torch.cuda.mem_get_info()
+            tracked_s = sum(int(st.quality != 2) for st in sstats)
+            kf_s = sum(int(st.keyframe) for st in sstats)
+            sustained = {"value": round(tracked_s / elapsed_s, 2), "unit": "frames/s", "frames_per_sequence": NF, "timed_steps": Ks, "ms_per_step": round(elapsed_s / Ks * 1e3, 3),
+                         "sequences_per_gpu": B, "tracked_fraction": round(tracked_s / (B * Ks), 5),
+                         "keyframes_per_sequence": round(1 + kf_s / B * (NF - 1) / Ks, 1), "hbm_bytes_per_keyframe": int(footprint), "corner_capacity": corner_cap,
+                         "hbm_used_gb_at_end": round((total0 - free1) / 1e9, 1), "hbm_total_gb": round(total0 / 1e9, 1),
+                         "host_max_rss_gb": round(_res.getrusage(_res.RUSAGE_SELF).ru_maxrss / 1e6, 1),
+                         "pcie_h2d_gb_per_s": round(B * Ks * frame_bytes / elapsed_s / 1e9, 2),
+                         "input": "host-fed through the input ring from %d distinct sequences x %d frames in pinned host memory (tracker i follows sequence i mod %d)" % (D, NF, D)}
+            farm.set_host_input(False)
+            del spool
     if cpu_sample is not None:
         fps1, n_tracked1, secs1 = cpu_one
         n_thr = max(1, min(ncpu, 16))
@@ -743,6 +806,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed_max / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
             "value_host_fed": host_fed["value"] if host_fed else None, "host_fed": host_fed,
+            "value_sustained": sustained["value"] if sustained else None, "sustained": sustained,
             "config": {"workload": "%s: synthetic TUM fr1-like %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step%s" % (args.workload, W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",
@@ -758,7 +822,8 @@ def main():
             "speedup_vs_cpu_all_cores": round(value / cpu["value"], 2) if cpu else None,
         }
         print(json.dumps(out))
-    farm.close()
+    if farm is not None:
+        farm.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -47,6 +47,26 @@ int sdvl_registry_reserve(sdvl_ctx *ctx, int extra) {
   return SDVL_OK;
 }
 
+namespace {
+typedef unsigned int push_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stage_push_kernel(const push_u32x4 *__restrict__ src, push_u32x4 *__restrict__ dst, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = __builtin_nontemporal_load(src + i);
+}
+}  // namespace
+
+hipError_t sdvl_push(sdvl_ctx *ctx, void *dst_dev, const void *src_staged, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  static const bool dma = getenv("SDVL_STAGE_DMA") != nullptr;
+  const uint8_t *s8 = static_cast<const uint8_t *>(src_staged), *ring = static_cast<const uint8_t *>(ctx->h_stage);
+  // inside the ring allocations are 256-byte granules on both sides: copying whole 16-byte units never leaves them
+  const bool staged = ring && s8 >= ring && s8 + bytes <= ring + ctx->h_stage_bytes && ((reinterpret_cast<uintptr_t>(s8) | reinterpret_cast<uintptr_t>(dst_dev)) & 15u) == 0;
+  if (dma || !staged || bytes > (static_cast<size_t>(64) << 20)) return hipMemcpyAsync(dst_dev, src_staged, bytes, hipMemcpyHostToDevice, ctx->stream);
+  const int n16 = static_cast<int>((bytes + 15) >> 4);
+  const int blocks = n16 <= 256 ? 1 : (n16 >= 256 * 64 ? 64 : (n16 + 255) / 256);
+  hipLaunchKernelGGL(stage_push_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const push_u32x4 *>(s8), static_cast<push_u32x4 *>(dst_dev), n16);
+  return hipGetLastError();
+}
+
 int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d) {
   const size_t need = (bytes + 255) / 256 * 256;
   const size_t cap = ctx->h_stage_bytes < ctx->d_stage_bytes ? ctx->h_stage_bytes : ctx->d_stage_bytes;
@@ -611,7 +631,7 @@ int sdvl_frames_upload(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const ui
     int k = 0;
     for (int i = 0; i < n; i++)
       if (mapped[i]) hj[k++] = UploadJob{mapped[i], frames[i]->own_level0};
-    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, sizeof(UploadJob) * static_cast<size_t>(n_mapped), hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_push(ctx, ds, hs, sizeof(UploadJob) * static_cast<size_t>(n_mapped)));
     SDVL_LAUNCH(ctx, "frames_upload", frames_upload_kernel, dim3(kUploadChunks, n_mapped), dim3(256), static_cast<const UploadJob *>(ds), width,
                 height, stride);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
@@ -846,7 +866,7 @@ int sdvl_frames_own_images(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
     if (f->home == ctx && f->reg_id >= 0) hr[n_reg++] = OwnRec{f->reg_id, 0, f->own_level0};
     f->v.level[0] = f->own_level0;
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, jb + sizeof(OwnRec) * static_cast<size_t>(m), hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, ds, hs, jb + sizeof(OwnRec) * static_cast<size_t>(m)));
   SDVL_LAUNCH(ctx, "frames_own", frames_upload_kernel, dim3(kUploadChunks, m), dim3(256), static_cast<const UploadJob *>(ds), frames[0]->width,
               frames[0]->height, frames[0]->width);
   if (n_reg > 0 && ctx->d_registry)
@@ -888,7 +908,7 @@ int sdvl_frame_set_corners(sdvl_ctx *ctx, sdvl_frame *f, int n, const int32_t *x
     for (int i = 0; i < n; i++) {
       st[4 * (i + 1)] = xyl[3 * i]; st[4 * (i + 1) + 1] = xyl[3 * i + 1]; st[4 * (i + 1) + 2] = xyl[3 * i + 2]; st[4 * (i + 1) + 3] = 0;
     }
-    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(f->v.corner_hdr, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_push(ctx, f->v.corner_hdr, st, bytes));
     SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   }
   f->hdr_stale = 0;

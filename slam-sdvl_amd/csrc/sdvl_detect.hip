@@ -1563,7 +1563,7 @@ int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
       const FrameView &v = frames[i]->v;
       hj[(l - 1) * n + i] = PyrJob{v.level[l - 1], v.level[l], v.lw[l - 1], v.lh[l - 1], v.lw[l], v.lh[l]};
     }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hj, bytes));
   for (int l = 1; l < levels; l++) {
     const FrameView &v = frames[0]->v;
     static const bool four_waves = getenv("SDVL_PYR_WG4") != nullptr;
@@ -1718,7 +1718,7 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
     hj[i].cell_kps = reinterpret_cast<uint32_t *>(scratch + slot.bytes * i + slot.kps_off);
     hj[i].cell_counts = reinterpret_cast<int32_t *>(scratch + slot.bytes * i + slot.counts_off);
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, job_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hj, job_bytes));
   int32_t *d_offs = static_cast<int32_t *>(ctx->d_out);
   uint32_t *d_kps = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->d_out) + offs_bytes);
   const CellGeo *d_cells = nullptr;
@@ -1868,7 +1868,7 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
     frames[i]->hdr_stale = 0;     // the pack kernel rewrites the header
     frames[i]->desc_valid = 0;
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dst, hst, fj_bytes + sj_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dst, hst, fj_bytes + sj_bytes));
   const FastJob *df = static_cast<const FastJob *>(dst);
   const SelJob *ds = reinterpret_cast<const SelJob *>(static_cast<uint8_t *>(dst) + fj_bytes);
   const CellGeo *d_cells = nullptr;

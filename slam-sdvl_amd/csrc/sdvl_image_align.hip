@@ -704,7 +704,7 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     }
   }
   if (feat_bytes) memcpy(static_cast<uint8_t *>(hs) + job_bytes, features, feat_bytes);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, job_bytes + feat_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, job_bytes + feat_bytes));
   const sdvl_align_feature *feats_dev = d_features ? d_features : reinterpret_cast<const sdvl_align_feature *>(static_cast<uint8_t *>(dsx) + job_bytes);
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   const bool direct = sdvl_direct_results();

@@ -179,6 +179,13 @@ int sdvl_ensure(sdvl_ctx *ctx, void **p, size_t *cur, size_t need, bool pinned);
 // last sdvl_stream_wait never overlap, so a call can fill its records while earlier copies are still in flight;
 // only when the ring is exhausted does this wait for the stream.
 int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d);
+// Records staged in the context's pinned ring (sdvl_stage_alloc) -> device memory, queued on ctx->stream.  Round 3: a small KERNEL
+// pulls them over the bus instead of a hipMemcpyAsync: a DMA copy command waits in its engine's queue behind whatever that engine
+// is doing — with a farm's 79 MB image transfers under way every job-record copy (a few KB, in front of every kernel) queued up
+// behind ~1.4 ms of somebody else's images, and the groups' steps ran one after the other (host-fed 115-135 k tracked frames/s with
+// the transfers running, 234 k with the same steps and the transfers skipped).  Sources outside the staging ring fall back to the
+// DMA copy.  SDVL_STAGE_DMA=1: always the DMA copy (A/B).
+hipError_t sdvl_push(sdvl_ctx *ctx, void *dst_dev, const void *src_staged, size_t bytes);
 // wait for everything queued on ctx->stream WITHOUT spinning: a mark (sdvl_mark_record) + sleeping polls (sdvl_mark_wait).
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
 // a point of the stream to wait for later: everything queued before the mark has completed once the wait returns; work

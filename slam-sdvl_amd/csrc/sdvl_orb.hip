@@ -325,7 +325,7 @@ int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t 
     const int bound = v.n_corners >= 0 ? v.n_corners : 1280;  // device-only count: a typical grid; the kernels grid-stride
     if (bound > *max_n) *max_n = bound;
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hj, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hj, bytes));
   *d_jobs = static_cast<OrbJob *>(dsx);
   return SDVL_OK;
 }
@@ -548,7 +548,7 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
     hj[i].ccap = ccap;
   }
   memcpy(static_cast<uint8_t *>(hs) + jb, locked_cells, mb);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, jb + mb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, jb + mb));
   static const bool scan_only = getenv("SDVL_FILTER_SCAN") != nullptr;  // A/B: the cells x corners scan for every grid
   if (n_cells <= kBinCells && !scan_only)
     SDVL_LAUNCH(ctx, "filter_select", filter_select_binned_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells,
@@ -647,7 +647,7 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   hj->n_ptr = nullptr;
   hj->n = n;
   hj->levels = f->v.levels;
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, job_off + sizeof(OrbJob), hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, job_off + sizeof(OrbJob)));
   SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, dim3((n + 3) / 4, 1), dim3(256), reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(dsx) + job_off));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, a_off + a_bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -491,7 +491,7 @@ extern "C" int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose
   if (n_obs) memcpy(h8 + jb, obs, sizeof(sdvl_pose_obs) * static_cast<size_t>(n_obs));
   memcpy(h8 + jb + ob, rand_idx, sizeof(int32_t) * static_cast<size_t>(n_rand));
   memcpy(h8 + jb + ob + rb, nits_table, sizeof(int32_t) * static_cast<size_t>(n_nits));
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, jb + ob + rb + nb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, jb + ob + rb + nb));
   const PoseJobDev *dj = reinterpret_cast<const PoseJobDev *>(d8);
   const sdvl_pose_obs *dobs = reinterpret_cast<const sdvl_pose_obs *>(d8 + jb);
   const int32_t *drand = reinterpret_cast<const int32_t *>(d8 + jb + ob), *dnits = reinterpret_cast<const int32_t *>(d8 + jb + ob + rb);

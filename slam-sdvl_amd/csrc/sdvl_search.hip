@@ -958,10 +958,10 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   const SearchFramePose *d_table = nullptr;
   if (table.size() <= kSearchTabCap) {
     memcpy(static_cast<uint8_t *>(hs) + in_bytes + blk_cap_bytes, table.data(), sizeof(SearchFramePose) * table.size());
-    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + blk_cap_bytes + sizeof(SearchFramePose) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, in_bytes + blk_cap_bytes + sizeof(SearchFramePose) * table.size()));
     d_table = reinterpret_cast<const SearchFramePose *>(static_cast<uint8_t *>(dsx) + in_bytes + blk_cap_bytes);
   } else {  // more distinct (frame, pose) pairs than the staging reserve: the table travels through the work buffer
-    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, in_bytes + blk_cap_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, in_bytes + blk_cap_bytes));
     rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, sizeof(SearchFramePose) * table.size(), false);
     if (rc) return rc;
     SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_work, table.data(), sizeof(SearchFramePose) * table.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -1102,7 +1102,7 @@ int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   }
   memcpy(h8 + fb + 2 * cb, req_point, sizeof(double) * 3 * static_cast<size_t>(n));
   if (n_rand) memcpy(h8 + fb + 2 * cb + pb, rand_raw, sizeof(int32_t) * static_cast<size_t>(n_rand));
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, fb + 2 * cb + pb + rndb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, fb + 2 * cb + pb + rndb));
   uint8_t *dx = static_cast<uint8_t *>(ctx->d_out) + d_off;
   PoseJobDev *d_jobs = reinterpret_cast<PoseJobDev *>(dx);
   sdvl_pose_obs *d_obs = reinterpret_cast<sdvl_pose_obs *>(dx + jb);
@@ -1200,7 +1200,7 @@ int sdvl_search_run_filter(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const s
   rc = sdvl_stage_alloc(ctx, sb, &hs, &dsx);
   if (rc) return rc;
   memcpy(hs, state, sizeof(sdvl_depth_state) * static_cast<size_t>(n));
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, sb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, sb));
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   sdvl_depth_out *d_fout = reinterpret_cast<sdvl_depth_out *>(static_cast<uint8_t *>(ctx->d_out) + d_off);
   sdvl_depth_out *h_fout = reinterpret_cast<sdvl_depth_out *>(static_cast<uint8_t *>(ctx->h_out) + h_off);
@@ -1251,7 +1251,7 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
   uint8_t *hs = static_cast<uint8_t *>(hsv), *ds = static_cast<uint8_t *>(dsv);
   memcpy(hs + jb, border, static_cast<size_t>(n) * 100);
   memcpy(hs + jb + bb, patch, pb);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ds, hs, jb + bb + pb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, ds, hs, jb + bb + pb));
   uint8_t *dout = static_cast<uint8_t *>(ctx->d_out);
   SDVL_LAUNCH(ctx, "align_patches", align_patches_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(64 * kWavesPerBlock), reinterpret_cast<const PatchJob *>(ds), ds + jb, ds + jb + bb, n, max_its, reinterpret_cast<double *>(dout), dout + ob_uv + ob_its, reinterpret_cast<int32_t *>(dout + ob_uv));
   SDVL_HIP_CHECK(ctx, hipGetLastError());

@@ -25,7 +25,7 @@ extern "C" int sdvl_synth_render(sdvl_ctx *ctx, int n, const sdvl_synth_view *vi
   int rc = sdvl_stage_alloc(ctx, bytes, &hs, &dsx);
   if (rc) return rc;
   memcpy(hs, views, bytes);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, bytes));
   hipLaunchKernelGGL(synth_render_kernel, dim3((width + 63) / 64, (height + 3) / 4, n), dim3(256), 0, ctx->stream,
                      static_cast<const sdvl_synth_view *>(dsx), width, height, static_cast<uint8_t *>(dev_out),
                      static_cast<long long>(frame_bytes));

@@ -583,7 +583,7 @@ int sdvl_frame_register(sdvl_ctx *ctx, const sdvl_frame *f, const double *pose7)
   r->e.pad_ = 0.0;
   r->id = f->reg_id;
   r->pad_ = 0;
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, sizeof(RegisterRec), hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, sizeof(RegisterRec)));
   SDVL_LAUNCH(ctx, "registry_write", registry_write_kernel, dim3(1), dim3(64), static_cast<const RegisterRec *>(dsx), 1,
               static_cast<SearchFramePose *>(ctx->d_registry));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
@@ -636,7 +636,7 @@ int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *tr
     fo += n_features[i];
   }
   if (fb) memcpy(h8 + rb + pb, features, fb);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, rb + pb + fb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, rb + pb + fb));
   SDVL_LAUNCH(ctx, "track_upload", track_upload_kernel, dim3(n), dim3(256), reinterpret_cast<const UploadRec *>(d8),
               reinterpret_cast<const TrackPoint *>(d8 + rb), reinterpret_cast<const TrackFeat *>(d8 + rb + pb), s->d_points, s->d_feats[0],
               s->d_feats[1], s->np, s->nf);
@@ -706,9 +706,9 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
   }
   memcpy(h8 + jb, cell_rank, sizeof(uint16_t) * static_cast<size_t>(n_jobs) * s->cells);
   memcpy(h8 + jb + cb, rand_raw, rb);
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(s->d_jobs, h8, sizeof(TrackJobDev) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(s->d_cell_rank, h8 + jb, sizeof(uint16_t) * static_cast<size_t>(n_jobs) * s->cells, hipMemcpyHostToDevice, ctx->stream));
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(s->d_rand, h8 + jb + cb, rb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_jobs, h8, sizeof(TrackJobDev) * n_jobs));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_cell_rank, h8 + jb, sizeof(uint16_t) * static_cast<size_t>(n_jobs) * s->cells));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_rand, h8 + jb + cb, rb));
   (void)d8;
   SDVL_LAUNCH(ctx, "track_align_prep", track_align_prep_kernel, dim3(n_jobs), dim3(256), static_cast<const TrackJobDev *>(s->d_jobs),
               static_cast<const TrackPoint *>(s->d_points), static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]),

@@ -141,7 +141,7 @@ int run_undistort(sdvl_ctx *ctx, int n, const void *const *src, int src_stride, 
     ctx->err = "camera matrix is singular";
     return SDVL_ERR_INVALID;
   }
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(dsx, hs, jb + xb + yb, hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, jb + xb + yb));
   UndistParams P{cam->fx, cam->fy, cam->u0, cam->v0, dist->d[0], dist->d[1], dist->d[2], dist->d[3], dist->d[4], w, h, src_stride, dst_stride};
   SDVL_LAUNCH(ctx, "undistort", undistort_kernel, dim3((w + 255) / 256, h, n), dim3(256), reinterpret_cast<const UndistJob *>(d8),
               reinterpret_cast<const double *>(d8 + jb), reinterpret_cast<const double *>(d8 + jb + xb), P);

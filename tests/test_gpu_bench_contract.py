@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--seqs", "32", "--cpu-frames", "12",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--seqs", "32", "--cpu-frames", "12", "--sustained-frames", "40",
                           *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -43,6 +43,10 @@ def check(d, steps=4, warmup=1):
     assert r["path_hbm"]["frac"] > 0
     if "valu" in r:   # present when an SQ pass is committed under profiles/
         assert r["valu"]["peak_wave_insts_per_s"] == 256 * 4 * 2.4e9 / 2 and 0 < r["valu"]["path_frac"] < 1
+    if d["sustained"] is not None:   # whole sequences on fresh trackers, host-fed (skipped with the reference's mapper in the step)
+        u = d["sustained"]
+        assert d["value_sustained"] == u["value"] > 0 and u["frames_per_sequence"] == 40 and u["timed_steps"] == 40 - 1 - warmup
+        assert u["tracked_fraction"] > 0.99 and 2 <= u["keyframes_per_sequence"] <= 20 and u["hbm_bytes_per_keyframe"] < 800000
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "tracked frames/s" and "sample" in c
     assert 0 < c["one_core"] <= c["value"] * 1.05   # the all-core figure is at least the one-core figure
