@@ -461,7 +461,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     // which corners to look at: with bins, the cells the search region touches (a superset of the corners in range: the
     // exact tests above decide); otherwise, or for regions spanning many cells, the whole list
     bool scanned = false;
-    if (binned) {
+    // an epipolar request whose depth interval projects onto ONE pixel (zero baseline: cur pose == ref pose) has NaN line constants
+    // (division by a zero-length segment, matcher.cc:139-148): every range comparison of the reference is then false and EVERY corner
+    // that passes the level and margin tests counts as in range.  A box around pxa would visit a few cells only — such requests
+    // scan the whole list, like the reference.
+    const bool line_ok = rq.fixed || (vline > 0.0 && nx == nx && ny == ny);
+    if (binned && line_ok) {
       double bx0, bx1, by0, by1;
       if (rq.fixed) {
         bx0 = rq.px0[0] - range; bx1 = rq.px0[0] + range; by0 = rq.px0[1] - range; by1 = rq.px0[1] + range;

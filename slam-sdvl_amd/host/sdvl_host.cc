@@ -1925,7 +1925,9 @@ bool SDVLBatch::BuildTable(SDVL &t) {
   feats->clear();
   t.track_.up_register.clear();
   vector<shared_ptr<Feature>> &features = t.last_frame_->GetFeatures();
-  if (static_cast<int>(features.size()) > track_cap_) return false;
+  // the alignment stage takes at most SDVL_MAX_ALIGN_FEATURES features per job: a frame with more (a keyframe of configuration C
+  // that has gathered matches + connections + candidates) goes through the host-driven step instead of failing the batch
+  if (static_cast<int>(features.size()) > std::min(track_cap_, static_cast<int>(SDVL_MAX_ALIGN_FEATURES))) return false;
   if (t.track_.points)
     for (const shared_ptr<Point> &old : *t.track_.points) old->SetTrackRow(-1);
   const int row_base = t.track_.slot * track_cap_;

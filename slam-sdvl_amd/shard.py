@@ -24,12 +24,42 @@ def sequence_twist(gidx):
 
 
 def reduce_throughput(tracked, elapsed, dist=None, device="cpu"):
-    """(sum of tracked frames over ranks, max elapsed over ranks) — the only collective of a run"""
+    """(sum of tracked frames over ranks, max elapsed over ranks) — the only collective of a run.  With a process group up the
+    reduction always goes through it, also for a group of one rank (RCCL is exercised on a one-GPU box)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(tracked), float(elapsed)
     t_sum = torch.tensor([float(tracked)], dtype=torch.float64, device=device)
     t_max = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
     dist.all_reduce(t_sum, op=dist.ReduceOp.SUM)
     dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     return float(t_sum[0]), float(t_max[0])
+
+
+# ---- relocalisation over several GPUs (SURVEY §8e; SDVL::Relocalize, sdvl.cc:205-238) ----------------------------------------------
+# Relocalize walks the keyframes NEWEST FIRST and accepts the first one whose alignment error is < 0.001 and whose reprojection
+# finds >= MinMatches points (:221, :231).  Split over G GPUs, rank r examines positions r, r + G, r + 2G, ... of that newest-first
+# order (round-robin, so every rank gets recent and old keyframes alike), and the answer is the SMALLEST position any rank
+# accepted: one all-reduce(MIN) of one int64.  In this build a tracker's keyframes live in the HBM of the GPU that tracked them and
+# relocalisation runs there as one launch over all of them (DESIGN §6); these two functions are the partition and the reduce a
+# cross-GPU split uses, tested over gloo (two ranks) and over RCCL (tests/test_gpu_rccl.py).
+NO_KEYFRAME = (1 << 62)
+
+
+def keyframe_positions_for_rank(n_keyframes, rank, world):
+    """positions (0 = newest) of the newest-first keyframe order that `rank` examines"""
+    assert 0 <= rank < world and n_keyframes >= 0
+    return list(range(rank, n_keyframes, world))
+
+
+def first_success(local_position, dist=None, device="cpu"):
+    """`local_position`: the smallest newest-first position this rank accepted, or None.  Returns the position Relocalize would have
+    stopped at had it walked all keyframes alone (the minimum over ranks), or None when no rank accepted any."""
+    import torch
+    mine = NO_KEYFRAME if local_position is None else int(local_position)
+    assert 0 <= mine <= NO_KEYFRAME
+    if dist is not None and dist.is_initialized():
+        t = torch.tensor([mine], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        mine = int(t[0])
+    return None if mine >= NO_KEYFRAME else mine

@@ -357,6 +357,33 @@ def test_search_points_matches_oracle(ctx, sdvl, orc, synth, fixed, k_ref, k_cur
     f_ref.close(); f_cur.close()
 
 
+def test_search_points_zero_baseline_epipolar_on_a_binned_frame(ctx, sdvl, orc, synth):
+    """cur pose == ref pose, epipolar (not fixed) requests: the depth interval projects onto one pixel, the line constants of
+    GetCornersInRange are NaN (matcher.cc:139-148) and every range test is false — every corner that passes the level and margin
+    tests is a candidate.  On a frame whose corners are binned (sdvl_detect_corners) the search must not narrow that to the cells
+    around the pixel: same results as the oracle and as the unbinned frame."""
+    img, = frames_of(synth, orc, TUM_CAM, 640, 480, [3])
+    T = trajectory_pose(orc, 3)
+    reqs, meta, ccur, f_ref, f_cur = search_requests(sdvl, orc, ctx, img, img, T, T, TUM_CAM, 64, 23, False, 0.0, False)
+    cam = sdvl.Camera(640, 480, *TUM_CAM)
+    plain = ctx.search_points(reqs, cam, sdvl.default_search_params())          # set_corners: no bins, full scan
+    f_bin = ctx.frame(img)
+    ctx.detect_corners([f_bin], sdvl.default_detect_params(), 1000)              # bins valid; the same corner list (tested elsewhere)
+    for r in reqs:
+        r.cur = f_bin.h.value
+    binned = ctx.search_points(reqs, cam, sdvl.default_search_params())
+    n_found = 0
+    for a, b, m in zip(plain, binned, meta):
+        want = orc.search_point(img, img, TUM_CAM, T, T, m["px"], m["bearing"], m["level"], m["desc"], m["idepth"], m["istd"], False, ccur, m["px0"])
+        assert a.found == b.found == want["found"] and a.best_corner == b.best_corner
+        assert tuple(a.px) == tuple(b.px)
+        if want["found"]:
+            n_found += 1
+            assert np.array_equal(np.array(b.px[:]), want["px"]) and b.level == want["level"]
+    assert n_found >= 20
+    f_ref.close(); f_cur.close(); f_bin.close()
+
+
 @pytest.mark.parametrize("k_cur,noise", [(6, 0.02), (30, 0.05), (60, 0.2)])
 def test_depth_filter_behind_the_search_matches_oracle(ctx, sdvl, orc, synth, k_cur, noise):
     """sdvl_search_points_filter: the mapper's depth filter (triangulation, parallax, the minimum-depth tests, Point::Update,

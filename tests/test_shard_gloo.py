@@ -28,7 +28,14 @@ def _worker(rank, world, port, per_gpu, q):
     elapsed = 1.0 + 0.25 * rank
     dist.barrier()
     total, tmax = shard.reduce_throughput(tracked, elapsed, dist)
-    q.put((rank, ids, total, tmax))
+    # relocalisation split: 11 keyframes, newest first; rank 0 accepts position 6 (its 4th), rank 1 position 3 (its 2nd)
+    mine = shard.keyframe_positions_for_rank(11, rank, world)
+    accepted = {0: 6, 1: 3}[rank]
+    assert accepted in mine
+    winner = shard.first_success(accepted, dist)
+    nobody = shard.first_success(None, dist)
+    one_side = shard.first_success(9 if rank == 1 else None, dist)
+    q.put((rank, ids, total, tmax, mine, winner, nobody, one_side))
     dist.destroy_process_group()
 
 
@@ -46,8 +53,10 @@ def test_two_ranks_shard_and_reduce():
         assert p.exitcode == 0
     all_ids = res[0][1] + res[1][1]
     assert sorted(all_ids) == list(range(world * per_gpu))             # disjoint and complete
-    for _, _, total, tmax in res:
+    for _, _, total, tmax, _, winner, nobody, one_side in res:
         assert total == (100 + 6) + (200 + 6) and tmax == 1.25          # every rank sees the job-wide numbers
+        assert winner == 3 and nobody is None and one_side == 9          # the keyframe Relocalize alone would have stopped at
+    assert sorted(res[0][4] + res[1][4]) == list(range(11)) and res[0][4] == [0, 2, 4, 6, 8, 10]   # round-robin over the newest-first order
 
 
 def test_sequences_differ():
@@ -57,3 +66,4 @@ def test_sequences_differ():
     tw = np.array([shard.sequence_twist(i) for i in range(14)])
     assert len({tuple(np.round(t, 9)) for t in tw}) == 14
     assert shard.reduce_throughput(5, 2.0) == (5.0, 2.0)                # single process: no collective
+    assert shard.first_success(4) == 4 and shard.first_success(None) is None
