@@ -255,13 +255,13 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(frames, mapper=False, threads=1):
+def cpu_baseline(frames, mapper=False, threads=1, ref_flags=False):
     """the CPU oracle (oracle/, kind "port") over a bounded sample of sequence 0: `threads` independent trackers, one host
     thread each (the reference tracker is single-threaded, so N cores = N independent sequences).  The ctypes
     call releases the GIL, every tracker owns its state.  Returns (tracked frames/s over all threads, tracked, wall s)."""
     import threading
     import oraclelib as ol
-    orc = ol.Oracle()
+    orc = ol.Oracle(ref_flags)      # ref_flags: the timing-only build with the reference's compiler flags (oracle/Makefile)
     for k, v in ORACLE_PARAMS.items():
         setattr(orc.params, k, v)
     out = [None] * threads
@@ -740,12 +740,23 @@ def main():
     if cpu_sample is not None:
         fps1, n_tracked1, secs1 = cpu_one
         n_thr = max(1, min(ncpu, 16))
-        fps, n_tracked, secs = cpu_all if cpu_all else (cpu_baseline(cpu_sample, args.mapper, n_thr) if n_thr > 1 else cpu_one)
-        cpu = {"value": round(fps, 2), "unit": "tracked frames/s", "cores": n_thr, "kind": "port",
-               "sample": "sequence 0 of the same workload, %d tracked frames per tracker: one tracker on one host core before the GPU run "
-                         "(%.1f s), %d independent trackers on %d host threads after it (%.1f s; %d usable CPUs)"
-                         % (n_tracked1, secs1, n_thr, n_thr, secs, ncpu),
-               "one_core": round(fps1, 2)}
+        # the headline CPU figure: the oracle built HERE with the reference's own flags (CMakeLists.txt:20: -O3 -march=native), all
+        # usable cores; beside it the same with the checker's flags (-march=x86-64-v3 -ffp-contract=off: the build every parity test
+        # compares with).  Neither calls OpenCV's SIMD pyrDown / FAST as the reference would: "kind" stays "port".
+        try:
+            fps, n_tracked, secs = cpu_baseline(cpu_sample, args.mapper, n_thr, ref_flags=True)
+            fps1r = cpu_baseline(cpu_sample, args.mapper, 1, ref_flags=True)[0] if n_thr > 1 else fps
+            flags = "-O3 -march=native -msse3 (the reference's CMakeLists.txt:20), built on this host"
+            fps_chk = (cpu_all if cpu_all else (cpu_baseline(cpu_sample, args.mapper, n_thr) if n_thr > 1 else cpu_one))[0]
+        except Exception as e:   # no compiler on the box: the checker's build is all there is
+            sys.stderr.write("bench.py: timing build of the oracle failed (%s); cpu_baseline uses the checker's build\n" % e)
+            fps, n_tracked, secs = cpu_all if cpu_all else (cpu_baseline(cpu_sample, args.mapper, n_thr) if n_thr > 1 else cpu_one)
+            fps1r, fps_chk, flags = fps1, fps, "-O3 -march=x86-64-v3 -ffp-contract=off (the checker's build)"
+        cpu = {"value": round(fps, 2), "unit": "tracked frames/s", "cores": n_thr, "kind": "port", "flags": flags,
+               "sample": "sequence 0 of the same workload, %d tracked frames per tracker: %d independent trackers on %d host threads after the GPU "
+                         "run (%.1f s; %d usable CPUs); one tracker on one core before it (%.1f s)" % (n_tracked1, n_thr, n_thr, secs, ncpu, secs1),
+               "one_core": round(fps1r, 2),
+               "checker_build": {"flags": "-O3 -march=x86-64-v3 -ffp-contract=off", "value": round(fps_chk, 2), "one_core": round(fps1, 2)}}
 
     if rank == 0:
         frames_rank = B * K

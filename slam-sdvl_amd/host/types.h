@@ -11,6 +11,21 @@
 #include <memory>
 #include <vector>
 
+// Real Eigen / OpenCV, when the build has them (this image has neither): the look-alikes below then convert to and from the real
+// types, so callers written against the reference's headers (sdvl.cc, map.cc, ui/: cv::Mat frames in, Eigen vectors out) pass and
+// receive their own types — SDVL::HandleFrame(const cv::Mat&) (sdvl.h:62), Frame(..., const cv::Mat&, ...) (frame.h:45),
+// Feature::GetPosition() -> Eigen::Vector2d (feature.h:66).  -DSDVL_NO_THIRD_PARTY_TYPES keeps the build free of both.
+#if !defined(SDVL_NO_THIRD_PARTY_TYPES) && defined(__has_include)
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define SDVL_HAVE_EIGEN 1
+#endif
+#if __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+#define SDVL_HAVE_OPENCV 1
+#endif
+#endif
+
 struct sdvl_frame;
 
 namespace sdvl {
@@ -29,6 +44,15 @@ struct Vec {
   const T &operator[](int i) const { return v[i]; }
   T x() const { return v[0]; }
   T y() const { return v[1]; }
+#ifdef SDVL_HAVE_EIGEN
+  // Eigen::Matrix<T, N, 1> in and out (Vector2d / Vector3d / Vector3i / Vector6d of the reference's signatures)
+  Vec(const Eigen::Matrix<T, N, 1> &e) { for (int i = 0; i < N; i++) v[i] = e(i); }
+  operator Eigen::Matrix<T, N, 1>() const {
+    Eigen::Matrix<T, N, 1> e;
+    for (int i = 0; i < N; i++) e(i) = v[i];
+    return e;
+  }
+#endif
 };
 typedef Vec<double, 2> Vector2d;
 typedef Vec<double, 3> Vector3d;
@@ -38,7 +62,9 @@ typedef Vec<double, 6> Vector6d;
 
 // cv::Mat (CV_8UC1) subset.  `data` is a host mirror (may be null until HostData() is called on the owning
 // Frame); dev/level bind the image to an HBM-resident pyramid level.
+#ifndef SDVL_HAVE_OPENCV
 enum { CV_8UC1 = 0 };  // the only cv::Mat type the tracking front-end sees (frame.cc:38-41 converts to grey)
+#endif
 
 struct Image {
   const uint8_t *data = nullptr;
@@ -62,6 +88,22 @@ struct Image {
     }
     return r;
   }
+#ifdef SDVL_HAVE_OPENCV
+  // a cv::Mat frame as the reference passes it (CV_8UC1, main.cc:128-138): a header over its pixels, the Mat kept alive
+  Image(const cv::Mat &m) {
+    if (!m.empty() && m.type() == CV_8UC1) {
+      auto keep = std::make_shared<cv::Mat>(m);
+      mat_owner = keep;
+      data = keep->data;
+      cols = keep->cols;
+      rows = keep->rows;
+      step = static_cast<int>(keep->step);
+    }
+  }
+  // the host mirror as a cv::Mat header (GetPyramid() users: homography_init.cc:196, ui/drawimage.cc); empty while only the HBM copy exists
+  operator cv::Mat() const { return data ? cv::Mat(rows, cols, CV_8UC1, const_cast<uint8_t *>(data), static_cast<size_t>(step)) : cv::Mat(); }
+  std::shared_ptr<void> mat_owner;
+#endif
   static Image Wrap(const uint8_t *p, int w, int h, int stride) {
     Image r;
     r.data = p; r.cols = w; r.rows = h; r.step = stride;

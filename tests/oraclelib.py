@@ -44,8 +44,14 @@ def _ensure(path, cmd, cwd):
     return path
 
 
-def load_oracle():
-    so = _ensure(os.path.join(ORACLE_DIR, "libsdvl_oracle.so"), ["make", "-s"], ORACLE_DIR)
+def load_oracle(ref_flags=False):
+    """the checker (libsdvl_oracle.so: -ffp-contract=off, every parity test compares with it) or, for TIMING ONLY, the same sources
+    built here and now with the reference's own flags (CMakeLists.txt:20: -O3 -march=native), libsdvl_oracle_refflags.so"""
+    if ref_flags:
+        so = os.path.join(ORACLE_DIR, "libsdvl_oracle_refflags.so")
+        subprocess.check_call(["make", "-s", "-B", "libsdvl_oracle_refflags.so"], cwd=ORACLE_DIR)   # -march=native: always for THIS host
+    else:
+        so = _ensure(os.path.join(ORACLE_DIR, "libsdvl_oracle.so"), ["make", "-s"], ORACLE_DIR)
     lib = C.CDLL(so)
     lib.sdvl_ref_shi_tomasi.restype = C.c_double
     return lib
@@ -72,8 +78,8 @@ XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])  # SURVEY §8d tra
 
 
 class Oracle:
-    def __init__(self):
-        self.lib = load_oracle()
+    def __init__(self, ref_flags=False):
+        self.lib = load_oracle(ref_flags)
         self.params = Params()
         self.lib.sdvl_ref_default_params(C.byref(self.params))
 

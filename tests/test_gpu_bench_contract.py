@@ -50,6 +50,7 @@ def check(d, steps=4, warmup=1):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "tracked frames/s" and "sample" in c
     assert 0 < c["one_core"] <= c["value"] * 1.05   # the all-core figure is at least the one-core figure
+    assert "march=native" in c["flags"] and c["checker_build"]["value"] > 0   # timed with the reference's own flags; the checker's build beside it
     assert d["value"] > 2 * c["one_core"]      # even this tiny batch (32 sequences, launch-latency bound) beats a CPU core several times over
 
 

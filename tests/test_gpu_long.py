@@ -149,36 +149,30 @@ def test_config_c_farm_of_64_sequences(trk, orc, synth):
         trk.configure()
 
 
-def test_pgm_list_with_tum_f2_intrinsics_and_distortion(orc, synth, tmp_path):
-    """How a real TUM / EuRoC sequence goes through the C++ front-end and the oracle (no dataset ships with the repo): grey
-    frames as a list of binary PGMs + the dataset's own configuration file.  Here: frames rendered with the intrinsics of
-    config_tum_f2.cfg and distorted-camera coefficients of the same file, so Camera::UndistortImage (camera.cc:100-105) is
-    inside the loop on both sides.
-        host/track_sequence --list frames.txt --config config_tum_f2.cfg
-    prints what tools/oracle_pgm_list.py (the CPU oracle on the same list) prints."""
+def _pgm_list_case(orc, tmp_path, imgs, w, h, cam, dist, cfg_name, sdvl_block):
+    """frames as binary PGMs + a configuration file in the reference's format -> rows of host/track_sequence (C++ front-end) and of
+    tools/oracle_pgm_list.py (CPU oracle), compared: decisions exact, poses within POSE_TOL"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "slam-sdvl_amd", "host", "track_sequence")
-    n = 8
-    imgs = [synth.render(trajectory_pose(orc, k), TUM2_CAM, 640, 480, frame_id=k) for k in range(n)]
+    n = len(imgs)
     lst = tmp_path / "frames.txt"
     with open(lst, "w") as fh:
         for k, im in enumerate(imgs):
             p = tmp_path / ("f%03d.pgm" % k)
             with open(p, "wb") as out:
-                out.write(b"P5\n640 480\n255\n")
+                out.write(("P5\n%d %d\n255\n" % (w, h)).encode())
                 out.write(im.tobytes())
             fh.write(str(p) + "\n")
-    cfg = tmp_path / "config_tum_f2.cfg"
-    with open(cfg, "w") as fh:      # the camera block + SDVL block of the reference's config/config_tum_f2.cfg
-        fh.write("%YAML:1.0\nCamera.width: 640\nCamera.height: 480\n")
-        for key, v in zip(("fx", "fy", "u0", "v0"), TUM2_CAM):
+    cfg = tmp_path / cfg_name
+    with open(cfg, "w") as fh:      # the camera block + SDVL block of the reference's file of that name
+        fh.write("%%YAML:1.0\nCamera.width: %d\nCamera.height: %d\n" % (w, h))
+        for key, v in zip(("fx", "fy", "u0", "v0"), cam):
             fh.write("Camera.%s: %r\n" % (key, float(v)))
-        for i, v in enumerate(TUM2_DIST):
+        for i, v in enumerate(dist):
             fh.write("Camera.d%d: %r\n" % (i + 1, float(v)))
-        fh.write('Video.type: 1\nVideo.path: "/../tum/f2_kidnap/rgb/"\nSDVL.cell_size: 32\nSDVL.min_avg_shift: 5\nSDVL.max_matches: 200\n'
-                 "SDVL.max_keyframes: 1000\nSDVL.use_orb: 1\nSDVL.fast_threshold: 10\nSDVL.lost_ratio: 0.7\nSDVL.num_features: 1000\n")
+        fh.write(sdvl_block)
     r = subprocess.run([exe, "--list", str(lst), "--config", str(cfg)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     o = subprocess.run([sys.executable, os.path.join(root, "tools", "oracle_pgm_list.py"), "--list", str(lst), "--config", str(cfg)],
@@ -190,4 +184,37 @@ def test_pgm_list_with_tum_f2_intrinsics_and_distortion(orc, synth, tmp_path):
     for k, (a, b) in enumerate(zip(got, want)):
         assert a[:6] == b[:6], (k, a[:6], b[:6])                   # frame, state, quality, matches, attempts, inliers
         assert np.abs(np.array([float(v) for v in a[6:13]]) - np.array([float(v) for v in b[6:13]])).max() <= POSE_TOL, k
+    return got
+
+
+def test_pgm_list_with_tum_f2_intrinsics_and_distortion(orc, synth, tmp_path):
+    """How a real TUM / EuRoC sequence goes through the C++ front-end and the oracle (no dataset ships with the repo): grey
+    frames as a list of binary PGMs + the dataset's own configuration file.  Here: frames rendered with the intrinsics of
+    config_tum_f2.cfg and distorted-camera coefficients of the same file, so Camera::UndistortImage (camera.cc:100-105) is
+    inside the loop on both sides.
+        host/track_sequence --list frames.txt --config config_tum_f2.cfg
+    prints what tools/oracle_pgm_list.py (the CPU oracle on the same list) prints."""
+    imgs = [synth.render(trajectory_pose(orc, k), TUM2_CAM, 640, 480, frame_id=k) for k in range(8)]
+    got = _pgm_list_case(orc, tmp_path, imgs, 640, 480, TUM2_CAM, TUM2_DIST, "config_tum_f2.cfg",
+                         'Video.type: 1\nVideo.path: "/../tum/f2_kidnap/rgb/"\nSDVL.cell_size: 32\nSDVL.min_avg_shift: 5\nSDVL.max_matches: 200\n'
+                         "SDVL.max_keyframes: 1000\nSDVL.use_orb: 1\nSDVL.fast_threshold: 10\nSDVL.lost_ratio: 0.7\nSDVL.num_features: 1000\n")
     assert int(got[-1][3]) >= 100                                    # tracked, through the undistortion
+
+
+def test_pgm_list_with_the_euroc_configuration(orc, synth, tmp_path):
+    """EuRoC's OWN block (config/config_euroc.cfg:9-19,34-43): 752x480, its intrinsics and radial-tangential distortion through
+    Camera::UndistortImage, and min_matches 5 (TUM: the default 20).  Two frames of the sequence show texture in a small window
+    only, so their match count falls between 5 and 20: with this configuration they are still tracked (CalcTrackingQuality,
+    sdvl.cc:240-264), on both sides alike."""
+    from oraclelib import EUROC_CAM, EUROC_DIST
+    imgs = [synth.render(trajectory_pose(orc, k), EUROC_CAM, 752, 480, frame_id=k) for k in range(9)]
+    for k in (5, 6):
+        poor = np.full_like(imgs[k], 127)
+        poor[176:304, 280:472] = imgs[k][176:304, 280:472]           # a 192x128 window: at most 24 grid cells can match
+        imgs[k] = poor
+    got = _pgm_list_case(orc, tmp_path, imgs, 752, 480, EUROC_CAM, EUROC_DIST, "config_euroc.cfg",
+                         'Video.type: 1\nVideo.path: "/../euroc/MH_01_easy/mav0/cam0/data/"\nSDVL.cell_size: 32\nSDVL.min_avg_shift: 20\nSDVL.max_matches: 200\n'
+                         "SDVL.max_keyframes: 1000\nSDVL.use_orb: 1\nSDVL.fast_threshold: 10\nSDVL.lost_ratio: 0.7\nSDVL.min_matches: 5\nSDVL.num_features: 1000\n")
+    few = [row for row in got if 5 <= int(row[3]) < 20]
+    assert few and all(int(row[2]) != 2 for row in few), [row[:4] for row in got]   # between EuRoC's 5 and the default 20: not TRACKING_BAD
+    assert int(got[-1][3]) >= 100                                    # and the full frames after them are tracked again
