@@ -333,8 +333,8 @@ struct IaItem { float patch, dx, dy; };
 // live in the job's slice of the context's work buffer (L2-resident: a job touches nothing else) instead of LDS, so that
 // jobs of up to SDVL_MAX_ALIGN_FEATURES features run the same kernel — configuration C aligns ~850 features per frame.
 // Same statements, same order: results are those of the LDS-resident form.
-template <bool kSpill>
-__global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *__restrict__ jobs,
+template <bool kSpill, int kT>
+__global__ __launch_bounds__(kT) void image_align_lds_kernel(const IaJob *__restrict__ jobs,
                                                                    const sdvl_align_feature *__restrict__ feats_all, Cam cam,
                                                                    sdvl_align_params prm, int max_f, sdvl_align_result *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
   uint8_t *s_okprev = s_ok + max_f;
   uint8_t *s_vis = s_okprev + max_f;
   uint8_t *s_valid = s_vis + max_f;
-  __shared__ double s_red[kWaves][32];
+  __shared__ double s_red[kT / 64][32];
   __shared__ double s_sum[32];
   __shared__ double s_H[21], s_L[36];
   __shared__ int s_tr[6];
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
   int its0 = 0, its1 = 0, its2 = 0, its3 = 0, its4 = 0, its5 = 0, its6 = 0, its7 = 0;
 
   // the feature records are read once: every level's PrecomputePatches and every iteration's projection use the LDS copy
-  for (int f = tid; f < nf; f += kThreads) {
+  for (int f = tid; f < nf; f += kT) {
     const sdvl_align_feature ft = F[f];
     const V3 xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
     s_fpos[f * 5 + 0] = ft.px;
@@ -397,15 +397,15 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
     const float scale = 1.0f / (1 << level);
     const double fl = cam.fx / (1 << level);
     // jacobian_cache_.setZero() (image_align.cc:69): items of features that fail this level's border test keep a zero J
-    for (int i = tid; i < n_items; i += kThreads) { s_item[i].dx = 0.f; s_item[i].dy = 0.f; }
-    for (int f = tid; f < nf; f += kThreads) s_okprev[f] = 2;  // forces H to be accumulated in the first iteration
+    for (int i = tid; i < n_items; i += kT) { s_item[i].dx = 0.f; s_item[i].dy = 0.f; }
+    for (int f = tid; f < nf; f += kT) s_okprev[f] = 2;  // forces H to be accumulated in the first iteration
     if (tid == 0) T_bk = T;
     __syncthreads();
 
     for (int it = 0; it < prm.max_its; it++) {
       if (it == 0) {
         // ---- PrecomputePatches(level), image_align.cc:208-267
-        for (int idx = tid; idx < n_items; idx += kThreads) {
+        for (int idx = tid; idx < n_items; idx += kT) {
           const int f = idx >> 4, p = idx & 15;
           const float u_ref = static_cast<float>(s_fpos[f * 5 + 0] * scale);
           const float v_ref = static_cast<float>(s_fpos[f * 5 + 1] * scale);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
       // ---- ComputeResiduals phase A: per-feature projection, image_align.cc:147-181
       if (tid == 0) s_changed = 0;
       __syncthreads();
-      for (int f = tid; f < nf; f += kThreads) {
+      for (int f = tid; f < nf; f += kT) {
         uint8_t ok = 0;
         if (s_vis[f]) {
           const V3 xr = {s_fpos[f * 5 + 2], s_fpos[f * 5 + 3], s_fpos[f * 5 + 4]};
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
       double acc[32];
 #pragma unroll
       for (int i = 0; i < 32; i++) acc[i] = 0.0;
-      for (int idx = tid; idx < n_items; idx += kThreads) {
+      for (int idx = tid; idx < n_items; idx += kT) {
         const int f = idx >> 4;
         if (!s_ok[f]) continue;
         const int p = idx & 15, y = p >> 2, x = p & 3;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kThreads) void image_align_lds_kernel(const IaJob *
       if (tid < 32) {
         double sacc = 0.0;
 #pragma unroll
-        for (int w = 0; w < kWaves; w++) sacc += s_red[w][tid];
+        for (int w = 0; w < kT / 64; w++) sacc += s_red[w][tid];
         if (tid < 21) {
           if (rebuild_h) s_H[tid] = sacc;  // keep for the iterations in which the contributing set stays the same
           else sacc = s_H[tid];
@@ -715,9 +715,13 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     const unsigned long long bit = 1ull << (ctx->device & 63);
     if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
       SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
-      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_lds_bytes(kLdsMaxF + 16))));
-      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_lds_bytes(kLdsMaxF + 16))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_lds_bytes(kLdsMaxF + 16))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_spill_lds_bytes(kMaxF + 16))));
       attr_devices.fetch_or(bit, std::memory_order_release);
     }
@@ -727,8 +731,21 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     const size_t lds = ia_lds_bytes(max_f);
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
-    hipExtLaunchKernelGGL(image_align_lds_kernel<false>, dim3(n_lds), dim3(kThreads), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
-                          feats_dev, c, *p, max_f, dst);
+    // Round 3: 256 threads per job instead of 512.  The kernel holds ~235 VGPRs per lane: eight waves of it are a whole CU's register
+    // file, so a launch of 256 jobs kept all 256 CUs to itself for its ~100 us (one slow chain of dependent phases per job) and
+    // nothing of the other streams' work ran beside it.  Four waves take half of every SIMD's registers: the job takes ~15 % longer
+    // alone, the other half of the CU keeps working — 289 k -> 298 k tracked frames/s, 307 k together with the same change in
+    // pose_hypotheses (one box, alternating runs).  128 threads: 296 k.  SDVL_IA_THREADS=512 / 128 select the other forms (A/B).
+    static const int ia_threads = getenv("SDVL_IA_THREADS") ? atoi(getenv("SDVL_IA_THREADS")) : 256;
+    if (ia_threads == 128)
+      hipExtLaunchKernelGGL((image_align_lds_kernel<false, 128>), dim3(n_lds), dim3(128), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+    else if (ia_threads == 256)
+      hipExtLaunchKernelGGL((image_align_lds_kernel<false, 256>), dim3(n_lds), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+    else
+      hipExtLaunchKernelGGL((image_align_lds_kernel<false, 512>), dim3(n_lds), dim3(512), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
   }
   if (n_gen > 0 && legacy) {
     SDVL_LAUNCH(ctx, "image_align_big", image_align_kernel, dim3(n_gen), dim3(kThreads), static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, dst);
@@ -736,7 +753,7 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     const int max_f = (max_nf_big + 7) / 8 * 8 + 8;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align_big", &ev_a, &ev_b);
-    hipExtLaunchKernelGGL(image_align_lds_kernel<true>, dim3(n_gen), dim3(kThreads), ia_spill_lds_bytes(max_f), ctx->stream, ev_a, ev_b, 0,
+    hipExtLaunchKernelGGL((image_align_lds_kernel<true, 512>), dim3(n_gen), dim3(512), ia_spill_lds_bytes(max_f), ctx->stream, ev_a, ev_b, 0,
                           static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, max_f, dst);
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());

@@ -124,17 +124,21 @@ __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, in
 }
 
 constexpr int kHypDraws = 128;    // draws of one workgroup
-constexpr int kHypThreads = 512;  // 2 waves converge the draws (a lane each), all 8 count the supporters
+// Round 3: 128 threads (the two waves that converge the draws, a lane each, also count the supporters) instead of 512.  At ~180 VGPRs
+// per lane eight waves filled a CU's register file and held it for the ~105 us the dependent FP64 chain of phase 1 takes, with six
+// of the eight waves idle; two waves leave three quarters of the CU to the other streams' kernels (289 k -> 298 k tracked frames/s).
+constexpr int kHypThreads = 128;
 
-__global__ __launch_bounds__(kHypThreads) void pose_hypotheses_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+__global__ __launch_bounds__(512) void pose_hypotheses_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
                                                                       const int32_t *__restrict__ rand_idx, sdvl_pose_params prm,
                                                                       HypResult *__restrict__ hyp) {
   __shared__ double s_rt[kHypDraws][13];  // R (9) and t (3) of every converged draw (+1 pad)
   __shared__ int s_ok[kHypDraws], s_sup[kHypDraws];
   const PoseJobDev &job = jobs[blockIdx.y];
   const int tid = threadIdx.x;
-  const int h0 = blockIdx.x * kHypDraws;
-  const int nd = min(kHypDraws, prm.max_ransac_its - h0);  // draws of this workgroup
+  const int per_wg = min(kHypDraws, static_cast<int>(blockDim.x));  // a lane converges one draw
+  const int h0 = blockIdx.x * per_wg;
+  const int nd = min(per_wg, prm.max_ransac_its - h0);  // draws of this workgroup
   const int size = job.n_obs;
   const sdvl_pose_obs *obs = obs_all + job.obs_begin;
   // ---- phase 1: ConvergePose of every draw, one lane each (feature_align.cc:176-197)
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(kHypThreads) void pose_hypotheses_kernel(const Pose
   // ---- phase 2: CheckReprojectionError of every draw over every match (feature_align.cc:190, 245-283): the (draw, match)
   //      pairs are dealt to all lanes of the workgroup; a supporter count is an integer sum, so its order is free
   const int pairs = nd * size;
-  for (int p = tid; p < pairs; p += kHypThreads) {
+  for (int p = tid; p < pairs; p += static_cast<int>(blockDim.x)) {
     const int d = p / size, q = p - d * size;
     if (!s_ok[d]) continue;
     M3 R;
@@ -439,7 +443,9 @@ size_t sdvl_pose_hyp_bytes() { return sizeof(HypResult); }
 
 int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
                              const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists) {
-  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypThreads), d_jobs, d_obs, d_rand, *p,
+  static const int hyp_threads = getenv("SDVL_HYP_THREADS") ? atoi(getenv("SDVL_HYP_THREADS")) : kHypThreads;
+  const int hyp_per_wg = hyp_threads < kHypDraws ? hyp_threads : kHypDraws;
+  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + hyp_per_wg - 1) / hyp_per_wg, n_jobs), dim3(hyp_threads), d_jobs, d_obs, d_rand, *p,
               static_cast<HypResult *>(d_hyp));
   SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel, dim3(n_jobs), dim3(64), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
               d_lists);
