@@ -136,7 +136,8 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
         # computed by the search itself, for the corners it compares: at least one per match)
         "search_points": 12 * n_c + n_s * (121 + 164 + i_fa * 81) + n_m * 961,
         "search_prepare": n_s * (120 + 80),                            # request records read, scalar-phase records written
-        "pose_hypotheses": 48 * n_m + 100 * 64,                      # match records read once + one result per RANSAC draw
+        "pose_hypotheses": 5 * 48 * 100 + 100 * 64,                  # the five matches of every RANSAC draw + one result per draw
+        "pose_supporters": 48 * n_m + 100 * 64,                      # match records read once (L2 serves the draws' re-reads) + the draws' results
         "pose_refine": 48 * n_m + 100 * 64 + 4 * n_m + 80,           # matches + draw results read, index lists + pose written
         # device-resident tracking tables (sdvl_track.hip): feature + point rows read, alignment records / requests / new rows written
         "track_align_prep": n_f * (48 + 24 + 56),

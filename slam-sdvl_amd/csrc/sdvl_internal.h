@@ -144,8 +144,9 @@ struct PoseJobDev {
 // queues pose_hypotheses + pose_refine for n_jobs device-resident jobs (no copies, no wait); d_hyp = n_jobs * max_ransac_its
 // records of sdvl_pose_hyp_bytes() each
 size_t sdvl_pose_hyp_bytes();
+// max_obs: the most observations any of the jobs can hold (the device knows the actual counts; the supporter kernel's grid covers this many)
 int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
-                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists);
+                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists, int max_obs);
 
 // sdvl_image_align.hip: queue the alignment of n_jobs pairs; features from the host (`features`) or resident (`d_features`);
 // results to `d_results` (device) or, when null, to the context's result buffers (see sdvl_image_align_begin)

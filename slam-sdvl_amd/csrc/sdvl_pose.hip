@@ -15,6 +15,8 @@
 // FP64 throughout, -ffp-contract=off, same expression order as host/sdvl_host.cc (which is the reference's).
 // Only sin/cos inside SE3::Exp differ from the host libm by <= 1 ulp (tolerance class, like image alignment).
 #include "sdvl_internal.h"
+#include <algorithm>
+
 #include "sdvl_math.h"
 
 namespace {
@@ -123,73 +125,72 @@ __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, in
   return true;
 }
 
-constexpr int kHypDraws = 128;    // draws of one workgroup
-// Round 3: 128 threads (the two waves that converge the draws, a lane each, also count the supporters) instead of 512.  At ~180 VGPRs
-// per lane eight waves filled a CU's register file and held it for the ~105 us the dependent FP64 chain of phase 1 takes, with six
-// of the eight waves idle; two waves leave three quarters of the CU to the other streams' kernels (289 k -> 298 k tracked frames/s).
-constexpr int kHypThreads = 128;
+// Round 3: two launches.  pose_hypotheses_kernel converges the draws, one LANE per draw (a dependent FP64 chain of ~105 us; at ~180
+// VGPRs per lane its waves are few and narrow: 64-thread workgroups, two per frame for 100 draws), and
+// pose_supporters_kernel counts every draw's supporters over all matches with one wave per (draw, 256 matches) — 100 x 1000 pairs
+// per frame in configuration C took 250 of the 370 us when the two waves of the first kernel walked them alone.
+constexpr int kHypDraws = 64;     // draws of one workgroup = lanes of its wave
+constexpr int kSupChunk = 256;    // matches one supporter wave tests against its draw (4 per lane)
 
-__global__ __launch_bounds__(512) void pose_hypotheses_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
-                                                                      const int32_t *__restrict__ rand_idx, sdvl_pose_params prm,
-                                                                      HypResult *__restrict__ hyp) {
-  __shared__ double s_rt[kHypDraws][13];  // R (9) and t (3) of every converged draw (+1 pad)
-  __shared__ int s_ok[kHypDraws], s_sup[kHypDraws];
+__global__ __launch_bounds__(kHypDraws) void pose_hypotheses_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+                                                                    const int32_t *__restrict__ rand_idx, sdvl_pose_params prm,
+                                                                    HypResult *__restrict__ hyp) {
   const PoseJobDev &job = jobs[blockIdx.y];
-  const int tid = threadIdx.x;
-  const int per_wg = min(kHypDraws, static_cast<int>(blockDim.x));  // a lane converges one draw
-  const int h0 = blockIdx.x * per_wg;
-  const int nd = min(per_wg, prm.max_ransac_its - h0);  // draws of this workgroup
+  const int h = blockIdx.x * kHypDraws + threadIdx.x;
+  if (h >= prm.max_ransac_its) return;
   const int size = job.n_obs;
   const sdvl_pose_obs *obs = obs_all + job.obs_begin;
-  // ---- phase 1: ConvergePose of every draw, one lane each (feature_align.cc:176-197)
-  if (tid < nd) {
-    const int h = h0 + tid;
-    HypResult r;
-    r.ok = 0;
-    r.supporters = 0;
-    for (int k = 0; k < 7; k++) r.se3[k] = job.pose[k];
-    if (size > 0) {
-      const int npoints = min(prm.max_ransac_points, size);
-      int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180) ...
-      if (prm.pad_ & 1) index %= size;           // ... or the raw rand() value when the host could not know `size` yet
-      int sel[8];
-      for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
-      Rigid se3;
-      if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
-        r.ok = 1;
-        se3_to7(se3, r.se3);
-        const M3 R = se3_rot(se3);
-#pragma unroll
-        for (int k = 0; k < 9; k++) s_rt[tid][k] = R.m[k];
-        s_rt[tid][9] = se3.t.x;
-        s_rt[tid][10] = se3.t.y;
-        s_rt[tid][11] = se3.t.z;
-      }
+  // ConvergePose of this draw (feature_align.cc:176-197)
+  HypResult r;
+  r.ok = 0;
+  r.supporters = 0;
+  for (int k = 0; k < 7; k++) r.se3[k] = job.pose[k];
+  if (size > 0) {
+    const int npoints = min(prm.max_ransac_points, size);
+    int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180) ...
+    if (prm.pad_ & 1) index %= size;           // ... or the raw rand() value when the host could not know `size` yet
+    int sel[8];
+    for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
+    Rigid se3;
+    if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
+      r.ok = 1;
+      se3_to7(se3, r.se3);
     }
-    s_ok[tid] = r.ok;
-    s_sup[tid] = 0;
-    HypResult &dst = hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h];
-    for (int k = 0; k < 7; k++) dst.se3[k] = r.se3[k];
-    dst.ok = r.ok;
   }
-  __syncthreads();
-  // ---- phase 2: CheckReprojectionError of every draw over every match (feature_align.cc:190, 245-283): the (draw, match)
-  //      pairs are dealt to all lanes of the workgroup; a supporter count is an integer sum, so its order is free
-  const int pairs = nd * size;
-  for (int p = tid; p < pairs; p += static_cast<int>(blockDim.x)) {
-    const int d = p / size, q = p - d * size;
-    if (!s_ok[d]) continue;
-    M3 R;
+  HypResult &dst = hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h];
+  for (int k = 0; k < 7; k++) dst.se3[k] = r.se3[k];
+  dst.ok = r.ok;
+  dst.supporters = 0;  // pose_supporters_kernel adds to it
+}
+
+// CheckReprojectionError of every draw over every match (feature_align.cc:190, 245-283).  blockIdx.x = draw, blockIdx.y = chunk of
+// kSupChunk matches, blockIdx.z = frame; a supporter count is an integer sum, so its order is free: one add per wave.
+__global__ __launch_bounds__(64) void pose_supporters_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+                                                             sdvl_pose_params prm, HypResult *__restrict__ hyp) {
+  const PoseJobDev &job = jobs[blockIdx.z];
+  const int size = job.n_obs;
+  const int q0 = static_cast<int>(blockIdx.y) * kSupChunk;
+  if (q0 >= size) return;
+  HypResult &H = hyp[static_cast<size_t>(blockIdx.z) * prm.max_ransac_its + blockIdx.x];
+  if (!H.ok) return;
+  const Rigid se3 = se3_from7(H.se3);
+  const M3 R = se3_rot(se3);
+  const sdvl_pose_obs *obs = obs_all + job.obs_begin;
+  const int lane = threadIdx.x;
+  int mine = 0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) R.m[k] = s_rt[d][k];
-    const V3 t = {s_rt[d][9], s_rt[d][10], s_rt[d][11]};
-    double ex, ey;
-    V3 pos;
-    reproj_error(obs[q], R, t, &ex, &ey, &pos);
-    if (sqrt(ex * ex + ey * ey) <= prm.inlier_threshold) atomicAdd(&s_sup[d], 1);
+  for (int u = 0; u < kSupChunk / 64; u++) {
+    const int q = q0 + u * 64 + lane;
+    if (q < size) {
+      double ex, ey;
+      V3 pos;
+      reproj_error(obs[q], R, se3.t, &ex, &ey, &pos);
+      mine += sqrt(ex * ex + ey * ey) <= prm.inlier_threshold ? 1 : 0;
+    }
   }
-  __syncthreads();
-  if (tid < nd) hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h0 + tid].supporters = s_sup[tid];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if (lane == 0 && mine > 0) atomicAdd(&H.supporters, mine);
 }
 
 // ---------------------------------------------------------------------------------------------- refinement (wave each)
@@ -442,10 +443,12 @@ __global__ __launch_bounds__(64) void pose_refine_kernel(const PoseJobDev *__res
 size_t sdvl_pose_hyp_bytes() { return sizeof(HypResult); }
 
 int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
-                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists) {
-  static const int hyp_threads = getenv("SDVL_HYP_THREADS") ? atoi(getenv("SDVL_HYP_THREADS")) : kHypThreads;
-  const int hyp_per_wg = hyp_threads < kHypDraws ? hyp_threads : kHypDraws;
-  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + hyp_per_wg - 1) / hyp_per_wg, n_jobs), dim3(hyp_threads), d_jobs, d_obs, d_rand, *p,
+                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists, int max_obs) {
+  if (max_obs < 1) max_obs = 1;
+  if (max_obs > kMaxObs) max_obs = kMaxObs;
+  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), d_jobs, d_obs, d_rand, *p,
+              static_cast<HypResult *>(d_hyp));
+  SDVL_LAUNCH(ctx, "pose_supporters", pose_supporters_kernel, dim3(p->max_ransac_its, (max_obs + kSupChunk - 1) / kSupChunk, n_jobs), dim3(64), d_jobs, d_obs, *p,
               static_cast<HypResult *>(d_hyp));
   SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel, dim3(n_jobs), dim3(64), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
               d_lists);
@@ -506,7 +509,9 @@ extern "C" int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose
   int32_t *dlists = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(ctx->d_out) + res_bytes);
   sdvl_pose_params prm = *p;
   prm.pad_ = 0;  // rand_idx holds indices already reduced modulo the match count
-  rc = sdvl_pose_enqueue_device(ctx, n_jobs, dj, dobs, drand, dnits, &prm, dhyp, dres, dlists);
+  int max_obs = 0;
+  for (int j = 0; j < n_jobs; j++) max_obs = std::max(max_obs, jobs[j].obs_end - jobs[j].obs_begin);
+  rc = sdvl_pose_enqueue_device(ctx, n_jobs, dj, dobs, drand, dnits, &prm, dhyp, dres, dlists, max_obs);
   if (rc) return rc;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes + list_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -762,7 +762,7 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
   sdvl_pose_params pp = s->prm.pose;
   pp.pad_ = 1;  // raw rand() values: the kernel reduces them modulo the match count it finds in the job
   rc = sdvl_pose_enqueue_device(ctx, n_jobs, s->d_pjobs, s->d_obs, s->d_rand, static_cast<const int32_t *>(ctx->d_nits), &pp, s->d_hyp, s->d_pres,
-                                s->d_lists);
+                                s->d_lists, s->mm);
   if (rc) return rc;
   {
     // s_before | s_found | (8-byte aligned) depths of the new frame's points, at most mm of them
