@@ -511,7 +511,8 @@ def main():
                 fibers = 2
             G = max(1, min(B // 8 if B >= 8 else 1, workers_auto * max(1, fibers)))
             if args.workload == "S-C":   # 4x the pixels and features per frame: 64 frames per launch fill the chip, more streams only
-                G = max(1, min(G, max(8, B // 64)))   # stretch the latency-bound kernels (512 sequences: 8 groups 33-40k, 16 groups 31k, 4 groups 28k frames/s)
+                G = max(1, min(G, max(4, B // 64)))   # stretch the latency-bound kernels (512 sequences: 8 groups 33-40k, 16 groups 31k, 4 groups 28k frames/s;
+                                                      # SURVEY's 64 sequences: 4 groups of 16 23.6k, 8 of 8 17k, 2 of 32 15k, 1 of 64 9k: the chain's latency per launch hardly depends on its size)
         while B % G:
             G -= 1
         Bg = B // G

@@ -26,13 +26,27 @@ struct OrbJob {
 
 __device__ __forceinline__ int wave_sum_i32(int v) { return orb_wave_sum_i32(v); }
 
-// grid.x = ceil(max_n / 4) workgroups of 4 waves, grid.y = jobs (frames)
-__global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restrict__ jobs) {
-  const OrbJob &job = jobs[blockIdx.y];
+// Blocks b and b + 8 share an XCD (observed placement, used for speed only): the `chunks` workgroups of frame f all run on XCD f % 8, so
+// the windows of neighbouring corners — a 10x10 or 31x31 window touches 10 / 31 lines of 128 B, and the corners of a cell row share
+// them — come out of ONE L2 instead of being fetched into all eight (round 2: shi_tomasi fetched 53 MB for 5.5 MB of windows).
+// 1-D grid of 8 * ceil(n_frames / 8) * chunks blocks; returns false for the padding blocks.
+__device__ __forceinline__ bool xcd_frame_block(int n_frames, int chunks, int *frame, int *chunk) {
+  const int b = static_cast<int>(blockIdx.x), q = b >> 3;
+  *frame = (q / chunks) * 8 + (b & 7);
+  *chunk = q % chunks;
+  return *frame < n_frames;
+}
+inline dim3 xcd_frame_grid(int n_frames, int chunks) { return dim3(static_cast<unsigned>((n_frames + 7) / 8 * 8 * chunks)); }
+
+// `chunks` workgroups of 4 waves per job (frame), a wave per corner
+__global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restrict__ jobs, int n_jobs, int chunks) {
+  int fj, bx;
+  if (!xcd_frame_block(n_jobs, chunks, &fj, &bx)) return;
+  const OrbJob &job = jobs[fj];
   const int lane = threadIdx.x & 63;
   const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
   // wave-uniform grid-stride loop: the corner count may only be known on the device
-  for (int ci = blockIdx.x * 4 + (threadIdx.x >> 6); ci < n; ci += gridDim.x * 4) {
+  for (int ci = bx * 4 + (threadIdx.x >> 6); ci < n; ci += chunks * 4) {
   const int cx = job.corners[4 * ci], cy = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
   if (cl < 0 || cl >= job.levels) continue;
   const int W = job.lw[cl], H = job.lh[cl];
@@ -59,11 +73,13 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
   }
 }
 
-__global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restrict__ jobs) {
-  const OrbJob &job = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restrict__ jobs, int n_jobs, int chunks) {
+  int fj, bx;
+  if (!xcd_frame_block(n_jobs, chunks, &fj, &bx)) return;
+  const OrbJob &job = jobs[fj];
   const int lane = threadIdx.x & 63;
   const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
-  for (int ci = blockIdx.x * 4 + (threadIdx.x >> 6); ci < n; ci += gridDim.x * 4) {
+  for (int ci = bx * 4 + (threadIdx.x >> 6); ci < n; ci += chunks * 4) {
   const int px = job.corners[4 * ci], py = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
   if (cl < 0 || cl >= job.levels) continue;
   const int W = job.lw[cl], H = job.lh[cl];
@@ -264,11 +280,13 @@ __global__ __launch_bounds__(256) void filter_select_binned_kernel(const FilterJ
 }
 
 // ORB descriptors of the corners filter_select_kernel kept, one wave each: grid.x covers max_out / 4 workgroups, grid.y = frames
-__global__ __launch_bounds__(256) void filter_describe_kernel(const FilterJob *__restrict__ jobs, int max_out) {
-  const FilterJob &job = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void filter_describe_kernel(const FilterJob *__restrict__ jobs, int max_out, int n_jobs, int chunks) {
+  int fj, bx;
+  if (!xcd_frame_block(n_jobs, chunks, &fj, &bx)) return;
+  const FilterJob &job = jobs[fj];
   const int lane = threadIdx.x & 63;
   const int total = min(job.out_count[0], max_out);
-  for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < total; k += gridDim.x * 4) {
+  for (int k = bx * 4 + (threadIdx.x >> 6); k < total; k += chunks * 4) {
     sdvl_filtered_corner *dst = job.out + k;
     const int cx = dst->x, cy = dst->y, cl = dst->level;
     const int W = job.lw[cl], H = job.lh[cl];
@@ -361,7 +379,7 @@ int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, 
   int max_n = 0;
   int rc = fill_jobs(ctx, n, frames, cap, d_desc, nullptr, &d_jobs, &max_n);
   if (rc) return rc;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
   for (int i = 0; i < n; i++) frames[i]->desc_valid = 1;
   if (out_desc) {
@@ -399,7 +417,7 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   rc = fill_jobs(ctx, n, frames, cap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   if (max_n == 0) return SDVL_OK;
-  SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
+  SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, sizeof(double) * cap, ctx->d_out, sizeof(double) * cap, sizeof(double) * max_n, n,
                                        hipMemcpyDeviceToHost, ctx->stream));
@@ -449,7 +467,7 @@ int sdvl_filter_inputs_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, in
   rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   max_n = max_n > ccap ? ccap : max_n;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
   {
     const int units = (ccap + 1) + (desc ? 2 * ccap : 0);  // 16-byte units per row
     SDVL_LAUNCH(ctx, "filter_gather", filter_gather_kernel, dim3((units + 255) / 256, n), dim3(256), static_cast<const OrbJob *>(d_jobs),
@@ -527,7 +545,7 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   max_n = max_n > ccap ? ccap : max_n;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, dim3((max_n + 3) / 4, n), dim3(256), d_jobs);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
   const size_t jb = (sizeof(FilterJob) * n + 255) / 256 * 256, mb = sizeof(uint32_t) * static_cast<size_t>(n) * mask_words;
   void *hs = nullptr, *dsx = nullptr;
   rc = sdvl_stage_alloc(ctx, jb + mb, &hs, &dsx);
@@ -556,8 +574,8 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   else
     SDVL_LAUNCH(ctx, "filter_select", filter_select_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells, margin,
                 min_feature_score, max_out);
-  SDVL_LAUNCH(ctx, "filter_describe", filter_describe_kernel, dim3((std::min(max_out, 512) + 3) / 4, n), dim3(256), static_cast<const FilterJob *>(dsx),
-              max_out);
+  SDVL_LAUNCH(ctx, "filter_describe", filter_describe_kernel, xcd_frame_grid(n, (std::min(max_out, 512) + 3) / 4), dim3(256), static_cast<const FilterJob *>(dsx),
+              max_out, n, (std::min(max_out, 512) + 3) / 4);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, d8 + sc_bytes, cnt_bytes + rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_FILTER, &ctx->filter_ticket));
@@ -648,7 +666,7 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   hj->n = n;
   hj->levels = f->v.levels;
   SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, job_off + sizeof(OrbJob)));
-  SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, dim3((n + 3) / 4, 1), dim3(256), reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(dsx) + job_off));
+  SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, xcd_frame_grid(1, (n + 3) / 4), dim3(256), reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(dsx) + job_off), 1, (n + 3) / 4);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, a_off + a_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

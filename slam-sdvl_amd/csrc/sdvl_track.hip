@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
   const Rigid pose = se3_from7(s_pose);
   const M3 R = se3_rot(pose);
   const int gw = static_cast<int>(ceil(cam.width / cell_size));
-  for (int i = tid; i < n_feat; i += kProjThreads) {
+  for (int i = tid; i < n_feat; i += static_cast<int>(blockDim.x)) {
     unsigned long long key = ~0ull;
     const int praw = F[i].point;
     if (praw >= 0 && !(praw & SDVL_TRACK_DUPLICATE)) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
   __syncthreads();
   const int n_cand = s_ncand;
   // position of every candidate in visiting order = number of smaller keys (keys are unique: they end in the feature index)
-  for (int i = tid; i < n_feat; i += kProjThreads) {
+  for (int i = tid; i < n_feat; i += static_cast<int>(blockDim.x)) {
     const unsigned long long key = s_key[i];
     if (key == ~0ull) continue;
     int r = 0;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
     s_cell[r] = static_cast<uint16_t>(key >> 48);
   }
   __syncthreads();
-  for (int k = tid; k < stride; k += kProjThreads) {
+  for (int k = tid; k < stride; k += static_cast<int>(blockDim.x)) {
     if (k < n_cand) {
       int first = k;
       const uint16_t c = s_cell[k];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
     }
   }
   const int nblk = stride / kWavesPerBlock;
-  for (int b = tid; b < nblk; b += kProjThreads) {
+  for (int b = tid; b < nblk; b += static_cast<int>(blockDim.x)) {
     int cnt = n_cand - b * kWavesPerBlock;
     cnt = cnt < 0 ? 0 : (cnt > kWavesPerBlock ? kWavesPerBlock : cnt);
     blocks[j * nblk + b] = SearchBlock{base + b * kWavesPerBlock, cnt};
@@ -745,7 +745,9 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
     }
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "track_project", &ev_a, &ev_b);
-    hipExtLaunchKernelGGL(track_project_kernel, dim3(n_jobs), dim3(kProjThreads), lds, ctx->stream, ev_a, ev_b, 0,
+    // a lane per feature of last_frame: 256 lanes cover the ~190 features of the metric configuration, configuration C's ~850 take 512
+    const int proj_threads = stride <= 256 ? 256 : kProjThreads;
+    hipExtLaunchKernelGGL(track_project_kernel, dim3(n_jobs), dim3(proj_threads), lds, ctx->stream, ev_a, ev_b, 0,
                           static_cast<const TrackJobDev *>(s->d_jobs), s->d_points, static_cast<const TrackFeat *>(s->d_feats[0]),
                           static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, stride, s->mm, s->max_its,
                           static_cast<const sdvl_align_result *>(s->d_ares), static_cast<const uint16_t *>(s->d_cell_rank), s->cells, c,
