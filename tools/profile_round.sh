@@ -10,23 +10,23 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/prof_sq
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --steps 20 --warmup 3 --cpu-frames 0 --host-steps 0 > $O/prof_kt.json 2> $O/prof_kt.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 --host-steps 0 > $O/prof_fetch.json 2> $O/prof_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 --host-steps 0 > $O/prof_write.json 2> $O/prof_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --steps 20 --warmup 3 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/prof_kt.json 2> $O/prof_kt.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/prof_fetch.json 2> $O/prof_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/prof_write.json 2> $O/prof_write.err
 # SQ counters in a pass of their own (8 SQ slots; MI355X_MICROARCH.md "rocprofv3 PMC slots"): LDS-array cycles and the extra cycles
 # bank conflicts cost, LDS instructions, waves launched, VALU instructions issued, cycles waves spent waiting / busy
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/prof_sq -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 --host-steps 0 > $O/prof_sq.json 2> $O/prof_sq.err
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/prof_sq -- python3 bench.py --steps 4 --warmup 1 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/prof_sq.json 2> $O/prof_sq.err
 find $O/prof_sq -name "*kernel_trace.csv" -delete
 # the stats files are small; the raw traces are not needed back
 find $O/prof_kt -name "*kernel_trace.csv" -delete
 find $O/prof_fetch $O/prof_write -name "*kernel_trace.csv" -delete
 # the other two configurations DESIGN §7 quotes: the reference's mapper inside every step, and BASELINE's configuration C
 python3 bench.py --mapper --steps 20 --warmup 4 --cpu-frames 0 --host-steps 0 > $O/bench_mapper.json 2> $O/bench_mapper.err
-python3 bench.py --workload S-C --seqs 512 --steps 30 --warmup 4 --cpu-frames 60 --host-steps 0 > $O/bench_config_c.json 2> $O/bench_config_c.err
-python3 bench.py --workload S-C --steps 30 --warmup 4 --cpu-frames 0 --host-steps 0 > $O/bench_config_c_64seq.json 2> $O/bench_config_c_64seq.err
+python3 bench.py --workload S-C --seqs 512 --steps 30 --warmup 4 --cpu-frames 60 --host-steps 0 --sustained-frames 0 > $O/bench_config_c.json 2> $O/bench_config_c.err
+python3 bench.py --workload S-C --steps 30 --warmup 4 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/bench_config_c_64seq.json 2> $O/bench_config_c_64seq.err
 # kernel stats of configuration C (the workload whose dominant kernel VERDICT r01 asked to halve)
 rm -rf $O/sc_kt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/sc_kt -- python3 bench.py --workload S-C --seqs 512 --steps 10 --warmup 3 --cpu-frames 0 --host-steps 0 > $O/sc_kt.json 2> $O/sc_kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/sc_kt -- python3 bench.py --workload S-C --seqs 512 --steps 10 --warmup 3 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/sc_kt.json 2> $O/sc_kt.err
 find $O/sc_kt -name "*kernel_trace.csv" -delete
 python3 tools/kernel_bench.py 256 6 > $O/kernel_bench_isolated.txt 2>&1
 python3 tools/pcie_probe.py > $O/pcie_probe.txt 2>&1
