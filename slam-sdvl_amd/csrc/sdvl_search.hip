@@ -480,14 +480,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         const int cy0 = max(0, static_cast<int>(floor(by0)) >> 5), cy1 = min(gh - 1, static_cast<int>(floor(by1)) >> 5);
         if (cx1 < cx0 || cy1 < cy0) {
           scanned = true;  // the region lies outside the image: no corner can be in range
-        } else if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 48) {
+        } else if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 48 && cy1 - cy0 < 4) {  // (taller regions: the full scan below)
           scanned = true;
-          for (int cyi = cy0; cyi <= cy1; cyi++) {
-            const int e0 = cf.bin_start[cyi * gw + cx0], e1 = cf.bin_start[cyi * gw + cx1 + 1];  // cells of a row are consecutive
-            for (int e = e0; e < e1; e += 64) {
-              const bool have = e + lane < e1;
+          const int nrows = cy1 - cy0 + 1;
+          {
+            // the entries of the (at most four) cell rows as ONE lane space: a search region of a few cells holds ~15 corners, so a
+            // round per row ran the whole range test two or three times for a quarter of a wave each.  Row r contributes entries
+            // [e0[r], e1[r]) (cells of a row are consecutive); lane index i maps to the row whose prefix range holds it.
+            int e0[4], pre[5];
+            pre[0] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int cyi = min(cy0 + r, cy1);
+              const int a = cf.bin_start[cyi * gw + cx0], b = cf.bin_start[cyi * gw + cx1 + 1];
+              e0[r] = a;
+              pre[r + 1] = pre[r] + (r < nrows ? b - a : 0);
+            }
+            const int total = pre[4];
+            for (int base = 0; base < total; base += 64) {
+              const int i = base + lane;
+              const bool have = i < total;
+              int r = 0;
+#pragma unroll
+              for (int q = 1; q < 4; q++) r += (i >= pre[q]) ? 1 : 0;
+              const int e = i + (r == 0 ? e0[0] - pre[0] : r == 1 ? e0[1] - pre[1] : r == 2 ? e0[2] - pre[2] : e0[3] - pre[3]);
               uint2 ent = make_uint2(0u, 0u);
-              if (have) ent = cf.bin_entries[e + lane];
+              if (have) ent = cf.bin_entries[e];
               scan_round(have, ent.x, static_cast<int>(ent.y));
             }
           }
