@@ -675,8 +675,10 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
   s->cam = *cam;
   s->prm = *p;
   s->jobs.assign(jobs, jobs + n_jobs);
-  // jobs | cell ranks | rand values: one staged copy
-  const size_t jb = (sizeof(TrackJobDev) * n_jobs + 255) / 256 * 256, cb = (sizeof(uint16_t) * static_cast<size_t>(n_jobs) * s->cells + 255) / 256 * 256;
+  // jobs | cell ranks | rand values: staged at the offsets the three arrays have in the set's scratch (they were carved one behind
+  // the other), so ONE push lands all of them — every push is a launch on the step's critical path
+  const size_t jb = static_cast<size_t>(reinterpret_cast<uint8_t *>(s->d_cell_rank) - reinterpret_cast<uint8_t *>(s->d_jobs));
+  const size_t cb = static_cast<size_t>(reinterpret_cast<uint8_t *>(s->d_rand) - reinterpret_cast<uint8_t *>(s->d_cell_rank));
   const size_t rb = sizeof(int32_t) * static_cast<size_t>(n_jobs) * s->max_its;
   void *hs = nullptr, *dsx = nullptr;
   rc = sdvl_stage_alloc(ctx, jb + cb + rb, &hs, &dsx);
@@ -706,9 +708,7 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
   }
   memcpy(h8 + jb, cell_rank, sizeof(uint16_t) * static_cast<size_t>(n_jobs) * s->cells);
   memcpy(h8 + jb + cb, rand_raw, rb);
-  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_jobs, h8, sizeof(TrackJobDev) * n_jobs));
-  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_cell_rank, h8 + jb, sizeof(uint16_t) * static_cast<size_t>(n_jobs) * s->cells));
-  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_rand, h8 + jb + cb, rb));
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_jobs, h8, jb + cb + rb));
   (void)d8;
   SDVL_LAUNCH(ctx, "track_align_prep", track_align_prep_kernel, dim3(n_jobs), dim3(256), static_cast<const TrackJobDev *>(s->d_jobs),
               static_cast<const TrackPoint *>(s->d_points), static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]),
