@@ -176,6 +176,14 @@ class Frame:
         self.ctx._check(self.ctx.lib.sdvl_frame_set_image_device(self.ctx.h, self.h, C.c_void_p(dev_ptr), stride or self.width))
         return self
 
+    def borrow_image_device(self, dev_ptr):
+        """level 0 aliases the caller's HBM image (dense rows) until the next upload / own_images"""
+        self.ctx._check(self.ctx.lib.sdvl_frame_borrow_image_device(self.ctx.h, self.h, C.c_void_p(dev_ptr)))
+        return self
+
+    def corner_capacity(self):
+        return self.ctx.lib.sdvl_frame_corner_capacity(self.h)
+
     def level(self, l):
         w, h = self.width >> l, self.height >> l
         out = np.zeros((h, w), np.uint8)
@@ -296,6 +304,15 @@ class Context:
     def pyramid_build(self, frames):
         arr = (C.c_void_p * len(frames))(*[f.h for f in frames])
         self._check(self.lib.sdvl_pyramid_build(self.h, len(frames), arr))
+
+    def set_corner_capacity(self, max_corners):
+        """corners_ capacity of the frames created from now on (<= MAX_CORNERS)"""
+        self._check(self.lib.sdvl_ctx_set_corner_capacity(self.h, int(max_corners)))
+
+    def own_images(self, frames):
+        """frames whose level 0 aliases a caller image copy it into their own storage (one launch)"""
+        arr = (C.c_void_p * len(frames))(*[f.h for f in frames])
+        self._check(self.lib.sdvl_frames_own_images(self.h, len(frames), arr))
 
     def fast_cells(self, frames, dp, cap=16384):
         """-> list of (keypoints[(x,y,score,level,cell)], cell_offsets) per frame"""
@@ -587,3 +604,34 @@ def default_align_params(fast=False):
 def default_search_params(use_orb=True, orb_size=31, patch_size=8):
     return SearchParams(patch_size=8, max_align_its=10, search_size=6, max_fast_levels=3,
                         margin=(4 + orb_size // 2) if use_orb else (1 + patch_size // 2), use_orb=int(use_orb))
+
+
+class Feed:
+    """sdvl_feed: one copy stream filled by one thread; consumers (contexts) acquire / release its slots"""
+
+    def __init__(self, device=0, n_slots=2):
+        self.lib = load_library()
+        self.lib.sdvl_feed_last_error.restype = C.c_char_p
+        self.lib.sdvl_feed_last_error.argtypes = [C.c_void_p]
+        h = C.c_void_p()
+        if self.lib.sdvl_feed_create(device, n_slots, C.byref(h)) != 0:
+            raise SdvlError("sdvl_feed_create failed")
+        self.h = h
+
+    def images(self, slot, host_ptrs, stride, width, height, dev_dst):
+        n = len(host_ptrs)
+        src = (C.c_void_p * n)(*[int(p) for p in host_ptrs])
+        dst = (C.c_void_p * n)(*[int(p) for p in dev_dst])
+        if self.lib.sdvl_feed_images(self.h, slot, n, src, stride, width, height, dst) != 0:
+            raise SdvlError("sdvl_feed_images: %s" % self.lib.sdvl_feed_last_error(self.h).decode())
+
+    def acquire(self, ctx, slot):
+        ctx._check(self.lib.sdvl_ctx_feed_acquire(ctx.h, self.h, slot))
+
+    def release(self, ctx, slot):
+        ctx._check(self.lib.sdvl_ctx_feed_release(ctx.h, self.h, slot))
+
+    def close(self):
+        if self.h:
+            self.lib.sdvl_feed_destroy(self.h)
+            self.h = None

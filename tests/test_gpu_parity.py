@@ -126,6 +126,72 @@ def test_fast_cells_euroc_size(ctx, sdvl, orc, synth):
     assert check_fast(ctx, sdvl, orc, frames_of(synth, orc, EUROC_CAM, 752, 480, [3])) > 3000
 
 
+def test_detect_corners_with_many_score_ties_goes_through_the_spill_area(ctx, sdvl, orc):
+    """isolated bright pixels on a 10-px lattice: 1680 FAST corners on level 0 and 1518 on level 1, all with the SAME score.
+    retainBest keeps every tie at its boundary (fast_detector.cc:140,147-148), so a level's concatenated list (all of them) outgrows
+    the LDS share select_pack plans for it (1.5 x (quota + cells) = 1088 / 640 entries) and is worked on in the frame's spill area
+    in HBM: same corners, same order as the oracle."""
+    img = np.full((480, 640), 40, np.uint8)
+    img[24:456:10, 24:616:10] = 200
+    want = orc.detect_pyramid(img)
+    f = ctx.frame(img)
+    got = ctx.detect_corners([f], sdvl.default_detect_params(), 1000)[0]
+    assert len(want) == 3198 and np.bincount(want[:, 2]).tolist() == [1680, 1518]   # three times num_features: the ties were kept
+    assert np.array_equal(got, want)
+    f.close()
+
+
+def test_corner_capacity_of_a_context(sdvl, orc, synth):
+    """sdvl_ctx_set_corner_capacity: frames created afterwards hold that many corners (their resident block shrinks with it); a
+    detection that fits behaves as ever, one that does not is reported as SDVL_ERR_CAPACITY by sdvl_frames_corner_counts"""
+    lib = sdvl.load_library()
+    lib.sdvl_frame_footprint_cap.restype = C.c_int64
+    big, small = lib.sdvl_frame_footprint_cap(640, 480, 5, sdvl.MAX_CORNERS), lib.sdvl_frame_footprint_cap(640, 480, 5, 1536)
+    assert 480_000 < small < 520_000 and 740_000 < big < 800_000        # 0.50 MB / 0.76 MB per 640x480 frame (1.43 MB in round 2)
+    c2 = sdvl.Context(0)
+    img, = frames_of(synth, orc, TUM_CAM, 640, 480, [2])
+    want = orc.detect_pyramid(img)
+    c2.set_corner_capacity(1536)
+    f = c2.frame(img)
+    assert f.corner_capacity() == 1536
+    assert np.array_equal(c2.detect_corners([f], sdvl.default_detect_params(), 1000)[0], want)
+    f.close()
+    c2.set_corner_capacity(512)
+    g = c2.frame(img)
+    with pytest.raises(sdvl.SdvlError, match="capacity"):
+        c2.detect_corners([g], sdvl.default_detect_params(), 1000)
+    g.close()
+    c2.close()
+
+
+def test_feed_slots_and_own_images(ctx, sdvl, orc, synth):
+    """sdvl_feed (one copy stream, slots with acquire / release) + sdvl_frame_borrow_image_device + sdvl_frames_own_images: frames
+    alias a slot's buffers, one of them takes its image over, the slot is refilled with other images: the owner keeps the old image
+    (level 0 and the pyramid it was built from), the alias sees the new one"""
+    import torch
+    imgs = frames_of(synth, orc, TUM_CAM, 640, 480, [0, 1, 2, 3])
+    fb = 640 * 480
+    pinned = torch.empty(4 * fb, dtype=torch.uint8, pin_memory=True)
+    pinned.numpy()[:] = np.concatenate([im.reshape(-1) for im in imgs])
+    slot = ctx.device_malloc(2 * fb)
+    feed = sdvl.Feed(0, 1)
+    feed.images(0, [pinned.data_ptr(), pinned.data_ptr() + fb], 640, 640, 480, [slot, slot + fb])     # images 0, 1 (one DMA: contiguous)
+    feed.acquire(ctx, 0)
+    fa, fo = sdvl.Frame(ctx, 640, 480), sdvl.Frame(ctx, 640, 480)
+    fa.borrow_image_device(slot)
+    fo.borrow_image_device(slot + fb)
+    ctx.pyramid_build([fa, fo])
+    assert np.array_equal(fa.level(0), imgs[0]) and np.array_equal(fo.level(0), imgs[1])
+    ctx.own_images([fo])                                    # fo keeps image 1; fa still aliases the slot
+    ctx.own_images([fo])                                    # a second call finds nothing to do
+    feed.release(ctx, 0)
+    feed.images(0, [pinned.data_ptr() + 2 * fb, pinned.data_ptr() + 3 * fb], 640, 640, 480, [slot, slot + fb])  # images 2, 3 into the same buffers
+    feed.acquire(ctx, 0)
+    assert np.array_equal(fo.level(0), imgs[1]) and np.array_equal(fo.level(1), orc.pyramid(imgs[1], 5)[1])
+    assert np.array_equal(fa.level(0), imgs[2])
+    fa.close(); fo.close(); feed.close(); ctx.device_free(slot)
+
+
 def test_device_retain_best_is_libstdcxx_order(ctx, orc):
     """the device restatement of nth_element + partition leaves the list exactly as libstdc++ does"""
     rng = np.random.default_rng(42)
