@@ -570,6 +570,8 @@ int sdvl_track_create(sdvl_ctx *ctx, int n_trackers, int max_points, int max_fea
 int sdvl_track_destroy(sdvl_ctx *ctx, sdvl_track_set *set);
 /* (frame, pose) becomes addressable by tables: keyframes when their pose is final, the bootstrap frame */
 int sdvl_frame_register(sdvl_ctx *ctx, const sdvl_frame *frame, const double *pose7);
+/* the same for n frames (poses7 = [n][7]) in one submission */
+int sdvl_frames_register(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const double *poses7);
 /* replaces the tables of n trackers: trackers[i] gets n_points[i] points and n_features[i] features (concatenated arrays),
  * its features go to buffer feat_buf[i].  Asynchronous. */
 int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *set, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,

@@ -571,20 +571,29 @@ int sdvl_track_destroy(sdvl_ctx *ctx, sdvl_track_set *s) {
   return SDVL_OK;
 }
 
-int sdvl_frame_register(sdvl_ctx *ctx, const sdvl_frame *f, const double *pose7) {
-  if (!ctx || !f || !pose7) return SDVL_ERR_INVALID;
-  SDVL_REQUIRE(ctx, f->home == ctx && f->reg_id >= 0 && f->reg_id < ctx->registry_cap, "frame was not created on this context");
+int sdvl_frame_register(sdvl_ctx *ctx, const sdvl_frame *f, const double *pose7) { return sdvl_frames_register(ctx, 1, &f, pose7); }
+
+// n frames in one push + one launch (a group of trackers registers ~10 reference frames per step when keyframes are created:
+// one at a time that was two dispatches each on the step's critical path)
+int sdvl_frames_register(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, const double *poses7) {
+  if (!ctx || n < 0 || (n > 0 && (!frames || !poses7))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  for (int i = 0; i < n; i++)
+    SDVL_REQUIRE(ctx, frames[i] && frames[i]->home == ctx && frames[i]->reg_id >= 0 && frames[i]->reg_id < ctx->registry_cap,
+                 "frame was not created on this context");
   void *hs = nullptr, *dsx = nullptr;
-  int rc = sdvl_stage_alloc(ctx, sizeof(RegisterRec), &hs, &dsx);
+  int rc = sdvl_stage_alloc(ctx, sizeof(RegisterRec) * static_cast<size_t>(n), &hs, &dsx);
   if (rc) return rc;
   RegisterRec *r = static_cast<RegisterRec *>(hs);
-  fill_view(&r->e.f, f);
-  memcpy(r->e.pose, pose7, sizeof(double) * 7);
-  r->e.pad_ = 0.0;
-  r->id = f->reg_id;
-  r->pad_ = 0;
-  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, sizeof(RegisterRec)));
-  SDVL_LAUNCH(ctx, "registry_write", registry_write_kernel, dim3(1), dim3(64), static_cast<const RegisterRec *>(dsx), 1,
+  for (int i = 0; i < n; i++) {
+    fill_view(&r[i].e.f, frames[i]);
+    memcpy(r[i].e.pose, poses7 + 7 * i, sizeof(double) * 7);
+    r[i].e.pad_ = 0.0;
+    r[i].id = frames[i]->reg_id;
+    r[i].pad_ = 0;
+  }
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, sizeof(RegisterRec) * static_cast<size_t>(n)));
+  SDVL_LAUNCH(ctx, "registry_write", registry_write_kernel, dim3((n + 63) / 64), dim3(64), static_cast<const RegisterRec *>(dsx), n,
               static_cast<SearchFramePose *>(ctx->d_registry));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;

@@ -2049,13 +2049,16 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
       vector<int32_t> up_trk, up_buf, up_np, up_nf;
       tr_up_points_.clear();
       tr_up_feats_.clear();
+      vector<const sdvl_frame *> reg_frames;   // every reference frame the rebuilt tables name for the first time: ONE submission
+      vector<double> reg_poses;
       for (int i : need) {
         SDVL::TrackState &ts = trk_[i]->track_;
         for (Frame *ref : ts.up_register)
           if (!ref->IsRegistered()) {
             double pose[7];
             ref->GetPose().ToArray(pose);
-            dev_->Check(sdvl_frame_register(dev_->ctx(), ref->device(), pose), "sdvl_frame_register");
+            reg_frames.push_back(ref->device());
+            reg_poses.insert(reg_poses.end(), pose, pose + 7);
             ref->SetRegistered();
           }
         up_trk.push_back(i);
@@ -2065,6 +2068,8 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         tr_up_points_.insert(tr_up_points_.end(), ts.up_points.begin(), ts.up_points.end());
         tr_up_feats_.insert(tr_up_feats_.end(), ts.up_feats.begin(), ts.up_feats.end());
       }
+      if (!reg_frames.empty())
+        dev_->Check(sdvl_frames_register(dev_->ctx(), static_cast<int>(reg_frames.size()), reg_frames.data(), reg_poses.data()), "sdvl_frames_register");
       dev_->Check(sdvl_track_upload(dev_->ctx(), track_, static_cast<int>(up_trk.size()), up_trk.data(), up_buf.data(), up_np.data(), tr_up_points_.data(),
                                     up_nf.data(), tr_up_feats_.data()), "sdvl_track_upload");
       for (int i : need) {
