@@ -194,8 +194,20 @@ __global__ __launch_bounds__(64) void pose_supporters_kernel(const PoseJobDev *_
 }
 
 // ---------------------------------------------------------------------------------------------- refinement (wave each)
+// Round 3: pose_refine_kernel runs on kRefWaves waves.  Wave 0 executes the function exactly as before (the replay of the RANSAC
+// budget, the ordered inlier / outlier lists, the median, the solves); the other waves only help where the time goes — the
+// normal-equation terms of ConvergePose, 28 per observation: a round covers 64 * kRefWaves observations (wave w computes
+// observations 64 w .. 64 w + 63 of the round), then lanes 0..27 of wave 0 add the round's terms IN OBSERVATION ORDER (the
+// reference's rounding).  The helpers wait at a workgroup barrier for wave 0's next command (RefineCtl): run a round / leave.
+struct RefineCtl {
+  double R[9], t[3], scale;
+  const uint16_t *list;
+  int n, q0, cmd;  // cmd: 1 = compute the terms of round q0, 0 = leave
+};
+template <int kRefWaves>
 struct RefineLds {
-  double terms[64][29];  // 28 normal-equation terms of up to 64 observations (+1 pad: no 2-way bank conflict pattern)
+  double terms[64 * kRefWaves][29];  // 28 normal-equation terms per observation of a round (+1 pad: no 2-way bank conflict pattern)
+  RefineCtl ctl;
   double sums[28];
   double errs[kMaxObs];
   uint16_t inl[kMaxObs], outl[kMaxObs], tmp[kMaxObs];
@@ -257,8 +269,50 @@ __device__ __forceinline__ double wave_kth_smallest(const double *vals, int n, i
   return __longlong_as_double(static_cast<long long>(prefix));
 }
 
-// ConvergePose over list[0..n) (n <= kMaxObs) by one wave; returns false when the list is empty
-__device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const uint16_t *list, int n, const Rigid &frame_pose, double fx,
+// the 28 terms of observation list[q] under (R, t) -> L.terms[row] (feature_align.cc:370-400)
+template <int kRefWaves>
+__device__ __forceinline__ void refine_terms(RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, const uint16_t *list, int q, int row, const M3 &R, const V3 &t,
+                                             double scale) {
+  const sdvl_pose_obs o = obs[list[q]];
+  double ex, ey;
+  V3 pos;
+  reproj_error(o, R, t, &ex, &ey, &pos);
+  double J[12];
+  jacobian_3d_to_plane(pos, J);
+#pragma unroll
+  for (int c = 0; c < 12; c++) J[c] *= o.inv_cov;
+  const double weight = tukey(sqrt(ex * ex + ey * ey) / scale);
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = r; c < 6; c++) L.terms[row][k++] = (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+#pragma unroll
+  for (int r = 0; r < 6; r++) L.terms[row][21 + r] = (J[r] * ex + J[6 + r] * ey) * weight;
+  L.terms[row][27] = (ex * ex + ey * ey) * weight;
+}
+
+// what a helper wave (1 .. kRefWaves - 1) does for the whole kernel: wait for wave 0's command, compute its 64 observations of the round
+template <int kRefWaves>
+__device__ void refine_helper_loop(RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, int wave, int lane) {
+  for (;;) {
+    __syncthreads();  // A: the command is published
+    if (L.ctl.cmd == 0) return;
+    const int q = L.ctl.q0 + 64 * wave + lane;
+    if (q < L.ctl.n) {
+      M3 R;
+#pragma unroll
+      for (int k = 0; k < 9; k++) R.m[k] = L.ctl.R[k];
+      const V3 t = {L.ctl.t[0], L.ctl.t[1], L.ctl.t[2]};
+      refine_terms(L, obs, L.ctl.list, q, 64 * wave + lane, R, t, L.ctl.scale);
+    }
+    __syncthreads();  // B: the round's terms are complete
+  }
+}
+
+// ConvergePose over list[0..n) (n <= kMaxObs) by wave 0 with the helpers; returns false when the list is empty
+template <int kRefWaves>
+__device__ bool converge_pose_wave(RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, const uint16_t *list, int n, const Rigid &frame_pose, double fx,
                                    int max_its, Rigid *se3, int lane) {
   Rigid last = frame_pose;
   *se3 = last;
@@ -282,32 +336,25 @@ __device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const
     const M3 R = se3_rot(*se3);
     if (lane < 28) L.sums[lane] = 0.0;
     double acc = 0.0;  // lanes 0..27: running sum of term `lane` in observation order
-    for (int q0 = 0; q0 < n; q0 += 64) {
-      const int q = q0 + lane;
-      if (q < n) {
-        const sdvl_pose_obs o = obs[list[q]];
-        double ex, ey;
-        V3 pos;
-        reproj_error(o, R, se3->t, &ex, &ey, &pos);
-        double J[12];
-        jacobian_3d_to_plane(pos, J);
+    for (int q0 = 0; q0 < n; q0 += 64 * kRefWaves) {
+      if (lane == 0) {  // the round's command for the helper waves
 #pragma unroll
-        for (int c = 0; c < 12; c++) J[c] *= o.inv_cov;
-        const double weight = tukey(sqrt(ex * ex + ey * ey) / scale);
-        int t = 0;
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-          for (int c = r; c < 6; c++) L.terms[lane][t++] = (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
-#pragma unroll
-        for (int r = 0; r < 6; r++) L.terms[lane][21 + r] = (J[r] * ex + J[6 + r] * ey) * weight;
-        L.terms[lane][27] = (ex * ex + ey * ey) * weight;
+        for (int k = 0; k < 9; k++) L.ctl.R[k] = R.m[k];
+        L.ctl.t[0] = se3->t.x; L.ctl.t[1] = se3->t.y; L.ctl.t[2] = se3->t.z;
+        L.ctl.scale = scale;
+        L.ctl.list = list;
+        L.ctl.n = n;
+        L.ctl.q0 = q0;
+        L.ctl.cmd = 1;
       }
-      wave_lds_sync();
+      __syncthreads();  // A
+      const int q = q0 + lane;
+      if (q < n) refine_terms(L, obs, list, q, lane, R, se3->t, scale);
+      __syncthreads();  // B
       if (lane < 28) {
         // in observation order; b accumulates with -= in the reference, and x - t == x + (-t) exactly.  Loads are issued
         // eight at a time so that the LDS latency is paid once per group, the adds stay a dependent chain.
-        const int m = min(64, n - q0);
+        const int m = min(64 * kRefWaves, n - q0);
         const bool neg = lane >= 21 && lane < 27;
         int j = 0;
         for (; j + 8 <= m; j += 8) {
@@ -353,15 +400,20 @@ __device__ bool converge_pose_wave(RefineLds &L, const sdvl_pose_obs *obs, const
   return true;
 }
 
-__global__ __launch_bounds__(64) void pose_refine_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+template <int kRefWaves>
+__global__ __launch_bounds__(64 * kRefWaves) void pose_refine_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
                                                          const int32_t *__restrict__ nits_table, const HypResult *__restrict__ hyp,
                                                          sdvl_pose_params prm, sdvl_pose_result *__restrict__ results,
                                                          int32_t *__restrict__ out_lists) {
-  __shared__ RefineLds L;
+  __shared__ RefineLds<kRefWaves> L;
   const PoseJobDev &job = jobs[blockIdx.x];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int size = job.n_obs;
   const sdvl_pose_obs *obs = obs_all + job.obs_begin;
+  if (wave > 0) {  // helper waves: ConvergePose's terms only (size == 0: wave 0 returns without a command)
+    if (size > 0) refine_helper_loop(L, obs, wave, lane);
+    return;
+  }
   sdvl_pose_result res;
   for (int k = 0; k < 7; k++) res.pose[k] = job.pose[k];
   res.n_draws = 0;
@@ -435,7 +487,11 @@ __global__ __launch_bounds__(64) void pose_refine_kernel(const PoseJobDev *__res
   int32_t *lists = out_lists + job.obs_begin;
   for (int q = lane; q < n_in; q += 64) lists[q] = L.inl[q];
   for (int q = lane; q < n_out; q += 64) lists[n_in + q] = L.outl[q];
-  if (lane == 0) results[blockIdx.x] = res;
+  if (lane == 0) {
+    results[blockIdx.x] = res;
+    L.ctl.cmd = 0;  // the helpers leave
+  }
+  __syncthreads();  // A
 }
 
 }  // namespace
@@ -450,7 +506,13 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
               static_cast<HypResult *>(d_hyp));
   SDVL_LAUNCH(ctx, "pose_supporters", pose_supporters_kernel, dim3(p->max_ransac_its, (max_obs + kSupChunk - 1) / kSupChunk, n_jobs), dim3(64), d_jobs, d_obs, *p,
               static_cast<HypResult *>(d_hyp));
-  SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel, dim3(n_jobs), dim3(64), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
+  // a frame of the metric configuration has <= 200 observations: one wave (three waves with 59 KB of LDS wait longer for a CU among the
+  // other streams' kernels than they save: 2.4 -> 3.9 ms of dispatch time per step); configuration C's ~850: wave 0 + two helpers
+  if (max_obs > 256)
+    SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel<3>, dim3(n_jobs), dim3(192), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
+                d_lists);
+  else
+  SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel<1>, dim3(n_jobs), dim3(64), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
               d_lists);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
