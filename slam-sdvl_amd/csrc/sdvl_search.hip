@@ -278,24 +278,33 @@ __global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev 
 // kStage: frames without corner bins get their corner list staged in LDS (16 KB per workgroup).  Launches whose frames all
 // carry bins (every frame that went through sdvl_detect_corners: the tracking path) use the form without the stage: 3.7 KB of
 // LDS per workgroup, so its workgroups fit beside the LDS-heavy kernels of the other streams.
-template <bool kStage>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
+// kW: waves of a workgroup.  The staged form shares the frame's corner list among the kWavesPerBlock requests of a block, so its
+// workgroup is the block (kW = kWavesPerBlock).  The form without the stage (round 3) runs ONE WAVE per workgroup, four workgroups per
+// block: among the other streams' one-wave kernels (fast_cells, pyr_down) a workgroup that needs four free wave slots on one CU at
+// the same moment is placed far less often than its share — every slot that frees is taken by a one-wave workgroup first.
+template <bool kStage, int kW>
+__global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
                                                                             const SearchFramePose *__restrict__ table,
                                                                             const SearchBlock *__restrict__ blocks,
                                                                             const SearchPrep *__restrict__ prep, Cam cam,
                                                                             sdvl_search_params prm, int n_blocks,
                                                                             sdvl_search_res *__restrict__ out,
                                                                             sdvl_search_res *__restrict__ out_host) {
-  __shared__ WaveLds s_lds[kWavesPerBlock];
+  static_assert(kW == kWavesPerBlock || (kW == 1 && !kStage), "one wave per workgroup only without the shared corner stage");
+  __shared__ WaveLds s_lds[kW];
   // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
   __shared__ uint32_t s_corners[kStage ? kLdsCorners : 1];
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // wave-uniform: request, prep and frame-table loads become scalar loads
+  const int lane = threadIdx.x & 63;
+  // wave-uniform: request, prep and frame-table loads become scalar loads.  kW == 1: the grid holds kWavesPerBlock workgroups per block
+  const int wv = kW == 1 ? static_cast<int>((blockIdx.x >> 3) % kWavesPerBlock) : __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   // Workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is padded to a multiple of 8).  XCD x takes the x-th
   // eighth of the block table: blocks are ordered by current frame, so one frame's corner list, search-level image and
   // ORB windows are fetched into ONE L2 instead of all eight.
-  const int per_xcd = static_cast<int>(gridDim.x >> 3);
-  const int bi = static_cast<int>(blockIdx.x & 7u) * per_xcd + static_cast<int>(blockIdx.x >> 3);
+  // (kW == 1: the grid is kWavesPerBlock times as long; workgroup h runs on XCD h & 7, and within an XCD's sequence h >> 3 the
+  //  kWavesPerBlock workgroups of a block follow each other)
+  const int per_xcd = static_cast<int>((kW == 1 ? gridDim.x / kWavesPerBlock : gridDim.x) >> 3);
+  const int bi = static_cast<int>(blockIdx.x & 7u) * per_xcd + static_cast<int>(kW == 1 ? (blockIdx.x >> 3) / kWavesPerBlock : (blockIdx.x >> 3));
   if (bi >= n_blocks) return;
   const SearchBlock blk = blocks[bi];
   if (blk.count <= 0) return;  // device-built batches reserve blocks for the most requests a tracker can have
@@ -309,13 +318,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
   // (workgroup-uniform: the workgroup's requests share the current frame)
   const bool binned = tcur.f.bin_start != nullptr;
   if (kStage && !binned) {
-    for (int ci = threadIdx.x; ci < min(n_corners, kLdsCorners); ci += 64 * kWavesPerBlock) s_corners[ci] = pack_corner(corners_g[ci]);
+    for (int ci = threadIdx.x; ci < min(n_corners, kLdsCorners); ci += 64 * kW) s_corners[ci] = pack_corner(corners_g[ci]);
     __syncthreads();
   }
   const auto corner_at = [&](int ci) { return (kStage && !binned && ci < kLdsCorners) ? s_corners[ci] : pack_corner(corners_g[ci]); };
   if (wv >= blk.count) return;
   const int ri = blk.first + wv;
-  WaveLds &L = s_lds[wv];
+  WaveLds &L = s_lds[kW == 1 ? 0 : wv];
   const SearchReqDev &rq = reqs[ri];
   const SearchFramePose &tref = table[rq.ref];
   sdvl_search_res res;
@@ -848,7 +857,7 @@ int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_
   SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n_slots + 255) / 256), dim3(256), d_reqs, d_table, n_slots, c, *p, d_prep);
   // device-built batches search frames that came out of sdvl_detect_corners: binned (a frame without bins would still be
   // searched correctly, its corner list read from HBM)
-  SDVL_LAUNCH(ctx, "search_points", search_points_kernel<false>, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock), d_reqs,
+  SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<false, 1>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8 * kWavesPerBlock)), dim3(64), d_reqs,
               d_table, d_blocks, static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, d_res, h_res);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
@@ -1001,12 +1010,12 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   bool all_binned = true;
   for (const sdvl_frame *f : B.frames) all_binned = all_binned && f->bins_valid;
   if (all_binned) {
-    SDVL_LAUNCH(ctx, "search_points", search_points_kernel<false>, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
+    SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<false, 1>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8 * kWavesPerBlock)), dim3(64),
                 static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
                 static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
                 sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
   } else {
-    SDVL_LAUNCH(ctx, "search_points", search_points_kernel<true>, dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
+    SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<true, kWavesPerBlock>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
                 static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
                 static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
                 sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
