@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
   const int lane = threadIdx.x & 63;
   const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
   // wave-uniform grid-stride loop: the corner count may only be known on the device
-  for (int ci = bx * 4 + (threadIdx.x >> 6); ci < n; ci += chunks * 4) {
+  const int wpb = static_cast<int>(blockDim.x >> 6);  // waves per workgroup: one (round 3) — a wave per corner needs no company
+  for (int ci = bx * wpb + (threadIdx.x >> 6); ci < n; ci += chunks * wpb) {
   const int cx = job.corners[4 * ci], cy = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
   if (cl < 0 || cl >= job.levels) continue;
   const int W = job.lw[cl], H = job.lh[cl];
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restric
   const OrbJob &job = jobs[fj];
   const int lane = threadIdx.x & 63;
   const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
-  for (int ci = bx * 4 + (threadIdx.x >> 6); ci < n; ci += chunks * 4) {
+  const int wpb = static_cast<int>(blockDim.x >> 6);  // waves per workgroup: one (round 3) — a wave per corner needs no company
+  for (int ci = bx * wpb + (threadIdx.x >> 6); ci < n; ci += chunks * wpb) {
   const int px = job.corners[4 * ci], py = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
   if (cl < 0 || cl >= job.levels) continue;
   const int W = job.lw[cl], H = job.lh[cl];
@@ -286,7 +288,8 @@ __global__ __launch_bounds__(256) void filter_describe_kernel(const FilterJob *_
   const FilterJob &job = jobs[fj];
   const int lane = threadIdx.x & 63;
   const int total = min(job.out_count[0], max_out);
-  for (int k = bx * 4 + (threadIdx.x >> 6); k < total; k += chunks * 4) {
+  const int wpb = static_cast<int>(blockDim.x >> 6);
+  for (int k = bx * wpb + (threadIdx.x >> 6); k < total; k += chunks * wpb) {
     sdvl_filtered_corner *dst = job.out + k;
     const int cx = dst->x, cy = dst->y, cl = dst->level;
     const int W = job.lw[cl], H = job.lh[cl];
@@ -379,7 +382,7 @@ int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, 
   int max_n = 0;
   int rc = fill_jobs(ctx, n, frames, cap, d_desc, nullptr, &d_jobs, &max_n);
   if (rc) return rc;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, xcd_frame_grid(n, max_n), dim3(64), d_jobs, n, max_n);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
   for (int i = 0; i < n; i++) frames[i]->desc_valid = 1;
   if (out_desc) {
@@ -417,7 +420,7 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   rc = fill_jobs(ctx, n, frames, cap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   if (max_n == 0) return SDVL_OK;
-  SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
+  SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, max_n), dim3(64), d_jobs, n, max_n);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, sizeof(double) * cap, ctx->d_out, sizeof(double) * cap, sizeof(double) * max_n, n,
                                        hipMemcpyDeviceToHost, ctx->stream));
@@ -467,7 +470,7 @@ int sdvl_filter_inputs_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, in
   rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   max_n = max_n > ccap ? ccap : max_n;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, max_n), dim3(64), d_jobs, n, max_n);
   {
     const int units = (ccap + 1) + (desc ? 2 * ccap : 0);  // 16-byte units per row
     SDVL_LAUNCH(ctx, "filter_gather", filter_gather_kernel, dim3((units + 255) / 256, n), dim3(256), static_cast<const OrbJob *>(d_jobs),
@@ -545,7 +548,7 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   max_n = max_n > ccap ? ccap : max_n;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, (max_n + 3) / 4), dim3(256), d_jobs, n, (max_n + 3) / 4);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, max_n), dim3(64), d_jobs, n, max_n);
   const size_t jb = (sizeof(FilterJob) * n + 255) / 256 * 256, mb = sizeof(uint32_t) * static_cast<size_t>(n) * mask_words;
   void *hs = nullptr, *dsx = nullptr;
   rc = sdvl_stage_alloc(ctx, jb + mb, &hs, &dsx);
@@ -574,8 +577,8 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   else
     SDVL_LAUNCH(ctx, "filter_select", filter_select_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells, margin,
                 min_feature_score, max_out);
-  SDVL_LAUNCH(ctx, "filter_describe", filter_describe_kernel, xcd_frame_grid(n, (std::min(max_out, 512) + 3) / 4), dim3(256), static_cast<const FilterJob *>(dsx),
-              max_out, n, (std::min(max_out, 512) + 3) / 4);
+  SDVL_LAUNCH(ctx, "filter_describe", filter_describe_kernel, xcd_frame_grid(n, std::min(max_out, 512)), dim3(64), static_cast<const FilterJob *>(dsx),
+              max_out, n, std::min(max_out, 512));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, d8 + sc_bytes, cnt_bytes + rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_FILTER, &ctx->filter_ticket));
@@ -666,7 +669,7 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   hj->n = n;
   hj->levels = f->v.levels;
   SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, job_off + sizeof(OrbJob)));
-  SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, xcd_frame_grid(1, (n + 3) / 4), dim3(256), reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(dsx) + job_off), 1, (n + 3) / 4);
+  SDVL_LAUNCH(ctx, "orb_describe", orb_describe_kernel, xcd_frame_grid(1, n), dim3(64), reinterpret_cast<const OrbJob *>(static_cast<uint8_t *>(dsx) + job_off), 1, n);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, a_off + a_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
