@@ -172,9 +172,9 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
 
 // Phase 0 of SearchPoint is scalar work per request (relative pose, depth-interval projection, margin test, affine warp,
 // search level): one LANE per request here instead of a whole wave repeating it 64 times in search_points_kernel.
-__global__ __launch_bounds__(256) void search_prepare_kernel(const SearchReqDev *__restrict__ reqs, const SearchFramePose *__restrict__ table,
+__global__ __launch_bounds__(64) void search_prepare_kernel(const SearchReqDev *__restrict__ reqs, const SearchFramePose *__restrict__ table,
                                                              int n, Cam cam, sdvl_search_params prm, SearchPrep *__restrict__ prep) {
-  const int ri = blockIdx.x * 256 + threadIdx.x;
+  const int ri = blockIdx.x * 64 + threadIdx.x;  // one-wave workgroups: placed as soon as ONE wave slot is free (see search_points_kernel)
   if (ri >= n) return;
   const SearchReqDev &rq = reqs[ri];
   SearchPrep out;
@@ -854,7 +854,7 @@ int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_
   SDVL_REQUIRE(ctx, p->max_align_its >= 0 && p->margin >= 4, "bad max_align_its / margin");
   if (n_slots <= 0 || n_blocks <= 0) return SDVL_OK;
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n_slots + 255) / 256), dim3(256), d_reqs, d_table, n_slots, c, *p, d_prep);
+  SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n_slots + 63) / 64), dim3(64), d_reqs, d_table, n_slots, c, *p, d_prep);
   // device-built batches search frames that came out of sdvl_detect_corners: binned (a frame without bins would still be
   // searched correctly, its corner list read from HBM)
   SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<false, 1>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8 * kWavesPerBlock)), dim3(64), d_reqs,
@@ -1005,7 +1005,7 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   // d_out: results | per-request records of the scalar phase
   SearchPrep *d_prep = reinterpret_cast<SearchPrep *>(static_cast<uint8_t *>(ctx->d_out) + out_dev_bytes);
-  SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n + 255) / 256), dim3(256), static_cast<const SearchReqDev *>(dsx), d_table, n, c,
+  SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n + 63) / 64), dim3(64), static_cast<const SearchReqDev *>(dsx), d_table, n, c,
               *p, d_prep);
   bool all_binned = true;
   for (const sdvl_frame *f : B.frames) all_binned = all_binned && f->bins_valid;
