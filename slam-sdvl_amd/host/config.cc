@@ -20,37 +20,37 @@ bool Config::SetParameter(const std::string &key, double v) {
   else if (key == "Camera.d3") c.d3 = v;
   else if (key == "Camera.d4") c.d4 = v;
   else if (key == "Camera.d5") c.d5 = v;
-  else if (key == "SDVL.pyramid_levels") kPyramidLevels_ = static_cast<int>(v);
-  else if (key == "SDVL.cell_size") kCellSize_ = static_cast<int>(v);
-  else if (key == "SDVL.min_avg_shift") kMinAvgShift_ = static_cast<int>(v);
-  else if (key == "SDVL.max_matches") kMaxMatches_ = static_cast<int>(v);
-  else if (key == "SDVL.min_matches") kMinMatches_ = static_cast<int>(v);
-  else if (key == "SDVL.max_keyframes") kMaxKeyframes_ = static_cast<int>(v);
-  else if (key == "SDVL.min_keyframe_its") kMinKeyframeIts_ = static_cast<int>(v);
-  else if (key == "SDVL.max_failed") kMaxFailed_ = static_cast<int>(v);
-  else if (key == "SDVL.max_search_keyframes") kMaxSearchKeyframes_ = static_cast<int>(v);
-  else if (key == "SDVL.max_optim_pose_its") kMaxOptimPoseIts_ = static_cast<int>(v);
-  else if (key == "SDVL.max_ransac_points") kMaxRansacPoints_ = static_cast<int>(v);
-  else if (key == "SDVL.max_ransac_its") kMaxRansacIts_ = static_cast<int>(v);
-  else if (key == "SDVL.threshold_converged") kThresholdConverged_ = v;
-  else if (key == "SDVL.min_init_corners") kMinInitCorners_ = static_cast<int>(v);
-  else if (key == "SDVL.inlier_error_threshold") kInlierErrorThreshold_ = v;
-  else if (key == "SDVL.map_scale") kMapScale_ = v;
-  else if (key == "SDVL.max_alignLevel") kMaxAlignLevel_ = static_cast<int>(v);
-  else if (key == "SDVL.min_alignLevel") kMinAlignLevel_ = static_cast<int>(v);
-  else if (key == "SDVL.max_img_align_its") kMaxImgAlignIts_ = static_cast<int>(v);
-  else if (key == "SDVL.align_patch_size") kAlignPatchSize_ = static_cast<int>(v);
-  else if (key == "SDVL.scale_min_dist") kScaleMinDist_ = v;
-  else if (key == "SDVL.lost_ratio") kLostRatio_ = v;
-  else if (key == "SDVL.patch_size") kPatchSize_ = static_cast<int>(v);
-  else if (key == "SDVL.max_align_its") kMaxAlignIts_ = static_cast<int>(v);
-  else if (key == "SDVL.search_size") kSearchSize_ = static_cast<int>(v);
-  else if (key == "SDVL.use_orb") kUseORB_ = (v != 0.0);
-  else if (key == "SDVL.orb_size") kORBSize_ = static_cast<int>(v);
-  else if (key == "SDVL.max_fast_levels") kMaxFastLevels_ = static_cast<int>(v);
-  else if (key == "SDVL.fast_threshold") kFastThreshold_ = static_cast<int>(v);
-  else if (key == "SDVL.min_feature_score") kMinFeatureScore_ = static_cast<int>(v);
-  else if (key == "SDVL.num_features") kNumFeatures_ = static_cast<int>(v);
+  else if (key == "SDVL.pyramid_levels") v_.pyramid_levels = static_cast<int>(v);
+  else if (key == "SDVL.cell_size") v_.cell_size = static_cast<int>(v);
+  else if (key == "SDVL.min_avg_shift") v_.min_avg_shift = static_cast<int>(v);
+  else if (key == "SDVL.max_matches") v_.max_matches = static_cast<int>(v);
+  else if (key == "SDVL.min_matches") v_.min_matches = static_cast<int>(v);
+  else if (key == "SDVL.max_keyframes") v_.max_keyframes = static_cast<int>(v);
+  else if (key == "SDVL.min_keyframe_its") v_.min_keyframe_its = static_cast<int>(v);
+  else if (key == "SDVL.max_failed") v_.max_failed = static_cast<int>(v);
+  else if (key == "SDVL.max_search_keyframes") v_.max_search_keyframes = static_cast<int>(v);
+  else if (key == "SDVL.max_optim_pose_its") v_.max_optim_pose_its = static_cast<int>(v);
+  else if (key == "SDVL.max_ransac_points") v_.max_ransac_points = static_cast<int>(v);
+  else if (key == "SDVL.max_ransac_its") v_.max_ransac_its = static_cast<int>(v);
+  else if (key == "SDVL.threshold_converged") v_.threshold_converged = v;
+  else if (key == "SDVL.min_init_corners") v_.min_init_corners = static_cast<int>(v);
+  else if (key == "SDVL.inlier_error_threshold") v_.inlier_error_threshold = v;
+  else if (key == "SDVL.map_scale") v_.map_scale = v;
+  else if (key == "SDVL.max_alignLevel") v_.max_align_level = static_cast<int>(v);
+  else if (key == "SDVL.min_alignLevel") v_.min_align_level = static_cast<int>(v);
+  else if (key == "SDVL.max_img_align_its") v_.max_img_align_its = static_cast<int>(v);
+  else if (key == "SDVL.align_patch_size") v_.align_patch_size = static_cast<int>(v);
+  else if (key == "SDVL.scale_min_dist") v_.scale_min_dist = v;
+  else if (key == "SDVL.lost_ratio") v_.lost_ratio = v;
+  else if (key == "SDVL.patch_size") v_.patch_size = static_cast<int>(v);
+  else if (key == "SDVL.max_align_its") v_.max_align_its = static_cast<int>(v);
+  else if (key == "SDVL.search_size") v_.search_size = static_cast<int>(v);
+  else if (key == "SDVL.use_orb") v_.use_orb = (v != 0.0);
+  else if (key == "SDVL.orb_size") v_.orb_size = static_cast<int>(v);
+  else if (key == "SDVL.max_fast_levels") v_.max_fast_levels = static_cast<int>(v);
+  else if (key == "SDVL.fast_threshold") v_.fast_threshold = static_cast<int>(v);
+  else if (key == "SDVL.min_feature_score") v_.min_feature_score = static_cast<int>(v);
+  else if (key == "SDVL.num_features") v_.num_features = static_cast<int>(v);
   else return false;
   return true;
 }

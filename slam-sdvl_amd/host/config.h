@@ -25,49 +25,52 @@ class Config {
   void Reset() { *this = Config(); }
 
   static CameraParameters &GetCameraParameters() { return GetInstance().camera_params_; }
-  static int PyramidLevels() { return GetInstance().kPyramidLevels_; }
-  static int CellSize() { return GetInstance().kCellSize_; }
-  static int MinAvgShift() { return GetInstance().kMinAvgShift_; }
-  static int MaxMatches() { return GetInstance().kMaxMatches_; }
-  static int MinMatches() { return GetInstance().kMinMatches_; }
-  static int MaxKeyframes() { return GetInstance().kMaxKeyframes_; }
-  static int MinKeyframeIts() { return GetInstance().kMinKeyframeIts_; }
-  static int MaxFailed() { return GetInstance().kMaxFailed_; }
-  static int MaxSearchKeyframes() { return GetInstance().kMaxSearchKeyframes_; }
-  static int MaxOptimPoseIts() { return GetInstance().kMaxOptimPoseIts_; }
-  static int MaxRansacPoints() { return GetInstance().kMaxRansacPoints_; }
-  static int MaxRansacIts() { return GetInstance().kMaxRansacIts_; }
-  static double ThresholdConverged() { return GetInstance().kThresholdConverged_; }
-  static int MinInitCorners() { return GetInstance().kMinInitCorners_; }
-  static double InlierErrorThreshold() { return GetInstance().kInlierErrorThreshold_; }
-  static double MapScale() { return GetInstance().kMapScale_; }
-  static int MaxAlignLevel() { return GetInstance().kMaxAlignLevel_; }
-  static int MinAlignLevel() { return GetInstance().kMinAlignLevel_; }
-  static int MaxImgAlignIts() { return GetInstance().kMaxImgAlignIts_; }
-  static int AlignPatchSize() { return GetInstance().kAlignPatchSize_; }
-  static double ScaleMinDist() { return GetInstance().kScaleMinDist_; }
-  static double LostRatio() { return GetInstance().kLostRatio_; }
-  static int PatchSize() { return GetInstance().kPatchSize_; }
-  static int MaxAlignIts() { return GetInstance().kMaxAlignIts_; }
-  static int SearchSize() { return GetInstance().kSearchSize_; }
-  static bool UseORB() { return GetInstance().kUseORB_; }
-  static int ORBSize() { return GetInstance().kORBSize_; }
-  static int MaxFastLevels() { return GetInstance().kMaxFastLevels_; }
-  static int FastThreshold() { return GetInstance().kFastThreshold_; }
-  static int MinFeatureScore() { return GetInstance().kMinFeatureScore_; }
-  static int NumFeatures() { return GetInstance().kNumFeatures_; }
+  static int PyramidLevels() { return GetInstance().v_.pyramid_levels; }
+  static int CellSize() { return GetInstance().v_.cell_size; }
+  static int MinAvgShift() { return GetInstance().v_.min_avg_shift; }
+  static int MaxMatches() { return GetInstance().v_.max_matches; }
+  static int MinMatches() { return GetInstance().v_.min_matches; }
+  static int MaxKeyframes() { return GetInstance().v_.max_keyframes; }
+  static int MinKeyframeIts() { return GetInstance().v_.min_keyframe_its; }
+  static int MaxFailed() { return GetInstance().v_.max_failed; }
+  static int MaxSearchKeyframes() { return GetInstance().v_.max_search_keyframes; }
+  static int MaxOptimPoseIts() { return GetInstance().v_.max_optim_pose_its; }
+  static int MaxRansacPoints() { return GetInstance().v_.max_ransac_points; }
+  static int MaxRansacIts() { return GetInstance().v_.max_ransac_its; }
+  static double ThresholdConverged() { return GetInstance().v_.threshold_converged; }
+  static int MinInitCorners() { return GetInstance().v_.min_init_corners; }
+  static double InlierErrorThreshold() { return GetInstance().v_.inlier_error_threshold; }
+  static double MapScale() { return GetInstance().v_.map_scale; }
+  static int MaxAlignLevel() { return GetInstance().v_.max_align_level; }
+  static int MinAlignLevel() { return GetInstance().v_.min_align_level; }
+  static int MaxImgAlignIts() { return GetInstance().v_.max_img_align_its; }
+  static int AlignPatchSize() { return GetInstance().v_.align_patch_size; }
+  static double ScaleMinDist() { return GetInstance().v_.scale_min_dist; }
+  static double LostRatio() { return GetInstance().v_.lost_ratio; }
+  static int PatchSize() { return GetInstance().v_.patch_size; }
+  static int MaxAlignIts() { return GetInstance().v_.max_align_its; }
+  static int SearchSize() { return GetInstance().v_.search_size; }
+  static bool UseORB() { return GetInstance().v_.use_orb; }
+  static int ORBSize() { return GetInstance().v_.orb_size; }
+  static int MaxFastLevels() { return GetInstance().v_.max_fast_levels; }
+  static int FastThreshold() { return GetInstance().v_.fast_threshold; }
+  static int MinFeatureScore() { return GetInstance().v_.min_feature_score; }
+  static int NumFeatures() { return GetInstance().v_.num_features; }
 
  private:
   Config() {}
   CameraParameters camera_params_;
-  // defaults: config.cc:55-85
-  int kPyramidLevels_ = 5, kCellSize_ = 32, kMinAvgShift_ = 50, kMaxMatches_ = 150, kMinMatches_ = 20, kMaxKeyframes_ = 100,
-      kMinKeyframeIts_ = 30, kMaxFailed_ = 15, kMaxSearchKeyframes_ = 5, kMaxOptimPoseIts_ = 10, kMaxRansacPoints_ = 5,
-      kMaxRansacIts_ = 100, kMinInitCorners_ = 50, kMaxAlignLevel_ = 4, kMinAlignLevel_ = 2, kMaxImgAlignIts_ = 30,
-      kAlignPatchSize_ = 4, kPatchSize_ = 8, kMaxAlignIts_ = 10, kSearchSize_ = 6, kORBSize_ = 31, kMaxFastLevels_ = 3,
-      kFastThreshold_ = 10, kMinFeatureScore_ = 50, kNumFeatures_ = 1000;
-  double kThresholdConverged_ = 0.1, kInlierErrorThreshold_ = 2.0, kMapScale_ = 1.0, kScaleMinDist_ = 0.25, kLostRatio_ = 0.7;
-  bool kUseORB_ = false;
+  // the tunables and their defaults (config.cc:55-85), one record: Reset() and the key table of config.cc address it as a whole
+  struct Values {
+    int pyramid_levels = 5, cell_size = 32, min_avg_shift = 50, max_matches = 150, min_matches = 20, max_keyframes = 100,
+        min_keyframe_its = 30, max_failed = 15, max_search_keyframes = 5, max_optim_pose_its = 10, max_ransac_points = 5,
+        max_ransac_its = 100, min_init_corners = 50, max_align_level = 4, min_align_level = 2, max_img_align_its = 30,
+        align_patch_size = 4, patch_size = 8, max_align_its = 10, search_size = 6, orb_size = 31, max_fast_levels = 3,
+        fast_threshold = 10, min_feature_score = 50, num_features = 1000;
+    double threshold_converged = 0.1, inlier_error_threshold = 2.0, map_scale = 1.0, scale_min_dist = 0.25, lost_ratio = 0.7;
+    bool use_orb = false;
+  };
+  Values v_;
 };
 
 }  // namespace sdvl
