@@ -660,10 +660,15 @@ def main():
             for c in ctxs:
                 c.timing(not os.environ.get("SDVL_BENCH_NO_KERNEL_TIMING"))
             barrier()
+            thr_h0, ru_h0 = throttled(), resource.getrusage(resource.RUSAGE_SELF)
             t0 = time.perf_counter()
             hstats = farm.run(hptrs, workers, hstats_buf)
             barrier()
             elapsed_h = time.perf_counter() - t0
+            thr_h1, ru_h1 = throttled(), resource.getrusage(resource.RUSAGE_SELF)
+            host_cpu_h = {"cpus_busy": round(((ru_h1.ru_utime - ru_h0.ru_utime) + (ru_h1.ru_stime - ru_h0.ru_stime)) / elapsed_h, 2),
+                          "system_share": round((ru_h1.ru_stime - ru_h0.ru_stime) / max(1e-9, (ru_h1.ru_utime - ru_h0.ru_utime) + (ru_h1.ru_stime - ru_h0.ru_stime)), 3),
+                          "usable": ncpu, "quota_throttled_ms": round((thr_h1[1] - thr_h0[1]) / 1e3, 1), "minor_faults": ru_h1.ru_minflt - ru_h0.ru_minflt}
             farm.set_host_input(False)
             h_timers = {}
             for c in ctxs:
@@ -672,16 +677,21 @@ def main():
                     h_timers[name] = (a[0] + ms, a[1] + n_l)
                 c.timing(False)
             h_stage_s, h_stage_n = farm.stage_times()
-            feed_call_s, feed_wait_s, feed_calls = farm.feed_stats()
+            feed_call_s, feed_wait_s, feed_calls, work_wait_s, late_acq, feed_thr_s = farm.feed_stats()
             tracked_h = sum(int(st.quality != 2) for st in hstats)
             th_all, eh_max = shard.reduce_throughput(tracked_h, elapsed_h, dist if distributed else None, "cuda")
             host_fed = {"value": round(th_all / eh_max, 2), "unit": "frames/s", "steps": Kh, "ms_per_step": round(eh_max / Kh * 1e3, 3),
                         "pcie_h2d_gb_per_s": round(world * B * Kh * frame_bytes / eh_max / 1e9, 2),
-                        "feeder": {"transfers": feed_calls, "s_in_transfer_calls": round(feed_call_s, 4), "s_waiting_for_a_free_slot": round(feed_wait_s, 4), "wall_s": round(elapsed_h, 4)},
+                        "host_cpu": host_cpu_h,
+                        "feeder": {"transfers": feed_calls, "s_in_transfer_calls": round(feed_call_s, 4), "s_waiting_for_a_free_slot": round(feed_wait_s, 4),
+                                   "s_waiting_for_its_own_transfers": round(feed_thr_s, 4), "wall_s": round(elapsed_h, 4),
+                                   "group_steps_begun_before_their_images_arrived": late_acq, "group_steps": feed_calls,
+                                   "worker_s_waiting_for_images_sum_over_groups": round(work_wait_s, 4)},
                         "kernel_ms_per_step": {k: round(v[0] / Kh, 4) for k, v in sorted(h_timers.items())},
                         "host_stage_ms_per_group_step": {k: round(v / max(1, h_stage_n) * 1e3, 3) for k, v in h_stage_s.items() if v > 0},
-                        "input": "pinned host memory, %d B per frame; the images of step s + 1 travel on the group's copy stream into a "
-                                 "2-step input ring in HBM while step s computes (SDVL_BENCH_NO_INPUT_RING=1: uploaded inside the step)" % frame_bytes}
+                        "input": "pinned host memory, %d B per frame; ONE feeder thread sends the images of the next steps (a ring of three steps per group in HBM, "
+                                 "at most two transfers queued on the device) on a copy stream of its own priority class; a group submits a step once its images "
+                                 "have arrived (SDVL_BENCH_NO_INPUT_RING=1: uploaded inside the step)" % frame_bytes}
     # ---- third leg, SUSTAINED: S-A is 300 frames per sequence (main.cc:126-159 loops over the whole sequence).  The
     # first leg keeps every input frame resident (B x frames x 307 KB) and so measures a burst of a few dozen frames; here FRESH
     # trackers run whole sequences.  What stays resident is what the path itself retains: every keyframe keeps its HBM frame
@@ -831,6 +841,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: round(v[0] / K, 4) for k, v in sorted(timers.items())},
             "host_stage_ms_per_group_step": {k: round(v / max(1, stage_n) * 1e3, 3) for k, v in stage_s.items()},
+            "host_cpu": {"cpus_busy": round(cpu_s / elapsed, 2), "usable": ncpu, "quota_throttled_ms": round((thr1[1] - thr0[1]) / 1e3, 1),
+                         "minor_faults": flt1 - flt0},
             "speedup_vs_cpu_1core": round(value / cpu["one_core"], 2) if cpu else None,
             "speedup_vs_cpu_all_cores": round(value / cpu["value"], 2) if cpu else None,
         }

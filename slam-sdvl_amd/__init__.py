@@ -125,11 +125,11 @@ ABI_SYMBOLS = [
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
     "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
     "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
-    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_filter_inputs_begin", "sdvl_filter_inputs_end", "sdvl_filter_corners_begin", "sdvl_filter_corners_end", "sdvl_orb_describe_points", "sdvl_image_align", "sdvl_image_align_begin", "sdvl_image_align_end", "sdvl_search_points", "sdvl_search_begin", "sdvl_search_slot", "sdvl_search_run", "sdvl_align_patches", "sdvl_pose_from_matches", "sdvl_search_points_filter", "sdvl_search_run_filter", "sdvl_search_run_chain", "sdvl_search_chain_end", "sdvl_frame_footprint", "sdvl_undistort", "sdvl_frames_upload_undistorted", "sdvl_ctx_set_wait_hook", "sdvl_ctx_wait_done", "sdvl_ctx_wait_block", "sdvl_ctx_health",
+    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_filter_inputs_begin", "sdvl_filter_inputs_end", "sdvl_filter_corners_begin", "sdvl_filter_corners_end", "sdvl_orb_describe_points", "sdvl_hamming_argmin", "sdvl_image_align", "sdvl_image_align_begin", "sdvl_image_align_end", "sdvl_search_points", "sdvl_search_begin", "sdvl_search_slot", "sdvl_search_run", "sdvl_align_patches", "sdvl_pose_from_matches", "sdvl_search_points_filter", "sdvl_search_run_filter", "sdvl_search_run_chain", "sdvl_search_chain_end", "sdvl_frame_footprint", "sdvl_undistort", "sdvl_frames_upload_undistorted", "sdvl_ctx_set_wait_hook", "sdvl_ctx_wait_done", "sdvl_ctx_wait_block", "sdvl_ctx_health",
     "sdvl_track_create", "sdvl_track_destroy", "sdvl_frame_register", "sdvl_frames_register", "sdvl_track_upload", "sdvl_track_align", "sdvl_track_search",
     "sdvl_track_collect", "sdvl_track_features", "sdvl_track_stats",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
-    "sdvl_frames_own_images", "sdvl_feed_create", "sdvl_feed_destroy", "sdvl_feed_last_error", "sdvl_feed_images", "sdvl_ctx_feed_acquire", "sdvl_ctx_feed_release", "sdvl_frame_footprint_cap", "sdvl_ctx_set_corner_capacity", "sdvl_frame_corner_capacity", "sdvl_detect_scratch_bytes",
+    "sdvl_frames_own_images", "sdvl_feed_create", "sdvl_feed_destroy", "sdvl_feed_last_error", "sdvl_feed_slot_arrived", "sdvl_feed_images", "sdvl_ctx_feed_acquire", "sdvl_ctx_feed_release", "sdvl_frame_footprint_cap", "sdvl_ctx_set_corner_capacity", "sdvl_frame_corner_capacity", "sdvl_detect_scratch_bytes",
 ]
 
 _lib = None
@@ -401,6 +401,24 @@ class Context:
         ang = np.zeros(len(xyl), np.float32)
         self._check(self.lib.sdvl_orb_describe_points(self.h, frame.h, len(xyl), _ptr(xyl, i32p), _ptr(desc, u8p), _ptr(ang, f32p)))
         return desc, ang
+
+    def hamming_argmin(self, queries, cand_lists, threshold=100):
+        """ORBDetector::Distance over per-query candidate lists + SearchFeatures' arg-min (orb_detector.cc:398-410,
+        matcher.cc:254-289).  queries [n][32] u8; cand_lists: n arrays [k_i][32] u8.  -> (best_index[n], best_dist[n])"""
+        q = np.ascontiguousarray(queries, np.uint8).reshape(-1, 32)
+        n = len(q)
+        offs = np.zeros(n + 1, np.int32)
+        offs[1:] = np.cumsum([len(c) for c in cand_lists])
+        cands = (np.ascontiguousarray(np.concatenate([np.asarray(c, np.uint8).reshape(-1, 32) for c in cand_lists]))
+                 if n else np.zeros((0, 32), np.uint8))
+        if len(cands) == 0:
+            cands = np.zeros((1, 32), np.uint8)
+        bi = np.zeros(n, np.int32)
+        bd = np.zeros(n, np.int32)
+        self.lib.sdvl_hamming_argmin.argtypes = [C.c_void_p, C.c_int, u8p, i32p, u8p, C.c_int, i32p, i32p]
+        self._check(self.lib.sdvl_hamming_argmin(self.h, n, _ptr(q, u8p), _ptr(offs, i32p), _ptr(cands, u8p), int(threshold),
+                                                 _ptr(bi, i32p), _ptr(bd, i32p)))
+        return bi, bd
 
     def image_align(self, jobs, feats, cam, ap):
         """jobs: list of (ref Frame, cur Frame, feat_begin, feat_end, T7); feats: AlignFeature array"""

@@ -744,7 +744,16 @@ int sdvl_feed_create(int device, int n_slots, sdvl_feed **out) {
   if (hipSetDevice(device) != hipSuccess) return SDVL_ERR_NO_DEVICE;
   sdvl_feed *f = new sdvl_feed();
   f->device = device;
-  bool ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
+  // A stream of another priority class gets a hardware queue of its own: the markers that follow every transfer (hipEventRecord
+  // behind an SDMA copy is a barrier packet that waits for the copy's signal) would otherwise sit in a queue shared with compute
+  // streams and stall them for the duration of every transfer.  SDVL_FEED_NORMAL_PRIORITY=1: a stream like any other (A/B).
+  bool ok;
+  if (getenv("SDVL_FEED_NORMAL_PRIORITY")) {
+    ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
+  } else {
+    int lo = 0, hi = 0;
+    ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi) == hipSuccess;
+  }
   f->ready.assign(n_slots, nullptr);
   f->released.assign(n_slots, nullptr);
   for (int i = 0; i < n_slots && ok; i++)
@@ -801,6 +810,15 @@ int sdvl_feed_images(sdvl_feed *f, int slot, int n, const uint8_t *const *imgs, 
   }
   SDVL_FEED_CHECK(f, hipEventRecord(f->ready[slot], f->stream));
   return SDVL_OK;
+}
+
+int sdvl_feed_slot_arrived(sdvl_feed *f, int slot) {
+  if (!f || slot < 0 || slot >= static_cast<int>(f->ready.size())) return SDVL_ERR_INVALID;
+  const hipError_t e = hipEventQuery(f->ready[slot]);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  f->err = std::string("hipEventQuery: ") + hipGetErrorString(e);
+  return SDVL_ERR_HIP;
 }
 
 int sdvl_ctx_feed_acquire(sdvl_ctx *ctx, sdvl_feed *f, int slot) {

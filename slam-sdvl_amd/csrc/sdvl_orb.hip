@@ -353,6 +353,46 @@ int fill_jobs(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t 
 
 }  // namespace
 
+// ORBDetector::Distance (extra/orb_detector.cc:398-410) over candidate lists + the arg-min of Matcher::SearchFeatures
+// (matcher.cc:254-289: best starts at threshold+1, strict '<' so the first smallest wins, ">= threshold" -> not found).
+// One wave per query; lanes stride the query's candidates, 32 B per candidate as two 16 B loads.
+struct HammingJob {
+  const uint8_t *queries;     // [n][32]
+  const int32_t *offsets;     // [n+1]
+  const uint8_t *cands;       // [offsets[n]][32]
+  int32_t *best;              // [n][2]: index within the query's list (or -1), distance (or threshold+1)
+  int n, threshold;
+};
+
+__global__ __launch_bounds__(64) void hamming_argmin_kernel(const HammingJob *jobp) {
+  const HammingJob &job = *jobp;
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= job.n) return;
+  const uint4 *qp = reinterpret_cast<const uint4 *>(job.queries + 32 * static_cast<size_t>(q));
+  const uint4 q0 = qp[0], q1 = qp[1];
+  const int begin = job.offsets[q], end = job.offsets[q + 1];
+  // key = distance << 32 | position: the smallest key is the first smallest distance
+  unsigned long long key = (static_cast<unsigned long long>(job.threshold + 1) << 32) | 0xffffffffull;
+  for (int c = begin + lane; c < end; c += 64) {
+    const uint4 *cp = reinterpret_cast<const uint4 *>(job.cands + 32 * static_cast<size_t>(c));
+    const uint4 a = cp[0], b = cp[1];
+    const int d = __popc(a.x ^ q0.x) + __popc(a.y ^ q0.y) + __popc(a.z ^ q0.z) + __popc(a.w ^ q0.w) + __popc(b.x ^ q1.x) +
+                  __popc(b.y ^ q1.y) + __popc(b.z ^ q1.z) + __popc(b.w ^ q1.w);
+    const unsigned long long k = (static_cast<unsigned long long>(d) << 32) | static_cast<unsigned>(c - begin);
+    key = k < key ? k : key;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off, 64);
+    key = o < key ? o : key;
+  }
+  if (lane == 0) {
+    const int d = static_cast<int>(key >> 32);
+    const bool found = d < job.threshold;
+    job.best[2 * q] = found ? static_cast<int>(key & 0xffffffffull) : -1;
+    job.best[2 * q + 1] = d;
+  }
+}
+
 extern "C" {
 
 int sdvl_orb_describe(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, uint8_t *out_desc) {
@@ -675,6 +715,48 @@ int sdvl_orb_describe_points(sdvl_ctx *ctx, const sdvl_frame *f, int n, const in
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(out_desc, ctx->h_out, d_bytes);
   if (out_angle_deg) memcpy(out_angle_deg, static_cast<uint8_t *>(ctx->h_out) + a_off, a_bytes);
+  return SDVL_OK;
+}
+
+int sdvl_hamming_argmin(sdvl_ctx *ctx, int n, const uint8_t *queries, const int32_t *cand_offsets, const uint8_t *cand_desc,
+                        int threshold, int32_t *best_index, int32_t *best_dist) {
+  if (!ctx || n < 0 || (n > 0 && (!queries || !cand_offsets || !best_index))) return SDVL_ERR_INVALID;
+  if (n == 0) return SDVL_OK;
+  SDVL_REQUIRE(ctx, cand_offsets[0] == 0, "cand_offsets[0] must be 0");
+  for (int i = 0; i < n; i++) SDVL_REQUIRE(ctx, cand_offsets[i + 1] >= cand_offsets[i], "cand_offsets must not decrease");
+  const int total = cand_offsets[n];
+  SDVL_REQUIRE(ctx, total == 0 || cand_desc, "candidate descriptors missing");
+  SDVL_REQUIRE(ctx, threshold >= 0 && threshold <= 256, "threshold outside [0, 256]");
+  // staged: queries[n][32] | offsets[n+1] | cands[total][32] | HammingJob ; d_out = best[n][2]
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t q_bytes = 32 * static_cast<size_t>(n), o_off = up(q_bytes), c_off = o_off + up(sizeof(int32_t) * (n + 1)),
+               j_off = c_off + up(32 * static_cast<size_t>(total)), r_bytes = sizeof(int32_t) * 2 * n;
+  void *hs = nullptr, *dsx = nullptr;
+  int rc = sdvl_ensure(ctx, &ctx->d_out, &ctx->d_out_bytes, r_bytes, false);
+  if (!rc) rc = sdvl_ensure(ctx, &ctx->h_out, &ctx->h_out_bytes, r_bytes, true);
+  if (!rc) rc = sdvl_stage_alloc(ctx, j_off + sizeof(HammingJob), &hs, &dsx);
+  if (rc) return rc;
+  uint8_t *h = static_cast<uint8_t *>(hs), *d = static_cast<uint8_t *>(dsx);
+  memcpy(h, queries, q_bytes);
+  memcpy(h + o_off, cand_offsets, sizeof(int32_t) * (n + 1));
+  if (total) memcpy(h + c_off, cand_desc, 32 * static_cast<size_t>(total));
+  HammingJob *hj = reinterpret_cast<HammingJob *>(h + j_off);
+  hj->queries = d;
+  hj->offsets = reinterpret_cast<const int32_t *>(d + o_off);
+  hj->cands = d + c_off;
+  hj->best = static_cast<int32_t *>(ctx->d_out);
+  hj->n = n;
+  hj->threshold = threshold;
+  SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, j_off + sizeof(HammingJob)));
+  SDVL_LAUNCH(ctx, "hamming_argmin", hamming_argmin_kernel, dim3(n), dim3(64), reinterpret_cast<const HammingJob *>(d + j_off));
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, r_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  const int32_t *r = static_cast<const int32_t *>(ctx->h_out);
+  for (int i = 0; i < n; i++) {
+    best_index[i] = r[2 * i];
+    if (best_dist) best_dist[i] = r[2 * i + 1];
+  }
   return SDVL_OK;
 }
 

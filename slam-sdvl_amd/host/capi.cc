@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <set>
 #include <atomic>
@@ -280,6 +281,19 @@ struct Farm {
   int kRingSlots = 3;
   sdvl_feed *feed = nullptr;
   double feed_call_s = 0.0, feed_wait_s = 0.0;  // the feeder's time inside sdvl_feed_images / waiting for a free slot, last run
+  double work_wait_s = 0.0;                     // the workers' time waiting for their step's transfer to be issued (under m)
+  double arrive_wait_s = 0.0;                   // ... and for it to arrive (host-side polls, summed over groups)
+  double feed_throttle_s = 0.0;                 // the feeder's time waiting for its own earlier transfers (at most 2 queued)
+  long late_acquires = 0;                       // group-steps that began while their transfer was still under way
+  // SDVL_FARM_TIMELINE=<file>: one line per group-step (group, step, enter, transfer issued, step returned, late) and per transfer
+  // (group, step, call begin, call end) of a host-fed run, seconds since the run began
+  struct StepMark { int g, s; double t_enter, t_issued, t_end; int late; double st[12]; int kf; };
+  struct FeedMark { int g, s; double t0, t1; };
+  std::vector<std::vector<StepMark>> step_marks;  // [group]
+  std::vector<FeedMark> feed_marks;
+  std::vector<std::vector<double>> mark_prev;
+  std::chrono::steady_clock::time_point run_t0;
+  double Since() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - run_t0).count(); }
   long feed_calls = 0;
   std::vector<int> issued;          // [group] steps whose images the feeder has queued
   std::condition_variable cv_feed;  // feeder <-> workers (under m)
@@ -312,10 +326,38 @@ struct Farm {
       sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(devices[g]));
       {
         std::unique_lock<std::mutex> lk(m);
+        const auto tw = std::chrono::steady_clock::now();
         cv_feed.wait(lk, [&] { return issued[g] > s || failed; });
+        work_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
         if (failed) return -1;
       }
+      const double t_issued = Since();
       const int slot = g * kRingSlots + s % kRingSlots;
+      const bool late = sdvl_feed_slot_arrived(feed, slot) == 0;  // statistics only: this step starts behind a transfer still under way
+      if (late) {
+        std::lock_guard<std::mutex> lk(m);
+        late_acquires++;
+      }
+      // The step is submitted only once its images are in HBM: a stream that waits for a transfer ON THE DEVICE holds a barrier
+      // packet in its hardware queue, and the streams that share the queue (4 queues for 16 groups) stall behind it although their
+      // own images arrived long ago.  SDVL_RING_DEVICE_WAIT=1: round 3's first form (hipStreamWaitEvent only).
+      static const bool device_wait = getenv("SDVL_RING_DEVICE_WAIT") != nullptr;
+      if (late && !device_wait) {
+        const auto tw = std::chrono::steady_clock::now();
+        for (;;) {
+          const int a = sdvl_feed_slot_arrived(feed, slot);
+          if (a != 0) {
+            if (a < 0) { g_err = std::string("input ring: ") + sdvl_feed_last_error(feed); return -1; }
+            break;
+          }
+          timespec ts{0, 50000};
+          nanosleep(&ts, nullptr);
+        }
+        const double dw = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+        std::lock_guard<std::mutex> lk(m);
+        arrive_wait_s += dw;
+      }
+      const double t_enter = Since();
       if (sdvl_ctx_feed_acquire(ctx, feed, slot) != SDVL_OK) {  // this step's kernels start behind its images
         g_err = std::string("input ring: ") + sdvl_last_error(ctx);
         return -1;
@@ -329,6 +371,16 @@ struct Farm {
       if (rc == 0 && sdvl_ctx_feed_release(ctx, feed, slot) != SDVL_OK) {
         g_err = std::string("input ring: ") + sdvl_last_error(ctx);
         return -1;
+      }
+      if (!step_marks.empty()) {
+        StepMark k{g, s, t_enter, t_issued, Since(), late ? 1 : 0, {0}, 0};
+        double now_t[ST_COUNT];
+        sdvlh_batch_stage_times(batches[g], now_t, ST_COUNT, 0);
+        if (mark_prev.size() != static_cast<size_t>(G)) mark_prev.assign(G, std::vector<double>(ST_COUNT, 0.0));
+        for (int i = 0; i < 12; i++) { k.st[i] = now_t[i] - mark_prev[g][i]; }
+        mark_prev[g].assign(now_t, now_t + ST_COUNT);
+        for (int i = 0; i < Bg; i++) k.kf += out[off + i].keyframe ? 1 : 0;
+        step_marks[g].push_back(k);
       }
       return rc;
     }
@@ -388,6 +440,8 @@ struct Farm {
     const size_t fb = static_cast<size_t>(w) * h;
     const int total = G * Bg;
     std::vector<void *> dst(Bg);
+    std::deque<int> in_flight;  // slots whose transfer has been queued and not yet seen complete, oldest first
+    static const int feed_in_flight = getenv("SDVL_FEED_IN_FLIGHT") ? std::max(1, atoi(getenv("SDVL_FEED_IN_FLIGHT"))) : 2;
     for (;;) {
       int g = -1, s = 0;
       {
@@ -409,7 +463,25 @@ struct Farm {
         }
         s = issued[g];
       }
+      // At most kFeedInFlight transfers are queued on the device at any time.  Every queued transfer is handed to a DMA engine at
+      // once and sits there waiting for its predecessor; with a ring's worth of them queued (48) every engine of the GPU holds one,
+      // and the small DMA copies of the compute streams (FilterCorners records, 1 MB) wait behind 79-MB transfers for tens of ms.
+      while (static_cast<int>(in_flight.size()) >= feed_in_flight) {
+        const int a = sdvl_feed_slot_arrived(feed, in_flight.front());
+        if (a < 0) {
+          std::lock_guard<std::mutex> lk(m);
+          failed = true; err = std::string("input ring: ") + sdvl_feed_last_error(feed);
+          cv_feed.notify_all();
+          return;
+        }
+        if (a == 1) { in_flight.pop_front(); continue; }
+        const auto tw = std::chrono::steady_clock::now();
+        timespec ts{0, 50000};
+        nanosleep(&ts, nullptr);
+        feed_throttle_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+      }
       const auto tc = std::chrono::steady_clock::now();
+      const double tm0 = Since();
       uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(s % kRingSlots) * Bg * fb;
       for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
       const size_t o = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
@@ -417,6 +489,8 @@ struct Farm {
                                       dst.data());
       feed_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
       feed_calls++;
+      in_flight.push_back(g * kRingSlots + s % kRingSlots);
+      if (!step_marks.empty()) feed_marks.push_back(FeedMark{g, s, tm0, Since()});
       {
         std::lock_guard<std::mutex> lk(m);
         if (rc != SDVL_OK) { failed = true; err = std::string("input ring: ") + sdvl_feed_last_error(feed); }
@@ -440,7 +514,10 @@ struct Farm {
           std::lock_guard<std::mutex> lk(m);
           if (failed) return;
         }
+        const bool marks_here = !step_marks.empty() && !(host_input && input_ring && use_feeder && feed);
+        const double tb = marks_here ? Since() : 0.0;
         const int rc = StepGroup(worker);
+        if (marks_here) step_marks[worker].push_back(StepMark{worker, s, tb, tb, Since(), 0, {0}, 0});
         {
           std::lock_guard<std::mutex> lk(m);
           done[worker]++;
@@ -669,11 +746,16 @@ void sdvlh_farm_set_host_input(void *fp, int on) {
 void sdvlh_farm_set_input_ring(void *fp, int on) { static_cast<Farm *>(fp)->input_ring = on != 0; }
 
 // the feeder thread of the last host-fed run: seconds inside sdvl_feed_images, seconds waiting for a free ring slot, transfers
-void sdvlh_farm_feed_stats(void *fp, double *out3) {
+// + seconds the workers waited for their step's transfer to be issued and to arrive (summed over groups), group-steps that began
+// before their images had arrived, seconds the feeder waited for its own earlier transfers (at most two are queued on the device)
+void sdvlh_farm_feed_stats(void *fp, double *out6) {
   Farm *f = static_cast<Farm *>(fp);
-  out3[0] = f->feed_call_s;
-  out3[1] = f->feed_wait_s;
-  out3[2] = static_cast<double>(f->feed_calls);
+  out6[0] = f->feed_call_s;
+  out6[1] = f->feed_wait_s;
+  out6[2] = static_cast<double>(f->feed_calls);
+  out6[3] = f->work_wait_s + f->arrive_wait_s;
+  out6[4] = static_cast<double>(f->late_acquires);
+  out6[5] = f->feed_throttle_s;
 }
 
 void sdvlh_farm_destroy(void *fp) {
@@ -805,9 +887,14 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
     f->done.assign(f->G, 0);
     f->busy.assign(f->G, 0);
     f->issued.assign(f->G, 0);
-    f->feed_call_s = f->feed_wait_s = 0.0;
+    f->feed_call_s = f->feed_wait_s = f->work_wait_s = f->arrive_wait_s = f->feed_throttle_s = 0.0;
+    f->late_acquires = 0;
     f->feed_calls = 0;
     f->failed = false;
+    f->step_marks.clear();
+    f->feed_marks.clear();
+    if (std::getenv("SDVL_FARM_TIMELINE")) f->step_marks.assign(f->G, {});
+    f->run_t0 = std::chrono::steady_clock::now();
   }
   std::thread feeder;
   if (f->host_input && f->input_ring && f->use_feeder) {
@@ -833,6 +920,19 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
     feeder.join();
   }
   if (profile) ProfStop();
+  if (!f->step_marks.empty()) {
+    if (FILE *fp = std::fopen(std::getenv("SDVL_FARM_TIMELINE"), "a")) {
+      std::fprintf(fp, "# run: %d groups x %d steps\n", f->G, n_steps);
+      for (const auto &v : f->step_marks)
+        for (const auto &k : v) {
+          std::fprintf(fp, "step %d %d %.6f %.6f %.6f %d kf %d stages", k.g, k.s, k.t_enter, k.t_issued, k.t_end, k.late, k.kf);
+          for (int i = 0; i < 12; i++) std::fprintf(fp, " %.4f", k.st[i]);
+          std::fprintf(fp, "\n");
+        }
+      for (const auto &k : f->feed_marks) std::fprintf(fp, "feed %d %d %.6f %.6f\n", k.g, k.s, k.t0, k.t1);
+      std::fclose(fp);
+    }
+  }
   if (f->failed) { g_err = f->err; return -1; }
   return 0;
 }

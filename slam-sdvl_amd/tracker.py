@@ -245,11 +245,13 @@ class TrackerFarm:
         return out
 
     def feed_stats(self):
-        """feeder thread of the last host-fed run -> (seconds inside the transfer calls, seconds waiting for a free ring slot, transfers)"""
-        out = (C.c_double * 3)()
+        """last host-fed run -> (seconds the feeder spent inside the transfer calls, seconds it waited for a free ring slot, transfers,
+        seconds the workers waited for their transfer to be issued and to arrive (summed over groups), group-steps that began before their
+        images had arrived, seconds the feeder waited for its own earlier transfers)"""
+        out = (C.c_double * 6)()
         self.lib.sdvlh_farm_feed_stats.argtypes = [C.c_void_p, C.c_void_p]
         self.lib.sdvlh_farm_feed_stats(self.h, out)
-        return out[0], out[1], int(out[2])
+        return out[0], out[1], int(out[2]), out[3], int(out[4]), out[5]
 
     def set_input_ring(self, on):
         """host-fed runs: the images of step s + 1 travel on the group's copy stream while step s computes (default on)"""

@@ -255,6 +255,42 @@ def test_shi_tomasi_and_orb_bit_exact(ctx, sdvl, orc, synth):
     f.close()
 
 
+def test_hamming_argmin_matches_search_features_rule(ctx, orc):
+    """ORBDetector::Distance + the arg-min of Matcher::SearchFeatures (orb_detector.cc:398-410, matcher.cc:254-289):
+    first strict minimum, not found at distance >= threshold, empty and ragged lists."""
+    rng = np.random.default_rng(77)
+    n = 300
+    queries = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    lists = []
+    for i in range(n):
+        k = [0, 1, 3, 64, 65, 200, 777][i % 7]
+        c = rng.integers(0, 256, (k, 32), dtype=np.uint8)
+        if k >= 3:
+            # near copies of the query (a few flipped bits) so distances fall on both sides of the threshold, with exact ties
+            for j in rng.choice(k, 3, replace=False):
+                c[j] = queries[i]
+                flips = rng.choice(256, int(rng.integers(0, 130)), replace=False)
+                for b in flips:
+                    c[j, b >> 3] ^= 1 << (b & 7)
+            a, b = sorted(rng.choice(k, 2, replace=False))
+            c[b] = c[a]                                   # duplicate: the earlier position must win
+        lists.append(c)
+    for thr in (100, 0, 256, 37):
+        gi, gd = ctx.hamming_argmin(queries, lists, thr)
+        for i in range(n):
+            best, bi = thr + 1, -1
+            for j, c in enumerate(lists[i]):
+                d = orc.orb_distance(queries[i], c)
+                assert d == int(np.unpackbits(queries[i] ^ c).sum())
+                if d < best:
+                    best, bi = d, j
+            if best >= thr:
+                bi = -1
+            assert (gi[i], gd[i]) == (bi, best), (thr, i)
+    gi, gd = ctx.hamming_argmin(np.zeros((0, 32), np.uint8), [], 100)
+    assert len(gi) == 0
+
+
 # ------------------------------------------------------------------------------------------------ K5/K6
 def align_inputs(sdvl, orc, img0, cam, n_feat, seed):
     """features of frame 0 on the scene plane z = 2 (camera 0 = world)."""
