@@ -631,6 +631,7 @@ class Feed:
         self.lib = load_library()
         self.lib.sdvl_feed_last_error.restype = C.c_char_p
         self.lib.sdvl_feed_last_error.argtypes = [C.c_void_p]
+        self.lib.sdvl_feed_slot_arrived.argtypes = [C.c_void_p, C.c_int]
         h = C.c_void_p()
         if self.lib.sdvl_feed_create(device, n_slots, C.byref(h)) != 0:
             raise SdvlError("sdvl_feed_create failed")
@@ -642,6 +643,13 @@ class Feed:
         dst = (C.c_void_p * n)(*[int(p) for p in dev_dst])
         if self.lib.sdvl_feed_images(self.h, slot, n, src, stride, width, height, dst) != 0:
             raise SdvlError("sdvl_feed_images: %s" % self.lib.sdvl_feed_last_error(self.h).decode())
+
+    def arrived(self, slot):
+        """True once the slot's last transfer is in HBM (never blocks)"""
+        r = self.lib.sdvl_feed_slot_arrived(self.h, slot)
+        if r < 0:
+            raise SdvlError("sdvl_feed_slot_arrived: %s" % self.lib.sdvl_feed_last_error(self.h).decode())
+        return r == 1
 
     def acquire(self, ctx, slot):
         ctx._check(self.lib.sdvl_ctx_feed_acquire(ctx.h, self.h, slot))

@@ -176,6 +176,13 @@ def test_feed_slots_and_own_images(ctx, sdvl, orc, synth):
     slot = ctx.device_malloc(2 * fb)
     feed = sdvl.Feed(0, 1)
     feed.images(0, [pinned.data_ptr(), pinned.data_ptr() + fb], 640, 640, 480, [slot, slot + fb])     # images 0, 1 (one DMA: contiguous)
+    import time
+    t_end = time.time() + 10.0
+    while not feed.arrived(0):                              # the consumer's host-side form of the wait (Farm::StepGroup)
+        assert time.time() < t_end, "the slot's transfer never arrived"
+        time.sleep(1e-4)
+    with pytest.raises(sdvl.SdvlError):
+        feed.arrived(1)                                     # no such slot
     feed.acquire(ctx, 0)
     fa, fo = sdvl.Frame(ctx, 640, 480), sdvl.Frame(ctx, 640, 480)
     fa.borrow_image_device(slot)
