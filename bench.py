@@ -295,6 +295,26 @@ def cpu_baseline(frames, mapper=False, threads=1, ref_flags=False):
     return tracked / wall, tracked, wall
 
 
+def host_memory_available():
+    """bytes this process can still take: MemAvailable, capped by the cgroup's limit minus its current use (None: unknown)"""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+                break
+    except (OSError, ValueError):
+        pass
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        if mx != "max":
+            left = int(mx) - int(open("/sys/fs/cgroup/memory.current").read().strip())
+            avail = left if avail is None else min(avail, left)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
 def visible_gpus():
     """GPUs this process could use, counted WITHOUT initialising HIP/HSA in it (a process that has touched the GPU must never
     start rank children): the KFD topology in sysfs lists every node, GPUs are the ones with SIMDs; ROCR_/HIP_/CUDA_VISIBLE_DEVICES
@@ -640,6 +660,9 @@ def main():
     host_fed = None
     Kh = max(0, args.host_steps)
     if Kh > 0:
+        host_free = host_memory_available()
+        while Kh > 4 and host_free is not None and B * Kh * frame_bytes + 12e9 > 0.85 * host_free:
+            Kh //= 2                                  # fewer host-fed steps rather than an out-of-memory kill
         try:
             hbuf = torch.empty(B * Kh * frame_bytes, dtype=torch.uint8, pin_memory=True)
         except RuntimeError as e:
@@ -711,9 +734,15 @@ def main():
         D = min(B, int(os.environ.get("SDVL_BENCH_SUSTAINED_DISTINCT", "32")))
         kf_budget = NF // 4 + 8             # S-A turns about one frame in five into a keyframe
         need2 = G * Bg * kf_budget * footprint + 3 * B * frame_bytes + B * scratch_per_frame
+        # host side: every keyframe keeps ~270 KB of Feature / Point objects (the reference's own representation): 4096 x 69 = 76 GB
+        host_need = B * (NF / 4.3) * 290e3 + D * NF * frame_bytes
+        host_free = host_memory_available()
         if need2 > 0.9 * free0:
             sys.stderr.write("bench.py: sustained leg skipped: %d sequences x ~%d keyframes x %.2f MB = %.0f GB of HBM, %.0f GB free\n" %
                              (B, kf_budget, footprint / 1e6, need2 / 1e9, free0 / 1e9))
+        elif host_free is not None and host_need > 0.85 * host_free:
+            sys.stderr.write("bench.py: sustained leg skipped: %d sequences x %d frames need about %.0f GB of host memory (keyframe objects), %.0f GB available\n" %
+                             (B, NF, host_need / 1e9, host_free / 1e9))
         else:
             farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
             farm.set_fibers(fibers)
