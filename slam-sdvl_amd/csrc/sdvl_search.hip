@@ -282,6 +282,17 @@ __global__ __launch_bounds__(64) void search_prepare_kernel(const SearchReqDev *
 // workgroup is the block (kW = kWavesPerBlock).  The form without the stage (round 3) runs ONE WAVE per workgroup, four workgroups per
 // block: among the other streams' one-wave kernels (fast_cells, pyr_down) a workgroup that needs four free wave slots on one CU at
 // the same moment is placed far less often than its share — every slot that frees is taken by a one-wave workgroup first.
+#ifdef SDVL_SEARCH_STATS
+// diagnostic build only (make HIPFLAGS+=-DSDVL_SEARCH_STATS): requests, binned / full scans, scan rounds, corners in range, regions (cells)
+__device__ unsigned long long g_search_stats[8];
+#define SDVL_STAT(i, v) do { const unsigned long long v_ = static_cast<unsigned long long>(v); if (lane == 0) atomicAdd(&g_search_stats[i], v_); } while (0)
+#else
+#define SDVL_STAT(i, v) do { } while (0)
+#endif
+
+// search regions of up to this many 32-px cells go through the corner bins (their corners: ~3.4 per cell); larger ones scan the whole list
+constexpr int kBinRegionCells = 320;
+
 template <bool kStage, int kW>
 __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
                                                                             const SearchFramePose *__restrict__ table,
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
       }
       int score = 0;
+      SDVL_STAT(4, __popcll(__ballot(inr)));
       if (lazy_desc) {
         unsigned long long m = __ballot(inr);
         const uint32_t rq_nib = (rq.desc[lane >> 3] >> (4 * (lane & 7))) & 0xFu;
@@ -489,10 +501,11 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const int cy0 = max(0, static_cast<int>(floor(by0)) >> 5), cy1 = min(gh - 1, static_cast<int>(floor(by1)) >> 5);
         if (cx1 < cx0 || cy1 < cy0) {
           scanned = true;  // the region lies outside the image: no corner can be in range
-        } else if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 48 && cy1 - cy0 < 4) {  // (taller regions: the full scan below)
+        } else if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= kBinRegionCells) {  // (larger regions: the full scan below)
           scanned = true;
-          const int nrows = cy1 - cy0 + 1;
-          {
+          // four cell rows at a time (a region of the metric configuration has at most four; configuration C's span up to a dozen)
+          for (int ry = cy0; ry <= cy1; ry += 4) {
+            const int nrows = min(4, cy1 - ry + 1);
             // the entries of the (at most four) cell rows as ONE lane space: a search region of a few cells holds ~15 corners, so a
             // round per row ran the whole range test two or three times for a quarter of a wave each.  Row r contributes entries
             // [e0[r], e1[r]) (cells of a row are consecutive); lane index i maps to the row whose prefix range holds it.
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             pre[0] = 0;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              const int cyi = min(cy0 + r, cy1);
+              const int cyi = min(ry + r, cy1);
               const int a = cf.bin_start[cyi * gw + cx0], b = cf.bin_start[cyi * gw + cx1 + 1];
               e0[r] = a;
               pre[r + 1] = pre[r] + (r < nrows ? b - a : 0);
@@ -515,14 +528,20 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
               const int e = i + (r == 0 ? e0[0] - pre[0] : r == 1 ? e0[1] - pre[1] : r == 2 ? e0[2] - pre[2] : e0[3] - pre[3]);
               uint2 ent = make_uint2(0u, 0u);
               if (have) ent = cf.bin_entries[e];
+              SDVL_STAT(3, 1);
               scan_round(have, ent.x, static_cast<int>(ent.y));
             }
           }
         }
       }
     }
+    SDVL_STAT(0, 1);
+    SDVL_STAT(scanned ? 1 : 2, 1);
     if (!scanned) {
+      SDVL_STAT(6, binned ? 1 : 0);
+      SDVL_STAT(7, line_ok ? 1 : 0);
       for (int c0 = 0; c0 < n_corners; c0 += 64) {
+        SDVL_STAT(3, 1);
         const int ci = c0 + lane;
         const bool have = ci < n_corners;
         scan_round(have, have ? corner_at(ci) : 0u, ci);
@@ -859,6 +878,17 @@ int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_
   // searched correctly, its corner list read from HBM)
   SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<false, 1>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8 * kWavesPerBlock)), dim3(64), d_reqs,
               d_table, d_blocks, static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, d_res, h_res);
+#ifdef SDVL_SEARCH_STATS
+  {
+    static int launches = 0;
+    if (++launches % 200 == 0) {
+      unsigned long long h[8];
+      if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_search_stats), sizeof(h)) == hipSuccess)
+        fprintf(stderr, "search stats after %d launches: requests %llu, binned %llu, full scans %llu (frame binned %llu, line ok %llu), scan rounds %llu, corners in range %llu\n",
+                launches, h[0], h[1], h[2], h[6], h[7], h[3], h[4]);
+    }
+  }
+#endif
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
 }

@@ -55,7 +55,10 @@ struct RegisterRec {  // sdvl_frame_register
   int id, pad_;
 };
 
-void fill_view(SearchFrame *d, const sdvl_frame *f) {
+// bins_pending: the frame's corners (and their bins) are produced by a detection that is queued BEHIND this call and ahead of the
+// kernels that will read the view (sdvl_track_align -> sdvl_detect_corners -> sdvl_track_search): the view names the frame's bin
+// arrays although the host does not call them valid yet.  sdvl_track_search checks that the detection did come (track_clear_bins).
+void fill_view(SearchFrame *d, const sdvl_frame *f, bool bins_pending = false) {
   memset(d, 0, sizeof(SearchFrame));
   for (int l = 0; l < f->v.levels; l++) {
     d->level[l] = f->v.level[l];
@@ -66,11 +69,23 @@ void fill_view(SearchFrame *d, const sdvl_frame *f) {
   d->desc = f->desc_valid ? f->v.desc : nullptr;  // null: a search computes the descriptors it compares (search_points_kernel)
   d->n_ptr = f->v.corner_hdr;
   d->levels = f->v.levels;
-  if (f->bins_valid) {
+  if (f->bins_valid || (bins_pending && f->bin_cells > 0)) {
     d->bin_start = f->bin_start;
     d->bin_entries = f->bin_entries;
     d->bin_gw = f->bin_gw;
     d->bin_cells = f->bin_cells;
+  }
+}
+
+// the rare case behind fill_view's bins_pending: current frames whose corners did not come out of sdvl_detect_corners (set by hand)
+// have no bins: their views go back to "scan the whole corner list"
+__global__ __launch_bounds__(64) void track_clear_bins_kernel(TrackJobDev *__restrict__ jobs, const uint8_t *__restrict__ no_bins, int n) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j < n && no_bins[j]) {
+    jobs[j].cur.bin_start = nullptr;
+    jobs[j].cur.bin_entries = nullptr;
+    jobs[j].cur.bin_gw = 0;
+    jobs[j].cur.bin_cells = 0;
   }
 }
 
@@ -698,7 +713,7 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
   for (int j = 0; j < n_jobs; j++) {
     const sdvl_track_job &a = jobs[j];
     TrackJobDev &d = hj[j];
-    fill_view(&d.cur, a.cur);
+    fill_view(&d.cur, a.cur, /*bins_pending*/ true);
     d.tracker = a.tracker;
     d.feat_buf = a.feat_buf;
     d.cur_id = a.cur->reg_id;
@@ -740,6 +755,23 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
   const Cam c{s->cam.width, s->cam.height, s->cam.fx, s->cam.fy, s->cam.u0, s->cam.v0};
   const int stride = s->stride;
   SearchFramePose *registry = static_cast<SearchFramePose *>(ctx->d_registry);
+  {
+    // sdvl_track_align named the current frames' corner bins before the detection that fills them was queued (fill_view): frames
+    // whose corners were set by hand instead have none
+    static const bool never = getenv("SDVL_TRACK_NO_BINS") != nullptr;  // A/B and test of this path: every view loses its bins
+    bool any = false;
+    for (const sdvl_track_job &a : s->jobs) any = any || (a.cur->bin_cells > 0 && (never || !a.cur->bins_valid));
+    if (any) {
+      void *hs = nullptr, *dsx = nullptr;
+      const int rc_m = sdvl_stage_alloc(ctx, static_cast<size_t>(n_jobs), &hs, &dsx);
+      if (rc_m) return rc_m;
+      uint8_t *hm = static_cast<uint8_t *>(hs);
+      for (int j = 0; j < n_jobs; j++) hm[j] = (s->jobs[j].cur->bin_cells > 0 && (never || !s->jobs[j].cur->bins_valid)) ? 1 : 0;
+      SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, static_cast<size_t>(n_jobs)));
+      hipLaunchKernelGGL(track_clear_bins_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, ctx->stream, s->d_jobs, static_cast<const uint8_t *>(dsx), n_jobs);
+      SDVL_HIP_CHECK(ctx, hipGetLastError());
+    }
+  }
   {
     const size_t lds = static_cast<size_t>(stride) * (8 + 16 + 2) + 64;
     if (lds > 60 * 1024) {  // beyond the default dynamic LDS limit: raise it once per device

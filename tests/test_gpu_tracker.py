@@ -439,8 +439,10 @@ def test_cpp_example_track_sequence_matches_the_oracle(orc, synth, tmp_path):
     ref = orc.tracker(640, 480, TUM_CAM)
     wants = [ref.handle_frame(im) for im in imgs]
     ref.close()
-    for args in (["--synthetic", str(n)], ["--list", str(lst)]):
-        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    # third run: the tracked step's search without the corner bins (SDVL_TRACK_NO_BINS=1: the views of the current frames lose the
+    # bins sdvl_track_align named ahead of the detection, as for frames whose corners were set by hand) — same answers
+    for args, env in ((["--synthetic", str(n)], {}), (["--list", str(lst)], {}), (["--synthetic", str(n)], {"SDVL_TRACK_NO_BINS": "1"})):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr
         rows = [l.split() for l in r.stdout.strip().splitlines()]
         assert len(rows) == n
