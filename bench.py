@@ -172,6 +172,23 @@ def _pmc_rows(fname):
         return list(csv.DictReader(fh)), os.path.relpath(files[-1], root)
 
 
+def measured_issue_rates():
+    """wave instructions per second that streams of independent instructions reach on this chip at 8 waves per SIMD
+    (tools/valu_peak_probe.cpp, committed as profiles/rNN/valu_peak_probe.txt): packed-f16, permute and FP64 instructions issue at
+    about half the rate of FP32 / integer ones — fast_cells is mostly the former.  {} when no probe output is committed."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "valu_peak_probe.txt")))
+    out = {}
+    if files:
+        for line in open(files[-1]):
+            m = re.match(r"(\S.*?)\s+8 wave\(s\) per SIMD:.*?([0-9.]+e[+-]?[0-9]+) wave instructions/s", line)
+            if m:
+                out[m.group(1).strip()] = float(m.group(2))
+    return out
+
+
 def _pmc_row(rows, kernel):
     """the row of timer name `kernel` (rocprofv3 names look like 'fast_cells_wave_kernel' or 'void image_align_lds_kernel<false>')"""
     for row in rows:
@@ -836,6 +853,8 @@ def main():
                 vk = valu["kernels"].get(name)
                 roofline["valu"] = {
                     "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS, "source": valu["source"] + " (SQ_INSTS_VALU, own --pmc pass)",
+                    "peak_note": "nominal: 256 CUs x 4 SIMDs x 2.4 GHz / 2; streams of independent instructions reach (tools/valu_peak_probe.cpp)",
+                    "measured_issue_rates": measured_issue_rates(),
                     "kernel_insts_per_launch": int(vk["insts_per_dispatch"] * frames_per_launch / valu["frames_per_dispatch"]) if vk else None,
                     "kernel_frac": round(vk["insts_per_dispatch"] * frames_per_launch / valu["frames_per_dispatch"] / avg_s / VALU_PEAK_WAVE_INSTS, 4) if vk else None,
                     "path_insts_per_frame": int(valu["path_insts_per_frame"]),
