@@ -67,6 +67,27 @@ hipError_t sdvl_push(sdvl_ctx *ctx, void *dst_dev, const void *src_staged, size_
   return hipGetLastError();
 }
 
+// The other direction: results that a kernel left in device memory go to a pinned host buffer through a kernel's stores (posted PCIe
+// writes) instead of a DMA command — the tracked step's last sizeable DMA copy (the FilterCorners records, ~1 MB per group-step) was
+// what waited behind parked image transfers.  Both pointers 16-byte aligned, whole 16-byte units are copied;
+// SDVL_STAGE_DMA=1 (or SDVL_RESULT_COPIES=1) keeps hipMemcpyAsync.
+namespace {
+__global__ __launch_bounds__(256) void stage_pull_kernel(const push_u32x4 *__restrict__ src, push_u32x4 *__restrict__ dst_host, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) __builtin_nontemporal_store(src[i], dst_host + i);
+}
+}  // namespace
+
+hipError_t sdvl_pull(sdvl_ctx *ctx, void *dst_host_pinned, const void *src_dev, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  static const bool dma = getenv("SDVL_STAGE_DMA") != nullptr || !sdvl_direct_results();
+  const bool ok = ((reinterpret_cast<uintptr_t>(dst_host_pinned) | reinterpret_cast<uintptr_t>(src_dev)) & 15u) == 0;
+  if (dma || !ok || bytes > (static_cast<size_t>(64) << 20)) return hipMemcpyAsync(dst_host_pinned, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  const int n16 = static_cast<int>((bytes + 15) >> 4);
+  const int blocks = n16 <= 256 ? 1 : (n16 >= 256 * 64 ? 64 : (n16 + 255) / 256);
+  hipLaunchKernelGGL(stage_pull_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const push_u32x4 *>(src_dev), static_cast<push_u32x4 *>(dst_host_pinned), n16);
+  return hipGetLastError();
+}
+
 int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d) {
   const size_t need = (bytes + 255) / 256 * 256;
   const size_t cap = ctx->h_stage_bytes < ctx->d_stage_bytes ? ctx->h_stage_bytes : ctx->d_stage_bytes;

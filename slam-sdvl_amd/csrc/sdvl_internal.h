@@ -187,6 +187,7 @@ int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d);
 // the transfers running, 234 k with the same steps and the transfers skipped).  Sources outside the staging ring fall back to the
 // DMA copy.  SDVL_STAGE_DMA=1: always the DMA copy (A/B).
 hipError_t sdvl_push(sdvl_ctx *ctx, void *dst_dev, const void *src_staged, size_t bytes);
+hipError_t sdvl_pull(sdvl_ctx *ctx, void *dst_host_pinned, const void *src_dev, size_t bytes);
 // wait for everything queued on ctx->stream WITHOUT spinning: a mark (sdvl_mark_record) + sleeping polls (sdvl_mark_wait).
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
 // a point of the stream to wait for later: everything queued before the mark has completed once the wait returns; work

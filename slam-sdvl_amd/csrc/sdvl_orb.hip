@@ -620,7 +620,7 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   SDVL_LAUNCH(ctx, "filter_describe", filter_describe_kernel, xcd_frame_grid(n, std::min(max_out, 512)), dim3(64), static_cast<const FilterJob *>(dsx),
               max_out, n, std::min(max_out, 512));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
-  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, d8 + sc_bytes, cnt_bytes + rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_pull(ctx, ctx->h_out, d8 + sc_bytes, cnt_bytes + rec_bytes));
   SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_FILTER, &ctx->filter_ticket));
   ctx->filter_pending = n;
   ctx->filter_ccap = max_out;
