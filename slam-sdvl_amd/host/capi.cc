@@ -319,6 +319,13 @@ struct Farm {
   }
 
   int StepGroup(int g) {
+    // diagnostic: extra host latency per group-step.  If throughput falls by as much, the groups' chains are latency-bound;
+    // if it does not, the GPU is the limiter and the host's share of a step is hidden behind the other groups' kernels.
+    static const int extra_us = getenv("SDVL_FARM_EXTRA_HOST_US") ? atoi(getenv("SDVL_FARM_EXTRA_HOST_US")) : 0;
+    if (extra_us > 0) {
+      timespec ts{extra_us / 1000000, (extra_us % 1000000) * 1000L};
+      nanosleep(&ts, nullptr);
+    }
     const int total = G * Bg;
     const int s = done[g];  // only the owner of a busy group reads or writes its counter
     const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
