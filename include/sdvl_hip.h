@@ -405,6 +405,10 @@ int sdvl_ctx_wait_done(sdvl_ctx *ctx);
 int sdvl_ctx_wait_block(sdvl_ctx *ctx);
 /* 0 while the stream is healthy (idle or busy), SDVL_ERR_HIP after a device fault: for schedulers that poll _wait_done */
 int sdvl_ctx_health(sdvl_ctx *ctx);
+/* Which path the work of this context took, counted on the host (a fast path must be SEEN to run: the tracked step scanned whole
+ * corner lists for a round and a half without failing anything).  out4[0] = tracked jobs (sdvl_track_search) whose search reads the
+ * corner bins, out4[1] = tracked jobs whose search scans the frame's whole corner list, out4[2..3] reserved (0). */
+int sdvl_ctx_counters(sdvl_ctx *ctx, int64_t *out4);
 
 /* ---- input stage: Camera::UndistortImage = cv::undistort(in, out, K, D) (camera.cc:39-67,100-105, main.cc:133) ----
  * d[0..4] = Camera.d1..d5 of the config = (k1, k2, p1, p2, k3).  As in the reference, d[0] == 0 means "no distortion":

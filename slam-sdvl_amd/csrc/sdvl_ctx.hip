@@ -219,6 +219,12 @@ extern "C" int sdvl_ctx_health(sdvl_ctx *ctx) {
   return SDVL_ERR_HIP;
 }
 
+extern "C" int sdvl_ctx_counters(sdvl_ctx *ctx, int64_t *out4) {
+  if (!ctx || !out4) return SDVL_ERR_INVALID;
+  for (int i = 0; i < 4; i++) out4[i] = ctx->counters[i];
+  return SDVL_OK;
+}
+
 // sleep (no spinning) until the wait in flight has completed
 extern "C" int sdvl_ctx_wait_block(sdvl_ctx *ctx) {
   if (!ctx || !ctx->waiting) return SDVL_OK;

@@ -97,6 +97,9 @@ struct sdvl_ctx {
   // any later wait on the stream has returned (wait_gen > counts_gen), so asking for them then costs no round trip
   void *h_counts = nullptr; size_t h_counts_bytes = 0;
   uint64_t wait_gen = 0, counts_gen = ~0ull;
+  // which path the tracked steps' searches took (sdvl_ctx_counters): [0] jobs searched through the corner bins, [1] jobs whose search
+  // scans the whole corner list (no bin layout for the frame size, corners set by hand, SDVL_TRACK_NO_BINS)
+  long long counters[4] = {0, 0, 0, 0};
   std::vector<void *> slabs;  // bulk frame storage, released with the context
   // Waiting for a point of the stream: a 32-bit sequence number written by the stream itself (hipStreamWriteValue32) into
   // pinned host memory, polled by the waiting thread with plain loads (SDVL_WAIT_EVENTS=1: HIP events + hipEventQuery)

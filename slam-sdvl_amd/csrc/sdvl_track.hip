@@ -761,6 +761,7 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
     static const bool never = getenv("SDVL_TRACK_NO_BINS") != nullptr;  // A/B and test of this path: every view loses its bins
     bool any = false;
     for (const sdvl_track_job &a : s->jobs) any = any || (a.cur->bin_cells > 0 && (never || !a.cur->bins_valid));
+    for (const sdvl_track_job &a : s->jobs) ctx->counters[(a.cur->bin_cells > 0 && !never && a.cur->bins_valid) ? 0 : 1]++;
     if (any) {
       void *hs = nullptr, *dsx = nullptr;
       const int rc_m = sdvl_stage_alloc(ctx, static_cast<size_t>(n_jobs), &hs, &dsx);

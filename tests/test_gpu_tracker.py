@@ -1,6 +1,7 @@
 """Closed-loop parity (BASELINE.json config 3: "full HIP front-end ... pose-delta tolerance check"): B synthetic
 sequences tracked on the MI355X through the host layer (sdvl::SDVLBatch) against the CPU oracle tracker run on
 the same frames.  Decisions (matches, attempts, inliers, keyframes) must be identical, poses within 1e-4."""
+import ctypes as C
 import importlib
 import os
 
@@ -331,6 +332,17 @@ def test_farm_at_bench_size_replicas_agree_and_match_the_oracle(trk, orc, synth)
             if k > 0:
                 assert g[1] == 0 and g[4] >= 100
         o.close()
+    # a fast path must be SEEN to run: every tracked job of every group searched through the corner bins (for a round and a half the
+    # tracked step scanned whole corner lists — same answers, 12 % of the throughput; sdvl_ctx_counters is the witness)
+    lib = sdvl.load_library()
+    lib.sdvl_ctx_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    binned = scanned = 0
+    for g in range(G):
+        out = (C.c_int64 * 4)()
+        assert lib.sdvl_ctx_counters(C.c_void_p(farm.ctx_handle(g)), out) == 0
+        binned += out[0]
+        scanned += out[1]
+    assert scanned == 0 and binned == n * (n_steps - 1), (binned, scanned)
     farm.close()
 
 
