@@ -40,7 +40,7 @@ __device__ __forceinline__ int reflect101_clamped(int p, int n) {
 // mirror inside the same row.  Horizontal 1-4-6-4-1 pass into 16-bit sums, then every thread finishes 4 adjacent outputs
 // and stores them as one word.
 template <int kPyrTW, int kPyrTH>
-__global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const PyrJob *__restrict__ jobs) {
+__global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const PyrJob *__restrict__ jobs, int n_jobs, int gx, int gy) {
   constexpr int kThreads = kPyrTW * kPyrTH / 4;  // every thread finishes 4 adjacent outputs
   constexpr int kPyrSH = 2 * kPyrTH + 3;         // source rows of a tile
   constexpr int kPyrSWW = kPyrTW / 2 + 2;        // source words of a tile row: bytes [2*tx0 - 4, 2*tx0 + 2*TW + 4)
@@ -51,8 +51,22 @@ __global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const Pyr
   };
   __shared__ uint32_t s_srcw[kPyrSH * (kPyrSWW + 1)];
   __shared__ __attribute__((aligned(8))) uint16_t s_h[kPyrSH][kPyrTW];
-  const PyrJob job = jobs[blockIdx.z];
-  const int tx0 = blockIdx.x * kPyrTW, ty0 = blockIdx.y * kPyrTH;
+  // Round 4: a 1-D grid dealt so that ALL tiles of a frame run on one XCD (workgroups go round-robin over the 8 XCDs: id & 7), in
+  // row-major tile order.  With the plain (x, y, frame) grid the x-neighbours of a 32-px tile row landed on eight different XCDs and
+  // each of their L2s fetched the same 128-B source lines, as did the vertical halo rows: 106 MB of HBM traffic per dispatch
+  // against 32.6 MB algorithmic (profiles/r03/pmc_hbm_traffic.csv).  gx == 0: the old 3-D grid (SDVL_PYR_GRID3D=1, A/B).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gx > 0) {
+    const int id = blockIdx.x, per_frame = gx * gy;
+    const int slot = id >> 3;
+    bz = (slot / per_frame) * 8 + (id & 7);
+    if (bz >= n_jobs) return;
+    const int t = slot % per_frame;
+    by = t / gx;
+    bx = t - by * gx;
+  }
+  const PyrJob job = jobs[bz];
+  const int tx0 = bx * kPyrTW, ty0 = by * kPyrTH;
   if (tx0 >= job.dw || ty0 >= job.dh) return;
   const int tid = threadIdx.x;
   uint8_t *s_bytes = reinterpret_cast<uint8_t *>(s_srcw);
@@ -1567,13 +1581,15 @@ int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
   for (int l = 1; l < levels; l++) {
     const FrameView &v = frames[0]->v;
     static const bool four_waves = getenv("SDVL_PYR_WG4") != nullptr;
-    if (four_waves) {
-      dim3 grid((v.lw[l] + 63) / 64, (v.lh[l] + 15) / 16, n);
-      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<64, 16>), grid, dim3(256), static_cast<const PyrJob *>(dsx) + (l - 1) * n);
-    } else {
-      dim3 grid((v.lw[l] + kPyrTW - 1) / kPyrTW, (v.lh[l] + kPyrTH - 1) / kPyrTH, n);
-      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<kPyrTW, kPyrTH>), grid, dim3(64), static_cast<const PyrJob *>(dsx) + (l - 1) * n);
-    }
+    static const bool grid3d = getenv("SDVL_PYR_GRID3D") != nullptr;
+    const int tw = four_waves ? 64 : kPyrTW, th = four_waves ? 16 : kPyrTH;
+    const int gx = (v.lw[l] + tw - 1) / tw, gy = (v.lh[l] + th - 1) / th;
+    const dim3 grid = grid3d ? dim3(gx, gy, n) : dim3(static_cast<unsigned>(gx) * gy * ((n + 7) / 8 * 8), 1, 1);
+    const int kgx = grid3d ? 0 : gx;
+    if (four_waves)
+      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<64, 16>), grid, dim3(256), static_cast<const PyrJob *>(dsx) + (l - 1) * n, n, kgx, gy);
+    else
+      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<kPyrTW, kPyrTH>), grid, dim3(64), static_cast<const PyrJob *>(dsx) + (l - 1) * n, n, kgx, gy);
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;

@@ -606,6 +606,532 @@ __global__ __launch_bounds__(kT) void image_align_lds_kernel(const IaJob *__rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------ round 4: lane = feature
+// The same Gauss-Newton as a chain of WAVES instead of a workgroup of (feature, pixel) threads.  What the round-3 profile said
+// about the kernel above: 231 VGPRs x 4 waves per job, ~6 workgroup barriers per evaluation, thread 0 alone in the solve — alone
+// 123 us per 256 jobs, 288 us among the other streams' kernels (every barrier waits for the slowest of four waves that all compete
+// with the neighbours' waves for issue slots).  Here:
+//  * lane = FEATURE; a wave walks its features in rounds of 64.  A lane reads only what it wrote itself (its feature's reference
+//    items, its 3-D point): no barrier and no fence between PrecomputePatches and ComputeResiduals;
+//  * the normal equations are factored per feature.  J(item) = (dx * Ja + dy * Jb) * fl with Ja, Jb the two rows of the feature's
+//    2x6 Jacobian (image_align.cc:263), so  sum_items J res = fl * (Ja * A + Jb * B)  with A = sum dx res, B = sum dy res over the
+//    feature's 16 pixels, and  sum_items J J^T = G^T S G  with G = fl * [Ja; Jb] and S = [Sxx Sxy; Sxy Syy] the feature's gradient
+//    sums.  An evaluation costs 16 x (bilinear + 2 products) + 24 double operations per feature instead of 16 x 66; H costs 111 per
+//    feature, and only when the contributing set changes.  Same mathematics, different rounding order: tolerance class (pose 1e-4;
+//    the kernel above already summed in its own order);
+//  * the 6x6 interpolated grid of the reference window is computed once and shared by the 16 pixels' value / dx / dy (the
+//    reference evaluates the same expression five times per pixel: bit-identical items from 32 bilinear sums instead of 80);
+//  * image windows come in as aligned dwords + v_alignbyte (10 loads per 5x5 window instead of 25 byte loads);
+//  * the solve, the SE3 update and the termination tests run redundantly on every lane (uniform values): no broadcast, no
+//    barrier, no idle lanes to wait for; the LDLT factor stays in LDS while H is reused;
+//  * kWaves = 1 (tracking: <= 192..384 features): no s_barrier anywhere.  kWaves = 4 for the large jobs of configuration C: one
+//    barrier per evaluation (per-wave partial sums through LDS, summed in wave order by everybody).
+// Cites: ImageAlign::ComputePose image_align.cc:46-84, Optimize :86-125, ComputeResiduals :127-206, PrecomputePatches :208-267.
+template <int N>
+__device__ __forceinline__ double wave_reduce_n(double *v, int lane) {
+  // halving butterfly: on return a lane holds the wave-wide sum of value index (lane >> (6 - log2 N)) & (N - 1)
+  int n = N;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    if (n > 1) {
+      const int h = n >> 1;
+      const bool up = lane & m;
+#pragma unroll
+      for (int i = 0; i < h; i++) {
+        const double keep = up ? v[i + h] : v[i], send = up ? v[i] : v[i + h];
+        v[i] = keep + shfl_xor_f64(send, m);
+      }
+      n = h;
+    } else {
+      v[0] += shfl_xor_f64(v[0], m);
+    }
+  }
+  return v[0];
+}
+
+__device__ __forceinline__ void ia_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// bytes [0, 8) of the row that starts at p (any alignment), from aligned dwords; `need` = how many of them the caller uses
+__device__ __forceinline__ void ia_load_row8(const uint8_t *p, int need, uint32_t *lo, uint32_t *hi) {
+  const uint32_t s = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)) & 3u;
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(p - s);
+  const uint32_t d0 = q[0], d1 = q[1];
+  // the third dword only where the row reaches into it: never touch memory behind the bytes the reference reads
+  const uint32_t d2 = q[(s + need > 8) ? 2 : 1];
+  *lo = __builtin_amdgcn_alignbyte(d1, d0, s);
+  *hi = __builtin_amdgcn_alignbyte(d2, d1, s);
+}
+__device__ __forceinline__ float ia_byte(uint32_t w, int k) { return static_cast<float>((w >> (8 * k)) & 0xffu); }
+
+// Rigid::Exp with the kernel's own sin / cos (sincos_2pi: fdlibm kernels, <= 1 ulp like libm's; no large-argument path — a
+// Gauss-Newton step of more than a turn is folded into [0, 2 pi), the result is rejected by the chi2 test anyway)
+__device__ __forceinline__ void ia_sincos(double x, double *s, double *c) {
+  if (!(x <= 6.28)) x = x - 6.283185307179586 * floor(x * 0.15915494309189535);
+  if (!(x >= 0.0 && x <= 6.3)) x = 0.0;  // NaN
+  sincos_2pi(x, s, c);
+}
+__device__ __forceinline__ Rigid ia_se3_exp(const double *u) {
+  const double kEps = 1e-10;
+  const V3 ups = {u[0], u[1], u[2]};
+  const V3 om = {u[3], u[4], u[5]};
+  const double theta = vnorm(om);
+  const double half_theta = 0.5 * theta;
+  double imag, real, sin_half;
+  ia_sincos(half_theta, &sin_half, &real);
+  if (theta < kEps) {
+    const double t2 = theta * theta;
+    const double t4 = t2 * t2;
+    imag = 0.5 - 0.0208333 * t2 + 0.000260417 * t4;
+  } else {
+    imag = sin_half / theta;
+  }
+  Rigid r;
+  r.q0 = real; r.q1 = imag * om.x; r.q2 = imag * om.y; r.q3 = imag * om.z;
+  M3 Om;
+  Om.m[0] = 0;     Om.m[1] = -om.z; Om.m[2] = om.y;
+  Om.m[3] = om.z;  Om.m[4] = 0;     Om.m[5] = -om.x;
+  Om.m[6] = -om.y; Om.m[7] = om.x;  Om.m[8] = 0;
+  const M3 Om2 = mmul(Om, Om);
+  M3 V;
+  if (theta < kEps) {
+    V = quat_to_mat(r.q0, r.q1, r.q2, r.q3);
+  } else {
+    const double t2 = theta * theta;
+    double sin_theta, cos_theta;
+    ia_sincos(theta, &sin_theta, &cos_theta);
+    const double ca = (1 - cos_theta) / (t2);
+    const double cb = (theta - sin_theta) / (t2 * theta);
+#pragma unroll
+    for (int i = 0; i < 9; i++) V.m[i] = (((i % 4) == 0 ? 1.0 : 0.0) + ca * Om.m[i]) + cb * Om2.m[i];
+  }
+  r.t = mvec(V, ups);
+  return r;
+}
+
+constexpr int kIaVis = 2, kIaOk = 4;  // feature flags in LDS: bit 0 valid, bit 1 visible (sticky, image_align.cc:233), bit 2 inside at the last evaluation
+
+// -DSDVL_IA_STAMPS: diagnostic build, phase times of job 0 in shader-clock ticks (s_memtime) -> sdvl_debug_ia_stamps
+#ifdef SDVL_IA_STAMPS
+__device__ unsigned long long g_ia_stamps[8];
+#define IA_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[k] += now_ - t_last_; t_last_ = now_; } while (0)
+#else
+#define IA_STAMP(k) do { } while (0)
+#endif
+
+template <int kWaves, bool kGlobalItems>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_wave_kernel(const IaJob *__restrict__ jobs,
+                                                                       const sdvl_align_feature *__restrict__ feats_all, Cam cam,
+                                                                       sdvl_align_params prm, int max_f, sdvl_align_result *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  // carve (max_f is a multiple of 64 * kWaves): x[4][max_f] doubles (point in frame 1: x, y, z, 1/z) | S[3][max_f] doubles (gradient
+  // sums of the level) | items: pd[16][max_f] float2 {patch, dx}, dy[16][max_f] floats (LDS, or the job's slice of the work buffer)
+  double *s_x = reinterpret_cast<double *>(s_dyn);
+  double *s_S = s_x + static_cast<size_t>(4) * max_f;
+  float2 *s_pd_l = reinterpret_cast<float2 *>(s_S + static_cast<size_t>(3) * max_f);
+  float *s_dy_l = reinterpret_cast<float *>(s_pd_l + static_cast<size_t>(16) * max_f);
+  uint8_t *s_flag = kGlobalItems ? reinterpret_cast<uint8_t *>(s_pd_l) : reinterpret_cast<uint8_t *>(s_dy_l + static_cast<size_t>(16) * max_f);
+  __shared__ double s_red[2][kWaves][8];
+  __shared__ int s_chg[2][kWaves];
+  __shared__ double s_redH[kWaves][24];
+  __shared__ double s_L[kWaves][21];  // the factor of H while H is reused: row-major lower triangle incl. D on the diagonal
+  __shared__ int s_tr[kWaves][6];
+  // the optimiser's pose and its roll-back copy (image_align.cc:95,112) — uniform values, kept out of the vector registers
+  __shared__ double s_T[kWaves][7], s_Tbk[kWaves][7];
+
+  const IaJob &job = jobs[blockIdx.x];
+  const int nf = job.n_feat;
+  const sdvl_align_feature *F = feats_all + job.feat_begin;
+  const int tid = threadIdx.x, lane = tid & 63, wave = kWaves > 1 ? (tid >> 6) : 0;
+  const int rounds = (nf + 64 * kWaves - 1) / (64 * kWaves);
+  // items of a job too large for LDS live in its slice of the work buffer, same layout with the job's own pitch
+  const int pitch = kGlobalItems ? (nf + 63) / 64 * 64 : max_f;
+  float2 *it_pd = kGlobalItems ? reinterpret_cast<float2 *>(job.patch_cache) : s_pd_l;
+  float *it_dy = kGlobalItems ? reinterpret_cast<float *>(job.patch_cache) + static_cast<size_t>(32) * pitch : s_dy_l;
+
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 7; q++) s_T[wave][q] = job.T[q];
+  }
+#ifdef SDVL_IA_STAMPS
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last_ = __builtin_amdgcn_s_memtime();
+#endif
+  double chi2 = 1e10, error = 1e10;
+  bool stop = false;
+  int n_meas = 0, iters_run = 0;
+  int its0 = 0, its1 = 0, its2 = 0, its3 = 0, its4 = 0, its5 = 0, its6 = 0, its7 = 0;
+
+  for (int r = 0; r < rounds; r++) {
+    const int f = (r * kWaves + wave) * 64 + lane;
+    if (f < nf) {
+      const sdvl_align_feature ft = F[f];
+      const V3 xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+      s_x[f] = xyz.x;
+      s_x[max_f + f] = xyz.y;
+      s_x[2 * max_f + f] = xyz.z;
+      s_x[3 * max_f + f] = 1. / xyz.z;  // z_inv of Jacobian3DToPlane, extra/utils.cc:103
+      s_flag[f] = ft.valid ? 1 : 0;
+    }
+  }
+  int eval = 0;  // parity of the partial-sum buffers
+  IA_STAMP(0);
+
+  for (int level = prm.max_level; level >= prm.min_level; level--) {
+    const int W = job.lw[level], H = job.lh[level];
+    const uint8_t *ref_img = job.ref_level[level];
+    const uint8_t *cur_img = job.cur_level[level];
+    const float scale = 1.0f / (1 << level);
+    const double fl = cam.fx / (1 << level);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 7; q++) s_Tbk[wave][q] = s_T[wave][q];
+    }
+    // ---- PrecomputePatches(level), image_align.cc:208-267
+    for (int r = 0; r < rounds; r++) {
+      const int f = (r * kWaves + wave) * 64 + lane;
+      if (f >= nf) continue;
+      const int flag = s_flag[f];
+      const float u_ref = static_cast<float>(F[f].px * scale);
+      const float v_ref = static_cast<float>(F[f].py * scale);
+      const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
+      const int border = 3;
+      if (!(flag & 1) || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) {
+        // jacobian_cache_.setZero() (image_align.cc:69): a feature seen at a coarser level that fails this level's border test would
+        // keep its old patch and a zero Jacobian (it cannot happen coarse-to-fine; kept for the reference's semantics)
+        if (flag & kIaVis) {
+#pragma unroll
+          for (int p = 0; p < 16; p++) {
+            it_pd[p * pitch + f].y = 0.f;
+            it_dy[p * pitch + f] = 0.f;
+          }
+          s_S[f] = 0.0; s_S[max_f + f] = 0.0; s_S[2 * max_f + f] = 0.0;
+        }
+        continue;
+      }
+      s_flag[f] = static_cast<uint8_t>(flag | kIaVis);
+      const float su = u_ref - ui, sv = v_ref - vi;
+      const float w_tl = static_cast<float>((1.0 - su) * (1.0 - sv));
+      const float w_tr = static_cast<float>(su * (1.0 - sv));
+      const float w_bl = static_cast<float>((1.0 - su) * sv);
+      const float w_br = su * sv;
+      // g[y][x] = the bilinear sum whose top-left pixel is (ui - 3 + x, vi - 3 + y): patch value of pixel (px, py) = g[py+1][px+1],
+      // dx = 0.5 (g[py+1][px+2] - g[py+1][px]), dy = 0.5 (g[py+2][px+1] - g[py][px+1]) — the reference's own five expressions
+      const uint8_t *wp = ref_img + static_cast<size_t>(vi - 3) * W + (ui - 3);
+      float g[3][6];  // rolling: rows y-2, y-1, y of the grid
+      float ra[7], rb[7];
+      {
+        uint32_t lo, hi;
+        ia_load_row8(wp, 7, &lo, &hi);
+#pragma unroll
+        for (int k = 0; k < 4; k++) ra[k] = ia_byte(lo, k);
+#pragma unroll
+        for (int k = 4; k < 7; k++) ra[k] = ia_byte(hi, k - 4);
+      }
+      double sxx = 0.0, sxy = 0.0, syy = 0.0;
+#pragma unroll
+      for (int y = 0; y < 6; y++) {
+        uint32_t lo, hi;
+        ia_load_row8(wp + static_cast<size_t>(y + 1) * W, 7, &lo, &hi);
+#pragma unroll
+        for (int k = 0; k < 4; k++) rb[k] = ia_byte(lo, k);
+#pragma unroll
+        for (int k = 4; k < 7; k++) rb[k] = ia_byte(hi, k - 4);
+#pragma unroll
+        for (int x = 0; x < 6; x++) g[y % 3][x] = w_tl * ra[x] + w_tr * ra[x + 1] + w_bl * rb[x] + w_br * rb[x + 1];
+#pragma unroll
+        for (int k = 0; k < 7; k++) ra[k] = rb[k];
+        if (y >= 2) {  // grid rows y-2, y-1, y are there: patch row py = y - 2
+          const int py = y - 2;
+#pragma unroll
+          for (int px = 0; px < 4; px++) {
+            const float patch = g[(y - 1) % 3][px + 1];
+            const float dx = 0.5f * (g[(y - 1) % 3][px + 2] - g[(y - 1) % 3][px]);
+            const float dy = 0.5f * (g[y % 3][px + 1] - g[(y - 2) % 3][px + 1]);
+            it_pd[(py * 4 + px) * pitch + f] = make_float2(patch, dx);
+            it_dy[(py * 4 + px) * pitch + f] = dy;
+            const double ddx = dx, ddy = dy;
+            sxx += ddx * ddx;
+            sxy += ddx * ddy;
+            syy += ddy * ddy;
+          }
+        }
+      }
+      s_S[f] = sxx;
+      s_S[max_f + f] = sxy;
+      s_S[2 * max_f + f] = syy;
+    }
+
+    IA_STAMP(1);
+    for (int it = 0; it < prm.max_its; it++) {
+      const int b = eval & 1;
+      eval++;
+      ia_wave_fence();
+      M3 R;
+      V3 Tt;
+      {
+        const Rigid T = se3_from7(s_T[wave]);
+        R = se3_rot(T);
+        Tt = T.t;
+      }
+      // ---- ComputeResiduals, image_align.cc:127-206
+      double acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] = 0.0;
+      bool chg = false;
+      for (int r = 0; r < rounds; r++) {
+        const int f = (r * kWaves + wave) * 64 + lane;
+        if (f >= nf) continue;
+        const int flag = s_flag[f];
+        if (!(flag & kIaVis)) continue;
+        const double X = s_x[f], Y = s_x[max_f + f], Z = s_x[2 * max_f + f];
+        const V3 xc = {R.m[0] * X + R.m[1] * Y + R.m[2] * Z + Tt.x, R.m[3] * X + R.m[4] * Y + R.m[5] * Z + Tt.y,
+                       R.m[6] * X + R.m[7] * Y + R.m[8] * Z + Tt.z};
+        const V2 pr = cam_project(cam, xc);
+        const float u_cur = static_cast<float>(pr.x * scale);
+        const float v_cur = static_cast<float>(pr.y * scale);
+        const float fu = floorf(u_cur), fv = floorf(v_cur);
+        // (int)floorf of NaN / huge values is undefined on the CPU; treat anything outside the image as a miss
+        const bool ok = fu >= 3.f && fv >= 3.f && fu < static_cast<float>(W - 3) && fv < static_cast<float>(H - 3);
+        if (ok != ((flag & kIaOk) != 0)) {
+          chg = true;
+          s_flag[f] = static_cast<uint8_t>(ok ? (flag | kIaOk) : (flag & ~kIaOk));
+        }
+        if (!ok) continue;
+        const int ui = static_cast<int>(fu), vi = static_cast<int>(fv);
+        const float su = u_cur - ui, sv = v_cur - vi;
+        const float w0 = static_cast<float>((1.0 - su) * (1.0 - sv));
+        const float w1 = static_cast<float>(su * (1.0 - sv));
+        const float w2 = static_cast<float>((1.0 - su) * sv);
+        const float w3 = su * sv;
+        const uint8_t *wp = cur_img + static_cast<size_t>(vi - 2) * W + (ui - 2);
+        float ra[5], rb[5];
+        {
+          uint32_t lo, hi;
+          ia_load_row8(wp, 5, &lo, &hi);
+#pragma unroll
+          for (int k = 0; k < 4; k++) ra[k] = ia_byte(lo, k);
+          ra[4] = ia_byte(hi, 0);
+        }
+        double A = 0.0, B = 0.0, c2 = 0.0;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          uint32_t lo, hi;
+          ia_load_row8(wp + static_cast<size_t>(y + 1) * W, 5, &lo, &hi);
+#pragma unroll
+          for (int k = 0; k < 4; k++) rb[k] = ia_byte(lo, k);
+          rb[4] = ia_byte(hi, 0);
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const float intensity = w0 * ra[x] + w1 * ra[x + 1] + w2 * rb[x] + w3 * rb[x + 1];
+            const float2 pd = it_pd[(y * 4 + x) * pitch + f];
+            const float dy = it_dy[(y * 4 + x) * pitch + f];
+            const float res = intensity - pd.x;
+            const double dres = res;
+            A += static_cast<double>(pd.y) * dres;
+            B += static_cast<double>(dy) * dres;
+            c2 += static_cast<double>(res * res);
+          }
+#pragma unroll
+          for (int k = 0; k < 5; k++) ra[k] = rb[k];
+        }
+        double fj[12];
+        {  // Jacobian3DToPlane with the stored 1/z, extra/utils.cc:99-118
+          const double z_inv = s_x[3 * max_f + f], z_inv_2 = z_inv * z_inv;
+          fj[0] = -z_inv; fj[1] = 0.0; fj[2] = X * z_inv_2; fj[3] = Y * fj[2]; fj[4] = -(1.0 + X * fj[2]); fj[5] = Y * z_inv;
+          fj[6] = 0.0; fj[7] = -z_inv; fj[8] = Y * z_inv_2; fj[9] = 1.0 + Y * fj[8]; fj[10] = -fj[3]; fj[11] = -X * z_inv;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[c] -= (A * fj[c] + B * fj[6 + c]) * fl;
+        acc[6] += c2;
+        acc[7] += 16.0;
+      }
+      IA_STAMP(2);
+      {
+        const bool any_chg = __any(chg ? 1 : 0) != 0;
+        const double tot = wave_reduce_n<8>(acc, lane);
+        if ((lane & 7) == 0) s_red[b][wave][(lane >> 3) & 7] = tot;
+        if (lane == 0) s_chg[b][wave] = any_chg ? 1 : 0;
+      }
+      if (kWaves > 1) __syncthreads(); else ia_wave_fence();
+      double Jres[6], sum_c2 = 0.0, sum_n = 0.0;
+      bool changed = false;
+      {
+        double s8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) s8[i] = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) s8[i] += s_red[b][w][i];
+          changed = changed || s_chg[b][w] != 0;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) Jres[c] = s8[c];
+        sum_c2 = s8[6];
+        sum_n = s8[7];
+      }
+      const bool rebuild_h = it == 0 || changed;
+      IA_STAMP(3);
+      if (rebuild_h) {
+        // H = sum over the contributing features of G^T S G (see the head of this section); it changes only with that set
+        double h16[16], h8[8];
+#pragma unroll
+        for (int i = 0; i < 16; i++) h16[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) h8[i] = 0.0;
+        for (int r = 0; r < rounds; r++) {
+          const int f = (r * kWaves + wave) * 64 + lane;
+          if (f >= nf) continue;
+          if (!(s_flag[f] & kIaOk) || !(s_flag[f] & kIaVis)) continue;
+          const double X = s_x[f], Y = s_x[max_f + f];
+          const double z_inv = s_x[3 * max_f + f], z_inv_2 = z_inv * z_inv;
+          double ga[6], gb[6];
+          {
+            const double j2 = X * z_inv_2, j3 = Y * j2, j8 = Y * z_inv_2;
+            ga[0] = -z_inv * fl; ga[1] = 0.0 * fl; ga[2] = j2 * fl; ga[3] = j3 * fl; ga[4] = -(1.0 + X * j2) * fl; ga[5] = (Y * z_inv) * fl;
+            gb[0] = 0.0 * fl; gb[1] = -z_inv * fl; gb[2] = j8 * fl; gb[3] = (1.0 + Y * j8) * fl; gb[4] = -j3 * fl; gb[5] = (-X * z_inv) * fl;
+          }
+          const double sxx = s_S[f], sxy = s_S[max_f + f], syy = s_S[2 * max_f + f];
+          double ma[6], mb[6];  // M = S G
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            ma[c] = sxx * ga[c] + sxy * gb[c];
+            mb[c] = sxy * ga[c] + syy * gb[c];
+          }
+          int k = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+            for (int c = rr; c < 6; c++) {
+              const double v = ga[rr] * ma[c] + gb[rr] * mb[c];
+              if (k < 16) h16[k] += v; else h8[k - 16] += v;
+              k++;
+            }
+        }
+        const double t16 = wave_reduce_n<16>(h16, lane);
+        const double t8 = wave_reduce_n<8>(h8, lane);
+        if ((lane & 3) == 0) s_redH[wave][(lane >> 2) & 15] = t16;
+        if ((lane & 7) == 0) s_redH[wave][16 + ((lane >> 3) & 7)] = t8;
+        if (kWaves > 1) __syncthreads(); else ia_wave_fence();
+        double Hm[36];
+        {
+          int k = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+            for (int c = rr; c < 6; c++) {
+              double s = 0.0;
+#pragma unroll
+              for (int w = 0; w < kWaves; w++) s += s_redH[w][k];
+              Hm[6 * rr + c] = s;
+              Hm[6 * c + rr] = s;
+              k++;
+            }
+        }
+        double La[36];
+        int tr[6];
+        ldlt_factor6_reg<true>(Hm, La, tr);
+        if (lane == 0) {
+          int k = 0;
+#pragma unroll
+          for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) s_L[wave][k++] = La[6 * i + j];
+#pragma unroll
+          for (int q = 0; q < 6; q++) s_tr[wave][q] = tr[q];
+        }
+        ia_wave_fence();
+      }
+      IA_STAMP(4);
+      // ---- Optimize body, image_align.cc:93-124 (every lane, uniform values)
+      double xs[6];
+      {
+        double La[36];
+        int tr[6];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j < 6; j++) La[6 * i + j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j <= i; j++) La[6 * i + j] = s_L[wave][k++];
+#pragma unroll
+        for (int q = 0; q < 6; q++) tr[q] = s_tr[wave][q];
+        ldlt_apply6_reg(La, tr, Jres, xs);
+      }
+      n_meas = static_cast<int>(sum_n);
+      iters_run++;
+      const double new_chi2 = static_cast<double>(static_cast<float>(sum_c2) / static_cast<float>(n_meas));
+      if (n_meas == 0) stop = true;
+      if (xs[0] != xs[0]) stop = true;
+      bool brk = false;
+      if ((it > 0 && new_chi2 > chi2) || stop) {
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 7; q++) s_T[wave][q] = s_Tbk[wave][q];
+        }
+        brk = true;
+      } else {
+        double mx[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) mx[r] = -xs[r];
+        const Rigid T0 = se3_from7(s_T[wave]);
+        const Rigid T1 = se3_mul(T0, ia_se3_exp(mx));
+        ia_wave_fence();  // every lane has read T before lane 0 replaces it
+        if (lane == 0) {
+          se3_to7(T0, s_Tbk[wave]);
+          se3_to7(T1, s_T[wave]);
+        }
+        chi2 = new_chi2;
+        switch (level) {
+          case 0: its0++; break; case 1: its1++; break; case 2: its2++; break; case 3: its3++; break;
+          case 4: its4++; break; case 5: its5++; break; case 6: its6++; break; default: its7++; break;
+        }
+        error = abs_max6(xs);
+        if (error <= 1e-10) brk = true;
+      }
+      IA_STAMP(5);
+      if (brk) break;
+    }
+    // image_align.cc:73-76
+    if (prm.fast && error > 0.01) {
+      error = 1e10;
+      break;
+    }
+  }
+  ia_wave_fence();
+  if (tid == 0) {
+    sdvl_align_result r;
+#pragma unroll
+    for (int q = 0; q < 7; q++) r.T[q] = s_T[0][q];
+    r.error = error;
+    r.chi2 = chi2;
+    r.n_meas = n_meas / 16;
+    r.its[0] = its0; r.its[1] = its1; r.its[2] = its2; r.its[3] = its3; r.its[4] = its4; r.its[5] = its5; r.its[6] = its6; r.its[7] = its7;
+    r.stop = stop ? 1 : 0;
+    r.iters_run = iters_run;
+    r.pad_ = 0;
+    out[job.out_index] = r;
+#ifdef SDVL_IA_STAMPS
+    if (blockIdx.x == 0) {
+      st_[6] = iters_run;
+      for (int q = 0; q < 7; q++) g_ia_stamps[q] = st_[q];
+    }
+    atomicMax(&g_ia_stamps[7], ((st_[0] + st_[1] + st_[2] + st_[3] + st_[4] + st_[5]) << 8) | static_cast<unsigned>(iters_run));
+#endif
+  }
+}
+
+size_t ia_wave_lds_bytes(int max_f, bool global_items) {
+  return static_cast<size_t>(max_f) * (7 * sizeof(double) + (global_items ? 0 : 48 * sizeof(float)) + 1) + 64;
+}
+size_t ia_wave_work_bytes(int nf) { return (static_cast<size_t>((nf + 63) / 64 * 64) * 48 * sizeof(float) + 255) / 256 * 256; }
+
 size_t ia_lds_bytes(int max_f) {
   return static_cast<size_t>(max_f) * (12 * sizeof(double) + 16 * sizeof(IaItem) + 2 * sizeof(int) + 4 * sizeof(float) + 5 * sizeof(double) + 4) + 64;
 }
@@ -626,6 +1152,15 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   // Jobs whose features fit the LDS-resident kernel run there; the (few) larger ones of the same call go to the global-memory
   // kernel in a second launch.  One oversized job used to send the whole batch to the slow kernel: with 256 trackers per
   // launch there is almost always a fresh keyframe with more than 384 features among them.
+  // round 4: the lane-per-feature kernels (image_align_wave_kernel) are the default; SDVL_IA_WAVE=0 brings the round-3 workgroup
+  // kernels back (A/B), SDVL_IA_WAVES=2|4 gives the LDS-sized jobs more than one wave
+  static const bool wave_form = !(getenv("SDVL_IA_WAVE") && atoi(getenv("SDVL_IA_WAVE")) == 0);
+  // The tracking-sized jobs keep their reference items in the work buffer too (L2-resident: 36 KB per job, every load coalesced
+  // over the wave's 64 features), not in LDS: alone the kernel takes the same 160-165 us per 256 jobs either way, but a workgroup
+  // that asks for 48 KB of LDS waits for a CU whose LDS the neighbours' small workgroups (fast_cells: 27 x 5.8 KB per CU) keep
+  // refilling — among the other streams' kernels 240 us per dispatch with 12 KB of LDS, 290 with 48 (the round-3 kernel: 74 KB,
+  // 290-320 us).  SDVL_IA_GLOBAL_ITEMS=0: items in LDS (A/B).
+  static const bool small_global = !(getenv("SDVL_IA_GLOBAL_ITEMS") && atoi(getenv("SDVL_IA_GLOBAL_ITEMS")) == 0);
   const bool force_generic = getenv("SDVL_IMAGE_ALIGN_GENERIC") != nullptr;
   const bool legacy = force_generic || getenv("SDVL_IMAGE_ALIGN_LEGACY_BIG") != nullptr;  // the round-1 global-memory kernel for the big jobs
   // jobs up to this many features keep their caches in LDS (SDVL_IA_LDS_MAX_F: experiments with the LDS / L2 trade-off)
@@ -656,9 +1191,11 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
       if (!force_generic && nf <= lds_max_f) {
         order[lo++] = j;
         if (nf > max_nf_lds) max_nf_lds = nf;
+        if (wave_form && small_global) work += ia_wave_work_bytes(nf);
       } else {
         order[--hi] = j;
-        work += legacy ? (static_cast<size_t>(nf) * 16 * (sizeof(float) + 6 * sizeof(double)) + 255) / 256 * 256 : ia_spill_work_bytes(nf);
+        work += legacy ? (static_cast<size_t>(nf) * 16 * (sizeof(float) + 6 * sizeof(double)) + 255) / 256 * 256
+                       : (wave_form ? ia_wave_work_bytes(nf) : ia_spill_work_bytes(nf));
         if (nf > max_nf_big) max_nf_big = nf;
       }
     }
@@ -697,6 +1234,10 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
       d.patch_cache = reinterpret_cast<float *>(wbase + woff + items * 6 * sizeof(double));
       woff += items * (sizeof(float) + 6 * sizeof(double));
       woff = (woff + 255) / 256 * 256;
+    } else if (wave_form && (q >= n_lds || small_global)) {  // the items of the job: {patch, dx}[16][pitch], dy[16][pitch], pitch = n_feat rounded up to 64
+      d.jac_cache = nullptr;
+      d.patch_cache = reinterpret_cast<float *>(wbase + woff);
+      woff += ia_wave_work_bytes(d.n_feat);
     } else if (q >= n_lds) {  // Jacobians [n_feat][12] doubles, then the items [n_feat][16] {patch, dx, dy}
       d.jac_cache = reinterpret_cast<double *>(wbase + woff);
       d.patch_cache = reinterpret_cast<float *>(wbase + woff + static_cast<size_t>(d.n_feat) * 12 * sizeof(double));
@@ -723,10 +1264,43 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
                                               static_cast<int>(ia_lds_bytes(kLdsMaxF + 16))));
       SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_lds_kernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_spill_lds_bytes(kMaxF + 16))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_wave_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kLdsMaxF, false))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_wave_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kLdsMaxF, false))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_wave_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kLdsMaxF + 128, false))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_wave_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
       attr_devices.fetch_or(bit, std::memory_order_release);
     }
   }
-  if (n_lds > 0) {
+  if (n_lds > 0 && wave_form) {
+    static const int ia_waves = getenv("SDVL_IA_WAVES") ? atoi(getenv("SDVL_IA_WAVES")) : 1;
+    const int kw = ia_waves == 4 ? 4 : (ia_waves == 2 ? 2 : 1);
+    const int max_f = (max_nf_lds + 64 * kw - 1) / (64 * kw) * (64 * kw) + (max_nf_lds == 0 ? 64 * kw : 0);
+    const size_t lds = ia_wave_lds_bytes(max_f, small_global);
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
+    if (small_global && kw == 4)
+      hipExtLaunchKernelGGL((image_align_wave_kernel<4, true>), dim3(n_lds), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+    else if (small_global && kw == 2)
+      hipExtLaunchKernelGGL((image_align_wave_kernel<2, true>), dim3(n_lds), dim3(128), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+    else if (small_global)
+      hipExtLaunchKernelGGL((image_align_wave_kernel<1, true>), dim3(n_lds), dim3(64), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+    else if (kw == 4)
+      hipExtLaunchKernelGGL((image_align_wave_kernel<4, false>), dim3(n_lds), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+    else if (kw == 2)
+      hipExtLaunchKernelGGL((image_align_wave_kernel<2, false>), dim3(n_lds), dim3(128), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+    else
+      hipExtLaunchKernelGGL((image_align_wave_kernel<1, false>), dim3(n_lds), dim3(64), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
+                            feats_dev, c, *p, max_f, dst);
+  } else if (n_lds > 0) {
     const int max_f = (max_nf_lds + 7) / 8 * 8 + 8;
     const size_t lds = ia_lds_bytes(max_f);
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -747,7 +1321,13 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
       hipExtLaunchKernelGGL((image_align_lds_kernel<false, 512>), dim3(n_lds), dim3(512), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
                             feats_dev, c, *p, max_f, dst);
   }
-  if (n_gen > 0 && legacy) {
+  if (n_gen > 0 && wave_form && !legacy) {
+    const int max_f = (max_nf_big + 255) / 256 * 256;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    sdvl_timer_events(ctx, "image_align_big", &ev_a, &ev_b);
+    hipExtLaunchKernelGGL((image_align_wave_kernel<4, true>), dim3(n_gen), dim3(256), ia_wave_lds_bytes(max_f, true), ctx->stream, ev_a, ev_b, 0,
+                          static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, max_f, dst);
+  } else if (n_gen > 0 && legacy) {
     SDVL_LAUNCH(ctx, "image_align_big", image_align_kernel, dim3(n_gen), dim3(kThreads), static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, dst);
   } else if (n_gen > 0) {
     const int max_f = (max_nf_big + 7) / 8 * 8 + 8;
@@ -794,3 +1374,9 @@ extern "C" int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job 
   if (rc) return rc;
   return sdvl_image_align_end(ctx, n_jobs, out);
 }
+
+#ifdef SDVL_IA_STAMPS
+extern "C" int sdvl_debug_ia_stamps(unsigned long long *out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ia_stamps), 64) == hipSuccess ? 0 : -1;
+}
+#endif

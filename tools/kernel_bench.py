@@ -49,6 +49,8 @@ for j in range(n):
         f.px, f.py = px[i]; f.fx, f.fy, f.fz = b[i]; f.depth = 2.0 / b[i, 2]; f.valid = 1
 jobs = [(fr0[j], fr3[j], j * nf, (j + 1) * nf, [1, 0, 0, 0, 0, 0, 0]) for j in range(n)]
 ap = sdvl.default_align_params()
+if os.environ.get('SDVL_KB_MAX_ITS'):
+    ap.max_its = int(os.environ['SDVL_KB_MAX_ITS'])
 ctx.timing_enable(True)
 ctx.timing_reset()
 its = 0
@@ -58,6 +60,10 @@ for _ in range(reps):
     ctx._check(lib.sdvl_orb_describe(ctx.h, n, arr0, 4096, None))
     res = ctx.image_align(jobs, feats, cam, ap)
     its += sum(r.iters_run for r in res)
+if hasattr(lib, 'sdvl_debug_ia_stamps'):
+    st = (C.c_ulonglong * 8)()
+    lib.sdvl_debug_ia_stamps(st)
+    print('ia stamps job0 (ticks): prologue %d precompute %d pass1 %d reduce %d rebuildH %d solve %d evals %d' % tuple(st[:7]), 'slowest job: %d ticks, %d evals' % (st[7] >> 8, st[7] & 255))
 # input stage: cv::undistort of n raw frames already in HBM (TUM fr1 coefficients) into the frames' level 0
 import ctypes as _C
 dist = sdvl.Distortion((_C.c_double * 5)(0.2624, -0.9531, -0.0054, 0.0026, 1.1633))
