@@ -188,8 +188,10 @@ int sdvl_ctx_prefetch_fence(sdvl_ctx *ctx, int ticket);
 typedef struct sdvl_feed sdvl_feed;
 int sdvl_feed_create(int device, int n_slots, sdvl_feed **out);
 int sdvl_feed_destroy(sdvl_feed *f);
+/* the message of the CALLING thread's last failed sdvl_feed_* call (the feeder and the consumers report independently) */
 const char *sdvl_feed_last_error(const sdvl_feed *f);
-/* 1: the slot's last transfer (sdvl_feed_images) has arrived in HBM, 0: still under way (a consumer that acquires it now will wait) */
+/* 1: the slot's last transfer (sdvl_feed_images) has arrived in HBM, 0: still under way (a consumer that acquires it now will wait).
+ * Only meaningful after a sdvl_feed_images for that slot: a slot that was never fed also reads 1 (nothing is under way). */
 int sdvl_feed_slot_arrived(sdvl_feed *f, int slot);
 int sdvl_feed_images(sdvl_feed *f, int slot, int n, const uint8_t *const *imgs, int stride, int width, int height, void *const *dev_dst);
 int sdvl_ctx_feed_acquire(sdvl_ctx *ctx, sdvl_feed *f, int slot);
@@ -284,8 +286,10 @@ int sdvl_filter_corners_end(sdvl_ctx *ctx, int n, int cap, int32_t *counts, sdvl
 /* ORBDetector::Distance (extra/orb_detector.cc:398-410) batched with the arg-min of Matcher::SearchFeatures
  * (matcher.cc:254-289): query i (32 B) is compared with the candidates cand_desc[cand_offsets[i] .. cand_offsets[i+1]);
  * best_index[i] = position within that list of the FIRST smallest Hamming distance, or -1 when that distance is not below
- * `threshold` (MIN_ORB_THRESHOLD = 100, matcher.h:37) or the list is empty; best_dist[i] (may be NULL) = that distance,
- * threshold+1 for an empty list or when every candidate is above threshold.  All pointers are host memory; blocking. */
+ * `threshold` (MIN_ORB_THRESHOLD = 100, matcher.h:37) or the list is empty (strict '<' between candidates, '>= threshold' means
+ * not found, as matcher.cc:280-288); best_dist[i] (may be NULL) = min(smallest distance, threshold + 1): the true minimum whenever
+ * it is <= threshold (so distance == threshold comes back with index -1), threshold + 1 for an empty list or when every candidate
+ * is further away.  All pointers are host memory; blocking. */
 int sdvl_hamming_argmin(sdvl_ctx *ctx, int n, const uint8_t *queries, const int32_t *cand_offsets, const uint8_t *cand_desc,
                         int threshold, int32_t *best_index, int32_t *best_dist);
 /* ORBDetector::GetDescriptor at arbitrary (x,y,level) points of one frame; out_angle_deg may be NULL */

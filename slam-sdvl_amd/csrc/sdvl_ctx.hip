@@ -762,8 +762,12 @@ struct sdvl_feed {
   int device = 0;
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> ready, released;
-  std::string err;
+  // the feeder thread (sdvl_feed_images) and the consumers' threads (sdvl_feed_slot_arrived) both report here: the message of a
+  // failed call is kept per calling thread, so that one thread's failure is neither torn nor replaced by another's
+  void fail(const std::string &m) const;
 };
+thread_local std::string t_feed_err;
+void sdvl_feed::fail(const std::string &m) const { t_feed_err = m; }
 
 int sdvl_feed_create(int device, int n_slots, sdvl_feed **out) {
   if (!out || n_slots <= 0) return SDVL_ERR_INVALID;
@@ -809,13 +813,13 @@ int sdvl_feed_destroy(sdvl_feed *f) {
   return SDVL_OK;
 }
 
-const char *sdvl_feed_last_error(const sdvl_feed *f) { return f ? f->err.c_str() : "null feed"; }
+const char *sdvl_feed_last_error(const sdvl_feed *f) { return f ? t_feed_err.c_str() : "null feed"; }
 
 #define SDVL_FEED_CHECK(f, expr)                                        \
   do {                                                                  \
     hipError_t e_ = (expr);                                             \
     if (e_ != hipSuccess) {                                             \
-      (f)->err = std::string(#expr) + ": " + hipGetErrorString(e_);     \
+      (f)->fail(std::string(#expr) + ": " + hipGetErrorString(e_));     \
       return SDVL_ERR_HIP;                                              \
     }                                                                   \
   } while (0)
@@ -827,7 +831,7 @@ int sdvl_feed_images(sdvl_feed *f, int slot, int n, const uint8_t *const *imgs, 
   SDVL_FEED_CHECK(f, hipStreamWaitEvent(f->stream, f->released[slot], 0));  // never recorded yet: no wait
   const size_t fb = static_cast<size_t>(width) * height;
   for (int i = 0; i < n;) {
-    if (!imgs[i] || !dev_dst[i]) { f->err = "null image or destination"; return SDVL_ERR_INVALID; }
+    if (!imgs[i] || !dev_dst[i]) { f->fail("null image or destination"); return SDVL_ERR_INVALID; }
     int run = 1;  // dense images that follow each other on both sides travel as ONE transfer
     if (stride == width)
       while (i + run < n && imgs[i + run] == imgs[i] + run * fb && dev_dst[i + run] == static_cast<uint8_t *>(dev_dst[i]) + run * fb) run++;
@@ -844,7 +848,7 @@ int sdvl_feed_slot_arrived(sdvl_feed *f, int slot) {
   const hipError_t e = hipEventQuery(f->ready[slot]);
   if (e == hipSuccess) return 1;
   if (e == hipErrorNotReady) return 0;
-  f->err = std::string("hipEventQuery: ") + hipGetErrorString(e);
+  f->fail(std::string("hipEventQuery: ") + hipGetErrorString(e));
   return SDVL_ERR_HIP;
 }
 

@@ -7,6 +7,8 @@
 //                           ordered (row-major = cv::FAST scan order) compaction by a block prefix sum.
 //       compact_cells_kernel: per frame exclusive scan of the cell counts + gather into a dense list.
 // Integer arithmetic only: results are bit-exact against the oracle.
+#include <atomic>
+
 #include "sdvl_internal.h"
 
 namespace {
@@ -1456,7 +1458,13 @@ __global__ __launch_bounds__(256) void select_pack_kernel(const SelJob *__restri
     if (batch_counts) batch_counts[blockIdx.x] = total;
     if (host_counts) host_counts[blockIdx.x] = total;
   }
-  if (bad) return;
+  if (bad) {
+    // an overflowed frame has NO corners: its bins must say so too — a tracked step's search for this frame is already queued and
+    // walks the bins without looking at the corner count (stale offsets of the pooled frame's previous life otherwise)
+    for (int c = tid; c <= cells; c += 256)
+      if (cells > 0) job.bin_start[c] = 0;
+    return;
+  }
   int4 *out = reinterpret_cast<int4 *>(job.corner_hdr + 4);
   const auto cell_of = [&](uint32_t v, int l) {
     const int x = min(static_cast<int>(v & 0xFFF) << l, job.lw[0] - 1), y = min(static_cast<int>((v >> 12) & 0xFFF) << l, job.lh[0] - 1);
@@ -1901,9 +1909,18 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
   // writes them into device memory and, when results go direct, into the pinned host array as well
   const bool direct = sdvl_direct_results() && sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK;
-  if (pack_lds > (48u << 10) && ctx->pack_lds_limit < pack_lds) {  // beyond the default dynamic-LDS limit: raise it once for this size
-    SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(select_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(pack_lds)));
+  if (pack_lds > (48u << 10)) {
+    // beyond the default dynamic-LDS limit.  The attribute belongs to the kernel object of a DEVICE, not to a context: it is raised
+    // once per device to the most any configuration can ask for (the CU's 160 KB less the kernel's static LDS), whichever thread
+    // gets there first — a per-context "already raised" mark let a second context with a smaller size lower it again
+    static std::atomic<unsigned long long> attr_devices{0};
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(select_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(152u << 10)));
+      attr_devices.fetch_or(bit, std::memory_order_release);
+    }
+    SDVL_REQUIRE(ctx, pack_lds <= (152u << 10), "selection lists of this configuration do not fit a compute unit's LDS");
     ctx->pack_lds_limit = pack_lds;
   }
   {

@@ -430,10 +430,13 @@ struct Farm {
     return sdvlh_batch_step_device(batches[g], dev_frames + off, stride, out + off);
   }
 
+  // the message of a failed group-step: the calling thread's own last error (thread-local), never another thread's
+  static std::string StepError() { return sdvlh_last_error(); }
+
   void FinishGroup(int g, int rc) {
     {
       std::lock_guard<std::mutex> lk(m);
-      if (rc != 0) { failed = true; err = sdvlh_last_error(); }
+      if (rc != 0 && !failed) { failed = true; err = StepError(); }  // the first error is the cause; later ones are its echoes
       done[g]++;
       busy[g] = 0;
     }
@@ -477,7 +480,7 @@ struct Farm {
         const int a = sdvl_feed_slot_arrived(feed, in_flight.front());
         if (a < 0) {
           std::lock_guard<std::mutex> lk(m);
-          failed = true; err = std::string("input ring: ") + sdvl_feed_last_error(feed);
+          if (!failed) { failed = true; err = std::string("input ring: ") + sdvl_feed_last_error(feed); }
           cv_feed.notify_all();
           return;
         }
@@ -500,7 +503,7 @@ struct Farm {
       if (!step_marks.empty()) feed_marks.push_back(FeedMark{g, s, tm0, Since()});
       {
         std::lock_guard<std::mutex> lk(m);
-        if (rc != SDVL_OK) { failed = true; err = std::string("input ring: ") + sdvl_feed_last_error(feed); }
+        if (rc != SDVL_OK && !failed) { failed = true; err = std::string("input ring: ") + sdvl_feed_last_error(feed); }
         issued[g]++;
       }
       cv_feed.notify_all();
@@ -528,7 +531,7 @@ struct Farm {
         {
           std::lock_guard<std::mutex> lk(m);
           done[worker]++;
-          if (rc != 0) { failed = true; err = sdvlh_last_error(); }
+          if (rc != 0 && !failed) { failed = true; err = StepError(); }
         }
         cv_feed.notify_all();
         if (rc != 0) return;
@@ -674,7 +677,7 @@ void Farm::RunShareFibers(int worker, int n_workers) {
       progressed = true;
       if (f.finished) {
         if (f.whole_run) {
-          if (f.rc != 0) { std::lock_guard<std::mutex> lk(m); failed = true; err = sdvlh_last_error(); }
+          if (f.rc != 0) { std::lock_guard<std::mutex> lk(m); if (!failed) { failed = true; err = StepError(); } }
         } else {
           FinishGroup(f.group, f.rc);
         }
@@ -688,8 +691,10 @@ void Farm::RunShareFibers(int worker, int n_workers) {
         for (Fiber &f : fibers)
           if (f.group >= 0 && f.waiting_on && sdvl_ctx_health(f.waiting_on) != SDVL_OK) {
             std::lock_guard<std::mutex> lk(m);
-            failed = true;
-            err = std::string("GPU fault while a group-step was waiting: ") + sdvl_last_error(f.waiting_on);
+            if (!failed) {
+              failed = true;
+              err = std::string("GPU fault while a group-step was waiting: ") + sdvl_last_error(f.waiting_on);
+            }
           }
         bool stop;
         { std::lock_guard<std::mutex> lk(m); stop = failed; }

@@ -2272,15 +2272,41 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   g_stage_times = &stage_times;
   stage_times.steps++;
   const auto t_begin = std::chrono::steady_clock::now();
-  if (!HandleFramesTracked(imgs, stats)) {
+  // A transient image (level 0 aliases a ring slot the caller rewrites) is safe only while nobody reads a frame's level 0 after
+  // the frame's own step.  Two configurations break that:
+  //  * a mapper THREAD consumes the frames handed to AddFrame after the step, on its own stream: such a batch takes a copy of
+  //    every image when the frame is built (the aliasing is refused);
+  //  * SDVL.min_alignLevel 0: the next step's image alignment reads last_frame's level 0 (image_align.cc:212): last_frame copies
+  //    its image out at the end of the step like a fresh keyframe does.
+  bool threaded_mapper = false;
+  for (SDVL *t : trk_) {
+    MapperMap *m = dynamic_cast<MapperMap *>(t->map_);
+    if (m && m->IsThreaded()) threaded_mapper = true;
+  }
+  vector<Image> owned;
+  if (threaded_mapper) {
+    bool any = false;
+    for (const Image &im : imgs) any = any || im.transient;
+    if (any) {
+      owned = imgs;
+      for (Image &im : owned) {
+        if (im.transient) { im.transient = false; im.borrow = false; }
+      }
+    }
+  }
+  const vector<Image> &in = owned.empty() ? imgs : owned;
+  if (!HandleFramesTracked(in, stats)) {
     SyncHostState();  // Feature lists and Point counters catch up with the device; the tables are rebuilt when tracking returns
-    HandleFramesGeneric(imgs, stats);
+    HandleFramesGeneric(in, stats);
   }
   {  // frames that became keyframes while their image sat in an input-ring slot keep a copy; everybody else never copied level 0
      // (the step's own frame pointer is gone by now: a fresh keyframe is the tracker's last_kf_, sdvl.cc:113)
+    const bool keep_last = Config::MinAlignLevel() == 0;
     vector<shared_ptr<Frame>> keep;
-    for (SDVL *t : trk_)
+    for (SDVL *t : trk_) {
       if (t->last_kf_ && t->last_kf_->ImageTransient()) keep.push_back(t->last_kf_);
+      if (keep_last && t->last_frame_ && t->last_frame_ != t->last_kf_ && t->last_frame_->ImageTransient()) keep.push_back(t->last_frame_);
+    }
     if (!keep.empty()) Frame::OwnImages(keep);
   }
   stage_times.t[ST_TOTAL] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

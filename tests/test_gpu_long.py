@@ -218,3 +218,66 @@ def test_pgm_list_with_the_euroc_configuration(orc, synth, tmp_path):
     few = [row for row in got if 5 <= int(row[3]) < 20]
     assert few and all(int(row[2]) != 2 for row in few), [row[:4] for row in got]   # between EuRoC's 5 and the default 20: not TRACKING_BAD
     assert int(got[-1][3]) >= 100                                    # and the full frames after them are tracked again
+
+
+def test_host_fed_farm_of_512_trackers_over_whole_sequences_equals_the_oracle(trk, orc, synth):
+    """The sustained leg of bench.py as a parity run (main.cc:126-159 loops over the whole sequence): a HOST-FED
+    farm — feeder thread, three-slot input ring, frames that alias their ring slot, keyframes copying their image out
+    (sdvl_frames_own_images) — of 2 groups x 256 trackers over all 300 frames of S-A, 8 distinct sequences from a pinned pool
+    (tracker i follows sequence i mod 8, as the bench's trackers follow i mod 32).  Every replica of a sequence gives the same
+    per-frame record, bit for bit, wherever it sits; the 8 distinct ones equal the CPU oracle at every one of the 300 frames
+    (decisions exact, poses within 1e-4).  ~69 keyframes per tracker are created, kept and searched against on the way."""
+    import ctypes as C
+    import torch
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    G, Bg, NF, D = 2, 256, 300, 8
+    n = G * Bg
+    fb = 640 * 480
+    trk.configure()
+    farm = trk.TrackerFarm(0, G, Bg, 640, 480, TUM_CAM)
+    ctx = B.CtxView(sdvl, farm.ctx_handle(0))
+    lib = sdvl.load_library()
+    xis = [XI * (1.0 + 0.15 * d) * (1 if d % 2 == 0 else -1) for d in range(D)]
+    pool = torch.empty(D * NF * fb, dtype=torch.uint8, pin_memory=True)
+    tmp = ctx.malloc(D * fb)
+    for k in range(NF):
+        views = [B.make_view(sdvl, trajectory_pose(orc, k, xis[d]), 20260201 + d, k) for d in range(D)]
+        ctx.render(views, tmp)
+        ctx.check(lib.sdvl_device_download(ctx.h, C.c_void_p(tmp), C.c_int64(D * fb), C.c_void_p(pool.data_ptr() + k * D * fb)))
+    ctx.check(lib.sdvl_device_free(ctx.h, C.c_void_p(tmp)))
+    which = np.arange(n, dtype=np.uint64) % D
+    ptrs = (pool.data_ptr() + (np.arange(NF, dtype=np.uint64)[:, None] * D + which[None, :]) * fb).astype(np.uint64)
+    farm.set_input_ring(True)
+    farm.set_host_input(True)
+    farm.reserve(Bg * (NF // 4 + 8))
+    st = farm.run(ptrs, G)
+    rec = [(s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas, tuple(s.pose[:])) for s in st]
+    farm.set_host_input(False)
+    farm.close()
+    assert len(rec) == NF * n
+    # replicas: tracker i and tracker i mod D ran the same images
+    for k in range(NF):
+        row = rec[k * n:(k + 1) * n]
+        for i in range(D, n):
+            assert row[i] == row[i % D], (k, i)
+    frames = pool.numpy().reshape(NF, D, 480, 640)
+
+    def check(d):
+        o = orc.tracker(640, 480, TUM_CAM)
+        n_kf = 0
+        for k in range(NF):
+            want = o.handle_frame(frames[k, d])
+            g = rec[k * n + d]
+            assert g[:9] == (want.state, want.quality, want.keyframe, want.n_corners, want.matches, want.attempts, want.inliers, want.outliers,
+                             want.align_meas), (k, d, g[:9])
+            assert np.abs(np.array(g[9]) - np.array(want.pose[:])).max() <= POSE_TOL, (k, d)
+            if k > 0:
+                assert g[1] == 0 and g[4] >= 100, (k, d)
+            n_kf += g[2]
+        o.close()
+        return n_kf
+
+    with ThreadPoolExecutor(max_workers=min(D, max(1, (os.cpu_count() or 2) // 2))) as ex:   # the oracle releases the GIL inside its calls
+        kfs = list(ex.map(check, range(D)))
+    assert min(kfs) >= 50, kfs

@@ -247,6 +247,66 @@ def test_transient_ring_images_equal_resident_images(trk, orc, synth):
     assert all(r[1] == 0 and r[4] >= 100 for r in resident[n:])
 
 
+def test_transient_images_with_min_align_level_0_on_a_one_slot_ring(trk, orc, synth):
+    """SDVL.min_alignLevel 0 is legal (config.cc:146): the next step's image alignment then reads last_frame's LEVEL 0
+    (image_align.cc:212).  With transient images that level aliases a ring slot; here the ring has ONE slot, rewritten before
+    every step, so a frame that did not take its image out at the end of its own step (only keyframes did) is
+    aligned against the NEXT image.  Results must equal those of frames that alias images resident for good, and the oracle's
+    with the same configuration."""
+    import ctypes as C
+    import importlib
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    n, n_steps = 2, 9
+    fb = 640 * 480
+    over = dict(trk.TUM_OVERRIDES)
+    over["SDVL.min_alignLevel"] = 0
+    trk.configure(over)
+    old = orc.params.min_align_level
+    orc.params.min_align_level = 0
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    try:
+        def run(mode):
+            dev = trk.HostDevice(0)
+            batch = trk.TrackerBatch(dev, n, 640, 480, TUM_CAM)
+            ctx = B.CtxView(sdvl, dev.ctx_handle())
+            buf = ctx.malloc(n * n_steps * fb)
+            slot = ctx.malloc(n * fb)
+            for k in range(n_steps):
+                views = [B.make_view(sdvl, trajectory_pose(orc, k, XI * (1.0 + 0.1 * i)), 20260001 + i, k) for i in range(n)]
+                ctx.render(views, buf + k * n * fb)
+            stream = C.c_void_p(ctx.lib.sdvl_ctx_stream(ctx.h))
+            out, imgs = [], []
+            for k in range(n_steps):
+                if mode == "resident":
+                    st = batch.step_device([buf + (k * n + i) * fb for i in range(n)])
+                else:
+                    assert hip.hipMemcpyAsync(slot, buf + k * n * fb, n * fb, 3, stream) == 0
+                    st = batch.step_device_transient([slot + i * fb for i in range(n)])
+                out += [(s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas, tuple(s.pose[:])) for s in st]
+            if mode == "resident":
+                imgs = [ctx.download(buf + (k * n) * fb, fb).reshape(480, 640).copy() for k in range(n_steps)]
+            batch.close()
+            dev.close()
+            return out, imgs
+
+        resident, imgs = run("resident")
+        ring, _ = run("ring")
+        assert ring == resident
+        assert all(r[1] == 0 and r[4] >= 100 for r in resident[n:])
+        o = orc.tracker(640, 480, TUM_CAM)
+        for k in range(n_steps):
+            want, g = o.handle_frame(imgs[k]), resident[k * n]
+            assert g[:9] == (want.state, want.quality, want.keyframe, want.n_corners, want.matches, want.attempts, want.inliers, want.outliers,
+                             want.align_meas), k
+            assert np.abs(np.array(g[9]) - np.array(want.pose[:])).max() <= POSE_TOL, k
+        o.close()
+    finally:
+        orc.params.min_align_level = old
+        trk.configure()
+
+
 def test_farm_host_input_ring_gives_identical_results(trk, orc, synth):
     """host-fed farm: frames in pinned host memory.  With the input ring (the images of step s + 1 travel on the group's copy
     stream while step s computes; contiguous runs as one DMA, the rest per image) and without it (every step uploads its own
@@ -288,14 +348,15 @@ def test_farm_host_input_ring_gives_identical_results(trk, orc, synth):
 
 
 def test_farm_at_bench_size_replicas_agree_and_match_the_oracle(trk, orc, synth):
-    """The bench configuration (2048 sequences, 16 groups of 128, one worker per group) on 8 distinct sequences replicated
-    256 times: where a sequence sits in a group, which group and which stream it runs on must not matter — every replica
-    gives the same per-frame record, bit for bit — and the 8 distinct ones equal the CPU oracle (decisions exact, poses
+    """The bench configuration (4096 sequences, 16 groups of 256, one worker per group: BENCH_rNN.json `config.groups` /
+    `sequences_per_group` — launch geometry, XCD dealing and block tables depend on the group size) on 8 distinct sequences
+    replicated 512 times: where a sequence sits in a group, which group and which stream it runs on must not matter — every
+    replica gives the same per-frame record, bit for bit — and the 8 distinct ones equal the CPU oracle (decisions exact, poses
     within 1e-4)."""
     import importlib
     sdvl = importlib.import_module("slam-sdvl_amd")
     import bench as B
-    G, Bg, n_steps, distinct = 16, 128, 6, 8
+    G, Bg, n_steps, distinct = 16, 256, 6, 8
     n = G * Bg
     trk.configure()
     farm = trk.TrackerFarm(0, G, Bg, 640, 480, TUM_CAM)
