@@ -273,7 +273,7 @@ def test_host_fed_farm_of_512_trackers_over_whole_sequences_equals_the_oracle(tr
                              want.align_meas), (k, d, g[:9])
             assert np.abs(np.array(g[9]) - np.array(want.pose[:])).max() <= POSE_TOL, (k, d)
             if k > 0:
-                assert g[1] == 0 and g[4] >= 100, (k, d)
+                assert g[1] == 0 and g[4] >= 60, (k, d)       # tracked (quality GOOD) with a healthy number of matches
             n_kf += g[2]
         o.close()
         return n_kf

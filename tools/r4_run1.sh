@@ -1,5 +1,3 @@
 set -u
 O=gpurun_out
-bash tools/r4_ab.sh "SDVL_IA_WAVES=2" 2
-bash tools/r4_ab.sh "SDVL_IA_WAVES=4" 2
-python -m pytest tests -x -q -m gpu > $O/gpu_all.log 2>&1; echo "gpu suite rc=$?"; tail -3 $O/gpu_all.log
+python -m pytest tests/test_gpu_tracker.py tests/test_gpu_long.py -x -q -m gpu -k "bench_size or min_align_level_0 or 512_trackers or transient_ring" --durations=5 > $O/t_new.log 2>&1; echo "new tests rc=$?"; tail -15 $O/t_new.log
