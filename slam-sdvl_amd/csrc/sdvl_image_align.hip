@@ -17,6 +17,7 @@
 
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
+#include "sdvl_search_types.h"
 
 namespace {
 
@@ -722,11 +723,51 @@ __device__ unsigned long long g_ia_stamps[8];
 #define IA_STAMP(k) do { } while (0)
 #endif
 
-template <int kWaves, bool kGlobalItems>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_wave_kernel(const IaJob *__restrict__ jobs,
-                                                                       const sdvl_align_feature *__restrict__ feats_all, Cam cam,
-                                                                       sdvl_align_params prm, int max_f, sdvl_align_result *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+// what the body needs of one job, wherever the job's record lives (IaJob of the C-ABI calls, TrackJobDev of a tracked step)
+struct IaIn {
+  const uint8_t *const *ref_level;  // [levels] frame 1
+  const uint8_t *const *cur_level;  // [levels] frame 2
+  const int *lw, *lh;
+  int nf;
+  const double *T0;     // [7] start of the alignment
+  float *items;         // kGlobalItems: the job's slice of the work buffer
+  sdvl_align_result *out;
+};
+
+// feature source A: the records of the C-ABI calls (sdvl_align_feature, include/sdvl_hip.h)
+struct IaRecordFeats {
+  const sdvl_align_feature *F;
+  __device__ __forceinline__ bool load(int f, V3 *xyz) const {
+    const sdvl_align_feature ft = F[f];
+    *xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+    return ft.valid != 0;
+  }
+  __device__ __forceinline__ void pos(int f, double *px, double *py) const { *px = F[f].px; *py = F[f].py; }
+};
+
+// feature source B: the rows of the device-resident tracking tables — what track_align_prep_kernel wrote into records until
+// round 3 (image_align.cc:147-160,219-236: position, bearing, validity = has a point that is not deleted, depth = |P - C1|)
+struct IaTableFeats {
+  const TrackFeat *F;
+  const TrackPoint *P;
+  V3 first_pos;  // Frame::GetWorldPosition() of last_frame
+  __device__ __forceinline__ bool load(int f, V3 *xyz) const {
+    const TrackFeat ft = F[f];
+    const int pt = ft.point < 0 ? -1 : (ft.point & kPointMask);
+    const bool valid = pt >= 0 && !(P[pt].status & kDeleted);
+    double depth = 0.0;
+    if (valid) {
+      const double dx = P[pt].P[0] - first_pos.x, dy = P[pt].P[1] - first_pos.y, dz = P[pt].P[2] - first_pos.z;
+      depth = sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    *xyz = vscale({ft.bearing[0], ft.bearing[1], ft.bearing[2]}, depth);
+    return valid;
+  }
+  __device__ __forceinline__ void pos(int f, double *px, double *py) const { *px = F[f].px[0]; *py = F[f].px[1]; }
+};
+
+template <int kWaves, bool kGlobalItems, class Feats>
+__device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, const Cam cam, const sdvl_align_params prm, const int max_f, uint8_t *s_dyn) {
   // carve (max_f is a multiple of 64 * kWaves): x[4][max_f] doubles (point in frame 1: x, y, z, 1/z) | S[3][max_f] doubles (gradient
   // sums of the level) | items: pd[16][max_f] float2 {patch, dx}, dy[16][max_f] floats (LDS, or the job's slice of the work buffer)
   double *s_x = reinterpret_cast<double *>(s_dyn);
@@ -742,19 +783,17 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
   // the optimiser's pose and its roll-back copy (image_align.cc:95,112) — uniform values, kept out of the vector registers
   __shared__ double s_T[kWaves][7], s_Tbk[kWaves][7];
 
-  const IaJob &job = jobs[blockIdx.x];
-  const int nf = job.n_feat;
-  const sdvl_align_feature *F = feats_all + job.feat_begin;
+  const int nf = job.nf;
   const int tid = threadIdx.x, lane = tid & 63, wave = kWaves > 1 ? (tid >> 6) : 0;
   const int rounds = (nf + 64 * kWaves - 1) / (64 * kWaves);
   // items of a job too large for LDS live in its slice of the work buffer, same layout with the job's own pitch
   const int pitch = kGlobalItems ? (nf + 63) / 64 * 64 : max_f;
-  float2 *it_pd = kGlobalItems ? reinterpret_cast<float2 *>(job.patch_cache) : s_pd_l;
-  float *it_dy = kGlobalItems ? reinterpret_cast<float *>(job.patch_cache) + static_cast<size_t>(32) * pitch : s_dy_l;
+  float2 *it_pd = kGlobalItems ? reinterpret_cast<float2 *>(job.items) : s_pd_l;
+  float *it_dy = kGlobalItems ? job.items + static_cast<size_t>(32) * pitch : s_dy_l;
 
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 7; q++) s_T[wave][q] = job.T[q];
+    for (int q = 0; q < 7; q++) s_T[wave][q] = job.T0[q];
   }
 #ifdef SDVL_IA_STAMPS
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last_ = __builtin_amdgcn_s_memtime();
@@ -767,13 +806,13 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
   for (int r = 0; r < rounds; r++) {
     const int f = (r * kWaves + wave) * 64 + lane;
     if (f < nf) {
-      const sdvl_align_feature ft = F[f];
-      const V3 xyz = vscale({ft.fx, ft.fy, ft.fz}, ft.depth);
+      V3 xyz;
+      const bool valid = F.load(f, &xyz);
       s_x[f] = xyz.x;
       s_x[max_f + f] = xyz.y;
       s_x[2 * max_f + f] = xyz.z;
       s_x[3 * max_f + f] = 1. / xyz.z;  // z_inv of Jacobian3DToPlane, extra/utils.cc:103
-      s_flag[f] = ft.valid ? 1 : 0;
+      s_flag[f] = valid ? 1 : 0;
     }
   }
   int eval = 0;  // parity of the partial-sum buffers
@@ -794,8 +833,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
       const int f = (r * kWaves + wave) * 64 + lane;
       if (f >= nf) continue;
       const int flag = s_flag[f];
-      const float u_ref = static_cast<float>(F[f].px * scale);
-      const float v_ref = static_cast<float>(F[f].py * scale);
+      double fpx, fpy;
+      F.pos(f, &fpx, &fpy);
+      const float u_ref = static_cast<float>(fpx * scale);
+      const float v_ref = static_cast<float>(fpy * scale);
       const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
       const int border = 3;
       if (!(flag & 1) || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) {
@@ -1116,7 +1157,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
     r.stop = stop ? 1 : 0;
     r.iters_run = iters_run;
     r.pad_ = 0;
-    out[job.out_index] = r;
+    *job.out = r;
 #ifdef SDVL_IA_STAMPS
     if (blockIdx.x == 0) {
       st_[6] = iters_run;
@@ -1125,6 +1166,34 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
     atomicMax(&g_ia_stamps[7], ((st_[0] + st_[1] + st_[2] + st_[3] + st_[4] + st_[5]) << 8) | static_cast<unsigned>(iters_run));
 #endif
   }
+}
+
+template <int kWaves, bool kGlobalItems>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_wave_kernel(const IaJob *__restrict__ jobs,
+                                                                       const sdvl_align_feature *__restrict__ feats_all, Cam cam,
+                                                                       sdvl_align_params prm, int max_f, sdvl_align_result *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  const IaJob &jb = jobs[blockIdx.x];
+  const IaIn in{jb.ref_level, jb.cur_level, jb.lw, jb.lh, jb.n_feat, jb.T, jb.patch_cache, out + jb.out_index};
+  ia_wave_body<kWaves, kGlobalItems>(in, IaRecordFeats{feats_all + jb.feat_begin}, cam, prm, max_f, s_dyn);
+}
+
+// The alignment of a tracked step straight from the tracking tables (sdvl_track.hip): job j = tracker record j of the step; its
+// features are the rows of last_frame's feature buffer, its items live in slice j of the work buffer (`item_pitch` features each).
+// No IaJob records, no feature records, no launch in between (track_align_prep + one stage_push per group-step until round 3).
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_track_kernel(
+    const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points, const TrackFeat *__restrict__ feats0, const TrackFeat *__restrict__ feats1,
+    int np, int nfeat_cap, Cam cam, sdvl_align_params prm, int max_f, float *__restrict__ items, sdvl_align_result *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  const TrackJobDev &jb = jobs[blockIdx.x];
+  const size_t pitch = static_cast<size_t>((jb.n_feat + 63) / 64 * 64);
+  (void)pitch;
+  const IaIn in{jb.last_level, jb.cur.level, jb.cur.lw, jb.cur.lh, jb.n_feat, jb.T0,
+                items + static_cast<size_t>(blockIdx.x) * 48 * static_cast<size_t>(max_f), out + blockIdx.x};
+  const IaTableFeats F{(jb.feat_buf ? feats1 : feats0) + static_cast<size_t>(jb.tracker) * nfeat_cap, points + static_cast<size_t>(jb.tracker) * np,
+                       se3_inverse(se3_from7(jb.last_pose)).t};
+  ia_wave_body<kWaves, true>(in, F, cam, prm, max_f, s_dyn);
 }
 
 size_t ia_wave_lds_bytes(int max_f, bool global_items) {
@@ -1338,6 +1407,48 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   if (!d_results && !direct) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return SDVL_OK;
+}
+
+// The alignment of a tracked step (sdvl_track_align): the jobs are the step's TrackJobDev records, already in HBM; features come
+// out of the tracking tables inside the kernel.  max_nf = the largest feature count among the jobs.
+int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev *d_jobs, const TrackPoint *d_points, const TrackFeat *d_feats0,
+                                   const TrackFeat *d_feats1, int np, int nfeat_cap, int max_nf, int levels, const sdvl_camera *cam,
+                                   const sdvl_align_params *p, sdvl_align_result *d_results) {
+  SDVL_REQUIRE(ctx, p->patch_size == 4, "only align_patch_size 4 is supported");
+  SDVL_REQUIRE(ctx, p->min_level >= 0 && p->max_level >= p->min_level && p->max_level < SDVL_MAX_LEVELS, "bad align levels");
+  SDVL_REQUIRE(ctx, p->max_level < levels, "max_align_level exceeds the pyramid depth");
+  SDVL_REQUIRE(ctx, p->max_its >= 0, "bad max_its");
+  if (max_nf > kMaxF) {
+    ctx->err = "too many features in one alignment job (SDVL_MAX_ALIGN_FEATURES)";
+    return SDVL_ERR_CAPACITY;
+  }
+  const int kw = max_nf > kLdsMaxF ? 4 : 1;  // configuration C's ~850 features per job: four waves share them
+  const int max_f = max_nf <= 0 ? 64 * kw : (max_nf + 64 * kw - 1) / (64 * kw) * (64 * kw);
+  const size_t work = static_cast<size_t>(n_jobs) * 48 * sizeof(float) * max_f;
+  const int rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, work + 256, false);
+  if (rc) return rc;
+  {
+    static std::atomic<unsigned long long> attr_devices{0};
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
+      SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_track_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
+      attr_devices.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  const Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  sdvl_timer_events(ctx, kw == 4 ? "image_align_big" : "image_align", &ev_a, &ev_b);
+  const size_t lds = ia_wave_lds_bytes(max_f, true);
+  if (kw == 4)
+    hipExtLaunchKernelGGL((image_align_track_kernel<4>), dim3(n_jobs), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, d_jobs, d_points, d_feats0, d_feats1, np,
+                          nfeat_cap, c, *p, max_f, static_cast<float *>(ctx->d_work), d_results);
+  else
+    hipExtLaunchKernelGGL((image_align_track_kernel<1>), dim3(n_jobs), dim3(64), lds, ctx->stream, ev_a, ev_b, 0, d_jobs, d_points, d_feats0, d_feats1, np,
+                          nfeat_cap, c, *p, max_f, static_cast<float *>(ctx->d_work), d_results);
+  SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
 }
 

@@ -131,4 +131,66 @@ __device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W
   return nib;
 }
 
+// ---- the same descriptor out of an LDS copy of the corner's neighbourhood (round 4) ----------------------------------------
+// orb_wave_nibble above makes TWO dependent trips to memory per corner: the 248 moment words, then — once the angle is known —
+// the 512 test pixels.  A wave that computes descriptors on demand inside a search (search_points_kernel) lives from one
+// memory round trip to the next (~15 of them per request, ~40 k cycles of wave-slot time for ~1200 instructions), so here the
+// whole neighbourhood any moment word or steered test can touch comes in with ONE batch of loads: rows -18 .. 18 (the pattern's
+// coordinates reach 13, rotated at most sqrt(2) 13 = 18.4 -> 18), columns -20 .. 19 (the moment words start at column -16; ten
+// words per row), 37 x 40 bytes.  Same bytes, same arithmetic: bit-identical descriptors.
+constexpr int kOrbWinRows = 37, kOrbWinPitch = 40, kOrbWinWords = kOrbWinRows * kOrbWinPitch / 4;  // 370 words = 1480 B
+
+// all 64 lanes: copy the window around `center` (row stride W; ORBDetector::IsInsideLimits holds: 19 px from every border, so
+// every byte read lies inside the image) into win[kOrbWinWords]
+__device__ __forceinline__ void orb_stage_window(const uint8_t *center, int W, int lane, uint32_t *win) {
+#pragma unroll
+  for (int r = 0; r < (kOrbWinWords + 63) / 64; r++) {
+    const int i = lane + 64 * r;
+    if (i < kOrbWinWords) {
+      const int row = i / 10, cw = i - row * 10;
+      uint32_t w;
+      __builtin_memcpy(&w, center + (row - 18) * W + (cw * 4 - 20), 4);
+      win[i] = w;
+    }
+  }
+}
+
+// the caller orders the wave's LDS writes before this (wave fence)
+__device__ __forceinline__ uint32_t orb_wave_nibble_win(const uint32_t *win, int lane, float *angle_deg_out) {
+  const uint8_t *wb = reinterpret_cast<const uint8_t *>(win) + 18 * kOrbWinPitch + 20;  // the centre pixel
+  int m10 = 0, m01 = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int task = lane + 64 * r;
+    if (task < 248) {
+      const int v = (task >> 3) - 15, u0 = -16 + 4 * (task & 7);
+      const uint32_t w = win[((v + 18) * kOrbWinPitch + 20 + u0) >> 2];  // (v + 18) * 40 + 4 + 4 (task & 7): word-aligned
+      const int sp = static_cast<int>(__builtin_amdgcn_udot4(w, c_orb_moments.m[task], 0u, false));
+      const int sup = static_cast<int>(__builtin_amdgcn_udot4(w, c_orb_moments.a[task], 0u, false));
+      m10 += sup - 16 * sp;
+      m01 += v * sp;
+    }
+  }
+  m10 = orb_wave_sum_i32(m10);
+  m01 = orb_wave_sum_i32(m01);
+  const float angle_deg = fast_atan2_deg(static_cast<float>(m01), static_cast<float>(m10));
+  const float factorPI = static_cast<float>(M_PI / 180.f);
+  const float angle = static_cast<float>(static_cast<double>(angle_deg) * factorPI);
+  double sn_d, cs_d;
+  sdvl::sincos_2pi(static_cast<double>(angle), &sn_d, &cs_d);
+  const float a = static_cast<float>(cs_d);
+  const float b = static_cast<float>(sn_d);
+  const float4 *pf = reinterpret_cast<const float4 *>(c_orb_pattern_f) + 4 * lane;
+  uint32_t nib = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float4 t = pf[q];  // x0, y0, x1, y1 of test 4 lane + q
+    const int t0 = wb[cv_round_f(t.x * b + t.y * a) * kOrbWinPitch + cv_round_f(t.x * a - t.y * b)];
+    const int t1 = wb[cv_round_f(t.z * b + t.w * a) * kOrbWinPitch + cv_round_f(t.z * a - t.w * b)];
+    nib |= (t0 < t1 ? 1u : 0u) << q;
+  }
+  *angle_deg_out = angle_deg;
+  return nib;
+}
+
 }  // namespace

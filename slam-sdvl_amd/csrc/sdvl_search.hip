@@ -22,6 +22,7 @@
 #include "sdvl_math.h"
 #include "sdvl_orb_device.h"
 #include "sdvl_search_types.h"
+#include "sdvl_search_prepare.h"
 
 namespace {
 
@@ -33,10 +34,23 @@ struct PatchJob {  // sdvl_align_patches
   double u, v;
 };
 
+// Round 4 experiment, measured and switched OFF: staging the descriptor neighbourhood (37 x 40 B) and the LK neighbourhood (20 x 20 B)
+// in LDS with one batch of loads each, on the theory that a search wave lives from one memory round trip to the next.  It does not:
+// the second and later touches of those bytes are L1 hits, and the staging's own index arithmetic, fences and 9 more VGPRs (64 +
+// 60 B of scratch instead of 55) cost more than they save — alone 155 us per 256 frames against 132, in the bench 5.3 ms of
+// dispatch time per step against 3.9, 330 k tracked frames/s against 350 k.  The waves are long-lived because eight of them share
+// a SIMD whose issue port is busy, not because they wait for memory: only fewer instructions help.
+constexpr bool kSearchOrbWindow = false, kSearchLkWindow = false;
+constexpr int kLkWin = 20, kLkWinBack = 9;  // LDS copy of the search image around the LK start: 20 x 20 bytes from (u0 - 9, v0 - 9)
 struct WaveLds {
   uint8_t border[104];
   uint8_t patch[64];
   float prod[3][64];
+  // round 4: one memory round trip instead of several.  orb: the 37 x 40 neighbourhood of a corner whose descriptor is computed on
+  // demand (sdvl_orb_device.h); lk: the 20 x 20 neighbourhood of the LK start — every iteration's 9 x 9 window is read out of it
+  // as long as the patch stays within [-5, +6] px of where it started (it moves a pixel or two; beyond that: the image itself)
+  uint32_t orb[kSearchOrbWindow ? kOrbWinWords : 1];
+  uint32_t lk[kSearchLkWindow ? kLkWin * kLkWin / 4 : 1];
 };
 
 __device__ __forceinline__ float interpolate8u(const uint8_t *img, int stride, float u, float v) {
@@ -79,9 +93,43 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return v;
 }
 
+template <bool kWindow = false>
 __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, int max_its, int lane, float *u_io, float *v_io,
                                  int *its_out, bool tree_sums = false) {
   const int y = lane >> 3, x = lane & 7;
+  // kWindow: the neighbourhood of the start position into LDS with one batch of loads (bytes outside the image are never read
+  // back: an iteration whose 9 x 9 window leaves the image ends the loop before it reads, matcher.cc:402)
+  int win_x0 = 0, win_y0 = 0;
+  bool win_ok = false;
+  if (kWindow) {
+    const float fu0 = floorf(*u_io), fv0 = floorf(*v_io);
+    if (fu0 >= 4.f && fv0 >= 4.f && fu0 < static_cast<float>(W - 4) && fv0 < static_cast<float>(H - 4)) {
+      win_ok = true;
+      win_x0 = static_cast<int>(fu0) - kLkWinBack;
+      win_y0 = static_cast<int>(fv0) - kLkWinBack;
+      const long long total = static_cast<long long>(W) * H;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int i = lane + 64 * r;
+        if (i < kLkWin * kLkWin / 4) {
+          const int row = i / (kLkWin / 4), cw = i - row * (kLkWin / 4);
+          const int gy = win_y0 + row;
+          const long long o = static_cast<long long>(gy) * W + (win_x0 + 4 * cw);
+          uint32_t w = 0;
+          if (gy >= 0 && gy < H) {
+            if (o >= 0 && o + 4 <= total) {
+              __builtin_memcpy(&w, img + o, 4);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if (o + k >= 0 && o + k < total) w |= static_cast<uint32_t>(img[o + k]) << (8 * k);
+            }
+          }
+          L.lk[i] = w;
+        }
+      }
+    }
+  }
   const uint8_t *it = &L.border[(y + 1) * 10 + 1 + x];
   const int jx = static_cast<int>(it[1]) - static_cast<int>(it[-1]);
   const int jy = static_cast<int>(it[10]) - static_cast<int>(it[-10]);
@@ -111,6 +159,7 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
   inv[2][1] = (m[2][0] * m[0][1] - m[2][1] * m[0][0]) * invdet;
   inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * invdet;
 
+  if (kWindow) wave_sync();  // the staged window is visible to every lane (the loads have had the set-up above to arrive)
   const float ref = static_cast<float>(L.patch[lane]);
   float mean_diff = 0.f;
   float u = *u_io, v = *v_io;
@@ -128,8 +177,15 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
     const float wTR = static_cast<float>(sx * (1.0 - sy));
     const float wBL = static_cast<float>((1.0 - sx) * sy);
     const float wBR = sx * sy;
-    const uint8_t *ip = img + static_cast<size_t>(v_r + y - 4) * W + (u_r + x - 4);
-    const float search_pixel = wTL * ip[0] + wTR * ip[1] + wBL * ip[W] + wBR * ip[W + 1];
+    float search_pixel;
+    // the 9 x 9 window of this iteration inside the staged 20 x 20? (wave-uniform: u, v are)
+    if (kWindow && win_ok && u_r - 4 >= win_x0 && u_r + 4 < win_x0 + kLkWin && v_r - 4 >= win_y0 && v_r + 4 < win_y0 + kLkWin) {
+      const uint8_t *ip = reinterpret_cast<const uint8_t *>(L.lk) + (v_r + y - 4 - win_y0) * kLkWin + (u_r + x - 4 - win_x0);
+      search_pixel = wTL * ip[0] + wTR * ip[1] + wBL * ip[kLkWin] + wBR * ip[kLkWin + 1];
+    } else {
+      const uint8_t *ip = img + static_cast<size_t>(v_r + y - 4) * W + (u_r + x - 4);
+      search_pixel = wTL * ip[0] + wTR * ip[1] + wBL * ip[W] + wBR * ip[W + 1];
+    }
     const float res = search_pixel - ref + mean_diff;
     float J0, J1, J2;
     if (tree_sums) {  // tolerance class: the same 64 terms summed as a butterfly (18 shuffles instead of a 64-step chain)
@@ -177,102 +233,11 @@ __global__ __launch_bounds__(64) void search_prepare_kernel(const SearchReqDev *
   const int ri = blockIdx.x * 64 + threadIdx.x;  // one-wave workgroups: placed as soon as ONE wave slot is free (see search_points_kernel)
   if (ri >= n) return;
   const SearchReqDev &rq = reqs[ri];
-  SearchPrep out;
-  out.alive = 0;
-  out.slevel = -1;
-  out.pxa[0] = out.pxa[1] = out.pxb[0] = out.pxb[1] = 0.0;
-  out.I00 = out.I01 = out.I10 = out.I11 = 0.0;
-  out.nx = out.ny = out.normdist = out.xdiff = out.ydiff = out.vline = out.range = out.range2 = 0.0;
-  const int level = rq.level;
-  if (level < 0) {  // a dead slot of a device-built batch (sdvl_track.hip): no request here
-    prep[ri] = out;
+  if (rq.level < 0) {  // a dead slot of a device-built batch: the frame indices may be anything
+    prep[ri] = search_prepare_one(rq, se3_identity(), se3_identity(), cam, prm);
     return;
   }
-  const SearchFramePose &tcur = table[rq.cur], &tref = table[rq.ref];
-  const Rigid cur_pose = se3_from7(tcur.pose), ref_pose = se3_from7(tref.pose);
-  const Rigid ref_world = se3_inverse(ref_pose);
-  const Rigid pose = se3_mul(cur_pose, ref_world);
-  const V3 fvec = {rq.bearing[0], rq.bearing[1], rq.bearing[2]};
-  const double idepth = rq.idepth, istd = rq.idepth_std;
-  bool alive = true;
-  V2 pxa = {0, 0}, pxb = {0, 0};
-  {
-    const double zmin = 1.0 / (idepth + 2.0 * istd);
-    const V3 rel = se3_apply(cur_pose, se3_apply(ref_world, vscale_l(zmin, fvec)));
-    if (rel.z < 0.0) alive = false;
-    else pxa = cam_project(cam, rel);
-    if (alive && !rq.fixed) {
-      const double zmax = 1.0 / (fmax(idepth - 2.0 * istd, 0.00000001));
-      const V3 rel2 = se3_apply(cur_pose, se3_apply(ref_world, vscale_l(zmax, fvec)));
-      if (rel2.z < 0.0) alive = false;
-      else pxb = cam_project(cam, rel2);
-    }
-  }
-  if (alive) {
-    const int lx = static_cast<int>(rq.px[0] / (1 << level)), ly = static_cast<int>(rq.px[1] / (1 << level));
-    if (!cam_inside_level(cam, lx, ly, prm.patch_size / 2 + 2, level)) alive = false;
-  }
-  if (!alive) {
-    prep[ri] = out;
-    return;
-  }
-  // ---- WarpMatrixAffine, matcher.cc:293-312
-  double A00, A01, A10, A11;
-  {
-    const int half_size = 5;
-    const double depth = 1.0 / idepth;
-    const V3 p3d = vscale(fvec, depth);
-    V3 xyz_du = cam_unproject(cam, {rq.px[0] + static_cast<double>(half_size) * (1 << level), rq.px[1] + 0.0 * (1 << level)});
-    V3 xyz_dv = cam_unproject(cam, {rq.px[0] + 0.0 * (1 << level), rq.px[1] + static_cast<double>(half_size) * (1 << level)});
-    const double su = p3d.z / xyz_du.z;
-    xyz_du = vscale(xyz_du, su);
-    const double sv = p3d.z / xyz_dv.z;
-    xyz_dv = vscale(xyz_dv, sv);
-    const V2 px_cur = cam_project(cam, se3_apply(pose, p3d));
-    const V2 px_du = cam_project(cam, se3_apply(pose, xyz_du));
-    const V2 px_dv = cam_project(cam, se3_apply(pose, xyz_dv));
-    A00 = (px_du.x - px_cur.x) / half_size;
-    A10 = (px_du.y - px_cur.y) / half_size;
-    A01 = (px_dv.x - px_cur.x) / half_size;
-    A11 = (px_dv.y - px_cur.y) / half_size;
-  }
-  // ---- GetSearchLevel, matcher.cc:314-323
-  int slevel = 0;
-  {
-    double det = A00 * A11 - A01 * A10;
-    const int mx = prm.max_fast_levels - 1;
-    while (det > 3.0 && slevel < mx) {
-      slevel += 1;
-      det *= 0.25;
-    }
-  }
-  {
-    const double det = A00 * A11 - A01 * A10;
-    const double invdet = 1.0 / det;
-    out.I00 = A11 * invdet; out.I01 = -A01 * invdet; out.I10 = -A10 * invdet; out.I11 = A00 * invdet;
-  }
-  out.alive = 1;
-  out.slevel = slevel;
-  out.pxa[0] = pxa.x; out.pxa[1] = pxa.y; out.pxb[0] = pxb.x; out.pxb[1] = pxb.y;
-  {
-    double range = prm.search_size;
-    for (int i = 1; i <= slevel; i++) range *= 1.2;
-    out.range = range;
-    out.range2 = range * range;
-    if (!rq.fixed) {  // epipolar line constants (matcher.cc:139-148); a fixed search tests a circle around px0 only
-      double ex = pxa.x - pxb.x, ey = pxa.y - pxb.y;
-      const double en = sqrt(ex * ex + ey * ey);
-      ex /= en;
-      ey /= en;
-      out.nx = ey;
-      out.ny = -ex;
-      out.normdist = pxa.x * out.nx + pxa.y * out.ny;
-      out.xdiff = pxb.x - pxa.x;
-      out.ydiff = pxb.y - pxa.y;
-      out.vline = (out.xdiff) * (out.xdiff) + (out.ydiff) * (out.ydiff);
-    }
-  }
-  prep[ri] = out;
+  prep[ri] = search_prepare_one(rq, se3_from7(table[rq.cur].pose), se3_from7(table[rq.ref].pose), cam, prm);
 }
 
 // kStage: frames without corner bins get their corner list staged in LDS (16 KB per workgroup).  Launches whose frames all
@@ -302,6 +267,8 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                                                                             sdvl_search_res *__restrict__ out,
                                                                             sdvl_search_res *__restrict__ out_host) {
   static_assert(kW == kWavesPerBlock || (kW == 1 && !kStage), "one wave per workgroup only without the shared corner stage");
+  // round 4: descriptor neighbourhoods and the LK neighbourhood through LDS (WaveLds::orb, ::lk)
+  constexpr bool kOrbWindow = kSearchOrbWindow, kLkWindow = kSearchLkWindow;
   __shared__ WaveLds s_lds[kW];
   // the current frame's corner list, packed x | y << 12 | level << 24, read from HBM once per workgroup instead of once
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
@@ -384,6 +351,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // ---- GetCornersInRange + SearchFeatures
   const int threshold = prm.use_orb ? 100 : prm.patch_size * prm.patch_size * 500;
   unsigned long long best = ~0ull;
+  uint32_t best_pk = 0;
   {
     const SearchFrame &cf = tcur.f;
     const double nx = pr.nx, ny = pr.ny, normdist = pr.normdist, xdiff = pr.xdiff, ydiff = pr.ydiff, vline = pr.vline;
@@ -445,7 +413,14 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
           uint32_t nib = 0;  // outside ORBDetector::IsInsideLimits the descriptor is all zeros (sdvl_orb.hip)
           if (jx >= 19 && jx < Wj - 19 && jy >= 19 && jy < Hj - 19) {
             float angle_deg;
-            nib = orb_wave_nibble(cf.level[jl] + static_cast<size_t>(jy) * Wj + jx, Wj, lane, &angle_deg);
+            if (kOrbWindow) {  // one batch of loads into LDS, moments and steered tests out of it (sdvl_orb_device.h)
+              wave_sync();     // the previous corner's window has been read by every lane
+              orb_stage_window(cf.level[jl] + static_cast<size_t>(jy) * Wj + jx, Wj, lane, L.orb);
+              wave_sync();
+              nib = orb_wave_nibble_win(L.orb, lane, &angle_deg);
+            } else {
+              nib = orb_wave_nibble(cf.level[jl] + static_cast<size_t>(jy) * Wj + jx, Wj, lane, &angle_deg);
+            }
           }
           const int sc = wave_sum_i32(__popc(nib ^ rq_nib));
           if (lane == j) score = sc;
@@ -476,7 +451,10 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         // score < best_score with first-index-wins == min over (score, index); scores may be negative for ZMSSD
         const unsigned long long key =
             (static_cast<unsigned long long>(static_cast<unsigned>(score + 0x40000000)) << 20) | static_cast<unsigned>(ci);
-        best = key < best ? key : best;
+        if (key < best) {
+          best = key;
+          best_pk = pk;  // the corner itself travels with the key: no trip to the corner list for the winner
+        }
       }
     };
     // which corners to look at: with bins, the cells the search region touches (a superset of the corners in range: the
@@ -547,7 +525,12 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         scan_round(have, have ? corner_at(ci) : 0u, ci);
       }
     }
+    const unsigned long long mine = best;
     best = wave_min_u64(best);
+    if (best != ~0ull) {  // keys are unique (they end in the corner's list index): exactly one lane holds the winner
+      const unsigned long long w = __ballot(mine == best);
+      best_pk = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(best_pk), __ffsll(static_cast<long long>(w)) - 1));
+    }
   }
   res.stage = 1;
   bool matched = false;
@@ -565,7 +548,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     return;
   }
   res.best_corner = best_ci;
-  const uint32_t bpk = corner_at(best_ci);
+  const uint32_t bpk = best_pk;
   const int bx = static_cast<int>(bpk & 0xFFFu), by = static_cast<int>((bpk >> 12) & 0xFFFu), bl = static_cast<int>(bpk >> 24);
   const double mpx = static_cast<double>(bx * (1 << bl)), mpy = static_cast<double>(by * (1 << bl));
   res.px[0] = mpx;
@@ -573,8 +556,10 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // ---- AlignPatch at the search level
   float u = static_cast<float>(mpx / (1 << slevel)), v = static_cast<float>(mpy / (1 << slevel));
   int its = 0;
-  const bool conv = align_patch_wave(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v, &its,
-                                     prm.lk_tree_sums != 0);
+  const bool conv = kLkWindow ? align_patch_wave<true>(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v,
+                                                       &its, prm.lk_tree_sums != 0)
+                              : align_patch_wave<false>(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v,
+                                                        &its, prm.lk_tree_sums != 0);
   res.lk_its = its;
   res.stage = 2;
   if (conv) {
@@ -867,13 +852,14 @@ __global__ __launch_bounds__(128) void depth_filter_kernel(const SearchReqDev *_
 
 int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_reqs, const SearchFramePose *d_table,
                               const SearchBlock *d_blocks, int n_blocks, const sdvl_camera *cam, const sdvl_search_params *p,
-                              SearchPrep *d_prep, sdvl_search_res *d_res, sdvl_search_res *h_res) {
+                              SearchPrep *d_prep, sdvl_search_res *d_res, sdvl_search_res *h_res, bool prepared) {
   SDVL_REQUIRE(ctx, p->patch_size == 8, "only patch_size 8 is supported (one wave64 per 8x8 patch)");
   SDVL_REQUIRE(ctx, p->max_fast_levels >= 1 && p->max_fast_levels <= 4, "bad max_fast_levels");
   SDVL_REQUIRE(ctx, p->max_align_its >= 0 && p->margin >= 4, "bad max_align_its / margin");
   if (n_slots <= 0 || n_blocks <= 0) return SDVL_OK;
   Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n_slots + 63) / 64), dim3(64), d_reqs, d_table, n_slots, c, *p, d_prep);
+  // `prepared`: the kernel that wrote the requests has written their prepare records too (track_project_kernel)
+  if (!prepared) SDVL_LAUNCH(ctx, "search_prepare", search_prepare_kernel, dim3((n_slots + 63) / 64), dim3(64), d_reqs, d_table, n_slots, c, *p, d_prep);
   // device-built batches search frames that came out of sdvl_detect_corners: binned (a frame without bins would still be
   // searched correctly, its corner list read from HBM)
   SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<false, 1>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8 * kWavesPerBlock)), dim3(64), d_reqs,

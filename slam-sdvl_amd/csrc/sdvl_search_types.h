@@ -83,6 +83,29 @@ struct TrackPoint {  // device form of sdvl_track_point: the frame pointer repla
 };
 static_assert(sizeof(TrackPoint) == sizeof(sdvl_track_point), "upload converts in place");
 static_assert(sizeof(sdvl_track_point) == 144, "layout");
+struct TrackFeat {  // a feature row of last_frame (sdvl_track_feature)
+  double px[2];
+  double bearing[3];
+  int32_t level;
+  int32_t point;
+};
+static_assert(sizeof(TrackFeat) == sizeof(sdvl_track_feature) && sizeof(TrackFeat) == 48, "layout");
+
+// one tracked step of one tracker, written by sdvl_track_align and read by every kernel of the step (track_project, track_commit,
+// and — round 4 — the image alignment itself: image_align_track_kernel builds its features from the table rows, no records in between)
+struct TrackJobDev {
+  SearchFrame cur;  // view of the new frame
+  int tracker, feat_buf;
+  int cur_id, last_id;
+  int frame_id, max_matches;
+  int n_feat, n_points;
+  double last_pose[7];
+  double pad_;
+  const uint8_t *last_level[SDVL_MAX_LEVELS];  // pyramid of last_frame (frame1 of the alignment; same geometry as cur)
+  double T0[7];                                // start of the alignment, frame2.pose * frame1.pose^-1 (image_align.cc:66)
+  double pad2_;
+};
+
 // the set's point rows and the row count per tracker (sdvl_track.hip)
 extern "C" TrackPoint *sdvl_track_points_device(sdvl_track_set *set, int *max_points, int *n_trackers);
 
@@ -92,13 +115,17 @@ extern "C" TrackPoint *sdvl_track_points_device(sdvl_track_set *set, int *max_po
 // be null) the same records in pinned host memory
 int sdvl_search_launch_device(sdvl_ctx *ctx, int n_slots, const SearchReqDev *d_reqs, const SearchFramePose *d_table,
                               const SearchBlock *d_blocks, int n_blocks, const sdvl_camera *cam, const sdvl_search_params *p,
-                              SearchPrep *d_prep, sdvl_search_res *d_res, sdvl_search_res *h_res);
+                              SearchPrep *d_prep, sdvl_search_res *d_res, sdvl_search_res *h_res, bool prepared = false);
 // second half of SelectPoints for n_frames trackers (feature_align.cc:105-149): d_cand_req may be null (candidate k of a
 // tracker = request cand_begin + k); d_match_cand (may be null) receives, per selected match, its candidate index
 // relative to cand_begin, at obs_begin + rank
 int sdvl_select_matches_launch(sdvl_ctx *ctx, int n_frames, const ChainFrameDev *d_frames, const int32_t *d_cand_req,
                                const int32_t *d_cand_first, const sdvl_search_res *d_res, const double *d_req_point,
                                const sdvl_camera *cam, PoseJobDev *d_jobs, sdvl_pose_obs *d_obs, int32_t *d_nobs, int32_t *d_match_cand);
+// sdvl_image_align.hip: the image alignment of a tracked step, features straight from the tracking tables (no records, no wait)
+int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev *d_jobs, const TrackPoint *d_points, const TrackFeat *d_feats0,
+                                   const TrackFeat *d_feats1, int np, int nfeat_cap, int max_nf, int levels, const sdvl_camera *cam,
+                                   const sdvl_align_params *p, sdvl_align_result *d_results);
 // the iteration-budget table of SelectInliers for all match counts up to max_size, resident in HBM (ctx->d_nits)
 extern "C" int sdvl_ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int max_size);
 

@@ -21,28 +21,12 @@
 #include "sdvl_internal.h"
 #include "sdvl_math.h"
 #include "sdvl_search_types.h"
+#include "sdvl_search_prepare.h"
 
 namespace {
 
 using namespace sdvl;
 
-struct TrackFeat {
-  double px[2];
-  double bearing[3];
-  int32_t level;
-  int32_t point;
-};
-static_assert(sizeof(TrackFeat) == sizeof(sdvl_track_feature) && sizeof(TrackFeat) == 48, "layout");
-
-struct TrackJobDev {
-  SearchFrame cur;  // view of the new frame
-  int tracker, feat_buf;
-  int cur_id, last_id;
-  int frame_id, max_matches;
-  int n_feat, n_points;
-  double last_pose[7];
-  double pad_;
-};
 
 struct UploadRec {  // sdvl_track_upload: where one tracker's staged rows go
   int tracker, feat_buf;
@@ -146,7 +130,8 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
                                                                      int patch, SearchFramePose *__restrict__ registry,
                                                                      SearchReqDev *__restrict__ reqs, double *__restrict__ req_point,
                                                                      int32_t *__restrict__ cand_first, int32_t *__restrict__ cand_feat,
-                                                                     SearchBlock *__restrict__ blocks, ChainFrameDev *__restrict__ chain) {
+                                                                     SearchBlock *__restrict__ blocks, ChainFrameDev *__restrict__ chain,
+                                                                     sdvl_search_params sprm, SearchPrep *__restrict__ prep) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_dyn);  // [stride] sort key of feature i, ~0 = not a candidate
   double *s_px = reinterpret_cast<double *>(s_key + stride);                   // [stride][2] its projection
@@ -228,6 +213,9 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
 #pragma unroll
     for (int w = 0; w < 8; w++) rq.desc[w] = p.desc[w];
     reqs[base + r] = rq;
+    // phase 0 of SearchPoint for the request this lane has just assembled (search_prepare_kernel's work, sdvl_search_prepare.h);
+    // the reference frame's pose comes out of the registry, the current frame's is the one this workgroup has just computed
+    if (prep) prep[base + r] = search_prepare_one(rq, pose, se3_from7(registry[p.ref].pose), cam, sprm);
     double *rp = req_point + 3 * static_cast<size_t>(base + r);
     rp[0] = p.P[0]; rp[1] = p.P[1]; rp[2] = p.P[2];
     cand_feat[base + r] = i;
@@ -242,6 +230,10 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
       cand_first[base + k] = base + first;
     } else {
       reqs[base + k].level = -1;  // dead slot: search_prepare / search_points skip it
+      if (prep) {
+        prep[base + k].alive = 0;
+        prep[base + k].slevel = -1;
+      }
     }
   }
   const int nblk = stride / kWavesPerBlock;
@@ -724,6 +716,11 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
     d.n_points = s->n_points[a.tracker];
     memcpy(d.last_pose, a.last_pose, sizeof(double) * 7);
     d.pad_ = 0.0;
+    SDVL_REQUIRE(ctx, a.last->width == a.cur->width && a.last->height == a.cur->height && a.last->v.levels == a.cur->v.levels,
+                 "frame pair with different geometry");
+    for (int l = 0; l < SDVL_MAX_LEVELS; l++) d.last_level[l] = l < a.last->v.levels ? a.last->v.level[l] : nullptr;
+    memcpy(d.T0, a.T, sizeof(double) * 7);
+    d.pad2_ = 0.0;
     aj[j].ref = a.last;
     aj[j].cur = a.cur;
     aj[j].feat_begin = j * s->stride;
@@ -734,11 +731,20 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
   memcpy(h8 + jb + cb, rand_raw, rb);
   SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_jobs, h8, jb + cb + rb));
   (void)d8;
-  SDVL_LAUNCH(ctx, "track_align_prep", track_align_prep_kernel, dim3(n_jobs), dim3(256), static_cast<const TrackJobDev *>(s->d_jobs),
-              static_cast<const TrackPoint *>(s->d_points), static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]),
-              s->np, s->nf, s->stride, s->d_afeat);
-  SDVL_HIP_CHECK(ctx, hipGetLastError());
-  rc = sdvl_image_align_enqueue(ctx, n_jobs, aj.data(), n_jobs * s->stride, nullptr, s->d_afeat, cam, &p->align, s->d_ares);
+  // Round 4: the alignment reads the tables itself (image_align_track_kernel): one launch instead of track_align_prep + a push of
+  // IaJob records + image_align.  SDVL_TRACK_ALIGN_RECORDS=1: the round-3 chain through sdvl_align_feature records (A/B).
+  static const bool via_records = getenv("SDVL_TRACK_ALIGN_RECORDS") != nullptr || (getenv("SDVL_IA_WAVE") && atoi(getenv("SDVL_IA_WAVE")) == 0);
+  if (via_records) {
+    SDVL_LAUNCH(ctx, "track_align_prep", track_align_prep_kernel, dim3(n_jobs), dim3(256), static_cast<const TrackJobDev *>(s->d_jobs),
+                static_cast<const TrackPoint *>(s->d_points), static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]),
+                s->np, s->nf, s->stride, s->d_afeat);
+    SDVL_HIP_CHECK(ctx, hipGetLastError());
+    rc = sdvl_image_align_enqueue(ctx, n_jobs, aj.data(), n_jobs * s->stride, nullptr, s->d_afeat, cam, &p->align, s->d_ares);
+  } else {
+    rc = sdvl_image_align_track_enqueue(ctx, n_jobs, static_cast<const TrackJobDev *>(s->d_jobs), static_cast<const TrackPoint *>(s->d_points),
+                                        static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, max_nf,
+                                        jobs[0].cur->v.levels, cam, &p->align, s->d_ares);
+  }
   if (rc) return rc;
   s->phase = 1;
   return SDVL_OK;
@@ -773,6 +779,9 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
       SDVL_HIP_CHECK(ctx, hipGetLastError());
     }
   }
+  // Round 4: track_project's lanes run SearchPoint's scalar phase for the requests they assemble: no search_prepare launch in a tracked
+  // step.  SDVL_TRACK_SEPARATE_PREPARE=1: the round-3 chain (A/B).
+  static const bool fused_prepare = getenv("SDVL_TRACK_SEPARATE_PREPARE") == nullptr;
   {
     const size_t lds = static_cast<size_t>(stride) * (8 + 16 + 2) + 64;
     if (lds > 60 * 1024) {  // beyond the default dynamic LDS limit: raise it once per device
@@ -793,11 +802,12 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
                           static_cast<const TrackJobDev *>(s->d_jobs), s->d_points, static_cast<const TrackFeat *>(s->d_feats[0]),
                           static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, stride, s->mm, s->max_its,
                           static_cast<const sdvl_align_result *>(s->d_ares), static_cast<const uint16_t *>(s->d_cell_rank), s->cells, c,
-                          s->prm.cell_size, s->prm.patch_size, registry, s->d_reqs, s->d_reqpt, s->d_cfirst, s->d_cfeat, s->d_blocks, s->d_chain);
+                          s->prm.cell_size, s->prm.patch_size, registry, s->d_reqs, s->d_reqpt, s->d_cfirst, s->d_cfeat, s->d_blocks, s->d_chain,
+                          s->prm.search, fused_prepare ? s->d_prep : nullptr);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
   }
   int rc = sdvl_search_launch_device(ctx, n_jobs * stride, s->d_reqs, registry, s->d_blocks, n_jobs * (stride / kWavesPerBlock), &s->cam,
-                                     &s->prm.search, s->d_prep, s->d_res, nullptr);
+                                     &s->prm.search, s->d_prep, s->d_res, nullptr, /*prepared*/ fused_prepare);
   if (rc) return rc;
   // match ranks are not needed separately: track_commit derives them again from the same flags
   rc = sdvl_select_matches_launch(ctx, n_jobs, s->d_chain, nullptr, s->d_cfirst, s->d_res, s->d_reqpt, &s->cam, s->d_pjobs, s->d_obs, s->d_nobs,
