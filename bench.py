@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+PCIE_LONE_STREAM_GBS = 57.0   # H2D of large pinned pieces on one stream, measured on these boxes (profiles/r03/pcie_probe.txt)
 W_IMG, H_IMG = 640, 480
 TUM_CAM = np.array([517.3, 516.5, 318.6, 255.3])
 FEATS_LABEL = "~200 feats"
@@ -439,11 +440,33 @@ def dry_rank(args, rank, world):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tracked_all, elapsed_max = shard.reduce_throughput(len(my) * K, elapsed, dist, "cpu")
+    # the host-fed leg runs on every rank: the same reductions as the real run (sum of tracked frames, max of the ranks' times, min / max
+    # of the ranks' own link rates), with a sleep in place of the farm
+    Kh = args.host_steps if args.host_steps >= 0 else (16 if world == 1 else 8)
+    host_fed = link = None
+    if Kh > 0:
+        frame_bytes = 640 * 480
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (1 + rank))
+        own_h = time.perf_counter() - t0                  # this rank's own time: its link rate; the job's time ends behind the barrier
+        if world > 1:
+            dist.barrier()
+        elapsed_h = time.perf_counter() - t0
+        th_all, eh_max = shard.reduce_throughput(len(my) * Kh, elapsed_h, dist, "cpu")
+        lo, hi = shard.reduce_min_max(len(my) * Kh * frame_bytes / own_h / 1e9, dist, "cpu")
+        agg = world * len(my) * Kh * frame_bytes / eh_max / 1e9
+        host_fed = {"value": round(th_all / eh_max, 2), "unit": "frames/s", "steps": Kh, "pcie_h2d_gb_per_s": round(agg, 6),
+                    "pcie_h2d_gb_per_s_per_gpu": {"min": round(lo, 6), "max": round(hi, 6)}, "tracked": th_all}
+        link = {"bound": "pcie_h2d", "achieved": round(agg / world, 6), "peak": PCIE_LONE_STREAM_GBS, "unit": "GB/s per GPU",
+                "frac": round(agg / world / PCIE_LONE_STREAM_GBS, 8), "per_gpu_min_max": host_fed["pcie_h2d_gb_per_s_per_gpu"]}
     if rank == 0:
         print(json.dumps({"metric": "tracked frames/sec (dry run, no GPU)", "value": round(tracked_all / elapsed_max, 2), "unit": "frames/s",
                           "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed_max / K * 1e3, 3), "dry": True,
                           "tracked": tracked_all, "cpu_share": int(os.environ.get("SDVL_BENCH_CPU_SHARE", "0")),
-                          "sequences": [my[0], my[-1]], "scaling": "weak"}))
+                          "sequences": [my[0], my[-1]], "scaling": "weak",
+                          "value_host_fed": host_fed["value"] if host_fed else None, "host_fed": host_fed, "roofline": {"link": link}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -470,7 +493,7 @@ def main():
     ap.add_argument("--host-steps", type=int, default=-1,
                     help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
-                         "default 16 on one GPU, 0 on several (every rank would pin 20 GB of host memory)")
+                         "default 16 on one GPU, 8 per rank on several (10 GB of pinned host memory per rank, NUMA-local to its GPU)")
     args = ap.parse_args()
     global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS
     wl = WORKLOADS[args.workload]
@@ -496,7 +519,9 @@ def main():
                              "--gpus N, or plain `python bench.py --gpus N`, which starts the ranks itself)" % (world, args.gpus))
     distributed = world > 1
     if args.host_steps < 0:
-        args.host_steps = 16 if world == 1 else 0
+        # the host-fed leg runs on EVERY rank (round 4): the drop-in figure is the one whose ranks share something — the host's DRAM and
+        # PCIe roots.  8 steps per rank on several GPUs (10 GB of pinned memory each, allocated after the NUMA binding), 16 on one
+        args.host_steps = 16 if world == 1 else 8
     if args.sustained_frames < 0:
         args.sustained_frames = 300 if (world == 1 and args.workload == "S-A" and not args.mapper and not dry) else 0
     dist = None
@@ -678,13 +703,21 @@ def main():
     Kh = max(0, args.host_steps)
     if Kh > 0:
         host_free = host_memory_available()
+        if host_free is not None:
+            host_free /= world                        # every rank of the node pins its own pool out of the same memory
         while Kh > 4 and host_free is not None and B * Kh * frame_bytes + 12e9 > 0.85 * host_free:
             Kh //= 2                                  # fewer host-fed steps rather than an out-of-memory kill
+        if distributed:                               # all ranks run the same number of steps (the smallest any of them can afford)
+            kh_t = torch.tensor([Kh], dtype=torch.int64, device="cuda")
+            dist.all_reduce(kh_t, op=dist.ReduceOp.MIN)
+            Kh = int(kh_t[0])
         try:
             hbuf = torch.empty(B * Kh * frame_bytes, dtype=torch.uint8, pin_memory=True)
         except RuntimeError as e:
             hbuf = None
             sys.stderr.write("bench.py: host-fed leg skipped, cannot pin %.1f GB of host memory (%s)\n" % (B * Kh * frame_bytes / 1e9, e))
+            if distributed:                           # the other ranks are about to enter the leg's barrier: fail the job loudly instead of hanging it
+                raise SystemExit("bench.py: rank %d cannot pin its host-fed pool; rerun with --host-steps 0 or fewer steps" % rank)
         if hbuf is not None:
             lib_hip = pkg.load_library()
             for k in range(Kh):                       # the frames that follow the resident leg's last one, rendered into the (now free) input area
@@ -703,6 +736,7 @@ def main():
             thr_h0, ru_h0 = throttled(), resource.getrusage(resource.RUSAGE_SELF)
             t0 = time.perf_counter()
             hstats = farm.run(hptrs, workers, hstats_buf)
+            own_h = time.perf_counter() - t0          # this rank's own time (its link rate); the job's time ends behind the barrier
             barrier()
             elapsed_h = time.perf_counter() - t0
             thr_h1, ru_h1 = throttled(), resource.getrusage(resource.RUSAGE_SELF)
@@ -720,8 +754,10 @@ def main():
             feed_call_s, feed_wait_s, feed_calls, work_wait_s, late_acq, feed_thr_s = farm.feed_stats()
             tracked_h = sum(int(st.quality != 2) for st in hstats)
             th_all, eh_max = shard.reduce_throughput(tracked_h, elapsed_h, dist if distributed else None, "cuda")
+            link_lo, link_hi = shard.reduce_min_max(B * Kh * frame_bytes / own_h / 1e9, dist if distributed else None, "cuda")
             host_fed = {"value": round(th_all / eh_max, 2), "unit": "frames/s", "steps": Kh, "ms_per_step": round(eh_max / Kh * 1e3, 3),
                         "pcie_h2d_gb_per_s": round(world * B * Kh * frame_bytes / eh_max / 1e9, 2),
+                        "pcie_h2d_gb_per_s_per_gpu": {"min": round(link_lo, 2), "max": round(link_hi, 2)},
                         "host_cpu": host_cpu_h,
                         "feeder": {"transfers": feed_calls, "s_in_transfer_calls": round(feed_call_s, 4), "s_waiting_for_a_free_slot": round(feed_wait_s, 4),
                                    "s_waiting_for_its_own_transfers": round(feed_thr_s, 4), "wall_s": round(elapsed_h, 4),
@@ -871,6 +907,16 @@ def main():
                 path_bytes += pf * share      # (pyr_down's figure already covers its four launches)
             roofline["path_hbm"] = {"algorithmic_bytes_per_frame": int(path_bytes), "achieved": round(path_bytes * (tracked_all / elapsed_max / world) / 1e9, 1),
                                     "frac": round(path_bytes * (tracked_all / elapsed_max / world) / 1e9 / HBM_PEAK_GBS, 5)}
+        if roofline is not None and host_fed:
+            # the link is the roof of the drop-in figure: SDVL::HandleFrame takes a HOST image (sdvl.cc:55-59); 307,200 B per frame over
+            # PCIe Gen5 x16.  peak = what ONE lone transfer stream of large pieces gets on these boxes (profiles/r03/pcie_probe.txt: 57 GB/s;
+            # the link's nominal 63 GB/s beside it)
+            per_gpu = host_fed["pcie_h2d_gb_per_s"] / world
+            roofline["link"] = {"bound": "pcie_h2d", "achieved": round(per_gpu, 2), "peak": PCIE_LONE_STREAM_GBS, "unit": "GB/s per GPU",
+                                "frac": round(per_gpu / PCIE_LONE_STREAM_GBS, 4), "nominal_peak": 63.0, "per_gpu_min_max": host_fed["pcie_h2d_gb_per_s_per_gpu"],
+                                "frames_per_s_at_peak_per_gpu": int(PCIE_LONE_STREAM_GBS * 1e9 / frame_bytes),
+                                "note": "value_host_fed / n_gpus x %d B per frame; the resident `value` is %.2f x what this link can feed: single-GPU kernel work "
+                                        "moves the resident figure only" % (frame_bytes, (tracked_all / elapsed_max) / max(1.0, host_fed["value"]))}
         value = tracked_all / elapsed_max
         out = {
             "metric": "tracked frames/sec (%dx%d, 5-lvl pyr, %s)" % (W_IMG, H_IMG, FEATS_LABEL), "value": round(value, 2), "unit": "frames/s",
@@ -882,6 +928,9 @@ def main():
                                    "one tracked frame per sequence per step%s" % (args.workload, W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",
                        "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "numa_node": numa_node, "parallelism": "sequences sharded over %d GPU(s)" % world,
+                       "cross_gpu_relocalisation": "declined: a tracker's keyframes live in the HBM of the GPU that tracked them and Relocalize "
+                                                   "(sdvl.cc:205-238) is one launch over all of them there; the round-robin partition and the min-index "
+                                                   "reduce of a split exist (shard.keyframe_positions_for_rank / first_success, gloo + RCCL tests) and are not used",
                        "features_per_frame": round(n_f / frames_rank, 1), "corners_per_frame": round(n_c / frames_rank, 1),
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
                        "lk_iterations_per_request": round(n_lk / max(1, n_s), 2), "fast_keypoints_per_frame": n_kp_measured,

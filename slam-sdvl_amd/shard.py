@@ -36,6 +36,19 @@ def reduce_throughput(tracked, elapsed, dist=None, device="cpu"):
     return float(t_sum[0]), float(t_max[0])
 
 
+def reduce_min_max(value, dist=None, device="cpu"):
+    """(min over ranks, max over ranks) of one per-rank figure — the per-GPU link rates of the host-fed leg, whose ranks share the
+    host's DRAM and PCIe roots: the slowest rank shows what the shared side costs"""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return float(value), float(value)
+    lo = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo[0]), float(hi[0])
+
+
 # ---- relocalisation over several GPUs (SURVEY §8e; SDVL::Relocalize, sdvl.cc:205-238) ----------------------------------------------
 # Relocalize walks the keyframes NEWEST FIRST and accepts the first one whose alignment error is < 0.001 and whose reprojection
 # finds >= MinMatches points (:221, :231).  Split over G GPUs, rank r examines positions r, r + G, r + 2G, ... of that newest-first

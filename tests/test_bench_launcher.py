@@ -32,6 +32,25 @@ def test_launcher_runs_two_ranks_over_gloo():
     # MAX over ranks: rank 1 sleeps 40 ms, rank 0 20 ms
     assert d["ms_per_step"] * 3 >= 39.0
     assert abs(d["value"] - d["tracked"] / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 0.02
+    # round 4: the N > 1 line carries the DROP-IN figure too — the host-fed leg runs on every rank (8 steps each by default), its
+    # tracked frames are summed, its time is the slowest rank's, and the ranks' own link rates come back as min / max
+    hf = d["host_fed"]
+    assert d["value_host_fed"] == hf["value"] and hf["steps"] == 8 and hf["tracked"] == 2 * 8 * 8
+    lo, hi = hf["pcie_h2d_gb_per_s_per_gpu"]["min"], hf["pcie_h2d_gb_per_s_per_gpu"]["max"]
+    assert 0 < lo < hi                                      # rank 1 sleeps twice as long as rank 0: its rate is the minimum
+    assert hi / lo > 1.3
+    link = d["roofline"]["link"]
+    assert link["bound"] == "pcie_h2d" and link["peak"] == 57.0 and link["per_gpu_min_max"] == hf["pcie_h2d_gb_per_s_per_gpu"]
+    assert abs(link["achieved"] - hf["pcie_h2d_gb_per_s"] / 2) < 1e-5 and abs(link["frac"] - link["achieved"] / 57.0) < 1e-6
+    assert lo * 0.9 <= link["achieved"] <= hi * 1.1          # the job's per-GPU rate is set by the slowest rank's time
+
+
+def test_host_fed_leg_can_be_switched_off_on_several_ranks():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--seqs", "8", "--host-steps", "0"],
+                         env=_env(SDVL_BENCH_DRY="1"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["value_host_fed"] is None and d["host_fed"] is None and d["roofline"]["link"] is None
 
 
 def test_launcher_refuses_fewer_gpus_than_asked():

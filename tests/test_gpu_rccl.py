@@ -27,6 +27,7 @@ def test_one_rank_nccl_group_runs_the_bench_reductions():
         dist.barrier()
         torch.cuda.synchronize()
         assert shard.reduce_throughput(1234, 0.5, dist, "cuda") == (1234.0, 0.5)
+        assert shard.reduce_min_max(51.25, dist, "cuda") == (51.25, 51.25)   # the per-GPU link rates of the host-fed leg
         assert shard.first_success(7, dist, "cuda") == 7
         assert shard.first_success(None, dist, "cuda") is None
         assert dist.get_backend() == "nccl"

@@ -35,7 +35,8 @@ def _worker(rank, world, port, per_gpu, q):
     winner = shard.first_success(accepted, dist)
     nobody = shard.first_success(None, dist)
     one_side = shard.first_success(9 if rank == 1 else None, dist)
-    q.put((rank, ids, total, tmax, mine, winner, nobody, one_side))
+    link = shard.reduce_min_max(50.0 + rank, dist)     # the ranks' own H2D rates of the host-fed leg
+    q.put((rank, ids, total, tmax, mine, winner, nobody, one_side, link))
     dist.destroy_process_group()
 
 
@@ -53,8 +54,9 @@ def test_two_ranks_shard_and_reduce():
         assert p.exitcode == 0
     all_ids = res[0][1] + res[1][1]
     assert sorted(all_ids) == list(range(world * per_gpu))             # disjoint and complete
-    for _, _, total, tmax, _, winner, nobody, one_side in res:
+    for _, _, total, tmax, _, winner, nobody, one_side, link in res:
         assert total == (100 + 6) + (200 + 6) and tmax == 1.25          # every rank sees the job-wide numbers
+        assert link == (50.0, 51.0)
         assert winner == 3 and nobody is None and one_side == 9          # the keyframe Relocalize alone would have stopped at
     assert sorted(res[0][4] + res[1][4]) == list(range(11)) and res[0][4] == [0, 2, 4, 6, 8, 10]   # round-robin over the newest-first order
 
@@ -66,4 +68,5 @@ def test_sequences_differ():
     tw = np.array([shard.sequence_twist(i) for i in range(14)])
     assert len({tuple(np.round(t, 9)) for t in tw}) == 14
     assert shard.reduce_throughput(5, 2.0) == (5.0, 2.0)                # single process: no collective
+    assert shard.reduce_min_max(3.5) == (3.5, 3.5)
     assert shard.first_success(4) == 4 and shard.first_success(None) is None

@@ -1,5 +1,4 @@
 set -u
 O=gpurun_out
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "search or align_patches or shi_tomasi" > $O/t_s.log 2>&1; echo "tests rc=$?"; tail -3 $O/t_s.log
-python tools/kernel_bench.py 256 6 > $O/kb_s.txt 2>&1; grep -E "search" $O/kb_s.txt
-for i in 1 2 3; do python bench.py --steps 40 --warmup 5 --cpu-frames 0 --host-steps 0 --sustained-frames 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); k=d['kernel_ms_per_step']; print('%.1f k' % (d['value']/1e3), 'search', k['search_points'], 'fast', k['fast_cells'], 'ia', k['image_align'], 'pyr', k['pyr_down'])"; done
+python bench.py > $O/bench_now.json 2> $O/bench_now.err; echo rc=$?
+tail -3 $O/bench_now.err
