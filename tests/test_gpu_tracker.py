@@ -538,6 +538,20 @@ def test_cpp_single_call_api_surface():
     assert len(lines) >= 16 and all(l.startswith("ok") for l in lines[:-1]) and lines[-1] == "0 check(s) failed"
 
 
+def test_cpp_front_end_alone_against_minimal_camera_and_point():
+    """slam-sdvl_amd/host/frontend_link_check: frontend.cc linked WITHOUT standalone.cc / mapper.cc / capi.cc, against a second,
+    independent implementation of the six members of the reference's Camera / Point it calls (host/minimal_deps.cc; INTEGRATION.md
+    route A).  The program tracks one frame through the reference's per-object calls — Frame ctor, FilterCorners, ImageAlign::ComputePose,
+    Matcher::SearchPoint, FeatureAlign::Reproject + OptimizePose — and recovers the rendered motion"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam-sdvl_amd", "host", "frontend_link_check")
+    assert os.path.exists(exe), "build() makes it (make -C slam-sdvl_amd/host)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) >= 7 and all(l.startswith("ok") for l in lines[:-1]) and lines[-1] == "0 check(s) failed", r.stdout
+
+
 def test_cpp_threaded_mode_tracker_and_mapper_on_two_threads():
     """slam-sdvl_amd/host/threaded_mode_check: main.cc's default mode (handler->Start(): the mapper runs on its own thread,
     map.cc:49-71) — two host threads inside the path, each with its own sdvl_ctx / stream, frames shared read-only.  The
