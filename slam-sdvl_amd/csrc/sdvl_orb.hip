@@ -74,37 +74,75 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
   }
 }
 
+// Round 4: FOUR corners per wave, 16 lanes each (until round 3 a wave per corner, lane = pixel of the 8x8 box: ~130 wave instructions
+// per corner, 17 M per keyframe dispatch — the path is bound by instruction issue).  Lane q of a corner's 16 owns four
+// adjacent pixels of box row q / 2: two words of its row (at x - 1 and x + 1: byte k of their difference is dx of pixel k) and one
+// word each of the rows above and below (dy) — four loads instead of sixteen; the three sums are exact integers in any order
+// (|dx|, |dy| <= 255, 64 terms), reduced inside the 16-lane DPP row.  ~27 instructions per corner.
+constexpr int kShiPerWave = 4;
 __global__ __launch_bounds__(256) void shi_tomasi_kernel(const OrbJob *__restrict__ jobs, int n_jobs, int chunks) {
   int fj, bx;
   if (!xcd_frame_block(n_jobs, chunks, &fj, &bx)) return;
   const OrbJob &job = jobs[fj];
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
   const int n = job.n_ptr ? min(job.n_ptr[0], SDVL_MAX_CORNERS) : job.n;
-  const int wpb = static_cast<int>(blockDim.x >> 6);  // waves per workgroup: one (round 3) — a wave per corner needs no company
-  for (int ci = bx * wpb + (threadIdx.x >> 6); ci < n; ci += chunks * wpb) {
-  const int px = job.corners[4 * ci], py = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
-  if (cl < 0 || cl >= job.levels) continue;
-  const int W = job.lw[cl], H = job.lh[cl];
-  const int x_min = px - 4, x_max = px + 4, y_min = py - 4, y_max = py + 4;
-  if (x_min < 1 || x_max >= W - 1 || y_min < 1 || y_max >= H - 1) {
-    if (lane == 0) job.out_score[ci] = 0.0;
-    continue;
-  }
-  const uint8_t *img = job.level[cl];
-  const int y = y_min + (lane >> 3), x = x_min + (lane & 7);
-  const int dx = static_cast<int>(img[static_cast<size_t>(y) * W + x + 1]) - static_cast<int>(img[static_cast<size_t>(y) * W + x - 1]);
-  const int dy = static_cast<int>(img[static_cast<size_t>(y + 1) * W + x]) - static_cast<int>(img[static_cast<size_t>(y - 1) * W + x]);
-  const int sxx = wave_sum_i32(dx * dx), syy = wave_sum_i32(dy * dy), sxy = wave_sum_i32(dx * dy);
-  if (lane == 0) {
-    float dXX = static_cast<float>(sxx), dYY = static_cast<float>(syy), dXY = static_cast<float>(sxy);
-    dXX = static_cast<float>(dXX / (2.0 * 64));
-    dYY = static_cast<float>(dYY / (2.0 * 64));
-    dXY = static_cast<float>(dXY / (2.0 * 64));
-    const float disc = (dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY);
-    job.out_score[ci] = 0.5 * (dXX + dYY - sqrt(static_cast<double>(disc)));
-  }
+  const int wpb = static_cast<int>(blockDim.x >> 6);
+  for (int c0 = (bx * wpb + (threadIdx.x >> 6)) * kShiPerWave; c0 < n; c0 += chunks * wpb * kShiPerWave) {
+    const int ci = c0 + grp;
+    int sxx = 0, syy = 0, sxy = 0;
+    bool inside = false;
+    if (ci < n) {
+      const int px = job.corners[4 * ci], py = job.corners[4 * ci + 1], cl = job.corners[4 * ci + 2];
+      if (cl >= 0 && cl < job.levels) {
+        const int W = job.lw[cl], H = job.lh[cl];
+        const int x_min = px - 4, x_max = px + 4, y_min = py - 4, y_max = py + 4;
+        inside = !(x_min < 1 || x_max >= W - 1 || y_min < 1 || y_max >= H - 1);
+        if (inside) {
+          const uint8_t *p = job.level[cl] + static_cast<size_t>(y_min + (q >> 1)) * W + (x_min + 4 * (q & 1));
+          uint32_t lf, rt, up, dn;
+          __builtin_memcpy(&lf, p - 1, 4);
+          __builtin_memcpy(&rt, p + 1, 4);
+          __builtin_memcpy(&up, p - W, 4);
+          __builtin_memcpy(&dn, p + W, 4);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int dx = static_cast<int>((rt >> (8 * k)) & 0xFFu) - static_cast<int>((lf >> (8 * k)) & 0xFFu);
+            const int dy = static_cast<int>((dn >> (8 * k)) & 0xFFu) - static_cast<int>((up >> (8 * k)) & 0xFFu);
+            sxx += dx * dx;
+            syy += dy * dy;
+            sxy += dx * dy;
+          }
+        }
+      }
+    }
+    // sums over the corner's 16 lanes: row_shr 1, 2, 4, 8 leave the row's total in its last lane
+#define SDVL_ROW_SUM(v)                                                   \
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);       \
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);       \
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, false);       \
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, false);
+    SDVL_ROW_SUM(sxx)
+    SDVL_ROW_SUM(syy)
+    SDVL_ROW_SUM(sxy)
+#undef SDVL_ROW_SUM
+    if (q == 15 && ci < n) {
+      const int cl = job.corners[4 * ci + 2];
+      if (cl >= 0 && cl < job.levels) {  // (corners of a level the frame does not have keep whatever the score buffer held, as before)
+        double score = 0.0;
+        if (inside) {
+          float dXX = static_cast<float>(sxx), dYY = static_cast<float>(syy), dXY = static_cast<float>(sxy);
+          dXX = static_cast<float>(dXX / (2.0 * 64));
+          dYY = static_cast<float>(dYY / (2.0 * 64));
+          dXY = static_cast<float>(dXY / (2.0 * 64));
+          const float disc = (dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY);
+          score = 0.5 * (dXX + dYY - sqrt(static_cast<double>(disc)));
+        }
+        job.out_score[ci] = score;
+      }
+    }
   }
 }
+inline int shi_chunks(int max_n) { return (max_n + kShiPerWave - 1) / kShiPerWave; }
 
 
 // ---- Frame::FilterCorners on the device (frame.cc:133-163, FastDetector::FilterCorners fast_detector.cc:177-218) ----------
@@ -460,7 +498,7 @@ int sdvl_shi_tomasi(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, int cap, do
   rc = fill_jobs(ctx, n, frames, cap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   if (max_n == 0) return SDVL_OK;
-  SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, max_n), dim3(64), d_jobs, n, max_n);
+  SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, shi_chunks(max_n)), dim3(64), d_jobs, n, shi_chunks(max_n));
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   SDVL_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->h_out, sizeof(double) * cap, ctx->d_out, sizeof(double) * cap, sizeof(double) * max_n, n,
                                        hipMemcpyDeviceToHost, ctx->stream));
@@ -510,7 +548,7 @@ int sdvl_filter_inputs_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, in
   rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   max_n = max_n > ccap ? ccap : max_n;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, max_n), dim3(64), d_jobs, n, max_n);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, shi_chunks(max_n)), dim3(64), d_jobs, n, shi_chunks(max_n));
   {
     const int units = (ccap + 1) + (desc ? 2 * ccap : 0);  // 16-byte units per row
     SDVL_LAUNCH(ctx, "filter_gather", filter_gather_kernel, dim3((units + 255) / 256, n), dim3(256), static_cast<const OrbJob *>(d_jobs),
@@ -588,7 +626,7 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   rc = fill_jobs(ctx, n, frames, ccap, nullptr, static_cast<double *>(ctx->d_out), &d_jobs, &max_n);
   if (rc) return rc;
   max_n = max_n > ccap ? ccap : max_n;
-  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, max_n), dim3(64), d_jobs, n, max_n);
+  if (max_n > 0) SDVL_LAUNCH(ctx, "shi_tomasi", shi_tomasi_kernel, xcd_frame_grid(n, shi_chunks(max_n)), dim3(64), d_jobs, n, shi_chunks(max_n));
   const size_t jb = (sizeof(FilterJob) * n + 255) / 256 * 256, mb = sizeof(uint32_t) * static_cast<size_t>(n) * mask_words;
   void *hs = nullptr, *dsx = nullptr;
   rc = sdvl_stage_alloc(ctx, jb + mb, &hs, &dsx);
