@@ -321,7 +321,12 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (lane == 0) { out[ri] = res; if (out_host) out_host[ri] = res; }
     return;
   }
-  const V2 pxa = {pr.pxa[0], pr.pxa[1]}, pxb = {pr.pxb[0], pr.pxb[1]};
+  // The epipolar constants of the request (ends of the projected depth interval, line normal, ...) are read where an epipolar
+  // request uses them, through a pointer the compiler may not cache: loaded up front they sat in 30 scalar registers across the
+  // whole kernel, and the kernel spilled 70 scalar registers into vector lanes — ~300 v_readlane / v_writelane (vector instructions:
+  // the path is bound by their issue) and as many s_nop in the hot loops, 40 of them in every round of the range test.  Tracked
+  // points are `fixed` (a circle around px0): they never touch these.
+  const volatile SearchPrep *prv = &prep[ri];
   const int slevel = pr.slevel;
   res.slevel = slevel;
   // ---- CreatePatch, matcher.cc:325-357
@@ -354,7 +359,6 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   uint32_t best_pk = 0;
   {
     const SearchFrame &cf = tcur.f;
-    const double nx = pr.nx, ny = pr.ny, normdist = pr.normdist, xdiff = pr.xdiff, ydiff = pr.ydiff, vline = pr.vline;
     int sumA = 0, sumAA = 0;
     if (!prm.use_orb) {
       const int pv = L.patch[lane];
@@ -384,16 +388,19 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
           const double ddx = rq.px0[0] - posx, ddy = rq.px0[1] - posy;
           if (ddx * ddx + ddy * ddy > range2) inr = false;
         } else {
+          const double nx = prv->nx, ny = prv->ny, normdist = prv->normdist;
           const double dist = normdist - (posx * nx + posy * ny);
           if (fabs(dist) > range) inr = false;
           if (inr) {
-            const double uu = ((posx - pxa.x) * xdiff + (posy - pxa.y) * ydiff) / vline;
+            const double xdiff = prv->xdiff, ydiff = prv->ydiff, vline = prv->vline;
+            const double pxa_x = prv->pxa[0], pxa_y = prv->pxa[1];
+            const double uu = ((posx - pxa_x) * xdiff + (posy - pxa_y) * ydiff) / vline;
             if (uu > 1) {
-              const double ddx = posx - pxb.x, ddy = posy - pxb.y;
+              const double ddx = posx - prv->pxb[0], ddy = posy - prv->pxb[1];
               if ((ddx * ddx + ddy * ddy) > range2) inr = false;
             }
             if (inr && uu < 0) {
-              const double ddx = posx - pxa.x, ddy = posy - pxa.y;
+              const double ddx = posx - pxa_x, ddy = posy - pxa_y;
               if ((ddx * ddx + ddy * ddy) > range2) inr = false;
             }
           }
@@ -464,13 +471,18 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // (division by a zero-length segment, matcher.cc:139-148): every range comparison of the reference is then false and EVERY corner
     // that passes the level and margin tests counts as in range.  A box around pxa would visit a few cells only — such requests
     // scan the whole list, like the reference.
-    const bool line_ok = rq.fixed || (vline > 0.0 && nx == nx && ny == ny);
+    bool line_ok = true;
+    if (!rq.fixed) {
+      const double vline = prv->vline, nx = prv->nx, ny = prv->ny;
+      line_ok = vline > 0.0 && nx == nx && ny == ny;
+    }
     if (binned && line_ok) {
       double bx0, bx1, by0, by1;
       if (rq.fixed) {
         bx0 = rq.px0[0] - range; bx1 = rq.px0[0] + range; by0 = rq.px0[1] - range; by1 = rq.px0[1] + range;
       } else {
-        bx0 = fmin(pxa.x, pxb.x) - range; bx1 = fmax(pxa.x, pxb.x) + range; by0 = fmin(pxa.y, pxb.y) - range; by1 = fmax(pxa.y, pxb.y) + range;
+        const double ax = prv->pxa[0], ay = prv->pxa[1], bx = prv->pxb[0], by = prv->pxb[1];
+        bx0 = fmin(ax, bx) - range; bx1 = fmax(ax, bx) + range; by0 = fmin(ay, by) - range; by1 = fmax(ay, by) + range;
       }
       const int gw = cf.bin_gw, gh = cf.bin_cells / cf.bin_gw;
       // NaN or absurd coordinates fail the comparisons below and fall through to the full scan
