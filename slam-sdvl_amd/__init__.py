@@ -120,7 +120,7 @@ class SynthView(C.Structure):
 ABI_SYMBOLS = [
     "sdvl_ctx_create", "sdvl_ctx_destroy", "sdvl_last_error", "sdvl_ctx_synchronize", "sdvl_ctx_stream",
     "sdvl_ctx_bind_thread", "sdvl_ctx_device", "sdvl_pointer_device", "sdvl_ctx_scratch_device",
-    "sdvl_ctx_timing_enable", "sdvl_ctx_timing_get", "sdvl_ctx_timing_reset",
+    "sdvl_ctx_timing_enable", "sdvl_ctx_timing_only", "sdvl_ctx_timing_get", "sdvl_ctx_timing_reset",
     "sdvl_frame_create", "sdvl_frame_create_many", "sdvl_frame_destroy", "sdvl_frame_upload", "sdvl_frames_upload", "sdvl_ctx_prefetch_images", "sdvl_ctx_prefetch_fence", "sdvl_frame_set_image_device", "sdvl_frame_borrow_image_device",
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
     "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
@@ -278,6 +278,11 @@ class Context:
     # ---- timing
     def timing_enable(self, on=True):
         self._check(self.lib.sdvl_ctx_timing_enable(self.h, int(on)))
+
+    def timing_only(self, name=None):
+        """time only the launches of kernel `name`; None = every launch"""
+        self.lib.sdvl_ctx_timing_only.argtypes = [C.c_void_p, C.c_char_p]
+        self._check(self.lib.sdvl_ctx_timing_only(self.h, name.encode() if name else None))
 
     def timing_reset(self):
         self._check(self.lib.sdvl_ctx_timing_reset(self.h))

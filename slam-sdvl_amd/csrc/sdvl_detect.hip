@@ -1709,7 +1709,10 @@ static int fast_cell_table(sdvl_ctx *ctx, const FastLevels &lv, const sdvl_frame
   if (ctx->d_fast_table) (void)hipFree(ctx->d_fast_table);
   ctx->d_fast_table = nullptr;
   SDVL_HIP_CHECK(ctx, hipMalloc(&ctx->d_fast_table, sizeof(CellGeo) * static_cast<size_t>(total > 0 ? total : 1)));
-  if (total > 0) SDVL_HIP_CHECK(ctx, hipMemcpy(ctx->d_fast_table, t.data(), sizeof(CellGeo) * static_cast<size_t>(total), hipMemcpyHostToDevice));
+  if (total > 0) {
+    SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_fast_table, t.data(), sizeof(CellGeo) * static_cast<size_t>(total), hipMemcpyHostToDevice, ctx->stream));
+    SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   ctx->fast_table_key = key;
   ctx->fast_table_cells = total;
   *out = static_cast<const CellGeo *>(ctx->d_fast_table);

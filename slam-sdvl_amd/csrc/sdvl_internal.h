@@ -131,6 +131,7 @@ struct sdvl_ctx {
   void *wait_user = nullptr;
   // per-kernel timing (HIP events on `stream`)
   int timing = 0;
+  std::string timing_only;  // when not empty: only launches of this name get dispatch events (sdvl_ctx_timing_only)
   std::vector<KernelTimer> timers;
   struct Pending { int timer; hipEvent_t a, b; };
   std::vector<Pending> pending;

@@ -1094,7 +1094,10 @@ int sdvl_ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int max_
   ctx->d_nits = nullptr;
   SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
   SDVL_HIP_CHECK(ctx, hipMalloc(&ctx->d_nits, entries * sizeof(int32_t)));
-  SDVL_HIP_CHECK(ctx, hipMemcpy(ctx->d_nits, t.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
+  // on the context's own stream, not the legacy stream (whose implicit synchronisation collides with a capture under way on another
+  // thread of the farm: SDVL_STEP_GRAPH=1)
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_nits, t.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->nits_points = npoints_cfg;
   ctx->nits_its = max_its;
   ctx->nits_max_size = max_size;

@@ -16,6 +16,7 @@
 // One workgroup per tracker in the three kernels; nothing here needs a workgroup-to-workgroup hand-off.
 // Compiled with -ffp-contract=off like everything else: the arithmetic is the host layer's, statement for statement.
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "sdvl_internal.h"
@@ -472,6 +473,12 @@ struct sdvl_track_set {
   int stride = 0;
   int phase = 0;  // 0 idle, 1 aligned, 2 searched
   uint32_t ticket = 0;
+  // SDVL_STEP_GRAPH=1 (A/B): the search -> pose -> commit chain of a step as a HIP graph.  The chain is captured
+  // every step (its scalars and launch geometry follow the step's feature counts), the instantiated graph is UPDATED in place with
+  // the new capture (same topology) and launched as one submission.
+  hipGraphExec_t graph_exec = nullptr;
+  double chain_submit_s = 0.0;  // host time inside the chain's submission (either form), for the A/B
+  long chain_submits = 0;
   sdvl_camera cam;
   sdvl_track_params prm;
 };
@@ -574,6 +581,10 @@ int sdvl_track_destroy(sdvl_ctx *ctx, sdvl_track_set *s) {
   if (s->d_feats[1]) (void)hipFree(s->d_feats[1]);
   if (s->d_scratch) (void)hipFree(s->d_scratch);
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+  if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+  if (getenv("SDVL_STEP_GRAPH_STATS") && s->chain_submits > 0)
+    fprintf(stderr, "sdvl_track: chain submission (%s): %.1f us per group-step over %ld steps\n", getenv("SDVL_STEP_GRAPH") ? "HIP graph" : "eager launches",
+            s->chain_submit_s / s->chain_submits * 1e6, s->chain_submits);
   delete s;
   return SDVL_OK;
 }
@@ -782,6 +793,33 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
   // Round 4: track_project's lanes run SearchPoint's scalar phase for the requests they assemble: no search_prepare launch in a tracked
   // step.  SDVL_TRACK_SEPARATE_PREPARE=1: the round-3 chain (A/B).
   static const bool fused_prepare = getenv("SDVL_TRACK_SEPARATE_PREPARE") == nullptr;
+  static const bool use_graph = getenv("SDVL_STEP_GRAPH") != nullptr;
+  const auto t_submit = std::chrono::steady_clock::now();
+  const bool timing_was = ctx->timing;
+  if (use_graph) {
+    ctx->timing = false;  // start / stop events of a dispatch cannot be recorded into a capture
+    SDVL_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  }
+  const auto end_capture = [&]() -> hipError_t {  // leaves the stream out of capture mode whatever happened inside
+    if (!use_graph) return hipSuccess;
+    ctx->timing = timing_was;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (e != hipSuccess) return e;
+    if (s->graph_exec) {
+      hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+      hipGraphNode_t bad = nullptr;
+      if (hipGraphExecUpdate(s->graph_exec, g, &bad, &res) != hipSuccess || res != hipGraphExecUpdateSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphExecDestroy(s->graph_exec);
+        s->graph_exec = nullptr;
+      }
+    }
+    if (!s->graph_exec) e = hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return e;
+    return hipGraphLaunch(s->graph_exec, ctx->stream);
+  };
   {
     const size_t lds = static_cast<size_t>(stride) * (8 + 16 + 2) + 64;
     if (lds > 60 * 1024) {  // beyond the default dynamic LDS limit: raise it once per device
@@ -808,16 +846,16 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
   }
   int rc = sdvl_search_launch_device(ctx, n_jobs * stride, s->d_reqs, registry, s->d_blocks, n_jobs * (stride / kWavesPerBlock), &s->cam,
                                      &s->prm.search, s->d_prep, s->d_res, nullptr, /*prepared*/ fused_prepare);
-  if (rc) return rc;
+  if (rc) { (void)end_capture(); return rc; }
   // match ranks are not needed separately: track_commit derives them again from the same flags
   rc = sdvl_select_matches_launch(ctx, n_jobs, s->d_chain, nullptr, s->d_cfirst, s->d_res, s->d_reqpt, &s->cam, s->d_pjobs, s->d_obs, s->d_nobs,
                                   nullptr);
-  if (rc) return rc;
+  if (rc) { (void)end_capture(); return rc; }
   sdvl_pose_params pp = s->prm.pose;
   pp.pad_ = 1;  // raw rand() values: the kernel reduces them modulo the match count it finds in the job
   rc = sdvl_pose_enqueue_device(ctx, n_jobs, s->d_pjobs, s->d_obs, s->d_rand, static_cast<const int32_t *>(ctx->d_nits), &pp, s->d_hyp, s->d_pres,
                                 s->d_lists, s->mm);
-  if (rc) return rc;
+  if (rc) { (void)end_capture(); return rc; }
   {
     // s_before | s_found | (8-byte aligned) depths of the new frame's points, at most mm of them
     const size_t lds = (static_cast<size_t>(stride + 1) * 2 + stride + 64 + 7) / 8 * 8 + static_cast<size_t>(s->mm) * 8;
@@ -832,6 +870,9 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
                           s->h_results, s->h_feats, s->h_stats);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
   }
+  SDVL_HIP_CHECK(ctx, end_capture());
+  s->chain_submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_submit).count();
+  s->chain_submits++;
   SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_CHAIN, &s->ticket));
   s->phase = 2;
   return SDVL_OK;

@@ -41,6 +41,14 @@ def check(d, steps=4, warmup=1):
     assert r["kernel"] == max(ms, key=ms.get), (r["kernel"], ms)
     assert abs(r["avg_launch_us"] * 1e-6 * r["achieved"] * 1e9 - r["algorithmic_bytes_per_launch"]) / r["algorithmic_bytes_per_launch"] < 0.01
     assert r["path_hbm"]["frac"] > 0
+    # round 4: every dispatch is timed during the warm-up steps; inside the timed region only the roofline's kernel carries events
+    kt = d["kernel_timing"]
+    assert kt["timed_region"] == "launches of %s only (the roofline's kernel)" % r["kernel"] and "warm-up" in kt["kernel_ms_per_step_from"]
+    # the link is the roof of the drop-in (host-fed) figure
+    ln = r["link"]
+    assert ln["bound"] == "pcie_h2d" and ln["peak"] == 57.0 and abs(ln["frac"] - ln["achieved"] / 57.0) < 1e-3
+    assert abs(ln["achieved"] - d["host_fed"]["pcie_h2d_gb_per_s"]) < 0.02 and ln["per_gpu_min_max"]["min"] > 0
+    assert d["config"]["cross_gpu_relocalisation"].startswith("declined")
     if "valu" in r:   # present when an SQ pass is committed under profiles/
         assert r["valu"]["peak_wave_insts_per_s"] == 256 * 4 * 2.4e9 / 2 and 0 < r["valu"]["path_frac"] < 1
     if d["sustained"] is not None:   # whole sequences on fresh trackers, host-fed (skipped with the reference's mapper in the step)
