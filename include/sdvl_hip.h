@@ -596,6 +596,12 @@ int sdvl_frames_register(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, 
  * its features go to buffer feat_buf[i].  Asynchronous. */
 int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *set, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,
                       const sdvl_track_point *points, const int32_t *n_features, const sdvl_track_feature *features);
+/* the same rows APPENDED behind the rows the tables hold (the step that has just run left trackers[i]'s new features in buffer
+ * feat_buf[i]): n_points[i] new points take the next point rows, n_features[i] new features the next feature rows of that buffer;
+ * features name points by their index in the whole table.  What a keyframe's seeded points (Map::InitCandidates, map.cc:262-400,
+ * with the plane-map stand-in) add to a table that is otherwise current on the device.  Asynchronous. */
+int sdvl_track_append(sdvl_ctx *ctx, sdvl_track_set *set, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,
+                      const sdvl_track_point *points, const int32_t *n_features, const sdvl_track_feature *features);
 /* first third of a step: alignment of n_jobs frames against their last frames, queued.  cell_rank[j][grid_cells] = position
  * of every grid cell in tracker j's shuffled cell_order_; rand_raw[j][max_ransac_its] = its next rand() values. */
 int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *set, int n_jobs, const sdvl_track_job *jobs, const uint16_t *cell_rank,

@@ -29,10 +29,12 @@ namespace {
 using namespace sdvl;
 
 
-struct UploadRec {  // sdvl_track_upload: where one tracker's staged rows go
+struct UploadRec {  // sdvl_track_upload / sdvl_track_append: where one tracker's staged rows go
   int tracker, feat_buf;
   int n_points, n_feat;
   long long point_off, feat_off;  // element offsets into the staged arrays
+  int point_dst, feat_dst;        // first row written in the tracker's tables (0: the table is replaced; > 0: rows are appended)
+  long long pad_;
 };
 
 struct RegisterRec {  // sdvl_frame_register
@@ -85,11 +87,11 @@ __global__ __launch_bounds__(256) void track_upload_kernel(const UploadRec *__re
   const UploadRec r = recs[blockIdx.x];
   // rows are multiples of 16 bytes: copy them as such
   const uint4 *sp = reinterpret_cast<const uint4 *>(src_points + r.point_off);
-  uint4 *dp = reinterpret_cast<uint4 *>(points + static_cast<size_t>(r.tracker) * np);
+  uint4 *dp = reinterpret_cast<uint4 *>(points + static_cast<size_t>(r.tracker) * np + r.point_dst);
   const int pw = r.n_points * static_cast<int>(sizeof(TrackPoint) / 16);
   for (int i = threadIdx.x; i < pw; i += 256) dp[i] = sp[i];
   const uint4 *sf = reinterpret_cast<const uint4 *>(src_feats + r.feat_off);
-  uint4 *df = reinterpret_cast<uint4 *>((r.feat_buf ? feats1 : feats0) + static_cast<size_t>(r.tracker) * nf);
+  uint4 *df = reinterpret_cast<uint4 *>((r.feat_buf ? feats1 : feats0) + static_cast<size_t>(r.tracker) * nf + r.feat_dst);
   const int fw = r.n_feat * static_cast<int>(sizeof(TrackFeat) / 16);
   for (int i = threadIdx.x; i < fw; i += 256) df[i] = sf[i];
 }
@@ -617,15 +619,19 @@ int sdvl_frames_register(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, 
   return SDVL_OK;
 }
 
-int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,
-                      const sdvl_track_point *points, const int32_t *n_features, const sdvl_track_feature *features) {
+// append == false: the tables of the trackers are replaced; true: the rows go behind the rows the tables hold (round 4: a keyframe of
+// the plane-map configuration adds its ~60 seeded points and their features to the tables the step has just updated on the device,
+// instead of the host rebuilding all ~250 rows from Feature / Point objects)
+static int track_upload_rows(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,
+                             const sdvl_track_point *points, const int32_t *n_features, const sdvl_track_feature *features, bool append) {
   if (!ctx || !s || s->ctx != ctx || n < 0 || (n > 0 && (!trackers || !feat_buf || !n_points || !n_features))) return SDVL_ERR_INVALID;
   if (n == 0) return SDVL_OK;
   SDVL_REQUIRE(ctx, s->phase == 0, "sdvl_track_upload while a step is in flight");
   size_t tp = 0, tf = 0;
   for (int i = 0; i < n; i++) {
     SDVL_REQUIRE(ctx, trackers[i] >= 0 && trackers[i] < s->n && (feat_buf[i] == 0 || feat_buf[i] == 1), "bad tracker / buffer index");
-    if (n_points[i] < 0 || n_points[i] > s->np || n_features[i] < 0 || n_features[i] > s->nf) {
+    const int p0 = append ? s->n_points[trackers[i]] : 0, f0 = append ? s->n_feat[feat_buf[i]][trackers[i]] : 0;
+    if (n_points[i] < 0 || p0 + n_points[i] > s->np || n_features[i] < 0 || f0 + n_features[i] > s->nf) {
       ctx->err = "table larger than the set's capacity";
       return SDVL_ERR_CAPACITY;
     }
@@ -642,7 +648,8 @@ int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *tr
   TrackPoint *hp = reinterpret_cast<TrackPoint *>(h8 + rb);
   size_t po = 0, fo = 0;
   for (int i = 0; i < n; i++) {
-    recs[i] = UploadRec{trackers[i], feat_buf[i], n_points[i], n_features[i], static_cast<long long>(po), static_cast<long long>(fo)};
+    const int p0 = append ? s->n_points[trackers[i]] : 0, f0 = append ? s->n_feat[feat_buf[i]][trackers[i]] : 0;
+    recs[i] = UploadRec{trackers[i], feat_buf[i], n_points[i], n_features[i], static_cast<long long>(po), static_cast<long long>(fo), p0, f0, 0};
     for (int k = 0; k < n_points[i]; k++) {
       const sdvl_track_point &src = points[po + k];
       SDVL_REQUIRE(ctx, src.ref && src.ref->home == ctx && src.ref->reg_id >= 0, "a point's reference frame was not created on this context");
@@ -655,10 +662,10 @@ int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *tr
     }
     for (int k = 0; k < n_features[i]; k++) {
       const int pt = features[fo + k].point;
-      SDVL_REQUIRE(ctx, pt < 0 || (pt & kPointMask) < n_points[i], "feature names a point outside its tracker's table");
+      SDVL_REQUIRE(ctx, pt < 0 || (pt & kPointMask) < p0 + n_points[i], "feature names a point outside its tracker's table");
     }
-    s->n_points[trackers[i]] = n_points[i];
-    s->n_feat[feat_buf[i]][trackers[i]] = n_features[i];
+    s->n_points[trackers[i]] = p0 + n_points[i];
+    s->n_feat[feat_buf[i]][trackers[i]] = f0 + n_features[i];
     po += n_points[i];
     fo += n_features[i];
   }
@@ -669,6 +676,16 @@ int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *tr
               s->d_feats[1], s->np, s->nf);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
+}
+
+int sdvl_track_upload(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,
+                      const sdvl_track_point *points, const int32_t *n_features, const sdvl_track_feature *features) {
+  return track_upload_rows(ctx, s, n, trackers, feat_buf, n_points, points, n_features, features, false);
+}
+
+int sdvl_track_append(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int32_t *trackers, const int32_t *feat_buf, const int32_t *n_points,
+                      const sdvl_track_point *points, const int32_t *n_features, const sdvl_track_feature *features) {
+  return track_upload_rows(ctx, s, n, trackers, feat_buf, n_points, points, n_features, features, true);
 }
 
 int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_track_job *jobs, const uint16_t *cell_rank, const int32_t *rand_raw,

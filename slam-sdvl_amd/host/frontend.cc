@@ -615,12 +615,10 @@ void Frame::FilterCornersBegin(const vector<shared_ptr<Frame>> &frames) {
   for (int i = 0; i < n; i++) {
     Frame &f = *frames[i];
     devs[i] = f.dev_;
-    vector<shared_ptr<Feature>> &kf_features = f.GetFeatures();
-    for (auto it = kf_features.begin(); it != kf_features.end(); it++) {  // FastDetector::LockCell, fast_detector.cc:48-51
-      const Vector2d &p = (*it)->GetPosition();
-      const int index = static_cast<int>(p(1) / cell) * gw + static_cast<int>(p(0) / cell);
+    f.ForEachFeaturePosition([&](double px, double py) {  // FastDetector::LockCell, fast_detector.cc:48-51
+      const int index = static_cast<int>(py / cell) * gw + static_cast<int>(px / cell);
       if (index >= 0 && index < gw * gh) locked[static_cast<size_t>(i) * words + (index >> 5)] |= 1u << (index & 31);
-    }
+    });
   }
   dev->Check(sdvl_filter_corners_begin(dev->ctx(), n, devs.data(), locked.data(), words, cell, DetectMargin(), Config::MinFeatureScore(),
                                        Config::UseORB() ? 1 : 0), "sdvl_filter_corners_begin");
@@ -650,10 +648,8 @@ void Frame::FilterCornersEnd(const vector<shared_ptr<Frame>> &frames, const std:
 // frame.cc:165-179
 int Frame::GetNumPoints() const {
   int count = 0;
-  if (flat_) {  // not materialised yet: a record with a point index is a feature with a point
+  if (flat_)  // not materialised yet: a record with a point index is a feature with a point
     for (const sdvl_track_feature_out &f : flat_->feats) count += f.point >= 0 ? 1 : 0;
-    return count;
-  }
   for (auto it = features_.begin(); it != features_.end(); it++) {
     if (!(*it)) continue;
     if (!(*it)->GetPointRaw()) continue;
@@ -701,13 +697,26 @@ void Frame::MaterializeFeatures() {
   const FlatSpan feats = flat_store_.feats;
   const shared_ptr<PointTable> points = flat_store_.points;
   flat_ = nullptr;  // GetFeatures() below must not come back here
-  features_.reserve(features_.size() + feats.size());
+  vector<shared_ptr<Feature>> behind;  // features added while the tracked ones were flat (a keyframe's seeds) stay behind them
+  behind.swap(features_);
+  features_.reserve(behind.size() + feats.size());
   for (const sdvl_track_feature_out &f : feats) {
     shared_ptr<Feature> feature = NewFeature(Vector2d(f.px[0], f.px[1]), f.level);
-    if (f.point >= 0) feature->SetPoint((*points)[f.point]);
-    else outliers_.push_back(feature->GetPosition());
+    if (f.point >= 0) {
+      const shared_ptr<Point> &pt = (*points)[f.point];
+      if (!link_on_materialize_) {
+        feature->SetPoint(pt);
+      } else if (!pt->ToDelete()) {  // (a point deleted since then has lost its features, Map::EmptyTrash, map.cc:207-259)
+        feature->SetPoint(pt);
+        pt->AddFeature(feature);
+      }
+    } else {
+      outliers_.push_back(feature->GetPosition());
+    }
     features_.push_back(std::move(feature));
   }
+  for (shared_ptr<Feature> &f : behind) features_.push_back(std::move(f));
+  link_on_materialize_ = false;
   flat_ = &flat_store_;
   DropFlat();
 }

@@ -300,7 +300,21 @@ class Frame : public std::enable_shared_from_this<Frame> {
   }
   Vector3d GetWorldPosition() const { return GetWorldPose().GetTranslation(); }
   Vector3d GetRelativePos(const Vector3d &pos) const { return pose_ * pos; }
-  void AddFeature(const std::shared_ptr<Feature> &f) { GetFeatures().push_back(f); scene_depth_hint_valid_ = false; }
+  // (on a frame whose tracked features are still flat records the new feature goes BEHIND them: MaterializeFeatures keeps that order)
+  void AddFeature(const std::shared_ptr<Feature> &f) { features_.push_back(f); scene_depth_hint_valid_ = false; }
+  // Round 4: a keyframe of the tracked path keeps its matched features flat; the points learn of their new observation
+  // (Point::AddFeature, sdvl.cc:109-111 / feature_align.cc) when — if ever — somebody asks for the Feature objects
+  void LinkPointsOnMaterialize() { link_on_materialize_ = true; }
+  // positions of all features, flat or not, without turning flat records into objects (FastDetector::LockCell, fast_detector.cc:48-51)
+  template <class Fn>
+  void ForEachFeaturePosition(Fn fn) const {
+    if (flat_)
+      for (const sdvl_track_feature_out &f : flat_->feats) fn(f.px[0], f.px[1]);
+    for (const std::shared_ptr<Feature> &f : features_) fn(f->GetPosition()(0), f->GetPosition()(1));
+  }
+  // the Feature objects appended behind the flat records (a keyframe's seeded features), without materialising anything
+  const std::vector<std::shared_ptr<Feature>> &ObjectFeatures() const { return features_; }
+  int NumFlatFeatures() const { return flat_ ? static_cast<int>(flat_->feats.size()) : 0; }
   // a Feature on this frame whose storage comes from the frame's arena (same object as make_shared<Feature>(frame, ...))
   std::shared_ptr<Feature> NewFeature(const Vector2d &p, int level) {
     if (!arena_) arena_ = NewArena();
@@ -312,7 +326,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
     return std::allocate_shared<Point>(ArenaAllocator<Point>(arena_));
   }
   void AddOutlier(const Vector2d &p) { outliers_.push_back(p); }
-  int GetNumFeatures() const { return flat_ ? static_cast<int>(flat_->feats.size()) : static_cast<int>(features_.size()); }
+  int GetNumFeatures() const { return (flat_ ? static_cast<int>(flat_->feats.size()) : 0) + static_cast<int>(features_.size()); }
   int GetNumPoints() const;
   bool Project(const Vector3d &p3D, Vector2d *p2D);
   void CreateCorners(int levels, int nfeatures);
@@ -380,6 +394,7 @@ class Frame : public std::enable_shared_from_this<Frame> {
   };
   FlatFeatures flat_store_;
   FlatFeatures *flat_ = nullptr;  // &flat_store_ while the features are still flat records
+  bool link_on_materialize_ = false;
   void MaterializeFeatures();
   void DropFlat();
   bool registered_ = false;  // the context's (frame, pose) registry holds this frame with its current pose

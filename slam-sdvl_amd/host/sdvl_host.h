@@ -182,6 +182,11 @@ class SDVL {
     std::vector<sdvl_track_point> up_points;
     std::vector<sdvl_track_feature> up_feats;
     std::vector<Frame *> up_register;                 // keyframes the registry does not know yet
+    // round 4: the step made the frame a keyframe and left the table current on the device: the rows of the points the map seeds on
+    // it are APPENDED (sdvl_track_append) instead of the table being rebuilt from objects; first_seed = the keyframe's object
+    // features before the seeding (what comes behind are the seeds)
+    bool append_pending = false;
+    size_t first_seed = 0;
   } track_;
 };
 
@@ -220,6 +225,7 @@ class SDVLBatch {
   bool HandleFramesTracked(const std::vector<Image> &imgs, FrameStats *stats);  // false: not applicable this step
   void HandleFramesGeneric(const std::vector<Image> &imgs, FrameStats *stats);
   bool BuildTable(SDVL &t);
+  bool AppendSeeds(SDVL &t, const std::shared_ptr<Frame> &kf);  // rows of the points seeded on kf -> track_.up_points / up_feats
   void SyncStats(SDVL &t);
   void FetchCornerCounts(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats);
   void EpilogueAndMapper(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats, std::vector<std::shared_ptr<Frame>> *kfs,

@@ -615,6 +615,54 @@ bool SDVLBatch::BuildTable(SDVL &t) {
   return true;
 }
 
+// The points PlaneMap::SeedFromFiltered has just put on keyframe `kf` (its object features from track_.first_seed on) as table rows
+// behind the rows the tables hold: point index = position in the tracker's point table, which grows by the same points.
+bool SDVLBatch::AppendSeeds(SDVL &t, const shared_ptr<Frame> &kf) {
+  SDVL::TrackState &ts = t.track_;
+  if (!ts.points) return false;
+  ts.up_points.clear();
+  ts.up_feats.clear();
+  const vector<shared_ptr<Feature>> &objs = kf->ObjectFeatures();
+  const int row_base = ts.slot * track_cap_;
+  if (static_cast<int>(ts.points->size() + (objs.size() - ts.first_seed)) > track_cap_) return false;
+  if (kf->NumFlatFeatures() + static_cast<int>(objs.size()) > std::min(track_cap_, static_cast<int>(SDVL_MAX_ALIGN_FEATURES))) return false;
+  if (kf->owner() != dev_ || !kf->IsRegistered()) return false;
+  ts.up_points.reserve(objs.size() - ts.first_seed);
+  ts.up_feats.reserve(objs.size() - ts.first_seed);
+  for (size_t fi = ts.first_seed; fi < objs.size(); fi++) {
+    Feature *ft = objs[fi].get();
+    Point *pt = ft ? ft->GetPointRaw() : nullptr;
+    if (!ft || !pt || pt->GetInitFeatureRaw() != ft) return false;  // a seed is the first observation of its own point
+    sdvl_track_feature f;
+    f.px[0] = ft->GetPosition()(0); f.px[1] = ft->GetPosition()(1);
+    f.bearing[0] = ft->GetVector()(0); f.bearing[1] = ft->GetVector()(1); f.bearing[2] = ft->GetVector()(2);
+    f.level = ft->GetLevel();
+    const int idx = static_cast<int>(ts.points->size());
+    f.point = idx;
+    ts.points->push_back(ft->GetPoint());
+    pt->SetTrackRow(row_base + idx);
+    ts.up_points.emplace_back();
+    sdvl_track_point &tp = ts.up_points.back();
+    const Vector3d P = pt->GetPosition();
+    tp.position[0] = P(0); tp.position[1] = P(1); tp.position[2] = P(2);
+    tp.px[0] = f.px[0]; tp.px[1] = f.px[1];
+    tp.bearing[0] = f.bearing[0]; tp.bearing[1] = f.bearing[1]; tp.bearing[2] = f.bearing[2];
+    tp.idepth = pt->GetInverseDepth();
+    tp.idepth_std = pt->GetStd();
+    tp.ref = kf->device();
+    tp.level = f.level;
+    tp.fixed = pt->IsFixed() ? 1 : 0;
+    tp.score = pt->Score();
+    tp.n_failed = pt->GetFailed();
+    tp.last_frame = pt->GetLastFrame();
+    tp.status = static_cast<int32_t>(pt->GetStatus());
+    if (ft->HasDescriptor()) std::memcpy(tp.desc, ft->DescriptorData().data(), 32);
+    else std::memset(tp.desc, 0, 32);
+    ts.up_feats.push_back(f);
+  }
+  return true;
+}
+
 // One step of B trackers on the device-resident tables: ONE submission (alignment, detection, reprojection, search, match
 // selection, pose, table update) and ONE wait.  The host keeps what only it can do: rand() (cell shuffle, RANSAC draws), the
 // motion model, tracking quality, the keyframe decision and everything a keyframe sets off.
@@ -824,25 +872,45 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         filter_begun = true;
       }
     }
+    static const bool flat_keyframes = std::getenv("SDVL_KEYFRAME_OBJECTS") == nullptr;  // =1: round 3's path (A/B)
+    vector<int> r_matches(R);
+    for (int k = 0; k < R; k++) r_matches[k] = tr_res_[k].matches;
     ParallelFor(R, [&](int k) {
       const int i = run[k];
       SDVL &t = *trk_[i];
       FrameStats &st = stats[i];
       if (decision[k] == 0) return;  // tracking lost: last_frame and its table stay
       if (decision[k] == 2) {
-        // the frame becomes part of the map: its features and the points behind them turn into objects
-        SyncStats(t);
-        vector<shared_ptr<Feature>> &features = t.current_frame_->GetFeatures();
-        for (auto it = features.begin(); it != features.end(); it++)
-          if (Point *p = (*it)->GetPointRaw()) p->AddFeature(*it);
+        // Round 4, plane-map trackers: the keyframe's ~190 matched features STAY flat records and its table stays the one the step has
+        // just left on the device — what the keyframe adds (the points the map seeds in its empty cells, ~60) is appended to both
+        // sides after the seeding (EpilogueAndMapper -> AppendSeeds -> sdvl_track_append).  Until round 3 every keyframe turned its
+        // features into objects, linked them to their points, and the whole table was rebuilt from the objects before the next step:
+        // 8 of a group-step's 12 ms of host time (MaterializeFeatures, BuildTable, malloc / mprotect under them), ~100 KB of fresh
+        // memory per keyframe.  The objects appear the first time somebody asks (Frame::GetFeatures(): API callers, relocalisation,
+        // the host-driven path, a table rebuild when the rows run out), the points learn of their observations then.
+        const bool plane = !dynamic_cast<MapperMap *>(t.map_);
+        const size_t rows = t.track_.points ? t.track_.points->size() : static_cast<size_t>(track_cap_);
+        const bool room = static_cast<int>(rows) + track_cells_ <= track_cap_ && r_matches[k] + track_cells_ <= track_cap_;
+        if (flat_keyframes && plane && room && t.current_frame_->HasFlatFeatures()) {
+          t.current_frame_->LinkPointsOnMaterialize();
+          t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
+          t.track_.append_pending = true;
+          t.track_.first_seed = t.current_frame_->ObjectFeatures().size();
+        } else {
+          // the frame becomes part of the map: its features and the points behind them turn into objects
+          SyncStats(t);
+          vector<shared_ptr<Feature>> &features = t.current_frame_->GetFeatures();
+          for (auto it = features.begin(); it != features.end(); it++)
+            if (Point *p = (*it)->GetPointRaw()) p->AddFeature(*it);
+          t.track_.valid = false;  // seeding / the mapper add features: the table is rebuilt from the keyframe
+        }
         t.current_frame_->ClearSceneDepthHint();  // a keyframe's features lose the points EmptyTrash deletes (map.cc:207-259)
         t.current_frame_->SetKeyframe();
         t.map_->AddKeyframe(t.current_frame_);
         t.last_kf_ = t.current_frame_;
         t.map_->LimitKeyframes(t.current_frame_);  // sdvl.cc:114
-        if (!dynamic_cast<MapperMap *>(t.map_)) t.pending_kf_ = t.current_frame_;
+        if (plane) t.pending_kf_ = t.current_frame_;
         st.keyframe = 1;
-        t.track_.valid = false;  // seeding / the mapper add features: the table is rebuilt from the keyframe
       } else {
         t.map_->AddFrame(t.current_frame_);
         t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
@@ -1269,12 +1337,36 @@ void SDVLBatch::EpilogueAndMapper(const vector<shared_ptr<Frame>> &frames, Frame
     if (!kfs.empty()) {
       const std::function<void(int, const std::function<void(int)> &)> pfor = [this](int n, const std::function<void(int)> &fn) { ParallelFor(n, fn); };
       Frame::FilterCornersEnd(kfs, &pfor);
+      vector<char> appended(kfs.size(), 0);
       ParallelFor(static_cast<int>(kfs.size()), [&](int k) {
         SDVL &t = *trk_[kf_owner[k]];
         PlaneMap *pm = dynamic_cast<PlaneMap *>(t.map_);
         if (pm) pm->SeedFromFiltered(kfs[k]);  // other Map implementations run their own mapper on AddKeyframe
         t.pending_kf_ = nullptr;
+        if (t.track_.append_pending) {
+          t.track_.append_pending = false;
+          if (t.track_.valid && AppendSeeds(t, kfs[k])) appended[k] = 1;
+          else t.track_.valid = false;  // something the rows cannot express: the table is rebuilt from the objects
+        }
       });
+      {  // the new rows of all keyframes of the step in ONE submission
+        vector<int32_t> up_trk, up_buf, up_np, up_nf;
+        tr_up_points_.clear();
+        tr_up_feats_.clear();
+        for (size_t k = 0; k < kfs.size(); k++) {
+          if (!appended[k]) continue;
+          SDVL::TrackState &ts = trk_[kf_owner[k]]->track_;
+          up_trk.push_back(kf_owner[k]);
+          up_buf.push_back(ts.feat_buf);
+          up_np.push_back(static_cast<int32_t>(ts.up_points.size()));
+          up_nf.push_back(static_cast<int32_t>(ts.up_feats.size()));
+          tr_up_points_.insert(tr_up_points_.end(), ts.up_points.begin(), ts.up_points.end());
+          tr_up_feats_.insert(tr_up_feats_.end(), ts.up_feats.begin(), ts.up_feats.end());
+        }
+        if (!up_trk.empty())
+          dev_->Check(sdvl_track_append(dev_->ctx(), track_, static_cast<int>(up_trk.size()), up_trk.data(), up_buf.data(), up_np.data(), tr_up_points_.data(),
+                                        up_nf.data(), tr_up_feats_.data()), "sdvl_track_append");
+      }
     }
   }
 

@@ -1,6 +1,5 @@
 set -u
 O=gpurun_out
-run() { env "$@" python bench.py --steps 60 --warmup 5 --cpu-frames 0 --host-steps 0 --sustained-frames 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%.1f' % (d['value']/1e3), end=' ')"; }
-for i in 1 2 3; do
-  echo -n "none: "; run SDVL_BENCH_NO_KERNEL_TIMING=1; echo -n " | dominant only: "; run SDVL_X=1; echo -n " | all: "; run SDVL_BENCH_TIME_ALL=1; echo
-done
+python -m pytest tests/test_gpu_tracker.py tests/test_gpu_long.py -x -q -m gpu > $O/t_flat.log 2>&1; echo "tracker+long tests rc=$?"; tail -4 $O/t_flat.log
+bash tools/r4_ab.sh "SDVL_KEYFRAME_OBJECTS=1" 3 60
+grep -h "host CPU\|host memory" $O/ab_a.err $O/ab_b.err
