@@ -732,6 +732,13 @@ struct IaIn {
   const double *T0;     // [7] start of the alignment
   float *items;         // kGlobalItems: the job's slice of the work buffer
   sdvl_align_result *out;
+  // kPre: what image_align_pre_kernel left for this job, one block per level (index 0 = max_level): items [48][pitch] floats,
+  // gradient sums [3][pitch] doubles, visibility bytes [pitch], and the factored normal matrix of the level's visible set
+  const float *pre_items = nullptr;
+  const double *pre_S = nullptr;
+  const uint8_t *pre_vis = nullptr;
+  const double *pre_fac = nullptr;  // [32] per level: L[21] | tr[6] | n_visible
+  int pre_pitch = 0;
 };
 
 // feature source A: the records of the C-ABI calls (sdvl_align_feature, include/sdvl_hip.h)
@@ -766,8 +773,97 @@ struct IaTableFeats {
   __device__ __forceinline__ void pos(int f, double *px, double *py) const { *px = F[f].px[0]; *py = F[f].px[1]; }
 };
 
-template <int kWaves, bool kGlobalItems, class Feats>
+// PrecomputePatches of ONE feature at one level (image_align.cc:208-267): border test, the 16 reference items {patch, dx, dy} and
+// the gradient sums Sxx, Sxy, Syy.  Returns whether the feature is visible at the level; writes nothing otherwise.
+__device__ __forceinline__ bool ia_precompute_feature(const uint8_t *ref_img, int W, int H, float scale, double fpx, double fpy, bool valid, int f,
+                                                      int pitch, float2 *it_pd, float *it_dy, double *sums3) {
+  const float u_ref = static_cast<float>(fpx * scale);
+  const float v_ref = static_cast<float>(fpy * scale);
+  const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
+  const int border = 3;
+  if (!valid || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) return false;
+  const float su = u_ref - ui, sv = v_ref - vi;
+  const float w_tl = static_cast<float>((1.0 - su) * (1.0 - sv));
+  const float w_tr = static_cast<float>(su * (1.0 - sv));
+  const float w_bl = static_cast<float>((1.0 - su) * sv);
+  const float w_br = su * sv;
+  // g[y][x] = the bilinear sum whose top-left pixel is (ui - 3 + x, vi - 3 + y): patch value of pixel (px, py) = g[py+1][px+1],
+  // dx = 0.5 (g[py+1][px+2] - g[py+1][px]), dy = 0.5 (g[py+2][px+1] - g[py][px+1]) — the reference's own five expressions
+  const uint8_t *wp = ref_img + static_cast<size_t>(vi - 3) * W + (ui - 3);
+  float g[3][6];  // rolling: rows y-2, y-1, y of the grid
+  float ra[7], rb[7];
+  {
+    uint32_t lo, hi;
+    ia_load_row8(wp, 7, &lo, &hi);
+#pragma unroll
+    for (int k = 0; k < 4; k++) ra[k] = ia_byte(lo, k);
+#pragma unroll
+    for (int k = 4; k < 7; k++) ra[k] = ia_byte(hi, k - 4);
+  }
+  double sxx = 0.0, sxy = 0.0, syy = 0.0;
+#pragma unroll
+  for (int y = 0; y < 6; y++) {
+    uint32_t lo, hi;
+    ia_load_row8(wp + static_cast<size_t>(y + 1) * W, 7, &lo, &hi);
+#pragma unroll
+    for (int k = 0; k < 4; k++) rb[k] = ia_byte(lo, k);
+#pragma unroll
+    for (int k = 4; k < 7; k++) rb[k] = ia_byte(hi, k - 4);
+#pragma unroll
+    for (int x = 0; x < 6; x++) g[y % 3][x] = w_tl * ra[x] + w_tr * ra[x + 1] + w_bl * rb[x] + w_br * rb[x + 1];
+#pragma unroll
+    for (int k = 0; k < 7; k++) ra[k] = rb[k];
+    if (y >= 2) {  // grid rows y-2, y-1, y are there: patch row py = y - 2
+      const int py = y - 2;
+#pragma unroll
+      for (int px = 0; px < 4; px++) {
+        const float patch = g[(y - 1) % 3][px + 1];
+        const float dx = 0.5f * (g[(y - 1) % 3][px + 2] - g[(y - 1) % 3][px]);
+        const float dy = 0.5f * (g[y % 3][px + 1] - g[(y - 2) % 3][px + 1]);
+        it_pd[(py * 4 + px) * pitch + f] = make_float2(patch, dx);
+        it_dy[(py * 4 + px) * pitch + f] = dy;
+        const double ddx = dx, ddy = dy;
+        sxx += ddx * ddx;
+        sxy += ddx * ddy;
+        syy += ddy * ddy;
+      }
+    }
+  }
+  sums3[0] = sxx;
+  sums3[1] = sxy;
+  sums3[2] = syy;
+  return true;
+}
+
+// the 21 entries of G^T S G of one feature (see the head of this section), added to h16 / h8
+__device__ __forceinline__ void ia_feature_h(double X, double Y, double z_inv, double fl, double sxx, double sxy, double syy, double *h16, double *h8) {
+  const double z_inv_2 = z_inv * z_inv;
+  double ga[6], gb[6];
+  {
+    const double j2 = X * z_inv_2, j3 = Y * j2, j8 = Y * z_inv_2;
+    ga[0] = -z_inv * fl; ga[1] = 0.0 * fl; ga[2] = j2 * fl; ga[3] = j3 * fl; ga[4] = -(1.0 + X * j2) * fl; ga[5] = (Y * z_inv) * fl;
+    gb[0] = 0.0 * fl; gb[1] = -z_inv * fl; gb[2] = j8 * fl; gb[3] = (1.0 + Y * j8) * fl; gb[4] = -j3 * fl; gb[5] = (-X * z_inv) * fl;
+  }
+  double ma[6], mb[6];  // M = S G
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    ma[c] = sxx * ga[c] + sxy * gb[c];
+    mb[c] = sxy * ga[c] + syy * gb[c];
+  }
+  int k = 0;
+#pragma unroll
+  for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+    for (int c = rr; c < 6; c++) {
+      const double v = ga[rr] * ma[c] + gb[rr] * mb[c];
+      if (k < 16) h16[k] += v; else h8[k - 16] += v;
+      k++;
+    }
+}
+
+template <int kWaves, bool kGlobalItems, bool kPre, class Feats>
 __device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, const Cam cam, const sdvl_align_params prm, const int max_f, uint8_t *s_dyn) {
+  static_assert(!kPre || kGlobalItems, "precomputed items live in the work buffer");
   // carve (max_f is a multiple of 64 * kWaves): x[4][max_f] doubles (point in frame 1: x, y, z, 1/z) | S[3][max_f] doubles (gradient
   // sums of the level) | items: pd[16][max_f] float2 {patch, dx}, dy[16][max_f] floats (LDS, or the job's slice of the work buffer)
   double *s_x = reinterpret_cast<double *>(s_dyn);
@@ -787,9 +883,11 @@ __device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, cons
   const int tid = threadIdx.x, lane = tid & 63, wave = kWaves > 1 ? (tid >> 6) : 0;
   const int rounds = (nf + 64 * kWaves - 1) / (64 * kWaves);
   // items of a job too large for LDS live in its slice of the work buffer, same layout with the job's own pitch
-  const int pitch = kGlobalItems ? (nf + 63) / 64 * 64 : max_f;
+  const int pitch = kPre ? job.pre_pitch : (kGlobalItems ? (nf + 63) / 64 * 64 : max_f);
   float2 *it_pd = kGlobalItems ? reinterpret_cast<float2 *>(job.items) : s_pd_l;
   float *it_dy = kGlobalItems ? job.items + static_cast<size_t>(32) * pitch : s_dy_l;
+  const double *S3 = s_S;  // gradient sums of the level: LDS, or (kPre) the level's block of the precompute kernel's output
+  int S_pitch = max_f;
 
   if (lane == 0) {
 #pragma unroll
@@ -829,80 +927,39 @@ __device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, cons
       for (int q = 0; q < 7; q++) s_Tbk[wave][q] = s_T[wave][q];
     }
     // ---- PrecomputePatches(level), image_align.cc:208-267
-    for (int r = 0; r < rounds; r++) {
-      const int f = (r * kWaves + wave) * 64 + lane;
-      if (f >= nf) continue;
-      const int flag = s_flag[f];
-      double fpx, fpy;
-      F.pos(f, &fpx, &fpy);
-      const float u_ref = static_cast<float>(fpx * scale);
-      const float v_ref = static_cast<float>(fpy * scale);
-      const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
-      const int border = 3;
-      if (!(flag & 1) || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) {
-        // jacobian_cache_.setZero() (image_align.cc:69): a feature seen at a coarser level that fails this level's border test would
-        // keep its old patch and a zero Jacobian (it cannot happen coarse-to-fine; kept for the reference's semantics)
-        if (flag & kIaVis) {
-#pragma unroll
-          for (int p = 0; p < 16; p++) {
-            it_pd[p * pitch + f].y = 0.f;
-            it_dy[p * pitch + f] = 0.f;
-          }
-          s_S[f] = 0.0; s_S[max_f + f] = 0.0; s_S[2 * max_f + f] = 0.0;
-        }
-        continue;
+    if (kPre) {
+      // done by image_align_pre_kernel for every level at once (the patches do not depend on the pose): this level's block
+      const int li = prm.max_level - level;
+      it_pd = reinterpret_cast<float2 *>(const_cast<float *>(job.pre_items) + static_cast<size_t>(li) * 48 * pitch);
+      it_dy = const_cast<float *>(job.pre_items) + static_cast<size_t>(li) * 48 * pitch + static_cast<size_t>(32) * pitch;
+      S3 = job.pre_S + static_cast<size_t>(li) * 3 * pitch;
+      S_pitch = pitch;
+      const uint8_t *vis = job.pre_vis + static_cast<size_t>(li) * pitch;
+      for (int r = 0; r < rounds; r++) {
+        const int f = (r * kWaves + wave) * 64 + lane;
+        if (f >= nf) continue;
+        // visible at this level: assumed inside the current image too (kIaOk) — that is the set the precomputed H belongs to
+        s_flag[f] = static_cast<uint8_t>((s_flag[f] & 1) | (vis[f] ? (kIaVis | kIaOk) : 0));
       }
-      s_flag[f] = static_cast<uint8_t>(flag | kIaVis);
-      const float su = u_ref - ui, sv = v_ref - vi;
-      const float w_tl = static_cast<float>((1.0 - su) * (1.0 - sv));
-      const float w_tr = static_cast<float>(su * (1.0 - sv));
-      const float w_bl = static_cast<float>((1.0 - su) * sv);
-      const float w_br = su * sv;
-      // g[y][x] = the bilinear sum whose top-left pixel is (ui - 3 + x, vi - 3 + y): patch value of pixel (px, py) = g[py+1][px+1],
-      // dx = 0.5 (g[py+1][px+2] - g[py+1][px]), dy = 0.5 (g[py+2][px+1] - g[py][px+1]) — the reference's own five expressions
-      const uint8_t *wp = ref_img + static_cast<size_t>(vi - 3) * W + (ui - 3);
-      float g[3][6];  // rolling: rows y-2, y-1, y of the grid
-      float ra[7], rb[7];
-      {
-        uint32_t lo, hi;
-        ia_load_row8(wp, 7, &lo, &hi);
-#pragma unroll
-        for (int k = 0; k < 4; k++) ra[k] = ia_byte(lo, k);
-#pragma unroll
-        for (int k = 4; k < 7; k++) ra[k] = ia_byte(hi, k - 4);
+      const double *fac = job.pre_fac + static_cast<size_t>(li) * 32;
+      if (lane < 21) s_L[wave][lane] = fac[lane];
+      if (lane >= 32 && lane < 38) s_tr[wave][lane - 32] = static_cast<int>(fac[21 + lane - 32]);
+    } else {
+      for (int r = 0; r < rounds; r++) {
+        const int f = (r * kWaves + wave) * 64 + lane;
+        if (f >= nf) continue;
+        const int flag = s_flag[f];
+        double fpx, fpy;
+        F.pos(f, &fpx, &fpy);
+        // (a feature seen at a coarser level cannot fail a finer level's border test: u doubles exactly, W_l = W_{l-1} / 2 rounds
+        //  down — so "visible" is simply "passes this level's test", image_align.cc:229-233)
+        double sums[3] = {0.0, 0.0, 0.0};
+        const bool vis = ia_precompute_feature(ref_img, W, H, scale, fpx, fpy, (flag & 1) != 0, f, pitch, it_pd, it_dy, sums);
+        s_S[f] = sums[0];
+        s_S[max_f + f] = sums[1];
+        s_S[2 * max_f + f] = sums[2];
+        s_flag[f] = static_cast<uint8_t>((flag & ~kIaVis) | (vis ? kIaVis : 0));
       }
-      double sxx = 0.0, sxy = 0.0, syy = 0.0;
-#pragma unroll
-      for (int y = 0; y < 6; y++) {
-        uint32_t lo, hi;
-        ia_load_row8(wp + static_cast<size_t>(y + 1) * W, 7, &lo, &hi);
-#pragma unroll
-        for (int k = 0; k < 4; k++) rb[k] = ia_byte(lo, k);
-#pragma unroll
-        for (int k = 4; k < 7; k++) rb[k] = ia_byte(hi, k - 4);
-#pragma unroll
-        for (int x = 0; x < 6; x++) g[y % 3][x] = w_tl * ra[x] + w_tr * ra[x + 1] + w_bl * rb[x] + w_br * rb[x + 1];
-#pragma unroll
-        for (int k = 0; k < 7; k++) ra[k] = rb[k];
-        if (y >= 2) {  // grid rows y-2, y-1, y are there: patch row py = y - 2
-          const int py = y - 2;
-#pragma unroll
-          for (int px = 0; px < 4; px++) {
-            const float patch = g[(y - 1) % 3][px + 1];
-            const float dx = 0.5f * (g[(y - 1) % 3][px + 2] - g[(y - 1) % 3][px]);
-            const float dy = 0.5f * (g[y % 3][px + 1] - g[(y - 2) % 3][px + 1]);
-            it_pd[(py * 4 + px) * pitch + f] = make_float2(patch, dx);
-            it_dy[(py * 4 + px) * pitch + f] = dy;
-            const double ddx = dx, ddy = dy;
-            sxx += ddx * ddx;
-            sxy += ddx * ddy;
-            syy += ddy * ddy;
-          }
-        }
-      }
-      s_S[f] = sxx;
-      s_S[max_f + f] = sxy;
-      s_S[2 * max_f + f] = syy;
     }
 
     IA_STAMP(1);
@@ -1014,7 +1071,7 @@ __device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, cons
         sum_c2 = s8[6];
         sum_n = s8[7];
       }
-      const bool rebuild_h = it == 0 || changed;
+      const bool rebuild_h = kPre ? changed : (it == 0 || changed);  // kPre: the level starts with the precomputed factor of its visible set
       IA_STAMP(3);
       if (rebuild_h) {
         // H = sum over the contributing features of G^T S G (see the head of this section); it changes only with that set
@@ -1027,30 +1084,7 @@ __device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, cons
           const int f = (r * kWaves + wave) * 64 + lane;
           if (f >= nf) continue;
           if (!(s_flag[f] & kIaOk) || !(s_flag[f] & kIaVis)) continue;
-          const double X = s_x[f], Y = s_x[max_f + f];
-          const double z_inv = s_x[3 * max_f + f], z_inv_2 = z_inv * z_inv;
-          double ga[6], gb[6];
-          {
-            const double j2 = X * z_inv_2, j3 = Y * j2, j8 = Y * z_inv_2;
-            ga[0] = -z_inv * fl; ga[1] = 0.0 * fl; ga[2] = j2 * fl; ga[3] = j3 * fl; ga[4] = -(1.0 + X * j2) * fl; ga[5] = (Y * z_inv) * fl;
-            gb[0] = 0.0 * fl; gb[1] = -z_inv * fl; gb[2] = j8 * fl; gb[3] = (1.0 + Y * j8) * fl; gb[4] = -j3 * fl; gb[5] = (-X * z_inv) * fl;
-          }
-          const double sxx = s_S[f], sxy = s_S[max_f + f], syy = s_S[2 * max_f + f];
-          double ma[6], mb[6];  // M = S G
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            ma[c] = sxx * ga[c] + sxy * gb[c];
-            mb[c] = sxy * ga[c] + syy * gb[c];
-          }
-          int k = 0;
-#pragma unroll
-          for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-            for (int c = rr; c < 6; c++) {
-              const double v = ga[rr] * ma[c] + gb[rr] * mb[c];
-              if (k < 16) h16[k] += v; else h8[k - 16] += v;
-              k++;
-            }
+          ia_feature_h(s_x[f], s_x[max_f + f], s_x[3 * max_f + f], fl, S3[f], S3[S_pitch + f], S3[2 * S_pitch + f], h16, h8);
         }
         const double t16 = wave_reduce_n<16>(h16, lane);
         const double t8 = wave_reduce_n<8>(h8, lane);
@@ -1175,7 +1209,124 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   const IaJob &jb = jobs[blockIdx.x];
   const IaIn in{jb.ref_level, jb.cur_level, jb.lw, jb.lh, jb.n_feat, jb.T, jb.patch_cache, out + jb.out_index};
-  ia_wave_body<kWaves, kGlobalItems>(in, IaRecordFeats{feats_all + jb.feat_begin}, cam, prm, max_f, s_dyn);
+  ia_wave_body<kWaves, kGlobalItems, false>(in, IaRecordFeats{feats_all + jb.feat_begin}, cam, prm, max_f, s_dyn);
+}
+
+// ---- PrecomputePatches as a launch of its own (VERDICT r03 #1b): the reference patches, their gradients and the normal matrix of
+// a level do not depend on the pose, so one workgroup per (job, level) prepares ALL levels of all jobs at once — 768 workgroups of 4
+// waves for a tracked step instead of 3 x (3 rounds of lane work + a 21-value reduction + an LDLT factorisation) inside every job's
+// one-wave Gauss-Newton chain (80 of the chain's 235 k clock ticks).  Per (job, level): items [48][pitch] floats, gradient sums
+// [3][pitch], visibility [pitch] bytes, and fac[32] = the LDLT factor of H over the level's visible features (L lower triangle 21 |
+// transpositions 6 | number of visible features): the Gauss-Newton kernel starts every level with it and rebuilds H only when a
+// feature leaves the image.
+struct IaPreOut {
+  float *items;
+  double *S;
+  uint8_t *vis;
+  double *fac;
+};
+__device__ __forceinline__ IaPreOut ia_pre_block(void *base, int n_jobs, int n_lv, int pitch, int job, int li) {
+  // [items: n_jobs * n_lv * 48 * pitch floats][S: n_jobs * n_lv * 3 * pitch doubles][fac: n_jobs * n_lv * 32 doubles][vis bytes]
+  const size_t blk = static_cast<size_t>(job) * n_lv + li, nb = static_cast<size_t>(n_jobs) * n_lv;
+  uint8_t *b = static_cast<uint8_t *>(base);
+  IaPreOut o;
+  o.items = reinterpret_cast<float *>(b) + blk * 48 * pitch;
+  o.S = reinterpret_cast<double *>(b + nb * 48 * pitch * sizeof(float)) + blk * 3 * pitch;
+  o.fac = reinterpret_cast<double *>(b + nb * 48 * pitch * sizeof(float) + nb * 3 * pitch * sizeof(double)) + blk * 32;
+  o.vis = b + nb * 48 * pitch * sizeof(float) + nb * 3 * pitch * sizeof(double) + nb * 32 * sizeof(double) + blk * pitch;
+  return o;
+}
+inline size_t ia_pre_bytes(int n_jobs, int n_lv, int pitch) {
+  const size_t nb = static_cast<size_t>(n_jobs) * n_lv;
+  return (nb * (48 * pitch * sizeof(float) + 3 * pitch * sizeof(double) + 32 * sizeof(double) + pitch) + 255) / 256 * 256;
+}
+
+template <class Feats>
+__device__ __forceinline__ void ia_pre_body(const uint8_t *ref_img, int W, int H, int level, int nf, const Feats F, double fx, int pitch, IaPreOut o) {
+  __shared__ double s_redH[4][24];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float scale = 1.0f / (1 << level);
+  const double fl = fx / (1 << level);
+  float2 *it_pd = reinterpret_cast<float2 *>(o.items);
+  float *it_dy = o.items + static_cast<size_t>(32) * pitch;
+  double h16[16], h8[8];
+#pragma unroll
+  for (int i = 0; i < 16; i++) h16[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) h8[i] = 0.0;
+  for (int f = tid; f < pitch; f += 256) {
+    bool vis = false;
+    double sums[3] = {0.0, 0.0, 0.0};
+    if (f < nf) {
+      V3 xyz;
+      const bool valid = F.load(f, &xyz);
+      double fpx, fpy;
+      F.pos(f, &fpx, &fpy);
+      vis = ia_precompute_feature(ref_img, W, H, scale, fpx, fpy, valid, f, pitch, it_pd, it_dy, sums);
+      if (vis) {
+        ia_feature_h(xyz.x, xyz.y, 1. / xyz.z, fl, sums[0], sums[1], sums[2], h16, h8);
+
+      }
+    }
+    o.S[f] = sums[0];
+    o.S[pitch + f] = sums[1];
+    o.S[2 * pitch + f] = sums[2];
+    o.vis[f] = vis ? 1 : 0;
+  }
+  const double t16 = wave_reduce_n<16>(h16, lane);
+  const double t8 = wave_reduce_n<8>(h8, lane);
+  if ((lane & 3) == 0) s_redH[wave][(lane >> 2) & 15] = t16;
+  if ((lane & 7) == 0) s_redH[wave][16 + ((lane >> 3) & 7)] = t8;
+  __syncthreads();
+  if (wave == 0) {
+    double Hm[36];
+    int k = 0;
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+      for (int c = rr; c < 6; c++) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) sum += s_redH[w][k];
+        Hm[6 * rr + c] = sum;
+        Hm[6 * c + rr] = sum;
+        k++;
+      }
+    double La[36];
+    int tr[6];
+    ldlt_factor6_reg<true>(Hm, La, tr);
+    if (lane == 0) {
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) o.fac[q++] = La[6 * i + j];
+#pragma unroll
+      for (int i = 0; i < 6; i++) o.fac[21 + i] = static_cast<double>(tr[i]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void image_align_pre_kernel(const IaJob *__restrict__ jobs, const sdvl_align_feature *__restrict__ feats_all, Cam cam,
+                                                              sdvl_align_params prm, int n_jobs, int pitch, void *pre) {
+  const int n_lv = prm.max_level - prm.min_level + 1;
+  const int job = static_cast<int>(blockIdx.x) / n_lv, li = static_cast<int>(blockIdx.x) - job * n_lv, level = prm.max_level - li;
+  const IaJob &jb = jobs[job];
+  ia_pre_body(jb.ref_level[level], jb.lw[level], jb.lh[level], level, jb.n_feat, IaRecordFeats{feats_all + jb.feat_begin}, cam.fx, pitch,
+              ia_pre_block(pre, n_jobs, n_lv, pitch, job, li));
+}
+
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_wave_pre_kernel(
+    const IaJob *__restrict__ jobs, const sdvl_align_feature *__restrict__ feats_all, Cam cam, sdvl_align_params prm, int n_jobs, int max_f, void *pre,
+    sdvl_align_result *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  const IaJob &jb = jobs[blockIdx.x];
+  const int n_lv = prm.max_level - prm.min_level + 1;
+  const IaPreOut o = ia_pre_block(pre, n_jobs, n_lv, max_f, static_cast<int>(blockIdx.x), 0);
+  IaIn in{jb.ref_level, jb.cur_level, jb.lw, jb.lh, jb.n_feat, jb.T, nullptr, out + jb.out_index};
+  in.pre_items = o.items; in.pre_S = o.S; in.pre_vis = o.vis; in.pre_fac = o.fac; in.pre_pitch = max_f;
+  ia_wave_body<kWaves, true, true>(in, IaRecordFeats{feats_all + jb.feat_begin}, cam, prm, max_f, s_dyn);
 }
 
 // The alignment of a tracked step straight from the tracking tables (sdvl_track.hip): job j = tracker record j of the step; its
@@ -1193,7 +1344,37 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
                 items + static_cast<size_t>(blockIdx.x) * 48 * static_cast<size_t>(max_f), out + blockIdx.x};
   const IaTableFeats F{(jb.feat_buf ? feats1 : feats0) + static_cast<size_t>(jb.tracker) * nfeat_cap, points + static_cast<size_t>(jb.tracker) * np,
                        se3_inverse(se3_from7(jb.last_pose)).t};
-  ia_wave_body<kWaves, true>(in, F, cam, prm, max_f, s_dyn);
+  ia_wave_body<kWaves, true, false>(in, F, cam, prm, max_f, s_dyn);
+}
+
+// the same two kernels for a tracked step: features out of the tracking tables
+__device__ __forceinline__ IaTableFeats ia_table_feats(const TrackJobDev &jb, const TrackPoint *points, const TrackFeat *feats0, const TrackFeat *feats1,
+                                                       int np, int nfeat_cap) {
+  return IaTableFeats{(jb.feat_buf ? feats1 : feats0) + static_cast<size_t>(jb.tracker) * nfeat_cap, points + static_cast<size_t>(jb.tracker) * np,
+                      se3_inverse(se3_from7(jb.last_pose)).t};
+}
+
+__global__ __launch_bounds__(256) void image_align_track_pre_kernel(const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points,
+                                                                    const TrackFeat *__restrict__ feats0, const TrackFeat *__restrict__ feats1, int np,
+                                                                    int nfeat_cap, Cam cam, sdvl_align_params prm, int n_jobs, int pitch, void *pre) {
+  const int n_lv = prm.max_level - prm.min_level + 1;
+  const int job = static_cast<int>(blockIdx.x) / n_lv, li = static_cast<int>(blockIdx.x) - job * n_lv, level = prm.max_level - li;
+  const TrackJobDev &jb = jobs[job];
+  ia_pre_body(jb.last_level[level], jb.cur.lw[level], jb.cur.lh[level], level, jb.n_feat, ia_table_feats(jb, points, feats0, feats1, np, nfeat_cap), cam.fx,
+              pitch, ia_pre_block(pre, n_jobs, n_lv, pitch, job, li));
+}
+
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_track_wave_pre_kernel(
+    const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points, const TrackFeat *__restrict__ feats0, const TrackFeat *__restrict__ feats1,
+    int np, int nfeat_cap, Cam cam, sdvl_align_params prm, int n_jobs, int max_f, void *pre, sdvl_align_result *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  const TrackJobDev &jb = jobs[blockIdx.x];
+  const int n_lv = prm.max_level - prm.min_level + 1;
+  const IaPreOut o = ia_pre_block(pre, n_jobs, n_lv, max_f, static_cast<int>(blockIdx.x), 0);
+  IaIn in{jb.last_level, jb.cur.level, jb.cur.lw, jb.cur.lh, jb.n_feat, jb.T0, nullptr, out + blockIdx.x};
+  in.pre_items = o.items; in.pre_S = o.S; in.pre_vis = o.vis; in.pre_fac = o.fac; in.pre_pitch = max_f;
+  ia_wave_body<kWaves, true, true>(in, ia_table_feats(jb, points, feats0, feats1, np, nfeat_cap), cam, prm, max_f, s_dyn);
 }
 
 size_t ia_wave_lds_bytes(int max_f, bool global_items) {
@@ -1271,6 +1452,16 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
     n_lds = lo;
   }
   const int n_gen = n_jobs - n_lds;
+  // PrecomputePatches as a wide launch in front of the Gauss-Newton chains (image_align_pre_kernel); SDVL_IA_PRE=0: inside the chains
+  static const bool pre_env = !(getenv("SDVL_IA_PRE") && atoi(getenv("SDVL_IA_PRE")) == 0);
+  const bool pre = pre_env && wave_form && small_global && !legacy;
+  const int n_lv = p->max_level - p->min_level + 1;
+  static const int ia_waves_env = getenv("SDVL_IA_WAVES") ? atoi(getenv("SDVL_IA_WAVES")) : 1;
+  const int kw_lds = ia_waves_env == 4 ? 4 : (ia_waves_env == 2 ? 2 : 1);
+  const int max_f_lds = (max_nf_lds + 64 * kw_lds - 1) / (64 * kw_lds) * (64 * kw_lds) + (max_nf_lds == 0 ? 64 * kw_lds : 0);
+  const int max_f_big = (max_nf_big + 255) / 256 * 256;
+  const size_t pre_lds_bytes = pre && n_lds > 0 ? ia_pre_bytes(n_lds, n_lv, max_f_lds) : 0;
+  if (pre) work = pre_lds_bytes + (n_gen > 0 ? ia_pre_bytes(n_gen, n_lv, max_f_big) : 0);
   const size_t job_bytes = (sizeof(IaJob) * n_jobs + 255) / 256 * 256;
   const size_t feat_bytes = d_features ? 0 : sizeof(sdvl_align_feature) * static_cast<size_t>(n_features);
   const size_t res_bytes = sizeof(sdvl_align_result) * n_jobs;
@@ -1341,17 +1532,30 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
                                               static_cast<int>(ia_wave_lds_bytes(kLdsMaxF + 128, false))));
       SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_wave_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_wave_pre_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
       attr_devices.fetch_or(bit, std::memory_order_release);
     }
   }
   if (n_lds > 0 && wave_form) {
-    static const int ia_waves = getenv("SDVL_IA_WAVES") ? atoi(getenv("SDVL_IA_WAVES")) : 1;
-    const int kw = ia_waves == 4 ? 4 : (ia_waves == 2 ? 2 : 1);
-    const int max_f = (max_nf_lds + 64 * kw - 1) / (64 * kw) * (64 * kw) + (max_nf_lds == 0 ? 64 * kw : 0);
+    const int kw = kw_lds;
+    const int max_f = max_f_lds;
     const size_t lds = ia_wave_lds_bytes(max_f, small_global);
+    if (pre)
+      SDVL_LAUNCH(ctx, "image_align_pre", image_align_pre_kernel, dim3(static_cast<unsigned>(n_lds) * n_lv), dim3(256), static_cast<const IaJob *>(dsx), feats_dev,
+                  c, *p, n_lds, max_f, ctx->d_work);
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align", &ev_a, &ev_b);
-    if (small_global && kw == 4)
+    if (pre && kw == 4)
+      hipExtLaunchKernelGGL((image_align_wave_pre_kernel<4>), dim3(n_lds), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx), feats_dev, c,
+                            *p, n_lds, max_f, ctx->d_work, dst);
+    else if (pre && kw == 2)
+      hipExtLaunchKernelGGL((image_align_wave_pre_kernel<2>), dim3(n_lds), dim3(128), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx), feats_dev, c,
+                            *p, n_lds, max_f, ctx->d_work, dst);
+    else if (pre)
+      hipExtLaunchKernelGGL((image_align_wave_pre_kernel<1>), dim3(n_lds), dim3(64), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx), feats_dev, c,
+                            *p, n_lds, max_f, ctx->d_work, dst);
+    else if (small_global && kw == 4)
       hipExtLaunchKernelGGL((image_align_wave_kernel<4, true>), dim3(n_lds), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
                             feats_dev, c, *p, max_f, dst);
     else if (small_global && kw == 2)
@@ -1390,7 +1594,15 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
       hipExtLaunchKernelGGL((image_align_lds_kernel<false, 512>), dim3(n_lds), dim3(512), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const IaJob *>(dsx),
                             feats_dev, c, *p, max_f, dst);
   }
-  if (n_gen > 0 && wave_form && !legacy) {
+  if (n_gen > 0 && pre) {
+    void *pre_big = static_cast<uint8_t *>(ctx->d_work) + pre_lds_bytes;
+    SDVL_LAUNCH(ctx, "image_align_pre", image_align_pre_kernel, dim3(static_cast<unsigned>(n_gen) * n_lv), dim3(256), static_cast<const IaJob *>(dsx) + n_lds,
+                feats_dev, c, *p, n_gen, max_f_big, pre_big);
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    sdvl_timer_events(ctx, "image_align_big", &ev_a, &ev_b);
+    hipExtLaunchKernelGGL((image_align_wave_pre_kernel<4>), dim3(n_gen), dim3(256), ia_wave_lds_bytes(max_f_big, true), ctx->stream, ev_a, ev_b, 0,
+                          static_cast<const IaJob *>(dsx) + n_lds, feats_dev, c, *p, n_gen, max_f_big, pre_big, dst);
+  } else if (n_gen > 0 && wave_form && !legacy) {
     const int max_f = (max_nf_big + 255) / 256 * 256;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "image_align_big", &ev_a, &ev_b);
@@ -1425,7 +1637,10 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
   }
   const int kw = max_nf > kLdsMaxF ? 4 : 1;  // configuration C's ~850 features per job: four waves share them
   const int max_f = max_nf <= 0 ? 64 * kw : (max_nf + 64 * kw - 1) / (64 * kw) * (64 * kw);
-  const size_t work = static_cast<size_t>(n_jobs) * 48 * sizeof(float) * max_f;
+  // PrecomputePatches of all levels as a wide launch in front of the Gauss-Newton chains (SDVL_IA_PRE=0: inside the chain, A/B)
+  static const bool pre = !(getenv("SDVL_IA_PRE") && atoi(getenv("SDVL_IA_PRE")) == 0);
+  const int n_lv = p->max_level - p->min_level + 1;
+  const size_t work = pre ? ia_pre_bytes(n_jobs, n_lv, max_f) : static_cast<size_t>(n_jobs) * 48 * sizeof(float) * max_f;
   const int rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, work + 256, false);
   if (rc) return rc;
   {
@@ -1435,6 +1650,8 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
       SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
       SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_track_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_track_wave_pre_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
       attr_devices.fetch_or(bit, std::memory_order_release);
     }
   }
@@ -1442,7 +1659,16 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   sdvl_timer_events(ctx, kw == 4 ? "image_align_big" : "image_align", &ev_a, &ev_b);
   const size_t lds = ia_wave_lds_bytes(max_f, true);
-  if (kw == 4)
+  if (pre) {
+    SDVL_LAUNCH(ctx, "image_align_pre", image_align_track_pre_kernel, dim3(static_cast<unsigned>(n_jobs) * n_lv), dim3(256), d_jobs, d_points, d_feats0, d_feats1,
+                np, nfeat_cap, c, *p, n_jobs, max_f, ctx->d_work);
+    if (kw == 4)
+      hipExtLaunchKernelGGL((image_align_track_wave_pre_kernel<4>), dim3(n_jobs), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, d_jobs, d_points, d_feats0, d_feats1,
+                            np, nfeat_cap, c, *p, n_jobs, max_f, ctx->d_work, d_results);
+    else
+      hipExtLaunchKernelGGL((image_align_track_wave_pre_kernel<1>), dim3(n_jobs), dim3(64), lds, ctx->stream, ev_a, ev_b, 0, d_jobs, d_points, d_feats0, d_feats1,
+                            np, nfeat_cap, c, *p, n_jobs, max_f, ctx->d_work, d_results);
+  } else if (kw == 4)
     hipExtLaunchKernelGGL((image_align_track_kernel<4>), dim3(n_jobs), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, d_jobs, d_points, d_feats0, d_feats1, np,
                           nfeat_cap, c, *p, max_f, static_cast<float *>(ctx->d_work), d_results);
   else
