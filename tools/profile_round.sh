@@ -30,15 +30,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/sc_kt -- python3 benc
 find $O/sc_kt -name "*kernel_trace.csv" -delete
 # the line earlier rounds quoted (2048 sequences, 100 steps), for comparison across rounds
 python3 bench.py --seqs 2048 --steps 100 --warmup 5 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/bench_2048x100.json 2> $O/bench_2048x100.err
-# the host-fed path: A/B of the feeder's three changes, and the two probes behind DESIGN §5
-bash tools/feeder_ab.sh > $O/feeder_ab.txt 2>&1
-hipcc --offload-arch=gfx950 -O2 -o /tmp/link_latency_probe tools/link_latency_probe.cpp -lpthread 2>/dev/null && timeout -k 5 120 /tmp/link_latency_probe > $O/link_latency_probe.txt 2>&1
+# (the A/B lines of the round: tools/profile_round_ab.sh, a call of its own — together they exceed one gpurun call)
 hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_peak_probe tools/valu_peak_probe.cpp 2>/dev/null && timeout -k 5 120 /tmp/valu_peak_probe > $O/valu_peak_probe.txt 2>&1
-hipcc --offload-arch=gfx950 -O2 -o /tmp/h2d_path_probe tools/h2d_path_probe.cpp 2>/dev/null && timeout -k 5 120 /tmp/h2d_path_probe > $O/h2d_path_probe.txt 2>&1
 python3 tools/kernel_bench.py 256 6 > $O/kernel_bench_isolated.txt 2>&1
 python3 tools/pcie_probe.py > $O/pcie_probe.txt 2>&1
 python3 tools/summarize_profiles.py $O $O/summary_r
-cp $O/bench_mapper.json $O/bench_config_c.json $O/bench_config_c_64seq.json $O/bench_2048x100.json $O/feeder_ab.txt $O/link_latency_probe.txt $O/h2d_path_probe.txt $O/valu_peak_probe.txt $O/kernel_bench_isolated.txt $O/pcie_probe.txt $O/summary_r/
+cp $O/bench_mapper.json $O/bench_config_c.json $O/bench_config_c_64seq.json $O/bench_2048x100.json $O/valu_peak_probe.txt $O/kernel_bench_isolated.txt $O/pcie_probe.txt $O/summary_r/
 ks=$(ls -S $O/sc_kt/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$ks" ] && cp "$ks" $O/summary_r/kernel_stats_config_c.csv
 ls -la $O/summary_r

@@ -34,6 +34,26 @@ for name in ("bench_default.json", "prof_kt.json"):
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, "bench_under_rocprof.json" if name == "prof_kt.json" else name))
 
+# dispatches per group-step: calls of every kernel in the traced run / (bootstrap + warm-up + timed steps) x groups
+try:
+    cfgj = json.loads(open(os.path.join(src, "prof_kt.json")).read().strip().splitlines()[-1])
+    gsteps = (1 + cfgj["warmup"] + cfgj["steps"]) * cfgj["config"]["groups_per_gpu"]
+    rows = list(csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))))
+    with open(os.path.join(dst, "dispatches_per_group_step.csv"), "w") as out:
+        out.write("kernel,calls,calls_per_group_step,avg_us,note\n")
+        tot = 0.0
+        for r in rows:
+            name = short(r["Name"])
+            if name.startswith(("synth_render", "__amd_rocclr_fillBuffer")):
+                continue   # set-up (rendering the inputs, zeroing the frame pool's headers), not part of a step
+            per = int(r["Calls"]) / gsteps
+            tot += per
+            csv.writer(out).writerow([name, r["Calls"], "%.2f" % per, "%.1f" % (float(r["AverageNs"]) / 1e3),
+                                      "%d group-steps in the traced run (%d groups x (1 bootstrap + %d warm-up + %d timed))" % (gsteps, cfgj["config"]["groups_per_gpu"], cfgj["warmup"], cfgj["steps"])])
+        csv.writer(out).writerow(["TOTAL", "", "%.2f" % tot, "", "keyframe-only kernels (shi_tomasi, filter_*, track_upload, stage_pull, frames_own) run in the group-steps that have keyframes"])
+except Exception as e:   # the summary is a convenience; a missing trace must not lose the other files
+    print("dispatch count not written:", e)
+
 # PMC passes: per kernel average FETCH_SIZE / WRITE_SIZE (KB as reported by rocprofv3)
 acc = {}
 for counter, sub in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
