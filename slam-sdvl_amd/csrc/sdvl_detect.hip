@@ -580,11 +580,24 @@ __device__ __forceinline__ void fc_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// slot `pos` of a cell's corner list as (uniform base + 32-bit byte offset): one shift, a store with a scalar base
+typedef __attribute__((address_space(1))) uint32_t *FcGlobalWords;
+__device__ __forceinline__ FcGlobalWords fc_slot(FcGlobalWords base, int pos) {
+  return (FcGlobalWords)((__attribute__((address_space(1))) char *)base + (static_cast<uint32_t>(pos) << 2));
+}
+
 constexpr int kFcDenseWords = (kTile + 2 * kPadRows) * kPitchHW + (kTile + 2) * kPitchHW;          // half tile + half scores: 1872
 constexpr int kFcSparseWords = (kTile + 2 * kPadRows) * kPitchW + (kTile + 2) * kPitchW + kTile * kTile / 2;  // byte tile + byte scores + list
 static_assert(kFcSparseWords <= kFcDenseWords, "the sparse layout lives inside the dense one");
 static_assert(((kTile + 2 * kPadRows) * kPitchHW * 4) % 16 == 0, "the half score plane is cleared with 16-byte stores");
 
+// kHalfScores (the default; SDVL_FAST_INT_SCORES=1 for the other form): the dense path's scores never leave the packed halves.
+// best >= t always, so "corner" is best - 1 >= t, a non-corner's best - 1 is t - 1, and a corner's score beats every non-corner's
+// whether the plane holds 0 or t - 1 for those: phase C stores best2 - 1 as it comes (two 16-bit stores, no conversion, no
+// compare) and keeps it in a register; the suppression folds max(t - 1, 0) into the neighbours' maximum m, and then
+// "is a corner AND beats its 8 neighbours" is the SIGN of m - score per half (integers in f16: exact, m == score gives +0).
+// The second pixel of a row's last pair in an odd-width ROI is not a tested pixel: it is given t - 1, a non-corner.
+template <bool kHalfScores>
 __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__restrict__ jobs, FastLevels lv, const CellGeo *__restrict__ cells) {
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[kFcDenseWords];
   const FastJob &job = jobs[blockIdx.y];
@@ -659,6 +672,64 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
     const int inv = (65536 + npr - 1) / npr;                   // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13
     const int npass = (ncand + 63) >> 6;                       // <= 6
     const _Float16 th = static_cast<_Float16>(t);
+    if constexpr (kHalfScores) {
+      const h2 t2 = h2{th, th}, one2 = h2{static_cast<_Float16>(1), static_cast<_Float16>(1)};
+      const _Float16 tf = static_cast<_Float16>(t > 1 ? t - 1 : 0);
+      const h2 floor2 = h2{tf, tf};
+      const bool odd = (tw & 1) != 0;
+      _Float16 *score_halves = reinterpret_cast<_Float16 *>(s_scoreh);
+      const FcGlobalWords gout = (FcGlobalWords)out;  // global, not flat, stores
+      uint32_t sc2[6], wofs[6], xy[6];  // per pass: the pair's scores (halves), its word in the half tile, (x | y << 12) of its first pixel
+#pragma unroll
+      for (int ps = 0; ps < 6; ps++) {
+        sc2[ps] = wofs[ps] = xy[ps] = 0u;
+        if (ps < npass) {
+          const int i = ps * 64 + lane;
+          if (i < ncand) {
+            const int qr = (i * inv) >> 16, j = i - qr * npr;
+            const int w = (qr + 3) * kPitchHW + 2 + j;  // tile row r = qr + 3 is ring row -3 of image row r
+            h2 s2 = fast_pair_best(&s_imgh[w], t2) - one2;
+            if (odd && j == npr - 1) s2.y = t2.y - one2.y;  // x + 1 == rw - 3: not a tested pixel
+            _Float16 *sh = score_halves + 2 * w + 2 * kPitchHW + 3;  // half 4 + x of plane row r + 1 (x = 3 + 2 j)
+            // two 16-bit stores, kept apart: the pair starts on an odd half, and merged into one UNALIGNED 32-bit LDS store (what
+            // the compiler makes of two plain stores) the kernel takes 227 us per 256 frames instead of 184
+            volatile _Float16 *vsh = sh;
+            vsh[0] = s2.x;
+            vsh[1] = s2.y;
+            sc2[ps] = __builtin_bit_cast(uint32_t, s2);
+            wofs[ps] = static_cast<uint32_t>(w);
+            xy[ps] = static_cast<uint32_t>(x0 + 3 + 2 * j) | (static_cast<uint32_t>(y0 + 3 + qr) << 12);
+          }
+        }
+      }
+      fc_wave_sync();
+#pragma unroll
+      for (int ps = 0; ps < 6; ps++) {
+        if (ps < npass) {
+          const uint32_t own = sc2[ps];
+          uint32_t diff = 0u;  // sign per half: corner that beats its 8 neighbours
+          if (ps * 64 + lane < ncand) {
+            const uint32_t *sw = &s_scoreh[wofs[ps] + kPitchHW + 1];  // halves (x-1 | x) of plane row r + 1; the next word (x+1 | x+2)
+            const uint32_t u0 = sw[-kPitchHW], u1 = sw[-kPitchHW + 1], c0 = sw[0], c1 = sw[1], d0 = sw[kPitchHW], d1 = sw[kPitchHW + 1];
+            const h2 up = pk_max3(as_h2(u0), mid_h2(u1, u0), as_h2(u1)), dn = pk_max3(as_h2(d0), mid_h2(d1, d0), as_h2(d1));
+            const h2 m = pk_max3(up, dn, pk_max3(as_h2(c0), as_h2(c1), floor2));
+            diff = __builtin_bit_cast(uint32_t, m - as_h2(own));
+          }
+          const uint32_t lo_sign = (diff >> 15) & 1u;
+          const bool ok0 = lo_sign != 0u, ok1 = static_cast<int32_t>(diff) < 0;
+          const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+          int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m0 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m0), 0)) +
+                    __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m1 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m1), 0));
+          const h2 s2 = as_h2(own);
+          if (ok0 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = xy[ps] | (static_cast<uint32_t>(static_cast<uint16_t>(s2.x)) << 24);
+          pos += static_cast<int>(lo_sign);
+          if (ok1 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (xy[ps] + 1u) | (static_cast<uint32_t>(static_cast<uint16_t>(s2.y)) << 24);
+          base += __popcll(m0) + __popcll(m1);
+        }
+      }
+      if (lane == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
+      return;
+    }
     uint32_t found[6][2];  // corner of slot (pass, pixel of the pair): score << 10 | row << 5 | x, 0 = none
 #pragma unroll
     for (int ps = 0; ps < 6; ps++) {
@@ -1672,6 +1743,11 @@ int64_t sdvl_detect_scratch_bytes(int width, int height, const sdvl_detect_param
   return static_cast<int64_t>(detect_slot_layout(total, p->max_fast_levels).bytes);
 }
 
+// SDVL_FAST_INT_SCORES=1: the dense path's epilogue on integer scores (round 3's form; A/B measurements, tests)
+static bool fast_cells_int_scores() {
+  static const bool v = getenv("SDVL_FAST_INT_SCORES") != nullptr;
+  return v;
+}
 // SDVL_FAST_WG4=1: the four-wave workgroup per cell (fast_cells_kernel) instead of one wave per cell (A/B measurements, tests)
 static bool fast_cells_four_waves() {
   static const bool v = getenv("SDVL_FAST_WG4") != nullptr;
@@ -1781,7 +1857,8 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   if (fast_cells_four_waves()) {
     SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv, d_cells);
   } else {
-    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
+    if (fast_cells_int_scores()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<false>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
+    else SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
   }
   SDVL_LAUNCH(ctx, "compact_cells", compact_cells_kernel, dim3(n), dim3(256), static_cast<const FastJob *>(dsx), total_cells, cap, d_kps, d_offs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
@@ -1931,7 +2008,8 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   if (fast_cells_four_waves()) {
     SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv, d_cells);
   } else {
-    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
+    if (fast_cells_int_scores()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<false>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
+    else SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
   }
   SDVL_LAUNCH(ctx, "select_cells", select_cells_kernel, dim3(static_cast<unsigned>((n + 7) / 8 * 8 * n_slices)), dim3(64), ds, sl, n);
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
