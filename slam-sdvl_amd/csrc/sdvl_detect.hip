@@ -689,11 +689,16 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
             const int qr = (i * inv) >> 16, j = i - qr * npr;
             const int w = (qr + 3) * kPitchHW + 2 + j;  // tile row r = qr + 3 is ring row -3 of image row r
             h2 s2 = fast_pair_best(&s_imgh[w], t2) - one2;
-            if (odd && j == npr - 1) s2.y = t2.y - one2.y;  // x + 1 == rw - 3: not a tested pixel
+            if (odd) {  // (a real branch on the wave-uniform flag: even widths, the common case, pay nothing)
+              asm volatile("");
+              if (j == npr - 1) s2.y = t2.y - one2.y;  // x + 1 == rw - 3: not a tested pixel
+            }
             _Float16 *sh = score_halves + 2 * w + 2 * kPitchHW + 3;  // half 4 + x of plane row r + 1 (x = 3 + 2 j)
             // two 16-bit stores, kept apart: the pair starts on an odd half, and merged into one UNALIGNED 32-bit LDS store (what
             // the compiler makes of two plain stores) the kernel takes 227 us per 256 frames instead of 184
-            volatile _Float16 *vsh = sh;
+            // (volatile through an LDS-address-space pointer: through a generic one they become flat stores with a wait each)
+            typedef __attribute__((address_space(3))) volatile _Float16 *LdsHalves;
+            const LdsHalves vsh = (LdsHalves)sh;
             vsh[0] = s2.x;
             vsh[1] = s2.y;
             sc2[ps] = __builtin_bit_cast(uint32_t, s2);

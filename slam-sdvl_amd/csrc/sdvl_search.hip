@@ -255,6 +255,17 @@ __device__ unsigned long long g_search_stats[8];
 #define SDVL_STAT(i, v) do { } while (0)
 #endif
 
+// -DSDVL_SEARCH_STAMPS: diagnostic build, time per part of search_points_kernel summed over all requests (s_memtime ticks) -> sdvl_debug_search_stamps
+#ifdef SDVL_SEARCH_STAMPS
+__device__ unsigned long long *g_search_stamps;  // 8 per request (no atomics: they would congest what is being timed)
+constexpr int kStampRequests = 1 << 18;
+#define SS_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[k] += now_ - t_last_; t_last_ = now_; } while (0)
+#define SS_FLUSH() do { if (lane == 0 && ri < kStampRequests && g_search_stamps) { for (int q_ = 0; q_ < 7; q_++) g_search_stamps[ri * 8 + q_] += st_[q_]; g_search_stamps[ri * 8 + 7] += 1ull; } } while (0)
+#else
+#define SS_STAMP(k) do { } while (0)
+#define SS_FLUSH() do { } while (0)
+#endif
+
 // search regions of up to this many 32-px cells go through the corner bins (their corners: ~3.4 per cell); larger ones scan the whole list
 constexpr int kBinRegionCells = 320;
 
@@ -274,6 +285,9 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // per request (GetCornersInRange scans ALL corners for every point, matcher.cc:123-230)
   __shared__ uint32_t s_corners[kStage ? kLdsCorners : 1];
   const int lane = threadIdx.x & 63;
+#ifdef SDVL_SEARCH_STAMPS
+  unsigned long long st_[7] = {0, 0, 0, 0, 0, 0, 0}, t_last_ = __builtin_amdgcn_s_memtime();
+#endif
   // wave-uniform: request, prep and frame-table loads become scalar loads.  kW == 1: the grid holds kWavesPerBlock workgroups per block
   const int wv = kW == 1 ? static_cast<int>((blockIdx.x >> 3) % kWavesPerBlock) : __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   // Workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is padded to a multiple of 8).  XCD x takes the x-th
@@ -322,13 +336,19 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     return;
   }
   // The epipolar constants of the request (ends of the projected depth interval, line normal, ...) are read where an epipolar
-  // request uses them, through a pointer the compiler may not cache: loaded up front they sat in 30 scalar registers across the
-  // whole kernel, and the kernel spilled 70 scalar registers into vector lanes — ~300 v_readlane / v_writelane (vector instructions:
-  // the path is bound by their issue) and as many s_nop in the hot loops, 40 of them in every round of the range test.  Tracked
-  // points are `fixed` (a circle around px0): they never touch these.
-  const volatile SearchPrep *prv = &prep[ri];
+  // request uses them, through a pointer the compiler cannot trace back to prep[ri] (`epi()`: an empty asm hands it over in scalar
+  // registers): loaded up front they sat in 30 scalar registers across the whole kernel, and the kernel spilled 70 scalar registers
+  // into vector lanes — ~300 v_readlane / v_writelane (vector instructions: the path is bound by their issue) and as many s_nop in
+  // the hot loops, 40 of them in every round of the range test.  Tracked points are `fixed` (a circle around px0): they never
+  // touch these.  (Not `volatile`: volatile loads are system-coherent flat loads with a wait each.)
+  const auto epi = [&]() {
+    const SearchPrep *pe = prep + ri;
+    asm volatile("" : "+s"(pe));
+    return pe;
+  };
   const int slevel = pr.slevel;
   res.slevel = slevel;
+  SS_STAMP(0);
   // ---- CreatePatch, matcher.cc:325-357
   {
     const double I00 = pr.I00, I01 = pr.I01, I10 = pr.I10, I11 = pr.I11;
@@ -351,6 +371,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
   }
   wave_sync();
+  SS_STAMP(1);
   const double range = pr.range, range2 = pr.range2;
 
   // ---- GetCornersInRange + SearchFeatures
@@ -388,6 +409,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
           const double ddx = rq.px0[0] - posx, ddy = rq.px0[1] - posy;
           if (ddx * ddx + ddy * ddy > range2) inr = false;
         } else {
+          const SearchPrep *prv = epi();
           const double nx = prv->nx, ny = prv->ny, normdist = prv->normdist;
           const double dist = normdist - (posx * nx + posy * ny);
           if (fabs(dist) > range) inr = false;
@@ -411,6 +433,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       if (lazy_desc) {
         unsigned long long m = __ballot(inr);
         const uint32_t rq_nib = (rq.desc[lane >> 3] >> (4 * (lane & 7))) & 0xFu;
+        SS_STAMP(2);
         while (m) {
           const int j = __ffsll(static_cast<long long>(m)) - 1;
           m &= m - 1;
@@ -431,7 +454,11 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
           }
           const int sc = wave_sum_i32(__popc(nib ^ rq_nib));
           if (lane == j) score = sc;
+#ifdef SDVL_SEARCH_STAMPS
+          st_[6]++;
+#endif
         }
+        SS_STAMP(3);
       }
       if (inr) {
         if (prm.use_orb) {
@@ -473,6 +500,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // scan the whole list, like the reference.
     bool line_ok = true;
     if (!rq.fixed) {
+      const SearchPrep *prv = epi();
       const double vline = prv->vline, nx = prv->nx, ny = prv->ny;
       line_ok = vline > 0.0 && nx == nx && ny == ny;
     }
@@ -481,6 +509,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       if (rq.fixed) {
         bx0 = rq.px0[0] - range; bx1 = rq.px0[0] + range; by0 = rq.px0[1] - range; by1 = rq.px0[1] + range;
       } else {
+        const SearchPrep *prv = epi();
         const double ax = prv->pxa[0], ay = prv->pxa[1], bx = prv->pxb[0], by = prv->pxb[1];
         bx0 = fmin(ax, bx) - range; bx1 = fmax(ax, bx) + range; by0 = fmin(ay, by) - range; by1 = fmax(ay, by) + range;
       }
@@ -544,6 +573,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       best_pk = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(best_pk), __ffsll(static_cast<long long>(w)) - 1));
     }
   }
+  SS_STAMP(2);
   res.stage = 1;
   bool matched = false;
   int best_ci = -1;
@@ -557,6 +587,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
   if (!matched) {
     if (lane == 0) { out[ri] = res; if (out_host) out_host[ri] = res; }
+    SS_FLUSH();
     return;
   }
   res.best_corner = best_ci;
@@ -572,6 +603,10 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                                                        &its, prm.lk_tree_sums != 0)
                               : align_patch_wave<false>(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v,
                                                         &its, prm.lk_tree_sums != 0);
+  SS_STAMP(4);
+#ifdef SDVL_SEARCH_STAMPS
+  st_[5] += its;
+#endif
   res.lk_its = its;
   res.stage = 2;
   if (conv) {
@@ -582,7 +617,27 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     res.stage = 3;
   }
   if (lane == 0) { out[ri] = res; if (out_host) out_host[ri] = res; }
+  SS_FLUSH();
 }
+
+#ifdef SDVL_SEARCH_STAMPS
+extern "C" int sdvl_debug_search_stamps(unsigned long long *out8, int reset) {
+  static unsigned long long *d_buf = nullptr;
+  const size_t bytes = sizeof(unsigned long long) * 8 * kStampRequests;
+  if (reset) {
+    if (!d_buf && hipMalloc(&d_buf, bytes) != hipSuccess) return -1;
+    if (hipMemset(d_buf, 0, bytes) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_search_stamps), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : -1;
+  }
+  if (!d_buf) return -1;
+  std::vector<unsigned long long> h(static_cast<size_t>(8) * kStampRequests);
+  if (hipMemcpy(h.data(), d_buf, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int q = 0; q < 8; q++) out8[q] = 0;
+  for (int r = 0; r < kStampRequests; r++)
+    for (int q = 0; q < 8; q++) out8[q] += h[static_cast<size_t>(r) * 8 + q];
+  return 0;
+}
+#endif
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void align_patches_kernel(const PatchJob *__restrict__ jobs, const uint8_t *__restrict__ border,
                                                                             const uint8_t *__restrict__ patch, int n, int max_its,

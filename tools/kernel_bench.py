@@ -116,9 +116,17 @@ print("search: requests=%d found=%d lk_its/found=%.2f" % (nreq, n_found, lk))
 ctx.synchronize()
 t_a = ctx.timing_get().get("search_points", (0.0, 0))
 ctx._check(lib.sdvl_detect_corners(ctx.h, n, arr3, C.byref(dp), 1000))   # new corner lists: descriptors invalid
+if hasattr(lib, 'sdvl_debug_search_stamps'):
+    lib.sdvl_debug_search_stamps(None, 1)
 for _ in range(max(1, reps // 3)):
     sres2 = ctx.search_points(sreqs, cam, sp)
 ctx.synchronize()
+if hasattr(lib, 'sdvl_debug_search_stamps'):   # -DSDVL_SEARCH_STAMPS build
+    st = (C.c_ulonglong * 8)()
+    lib.sdvl_debug_search_stamps(st, 0)
+    nw = max(1, st[7])
+    print('search stamps per request (ticks): head %.1f patch %.1f scan %.1f descriptors %.1f lk %.1f | lk its %.2f descriptors %.2f | requests %d' %
+          (st[0] / nw, st[1] / nw, st[2] / nw, st[3] / nw, st[4] / nw, st[5] / nw, st[6] / nw, nw))
 t_b = ctx.timing_get().get("search_points", (0.0, 0))
 assert os.environ.get('SDVL_KB_NOASSERT') or ([r.found for r in sres2] == [r.found for r in sres] and [tuple(r.px) for r in sres2] == [tuple(r.px) for r in sres])
 print("search_points, descriptors on demand: %.1f us/launch (descriptors in HBM: %.1f us/launch)" %
