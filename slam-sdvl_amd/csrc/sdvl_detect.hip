@@ -188,9 +188,13 @@ struct FastLevels {
   int cell_size, margin, threshold;
 };
 
-struct CellGeo {  // one cell of the detection grid: pyramid level and the ROI left after the image margin (fast_detector.cc:84-92)
-  int16_t x0, y0, rw, rh;  // rw <= 0: the margin swallows the cell
+// one cell of the detection grid: pyramid level and the ROI left after the image margin (fast_detector.cc:84-92).  Four 32-bit words:
+// the record of a (wave-uniform) cell index comes in with ONE scalar load — 16-bit fields came in as four vector loads.
+struct __attribute__((aligned(16))) CellGeo {
+  uint32_t xy;  // x0 | y0 << 16
+  uint32_t wh;  // rw | rh << 16; rw == 0: the margin swallows the cell
   int32_t level;
+  int32_t pad_;
 };
 
 struct FastJob {
@@ -362,14 +366,14 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
   // division by the grid width and the margin clipping were ~100 dependent scalar instructions at the head of every workgroup
   const CellGeo geo = cells[gcell];
   const int tid = threadIdx.x;
-  if (geo.rw <= 0) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
+  if ((geo.wh & 0xFFFFu) == 0u) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
     if (tid == 0) job.cell_counts[gcell] = 0;
     return;
   }
   const int l = geo.level;
   const int W = job.lw[l];
-  const int x0 = geo.x0, y0 = geo.y0;
-  const int rw = geo.rw, rh = geo.rh;  // <= 32
+  const int x0 = static_cast<int>(geo.xy & 0xFFFFu), y0 = static_cast<int>(geo.xy >> 16);
+  const int rw = static_cast<int>(geo.wh & 0xFFFFu), rh = static_cast<int>(geo.wh >> 16);  // <= 32
   const uint8_t *img = job.level[l];
   const int row = tid >> 3, wq = tid & 7, cg = wq * 4;
   {
@@ -607,15 +611,19 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
   if (gcell >= total_cells) return;
   const CellGeo geo = cells[gcell];
   const int lane = threadIdx.x;
-  if (geo.rw <= 0) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
+  if ((geo.wh & 0xFFFFu) == 0u) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
     if (lane == 0) job.cell_counts[gcell] = 0;
     return;
   }
   const int l = geo.level;
   const int W = job.lw[l];
-  const int x0 = geo.x0, y0 = geo.y0;
-  const int rw = geo.rw, rh = geo.rh;  // <= 32
-  const uint8_t *img = job.level[l];
+  const int x0 = static_cast<int>(geo.xy & 0xFFFFu), y0 = static_cast<int>(geo.xy >> 16);
+  const int rw = static_cast<int>(geo.wh & 0xFFFFu), rh = static_cast<int>(geo.wh >> 16);  // <= 32
+  // the level as global memory behind a scalar base, 32-bit byte offsets from it (a generic pointer costs 64-bit vector
+  // arithmetic per address and flat loads, which wait on two counters)
+  typedef __attribute__((address_space(1))) const uint8_t *GlobalBytes;
+  const GlobalBytes img = (GlobalBytes)job.level[l];
+  const uint32_t roi0 = static_cast<uint32_t>(y0) * static_cast<uint32_t>(W) + static_cast<uint32_t>(x0);  // offset of the ROI's first pixel
   const int t = lv.threshold;
   // ---- density probe: compass pre-test on an 8 x 8 sample of the tested pixels, straight from the image
   bool dense;
@@ -624,30 +632,49 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
     bool probed = false, passed = false;
     if (tw > 0 && th > 0) {
       const int pr = 3 + ((lane >> 3) * th >> 3), px = 3 + ((lane & 7) * tw >> 3);
-      const uint8_t *q = img + static_cast<size_t>(y0 + pr) * W + x0 + px;
+      const uint32_t q = roi0 + static_cast<uint32_t>(pr * W + px), w3 = static_cast<uint32_t>(3 * W);
       probed = true;
-      passed = fast_compass_pass(q[0], q[3 * W], q[3], q[-3 * W], q[-3], t);
+      passed = fast_compass_pass(img[q], img[q + w3], img[q + 3u], img[q - w3], img[q - 3u], t);
     }
     dense = 2 * __popcll(__ballot(passed)) > __popcll(__ballot(probed));
   }
   // ---- the tile: lane = (row, half row): 16 pixels = 4 words, so that (lane, word, byte) order is scan order
   const int row = lane >> 1, wbase = (lane & 1) * 4;
-  uint32_t pk[4];
+  uint32_t pk[4] = {0u, 0u, 0u, 0u};
+  // Word-aligned level (every pyramid this library builds): the lane's 16 pixels are one 16-byte load from the word at or below
+  // them plus — when the ROI starts off a word — the word behind, shifted into place (v_alignbyte); pixels right of the ROI come
+  // along as they are (no decision reads them: every ring lies within 3 px of a tested pixel, inside the ROI).  The span of 36
+  // bytes stays inside the row, or the rows below the ROI take the overrun of its last row.
+  const int H = job.lh[l];
+  const bool aligned_rows = (reinterpret_cast<uintptr_t>(job.level[l]) & 3u) == 0 && (W & 3) == 0 && ((x0 & ~3) + 36 <= W || y0 + rh < H);
+  if (aligned_rows) {
+    if (row < rh) {
+      const int shift = x0 & 3;
+      const uint32_t o = (roi0 & ~3u) + static_cast<uint32_t>(row * W + 4 * wbase);
+      const __attribute__((address_space(1))) uint32_t *q4 = (const __attribute__((address_space(1))) uint32_t *)(img + o);
+      uint32_t d[5] = {q4[0], q4[1], q4[2], q4[3], 0u};  // (one 16-byte load)
+      if (shift) {
+        d[4] = q4[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int cg = (wbase + k) * 4;
-    uint32_t pack = 0;
-    if (row < rh && cg < rw) {
-      const uint8_t *src = img + static_cast<size_t>(y0 + row) * W + x0 + cg;
-      if (cg + 4 <= rw && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {
-        pack = *reinterpret_cast<const uint32_t *>(src);
+        for (int k = 0; k < 4; k++) pk[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], static_cast<uint32_t>(shift));
       } else {
 #pragma unroll
-        for (int b = 0; b < 4; b++)
-          if (cg + b < rw) pack |= static_cast<uint32_t>(src[b]) << (8 * b);
+        for (int k = 0; k < 4; k++) pk[k] = d[k];
       }
     }
-    pk[k] = pack;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int cg = (wbase + k) * 4;
+      uint32_t pack = 0;
+      if (row < rh && cg < rw) {
+        const uint32_t o = roi0 + static_cast<uint32_t>(row * W + cg);
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (cg + b < rw) pack |= static_cast<uint32_t>(img[o + b]) << (8 * b);
+      }
+      pk[k] = pack;
+    }
   }
   uint32_t *out = job.cell_kps + static_cast<size_t>(gcell) * SDVL_CELL_KP_CAP;
   int base = 0;  // survivors written so far, in cv::FAST's output order (row-major)
@@ -1780,9 +1807,10 @@ static int fast_cell_table(sdvl_ctx *ctx, const FastLevels &lv, const sdvl_frame
       const int x0 = std::max(lv.margin, cj * lv.cell_size), x1 = std::min(W - lv.margin, cj * lv.cell_size + lv.cell_size);
       CellGeo &g = t[lv.cell_begin[l] + c];
       const bool empty = y1 <= y0 || x1 <= x0;
-      g.x0 = static_cast<int16_t>(x0); g.y0 = static_cast<int16_t>(y0);
-      g.rw = static_cast<int16_t>(empty ? 0 : x1 - x0); g.rh = static_cast<int16_t>(empty ? 0 : y1 - y0);
+      g.xy = static_cast<uint32_t>(x0 & 0xFFFF) | (static_cast<uint32_t>(y0 & 0xFFFF) << 16);
+      g.wh = empty ? 0u : (static_cast<uint32_t>(x1 - x0) | (static_cast<uint32_t>(y1 - y0) << 16));
       g.level = l;
+      g.pad_ = 0;
     }
   }
   SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
