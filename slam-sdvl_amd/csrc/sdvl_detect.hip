@@ -194,7 +194,7 @@ struct __attribute__((aligned(16))) CellGeo {
   uint32_t xy;  // x0 | y0 << 16
   uint32_t wh;  // rw | rh << 16; rw == 0: the margin swallows the cell
   int32_t level;
-  int32_t pad_;
+  int32_t pair_inv;  // (65536 + npr - 1) / npr for the npr = (rw - 5) / 2 pixel pairs of a tested row: q / npr == (q * pair_inv) >> 16 for q < 1024
 };
 
 struct FastJob {
@@ -685,18 +685,25 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // pixels as halves: pixel x at half 4 + x
       const uint32_t pack = pk[k];
-      const auto lo = __builtin_amdgcn_cvt_pkrtz(static_cast<float>(pack & 0xFFu), static_cast<float>((pack >> 8) & 0xFFu));
-      const auto hi = __builtin_amdgcn_cvt_pkrtz(static_cast<float>((pack >> 16) & 0xFFu), static_cast<float>(pack >> 24));
       uint2 hw;
-      hw.x = __builtin_bit_cast(uint32_t, lo);
-      hw.y = __builtin_bit_cast(uint32_t, hi);
+      if (kHalfScores) {
+        // the half 0x6400 | b IS 1024 + b (ulp 1 on [1024, 2048)): one byte shuffle per pixel pair instead of two conversions and
+        // a pack.  Every use of a pixel is a min / max or a difference of two pixels: the offset never shows.
+        hw.x = __builtin_amdgcn_perm(0x64646464u, pack, 0x04010400u);  // selector bytes 0-3: bytes of `pack`, 4-7: of the constant
+        hw.y = __builtin_amdgcn_perm(0x64646464u, pack, 0x04030402u);
+      } else {
+        const auto lo = __builtin_amdgcn_cvt_pkrtz(static_cast<float>(pack & 0xFFu), static_cast<float>((pack >> 8) & 0xFFu));
+        const auto hi = __builtin_amdgcn_cvt_pkrtz(static_cast<float>((pack >> 16) & 0xFFu), static_cast<float>(pack >> 24));
+        hw.x = __builtin_bit_cast(uint32_t, lo);
+        hw.y = __builtin_bit_cast(uint32_t, hi);
+      }
       *reinterpret_cast<uint2 *>(&s_imgh[(row + kPadRows) * kPitchHW + 2 + 2 * (wbase + k)]) = hw;
     }
     fc_wave_sync();
     const int tw = rw - 6;
     const int npr = tw > 0 ? (tw + 1) >> 1 : 1;
     const int ncand = tw > 0 && rh > 6 ? npr * (rh - 6) : 0;   // pixel pairs, <= 13 x 26 = 338
-    const int inv = (65536 + npr - 1) / npr;                   // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13
+    const int inv = geo.pair_inv;                              // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13 (from the table: a division here is ten vector instructions)
     const int npass = (ncand + 63) >> 6;                       // <= 6
     const _Float16 th = static_cast<_Float16>(t);
     if constexpr (kHalfScores) {
@@ -1810,7 +1817,10 @@ static int fast_cell_table(sdvl_ctx *ctx, const FastLevels &lv, const sdvl_frame
       g.xy = static_cast<uint32_t>(x0 & 0xFFFF) | (static_cast<uint32_t>(y0 & 0xFFFF) << 16);
       g.wh = empty ? 0u : (static_cast<uint32_t>(x1 - x0) | (static_cast<uint32_t>(y1 - y0) << 16));
       g.level = l;
-      g.pad_ = 0;
+      {
+        const int tw = (empty ? 0 : x1 - x0) - 6, npr = tw > 0 ? (tw + 1) >> 1 : 1;
+        g.pair_inv = (65536 + npr - 1) / npr;
+      }
     }
   }
   SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
