@@ -138,14 +138,12 @@ __global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const Pyr
     if (2 * xp < nx) {
       const uint32_t *w = &s_srcw[r * (kPyrSWW + 1) + xp];
       const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-      // v_perm_b32: selector bytes 0-3 name bytes of the second operand, 4-7 of the first, 0x0c a zero byte
-      const u16x2 p02 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c040c02u));
-      const u16x2 p13 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c050c03u));
-      const u16x2 p24 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c060c04u));
-      const u16x2 p35 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1, w0, 0x0c070c05u));
-      const u16x2 p46 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w2, w1, 0x0c040c02u));
-      const u16x2 four = {4, 4}, six = {6, 6};
-      const u16x2 h = p02 + p46 + four * (p13 + p35) + six * p24;
+      // the five taps of an output as two byte dot products (v_dot4_u32_u8), the weights laid over the bytes of the words they fall
+      // on: output x = bytes 2, 3 of w0 (1, 4) and 0 .. 2 of w1 (6, 4, 1); output x + 1 = all of w1 (1, 4, 6, 4) and byte 0 of w2.
+      // (Round 4; before: five byte shuffles into 16-bit lanes and six packed operations per pair.)
+      const uint32_t hx = __builtin_amdgcn_udot4(w1, 0x00010406u, __builtin_amdgcn_udot4(w0, 0x04010000u, 0u, false), false);
+      const uint32_t hx1 = __builtin_amdgcn_udot4(w2, 0x00000001u, __builtin_amdgcn_udot4(w1, 0x04060401u, 0u, false), false);
+      const uint32_t h = hx | (hx1 << 16);
       *reinterpret_cast<uint32_t *>(&s_h[r][2 * xp]) = __builtin_bit_cast(uint32_t, h);
     }
   }
