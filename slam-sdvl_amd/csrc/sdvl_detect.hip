@@ -191,7 +191,7 @@ struct FastLevels {
 struct __attribute__((aligned(16))) CellGeo {
   uint32_t xy;  // x0 | y0 << 16
   uint32_t wh;  // rw | rh << 16; rw == 0: the margin swallows the cell
-  int32_t level;
+  int32_t level;     // level | quad_inv << 8: (65536 + nq - 1) / nq for the nq = (npr + 1) / 2 pairs of pairs of a tested row
   int32_t pair_inv;  // (65536 + npr - 1) / npr for the npr = (rw - 5) / 2 pixel pairs of a tested row: q / npr == (q * pair_inv) >> 16 for q < 1024
 };
 
@@ -296,20 +296,19 @@ __device__ __forceinline__ h2 as_h2(uint32_t w) { return __builtin_bit_cast(h2, 
 // the two halves that straddle the words lo | hi: (hi : lo) >> 16
 __device__ __forceinline__ h2 mid_h2(uint32_t hi, uint32_t lo) { return as_h2(__builtin_amdgcn_alignbit(hi, lo, 16)); }
 
-// w = word of the half tile at (tile row of ring row -3, halves x-3 | x-2) for the pair (x, x+1), x odd; t2 = (t, t).
-// Returns (best(x), best(x+1)) with best as in fast_corner_best.
-__device__ __forceinline__ h2 fast_pair_best(const uint32_t *w, h2 t2) {
-#define SDVL_HW(DY, K) w[((DY) + 3) * kPitchHW + (K)]  // K = (dx + 3) / 2 for odd dx: halves (x + dx, x + dx + 1)
-  const uint32_t a1 = SDVL_HW(3, 1), a2 = SDVL_HW(3, 2), b1 = SDVL_HW(-3, 1), b2 = SDVL_HW(-3, 2);
-  const uint32_t c0 = SDVL_HW(2, 0), c1 = SDVL_HW(2, 1), c2 = SDVL_HW(2, 2), c3 = SDVL_HW(2, 3);
-  const uint32_t d0 = SDVL_HW(-2, 0), d1 = SDVL_HW(-2, 1), d2 = SDVL_HW(-2, 2), d3 = SDVL_HW(-2, 3);
-  const uint32_t z1 = SDVL_HW(0, 1), z2 = SDVL_HW(0, 2);
+// the 20 words of the half tile a pair's ring lies in: rows +3 / -3 words 1, 2 (a, b), rows +2 / -2 words 0 .. 3 (c, d), rows +1 / -1
+// words 0 and 3 (u, l), row 0 words 0 .. 3 (z); word K of a row = halves (x - 3 + 2 K, x - 2 + 2 K) of the pair (x, x + 1), x odd
+struct PairRing {
+  uint32_t a1, a2, b1, b2, c0, c1, c2, c3, d0, d1, d2, d3, z0, z1, z2, z3, u0, u3, l0, l3;
+};
+
+// (best(x), best(x+1)) with best as in fast_corner_best; t2 = (t, t)
+__device__ __forceinline__ h2 fast_pair_best_ring(const PairRing &q, h2 t2) {
   // cv::FAST offsets16: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-  const h2 e0 = mid_h2(a2, a1), e1 = as_h2(a2), e2 = mid_h2(c3, c2), e3 = as_h2(SDVL_HW(1, 3)), e4 = as_h2(SDVL_HW(0, 3)),
-           e5 = as_h2(SDVL_HW(-1, 3)), e6 = mid_h2(d3, d2), e7 = as_h2(b2), e8 = mid_h2(b2, b1), e9 = as_h2(b1), e10 = mid_h2(d1, d0),
-           e11 = as_h2(SDVL_HW(-1, 0)), e12 = as_h2(SDVL_HW(0, 0)), e13 = as_h2(SDVL_HW(1, 0)), e14 = mid_h2(c1, c0), e15 = as_h2(a1);
-  const h2 v = mid_h2(z2, z1);
-#undef SDVL_HW
+  const h2 e0 = mid_h2(q.a2, q.a1), e1 = as_h2(q.a2), e2 = mid_h2(q.c3, q.c2), e3 = as_h2(q.u3), e4 = as_h2(q.z3), e5 = as_h2(q.l3),
+           e6 = mid_h2(q.d3, q.d2), e7 = as_h2(q.b2), e8 = mid_h2(q.b2, q.b1), e9 = as_h2(q.b1), e10 = mid_h2(q.d1, q.d0), e11 = as_h2(q.l0),
+           e12 = as_h2(q.z0), e13 = as_h2(q.u0), e14 = mid_h2(q.c1, q.c0), e15 = as_h2(q.a1);
+  const h2 v = mid_h2(q.z2, q.z1);
 #define SDVL_W3(K, A, B, C) const h2 n##K = pk_min3(e##A, e##B, e##C), x##K = pk_max3(e##A, e##B, e##C);
   SDVL_W3(0, 0, 1, 2) SDVL_W3(1, 1, 2, 3) SDVL_W3(2, 2, 3, 4) SDVL_W3(3, 3, 4, 5) SDVL_W3(4, 4, 5, 6) SDVL_W3(5, 5, 6, 7)
   SDVL_W3(6, 6, 7, 8) SDVL_W3(7, 7, 8, 9) SDVL_W3(8, 8, 9, 10) SDVL_W3(9, 9, 10, 11) SDVL_W3(10, 10, 11, 12) SDVL_W3(11, 11, 12, 13)
@@ -325,6 +324,32 @@ __device__ __forceinline__ h2 fast_pair_best(const uint32_t *w, h2 t2) {
   const h2 min_x = pk_min3(pk_min3(pk_min3(X0, X1, X2), pk_min3(X3, X4, X5), pk_min3(X6, X7, X8)),
                            pk_min3(pk_min3(X9, X10, X11), pk_min3(X12, X13, X14), X15), X15);
   return pk_max3(t2, v - min_x, max_n - v);
+}
+
+// w = word of the half tile at (tile row of ring row -3, halves x-3 | x-2) for the pair (x, x+1), x odd
+__device__ __forceinline__ h2 fast_pair_best(const uint32_t *w, h2 t2) {
+#define SDVL_HW(DY, K) w[((DY) + 3) * kPitchHW + (K)]  // K = (dx + 3) / 2 for odd dx: halves (x + dx, x + dx + 1)
+  const PairRing q = {SDVL_HW(3, 1), SDVL_HW(3, 2), SDVL_HW(-3, 1), SDVL_HW(-3, 2), SDVL_HW(2, 0), SDVL_HW(2, 1), SDVL_HW(2, 2), SDVL_HW(2, 3),
+                      SDVL_HW(-2, 0), SDVL_HW(-2, 1), SDVL_HW(-2, 2), SDVL_HW(-2, 3), SDVL_HW(0, 0), SDVL_HW(0, 1), SDVL_HW(0, 2), SDVL_HW(0, 3),
+                      SDVL_HW(1, 0), SDVL_HW(1, 3), SDVL_HW(-1, 0), SDVL_HW(-1, 3)};
+#undef SDVL_HW
+  return fast_pair_best_ring(q, t2);
+}
+
+// Two horizontally adjacent pairs (x .. x+3, x = 3 mod 4) at once: w as for the first pair and EVEN (8-byte aligned).  The second
+// pair's ring is the first one's moved by one word, so the two share 11 of their 2 x 20 words: 29 loads, the even-odd word pairs
+// as 64-bit loads (which the LDS serves at twice the rate of two 32-bit ones).
+__device__ __forceinline__ void fast_quad_best(const uint32_t *w, h2 t2, h2 *best_a, h2 *best_b) {
+  const auto w2 = [w](int dy, int k) { return *reinterpret_cast<const uint2 *>(&w[(dy + 3) * kPitchHW + k]); };  // k even
+  const auto w1 = [w](int dy, int k) { return w[(dy + 3) * kPitchHW + k]; };
+  const uint32_t a1 = w1(3, 1), b1 = w1(-3, 1);
+  const uint2 a23 = w2(3, 2), b23 = w2(-3, 2);
+  const uint2 c01 = w2(2, 0), c23 = w2(2, 2), d01 = w2(-2, 0), d23 = w2(-2, 2), z01 = w2(0, 0), z23 = w2(0, 2), u01 = w2(1, 0), l01 = w2(-1, 0);
+  const uint32_t c4 = w1(2, 4), d4 = w1(-2, 4), z4 = w1(0, 4), u3 = w1(1, 3), u4 = w1(1, 4), l3 = w1(-1, 3), l4 = w1(-1, 4);
+  const PairRing qa = {a1, a23.x, b1, b23.x, c01.x, c01.y, c23.x, c23.y, d01.x, d01.y, d23.x, d23.y, z01.x, z01.y, z23.x, z23.y, u01.x, u3, l01.x, l3};
+  const PairRing qb = {a23.x, a23.y, b23.x, b23.y, c01.y, c23.x, c23.y, c4, d01.y, d23.x, d23.y, d4, z01.y, z23.x, z23.y, z4, u01.y, u4, l01.y, l4};
+  *best_a = fast_pair_best_ring(qa, t2);
+  *best_b = fast_pair_best_ring(qb, t2);
 }
 
 // exclusive rank of (lane, bit k) in lane-major order over the wave for the 4-bit flag sets `flags`, and the wave total
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restri
     if (tid == 0) job.cell_counts[gcell] = 0;
     return;
   }
-  const int l = geo.level;
+  const int l = geo.level & 0xFF;
   const int W = job.lw[l];
   const int x0 = static_cast<int>(geo.xy & 0xFFFFu), y0 = static_cast<int>(geo.xy >> 16);
   const int rw = static_cast<int>(geo.wh & 0xFFFFu), rh = static_cast<int>(geo.wh >> 16);  // <= 32
@@ -599,7 +624,10 @@ static_assert(((kTile + 2 * kPadRows) * kPitchHW * 4) % 16 == 0, "the half score
 // compare) and keeps it in a register; the suppression folds max(t - 1, 0) into the neighbours' maximum m, and then
 // "is a corner AND beats its 8 neighbours" is the SIGN of m - score per half (integers in f16: exact, m == score gives +0).
 // The second pixel of a row's last pair in an odd-width ROI is not a tested pixel: it is given t - 1, a non-corner.
-template <bool kHalfScores>
+// kQuads (the default; SDVL_FAST_PAIRS=1 for one pair per lane and pass): a lane takes FOUR adjacent pixels, two pairs, per pass —
+// the rings of the two pairs share loads (fast_quad_best), and the index arithmetic, the suppression's neighbour loads and the ordered
+// compaction are paid once per four pixels: 3 passes of 182 lane tasks instead of 6 of 338.
+template <bool kHalfScores, bool kQuads = false>
 __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__restrict__ jobs, FastLevels lv, const CellGeo *__restrict__ cells) {
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[kFcDenseWords];
   const FastJob &job = jobs[blockIdx.y];
@@ -613,7 +641,7 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
     if (lane == 0) job.cell_counts[gcell] = 0;
     return;
   }
-  const int l = geo.level;
+  const int l = geo.level & 0xFF;
   const int W = job.lw[l];
   const int x0 = static_cast<int>(geo.xy & 0xFFFFu), y0 = static_cast<int>(geo.xy >> 16);
   const int rw = static_cast<int>(geo.wh & 0xFFFFu), rh = static_cast<int>(geo.wh >> 16);  // <= 32
@@ -704,6 +732,93 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
     const int inv = geo.pair_inv;                              // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13 (from the table: a division here is ten vector instructions)
     const int npass = (ncand + 63) >> 6;                       // <= 6
     const _Float16 th = static_cast<_Float16>(t);
+    if constexpr (kQuads) {
+      static_assert(kHalfScores, "the quad path keeps its scores as halves");
+      const h2 t2 = h2{th, th}, one2 = h2{static_cast<_Float16>(1), static_cast<_Float16>(1)};
+      const h2 below2 = t2 - one2;  // best - 1 of a pixel that is no corner
+      const _Float16 tf = static_cast<_Float16>(t > 1 ? t - 1 : 0);
+      const h2 floor2 = h2{tf, tf};
+      const bool odd = (tw & 1) != 0;
+      const int nq = (npr + 1) >> 1;                                  // pairs of pairs in a tested row, <= 7
+      const int nquad = tw > 0 && rh > 6 ? nq * (rh - 6) : 0;         // <= 182
+      const int qinv = geo.level >> 8;                                // q / nq == (q * qinv) >> 16
+      const int nqpass = (nquad + 63) >> 6;                           // <= 3
+      typedef __attribute__((address_space(3))) volatile _Float16 *LdsHalves;
+      typedef __attribute__((address_space(3))) uint32_t *LdsWords;
+      const FcGlobalWords gout = (FcGlobalWords)out;
+      uint32_t sa[3], sb[3], wofs[3], xy[3];  // per pass: the two pairs' scores (halves), the first pair's word in the half tile, (x | y << 12) of its first pixel
+#pragma unroll
+      for (int ps = 0; ps < 3; ps++) {
+        sa[ps] = sb[ps] = wofs[ps] = xy[ps] = 0u;
+        if (ps < nqpass) {
+          const int i = ps * 64 + lane;
+          if (i < nquad) {
+            const int qr = (i * qinv) >> 16, m = i - qr * nq;
+            const int w = (qr + 3) * kPitchHW + 2 + 2 * m;  // even: tile row qr + 3 is ring row -3 of image row qr + 3; pixel x = 3 + 4 m
+            h2 a, b;
+            fast_quad_best(&s_imgh[w], t2, &a, &b);
+            a = a - one2;
+            b = b - one2;
+            if (2 * m + 1 >= npr) b = below2;  // the row's last pair of pairs holds one pair when npr is odd
+            if (odd) {  // the second pixel of the row's last pair (x + 1 == rw - 3) is not a tested pixel
+              asm volatile("");
+              if (2 * m + 1 == npr - 1) b.y = below2.y;
+              if (2 * m == npr - 1) a.y = below2.y;
+            }
+            // halves 4 + x .. 4 + x + 3 of plane row qr + 4: the first on its own, the middle two are an aligned word, the last on its own
+            _Float16 *sh = reinterpret_cast<_Float16 *>(s_scoreh) + 2 * w + 2 * kPitchHW + 3;
+            const LdsHalves vsh = (LdsHalves)sh;
+            vsh[0] = a.x;
+            *(LdsWords)(sh + 1) = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x05040302u);  // (a.y | b.x << 16)
+            vsh[3] = b.y;
+            sa[ps] = __builtin_bit_cast(uint32_t, a);
+            sb[ps] = __builtin_bit_cast(uint32_t, b);
+            wofs[ps] = static_cast<uint32_t>(w);
+            xy[ps] = static_cast<uint32_t>(x0 + 3 + 4 * m) | (static_cast<uint32_t>(y0 + 3 + qr) << 12);
+          }
+        }
+      }
+      fc_wave_sync();
+#pragma unroll
+      for (int ps = 0; ps < 3; ps++) {
+        if (ps < nqpass) {
+          const uint32_t own_a = sa[ps], own_b = sb[ps];
+          uint32_t da = 0u, db = 0u;  // sign per half: corner that beats its 8 neighbours
+          if (ps * 64 + lane < nquad) {
+            // plane rows r, r + 1, r + 2 (r + 1 = the pixels' own), halves (x-1 | x) (x+1 | x+2) (x+3 | x+4): an odd word and an aligned pair
+            const uint32_t *sw = &s_scoreh[wofs[ps] + kPitchHW + 1];
+            const uint32_t u0 = sw[-kPitchHW], c0 = sw[0], d0 = sw[kPitchHW];
+            const uint2 u12 = *reinterpret_cast<const uint2 *>(sw - kPitchHW + 1), c12 = *reinterpret_cast<const uint2 *>(sw + 1),
+                        d12 = *reinterpret_cast<const uint2 *>(sw + kPitchHW + 1);
+            const h2 up_a = pk_max3(as_h2(u0), mid_h2(u12.x, u0), as_h2(u12.x)), dn_a = pk_max3(as_h2(d0), mid_h2(d12.x, d0), as_h2(d12.x));
+            const h2 up_b = pk_max3(as_h2(u12.x), mid_h2(u12.y, u12.x), as_h2(u12.y)), dn_b = pk_max3(as_h2(d12.x), mid_h2(d12.y, d12.x), as_h2(d12.y));
+            const h2 m_a = pk_max3(up_a, dn_a, pk_max3(as_h2(c0), as_h2(c12.x), floor2));
+            const h2 m_b = pk_max3(up_b, dn_b, pk_max3(as_h2(c12.x), as_h2(c12.y), floor2));
+            da = __builtin_bit_cast(uint32_t, m_a - as_h2(own_a));
+            db = __builtin_bit_cast(uint32_t, m_b - as_h2(own_b));
+          }
+          const uint32_t lo_a = (da >> 15) & 1u, lo_b = (db >> 15) & 1u;
+          const bool ok0 = lo_a != 0u, ok1 = static_cast<int32_t>(da) < 0, ok2 = lo_b != 0u, ok3 = static_cast<int32_t>(db) < 0;
+          const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1), m2 = __ballot(ok2), m3 = __ballot(ok3);
+          const auto below = [](unsigned long long m) {
+            return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0)));
+          };
+          int pos = base + below(m0) + below(m1) + below(m2) + below(m3);
+          const h2 a = as_h2(own_a), b = as_h2(own_b);
+          const uint32_t kp = xy[ps];
+          if (ok0 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = kp | (static_cast<uint32_t>(static_cast<uint16_t>(a.x)) << 24);
+          pos += static_cast<int>(lo_a);
+          if (ok1 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (kp + 1u) | (static_cast<uint32_t>(static_cast<uint16_t>(a.y)) << 24);
+          pos += static_cast<int>(da >> 31);
+          if (ok2 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (kp + 2u) | (static_cast<uint32_t>(static_cast<uint16_t>(b.x)) << 24);
+          pos += static_cast<int>(lo_b);
+          if (ok3 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (kp + 3u) | (static_cast<uint32_t>(static_cast<uint16_t>(b.y)) << 24);
+          base += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        }
+      }
+      if (lane == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
+      return;
+    }
     if constexpr (kHalfScores) {
       const h2 t2 = h2{th, th}, one2 = h2{static_cast<_Float16>(1), static_cast<_Float16>(1)};
       const _Float16 tf = static_cast<_Float16>(t > 1 ? t - 1 : 0);
@@ -1785,6 +1900,11 @@ static bool fast_cells_int_scores() {
   static const bool v = getenv("SDVL_FAST_INT_SCORES") != nullptr;
   return v;
 }
+// SDVL_FAST_PAIRS=1: the dense path with one pixel pair per lane and pass (A/B measurements, tests)
+static bool fast_cells_pairs() {
+  static const bool v = getenv("SDVL_FAST_PAIRS") != nullptr;
+  return v;
+}
 // SDVL_FAST_WG4=1: the four-wave workgroup per cell (fast_cells_kernel) instead of one wave per cell (A/B measurements, tests)
 static bool fast_cells_four_waves() {
   static const bool v = getenv("SDVL_FAST_WG4") != nullptr;
@@ -1818,6 +1938,8 @@ static int fast_cell_table(sdvl_ctx *ctx, const FastLevels &lv, const sdvl_frame
       {
         const int tw = (empty ? 0 : x1 - x0) - 6, npr = tw > 0 ? (tw + 1) >> 1 : 1;
         g.pair_inv = (65536 + npr - 1) / npr;
+        const int nq = (npr + 1) >> 1;
+        g.level = l | (((65536 + nq - 1) / nq) << 8);
       }
     }
   }
@@ -1899,7 +2021,8 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
     SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv, d_cells);
   } else {
     if (fast_cells_int_scores()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<false>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
-    else SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
+    else if (fast_cells_pairs()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
+    else SDVL_LAUNCH(ctx, "fast_cells", (fast_cells_wave_kernel<true, true>), dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
   }
   SDVL_LAUNCH(ctx, "compact_cells", compact_cells_kernel, dim3(n), dim3(256), static_cast<const FastJob *>(dsx), total_cells, cap, d_kps, d_offs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
@@ -2050,7 +2173,8 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
     SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv, d_cells);
   } else {
     if (fast_cells_int_scores()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<false>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
-    else SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
+    else if (fast_cells_pairs()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
+    else SDVL_LAUNCH(ctx, "fast_cells", (fast_cells_wave_kernel<true, true>), dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
   }
   SDVL_LAUNCH(ctx, "select_cells", select_cells_kernel, dim3(static_cast<unsigned>((n + 7) / 8 * 8 * n_slices)), dim3(64), ds, sl, n);
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
