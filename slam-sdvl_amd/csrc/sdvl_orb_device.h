@@ -120,11 +120,17 @@ __device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W
   // lane k: tests 4k .. 4k+3  (byte k/2, bits (k&1)*4 ..); its 16 pattern bytes come in one 128-bit load
   const float4 *pf = reinterpret_cast<const float4 *>(c_orb_pattern_f) + 4 * lane;
   uint32_t nib = 0;
+  // (row, column) of a steered point = (x b + y a, x a - y b) = x (b, a) + y (a, -b): two packed products and a packed sum
+  // (v_pk_mul_f32 / v_pk_add_f32) per point instead of four products and two sums; x a + (-(y b)) IS x a - y b, bit for bit
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 ba = {b, a}, anb = {a, -b};
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const float4 t = pf[q];  // x0, y0, x1, y1 of test 4 lane + q
-    const int t0 = center[cv_round_f(t.x * b + t.y * a) * W + cv_round_f(t.x * a - t.y * b)];
-    const int t1 = center[cv_round_f(t.z * b + t.w * a) * W + cv_round_f(t.z * a - t.w * b)];
+    const f2 p0 = f2{t.x, t.x} * ba + f2{t.y, t.y} * anb;
+    const f2 p1 = f2{t.z, t.z} * ba + f2{t.w, t.w} * anb;
+    const int t0 = center[cv_round_f(p0.x) * W + cv_round_f(p0.y)];
+    const int t1 = center[cv_round_f(p1.x) * W + cv_round_f(p1.y)];
     nib |= (t0 < t1 ? 1u : 0u) << q;
   }
   *angle_deg_out = angle_deg;

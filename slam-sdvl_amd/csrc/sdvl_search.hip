@@ -14,6 +14,7 @@
 // Compiled with -ffp-contract=off.  sdvl_align_patches exposes phase 3 alone.
 #include <unordered_map>
 #include <utility>
+#include <type_traits>
 #include <vector>
 
 #include <cmath>
@@ -84,6 +85,21 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     v = o < v ? o : v;
   }
   return v;
+}
+
+// minimum over the 64 lanes (all active) in every lane: DPP steps inside the 16-lane rows, two row broadcasts, one readlane
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  const auto step = [](uint32_t x, auto ctrl, auto rows) {
+    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(x), decltype(ctrl)::value, decltype(rows)::value, 0xf, false));
+    return o < x ? o : x;
+  };
+  v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+  v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+  v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+  v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8: lane 15 of a row holds the row's minimum
+  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+  v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
 // Matcher::AlignPatch, matcher.cc:359-445.  border/patch in this wave's LDS.  Returns converged; *u,*v updated.
@@ -567,7 +583,14 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       }
     }
     const unsigned long long mine = best;
-    best = wave_min_u64(best);
+    if (prm.use_orb) {
+      // Hamming scores are < 4096: the low word of a key (score << 20 | corner index) orders the keys, the high word is the same in all
+      // of them (0x40000, the offset that keeps ZMSSD scores positive) — a 32-bit minimum in 7 DPP steps instead of 6 exchanges of 64 bits
+      const uint32_t m32 = wave_min_u32(static_cast<uint32_t>(best));
+      best = m32 == ~0u ? ~0ull : ((0x40000ull << 32) | m32);
+    } else {
+      best = wave_min_u64(best);
+    }
     if (best != ~0ull) {  // keys are unique (they end in the corner's list index): exactly one lane holds the winner
       const unsigned long long w = __ballot(mine == best);
       best_pk = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(best_pk), __ffsll(static_cast<long long>(w)) - 1));
