@@ -370,7 +370,8 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const double I00 = pr.I00, I01 = pr.I01, I10 = pr.I10, I11 = pr.I11;
     const uint8_t *img = tref.f.level[level];
     const int W = tref.f.lw[level], H = tref.f.lh[level];
-    const double pyrx = rq.px[0] / (1 << level), pyry = rq.px[1] / (1 << level);
+    // x / 2^level as ldexp(x, -level): the same double (a power of two scales exactly), one instruction instead of a division's fifteen
+    const double pyrx = __builtin_ldexp(rq.px[0], -level), pyry = __builtin_ldexp(rq.px[1], -level);
     const bool bad = (I00 != I00);  // std::isnan(matrix_inv(0,0)): the reference returns leaving stale patches
     for (int s = lane; s < 100; s += 64) {
       const int y = s / 10, x = s - y * 10;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   res.px[0] = mpx;
   res.px[1] = mpy;
   // ---- AlignPatch at the search level
-  float u = static_cast<float>(mpx / (1 << slevel)), v = static_cast<float>(mpy / (1 << slevel));
+  float u = static_cast<float>(__builtin_ldexp(mpx, -slevel)), v = static_cast<float>(__builtin_ldexp(mpy, -slevel));  // mpx / (1 << slevel), exactly
   int its = 0;
   const bool conv = kLkWindow ? align_patch_wave<true>(L, tcur.f.level[slevel], tcur.f.lw[slevel], tcur.f.lh[slevel], prm.max_align_its, lane, &u, &v,
                                                        &its, prm.lk_tree_sums != 0)
