@@ -61,9 +61,8 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const OrbJob *__restr
     if (lane == 0 && job.out_angle) job.out_angle[ci] = -1.f;
     continue;
   }
-  const uint8_t *center = job.level[cl] + static_cast<size_t>(cy) * W + cx;
   float angle_deg;
-  const uint32_t nib = orb_wave_nibble(center, W, lane, &angle_deg);
+  const uint32_t nib = orb_wave_nibble(job.level[cl], static_cast<uint32_t>(cy * W + cx), W, lane, &angle_deg);
   const uint32_t hi = __shfl_down(nib, 1, 64);
   if ((lane & 1) == 0) {
     const uint8_t byte = static_cast<uint8_t>(nib | (hi << 4));
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(256) void filter_describe_kernel(const FilterJob *_
     uint8_t byte = 0;
     if (cx >= 19 && cx < W - 19 && cy >= 19 && cy < H - 19) {  // ORBDetector::IsInsideLimits; zeros outside, as orb_describe_kernel
       float angle_deg;
-      const uint32_t nib = orb_wave_nibble(job.level[cl] + static_cast<size_t>(cy) * W + cx, W, lane, &angle_deg);
+      const uint32_t nib = orb_wave_nibble(job.level[cl], static_cast<uint32_t>(cy * W + cx), W, lane, &angle_deg);
       const uint32_t hi = __shfl_down(nib, 1, 64);
       byte = static_cast<uint8_t>(nib | (hi << 4));
     }

@@ -91,7 +91,11 @@ __device__ __forceinline__ int cv_round_f(float v) { return static_cast<int>(__b
 // The 4 BRIEF bits of this lane (tests 4*lane .. 4*lane+3, bit q = test 4*lane+q) for the corner at `center` (row stride
 // W); the caller has checked ORBDetector::IsInsideLimits (19 px from every border).  All 64 lanes must call.
 // Byte b of the descriptor = nibble of lane 2b | nibble of lane 2b+1 << 4.
-__device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W, int lane, float *angle_deg_out) {
+// The level comes as (base pointer, byte offset of the corner): every pixel address is base + a 32-bit offset, a load with a scalar
+// base register and one vector add — `center + v * W + u0` on a generic pointer cost a sign extension and a 64-bit add per load.
+typedef __attribute__((address_space(1))) const uint8_t *OrbGlobalBytes;
+__device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *level, uint32_t center_off, int W, int lane, float *angle_deg_out) {
+  const OrbGlobalBytes center = (OrbGlobalBytes)level;
   // intensity centroid over the disc: 31 rows x 8 four-pixel segments (u = -16 .. 15) = 248 tasks over 64 lanes,
   // one unaligned 32-bit load per task; umax_ (orb_detector.cc:325-348) lives in two immediates, 4 bits per row
   int m10 = 0, m01 = 0;
@@ -100,8 +104,9 @@ __device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W
     const int task = lane + 64 * r;
     if (task < 248) {
       const int v = (task >> 3) - 15, u0 = -16 + 4 * (task & 7);
-      uint32_t w;
-      __builtin_memcpy(&w, center + v * W + u0, 4);
+      const uint32_t o = center_off + static_cast<uint32_t>(v * W + u0);
+      struct __attribute__((packed)) Unaligned32 { uint32_t v; };
+      const uint32_t w = ((__attribute__((address_space(1))) const Unaligned32 *)(center + o))->v;  // one unaligned 32-bit load
       const int sp = static_cast<int>(__builtin_amdgcn_udot4(w, c_orb_moments.m[task], 0u, false));   // sum of the pixels inside the disc
       const int sup = static_cast<int>(__builtin_amdgcn_udot4(w, c_orb_moments.a[task], 0u, false));  // sum of (u + 16) p
       m10 += sup - 16 * sp;
@@ -129,8 +134,8 @@ __device__ __forceinline__ uint32_t orb_wave_nibble(const uint8_t *center, int W
     const float4 t = pf[q];  // x0, y0, x1, y1 of test 4 lane + q
     const f2 p0 = f2{t.x, t.x} * ba + f2{t.y, t.y} * anb;
     const f2 p1 = f2{t.z, t.z} * ba + f2{t.w, t.w} * anb;
-    const int t0 = center[cv_round_f(p0.x) * W + cv_round_f(p0.y)];
-    const int t1 = center[cv_round_f(p1.x) * W + cv_round_f(p1.y)];
+    const int t0 = center[center_off + static_cast<uint32_t>(cv_round_f(p0.x) * W + cv_round_f(p0.y))];
+    const int t1 = center[center_off + static_cast<uint32_t>(cv_round_f(p1.x) * W + cv_round_f(p1.y))];
     nib |= (t0 < t1 ? 1u : 0u) << q;
   }
   *angle_deg_out = angle_deg;

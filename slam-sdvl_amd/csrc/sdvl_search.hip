@@ -62,8 +62,10 @@ __device__ __forceinline__ float interpolate8u(const uint8_t *img, int stride, f
   const float w01 = (1.0f - sx) * sy;
   const float w10 = sx * (1.0f - sy);
   const float w11 = 1.0f - w00 - w01 - w10;
-  const uint8_t *p = img + static_cast<size_t>(y) * stride + x;
-  return w00 * p[0] + w01 * p[stride] + w10 * p[1] + w11 * p[stride + 1];
+  // (global memory behind a scalar base, one 32-bit offset: x, y >= 0 — the caller has tested the position against the image)
+  const __attribute__((address_space(1))) uint8_t *g = (const __attribute__((address_space(1))) uint8_t *)img;
+  const uint32_t o = static_cast<uint32_t>(y * stride + x), st = static_cast<uint32_t>(stride);
+  return w00 * g[o] + w01 * g[o + st] + w10 * g[o + 1u] + w11 * g[o + st + 1u];
 }
 
 // LDS hand-off between the lanes of ONE wave: order the compiler's view of memory, no s_barrier needed
@@ -199,8 +201,10 @@ __device__ bool align_patch_wave(WaveLds &L, const uint8_t *img, int W, int H, i
       const uint8_t *ip = reinterpret_cast<const uint8_t *>(L.lk) + (v_r + y - 4 - win_y0) * kLkWin + (u_r + x - 4 - win_x0);
       search_pixel = wTL * ip[0] + wTR * ip[1] + wBL * ip[kLkWin] + wBR * ip[kLkWin + 1];
     } else {
-      const uint8_t *ip = img + static_cast<size_t>(v_r + y - 4) * W + (u_r + x - 4);
-      search_pixel = wTL * ip[0] + wTR * ip[1] + wBL * ip[W] + wBR * ip[W + 1];
+      // (u_r, v_r >= 4: the offset is not negative; global memory behind a scalar base)
+      const __attribute__((address_space(1))) uint8_t *g = (const __attribute__((address_space(1))) uint8_t *)img;
+      const uint32_t o = static_cast<uint32_t>((v_r + y - 4) * W + (u_r + x - 4)), st = static_cast<uint32_t>(W);
+      search_pixel = wTL * g[o] + wTR * g[o + 1u] + wBL * g[o + st] + wBR * g[o + st + 1u];
     }
     const float res = search_pixel - ref + mean_diff;
     float J0, J1, J2;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
               wave_sync();
               nib = orb_wave_nibble_win(L.orb, lane, &angle_deg);
             } else {
-              nib = orb_wave_nibble(cf.level[jl] + static_cast<size_t>(jy) * Wj + jx, Wj, lane, &angle_deg);
+              nib = orb_wave_nibble(cf.level[jl], static_cast<uint32_t>(jy * Wj + jx), Wj, lane, &angle_deg);
             }
           }
           const int sc = wave_sum_i32(__popc(nib ^ rq_nib));
