@@ -554,7 +554,9 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               const int cyi = min(ry + r, cy1);
-              const int a = cf.bin_start[cyi * gw + cx0], b = cf.bin_start[cyi * gw + cx1 + 1];
+              const __attribute__((address_space(1))) int *bs = (const __attribute__((address_space(1))) int *)cf.bin_start;  // global, not flat, loads
+              const uint32_t brow = static_cast<uint32_t>(cyi * gw);
+              const int a = bs[brow + static_cast<uint32_t>(cx0)], b = bs[brow + static_cast<uint32_t>(cx1 + 1)];
               e0[r] = a;
               pre[r + 1] = pre[r] + (r < nrows ? b - a : 0);
             }
@@ -567,7 +569,10 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
               for (int q = 1; q < 4; q++) r += (i >= pre[q]) ? 1 : 0;
               const int e = i + (r == 0 ? e0[0] - pre[0] : r == 1 ? e0[1] - pre[1] : r == 2 ? e0[2] - pre[2] : e0[3] - pre[3]);
               uint2 ent = make_uint2(0u, 0u);
-              if (have) ent = cf.bin_entries[e];
+              if (have) {  // (a global load: the entry as one 64-bit scalar type — vector classes do not copy out of an address space)
+                const unsigned long long e64 = ((const __attribute__((address_space(1))) unsigned long long *)cf.bin_entries)[static_cast<uint32_t>(e)];
+                ent = make_uint2(static_cast<uint32_t>(e64), static_cast<uint32_t>(e64 >> 32));
+              }
               SDVL_STAT(3, 1);
               scan_round(have, ent.x, static_cast<int>(ent.y));
             }
