@@ -93,8 +93,10 @@ __global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const Pyr
       if (lr < kRowsPerRound && 4 * lq < nwords) {
         for (int r = lr; r < rows; r += kRowsPerRound) {
           const int sy = reflect101_clamped(2 * ty0 - 2 + r, job.sh);
-          uint32_t v[4];
-          __builtin_memcpy(v, reinterpret_cast<const uint32_t *>(job.src + static_cast<size_t>(sy) * job.sw) + s, 16);
+          // (global memory behind a scalar base, a 32-bit word index: one 16-byte load)
+          const __attribute__((address_space(1))) uint32_t *srcw = (const __attribute__((address_space(1))) uint32_t *)job.src;
+          const __attribute__((address_space(1))) uint32_t *pw = srcw + static_cast<uint32_t>(sy * words_row + s);
+          const uint32_t v[4] = {pw[0], pw[1], pw[2], pw[3]};
           uint32_t *dst = &s_srcw[r * (kPyrSWW + 1)];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
@@ -167,8 +169,9 @@ __global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const Pyr
       a23 = (a23 + half) >> 8;
       int acc[4] = {a01.x, a01.y, a23.x, a23.y};
       uint8_t *d = job.dst + static_cast<size_t>(oy) * job.dw + ox;
-      if (ox + 3 < job.dw && (reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
-        *reinterpret_cast<uint32_t *>(d) = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, a23), __builtin_bit_cast(uint32_t, a01), 0x06040200u);
+      if (ox + 3 < job.dw && (reinterpret_cast<uintptr_t>(job.dst) & 3u) == 0 && (job.dw & 3) == 0) {  // (ox is a multiple of 4)
+        __attribute__((address_space(1))) uint32_t *dstw = (__attribute__((address_space(1))) uint32_t *)job.dst;
+        dstw[static_cast<uint32_t>(oy * job.dw + ox) >> 2] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, a23), __builtin_bit_cast(uint32_t, a01), 0x06040200u);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; k++)
