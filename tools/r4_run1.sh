@@ -1,5 +1,10 @@
 set -u
 O=gpurun_out
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_tracker.py -x -q -m gpu -k "not other_forms" > $O/t_fast.log 2>&1; echo "tests rc=$?"; tail -2 $O/t_fast.log
-python tools/kernel_bench.py 256 10 > $O/kb_v.log 2>&1; echo "rc=$? $(grep -E '^  fast_cells|^  search_points|^  pyr_down|select_cells' $O/kb_v.log)"
-bash tools/r4_ab.sh "SDVL_FAST_PAIRS=1" 3 40
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$?"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "driver-style bench rc=$?"
+python -c "
+import json
+for f in ('$O/bench_default.json','$O/bench_driver.json'):
+    d=json.loads(open(f).read().strip().splitlines()[-1])
+    print(d['value'], d['steps'], d['ms_per_step'], d['value_host_fed'], d['value_sustained'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['valu']['path_insts_per_frame'], d['roofline']['valu']['path_frac'])
+"
