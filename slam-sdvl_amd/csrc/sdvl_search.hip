@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void search_prepare_kernel(const SearchReqDev *
     prep[ri] = search_prepare_one(rq, se3_identity(), se3_identity(), cam, prm);
     return;
   }
-  prep[ri] = search_prepare_one(rq, se3_from7(table[rq.cur].pose), se3_from7(table[rq.ref].pose), cam, prm);
+  prep[ri] = search_prepare_one(rq, se3_from7(table[rq.cur].pose), se3_from7(table[rq.ref].pose), cam, prm, &table[rq.cur].f);
 }
 
 // kStage: frames without corner bins get their corner list staged in LDS (16 KB per workgroup).  Launches whose frames all
@@ -286,8 +286,6 @@ constexpr int kStampRequests = 1 << 18;
 #define SS_FLUSH() do { } while (0)
 #endif
 
-// search regions of up to this many 32-px cells go through the corner bins (their corners: ~3.4 per cell); larger ones scan the whole list
-constexpr int kBinRegionCells = 320;
 
 template <bool kStage, int kW>
 __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_points_kernel(const SearchReqDev *__restrict__ reqs,
@@ -525,7 +523,42 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       const double vline = prv->vline, nx = prv->nx, ny = prv->ny;
       line_ok = vline > 0.0 && nx == nx && ny == ny;
     }
-    if (binned && line_ok) {
+    // one round of the binned scan: the entries of (at most four) cell rows as ONE lane space — a search region of a few cells holds
+    // ~15 corners, so a round per row ran the whole range test two or three times for a quarter of a wave each.  Row r contributes
+    // entries [e0[r], e0[r] + pre[r + 1] - pre[r]) (cells of a row are consecutive); lane index i maps to the row whose prefix range holds it.
+    const auto scan_rows = [&](const int (&e0)[4], const int (&pre)[5]) {
+      const int total = pre[4];
+      for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        const bool have = i < total;
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 4; q++) r += (i >= pre[q]) ? 1 : 0;
+        const int e = i + (r == 0 ? e0[0] - pre[0] : r == 1 ? e0[1] - pre[1] : r == 2 ? e0[2] - pre[2] : e0[3] - pre[3]);
+        uint2 ent = make_uint2(0u, 0u);
+        if (have) {  // (a global load: the entry as one 64-bit scalar type — vector classes do not copy out of an address space)
+          const unsigned long long e64 = ((const __attribute__((address_space(1))) unsigned long long *)cf.bin_entries)[static_cast<uint32_t>(e)];
+          ent = make_uint2(static_cast<uint32_t>(e64), static_cast<uint32_t>(e64 >> 32));
+        }
+        SDVL_STAT(3, 1);
+        scan_round(have, ent.x, static_cast<int>(ent.y));
+      }
+    };
+    // The request's lane of the prepare step has looked the bins up already (SearchPrep::bin_mode): nothing in range, or up to four cell rows.
+    int row_e0[4] = {0, 0, 0, 0}, row_pre[5] = {0, 0, 0, 0, 0};
+    int ry = 0, ry_end = -1, box_cx0 = 0, box_cx1 = 0;  // cell rows ry .. ry_end still to look up here (none when the prepare step did it)
+    bool rows_ready = false;
+    if (binned && pr.bin_mode == 1) {
+      scanned = true;
+    } else if (binned && pr.bin_mode == 2) {
+      scanned = true;
+      rows_ready = true;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        row_e0[r] = pr.bin_e0[r];
+        row_pre[r + 1] = pr.bin_pre[r];
+      }
+    } else if (binned && line_ok) {
       double bx0, bx1, by0, by1;
       if (rq.fixed) {
         bx0 = rq.px0[0] - range; bx1 = rq.px0[0] + range; by0 = rq.px0[1] - range; by1 = rq.px0[1] + range;
@@ -543,42 +576,29 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(8, 8)))
           scanned = true;  // the region lies outside the image: no corner can be in range
         } else if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= kBinRegionCells) {  // (larger regions: the full scan below)
           scanned = true;
-          // four cell rows at a time (a region of the metric configuration has at most four; configuration C's span up to a dozen)
-          for (int ry = cy0; ry <= cy1; ry += 4) {
-            const int nrows = min(4, cy1 - ry + 1);
-            // the entries of the (at most four) cell rows as ONE lane space: a search region of a few cells holds ~15 corners, so a
-            // round per row ran the whole range test two or three times for a quarter of a wave each.  Row r contributes entries
-            // [e0[r], e1[r]) (cells of a row are consecutive); lane index i maps to the row whose prefix range holds it.
-            int e0[4], pre[5];
-            pre[0] = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int cyi = min(ry + r, cy1);
-              const __attribute__((address_space(1))) int *bs = (const __attribute__((address_space(1))) int *)cf.bin_start;  // global, not flat, loads
-              const uint32_t brow = static_cast<uint32_t>(cyi * gw);
-              const int a = bs[brow + static_cast<uint32_t>(cx0)], b = bs[brow + static_cast<uint32_t>(cx1 + 1)];
-              e0[r] = a;
-              pre[r + 1] = pre[r] + (r < nrows ? b - a : 0);
-            }
-            const int total = pre[4];
-            for (int base = 0; base < total; base += 64) {
-              const int i = base + lane;
-              const bool have = i < total;
-              int r = 0;
-#pragma unroll
-              for (int q = 1; q < 4; q++) r += (i >= pre[q]) ? 1 : 0;
-              const int e = i + (r == 0 ? e0[0] - pre[0] : r == 1 ? e0[1] - pre[1] : r == 2 ? e0[2] - pre[2] : e0[3] - pre[3]);
-              uint2 ent = make_uint2(0u, 0u);
-              if (have) {  // (a global load: the entry as one 64-bit scalar type — vector classes do not copy out of an address space)
-                const unsigned long long e64 = ((const __attribute__((address_space(1))) unsigned long long *)cf.bin_entries)[static_cast<uint32_t>(e)];
-                ent = make_uint2(static_cast<uint32_t>(e64), static_cast<uint32_t>(e64 >> 32));
-              }
-              SDVL_STAT(3, 1);
-              scan_round(have, ent.x, static_cast<int>(ent.y));
-            }
-          }
+          ry = cy0; ry_end = cy1; box_cx0 = cx0; box_cx1 = cx1;
         }
       }
+    }
+    // four cell rows at a time (a region of the metric configuration has at most four; configuration C's span up to a dozen)
+    while (rows_ready || ry <= ry_end) {
+      if (!rows_ready) {
+        const int gw = cf.bin_gw;
+        const int nrows = min(4, ry_end - ry + 1);
+        row_pre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int cyi = min(ry + r, ry_end);
+          const __attribute__((address_space(1))) int *bs = (const __attribute__((address_space(1))) int *)cf.bin_start;  // global, not flat, loads
+          const uint32_t brow = static_cast<uint32_t>(cyi * gw);
+          const int a = bs[brow + static_cast<uint32_t>(box_cx0)], b = bs[brow + static_cast<uint32_t>(box_cx1 + 1)];
+          row_e0[r] = a;
+          row_pre[r + 1] = row_pre[r] + (r < nrows ? b - a : 0);
+        }
+        ry += 4;
+      }
+      scan_rows(row_e0, row_pre);
+      if (rows_ready) break;
     }
     SDVL_STAT(0, 1);
     SDVL_STAT(scanned ? 1 : 2, 1);

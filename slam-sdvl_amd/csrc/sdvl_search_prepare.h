@@ -9,10 +9,14 @@
 
 #include "sdvl_search_types.h"
 
+// cf: the current frame's view when its corner bins are final at this point of the stream (null: the wave kernel looks them up)
 __device__ __forceinline__ SearchPrep search_prepare_one(const SearchReqDev &rq, const sdvl::Rigid &cur_pose, const sdvl::Rigid &ref_pose,
-                                                         const sdvl::Cam &cam, const sdvl_search_params &prm) {
+                                                         const sdvl::Cam &cam, const sdvl_search_params &prm, const SearchFrame *cf = nullptr) {
   using namespace sdvl;
   SearchPrep out;
+  out.bin_mode = 0;
+  out.bin_pad_ = 0;
+  for (int r = 0; r < 4; r++) out.bin_e0[r] = out.bin_pre[r] = 0;
   out.alive = 0;
   out.slevel = -1;
   out.pxa[0] = out.pxa[1] = out.pxb[0] = out.pxb[1] = 0.0;
@@ -97,6 +101,37 @@ __device__ __forceinline__ SearchPrep search_prepare_one(const SearchReqDev &rq,
       out.xdiff = pxb.x - pxa.x;
       out.ydiff = pxb.y - pxa.y;
       out.vline = (out.xdiff) * (out.xdiff) + (out.ydiff) * (out.ydiff);
+    }
+  }
+  // ---- the cells of the corner bins the search region touches (the statements of search_points_kernel's own look-up, same doubles)
+  if (cf && cf->bin_start != nullptr) {
+    const bool line_ok = rq.fixed || (out.vline > 0.0 && out.nx == out.nx && out.ny == out.ny);
+    if (line_ok) {
+      const double range = out.range;
+      double bx0, bx1, by0, by1;
+      if (rq.fixed) {
+        bx0 = rq.px0[0] - range; bx1 = rq.px0[0] + range; by0 = rq.px0[1] - range; by1 = rq.px0[1] + range;
+      } else {
+        bx0 = fmin(pxa.x, pxb.x) - range; bx1 = fmax(pxa.x, pxb.x) + range; by0 = fmin(pxa.y, pxb.y) - range; by1 = fmax(pxa.y, pxb.y) + range;
+      }
+      if (bx0 > -1.0e6 && bx1 < 1.0e6 && by0 > -1.0e6 && by1 < 1.0e6) {
+        const int gw = cf->bin_gw, gh = cf->bin_cells / cf->bin_gw;
+        const int cx0 = max(0, static_cast<int>(floor(bx0)) >> 5), cx1 = min(gw - 1, static_cast<int>(floor(bx1)) >> 5);
+        const int cy0 = max(0, static_cast<int>(floor(by0)) >> 5), cy1 = min(gh - 1, static_cast<int>(floor(by1)) >> 5);
+        if (cx1 < cx0 || cy1 < cy0) {
+          out.bin_mode = 1;
+        } else if (cy1 - cy0 < 4 && (cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= kBinRegionCells) {
+          out.bin_mode = 2;
+          int acc = 0;
+          for (int r = 0; r < 4; r++) {
+            const int cyi = min(cy0 + r, cy1);
+            const int a = cf->bin_start[cyi * gw + cx0], b = cf->bin_start[cyi * gw + cx1 + 1];
+            out.bin_e0[r] = a;
+            acc += (cy0 + r <= cy1) ? b - a : 0;
+            out.bin_pre[r] = acc;
+          }
+        }
+      }
     }
   }
   return out;

@@ -52,7 +52,16 @@ struct SearchPrep {
   // wave-uniform constants of GetCornersInRange (matcher.cc:139-148, 92-94), computed once by the request's lane; the wave
   // kernel reads the record with scalar loads, so they live in SGPRs instead of 64 copies in VGPRs
   double nx, ny, normdist, xdiff, ydiff, vline, range, range2;
+  // the corner bins the search region touches, looked up by the request's lane as well (round 4: in the wave kernel the box, its cell
+  // range and the eight bin offsets were ~100 vector instructions every lane repeated for itself).  bin_mode 0: not prepared (no bins,
+  // degenerate epipolar line, a region of more than four cell rows or kBinRegionCells cells: the wave kernel decides as before);
+  // 1: the region lies outside the image; 2: cell rows 0..3 contribute entries [bin_e0[r], bin_e0[r] + bin_pre[r + 1] - bin_pre[r])
+  int bin_mode, bin_pad_;
+  int bin_e0[4], bin_pre[4];  // bin_pre[r] = entries of the rows before r + 1 (bin_pre[3] = all of them)
 };
+
+// search regions of up to this many 32-px cells go through the corner bins (their corners: ~3.4 per cell); larger ones scan the whole list
+constexpr int kBinRegionCells = 320;
 
 struct ChainFrameDev {
   int cand_begin, cand_end;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kProjThreads) void track_project_kernel(const Track
     reqs[base + r] = rq;
     // phase 0 of SearchPoint for the request this lane has just assembled (search_prepare_kernel's work, sdvl_search_prepare.h);
     // the reference frame's pose comes out of the registry, the current frame's is the one this workgroup has just computed
-    if (prep) prep[base + r] = search_prepare_one(rq, pose, se3_from7(registry[p.ref].pose), cam, sprm);
+    if (prep) prep[base + r] = search_prepare_one(rq, pose, se3_from7(registry[p.ref].pose), cam, sprm, &jb.cur);  // (the bins were filled earlier in this stream)
     double *rp = req_point + 3 * static_cast<size_t>(base + r);
     rp[0] = p.P[0]; rp[1] = p.P[1]; rp[2] = p.P[2];
     cand_feat[base + r] = i;
