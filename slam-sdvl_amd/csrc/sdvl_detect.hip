@@ -675,7 +675,8 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
   // along as they are (no decision reads them: every ring lies within 3 px of a tested pixel, inside the ROI).  The span of 36
   // bytes stays inside the row, or the rows below the ROI take the overrun of its last row.
   const int H = job.lh[l];
-  const bool aligned_rows = (reinterpret_cast<uintptr_t>(job.level[l]) & 3u) == 0 && (W & 3) == 0 && ((x0 & ~3) + 36 <= W || y0 + rh < H);
+  // (W >= 40: an overrun of the span stays within the ONE row that is known to lie below)
+  const bool aligned_rows = (reinterpret_cast<uintptr_t>(job.level[l]) & 3u) == 0 && (W & 3) == 0 && W >= 40 && ((x0 & ~3) + 36 <= W || y0 + rh < H);
   if (aligned_rows) {
     if (row < rh) {
       const int shift = x0 & 3;

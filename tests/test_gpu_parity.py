@@ -50,18 +50,18 @@ def test_pyramid_bit_exact(ctx, orc, shape):
 
 
 # ------------------------------------------------------------------------------------------------ K2
-def check_fast(ctx, sdvl, orc, imgs, margin=19, thr=10, cell=32):
+def check_fast(ctx, sdvl, orc, imgs, margin=19, thr=10, cell=32, levels=5):
     dp = sdvl.default_detect_params()
     dp.margin, dp.fast_threshold, dp.cell_size = margin, thr, cell
     orc.params.fast_threshold = thr
     orc.params.cell_size = cell
     orc.params.use_orb = 1 if margin == 19 else 0
     try:
-        fr = [ctx.frame(im) for im in imgs]
+        fr = [ctx.frame(im, levels=levels) for im in imgs]
         got, cpl = ctx.fast_cells(fr, dp, cap=60000)
         total = 0
         for f, im, (kps, offs) in zip(fr, imgs, got):
-            pyr = orc.pyramid(im, 5)
+            pyr = orc.pyramid(im, levels)
             base = 0
             for l in range(3):
                 wk, woffs, _ = orc.fast_cells(pyr[l], cap=400000)
@@ -107,6 +107,17 @@ def test_fast_cells_sparse_corners_and_other_cell_sizes(ctx, sdvl, orc):
     for cell in (30, 31):      # what the per-frame cell-list capacity admits at 640x480 besides 32 (smaller cells: SDVL_ERR_CAPACITY)
         assert check_fast(ctx, sdvl, orc, [mixed], cell=cell) > 1000, cell
         assert check_fast(ctx, sdvl, orc, [dense], margin=5, thr=30, cell=cell) > 1000, cell
+
+
+@pytest.mark.parametrize("shape", [(112, 144), (120, 172), (190, 250), (144, 176)])
+def test_fast_cells_small_and_unaligned_levels(ctx, sdvl, orc, shape):
+    """levels whose rows are not word-aligned (250 px; 172 -> 86 -> 43), narrower than the 36-byte span of a lane's tile load (144 -> 72 -> 36)
+    or both: the tile comes in byte by byte there instead of as one 16-byte load per lane — same corners"""
+    h, w = shape
+    dense = rand_img(21 + w, h, w)
+    sparse = sparse_corner_image(5, 480, 640)[:h, :w].copy()
+    assert check_fast(ctx, sdvl, orc, [dense, sparse], margin=5, thr=20, levels=3) > 200
+    assert check_fast(ctx, sdvl, orc, [dense], thr=35, levels=3) > 50   # the ORB margin (19): ROIs that start three bytes off a word
 
 
 def test_fast_cells_bit_exact_synthetic(ctx, sdvl, orc, synth):
