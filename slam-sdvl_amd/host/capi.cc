@@ -226,6 +226,22 @@ int sdvlh_batch_step_device(void *bp, const void *const *dev_imgs, int stride, s
   return step(b, v, out);
 }
 
+// Look-ahead (SDVLBatch::SetNextImages): the device images the NEXT sdvlh_batch_step_device call will be given; their pyramids and
+// corner detection are queued behind the coming step's search / pose chain.  They must stay valid until that call.
+int sdvlh_batch_set_next_device(void *bp, const void *const *dev_imgs, int stride) {
+  Batch *b = static_cast<Batch *>(bp);
+  try {
+    std::vector<Image> v;
+    if (dev_imgs)
+      for (size_t i = 0; i < b->trackers.size(); i++) v.push_back(Image::WrapDevice(dev_imgs[i], b->w, b->h, stride, true));
+    b->batch->SetNextImages(v);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // the same for images in a buffer the caller will overwrite (an input ring): every frame copies its image into its own level 0
 int sdvlh_batch_step_device_copy(void *bp, const void *const *dev_imgs, int stride, sdvlh_frame_stats *out) {
   Batch *b = static_cast<Batch *>(bp);
@@ -427,6 +443,9 @@ struct Farm {
                       : sdvlh_batch_step_device_transient(batches[g], dst.data(), stride, out + off);
     }
     if (host_input) return sdvlh_batch_step_host(batches[g], reinterpret_cast<const uint8_t *const *>(dev_frames + off), stride, out + off);
+    // frames resident in HBM: the group knows its next images — their pyramids and detection are queued a step ahead (SDVL_NO_LOOKAHEAD=1: A/B)
+    static const bool lookahead = getenv("SDVL_NO_LOOKAHEAD") == nullptr;
+    if (lookahead && s + 1 < n_steps && sdvlh_batch_set_next_device(batches[g], dev_frames + off + total, stride) != 0) return -1;
     return sdvlh_batch_step_device(batches[g], dev_frames + off, stride, out + off);
   }
 

@@ -197,6 +197,12 @@ class SDVLBatch {
   ~SDVLBatch();
   // imgs[i] feeds tracker i; stats[i] receives its FrameStats
   void HandleFrames(const std::vector<Image> &imgs, FrameStats *stats);
+  // Round 4: a caller that already holds the images of the NEXT step (a sequence from disk, frames resident in HBM) names them before
+  // the current step: their pyramids and corner detection — all that depends on the image alone, 45 % of a step's vector instructions —
+  // are queued right behind the current step's search / pose chain and run while the host waits for that chain and does its keyframe
+  // bookkeeping; the next HandleFrames with these images picks the frames up.  Same kernels on the same inputs: same results.
+  // The images must stay valid until that call (device images are aliased).  An unused look-ahead is dropped.
+  void SetNextImages(const std::vector<Image> &next);
   // pose stage (RANSAC + refinement) on the device (default) or with the host implementation; process-wide switch,
   // also set by SDVL_POSE_HOST=1 in the environment.  Both produce the same decisions (tests/test_gpu_tracker.py).
   static void SetDevicePose(bool on);
@@ -223,6 +229,9 @@ class SDVLBatch {
   std::vector<int32_t> chain_cand_req_, chain_cand_first_, chain_rand_;
   // ---- device-resident tables
   bool HandleFramesTracked(const std::vector<Image> &imgs, FrameStats *stats);  // false: not applicable this step
+  std::vector<Image> next_imgs_;                        // SetNextImages: what the next step will be given
+  std::vector<std::shared_ptr<Frame>> ahead_frames_;    // their frames, pyramids and detection queued
+  std::vector<const void *> ahead_src_;                 // the images they were made from
   void HandleFramesGeneric(const std::vector<Image> &imgs, FrameStats *stats);
   bool BuildTable(SDVL &t);
   bool AppendSeeds(SDVL &t, const std::shared_ptr<Frame> &kf);  // rows of the points seeded on kf -> track_.up_points / up_feats

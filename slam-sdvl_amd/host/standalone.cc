@@ -487,6 +487,8 @@ void SDVLBatch::ParallelFor(int n, const std::function<void(int)> &fn) {
 }
 
 static int g_device_pose = -1;  // -1: not decided yet (environment)
+void SDVLBatch::SetNextImages(const vector<Image> &next) { next_imgs_ = next; }
+
 void SDVLBatch::SetDevicePose(bool on) { g_device_pose = on ? 1 : 0; }
 bool SDVLBatch::DevicePose() {
   if (g_device_pose < 0) {
@@ -738,7 +740,19 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
   // ---- stage 0: Frame construction, sdvl.cc:59 (pyramids now, detection behind the alignment)
   vector<shared_ptr<Frame>> frames;
   const std::function<void(int, std::function<void(int)>)> pfor = [this](int n, std::function<void(int)> fn) { ParallelFor(n, fn); };
-  Frame::CreateBatch(&camera, &trk_[0]->orb_detector_, imgs, false, Config::NumFeatures(), &frames, &pfor);
+  // the frames of a look-ahead (SetNextImages before the previous step): pyramids and detection are queued already
+  bool detected_ahead = false;
+  if (!ahead_frames_.empty()) {
+    bool same = static_cast<int>(ahead_frames_.size()) == B && static_cast<int>(imgs.size()) == B;
+    for (int i = 0; same && i < B; i++) same = imgs[i].dev_src != nullptr && imgs[i].dev_src == ahead_src_[i];
+    if (same) {
+      frames.swap(ahead_frames_);
+      detected_ahead = true;
+    }
+    ahead_frames_.clear();
+    ahead_src_.clear();
+  }
+  if (!detected_ahead) Frame::CreateBatch(&camera, &trk_[0]->orb_detector_, imgs, false, Config::NumFeatures(), &frames, &pfor);
   vector<int> run;
   clk.reset(new StageClock(ST_PRELUDE));
   for (int i = 0; i < B; i++) {
@@ -803,9 +817,21 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     prm.pad_ = 0;
     const sdvl_camera cam = camera.abi();
     dev_->Check(sdvl_track_align(dev_->ctx(), track_, R, tr_jobs_.data(), tr_rank_.data(), tr_rand_.data(), &cam, &prm), "sdvl_track_align");
-    Frame::DetectBatch(frames, Config::NumFeatures());  // FAST + selection run behind the alignment
+    if (!detected_ahead) Frame::DetectBatch(frames, Config::NumFeatures());  // FAST + selection run behind the alignment
     clk.reset(new StageClock(ST_SEARCH));
     dev_->Check(sdvl_track_search(dev_->ctx(), track_), "sdvl_track_search");
+    // the look-ahead: the next step's pyramids and detection go behind this step's chain, ahead of its keyframe kernels
+    if (!next_imgs_.empty() && R == B && static_cast<int>(next_imgs_.size()) == B) {
+      bool device_images = true;
+      for (const Image &im : next_imgs_) device_images = device_images && im.dev_src != nullptr && !im.transient;
+      if (device_images) {
+        Frame::CreateBatch(&camera, &trk_[0]->orb_detector_, next_imgs_, false, Config::NumFeatures(), &ahead_frames_, &pfor);
+        Frame::DetectBatch(ahead_frames_, Config::NumFeatures());
+        ahead_src_.clear();
+        for (const Image &im : next_imgs_) ahead_src_.push_back(im.dev_src);
+      }
+    }
+    next_imgs_.clear();
     tr_res_.resize(R);
     dev_->Check(sdvl_track_collect(dev_->ctx(), track_, R, tr_res_.data()), "sdvl_track_collect");
 
@@ -919,7 +945,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     });
   }
   clk.reset();
-  if (R == 0) Frame::DetectBatch(frames, Config::NumFeatures());  // bootstrap-only step: the new keyframes still need their corners
+  if (R == 0 && !detected_ahead) Frame::DetectBatch(frames, Config::NumFeatures());  // bootstrap-only step: the new keyframes still need their corners
   // a mapper that looks at the frames it was given (MapperMap: scene depth of every frame, feature lists of keyframes)
   // materialises them on demand; a keyframe's table is rebuilt afterwards in any case
   EpilogueAndMapper(frames, stats, &kfs, &kf_owner, filter_begun);
@@ -972,6 +998,9 @@ void SDVLBatch::HandleFrames(const vector<Image> &imgs, FrameStats *stats) {
   }
   const vector<Image> &in = owned.empty() ? imgs : owned;
   if (!HandleFramesTracked(in, stats)) {
+    next_imgs_.clear();  // the host-driven path takes no look-ahead, and one that was queued is dropped
+    ahead_frames_.clear();
+    ahead_src_.clear();
     SyncHostState();  // Feature lists and Point counters catch up with the device; the tables are rebuilt when tracking returns
     HandleFramesGeneric(in, stats);
   }

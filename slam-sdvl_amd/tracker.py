@@ -35,6 +35,7 @@ def load_host_library():
         lib.sdvlh_batch_step_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.sdvlh_batch_step_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.sdvlh_batch_step_device_transient.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.sdvlh_batch_set_next_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.sdvlh_config_set.argtypes = [C.c_char_p, C.c_double]
         _lib = lib
     return _lib
@@ -146,6 +147,13 @@ class TrackerBatch:
         if self.lib.sdvlh_batch_step_device(self.h, ptrs, self.w, self._stats) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
         return self._stats
+
+    def set_next_device(self, dev_ptrs):
+        """look-ahead: the device images the NEXT step_device call will be given (None: none); their pyramids and corner detection
+        are queued behind the coming step's search / pose chain (SDVLBatch::SetNextImages)"""
+        ptrs = (C.c_void_p * self.B)(*[int(p) for p in dev_ptrs]) if dev_ptrs is not None else None
+        if self.lib.sdvlh_batch_set_next_device(self.h, ptrs, self.w) != 0:
+            raise RuntimeError(self.lib.sdvlh_last_error().decode())
 
     def step_device_transient(self, dev_ptrs):
         """frames in HBM that stay valid for THIS step only (a slot of an input ring): aliased while tracked, frames that become

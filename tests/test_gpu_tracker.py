@@ -247,6 +247,48 @@ def test_transient_ring_images_equal_resident_images(trk, orc, synth):
     assert all(r[1] == 0 and r[4] >= 100 for r in resident[n:])
 
 
+def test_look_ahead_of_the_next_images_changes_nothing(trk, orc, synth):
+    """SDVLBatch::SetNextImages: the next step's pyramids and corner detection queued behind the current step's chain (what the farm
+    does for frames resident in HBM) — the per-frame results equal those of steps that build their frames themselves, bit for bit;
+    a look-ahead of OTHER images than the step then brings is dropped, one announced and never used is dropped too"""
+    import importlib
+    sdvl = importlib.import_module("slam-sdvl_amd")
+    import bench as B
+    n, n_steps = 4, 12
+    fb = 640 * 480
+    trk.configure()
+
+    def run(mode):
+        dev = trk.HostDevice(0)
+        batch = trk.TrackerBatch(dev, n, 640, 480, TUM_CAM)
+        ctx = B.CtxView(sdvl, dev.ctx_handle())
+        buf = ctx.malloc(n * n_steps * fb)
+        for k in range(n_steps):
+            views = [B.make_view(sdvl, trajectory_pose(orc, k, XI * (1.0 + 0.1 * i)), 20260001 + i, k) for i in range(n)]
+            ctx.render(views, buf + k * n * fb)
+        ptrs = lambda k: [buf + (k * n + i) * fb for i in range(n)]
+        out = []
+        for k in range(n_steps):
+            if k + 1 < n_steps:
+                if mode == "ahead":
+                    batch.set_next_device(ptrs(k + 1))
+                elif mode == "wrong":     # every third step names the images of the step after next: not what comes
+                    batch.set_next_device(ptrs(min(k + 2, n_steps - 1)) if k % 3 == 0 else ptrs(k + 1))
+            elif mode != "plain":
+                batch.set_next_device(ptrs(0))   # announced, never used: dropped when the batch goes
+            st = batch.step_device(ptrs(k))
+            out += [(s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas, tuple(s.pose[:])) for s in st]
+        batch.close()
+        dev.close()
+        return out
+
+    plain = run("plain")
+    assert run("ahead") == plain
+    assert run("wrong") == plain
+    assert sum(r[2] for r in plain[n:]) >= n           # keyframes were created after the bootstrap
+    assert all(r[1] == 0 and r[4] >= 100 for r in plain[n:])
+
+
 def test_transient_images_with_min_align_level_0_on_a_one_slot_ring(trk, orc, synth):
     """SDVL.min_alignLevel 0 is legal (config.cc:146): the next step's image alignment then reads last_frame's LEVEL 0
     (image_align.cc:212).  With transient images that level aliases a ring slot; here the ring has ONE slot, rewritten before
