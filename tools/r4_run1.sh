@@ -1,3 +1,5 @@
 set -u
 O=gpurun_out
-python -m pytest tests/test_gpu_tracker.py -x -q -m gpu -k "look_ahead or transient" > $O/t_fast.log 2>&1; echo "tests rc=$?"; tail -5 $O/t_fast.log
+SDVL_PROFILE=1 python bench.py --steps 60 --warmup 5 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/prof.json 2> $O/prof.err; echo rc=$?
+grep -n "^----" $O/prof.err | tail -3
+awk '/^---- charged/{c++} c>=2' $O/prof.err | head -75
