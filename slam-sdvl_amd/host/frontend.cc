@@ -59,9 +59,20 @@ ChunkPool::~ChunkPool() {
 }
 void ChunkPool::Map(size_t bytes) {
   bytes = (bytes + kChunk - 1) / kChunk * kChunk;
-  void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-  if (p == MAP_FAILED) throw std::bad_alloc();
-  regions_.push_back({p, bytes});
+  // Round 4: the region starts on a 2-MB boundary and asks for transparent huge pages (the boxes run THP in `madvise` mode): the
+  // arenas of the keyframes are memory that is written once and kept, i.e. first-touch faults — one per 2 MB instead of one per 4 KB.
+  // SDVL_NO_HUGEPAGE=1: plain pages (A/B).
+  static const bool huge = std::getenv("SDVL_NO_HUGEPAGE") == nullptr;
+  constexpr size_t kHuge = 2u << 20;
+  const size_t span = huge ? bytes + kHuge : bytes;
+  void *raw = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (raw == MAP_FAILED) throw std::bad_alloc();
+  regions_.push_back({raw, span});
+  void *p = raw;
+  if (huge) {
+    p = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(raw) + kHuge - 1) / kHuge * kHuge);
+    (void)madvise(p, bytes / kHuge * kHuge, MADV_HUGEPAGE);  // advice only: plain pages if the kernel declines
+  }
   char *c = static_cast<char *>(p);
   for (size_t off = bytes; off >= kChunk; off -= kChunk) free_.push_back(c + off - kChunk);  // lowest address handed out first
 }
