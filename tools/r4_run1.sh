@@ -1,11 +1,7 @@
 set -u
 O=gpurun_out
-python -m pytest tests/test_gpu_tracker.py tests/test_gpu_long.py -x -q -m gpu > $O/t_fast.log 2>&1; echo "tests rc=$?"; tail -3 $O/t_fast.log
-python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$?"
-python -c "
-import json
-d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1])
-print(d['value'], d['steps'], d['ms_per_step'], d['value_host_fed'], d['value_sustained'], d['roofline']['kernel'], d['roofline']['frac'])
-print({k:v for k,v in d['sustained'].items() if k in ('host_rss_gb','keyframes_per_sequence','hbm_used_gb','value')})
-"
-grep -E "CPUs busy|page faults" $O/bench_default.err | tail -4
+for cfg in "512 8" "512 16" "1024 16" "1024 8" "2048 16"; do
+set -- $cfg
+r=$(timeout -k 10 300 python bench.py --workload S-C --seqs $1 --groups $2 --steps 30 --warmup 4 --cpu-frames 0 --host-steps 0 --sustained-frames 0 2>$O/ab_a.err | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%.1f k  %.2f ms/step' % (d['value']/1e3, d['ms_per_step']))")
+echo "S-C seqs $1 groups $2: $r  $(grep -o '= [0-9.]* CPUs busy' $O/ab_a.err | tail -1)"
+done
