@@ -807,17 +807,24 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
           const auto below = [](unsigned long long m) {
             return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0)));
           };
-          int pos = base + below(m0) + below(m1) + below(m2) + below(m3);
+          const int pos0 = base + below(m0) + below(m1) + below(m2) + below(m3);
           const h2 a = as_h2(own_a), b = as_h2(own_b);
           const uint32_t kp = xy[ps];
-          if (ok0 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = kp | (static_cast<uint32_t>(static_cast<uint16_t>(a.x)) << 24);
-          pos += static_cast<int>(lo_a);
-          if (ok1 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (kp + 1u) | (static_cast<uint32_t>(static_cast<uint16_t>(a.y)) << 24);
-          pos += static_cast<int>(da >> 31);
-          if (ok2 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (kp + 2u) | (static_cast<uint32_t>(static_cast<uint16_t>(b.x)) << 24);
-          pos += static_cast<int>(lo_b);
-          if (ok3 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (kp + 3u) | (static_cast<uint32_t>(static_cast<uint16_t>(b.y)) << 24);
-          base += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+          const int after = base + __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+          // (a cell rarely fills its list: one scalar test for the pass instead of a vector compare per store)
+          const auto emit = [&](auto checked) {
+            int pos = pos0;
+            if (ok0 && (!decltype(checked)::value || pos < SDVL_CELL_KP_CAP)) *fc_slot(gout, pos) = kp | (static_cast<uint32_t>(static_cast<uint16_t>(a.x)) << 24);
+            pos += static_cast<int>(lo_a);
+            if (ok1 && (!decltype(checked)::value || pos < SDVL_CELL_KP_CAP)) *fc_slot(gout, pos) = (kp + 1u) | (static_cast<uint32_t>(static_cast<uint16_t>(a.y)) << 24);
+            pos += static_cast<int>(da >> 31);
+            if (ok2 && (!decltype(checked)::value || pos < SDVL_CELL_KP_CAP)) *fc_slot(gout, pos) = (kp + 2u) | (static_cast<uint32_t>(static_cast<uint16_t>(b.x)) << 24);
+            pos += static_cast<int>(lo_b);
+            if (ok3 && (!decltype(checked)::value || pos < SDVL_CELL_KP_CAP)) *fc_slot(gout, pos) = (kp + 3u) | (static_cast<uint32_t>(static_cast<uint16_t>(b.y)) << 24);
+          };
+          if (after <= SDVL_CELL_KP_CAP) emit(std::false_type{});
+          else emit(std::true_type{});
+          base = after;
         }
       }
       if (lane == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
