@@ -1,9 +1,13 @@
 set -u
 O=gpurun_out
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fast_cells or detect or corner" > $O/t_fast.log 2>&1; echo "tests rc=$?"; tail -2 $O/t_fast.log
-python tools/kernel_bench.py 256 10 > $O/kb_v.log 2>&1; echo "rc=$? $(grep -E '^  fast_cells' $O/kb_v.log)"
-for cfg in "512 8" "512 16" "1024 16" "1024 8"; do
-set -- $cfg
-r=$(timeout -k 10 300 python bench.py --workload S-C --seqs $1 --groups $2 --steps 30 --warmup 4 --cpu-frames 0 --host-steps 0 --sustained-frames 0 2>$O/ab_a.err | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%.1f k  %.2f ms/step' % (d['value']/1e3, d['ms_per_step']))")
-echo "S-C seqs $1 groups $2: $r  $(grep -o '= [0-9.]* CPUs busy' $O/ab_a.err | tail -1)"
-done
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$?"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "driver-style bench rc=$?"
+python -c "
+import json
+for f in ('$O/bench_default.json','$O/bench_driver.json'):
+    d=json.loads(open(f).read().strip().splitlines()[-1])
+    v=d['roofline']['valu']
+    print(d['value'], d['steps'], d['ms_per_step'], d['value_host_fed'], d['value_sustained'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['avg_launch_us'], v['path_insts_per_frame'], v['path_frac'], v['kernel_frac'])
+    print({k: v['insts_per_frame'][k] for k in list(v['insts_per_frame'])[:8]})
+"
+grep -E "CPUs busy|page faults" $O/bench_default.err | tail -2
