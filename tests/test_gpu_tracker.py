@@ -247,7 +247,8 @@ def test_transient_ring_images_equal_resident_images(trk, orc, synth):
     assert all(r[1] == 0 and r[4] >= 100 for r in resident[n:])
 
 
-def test_look_ahead_of_the_next_images_changes_nothing(trk, orc, synth):
+@pytest.mark.parametrize("mapper", [False, True])
+def test_look_ahead_of_the_next_images_changes_nothing(trk, orc, synth, mapper):
     """SDVLBatch::SetNextImages: the next step's pyramids and corner detection queued behind the current step's chain (what the farm
     does for frames resident in HBM) — the per-frame results equal those of steps that build their frames themselves, bit for bit;
     a look-ahead of OTHER images than the step then brings is dropped, one announced and never used is dropped too"""
@@ -260,7 +261,11 @@ def test_look_ahead_of_the_next_images_changes_nothing(trk, orc, synth):
 
     def run(mode):
         dev = trk.HostDevice(0)
-        batch = trk.TrackerBatch(dev, n, 640, 480, TUM_CAM)
+        trk.set_mapper(mapper)   # True: the reference's mapper in every step (its searches and the depth filter queue behind the look-ahead)
+        try:
+            batch = trk.TrackerBatch(dev, n, 640, 480, TUM_CAM)
+        finally:
+            trk.set_mapper(False)
         ctx = B.CtxView(sdvl, dev.ctx_handle())
         buf = ctx.malloc(n * n_steps * fb)
         for k in range(n_steps):
