@@ -41,10 +41,18 @@ WORKLOADS = {
     # seqs: tried in this order, the first whose resident input frames + keyframe pool fit the GPU is used (with the device-
     # resident tracking tables the kernels are the limit, and 256 sequences per launch amortise their latency better than 128)
     "S-A": dict(w=640, h=480, cam=[517.3, 516.5, 318.6, 255.3], seqs=[4096, 3072, 2048], over={}, label="~200 feats", cpu_frames=300),
+    # SURVEY §8(d) S-B / BASELINE config 4: EuRoC MH_01's geometry (config/config_euroc.cfg:9-14,42: 752x480, its intrinsics,
+    # min_matches 5), four independent 300-frame chunks with seeds 20260010..13.  On one GPU the sequences follow the chunks round-robin
+    # (sequence g: chunk g mod 4); with `--gpus 4` every rank tracks ONE chunk (shard.chunk_for_sequence)
+    "S-B": dict(w=752, h=480, cam=[458.654, 457.296, 367.215, 248.375], seqs=[3072, 2048, 1024], over={"SDVL.min_matches": 5}, label="~200 feats",
+                cpu_frames=300, chunks=4, seed0=20260010),
     "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=[64], label="~1000 feats", cpu_frames=60,
                 over={"SDVL.num_features": 4000, "SDVL.max_matches": 1000}),
 }
 XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])
+TEXTURES = {"plane": 0, "camera": 1}   # csrc/sdvl_synth.h: SDVL_TEXTURE_PLANE_NOISE (rounds 1-4: a FAST corner on every second pixel) / SDVL_TEXTURE_CAMERA
+TEXTURE = 0
+SEQ_SEED = None     # global sequence index -> texture seed (main() sets it from the workload)
 
 
 def quat_to_R(q):
@@ -77,7 +85,7 @@ def make_view(pkg, T, seed, frame_id):
     for i in range(3):
         v.t[i] = float(T[4 + i])
     v.plane[0], v.plane[1], v.plane[2], v.plane[3] = 0.0, 0.0, 1.0, 2.0
-    v.seed, v.frame_id = seed, frame_id
+    v.seed, v.frame_id, v.texture = seed, frame_id, TEXTURE
     return v
 
 
@@ -176,6 +184,24 @@ def _pmc_rows(fname):
         return [], None
     with open(files[-1]) as fh:
         return list(csv.DictReader(fh)), os.path.relpath(files[-1], root)
+
+
+def profile_staleness():
+    """(stale, detail): were the committed PMC passes (newest profiles/rNN/source_stamp.json) taken on the kernel sources of THIS tree,
+    on this workload and texture?  stale = None when no stamp is committed (rounds 1-4's profiles carry none)."""
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "source_stamp.json")))
+    if not files:
+        return None, "no profiles/rNN/source_stamp.json committed"
+    try:
+        st = json.load(open(files[-1]))
+        stamp = importlib.import_module("slam-sdvl_amd.stamp").kernel_source_stamp()
+    except (OSError, ValueError) as e:
+        return None, "unreadable stamp: %s" % e
+    changed = sorted(k for k in set(st.get("files", {})) | set(stamp["files"]) if st.get("files", {}).get(k) != stamp["files"].get(k))
+    return bool(changed), {"stamp": os.path.relpath(files[-1], root), "profiled_workload": st.get("workload"), "profiled_texture": st.get("texture"),
+                           "changed_files": changed}
 
 
 def measured_issue_rates():
@@ -329,6 +355,49 @@ def cpu_baseline(frames, mapper=False, threads=1, ref_flags=False):
     tracked = sum(o[0] for o in out)
     wall = max(o[1] for o in out)       # the slowest thread's summed HandleFrame time = the job's wall time
     return tracked / wall, tracked, wall
+
+
+def latency_legs(wl, texture, n_frames, mapper=False):
+    """The reference's own shape of use (main.cc:126-159): ONE camera through SDVL::HandleFrame, frame after frame — and 16 cameras,
+    one host thread + one HIP stream each — measured by host/track_sequence, the C++ loop against the reference's API, as child
+    processes BEFORE this process touches the GPU (they have the chip to themselves).  The window is main.cc:136-138: the
+    HandleFrame call alone; the image is on the device by then (Camera::UndistortImage, main.cc:133, is outside, as in the
+    reference).  Returns the `latency` block or None."""
+    import subprocess
+    exe = os.path.join(ROOT, "slam-sdvl_amd", "host", "track_sequence")
+    if not os.path.exists(exe):
+        sys.stderr.write("bench.py: %s is not built; latency legs skipped\n" % exe)
+        return None
+    base = [exe, "--synthetic", str(n_frames), "--texture", texture, "--size", str(wl["w"]), str(wl["h"]), "--cam"] + [repr(float(c)) for c in wl["cam"]] + [
+        "--seed", str(wl.get("seed0", 20260001)), "--prerender", "--quiet", "--json"]
+    for k, v in wl["over"].items():
+        base += ["--set", k, repr(float(v))]
+    if mapper:
+        base.append("--mapper")
+    out = {}
+    for name, n in (("b1", 1), ("b16", 16)):
+        try:
+            r = subprocess.run(base + ["--trackers", str(n)], capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                sys.stderr.write("bench.py: latency leg %s failed (rc %d): %s\n" % (name, r.returncode, r.stderr[-400:]))
+                continue
+            out[name] = json.loads(line[-1])
+        except (subprocess.SubprocessError, ValueError) as e:
+            sys.stderr.write("bench.py: latency leg %s failed: %s\n" % (name, e))
+    if not out:
+        return None
+    blk = {"api": "SDVL::HandleFrame, one call per frame and camera (host/track_sequence.cc = the loop of main.cc:126-159); window = the call alone "
+                  "(main.cc:136-138), the frame is in HBM by then (Camera::UndistortImage, main.cc:133, outside the window as in the reference)",
+           "frames_per_sequence": n_frames}
+    if "b1" in out:
+        blk.update({"b1_frames_per_s": out["b1"]["frames_per_s"], "b1_ms_per_frame_p50": out["b1"]["ms_per_frame_p50"],
+                    "b1_ms_per_frame_p95": out["b1"]["ms_per_frame_p95"], "b1_tracked": out["b1"]["tracked"]})
+    if "b16" in out:
+        blk.update({"b16_frames_per_s": out["b16"]["frames_per_s"], "b16_frames_per_s_per_camera": out["b16"]["frames_per_s_per_camera"],
+                    "b16_ms_per_frame_p50": out["b16"]["ms_per_frame_p50"], "b16_ms_per_frame_p95": out["b16"]["ms_per_frame_p95"],
+                    "b16_tracked": out["b16"]["tracked"]})
+    return blk
 
 
 def host_memory_available():
@@ -494,7 +563,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S-A", help="S-A: the metric configuration (640x480); S-C: 1280x960, 4000 features")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S-A",
+                    help="S-A: the metric configuration (640x480); S-B: EuRoC geometry 752x480, four chunks; S-C: 1280x960, 4000 features")
+    ap.add_argument("--texture", choices=sorted(TEXTURES), default="plane",
+                    help="plane: value noise, a FAST corner on every second tested pixel (rounds 1-4); camera: piecewise-smooth shading + soft-edged "
+                         "shapes, 2-5 k FAST keypoints per 640x480 frame (a few % of the pixels, like a camera frame)")
+    ap.add_argument("--latency-frames", type=int, default=-1,
+                    help="frames of the LATENCY legs (one sequence alone and 16 sequences through the C++ SDVL::HandleFrame loop, host/track_sequence): "
+                         "0 = skip; default 300 for S-A / S-B on one GPU")
     ap.add_argument("--seqs", type=int, default=int(os.environ.get("SDVL_BENCH_SEQS", "0")), help="independent sequences per GPU (0 = the workload's)")
     ap.add_argument("--groups", type=int, default=0, help="groups per GPU, each = host thread + HIP stream (0 = auto)")
     ap.add_argument("--threads", type=int, default=0, help="extra host threads inside a group for per-sequence stages (0 = 1)")
@@ -513,10 +589,11 @@ def main():
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
                          "default 16 on one GPU, 8 per rank on several (10 GB of pinned host memory per rank, NUMA-local to its GPU)")
     args = ap.parse_args()
-    global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS
+    global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS, TEXTURE, SEQ_SEED
     wl = WORKLOADS[args.workload]
     W_IMG, H_IMG, TUM_CAM, FEATS_LABEL = wl["w"], wl["h"], np.array(wl["cam"]), wl["label"]
     ORACLE_PARAMS = {k.split(".")[1]: v for k, v in wl["over"].items()}
+    TEXTURE = TEXTURES[args.texture]
     seq_choices = [args.seqs] if args.seqs > 0 else list(wl["seqs"])
     args.seqs = seq_choices[0]
     if args.cpu_frames < 0:
@@ -545,6 +622,11 @@ def main():
     dist = None
     if dry:
         return dry_rank(args, rank, world)
+    if args.latency_frames < 0:
+        args.latency_frames = 300 if (world == 1 and args.workload in ("S-A", "S-B")) else 0
+    latency = None
+    if world == 1 and args.latency_frames > 2:
+        latency = latency_legs(wl, args.texture, args.latency_frames, args.mapper)   # child processes, before this one touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -613,9 +695,13 @@ def main():
     ctx = ctxs[0]
 
     my_seqs = shard.sequences_for_rank(rank, world, B)   # independent sequences: no data-path collective
+    if "chunks" in wl:   # S-B: the texture seed names the chunk (20260010..13); a rank's sequences differ by their twists
+        SEQ_SEED = lambda g: wl["seed0"] + shard.chunk_for_sequence(g, B, world, wl["chunks"])
+    else:
+        SEQ_SEED = shard.sequence_seed
     buf = ctx.malloc(B * n_frames * frame_bytes)
     for k in range(n_frames):                 # frame-major layout: step k reads B consecutive frames
-        views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * k), shard.sequence_seed(g), k) for g in my_seqs]
+        views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * k), SEQ_SEED(g), k) for g in my_seqs]
         ctx.render(views, buf + k * B * frame_bytes)
     ptrs = (buf + (np.arange(n_frames, dtype=np.uint64)[:, None] * B + np.arange(B, dtype=np.uint64)[None, :]) * frame_bytes).astype(np.uint64)
 
@@ -632,7 +718,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_frames > 0:   # at N = 1 only: with more ranks the host cores belong to their farms
         n_cpu = args.cpu_frames
         cbuf = ctx.malloc(n_cpu * frame_bytes)
-        views = [make_view(pkg, se3_exp(shard.sequence_twist(0) * k), shard.sequence_seed(0), k) for k in range(n_cpu)]
+        views = [make_view(pkg, se3_exp(shard.sequence_twist(0) * k), SEQ_SEED(0), k) for k in range(n_cpu)]
         ctx.render(views, cbuf)
         host = ctx.download(cbuf, n_cpu * frame_bytes).reshape(n_cpu, H_IMG, W_IMG)
         cpu_sample = [host[k].copy() for k in range(n_cpu)]
@@ -762,7 +848,7 @@ def main():
             lib_hip = pkg.load_library()
             for k in range(Kh):                       # the frames that follow the resident leg's last one, rendered into the (now free) input area
                 ka = n_frames + k
-                views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * ka), shard.sequence_seed(g), ka) for g in my_seqs]
+                views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * ka), SEQ_SEED(g), ka) for g in my_seqs]
                 ctx.render(views, buf)
                 ctx.check(lib_hip.sdvl_device_download(ctx.h, C.c_void_p(buf), C.c_int64(B * frame_bytes), C.c_void_p(hbuf.data_ptr() + k * B * frame_bytes)))
             hptrs = (hbuf.data_ptr() + (np.arange(Kh, dtype=np.uint64)[:, None] * B + np.arange(B, dtype=np.uint64)[None, :]) * frame_bytes).astype(np.uint64)
@@ -843,7 +929,7 @@ def main():
             spool = torch.empty(D * NF * frame_bytes, dtype=torch.uint8, pin_memory=True)
             tmp = ctx2.malloc(D * frame_bytes)
             for k in range(NF):
-                views = [make_view(pkg, se3_exp(shard.sequence_twist(d) * k), shard.sequence_seed(d), k) for d in range(D)]
+                views = [make_view(pkg, se3_exp(shard.sequence_twist(d) * k), SEQ_SEED(d), k) for d in range(D)]
                 ctx2.render(views, tmp)
                 ctx2.check(lib_hip.sdvl_device_download(ctx2.h, C.c_void_p(tmp), C.c_int64(D * frame_bytes), C.c_void_p(spool.data_ptr() + k * D * frame_bytes)))
             ctx2.check(lib_hip.sdvl_device_free(ctx2.h, C.c_void_p(tmp)))
@@ -892,6 +978,11 @@ def main():
                "one_core": round(fps1r, 2),
                "checker_build": {"flags": "-O3 -march=x86-64-v3 -ffp-contract=off", "value": round(fps_chk, 2), "one_core": round(fps1, 2)}}
 
+    if latency and cpu:
+        for b in ("b1", "b16"):
+            if b + "_frames_per_s" in latency:
+                latency[b + "_vs_cpu_one_core"] = round(latency[b + "_frames_per_s"] / cpu["one_core"], 2)
+        latency["target"] = "north_star: >= 30 x the CPU reference path for one camera = %.0f frames/s here" % (30 * cpu["one_core"])
     if rank == 0:
         frames_rank = B * K
         # the dominant kernel = the one with the most dispatch time in the timed region, nothing else (round 2 broke near-ties by
@@ -919,11 +1010,19 @@ def main():
             roofline = {"bound": "hbm", "kernel": name, "selection_rule": "argmax of kernel_ms_per_step (dispatch time, HIP events on the kernel's own stream)",
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_us": round(avg_s * 1e6, 2), "frames_per_launch": round(frames_per_launch, 1),
                         "achieved": None, "frac": None, "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": None}
+            # the counters need rocprofv3 passes of their own (tools/profile_round.sh): the line quotes the committed ones when they were taken
+            # on this workload and texture, and says whether the kernels have changed since (traffic_stale)
+            stale, stale_detail = profile_staleness()
+            same_input = isinstance(stale_detail, dict) and stale_detail.get("profiled_workload") in (None, args.workload) and \
+                stale_detail.get("profiled_texture") in (None, args.texture)
+            if stale is None:
+                same_input = args.workload == "S-A" and args.texture == "plane"     # rounds 1-4's passes: S-A on the plane texture
             if per_frame is not None:
                 bytes_per_launch = per_frame * frames_per_launch
                 achieved = bytes_per_launch / avg_s / 1e9
-                traffic, traffic_src = pmc_traffic_bytes(name, frames_per_launch) if args.workload == "S-A" else (None, None)  # the PMC passes were taken on S-A
+                traffic, traffic_src = pmc_traffic_bytes(name, frames_per_launch) if same_input else (None, None)
                 roofline.update({"achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                                 "traffic_stale": stale, "traffic_stale_detail": stale_detail,
                                  "algorithmic_bytes_per_launch": int(bytes_per_launch),
                                  "algorithmic_bytes_note": "SURVEY §8(d) per-frame bytes of this kernel x frames per launch; search_points adds the 31x31 ORB window of "
                                                            "every compared corner (961 B x matches): descriptors are computed inside the search" if name == "search_points" else
@@ -931,7 +1030,7 @@ def main():
             # the roof that governs: none of these kernels streams, they issue tens to hundreds of VALU instructions per byte.  Wave-level
             # VALU instructions per launch (SQ_INSTS_VALU of the committed SQ pass, scaled to this run's frames per launch) over the
             # launch's duration, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave instruction
-            if valu and args.workload == "S-A":
+            if valu and same_input:
                 vk = valu["kernels"].get(name)
                 roofline["valu"] = {
                     "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS, "source": valu["source"] + " (SQ_INSTS_VALU, own --pmc pass)",
@@ -970,9 +1069,16 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
             "value_host_fed": host_fed["value"] if host_fed else None, "host_fed": host_fed,
             "value_sustained": sustained["value"] if sustained else None, "sustained": sustained,
-            "config": {"workload": "%s: synthetic TUM fr1-like %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
-                                   "one tracked frame per sequence per step%s" % (args.workload, W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
+            "config": {"workload": "%s: synthetic %s %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
+                                   "one tracked frame per sequence per step%s" % (args.workload, {"S-A": "TUM fr1-like", "S-B": "EuRoC MH_01-like (config_euroc.cfg)", "S-C": "roofline case"}[args.workload], W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",
+                       "texture": args.texture + (": piecewise-smooth shading + soft-edged shapes at three scales (csrc/sdvl_synth.h SDVL_TEXTURE_CAMERA)" if TEXTURE else
+                                                  ": five octaves of value noise, a FAST corner on every second tested pixel (rounds 1-4)"),
+                       "look_ahead": not os.environ.get("SDVL_NO_LOOKAHEAD"),
+                       "look_ahead_note": "the resident leg names step k+1's images before step k (SDVLBatch::SetNextImages): their pyramids and FAST are queued "
+                                          "behind step k's chain; a live SDVL::HandleFrame caller has no next frame - the latency block is measured without it",
+                       "chunks": ("%d chunks, texture seeds %d..%d; sequence g follows chunk shard.chunk_for_sequence(g) - one chunk per rank with --gpus %d" %
+                                  (wl["chunks"], wl["seed0"], wl["seed0"] + wl["chunks"] - 1, wl["chunks"])) if "chunks" in wl else None,
                        "sequences_per_gpu": B, "groups_per_gpu": G, "sequences_per_group": Bg, "host_threads_per_group": threads, "host_worker_threads": workers, "group_steps_per_worker": fibers, "numa_node": numa_node, "parallelism": "sequences sharded over %d GPU(s)" % world,
                        "cross_gpu_relocalisation": "declined: a tracker's keyframes live in the HBM of the GPU that tracked them and Relocalize "
                                                    "(sdvl.cc:205-238) is one launch over all of them there; the round-robin partition and the min-index "
@@ -981,7 +1087,7 @@ def main():
                        "search_requests_per_frame": round(n_s / frames_rank, 1), "gn_evaluations_per_frame": round(n_ia / frames_rank, 1),
                        "lk_iterations_per_request": round(n_lk / max(1, n_s), 2), "fast_keypoints_per_frame": n_kp_measured,
                        "matches_per_frame": round(n_m / frames_rank, 1), "keyframes_per_frame": round(n_kf / frames_rank, 3)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "latency": latency,
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(all_ms_per_step.items())},
             "kernel_timing": {"timed_region": "every dispatch" if time_all else ("none" if no_timing else "launches of %s only (the roofline's kernel)" % dom_name),
                               "kernel_ms_per_step_from": "the timed region" if (time_all or not warm_timers) else "the last %d warm-up step(s), every dispatch timed" % Wt,

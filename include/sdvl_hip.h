@@ -623,6 +623,14 @@ int sdvl_synth_render(sdvl_ctx *ctx, int n, const struct sdvl_synth_view *views,
 int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out);
 int sdvl_device_free(sdvl_ctx *ctx, void *p);
 int sdvl_device_download(sdvl_ctx *ctx, const void *dev, int64_t bytes, void *host);
+/* Page-locked host memory the GPU reads where it lies.  SDVL::HandleFrame(const cv::Mat&) (sdvl.cc:55-59) is handed a host image:
+ * when that image lives in memory from sdvl_host_alloc_pinned — or in a buffer the caller registered once with
+ * sdvl_host_register, e.g. the capture buffers behind the cv::Mat of main.cc:131 — sdvl_frames_upload pulls it over the link
+ * with a kernel (no staging copy, no DMA queue); a pageable image goes through hipMemcpyAsync's bounce buffer instead. */
+int sdvl_host_alloc_pinned(sdvl_ctx *ctx, int64_t bytes, void **out);
+int sdvl_host_free_pinned(sdvl_ctx *ctx, void *p);
+int sdvl_host_register(sdvl_ctx *ctx, void *p, int64_t bytes);
+int sdvl_host_unregister(sdvl_ctx *ctx, void *p);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,7 @@ class DepthOut(C.Structure):
 class SynthView(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
                 ("R", C.c_double * 9), ("t", C.c_double * 3), ("plane", C.c_double * 4),
-                ("seed", C.c_uint32), ("frame_id", C.c_uint32)]
+                ("seed", C.c_uint32), ("frame_id", C.c_uint32), ("texture", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 # every symbol include/sdvl_hip.h declares
@@ -130,6 +130,7 @@ ABI_SYMBOLS = [
     "sdvl_track_collect", "sdvl_track_features", "sdvl_track_stats",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
     "sdvl_frames_own_images", "sdvl_feed_create", "sdvl_feed_destroy", "sdvl_feed_last_error", "sdvl_feed_slot_arrived", "sdvl_feed_images", "sdvl_ctx_feed_acquire", "sdvl_ctx_feed_release", "sdvl_frame_footprint_cap", "sdvl_ctx_set_corner_capacity", "sdvl_frame_corner_capacity", "sdvl_detect_scratch_bytes",
+    "sdvl_host_alloc_pinned", "sdvl_host_free_pinned", "sdvl_host_register", "sdvl_host_unregister",
 ]
 
 _lib = None

@@ -1071,4 +1071,32 @@ int sdvl_device_download(sdvl_ctx *ctx, const void *dev, int64_t bytes, void *ho
   return SDVL_OK;
 }
 
+int sdvl_host_alloc_pinned(sdvl_ctx *ctx, int64_t bytes, void **out) {
+  if (!ctx || !out || bytes <= 0) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  SDVL_HIP_CHECK(ctx, hipHostMalloc(out, static_cast<size_t>(bytes), hipHostMallocMapped | hipHostMallocPortable));
+  return SDVL_OK;
+}
+
+int sdvl_host_free_pinned(sdvl_ctx *ctx, void *p) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  SDVL_HIP_CHECK(ctx, hipHostFree(p));
+  return SDVL_OK;
+}
+
+int sdvl_host_register(sdvl_ctx *ctx, void *p, int64_t bytes) {
+  if (!ctx || !p || bytes <= 0) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  SDVL_HIP_CHECK(ctx, hipHostRegister(p, static_cast<size_t>(bytes), hipHostRegisterMapped | hipHostRegisterPortable));
+  return SDVL_OK;
+}
+
+int sdvl_host_unregister(sdvl_ctx *ctx, void *p) {
+  if (!ctx || !p) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  SDVL_HIP_CHECK(ctx, hipHostUnregister(p));
+  return SDVL_OK;
+}
+
 }  // extern "C"

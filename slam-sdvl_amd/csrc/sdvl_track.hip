@@ -635,6 +635,7 @@ static int track_upload_rows(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int3
       ctx->err = "table larger than the set's capacity";
       return SDVL_ERR_CAPACITY;
     }
+    for (int j = 0; j < i; j++) SDVL_REQUIRE(ctx, trackers[j] != trackers[i], "a tracker is named twice in one upload");
     tp += n_points[i];
     tf += n_features[i];
   }
@@ -664,8 +665,6 @@ static int track_upload_rows(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int3
       const int pt = features[fo + k].point;
       SDVL_REQUIRE(ctx, pt < 0 || (pt & kPointMask) < p0 + n_points[i], "feature names a point outside its tracker's table");
     }
-    s->n_points[trackers[i]] = p0 + n_points[i];
-    s->n_feat[feat_buf[i]][trackers[i]] = f0 + n_features[i];
     po += n_points[i];
     fo += n_features[i];
   }
@@ -675,6 +674,11 @@ static int track_upload_rows(sdvl_ctx *ctx, sdvl_track_set *s, int n, const int3
               reinterpret_cast<const TrackPoint *>(d8 + rb), reinterpret_cast<const TrackFeat *>(d8 + rb + pb), s->d_points, s->d_feats[0],
               s->d_feats[1], s->np, s->nf);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
+  // every record was valid and the rows are on their way: only now do the host-side counts follow (a failed call leaves them untouched)
+  for (int i = 0; i < n; i++) {
+    s->n_points[trackers[i]] = recs[i].point_dst + n_points[i];
+    s->n_feat[feat_buf[i]][trackers[i]] = recs[i].feat_dst + n_features[i];
+  }
   return SDVL_OK;
 }
 
@@ -813,6 +817,17 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
   static const bool use_graph = getenv("SDVL_STEP_GRAPH") != nullptr;
   const auto t_submit = std::chrono::steady_clock::now();
   const bool timing_was = ctx->timing;
+  // (one-time set-up calls stay outside a capture)
+  if (static_cast<size_t>(stride) * (8 + 16 + 2) + 64 > 60 * 1024) {  // track_project beyond the default dynamic LDS limit: raise it once per device
+    static std::atomic<unsigned long long> attr_devices{0};
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
+      SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(track_project_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              4096 * (8 + 16 + 2) + 64));
+      attr_devices.fetch_or(bit, std::memory_order_release);
+    }
+  }
   if (use_graph) {
     ctx->timing = false;  // start / stop events of a dispatch cannot be recorded into a capture
     SDVL_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -839,16 +854,6 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
   };
   {
     const size_t lds = static_cast<size_t>(stride) * (8 + 16 + 2) + 64;
-    if (lds > 60 * 1024) {  // beyond the default dynamic LDS limit: raise it once per device
-      static std::atomic<unsigned long long> attr_devices{0};
-      const unsigned long long bit = 1ull << (ctx->device & 63);
-      if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
-        SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
-        SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(track_project_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                4096 * (8 + 16 + 2) + 64));
-        attr_devices.fetch_or(bit, std::memory_order_release);
-      }
-    }
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "track_project", &ev_a, &ev_b);
     // a lane per feature of last_frame: 256 lanes cover the ~190 features of the metric configuration, configuration C's ~850 take 512
@@ -859,7 +864,10 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
                           static_cast<const sdvl_align_result *>(s->d_ares), static_cast<const uint16_t *>(s->d_cell_rank), s->cells, c,
                           s->prm.cell_size, s->prm.patch_size, registry, s->d_reqs, s->d_reqpt, s->d_cfirst, s->d_cfeat, s->d_blocks, s->d_chain,
                           s->prm.search, fused_prepare ? s->d_prep : nullptr);
-    SDVL_HIP_CHECK(ctx, hipGetLastError());
+    if (hipError_t le = hipGetLastError(); le != hipSuccess) {  // never leave the stream in capture mode
+      (void)end_capture();
+      SDVL_HIP_CHECK(ctx, le);
+    }
   }
   int rc = sdvl_search_launch_device(ctx, n_jobs * stride, s->d_reqs, registry, s->d_blocks, n_jobs * (stride / kWavesPerBlock), &s->cam,
                                      &s->prm.search, s->d_prep, s->d_res, nullptr, /*prepared*/ fused_prepare);
@@ -885,7 +893,10 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
                           static_cast<const sdvl_search_res *>(s->d_res), static_cast<const sdvl_pose_result *>(s->d_pres),
                           static_cast<const int32_t *>(s->d_lists), static_cast<const sdvl_align_result *>(s->d_ares), c, s->prm.max_failed, registry,
                           s->h_results, s->h_feats, s->h_stats);
-    SDVL_HIP_CHECK(ctx, hipGetLastError());
+    if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+      (void)end_capture();
+      SDVL_HIP_CHECK(ctx, le);
+    }
   }
   SDVL_HIP_CHECK(ctx, end_capture());
   s->chain_submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_submit).count();

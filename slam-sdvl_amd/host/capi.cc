@@ -227,7 +227,10 @@ int sdvlh_batch_step_device(void *bp, const void *const *dev_imgs, int stride, s
 }
 
 // Look-ahead (SDVLBatch::SetNextImages): the device images the NEXT sdvlh_batch_step_device call will be given; their pyramids and
-// corner detection are queued behind the coming step's search / pose chain.  They must stay valid until that call.
+// corner detection are queued behind the coming step's search / pose chain.  They must stay valid AND UNCHANGED until that call:
+// the look-ahead is matched to the next step's images by device address alone, so a buffer that is rewritten in between would be
+// tracked from pyramids of its old content.  The look-ahead belongs to the one coming step: if that step cannot use it (a bootstrap
+// step, the host-driven path) it is dropped.
 int sdvlh_batch_set_next_device(void *bp, const void *const *dev_imgs, int stride) {
   Batch *b = static_cast<Batch *>(bp);
   try {

@@ -150,6 +150,8 @@ class SDVL {
   bool HasMap() { return state_ == STATE_RUNNING; }
   const FrameStats &LastStats() const { return stats_; }
   Map *GetMap() { return map_; }
+  // wall clock per host stage of this tracker's own HandleFrame calls (null before the first call); diagnostic
+  const StageTimes *HandleFrameStageTimes() const;
 
  private:
   friend class SDVLBatch;
@@ -170,6 +172,11 @@ class SDVL {
   SE3 first_pose_;
   FrameStats stats_;
   bool relocalize_pending_ = false;
+  // Round 5: HandleFrame() steps through a batch of one that LIVES with the tracker, so a lone camera gets the device-resident
+  // tracking tables too — a tracked frame is one submission and one wait instead of the host-driven stage-by-stage form
+  // (SDVL_HANDLEFRAME_ONE_SHOT=1: a fresh batch per call, rounds 1-4)
+  std::unique_ptr<SDVLBatch> self_batch_;
+  void SyncSelfBatch();
   // device-resident tracking table of this tracker (SDVLBatch owns the set): valid = the table holds last_frame_'s features
   struct TrackState {
     bool valid = false;

@@ -268,6 +268,7 @@ SDVL::SDVL(Camera *camera)
 
 SDVL::~SDVL() {
   if (own_map_) own_map_->Stop();
+  self_batch_.reset();  // its tracking tables go before the frames and the device do
   current_frame_.reset();
   last_frame_.reset();
   last_kf_.reset();
@@ -278,6 +279,13 @@ SDVL::~SDVL() {
 void SDVL::SetBootstrapPlane(const Vector3d &n, double d) {
   if (PlaneMap *pm = dynamic_cast<PlaneMap *>(map_)) pm->SetPlane(n, d);
 }
+
+// the Point counters and feature lists HandleFrame's batch keeps on the device reach the host objects the queries below read
+void SDVL::SyncSelfBatch() {
+  if (self_batch_) self_batch_->SyncHostState();
+}
+
+const StageTimes *SDVL::HandleFrameStageTimes() const { return self_batch_ ? &self_batch_->stage_times : nullptr; }
 
 // sdvl.cc:283-291
 void SDVL::GetCameraTrail(vector<std::pair<SE3, bool>> *positions) {
@@ -290,6 +298,7 @@ void SDVL::GetCameraTrail(vector<std::pair<SE3, bool>> *positions) {
 // sdvl.cc:293-324: converged points twice, the others as the two ends of their depth interval
 void SDVL::GetPoints(vector<Vector3d> *positions) {
   std::unique_lock<std::mutex> lock(map_->GetMutex());
+  SyncSelfBatch();
   positions->clear();
   for (auto it = map_->GetKeyframes().begin(); it != map_->GetKeyframes().end(); it++) {
     for (auto feature = (*it)->GetFeatures().begin(); feature != (*it)->GetFeatures().end(); feature++) {
@@ -313,6 +322,7 @@ void SDVL::GetPoints(vector<Vector3d> *positions) {
 // sdvl.cc:326-349: (x, y, Point status) of the last frame's features, then its outliers as status P_OUTLIER
 void SDVL::GetLastFeatures(vector<Vector3i> *positions) {
   std::unique_lock<std::mutex> lock(map_->GetMutex());
+  SyncSelfBatch();
   positions->clear();
   if (!last_frame_) return;
   vector<shared_ptr<Feature>> &features = last_frame_->GetFeatures();
@@ -351,10 +361,22 @@ void SDVL::CalcTrackingQuality(int matches, int attempts) {
 
 bool SDVL::HandleFrame(const Image &img) {
   std::unique_lock<std::mutex> lock(map_->GetMutex());  // the mapper thread of threaded mode stays out meanwhile
-  SDVLBatch one(Device::Current(), {this}, 1);
-  one.persistent_ = false;  // a one-call batch: no device-resident tables to amortise
+  static const bool one_shot = std::getenv("SDVL_HANDLEFRAME_ONE_SHOT") != nullptr;
   FrameStats st;
-  one.HandleFrames({img}, &st);
+  if (one_shot) {  // rounds 1-4: a one-call batch, no device-resident tables, every stage driven from the host
+    SDVLBatch one(Device::Current(), {this}, 1);
+    one.persistent_ = false;
+    one.HandleFrames({img}, &st);
+    return true;
+  }
+  Device *dev = Device::Current();
+  if (!self_batch_ || self_batch_->dev_ != dev) {  // first call, or the caller moved to another Device (= stream)
+    if (self_batch_) self_batch_->SyncHostState();
+    self_batch_.reset(new SDVLBatch(dev, {this}, 1));
+    track_.valid = false;
+  }
+  track_.slot = 0;  // (a farm batch that also steps this tracker would have renumbered it)
+  self_batch_->HandleFrames({img}, &st);
   return true;
 }
 
@@ -831,7 +853,6 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         for (const Image &im : next_imgs_) ahead_src_.push_back(im.dev_src);
       }
     }
-    next_imgs_.clear();
     tr_res_.resize(R);
     dev_->Check(sdvl_track_collect(dev_->ctx(), track_, R, tr_res_.data()), "sdvl_track_collect");
 
@@ -945,6 +966,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     });
   }
   clk.reset();
+  next_imgs_.clear();  // a look-ahead belongs to ONE step, whether that step could use it (R == B tracked frames) or not (bootstrap)
   if (R == 0 && !detected_ahead) Frame::DetectBatch(frames, Config::NumFeatures());  // bootstrap-only step: the new keyframes still need their corners
   // a mapper that looks at the frames it was given (MapperMap: scene depth of every frame, feature lists of keyframes)
   // materialises them on demand; a keyframe's table is rebuilt afterwards in any case

@@ -33,7 +33,7 @@ static SE3 PoseOf(int k) {
 
 static void Render(int k, std::vector<uint8_t> *px) {
   const SE3 T = PoseOf(k);
-  sdvl_synth_view v;
+  sdvl_synth_view v = {};
   v.fx = kCam[0]; v.fy = kCam[1]; v.u0 = kCam[2]; v.v0 = kCam[3];
   const M3 R = T.GetRotation();
   for (int q = 0; q < 9; q++) v.R[q] = R.m[q];

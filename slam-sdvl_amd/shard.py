@@ -16,6 +16,17 @@ def sequence_seed(gidx):
     return 20260001 + gidx
 
 
+def chunk_for_sequence(gidx, per_gpu, world, chunks=4):
+    """S-B (BASELINE config 4: "1 vs 4 GPUs sharding independent sequence chunks"): which of the `chunks` independent
+    chunks global sequence `gidx` follows.  SURVEY §8e's partition: rank g owns the chunks {c : c mod G = g}; the rank's sequences
+    go round those.  One rank: all chunks, sequence j follows chunk j mod chunks; as many ranks as chunks: every rank tracks ONE
+    chunk; more ranks than chunks: rank r tracks chunk r mod chunks."""
+    assert per_gpu > 0 and world > 0 and chunks > 0 and gidx >= 0
+    rank, j = divmod(gidx, per_gpu)
+    mine = [c for c in range(chunks) if c % world == rank % world] if world < chunks else [rank % chunks]
+    return mine[j % len(mine)]
+
+
 def sequence_twist(gidx):
     """per-sequence camera twist per frame: the S-A twist scaled / mirrored so that sequences differ"""
     s = 1.0 + 0.05 * (gidx % 7)

@@ -150,7 +150,8 @@ class TrackerBatch:
 
     def set_next_device(self, dev_ptrs):
         """look-ahead: the device images the NEXT step_device call will be given (None: none); their pyramids and corner detection
-        are queued behind the coming step's search / pose chain (SDVLBatch::SetNextImages)"""
+        are queued behind the coming step's search / pose chain (SDVLBatch::SetNextImages).  The buffers must keep their CONTENT until that
+        call: the look-ahead is recognised by device address alone.  It belongs to the one coming step and is dropped if that step cannot use it"""
         ptrs = (C.c_void_p * self.B)(*[int(p) for p in dev_ptrs]) if dev_ptrs is not None else None
         if self.lib.sdvlh_batch_set_next_device(self.h, ptrs, self.w) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())

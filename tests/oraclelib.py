@@ -35,7 +35,7 @@ class FrameStats(C.Structure):
 class SynthView(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
                 ("R", C.c_double * 9), ("t", C.c_double * 3), ("plane", C.c_double * 4),
-                ("seed", C.c_uint32), ("frame_id", C.c_uint32)]
+                ("seed", C.c_uint32), ("frame_id", C.c_uint32), ("texture", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 def _ensure(path, cmd, cwd):
@@ -300,7 +300,7 @@ class Synth:
     def __init__(self):
         self.lib = load_synth()
 
-    def render(self, T_cw, cam, w, h, seed=20260001, frame_id=0, plane=(0, 0, 1, 2.0)):
+    def render(self, T_cw, cam, w, h, seed=20260001, frame_id=0, plane=(0, 0, 1, 2.0), texture=0):
         v = SynthView()
         v.fx, v.fy, v.u0, v.v0 = [float(c) for c in cam]
         R = quat_to_R(T_cw[:4])
@@ -310,7 +310,7 @@ class Synth:
             v.t[i] = float(T_cw[4 + i])
         for i in range(4):
             v.plane[i] = float(plane[i])
-        v.seed = seed; v.frame_id = frame_id
+        v.seed = seed; v.frame_id = frame_id; v.texture = texture
         out = np.zeros((h, w), np.uint8)
         self.lib.sdvl_synth_render_host(C.byref(v), w, h, ptr(out, u8p), w)
         return out

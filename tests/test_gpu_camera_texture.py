@@ -1,0 +1,177 @@
+"""Round 5: the parity suite on the inputs VERDICT r04 asked for — the camera-like texture (sparse FAST corners: the path a camera
+frame takes through fast_cells, short per-cell lists in select_cells, corners clustered on edges in the search) and S-B (EuRoC
+geometry, config_euroc.cfg, seeds 20260010..13).  Same bars as everywhere: FAST lists incl. order and every per-frame decision
+identical to the CPU oracle, poses within 1e-4."""
+import ctypes as C
+import importlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oraclelib import EUROC_CAM, TUM_CAM, XI, trajectory_pose
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sdvl():
+    return importlib.import_module("slam-sdvl_amd")
+
+
+@pytest.fixture(scope="module")
+def trk():
+    importlib.import_module("slam-sdvl_amd")
+    return importlib.import_module("slam-sdvl_amd.tracker")
+
+
+def record(s):
+    return (s.state, s.quality, s.keyframe, s.n_corners, s.matches, s.attempts, s.inliers, s.outliers, s.align_meas)
+
+
+@pytest.mark.parametrize("w,h,cam", [(640, 480, TUM_CAM), (752, 480, EUROC_CAM)])
+def test_fast_and_selection_on_the_camera_texture(sdvl, orc, synth, w, h, cam):
+    """per-cell FAST lists (x, y, score, ORDER) and DetectPyramid's selected corners incl. order: the sparse path of fast_cells and
+    the short lists of select_cells / select_pack"""
+    from test_gpu_parity import check_fast
+    ctx = sdvl.Context(0)
+    try:
+        imgs = [synth.render(trajectory_pose(orc, k), cam, w, h, seed=20260010 + k, frame_id=k, texture=1) for k in (0, 5, 9)]
+        n = check_fast(ctx, sdvl, orc, imgs)
+        assert 3 * 1500 < n < 3 * 8000, n                        # a few thousand keypoints per frame, not 13 k
+        assert check_fast(ctx, sdvl, orc, imgs[:1], margin=5, thr=25) > 500
+        dp = sdvl.default_detect_params()
+        frames = [ctx.frame(im) for im in imgs]
+        for nfeat in (1000, 300):
+            for g, im in zip(ctx.detect_corners(frames, dp, nfeat), imgs):
+                assert np.array_equal(g, orc.detect_pyramid(im, nfeatures=nfeat)), nfeat
+        for f in frames:
+            f.close()
+    finally:
+        ctx.close()
+
+
+def test_camera_texture_300_frames_closed_loop(trk, orc, synth):
+    """S-A's 300 frames on the camera texture (device-resident tables, plane map): every decision of every frame equals the oracle's"""
+    trk.configure()
+    dev = trk.HostDevice(0)
+    batch = trk.TrackerBatch(dev, 1, 640, 480, TUM_CAM)
+    ref = orc.tracker(640, 480, TUM_CAM)
+    n_kf, matches = 0, []
+    for k in range(300):
+        img = synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, frame_id=k, texture=1)
+        g, w = batch.step_host([img])[0], ref.handle_frame(img)
+        assert record(g) == record(w), (k, record(g), record(w))
+        assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, k
+        if k > 0:
+            assert g.quality == 0
+            matches.append(g.matches)
+        n_kf += g.keyframe
+    assert np.mean(matches) >= 150 and n_kf >= 40, (np.mean(matches), n_kf)
+    batch.close(); ref.close(); dev.close()
+
+
+@pytest.mark.parametrize("texture", [0, 1])
+def test_s_b_chunks_closed_loop(trk, orc, synth, texture):
+    """S-B (BASELINE config 4): 752x480, config_euroc.cfg's intrinsics and min_matches 5, the four chunk seeds
+    20260010..13, one batch of four trackers"""
+    over = dict(trk.TUM_OVERRIDES)
+    over["SDVL.min_matches"] = 5
+    trk.configure(over)
+    old = orc.params.min_matches
+    orc.params.min_matches = 5
+    try:
+        dev = trk.HostDevice(0)
+        shard = importlib.import_module("slam-sdvl_amd.shard")
+        batch = trk.TrackerBatch(dev, 4, 752, 480, EUROC_CAM, host_threads=2)
+        refs = [orc.tracker(752, 480, EUROC_CAM) for _ in range(4)]
+        for k in range(12):
+            imgs = [synth.render(trajectory_pose(orc, k, shard.sequence_twist(i)), EUROC_CAM, 752, 480, seed=20260010 + shard.chunk_for_sequence(i, 4, 1),
+                                 frame_id=k, texture=texture) for i in range(4)]
+            got = batch.step_host(imgs)
+            for i in range(4):
+                w = refs[i].handle_frame(imgs[i])
+                assert record(got[i]) == record(w), (k, i)
+                assert np.abs(np.array(got[i].pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, (k, i)
+                if k > 0:
+                    assert got[i].quality == 0 and got[i].matches >= 100
+        batch.close(); dev.close()
+        for r in refs:
+            r.close()
+    finally:
+        orc.params.min_matches = old
+        trk.configure()
+
+
+def test_farm_at_bench_size_on_the_camera_texture(trk, sdvl, orc):
+    """bench.py --texture camera at its own shape (16 groups x 256 sequences, frames rendered on the device and resident, look-ahead on):
+    8 distinct sequences x 512 replicas — every replica the same record wherever it sits, the 8 equal to the oracle"""
+    import bench as B
+    G, Bg, n_steps, distinct = 16, 256, 5, 8
+    n = G * Bg
+    trk.configure()
+    farm = trk.TrackerFarm(0, G, Bg, 640, 480, TUM_CAM)
+    ctx = B.CtxView(sdvl, farm.ctx_handle(0))
+    fb = 640 * 480
+    xis = [XI * (1.0 + 0.2 * i) * (1 if i % 2 == 0 else -1) for i in range(distinct)]
+    which = [(i * 7 + i // Bg) % distinct for i in range(n)]
+    buf = ctx.malloc(n * n_steps * fb)
+    old = B.TEXTURE
+    B.TEXTURE = B.TEXTURES["camera"]
+    try:
+        for k in range(n_steps):
+            ctx.render([B.make_view(sdvl, trajectory_pose(orc, k, xis[which[i]]), 20260201 + which[i], k) for i in range(n)], buf + k * n * fb)
+    finally:
+        B.TEXTURE = old
+    ptrs = (buf + (np.arange(n_steps, dtype=np.uint64)[:, None] * n + np.arange(n, dtype=np.uint64)[None, :]) * fb).astype(np.uint64)
+    farm.reserve(Bg * 6)
+    st = farm.run(ptrs, G)
+    rec = [record(s) + (tuple(s.pose[:]),) for s in st]
+    first = {}
+    for k in range(n_steps):
+        for i in range(n):
+            key = (k, which[i])
+            first.setdefault(key, rec[k * n + i])
+            assert rec[k * n + i] == first[key], (k, i)
+    for d in range(distinct):
+        o = orc.tracker(640, 480, TUM_CAM)
+        i0 = which.index(d)
+        for k in range(n_steps):
+            img = ctx.download(buf + (k * n + i0) * fb, fb).reshape(480, 640)
+            want = o.handle_frame(img)
+            g = first[(k, d)]
+            assert g[:9] == record(want), (k, d, g[:9], record(want))
+            assert np.abs(np.array(g[9]) - np.array(want.pose[:])).max() <= POSE_TOL
+            if k > 0:
+                assert g[1] == 0 and g[4] >= 100
+        o.close()
+    farm.close()
+
+
+@pytest.mark.parametrize("env,extra", [({}, []), ({"SDVL_HANDLEFRAME_ONE_SHOT": "1"}, []), ({}, ["--trackers", "3"])])
+def test_one_camera_through_handleframe_on_the_camera_texture(orc, synth, env, extra):
+    """host/track_sequence = the loop of main.cc:126-159, one SDVL::HandleFrame call per frame.  Round 5: the call steps through a
+    batch of one that lives with the tracker (device-resident tables, one submission per tracked frame); SDVL_HANDLEFRAME_ONE_SHOT=1
+    keeps rounds 1-4's host-driven form; --trackers 3: three cameras on three host threads and streams.  All give the oracle's answers."""
+    exe = os.path.join(ROOT, "slam-sdvl_amd", "host", "track_sequence")
+    assert os.path.exists(exe), "build() makes it (make -C slam-sdvl_amd/host)"
+    n = 24
+    ref = orc.tracker(640, 480, TUM_CAM)
+    wants = [ref.handle_frame(synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, frame_id=k, texture=1)) for k in range(n)]
+    ref.close()
+    r = subprocess.run([exe, "--synthetic", str(n), "--texture", "camera", "--prerender", "--json"] + extra, capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    rows = [l.split() for l in lines if not l.startswith("{")]
+    assert len(rows) == n
+    for k, (row, w) in enumerate(zip(rows, wants)):
+        assert [int(v) for v in row[:6]] == [k, w.state, w.quality, w.matches, w.attempts, w.inliers], k
+        assert np.abs(np.array([float(v) for v in row[6:13]]) - np.array(w.pose[:])).max() <= POSE_TOL
+    summary = json.loads(lines[-1])
+    n_trk = int(extra[1]) if extra else 1
+    assert summary["trackers"] == n_trk and summary["tracked"] == n_trk * (n - 1) and summary["frames_per_s"] > 0

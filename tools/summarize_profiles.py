@@ -114,4 +114,23 @@ if f:
             csv.writer(out).writerow([k, disp] + ["%.1f" % avg[n] for n in names] + ["%.4f" % conf, "%.1f" % ipw,
                                      "one --pmc pass of SQ counters; %s; lds_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE "
                                      "(extra LDS cycles per LDS-array cycle)" % cfg])
+# which kernel sources, workload and texture these passes belong to (bench.py: roofline.traffic_stale)
+try:
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    stamp = importlib.import_module("slam-sdvl_amd.stamp").kernel_source_stamp()
+    wl, tex = None, None
+    for name in ("prof_fetch.json", "prof_sq.json", "prof_kt.json"):
+        pj = os.path.join(src, name)
+        if os.path.exists(pj) and os.path.getsize(pj):
+            try:
+                c = json.loads(open(pj).read().strip().splitlines()[-1])["config"]
+                wl, tex = c["workload"].split(":")[0], c.get("texture", "plane").split(":")[0]
+                break
+            except Exception:
+                pass
+    stamp.update({"workload": wl, "texture": tex})
+    json.dump(stamp, open(os.path.join(dst, "source_stamp.json"), "w"), indent=1, sort_keys=True)
+except Exception as e:
+    print("source stamp not written:", e)
 print("wrote", sorted(os.listdir(dst)))
