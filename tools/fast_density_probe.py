@@ -22,6 +22,7 @@ synth = ol.Synth()
 orc_pose = np.array([1, 0, 0, 0, 0.05, 0.02, 0.0])
 images = {
     "synthetic plane (bench.py)": synth.render(orc_pose, ol.TUM_CAM, 640, 480),
+    "camera texture (bench.py --texture camera)": synth.render(orc_pose, ol.TUM_CAM, 640, 480, texture=1),
     "white noise": np.random.default_rng(1).integers(0, 256, (480, 640), dtype=np.uint8),
     "smooth + 500 small shapes": sparse_corner_image(3, 480, 640),
 }
@@ -33,6 +34,6 @@ for name, img in images.items():
         got, _ = ctx.fast_cells(frames, dp, cap=60000)
     t = ctx.timing_get()["fast_cells"]
     kp = len(got[0][0])
-    print("%-28s %7d keypoints after NMS per frame   fast_cells %7.1f us per %d frames" % (name, kp, t[0] / t[1] * 1e3, n))
+    print("%-46s %7d keypoints after NMS per frame   fast_cells %7.1f us per %d frames" % (name, kp, t[0] / t[1] * 1e3, n))
     for f in frames:
         f.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmark through the C-ABI (one stream, no tracker): dispatch time of every kernel on a batch of
 n synthetic 640x480 frames, with the algorithmic bytes of SURVEY §8(d) -> GB/s.  Used to tune kernels in isolation.
-    python tools/kernel_bench.py [n_frames] [reps]"""
+    python tools/kernel_bench.py [n_frames] [reps]          (SDVL_KB_TEXTURE=camera: the camera-like texture)"""
 import importlib
 import os
 import sys
@@ -15,6 +15,7 @@ sdvl = importlib.import_module("slam-sdvl_amd")
 shard = importlib.import_module("slam-sdvl_amd.shard")
 import bench as B  # noqa: E402  (se3_exp, make_view)
 
+B.TEXTURE = B.TEXTURES[os.environ.get("SDVL_KB_TEXTURE", "plane")]   # SDVL_KB_TEXTURE=camera: the camera-like texture
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 W, H = 640, 480
