@@ -623,6 +623,14 @@ int sdvl_synth_render(sdvl_ctx *ctx, int n, const struct sdvl_synth_view *views,
 int sdvl_device_malloc(sdvl_ctx *ctx, int64_t bytes, void **out);
 int sdvl_device_free(sdvl_ctx *ctx, void *p);
 int sdvl_device_download(sdvl_ctx *ctx, const void *dev, int64_t bytes, void *host);
+/* Fork / join inside one context (round 5).  Work queued between _fork_begin and _fork_end runs on a side stream that starts behind
+ * the point of the main stream _fork_mark recorded and is joined into the main stream by _fork_end: everything queued afterwards waits
+ * for both.  A lone camera's tracked frame uses it (host/standalone.cc): Frame::CreateCorners' FAST + selection (frame.cc:122-131,
+ * reached from the Frame constructor, sdvl.cc:59) needs the pyramid only, so it runs beside ImageAlign::ComputePose (sdvl.cc:189)
+ * instead of behind it.  One fork at a time; results are identical (the same kernels on the same inputs). */
+int sdvl_ctx_fork_mark(sdvl_ctx *ctx);
+int sdvl_ctx_fork_begin(sdvl_ctx *ctx);
+int sdvl_ctx_fork_end(sdvl_ctx *ctx);
 /* Page-locked host memory the GPU reads where it lies.  SDVL::HandleFrame(const cv::Mat&) (sdvl.cc:55-59) is handed a host image:
  * when that image lives in memory from sdvl_host_alloc_pinned — or in a buffer the caller registered once with
  * sdvl_host_register, e.g. the capture buffers behind the cv::Mat of main.cc:131 — sdvl_frames_upload pulls it over the link

@@ -184,6 +184,10 @@ hipError_t sdvl_mark_wait(sdvl_ctx *ctx, int kind, uint32_t ticket) {
 }
 
 hipError_t sdvl_stream_wait(sdvl_ctx *ctx) {
+  if (ctx->forked) {  // a whole-context wait inside a fork (the staging ring ran out): both chains must have drained
+    hipError_t es = hipStreamSynchronize(ctx->main_stream);
+    if (es != hipSuccess) return es;
+  }
   uint32_t t = 0;
   hipError_t e = sdvl_mark_record(ctx, SDVL_MARK_STREAM, &t);
   if (e != hipSuccess) return e;
@@ -391,6 +395,13 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
   }
+  if (ctx->forked) ctx->stream = ctx->main_stream;
+  if (ctx->side_stream) {
+    (void)hipStreamSynchronize(ctx->side_stream);
+    (void)hipStreamDestroy(ctx->side_stream);
+  }
+  if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+  if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
   for (hipEvent_t e : ctx->copy_event)
     if (e) (void)hipEventDestroy(e);
   if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
@@ -1068,6 +1079,42 @@ int sdvl_device_download(sdvl_ctx *ctx, const void *dev, int64_t bytes, void *ho
   if (!ctx || !dev || !host || bytes <= 0) return SDVL_ERR_INVALID;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(host, dev, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  return SDVL_OK;
+}
+
+// ---- fork / join: a side chain behind an earlier point of the main stream ---------------------------------------------------------
+int sdvl_ctx_fork_mark(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, !ctx->forked, "sdvl_ctx_fork_mark inside a fork");
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  if (!ctx->side_stream) {
+    SDVL_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    SDVL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
+  }
+  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+  ctx->fork_marked = 1;
+  return SDVL_OK;
+}
+
+int sdvl_ctx_fork_begin(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, ctx->fork_marked && !ctx->forked, "sdvl_ctx_fork_begin without sdvl_ctx_fork_mark");
+  SDVL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->fork_event, 0));
+  ctx->main_stream = ctx->stream;
+  ctx->stream = ctx->side_stream;
+  ctx->forked = 1;
+  ctx->fork_marked = 0;
+  return SDVL_OK;
+}
+
+int sdvl_ctx_fork_end(sdvl_ctx *ctx) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, ctx->forked, "sdvl_ctx_fork_end without sdvl_ctx_fork_begin");
+  ctx->stream = ctx->main_stream;
+  ctx->forked = 0;
+  SDVL_HIP_CHECK(ctx, hipEventRecord(ctx->join_event, ctx->side_stream));
+  SDVL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
   return SDVL_OK;
 }
 

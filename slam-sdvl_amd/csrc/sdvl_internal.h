@@ -68,6 +68,11 @@ struct sdvl_ctx {
   void *h_prefetch_jobs[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned job lists, read by the gather kernel where they are
   size_t prefetch_jobs_cap = 0;
   unsigned prefetch_count = 0;
+  // Round 5: a side stream for work that depends on an earlier point of the main stream only (sdvl_ctx_fork_mark / _begin / _end):
+  // a lone camera's corner detection needs the pyramid, not the image alignment queued behind it, so the two chains run side by side
+  hipStream_t side_stream = nullptr, main_stream = nullptr;
+  hipEvent_t fork_event = nullptr, join_event = nullptr;
+  int fork_marked = 0, forked = 0;
   std::string err;
   // pinned + device staging, grown on demand
   void *h_stage = nullptr; size_t h_stage_bytes = 0;

@@ -838,8 +838,26 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     prm.max_failed = Config::MaxFailed();
     prm.pad_ = 0;
     const sdvl_camera cam = camera.abi();
+    // Round 5: a SMALL batch (a lone camera's HandleFrame above all) is a chain of launches that each fill a sliver of the chip: its
+    // detection (FAST, selection: needs the pyramid only) runs on the context's side stream BESIDE the alignment instead of behind it
+    // (sdvl_ctx_fork_*); a farm's large batches keep one stream per group — there the other groups are the company.
+    // SDVL_DETECT_FORK=0 / 1 forces it off / on.
+    static const int fork_env = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
+    const bool fork_detect = !detected_ahead && (fork_env >= 0 ? fork_env != 0 : B <= 32);
+    if (fork_detect) dev_->Check(sdvl_ctx_fork_mark(dev_->ctx()), "sdvl_ctx_fork_mark");  // the pyramids are queued: the side chain starts here
     dev_->Check(sdvl_track_align(dev_->ctx(), track_, R, tr_jobs_.data(), tr_rank_.data(), tr_rand_.data(), &cam, &prm), "sdvl_track_align");
-    if (!detected_ahead) Frame::DetectBatch(frames, Config::NumFeatures());  // FAST + selection run behind the alignment
+    if (fork_detect) {
+      dev_->Check(sdvl_ctx_fork_begin(dev_->ctx()), "sdvl_ctx_fork_begin");
+      try {
+        Frame::DetectBatch(frames, Config::NumFeatures());
+      } catch (...) {  // whatever the detection throws, the context leaves the fork
+        (void)sdvl_ctx_fork_end(dev_->ctx());
+        throw;
+      }
+      dev_->Check(sdvl_ctx_fork_end(dev_->ctx()), "sdvl_ctx_fork_end");
+    } else if (!detected_ahead) {
+      Frame::DetectBatch(frames, Config::NumFeatures());  // FAST + selection run behind the alignment
+    }
     clk.reset(new StageClock(ST_SEARCH));
     dev_->Check(sdvl_track_search(dev_->ctx(), track_), "sdvl_track_search");
     // the look-ahead: the next step's pyramids and detection go behind this step's chain, ahead of its keyframe kernels
@@ -967,7 +985,22 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
   }
   clk.reset();
   next_imgs_.clear();  // a look-ahead belongs to ONE step, whether that step could use it (R == B tracked frames) or not (bootstrap)
-  if (R == 0 && !detected_ahead) Frame::DetectBatch(frames, Config::NumFeatures());  // bootstrap-only step: the new keyframes still need their corners
+  if (R == 0 && !detected_ahead) {  // bootstrap-only step: the new keyframes still need their corners
+    // (a small batch detects on the side stream here too: the stream and its queue exist by the time a tracked frame forks)
+    static const int fork_env0 = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
+    const bool fork0 = fork_env0 >= 0 ? fork_env0 != 0 : B <= 32;
+    if (fork0) {
+      dev_->Check(sdvl_ctx_fork_mark(dev_->ctx()), "sdvl_ctx_fork_mark");
+      dev_->Check(sdvl_ctx_fork_begin(dev_->ctx()), "sdvl_ctx_fork_begin");
+    }
+    try {
+      Frame::DetectBatch(frames, Config::NumFeatures());
+    } catch (...) {
+      if (fork0) (void)sdvl_ctx_fork_end(dev_->ctx());
+      throw;
+    }
+    if (fork0) dev_->Check(sdvl_ctx_fork_end(dev_->ctx()), "sdvl_ctx_fork_end");
+  }
   // a mapper that looks at the frames it was given (MapperMap: scene depth of every frame, feature lists of keyframes)
   // materialises them on demand; a keyframe's table is rebuilt afterwards in any case
   EpilogueAndMapper(frames, stats, &kfs, &kf_owner, filter_begun);

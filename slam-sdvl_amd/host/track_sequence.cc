@@ -6,7 +6,8 @@
 //   track_sequence --list frames.txt                             one binary PGM (P5, 8 bit) path per line, e.g. a TUM / EuRoC list
 //   common:  [--config file.cfg] [--size W H] [--cam fx fy u0 v0] [--dist d0 d1 d2 d3 d4] [--plane nx ny nz d] [--mapper]
 //   round 5 (bench.py's latency legs):  [--texture plane|camera]  [--trackers N]  N cameras = N host threads, each with its own Device
-//            (= HIP stream), Camera, Map and SDVL, all fed the same frames;  [--prerender]  the synthetic frames are rendered on the GPU
+//            (= HIP stream), Camera, Map and SDVL, all fed the same frames;  [--batch]  with --trackers N: the N cameras step together through
+//            ONE sdvl::SDVLBatch::HandleFrames call per frame on one thread and one stream (the batched form of the same call);  [--prerender]  the synthetic frames are rendered on the GPU
 //            into page-locked host memory before the loop (the window of main.cc:136-138 never contained the rendering anyway; this keeps
 //            a 300-frame run short);  [--pageable]  with --prerender: plain malloc'ed frames, what an unregistered cv::Mat is;
 //            [--set SDVL.key value]  a configuration value (after --config);  [--quiet]  no per-frame lines;  [--json]  one JSON line with the rates;  [--profile]  per-kernel dispatch time and host stages
@@ -66,7 +67,7 @@ int main(int argc, char **argv) {
   double cam4[4] = {517.3, 516.5, 318.6, 255.3}, dist[5] = {0, 0, 0, 0, 0}, plane[4] = {0, 0, 1, 2.0};
   std::string list, cfg;
   bool mapper = false, size_given = false, cam_given = false, dist_given = false;
-  bool prerender = false, pageable = false, quiet = false, json = false, profile = false;
+  bool prerender = false, pageable = false, quiet = false, json = false, profile = false, batch = false;
   int n_trackers = 1;
   std::vector<std::pair<std::string, double>> sets;  // --set SDVL.key value, applied after the configuration file
   unsigned texture = SDVL_TEXTURE_PLANE_NOISE;
@@ -84,6 +85,7 @@ int main(int argc, char **argv) {
     else if (a == "--mapper") mapper = true;
     else if (a == "--texture") { need(1); const std::string t = argv[++i]; if (t == "camera") texture = SDVL_TEXTURE_CAMERA; else if (t != "plane") { std::cerr << "unknown texture " << t << std::endl; return 2; } }
     else if (a == "--trackers") { need(1); n_trackers = std::max(1, std::atoi(argv[++i])); }
+    else if (a == "--batch") batch = true;
     else if (a == "--prerender") prerender = true;
     else if (a == "--pageable") pageable = true;
     else if (a == "--quiet") quiet = true;
@@ -247,8 +249,61 @@ int main(int argc, char **argv) {
         me.err = e.what();
       }
     };
+    // --batch: the N cameras are frames of ONE SDVLBatch::HandleFrames call (one thread, one stream, one launch per kernel for all N)
+    auto run_batch = [&]() {
+      PerTracker &me = per[0];
+      try {
+        Device dev(0);
+        Device::SetCurrent(&dev);
+        Camera camera(W, H, cam4[0], cam4[1], cam4[2], cam4[3]);
+        camera.SetDistortions(dist[0], dist[1], dist[2], dist[3], dist[4]);
+        std::vector<std::unique_ptr<Map>> maps;
+        std::vector<std::unique_ptr<SDVL>> trackers;
+        std::vector<SDVL *> raw;
+        for (int i = 0; i < n_trackers; i++) {
+          if (mapper) maps.emplace_back(new MapperMap(Vector3d(plane[0], plane[1], plane[2]), plane[3], &camera));
+          else maps.emplace_back(new PlaneMap(Vector3d(plane[0], plane[1], plane[2]), plane[3]));
+          trackers.emplace_back(new SDVL(&camera, maps.back().get()));
+          raw.push_back(trackers.back().get());
+        }
+        {
+          SDVLBatch b(&dev, raw, 1);
+          std::vector<FrameStats> st(n_trackers);
+          std::vector<uint8_t> px(pool ? 0 : frame_bytes);
+          for (int k = 0; k < n_frames; k++) {
+            uint8_t *data = px.data();
+            if (pool) data = pool + frame_bytes * k;
+            else if (n_synth > 0) { const sdvl_synth_view v = view_of(k); sdvl_synth_render_host(&v, W, H, px.data(), W); }
+            else { int w = 0, h = 0; if (!ReadPGM(files[k], &w, &h, &px) || w != W || h != H) { me.err = "cannot read " + files[k]; return; } data = px.data(); }
+            Image img;
+            img.data = data; img.cols = W; img.rows = H; img.step = W;
+            std::vector<Image> imgs(n_trackers);
+            for (int i = 0; i < n_trackers; i++) camera.UndistortImage(img, &imgs[i]);  // every camera its own frame in HBM (main.cc:133, outside the window)
+            const auto t0 = std::chrono::steady_clock::now();
+            b.HandleFrames(imgs, st.data());
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (k > 0) {
+              me.busy += dt;
+              for (int i = 0; i < n_trackers; i++) me.tracked += st[i].quality != 2;
+              me.ms.push_back(static_cast<float>(dt * 1e3));
+            }
+            if (!quiet)
+              std::printf("%d %d %d %d %d %d  %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", k, st[0].state, st[0].quality, st[0].matches, st[0].attempts, st[0].inliers,
+                          st[0].pose[0], st[0].pose[1], st[0].pose[2], st[0].pose[3], st[0].pose[4], st[0].pose[5], st[0].pose[6]);
+          }
+        }
+        trackers.clear();
+        maps.clear();
+      } catch (const std::exception &e) {
+        me.err = e.what();
+      }
+    };
     double wall = 0.0;
-    if (n_trackers == 1) {
+    if (batch) {
+      const auto w0 = std::chrono::steady_clock::now();
+      run_batch();
+      wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    } else if (n_trackers == 1) {
       const auto w0 = std::chrono::steady_clock::now();
       run_tracker(0);
       wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
@@ -285,16 +340,19 @@ int main(int argc, char **argv) {
     const auto pct = [&](double q) { return all_ms.empty() ? 0.0 : static_cast<double>(all_ms[std::min(all_ms.size() - 1, static_cast<size_t>(q * all_ms.size()))]); };
     // one camera: tracked frames over the summed HandleFrame time (the window of main.cc:136-138).  N cameras: every camera's own rate is
     // its tracked frames over ITS summed HandleFrame time; the job's rate is all tracked frames over the slowest camera's summed time
-    const double per_camera = busy_sum > 0 ? tracked / busy_sum : 0.0, total = busy_max > 0 ? tracked / busy_max : 0.0;
+    const double total = busy_max > 0 ? tracked / busy_max : 0.0;
+    const double per_camera = batch ? total / n_trackers : (busy_sum > 0 ? tracked / busy_sum : 0.0);
     std::fprintf(stderr, "%d tracked frames in %.3f s of HandleFrame = %.1f tracked frames/s (%d sequence(s), one stream each; per camera %.1f)\n", tracked,
                  busy_max, total, n_trackers, per_camera);
     if (json)
       std::printf("{\"trackers\": %d, \"frames\": %d, \"tracked\": %d, \"frames_per_s\": %.2f, \"frames_per_s_per_camera\": %.2f, \"ms_per_frame_p50\": %.4f, "
                   "\"ms_per_frame_p95\": %.4f, \"ms_per_frame_max\": %.4f, \"wall_s\": %.3f, \"input\": \"%s\", \"texture\": \"%s\", \"width\": %d, \"height\": %d, "
-                  "\"mapper\": %s, \"api\": \"SDVL::HandleFrame per frame (host/track_sequence.cc, the loop of main.cc:126-159)\"}\n",
+                  "\"mapper\": %s, \"api\": \"%s\"}\n",
                   n_trackers, n_frames, tracked, total, per_camera, pct(0.5), pct(0.95), all_ms.empty() ? 0.0 : static_cast<double>(all_ms.back()), wall,
                   pool ? (pool_pinned ? "page-locked host memory" : "pageable host memory") : "host memory of the loop (pageable)",
-                  texture == SDVL_TEXTURE_CAMERA ? "camera" : "plane", W, H, mapper ? "true" : "false");
+                  texture == SDVL_TEXTURE_CAMERA ? "camera" : "plane", W, H, mapper ? "true" : "false",
+                  batch ? "sdvl::SDVLBatch::HandleFrames, one call per frame for all cameras (one thread, one stream)"
+                        : "SDVL::HandleFrame per frame and camera (host/track_sequence.cc, the loop of main.cc:126-159; one thread and stream per camera)");
   } catch (const std::exception &e) {
     std::cerr << "track_sequence: " << e.what() << std::endl;
     return 1;
