@@ -627,6 +627,11 @@ def main():
     latency = None
     if world == 1 and args.latency_frames > 2:
         latency = latency_legs(wl, args.texture, args.latency_frames, args.mapper)   # child processes, before this one touches the GPU
+    # The farm's 16 groups are 16 HIP streams; the runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise,
+    # and kernels of two groups that share a queue run one behind the other.  16 queues: +5 % over three alternating pairs
+    # (profiles/r05/ab_round5.txt: 444 k against 423 k).  Must be in the environment before HIP initialises; a caller's own setting wins.
+    # (The latency legs above run without it: 16 lone cameras on 16 host threads lose with it.)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -1074,7 +1079,7 @@ def main():
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",
                        "texture": args.texture + (": piecewise-smooth shading + soft-edged shapes at three scales (csrc/sdvl_synth.h SDVL_TEXTURE_CAMERA)" if TEXTURE else
                                                   ": five octaves of value noise, a FAST corner on every second tested pixel (rounds 1-4)"),
-                       "look_ahead": not os.environ.get("SDVL_NO_LOOKAHEAD"),
+                       "look_ahead": not os.environ.get("SDVL_NO_LOOKAHEAD"), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "look_ahead_note": "the resident leg names step k+1's images before step k (SDVLBatch::SetNextImages): their pyramids and FAST are queued "
                                           "behind step k's chain; a live SDVL::HandleFrame caller has no next frame - the latency block is measured without it",
                        "chunks": ("%d chunks, texture seeds %d..%d; sequence g follows chunk shard.chunk_for_sequence(g) - one chunk per rank with --gpus %d" %

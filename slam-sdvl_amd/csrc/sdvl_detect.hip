@@ -187,6 +187,7 @@ struct FastLevels {
   int cell_begin[SDVL_MAX_LEVELS + 1];  // first global cell index of each level
   int wcells[SDVL_MAX_LEVELS];
   int cell_size, margin, threshold;
+  int dense_num;  // a cell takes the DENSE path when more than dense_num of 64 probed pixels pass the compass test
 };
 
 // one cell of the detection grid: pyramid level and the ROI left after the image margin (fast_detector.cc:84-92).  Four 32-bit words:
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
       probed = true;
       passed = fast_compass_pass(img[q], img[q + w3], img[q + 3u], img[q - w3], img[q - 3u], t);
     }
-    dense = 2 * __popcll(__ballot(passed)) > __popcll(__ballot(probed));
+    dense = 64 * __popcll(__ballot(passed)) > lv.dense_num * __popcll(__ballot(probed));
   }
   // ---- the tile: lane = (row, half row): 16 pixels = 4 words, so that (lane, word, byte) order is scan order
   const int row = lane >> 1, wbase = (lane & 1) * 4;
@@ -1907,6 +1908,19 @@ int64_t sdvl_detect_scratch_bytes(int width, int height, const sdvl_detect_param
 }
 
 // SDVL_FAST_INT_SCORES=1: the dense path's epilogue on integer scores (round 3's form; A/B measurements, tests)
+// the share (of 64) of a cell's probed pixels that must pass the compass test for the cell to take the dense path
+// (SDVL_FAST_DENSE_NUM: 0 = every cell dense, 64 = every cell through the candidate list; A/B and the sweep of profiles/r05)
+static int fast_cells_dense_num() {
+  static const int v = [] {
+    const char *e = getenv("SDVL_FAST_DENSE_NUM");
+    // 16 of 64: measured (profiles/r05/fast_dense_sweep.txt) — the candidate-list path only pays below ~25 % compass passes; at the
+    // 29 % of the camera-like texture's level 0 (rounds 2-4: threshold 32) it cost 166 us per 256 frames against 155 now, 158 all dense
+    const int n = e ? atoi(e) : 16;
+    return n < 0 ? 0 : (n > 64 ? 64 : n);
+  }();
+  return v;
+}
+
 static bool fast_cells_int_scores() {
   static const bool v = getenv("SDVL_FAST_INT_SCORES") != nullptr;
   return v;
@@ -1983,6 +1997,7 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
   lv.cell_size = p->cell_size;
   lv.margin = p->margin;
   lv.threshold = p->fast_threshold < 0 ? 0 : (p->fast_threshold > 255 ? 255 : p->fast_threshold);
+  lv.dense_num = fast_cells_dense_num();
   int total_cells = 0;
   for (int l = 0; l < lv.n_levels; l++) {
     SDVL_REQUIRE(ctx, l < frames[0]->v.levels, "max_fast_levels exceeds the pyramid depth");
@@ -2093,6 +2108,7 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   lv.cell_size = sl.cell_size = p->cell_size;
   lv.margin = sl.margin = p->margin;
   lv.threshold = p->fast_threshold < 0 ? 0 : (p->fast_threshold > 255 ? 255 : p->fast_threshold);
+  lv.dense_num = fast_cells_dense_num();
   // level quotas, fast_detector.cc:161-174
   const double scale = 1.2;
   double factor = 1.0, val = 0.0;
