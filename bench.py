@@ -581,9 +581,12 @@ def main():
                     help="run the reference's mapper (map.cc, sequential mode) inside every step instead of the plane map stub")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (0 = skip, -1 = the workload's)")
     ap.add_argument("--sustained-frames", type=int, default=-1,
-                    help="frames per sequence of the third, SUSTAINED leg: fresh trackers run a whole sequence of SURVEY §8d's S-A (300 frames, "
-                         "~60 keyframes each, every keyframe keeps its HBM frame) host-fed from a pool of distinct sequences; reported as "
-                         "value_sustained with keyframes per sequence and the HBM / RSS peaks; 0 = skip; default 300 for S-A on one GPU")
+                    help="frames per sequence of the third, SUSTAINED leg: fresh trackers run long sequences (two lengths of SURVEY §8d's S-A: 600 frames) "
+                         "host-fed from a pool of distinct sequences, with SDVL.max_keyframes = --sustained-max-keyframes so that the map — and with "
+                         "it HBM and host memory — stops growing; reported as value_sustained with the memory in use at the middle and at the end; "
+                         "0 = skip; default 600 for S-A on one GPU")
+    ap.add_argument("--sustained-max-keyframes", type=int, default=48,
+                    help="SDVL.max_keyframes of the sustained leg (the reference's cfg files say 1000, its default is 100: config.cc:63); 0 = the workload's")
     ap.add_argument("--host-steps", type=int, default=-1,
                     help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
@@ -618,7 +621,7 @@ def main():
         # PCIe roots.  8 steps per rank on several GPUs (10 GB of pinned memory each, allocated after the NUMA binding), 16 on one
         args.host_steps = 16 if world == 1 else 8
     if args.sustained_frames < 0:
-        args.sustained_frames = 300 if (world == 1 and args.workload == "S-A" and not args.mapper and not dry) else 0
+        args.sustained_frames = 600 if (world == 1 and args.workload == "S-A" and not args.mapper and not dry) else 0
     dist = None
     if dry:
         return dry_rank(args, rank, world)
@@ -916,10 +919,13 @@ def main():
         torch.cuda.synchronize()
         free0, total0 = torch.cuda.mem_get_info()
         D = min(B, int(os.environ.get("SDVL_BENCH_SUSTAINED_DISTINCT", "32")))
+        max_kf = args.sustained_max_keyframes
         kf_budget = NF // 4 + 8             # S-A turns about one frame in five into a keyframe
+        if max_kf > 0:
+            kf_budget = min(kf_budget, max_kf + 8)   # PlaneMap::LimitKeyframes hands the culled keyframes' HBM frames back to the pool
         need2 = G * Bg * kf_budget * footprint + 3 * B * frame_bytes + B * scratch_per_frame
-        # host side: every keyframe keeps ~270 KB of Feature / Point objects (the reference's own representation): 4096 x 69 = 76 GB
-        host_need = B * (NF / 4.3) * 290e3 + D * NF * frame_bytes
+        # host side: every keyframe keeps ~270 KB of Feature / Point objects (the reference's own representation)
+        host_need = B * min(NF / 4.3, kf_budget) * 290e3 + D * NF * frame_bytes
         host_free = host_memory_available()
         if need2 > 0.9 * free0:
             sys.stderr.write("bench.py: sustained leg skipped: %d sequences x ~%d keyframes x %.2f MB = %.0f GB of HBM, %.0f GB free\n" %
@@ -928,6 +934,8 @@ def main():
             sys.stderr.write("bench.py: sustained leg skipped: %d sequences x %d frames need about %.0f GB of host memory (keyframe objects), %.0f GB available\n" %
                              (B, NF, host_need / 1e9, host_free / 1e9))
         else:
+            if max_kf > 0:
+                trk.configure(dict(trk.TUM_OVERRIDES, **dict(wl["over"], **{"SDVL.max_keyframes": max_kf})))
             farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
             farm.set_fibers(fibers)
             ctx2 = CtxView(pkg, farm.ctx_handle(0))
@@ -944,19 +952,42 @@ def main():
             farm.reserve(Bg * kf_budget)
             farm.run(sptrs[:1 + Wm], workers)                      # bootstrap keyframe + warm-up, untimed
             Ks = NF - 1 - Wm
-            sbuf = farm.alloc_stats(Ks)
+            half = Ks // 2                                         # the timed region in two halves: memory is read in between
+            sbuf = farm.alloc_stats(Ks - half)
+
+            def mem_now():
+                torch.cuda.synchronize()
+                fr, _ = torch.cuda.mem_get_info()
+                rss = 0.0
+                try:
+                    for line in open("/proc/self/status"):
+                        if line.startswith("VmRSS:"):
+                            rss = int(line.split()[1]) / 1e6
+                except (OSError, ValueError):
+                    pass
+                return round((total0 - fr) / 1e9, 1), round(rss, 1)
             barrier()
             t0 = time.perf_counter()
-            sstats = farm.run(sptrs[1 + Wm:], workers, sbuf)
+            sstats_a = farm.run(sptrs[1 + Wm:1 + Wm + half], workers, sbuf)
             barrier()
-            elapsed_s = time.perf_counter() - t0
-            free1, _ = torch.cuda.mem_get_info()
-            tracked_s = sum(int(st.quality != 2) for st in sstats)
-            kf_s = sum(int(st.keyframe) for st in sstats)
+            elapsed_a = time.perf_counter() - t0
+            tracked_s = sum(int(st.quality != 2) for st in sstats_a[:half * B])
+            kf_s = sum(int(st.keyframe) for st in sstats_a[:half * B])
+            mem_mid = mem_now()
+            barrier()
+            t0 = time.perf_counter()
+            sstats_b = farm.run(sptrs[1 + Wm + half:], workers, sbuf)
+            barrier()
+            elapsed_s = elapsed_a + (time.perf_counter() - t0)
+            tracked_s += sum(int(st.quality != 2) for st in sstats_b[:(Ks - half) * B])
+            kf_s += sum(int(st.keyframe) for st in sstats_b[:(Ks - half) * B])
+            mem_end = mem_now()
             sustained = {"value": round(tracked_s / elapsed_s, 2), "unit": "frames/s", "frames_per_sequence": NF, "timed_steps": Ks, "ms_per_step": round(elapsed_s / Ks * 1e3, 3),
                          "sequences_per_gpu": B, "tracked_fraction": round(tracked_s / (B * Ks), 5),
-                         "keyframes_per_sequence": round(1 + kf_s / B * (NF - 1) / Ks, 1), "hbm_bytes_per_keyframe": int(footprint), "corner_capacity": corner_cap,
-                         "hbm_used_gb_at_end": round((total0 - free1) / 1e9, 1), "hbm_total_gb": round(total0 / 1e9, 1),
+                         "max_keyframes": max_kf if max_kf > 0 else "the workload's (never reached)",
+                         "keyframes_made_per_sequence": round(1 + kf_s / B * (NF - 1) / Ks, 1), "hbm_bytes_per_keyframe": int(footprint), "corner_capacity": corner_cap,
+                         "hbm_used_gb_at_frame_%d" % (1 + Wm + half): mem_mid[0], "hbm_used_gb_at_end": mem_end[0], "hbm_total_gb": round(total0 / 1e9, 1),
+                         "host_rss_gb_at_frame_%d" % (1 + Wm + half): mem_mid[1], "host_rss_gb_at_end": mem_end[1],
                          "host_max_rss_gb": round(_res.getrusage(_res.RUSAGE_SELF).ru_maxrss / 1e6, 1),
                          "pcie_h2d_gb_per_s": round(B * Ks * frame_bytes / elapsed_s / 1e9, 2),
                          "input": "host-fed through the input ring from %d distinct sequences x %d frames in pinned host memory (tracker i follows sequence i mod %d)" % (D, NF, D)}

@@ -341,6 +341,7 @@ struct Tracker {
               keyframes.push_back(current);
               map_last_kf = current;
               last_kf = current;
+              PlaneLimitKeyframes(current);
               SeedPoints(current);  // plane map stub instead of the mapper, outside the reference's timing window
             }
             st.keyframe = 1;
@@ -377,15 +378,43 @@ struct Tracker {
     return false;
   }
 
+  // The plane-map stub honours max_keyframes the way Map::LimitKeyframes does (map.cc:190-205,692-706): once the list is full the
+  // keyframe furthest from the new one is culled — and, the stub being the owner of the points it seeded there, the points whose
+  // first observation lies in that keyframe are deleted with it (slam-sdvl_amd/host/sdvl_host.h, PlaneMap).  `max_keyframes` here
+  // is the tracker's field (use_mapper's argument, or set_max_keyframes); the reference's cfg files say 1000.
+  std::vector<std::shared_ptr<RFrame>> plane_culled;
+  void PlaneLimitKeyframes(const std::shared_ptr<RFrame> &frame) {
+    if (static_cast<int>(keyframes.size()) < max_keyframes) return;
+    const Vec3 pos = frame->WorldPosition();
+    std::shared_ptr<RFrame> kf;
+    double maxdist = 0.0;
+    for (auto &k : keyframes) {
+      const double dist = Norm(k->WorldPosition() - pos);
+      if (dist > maxdist) { maxdist = dist; kf = k; }
+    }
+    if (!kf || kf == frame) return;
+    kf->del = true;
+    plane_culled.push_back(kf);
+  }
+
   // Map::EmptyTrash (points part), map.cc:207-259
   void EmptyTrash() {
     EmptyFrameTrash();
+    for (auto &kf : plane_culled) {
+      for (auto &f : kf->features)
+        if (f && f->point && !f->point->del && f->point->init_feature == f) points_trash.push_back(f->point);
+      for (auto it = keyframes.begin(); it != keyframes.end(); it++)
+        if (*it == kf) { keyframes.erase(it); break; }
+      keepalive.push_back(kf);  // (features of other points still name the frame by raw pointer; nothing reads it any more)
+    }
     for (auto &p : points_trash) {
       for (auto &f : p->features) f->point = nullptr;
       p->features.clear();
       p->del = true;
     }
     points_trash.clear();
+    for (auto &kf : plane_culled) kf->features.clear();
+    plane_culled.clear();
   }
 
 

@@ -261,6 +261,10 @@ void *sdvl_ref_tracker_create(const sdvl_ref_params *p, int w, int h, const doub
   return new Tracker(ToParams(p), ToCam(cam, w, h), pl, ToSE3(first_pose7));
 }
 void sdvl_ref_tracker_destroy(void *t) { delete static_cast<Tracker *>(t); }
+// SDVL.max_keyframes for the plane-map stub too (Tracker::PlaneLimitKeyframes); the reference's default is 100 (config.cc:63),
+// its cfg files say 1000
+void sdvl_ref_tracker_set_max_keyframes(void *t, int max_keyframes) { static_cast<sdvlref::Tracker *>(t)->max_keyframes = max_keyframes; }
+
 // switch the tracker to the reference's mapper in sequential mode (SDVL::Mapping after every frame, main.cc:148-149)
 void sdvl_ref_tracker_use_mapper(void *t, int on, int max_search_keyframes, int max_keyframes, double map_scale, double scale_min_dist) {
   Tracker *tr = static_cast<Tracker *>(t);

@@ -85,6 +85,7 @@ int sdvl_ref_pose_from_matches(const sdvl_ref_params *p, int w, int h, const dou
 void *sdvl_ref_tracker_create(const sdvl_ref_params *p, int w, int h, const double *cam, const double *plane4,
                               const double *first_pose7);
 void sdvl_ref_tracker_destroy(void *t);
+void sdvl_ref_tracker_set_max_keyframes(void *t, int max_keyframes);
 void sdvl_ref_tracker_use_mapper(void *t, int on, int max_search_keyframes, int max_keyframes, double map_scale, double scale_min_dist);
 void sdvl_ref_tracker_map_stats(void *t, int *out6);
 int sdvl_ref_tracker_mapper_points(void *t, int cap, double *out_xyzc);

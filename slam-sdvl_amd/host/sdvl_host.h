@@ -30,10 +30,18 @@ class PlaneMap : public Map {
   void InitCandidates(const std::shared_ptr<Frame> &kf) override;
   void SeedFromFiltered(const std::shared_ptr<Frame> &kf);  // after Frame::FilterCorners()
   void SetPlane(const Vector3d &n, double d) { n_ = n; d_ = d; }
+  // Round 5: the stub honours SDVL.max_keyframes like the reference's map (map.cc:190-205,692-706: once the list is full, the
+  // keyframe furthest from the new one goes to the trash) — and, being the owner of the points it seeded there, deletes the points
+  // whose FIRST observation lies in the culled keyframe with it (the reference keeps a culled keyframe's image alive for as long as
+  // any point names it; here the HBM frame goes back to the pool, so whole sequences run in bounded memory).  The oracle's plane
+  // map does the same (oracle/ref_tracker.h); with the reference's cfg values (max_keyframes 1000) S-A never gets there.
+  void LimitKeyframes(const std::shared_ptr<Frame> &frame) override;
+  void EmptyTrash() override;
 
  private:
   Vector3d n_;
   double d_;
+  std::vector<std::shared_ptr<Frame>> culled_;
 };
 
 // map.h:44-139 — the reference's mapper in SEQUENTIAL mode (main.cc:148-149: SDVL::Mapping() = Map::UpdateMap() after every

@@ -201,6 +201,45 @@ void Map::EmptyTrash() {
   points_trash_.clear();
 }
 
+// map.cc:190-205,692-706 for the plane-map stub (see sdvl_host.h)
+void PlaneMap::LimitKeyframes(const shared_ptr<Frame> &frame) {
+  if (static_cast<int>(keyframes_.size()) < Config::MaxKeyframes()) return;
+  const Vector3d pos = frame->GetWorldPosition();
+  shared_ptr<Frame> kf;
+  double maxdist = 0.0;
+  for (auto it = keyframes_.begin(); it != keyframes_.end(); it++) {
+    const Vector3d q = (*it)->GetWorldPosition();
+    const double dist = vnorm({q(0) - pos(0), q(1) - pos(1), q(2) - pos(2)});
+    if (dist > maxdist) {
+      maxdist = dist;
+      kf = *it;
+    }
+  }
+  if (!kf || kf == frame) return;
+  kf->SetDelete();
+  culled_.push_back(kf);
+}
+
+void PlaneMap::EmptyTrash() {
+  for (const shared_ptr<Frame> &kf : culled_) {
+    // the points this keyframe seeded (their first observation is one of its features) go with it
+    vector<shared_ptr<Feature>> &features = kf->GetFeatures();
+    for (auto it = features.begin(); it != features.end(); it++) {
+      if (!*it) continue;
+      shared_ptr<Point> p = (*it)->GetPoint();
+      if (p && !p->ToDelete() && p->GetInitFeature() == *it) DeletePoint(p);
+    }
+    for (auto it = keyframes_.begin(); it != keyframes_.end(); it++)
+      if (*it == kf) {
+        keyframes_.erase(it);
+        break;
+      }
+  }
+  Map::EmptyTrash();  // (clears the doomed points' feature lists, the culled keyframe's features among them)
+  for (const shared_ptr<Frame> &kf : culled_) kf->RemoveFeatures();
+  culled_.clear();
+}
+
 void PlaneMap::InitCandidates(const shared_ptr<Frame> &kf) {
   kf->FilterCorners();
   SeedFromFiltered(kf);

@@ -253,6 +253,10 @@ class OracleTracker:
         self.lib.sdvl_ref_tracker_handle_frame(C.c_void_p(self.h_), ptr(img, u8p), self.w, C.byref(st))
         return st
 
+    def set_max_keyframes(self, n):
+        """SDVL.max_keyframes (the plane-map stub honours it like Map::LimitKeyframes, map.cc:190-205)"""
+        self.lib.sdvl_ref_tracker_set_max_keyframes(C.c_void_p(self.h_), int(n))
+
     def use_mapper(self, on=True, max_search_keyframes=5, max_keyframes=100, map_scale=1.0, scale_min_dist=0.25):
         """the reference's mapper in sequential mode (map.cc) instead of the plane map stub"""
         self.lib.sdvl_ref_tracker_use_mapper(C.c_void_p(self.h_), int(on), int(max_search_keyframes), int(max_keyframes),

@@ -175,3 +175,38 @@ def test_one_camera_through_handleframe_on_the_camera_texture(orc, synth, env, e
     summary = json.loads(lines[-1])
     n_trk = int(extra[1]) if extra else 1
     assert summary["trackers"] == n_trk and summary["tracked"] == n_trk * (n - 1) and summary["frames_per_s"] > 0
+
+
+@pytest.mark.parametrize("texture", [0, 1])
+def test_plane_map_honours_max_keyframes_like_the_oracle(trk, orc, synth, texture):
+    """SDVL.max_keyframes on the plane-map stub (PlaneMap::LimitKeyframes, round 5): once 10 keyframes are held, the one furthest from
+    every new keyframe is culled together with the points it seeded — on the device-resident tables that is a table rebuild for the
+    trackers that still had rows of those points.  Decisions and poses equal the oracle's over 110 frames (~20 keyframes, ~10 culled)."""
+    over = dict(trk.TUM_OVERRIDES)
+    over["SDVL.max_keyframes"] = 10
+    trk.configure(over)
+    try:
+        dev = trk.HostDevice(0)
+        B = 3
+        xis = [XI * (1.0 + 0.1 * i) * (1 if i % 2 == 0 else -1) for i in range(B)]
+        batch = trk.TrackerBatch(dev, B, 640, 480, TUM_CAM)
+        refs = [orc.tracker(640, 480, TUM_CAM) for _ in range(B)]
+        for r in refs:
+            r.set_max_keyframes(10)
+        n_kf = 0
+        for k in range(110):
+            imgs = [synth.render(trajectory_pose(orc, k, xis[i]), TUM_CAM, 640, 480, seed=20260001 + i, frame_id=k, texture=texture) for i in range(B)]
+            got = batch.step_host(imgs)
+            for i in range(B):
+                w = refs[i].handle_frame(imgs[i])
+                assert record(got[i]) == record(w), (k, i, record(got[i]), record(w))
+                assert np.abs(np.array(got[i].pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, (k, i)
+                if k > 0:
+                    assert got[i].quality == 0 and got[i].matches >= 100
+            n_kf += got[0].keyframe
+        assert n_kf >= 16, n_kf           # well past the cap: the culling path ran
+        batch.close(); dev.close()
+        for r in refs:
+            r.close()
+    finally:
+        trk.configure()
