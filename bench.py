@@ -375,9 +375,9 @@ def latency_legs(wl, texture, n_frames, mapper=False):
     if mapper:
         base.append("--mapper")
     out = {}
-    for name, n in (("b1", 1), ("b16", 16)):
+    for name, n, extra in (("b1", 1, []), ("b16", 16, []), ("b16_batched", 16, ["--batch"])):
         try:
-            r = subprocess.run(base + ["--trackers", str(n)], capture_output=True, text=True, timeout=600)
+            r = subprocess.run(base + ["--trackers", str(n)] + extra, capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 sys.stderr.write("bench.py: latency leg %s failed (rc %d): %s\n" % (name, r.returncode, r.stderr[-400:]))
@@ -396,7 +396,13 @@ def latency_legs(wl, texture, n_frames, mapper=False):
     if "b16" in out:
         blk.update({"b16_frames_per_s": out["b16"]["frames_per_s"], "b16_frames_per_s_per_camera": out["b16"]["frames_per_s_per_camera"],
                     "b16_ms_per_frame_p50": out["b16"]["ms_per_frame_p50"], "b16_ms_per_frame_p95": out["b16"]["ms_per_frame_p95"],
-                    "b16_tracked": out["b16"]["tracked"]})
+                    "b16_tracked": out["b16"]["tracked"],
+                    "b16_note": "16 cameras = 16 host threads, each its own Device (HIP stream) and SDVL::HandleFrame loop"})
+    if "b16_batched" in out:
+        blk.update({"b16_batched_frames_per_s": out["b16_batched"]["frames_per_s"], "b16_batched_ms_per_step_p50": out["b16_batched"]["ms_per_frame_p50"],
+                    "b16_batched_ms_per_step_p95": out["b16_batched"]["ms_per_frame_p95"],
+                    "b16_batched_note": "the same 16 cameras through ONE sdvl::SDVLBatch::HandleFrames call per frame (one thread, one stream, one launch "
+                                        "per kernel for all 16): what a caller with several cameras should use"})
     return blk
 
 
@@ -1015,7 +1021,7 @@ def main():
                "checker_build": {"flags": "-O3 -march=x86-64-v3 -ffp-contract=off", "value": round(fps_chk, 2), "one_core": round(fps1, 2)}}
 
     if latency and cpu:
-        for b in ("b1", "b16"):
+        for b in ("b1", "b16", "b16_batched"):
             if b + "_frames_per_s" in latency:
                 latency[b + "_vs_cpu_one_core"] = round(latency[b + "_frames_per_s"] / cpu["one_core"], 2)
         latency["target"] = "north_star: >= 30 x the CPU reference path for one camera = %.0f frames/s here" % (30 * cpu["one_core"])

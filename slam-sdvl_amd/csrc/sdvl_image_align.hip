@@ -1635,7 +1635,11 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
     ctx->err = "too many features in one alignment job (SDVL_MAX_ALIGN_FEATURES)";
     return SDVL_ERR_CAPACITY;
   }
-  const int kw = max_nf > kLdsMaxF ? 4 : 1;  // configuration C's ~850 features per job: four waves share them
+  // configuration C's ~850 features per job: four waves share them.  Round 5: so do the jobs of a SMALL batch (a lone camera's
+  // HandleFrame): one feature per lane instead of three rounds per lane shortens every Gauss-Newton evaluation of a chain that has the
+  // chip to itself; a farm's launches of hundreds of jobs keep one wave per job (fewer instructions in total).  SDVL_IA_SMALL_WAVES=1|4
+  static const int small_kw = getenv("SDVL_IA_SMALL_WAVES") ? atoi(getenv("SDVL_IA_SMALL_WAVES")) : 4;
+  const int kw = (max_nf > kLdsMaxF || (n_jobs <= 32 && small_kw == 4)) ? 4 : 1;
   const int max_f = max_nf <= 0 ? 64 * kw : (max_nf + 64 * kw - 1) / (64 * kw) * (64 * kw);
   // PrecomputePatches of all levels as a wide launch in front of the Gauss-Newton chains (SDVL_IA_PRE=0: inside the chain, A/B)
   static const bool pre = !(getenv("SDVL_IA_PRE") && atoi(getenv("SDVL_IA_PRE")) == 0);
@@ -1657,7 +1661,7 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
   }
   const Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
-  sdvl_timer_events(ctx, kw == 4 ? "image_align_big" : "image_align", &ev_a, &ev_b);
+  sdvl_timer_events(ctx, max_nf > kLdsMaxF ? "image_align_big" : "image_align", &ev_a, &ev_b);
   const size_t lds = ia_wave_lds_bytes(max_f, true);
   if (pre) {
     SDVL_LAUNCH(ctx, "image_align_pre", image_align_track_pre_kernel, dim3(static_cast<unsigned>(n_jobs) * n_lv), dim3(256), d_jobs, d_points, d_feats0, d_feats1,
