@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--seqs", "32", "--cpu-frames", "12", "--sustained-frames", "40",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--seqs", "32", "--cpu-frames", "12", "--sustained-frames", "40", "--latency-frames", "12",
                           *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -19,7 +19,7 @@ def run_bench(*extra):
     return json.loads(lines[0])
 
 
-def check(d, steps=4, warmup=1):
+def check(d, steps=4, warmup=1, mapper=False):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -57,7 +57,19 @@ def check(d, steps=4, warmup=1):
     if d["sustained"] is not None:   # whole sequences on fresh trackers, host-fed (skipped with the reference's mapper in the step)
         u = d["sustained"]
         assert d["value_sustained"] == u["value"] > 0 and u["frames_per_sequence"] == 40 and u["timed_steps"] == 40 - 1 - warmup
-        assert u["tracked_fraction"] > 0.99 and 2 <= u["keyframes_per_sequence"] <= 20 and u["hbm_bytes_per_keyframe"] < 800000
+        assert u["tracked_fraction"] > 0.99 and 2 <= u["keyframes_made_per_sequence"] <= 20 and u["hbm_bytes_per_keyframe"] < 800000
+        assert u["max_keyframes"] == 48 and u["hbm_used_gb_at_end"] > 0 and u["host_rss_gb_at_end"] > 0
+    # round 5: the counters the line quotes say whether the kernels changed since they were taken (None: no stamp committed)
+    assert "traffic_stale" in r and r["traffic_stale"] in (None, True, False)
+    if r["traffic_stale"] is not None:
+        assert "changed_files" in r["traffic_stale_detail"]
+    assert d["config"]["texture"].split(":")[0] in ("plane", "camera") and d["config"]["look_ahead"] in (True, False)
+    # round 5: the reference's own shape of use — one camera through SDVL::HandleFrame — and 16 cameras, threads and batched
+    lat = d["latency"]
+    if not mapper:
+        assert lat is not None and lat["b1_tracked"] == 11 and lat["b1_frames_per_s"] > 200 and lat["b16_tracked"] == 16 * 11
+        assert lat["b16_batched_frames_per_s"] > lat["b1_frames_per_s"]          # 16 cameras in one call outrun one camera
+        assert abs(lat["b1_vs_cpu_one_core"] - lat["b1_frames_per_s"] / d["cpu_baseline"]["one_core"]) < 0.02
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "tracked frames/s" and "sample" in c
     assert 0 < c["one_core"] <= c["value"] * 1.05   # the all-core figure is at least the one-core figure
@@ -76,4 +88,13 @@ def test_bench_line_contract_with_the_drivers_warmup():
 
 
 def test_bench_line_contract_mapper_and_fibers():
-    check(run_bench("--mapper", "--groups", "4", "--workers", "2", "--fibers", "2"))
+    check(run_bench("--mapper", "--groups", "4", "--workers", "2", "--fibers", "2", "--latency-frames", "0"), mapper=True)
+
+
+def test_bench_line_contract_s_b_on_the_camera_texture():
+    """BASELINE config 4's workload (S-B: 752x480, config_euroc.cfg) on the camera-like texture"""
+    d = run_bench("--workload", "S-B", "--texture", "camera", "--sustained-frames", "0")
+    check(d)
+    assert d["metric"].startswith("tracked frames/sec (752x480") and d["config"]["workload"].startswith("S-B")
+    assert d["config"]["texture"].startswith("camera") and "20260010" in d["config"]["chunks"]
+    assert 2000 < d["config"]["fast_keypoints_per_frame"] < 8000
