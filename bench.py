@@ -174,12 +174,24 @@ def algorithmic_bytes_per_frame(kernel, n_c, n_f, n_s, i_ia, i_fa, n_m=190, n_kp
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz
 
 
-def _pmc_rows(fname):
-    """rows of the newest committed profiles/rNN/<fname> (written by tools/summarize_profiles.py from separate --pmc passes)"""
-    import csv
+PROFILE_TAG = "sa_plane"    # which committed profile belongs to this run: profiles/rNN/<workload>_<texture>/ (main() sets it)
+
+
+def _profile_files(fname):
+    """committed profile files for this run's workload and texture, oldest first: profiles/rNN/<tag>/<fname> (round 5 on), and for S-A
+    on the plane texture also rounds 1-4's profiles/rNN/<fname>"""
     import glob
     root = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", fname)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", PROFILE_TAG, fname)))
+    if PROFILE_TAG == "sa_plane":
+        files = sorted(glob.glob(os.path.join(root, "profiles", "r*", fname))) + files
+    return files, root
+
+
+def _pmc_rows(fname):
+    """rows of the newest committed <fname> for this workload and texture (written by tools/summarize_profiles.py from separate --pmc passes)"""
+    import csv
+    files, root = _profile_files(fname)
     if not files:
         return [], None
     with open(files[-1]) as fh:
@@ -187,13 +199,11 @@ def _pmc_rows(fname):
 
 
 def profile_staleness():
-    """(stale, detail): were the committed PMC passes (newest profiles/rNN/source_stamp.json) taken on the kernel sources of THIS tree,
-    on this workload and texture?  stale = None when no stamp is committed (rounds 1-4's profiles carry none)."""
-    import glob
-    root = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "source_stamp.json")))
+    """(stale, detail): were the committed PMC passes of this workload and texture (newest profiles/rNN/<tag>/source_stamp.json) taken on
+    the kernel sources of THIS tree?  stale = None when no stamp is committed for it (rounds 1-4's profiles carry none)."""
+    files, root = _profile_files("source_stamp.json")
     if not files:
-        return None, "no profiles/rNN/source_stamp.json committed"
+        return None, "no source_stamp.json committed for %s" % PROFILE_TAG
     try:
         st = json.load(open(files[-1]))
         stamp = importlib.import_module("slam-sdvl_amd.stamp").kernel_source_stamp()
@@ -603,6 +613,8 @@ def main():
     W_IMG, H_IMG, TUM_CAM, FEATS_LABEL = wl["w"], wl["h"], np.array(wl["cam"]), wl["label"]
     ORACLE_PARAMS = {k.split(".")[1]: v for k, v in wl["over"].items()}
     TEXTURE = TEXTURES[args.texture]
+    global PROFILE_TAG
+    PROFILE_TAG = "%s_%s" % (args.workload.lower().replace("-", ""), args.texture)
     seq_choices = [args.seqs] if args.seqs > 0 else list(wl["seqs"])
     args.seqs = seq_choices[0]
     if args.cpu_frames < 0:
@@ -1055,10 +1067,7 @@ def main():
             # the counters need rocprofv3 passes of their own (tools/profile_round.sh): the line quotes the committed ones when they were taken
             # on this workload and texture, and says whether the kernels have changed since (traffic_stale)
             stale, stale_detail = profile_staleness()
-            same_input = isinstance(stale_detail, dict) and stale_detail.get("profiled_workload") in (None, args.workload) and \
-                stale_detail.get("profiled_texture") in (None, args.texture)
-            if stale is None:
-                same_input = args.workload == "S-A" and args.texture == "plane"     # rounds 1-4's passes: S-A on the plane texture
+            same_input = True     # _pmc_rows only finds passes of this workload and texture (profiles/rNN/<tag>/)
             if per_frame is not None:
                 bytes_per_launch = per_frame * frames_per_launch
                 achieved = bytes_per_launch / avg_s / 1e9
@@ -1083,6 +1092,27 @@ def main():
                     "path_insts_per_frame": int(valu["path_insts_per_frame"]),
                     "path_frac": round(valu["path_insts_per_frame"] * (tracked_all / elapsed_max / world) / VALU_PEAK_WAVE_INSTS, 4),
                     "insts_per_frame": {k: int(v["insts_per_frame"]) for k, v in sorted(valu["kernels"].items(), key=lambda kv: -kv[1]["insts_per_frame"])[:8]}}
+            # With 16 hardware queues (round 5) sixteen kernels run side by side and every dispatch stretches; the kernel with the most
+            # dispatch TIME is then a short one launched four times per step (pyr_down), not the one that does the most WORK.  Beside the
+            # contract's kernel the line therefore names the kernel with the most vector instructions per frame (committed SQ pass) with the
+            # same figures, its launch duration from the warm-up steps in which every dispatch carried events.
+            if valu and valu["kernels"] and warm_timers:
+                hv = max(valu["kernels"].items(), key=lambda kv: kv[1]["insts_per_frame"])[0]
+                if hv in warm_timers and warm_timers[hv][1] > 0:
+                    hv_avg_s = warm_timers[hv][0] / warm_timers[hv][1] * 1e-3
+                    hv_fpl = B / (warm_timers[hv][1] / max(1, Wt))
+                    hv_pf = algorithmic_bytes_per_frame(hv, n_c / frames_rank, n_f / frames_rank, n_s / frames_rank, n_ia / frames_rank, n_lk / max(1, n_s),
+                                                        n_m / frames_rank, n_kp_measured)
+                    if hv_pf:
+                        hv_traffic, _ = pmc_traffic_bytes(hv, hv_fpl)
+                        roofline["heaviest_by_instructions"] = {
+                            "kernel": hv, "insts_per_frame": int(valu["kernels"][hv]["insts_per_frame"]),
+                            "share_of_path_insts": round(valu["kernels"][hv]["insts_per_frame"] / valu["path_insts_per_frame"], 3),
+                            "avg_launch_us": round(hv_avg_s * 1e6, 2), "frames_per_launch": round(hv_fpl, 1),
+                            "algorithmic_bytes_per_launch": int(hv_pf * hv_fpl), "achieved": round(hv_pf * hv_fpl / hv_avg_s / 1e9, 2),
+                            "frac": round(hv_pf * hv_fpl / hv_avg_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": hv_traffic,
+                            "valu_frac": round(valu["kernels"][hv]["insts_per_dispatch"] * hv_fpl / valu["frames_per_dispatch"] / hv_avg_s / VALU_PEAK_WAVE_INSTS, 4),
+                            "timed": "the last %d warm-up step(s), every dispatch timed" % Wt}
             # the whole path against HBM: all kernels' algorithmic bytes per tracked frame x frames/s
             path_bytes = 0.0
             for k in all_ms_per_step:

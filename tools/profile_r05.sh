@@ -23,4 +23,5 @@ if [ -z "${SKIP_PMC:-}" ]; then
   find $O/prof_fetch $O/prof_write $O/prof_sq -name "*kernel_trace.csv" -delete
 fi
 python3 tools/summarize_profiles.py $O $O/summary
+rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/prof_sq   # the raw counter files are tens of MB; gpurun_out/ travels back only below 64 MiB
 ls -la $O/summary
