@@ -1332,19 +1332,19 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 
 // The alignment of a tracked step straight from the tracking tables (sdvl_track.hip): job j = tracker record j of the step; its
 // features are the rows of last_frame's feature buffer, its items live in slice j of the work buffer (`item_pitch` features each).
 // No IaJob records, no feature records, no launch in between (track_align_prep + one stage_push per group-step until round 3).
-template <int kWaves>
+// kGlobalItems = false (round 5, SDVL_IA_TRACK_FUSED=1): the reference items of the level being optimised live in LDS (48 floats per feature)
+// and PrecomputePatches runs inside the chain — no image_align_pre launch, nothing handed through L2 / HBM between two kernels
+template <int kWaves, bool kGlobalItems = true>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_track_kernel(
     const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points, const TrackFeat *__restrict__ feats0, const TrackFeat *__restrict__ feats1,
     int np, int nfeat_cap, Cam cam, sdvl_align_params prm, int max_f, float *__restrict__ items, sdvl_align_result *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   const TrackJobDev &jb = jobs[blockIdx.x];
-  const size_t pitch = static_cast<size_t>((jb.n_feat + 63) / 64 * 64);
-  (void)pitch;
   const IaIn in{jb.last_level, jb.cur.level, jb.cur.lw, jb.cur.lh, jb.n_feat, jb.T0,
-                items + static_cast<size_t>(blockIdx.x) * 48 * static_cast<size_t>(max_f), out + blockIdx.x};
+                kGlobalItems ? items + static_cast<size_t>(blockIdx.x) * 48 * static_cast<size_t>(max_f) : nullptr, out + blockIdx.x};
   const IaTableFeats F{(jb.feat_buf ? feats1 : feats0) + static_cast<size_t>(jb.tracker) * nfeat_cap, points + static_cast<size_t>(jb.tracker) * np,
                        se3_inverse(se3_from7(jb.last_pose)).t};
-  ia_wave_body<kWaves, true, false>(in, F, cam, prm, max_f, s_dyn);
+  ia_wave_body<kWaves, kGlobalItems, false>(in, F, cam, prm, max_f, s_dyn);
 }
 
 // the same two kernels for a tracked step: features out of the tracking tables
@@ -1642,7 +1642,12 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
   const int kw = (max_nf > kLdsMaxF || (n_jobs <= 32 && small_kw == 4)) ? 4 : 1;
   const int max_f = max_nf <= 0 ? 64 * kw : (max_nf + 64 * kw - 1) / (64 * kw) * (64 * kw);
   // PrecomputePatches of all levels as a wide launch in front of the Gauss-Newton chains (SDVL_IA_PRE=0: inside the chain, A/B)
-  static const bool pre = !(getenv("SDVL_IA_PRE") && atoi(getenv("SDVL_IA_PRE")) == 0);
+  // SDVL_IA_TRACK_FUSED=1 (round 5, measured): no precompute launch and the items of the level at hand in LDS — jobs of up to
+  // kLdsMaxF features only (48 floats per feature: 47 KB of LDS for S-A's 192)
+  static const bool fused_env = getenv("SDVL_IA_TRACK_FUSED") && atoi(getenv("SDVL_IA_TRACK_FUSED")) != 0;
+  const bool fused = fused_env && max_nf <= kLdsMaxF;
+  static const bool pre_env = !(getenv("SDVL_IA_PRE") && atoi(getenv("SDVL_IA_PRE")) == 0);
+  const bool pre = pre_env && !fused;
   const int n_lv = p->max_level - p->min_level + 1;
   const size_t work = pre ? ia_pre_bytes(n_jobs, n_lv, max_f) : static_cast<size_t>(n_jobs) * 48 * sizeof(float) * max_f;
   const int rc = sdvl_ensure(ctx, &ctx->d_work, &ctx->d_work_bytes, work + 256, false);
@@ -1656,14 +1661,25 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
                                               static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
       SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_track_wave_pre_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(ia_wave_lds_bytes(kMaxF, true))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_track_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kLdsMaxF, false))));
+      SDVL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(image_align_track_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(ia_wave_lds_bytes(kLdsMaxF + 128, false))));
       attr_devices.fetch_or(bit, std::memory_order_release);
     }
   }
   const Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   sdvl_timer_events(ctx, max_nf > kLdsMaxF ? "image_align_big" : "image_align", &ev_a, &ev_b);
-  const size_t lds = ia_wave_lds_bytes(max_f, true);
-  if (pre) {
+  const size_t lds = ia_wave_lds_bytes(max_f, !fused);
+  if (fused) {
+    if (kw == 4)
+      hipExtLaunchKernelGGL((image_align_track_kernel<4, false>), dim3(n_jobs), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, d_jobs, d_points, d_feats0, d_feats1, np,
+                            nfeat_cap, c, *p, max_f, static_cast<float *>(nullptr), d_results);
+    else
+      hipExtLaunchKernelGGL((image_align_track_kernel<1, false>), dim3(n_jobs), dim3(64), lds, ctx->stream, ev_a, ev_b, 0, d_jobs, d_points, d_feats0, d_feats1, np,
+                            nfeat_cap, c, *p, max_f, static_cast<float *>(nullptr), d_results);
+  } else if (pre) {
     SDVL_LAUNCH(ctx, "image_align_pre", image_align_track_pre_kernel, dim3(static_cast<unsigned>(n_jobs) * n_lv), dim3(256), d_jobs, d_points, d_feats0, d_feats1,
                 np, nfeat_cap, c, *p, n_jobs, max_f, ctx->d_work);
     if (kw == 4)
