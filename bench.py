@@ -648,11 +648,10 @@ def main():
     latency = None
     if world == 1 and args.latency_frames > 2:
         latency = latency_legs(wl, args.texture, args.latency_frames, args.mapper)   # child processes, before this one touches the GPU
-    # The farm's 16 groups are 16 HIP streams; the runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise,
-    # and kernels of two groups that share a queue run one behind the other.  16 queues: +5 % over three alternating pairs
-    # (profiles/r05/ab_round5.txt: 444 k against 423 k).  Must be in the environment before HIP initialises; a caller's own setting wins.
-    # (The latency legs above run without it: 16 lone cameras on 16 host threads lose with it.)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (GPU_MAX_HW_QUEUES: the farm's 16 groups are 16 HIP streams and the runtime multiplexes a process's streams onto 4 hardware queues by
+    #  default.  16 queues gave +5 % over three alternating pairs on one box (profiles/r05/ab_round5.txt) and nothing on the next
+    #  (ab_queues_by_steps.txt: within the run-to-run spread at 10 / 20 / 40 / 80 steps), while every dispatch gets 2-10 x longer because
+    #  sixteen kernels share the chip - so the runtime's default stays; a caller's own setting is reported in config.gpu_max_hw_queues.)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -1092,10 +1091,10 @@ def main():
                     "path_insts_per_frame": int(valu["path_insts_per_frame"]),
                     "path_frac": round(valu["path_insts_per_frame"] * (tracked_all / elapsed_max / world) / VALU_PEAK_WAVE_INSTS, 4),
                     "insts_per_frame": {k: int(v["insts_per_frame"]) for k, v in sorted(valu["kernels"].items(), key=lambda kv: -kv[1]["insts_per_frame"])[:8]}}
-            # With 16 hardware queues (round 5) sixteen kernels run side by side and every dispatch stretches; the kernel with the most
-            # dispatch TIME is then a short one launched four times per step (pyr_down), not the one that does the most WORK.  Beside the
-            # contract's kernel the line therefore names the kernel with the most vector instructions per frame (committed SQ pass) with the
-            # same figures, its launch duration from the warm-up steps in which every dispatch carried events.
+            # Beside the contract's kernel (most dispatch TIME in the timed region) the line names the kernel with the most vector
+            # instructions per frame (committed SQ pass) with the same figures, its launch duration from the warm-up steps in which every
+            # dispatch carried events: the two differ when a short kernel launched several times per step (pyr_down) collects more queueing
+            # time than the kernel that does the most work.
             if valu and valu["kernels"] and warm_timers:
                 hv = max(valu["kernels"].items(), key=lambda kv: kv[1]["insts_per_frame"])[0]
                 if hv in warm_timers and warm_timers[hv][1] > 0:
@@ -1146,7 +1145,7 @@ def main():
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",
                        "texture": args.texture + (": piecewise-smooth shading + soft-edged shapes at three scales (csrc/sdvl_synth.h SDVL_TEXTURE_CAMERA)" if TEXTURE else
                                                   ": five octaves of value noise, a FAST corner on every second tested pixel (rounds 1-4)"),
-                       "look_ahead": not os.environ.get("SDVL_NO_LOOKAHEAD"), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "look_ahead": not os.environ.get("SDVL_NO_LOOKAHEAD"), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                        "look_ahead_note": "the resident leg names step k+1's images before step k (SDVLBatch::SetNextImages): their pyramids and FAST are queued "
                                           "behind step k's chain; a live SDVL::HandleFrame caller has no next frame - the latency block is measured without it",
                        "chunks": ("%d chunks, texture seeds %d..%d; sequence g follows chunk shard.chunk_for_sequence(g) - one chunk per rank with --gpus %d" %
