@@ -415,7 +415,15 @@ bool SDVL::HandleFrame(const Image &img) {
     track_.valid = false;
   }
   track_.slot = 0;  // (a farm batch that also steps this tracker would have renumbered it)
-  self_batch_->HandleFrames({img}, &st);
+  try {
+    self_batch_->HandleFrames({img}, &st);
+  } catch (...) {
+    // a step that failed half way leaves the set's tables and its own bookkeeping in an unknown state: the next call starts with a
+    // fresh batch and rebuilds the table from the host objects (what the one-shot form did after every call)
+    self_batch_.reset();
+    track_.valid = false;
+    throw;
+  }
   return true;
 }
 
