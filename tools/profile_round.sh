@@ -30,7 +30,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/sc_kt -- python3 benc
 find $O/sc_kt -name "*kernel_trace.csv" -delete
 # the line earlier rounds quoted (2048 sequences, 100 steps), for comparison across rounds
 python3 bench.py --seqs 2048 --steps 100 --warmup 5 --cpu-frames 0 --host-steps 0 --sustained-frames 0 > $O/bench_2048x100.json 2> $O/bench_2048x100.err
-# (the A/B lines of the round: tools/profile_round_ab.sh, a call of its own — together they exceed one gpurun call)
+# (A/B lines: tools/ab_r05.sh "<ENV=VAL>" "<extra args>" PAIRS STEPS, a call of its own; round 5 per-workload profiles: tools/profile_r05.sh)
 hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_peak_probe tools/valu_peak_probe.cpp 2>/dev/null && timeout -k 5 120 /tmp/valu_peak_probe > $O/valu_peak_probe.txt 2>&1
 python3 tools/kernel_bench.py 256 6 > $O/kernel_bench_isolated.txt 2>&1
 python3 tools/pcie_probe.py > $O/pcie_probe.txt 2>&1
