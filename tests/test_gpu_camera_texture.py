@@ -210,3 +210,63 @@ def test_plane_map_honours_max_keyframes_like_the_oracle(trk, orc, synth, textur
             r.close()
     finally:
         trk.configure()
+
+
+def test_fork_join_and_pinned_host_memory_through_the_c_abi(sdvl, orc, synth):
+    """round 5's additions to include/sdvl_hip.h used directly: an image in page-locked memory from sdvl_host_alloc_pinned (and one in a
+    registered numpy buffer) goes through sdvl_frames_upload's gather kernel; sdvl_ctx_fork_mark / _begin / _end put the detection on the side
+    stream beside an image alignment — corners, alignment result and pyramid equal the unforked run's; misuse is refused"""
+    ctx = sdvl.Context(0)
+    lib = ctx.lib
+    try:
+        imgs = [synth.render(trajectory_pose(orc, k), TUM_CAM, 640, 480, frame_id=k, texture=1) for k in (0, 3)]
+        p = C.c_void_p()
+        assert lib.sdvl_host_alloc_pinned(ctx.h, C.c_int64(640 * 480), C.byref(p)) == 0
+        C.memmove(p.value, imgs[0].ctypes.data, 640 * 480)
+        reg = np.ascontiguousarray(imgs[1])
+        assert lib.sdvl_host_register(ctx.h, C.c_void_p(reg.ctypes.data), C.c_int64(reg.nbytes)) == 0
+        f0, f3 = ctx.frame(width=640, height=480), ctx.frame(width=640, height=480)
+        ctx.frames_upload([f0, f3], [p.value, reg.ctypes.data], 640)
+        ctx.pyramid_build([f0, f3])
+        want = [orc.pyramid(im) for im in imgs]
+        for l in range(5):
+            assert np.array_equal(f0.level(l), want[0][l]) and np.array_equal(f3.level(l), want[1][l])
+        dp = sdvl.default_detect_params()
+        from golden.make_golden import align_features
+        px, bearing, depth, valid = align_features(200, 20260200)
+        feats = (sdvl.AlignFeature * 200)()
+        for i in range(200):
+            feats[i].px, feats[i].py = px[i]
+            feats[i].fx, feats[i].fy, feats[i].fz = bearing[i]
+            feats[i].depth, feats[i].valid = depth[i], int(valid[i])
+        cam, ap = sdvl.Camera(640, 480, *TUM_CAM), sdvl.default_align_params()
+        plain_align = ctx.image_align([(f0, f3, 0, 200, [1, 0, 0, 0, 0, 0, 0])], feats, cam, ap)[0]
+        plain_corners = ctx.detect_corners([f3], dp, 1000)[0]
+        # the same two pieces of work, the detection forked off behind the pyramid
+        ctx.pyramid_build([f3])
+        assert lib.sdvl_ctx_fork_begin(ctx.h) != 0                      # no mark yet: refused
+        assert lib.sdvl_ctx_fork_mark(ctx.h) == 0
+        ja = (sdvl.AlignJob * 1)()
+        ja[0].ref, ja[0].cur, ja[0].feat_begin, ja[0].feat_end = f0.h.value, f3.h.value, 0, 200
+        ja[0].T[0] = 1.0
+        assert lib.sdvl_image_align_begin(ctx.h, 1, ja, 200, feats, C.byref(cam), C.byref(ap)) == 0
+        assert lib.sdvl_ctx_fork_begin(ctx.h) == 0
+        assert lib.sdvl_ctx_fork_mark(ctx.h) != 0                       # one fork at a time
+        arr = (C.c_void_p * 1)(f3.h)
+        assert lib.sdvl_detect_corners(ctx.h, 1, arr, C.byref(dp), 1000) == 0
+        assert lib.sdvl_ctx_fork_end(ctx.h) == 0
+        assert lib.sdvl_ctx_fork_end(ctx.h) != 0                        # nothing to join
+        res = (sdvl.AlignResult * 1)()
+        assert lib.sdvl_image_align_end(ctx.h, 1, res) == 0
+        assert list(res[0].T) == list(plain_align.T) and res[0].n_meas == plain_align.n_meas
+        counts = np.zeros(1, np.int32)
+        assert lib.sdvl_frames_corner_counts(ctx.h, 1, arr, counts.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        xyl = np.zeros((int(counts[0]), 3), np.int32)
+        k = C.c_int()
+        assert lib.sdvl_frame_download_corners(ctx.h, f3.h, len(xyl), xyl.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(k)) == 0
+        assert np.array_equal(xyl[:k.value], plain_corners) and np.array_equal(plain_corners, orc.detect_pyramid(imgs[1]))
+        f0.close(); f3.close()
+        assert lib.sdvl_host_unregister(ctx.h, C.c_void_p(reg.ctypes.data)) == 0
+        assert lib.sdvl_host_free_pinned(ctx.h, p) == 0
+    finally:
+        ctx.close()
