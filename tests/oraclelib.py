@@ -246,6 +246,7 @@ class OracleTracker:
         fp = np.ascontiguousarray(first_pose, np.float64)
         self.lib.sdvl_ref_tracker_create.restype = C.c_void_p
         self.h_ = self.lib.sdvl_ref_tracker_create(C.byref(orc.params), w, h, ptr(cam, f64p), ptr(plane, f64p), ptr(fp, f64p))
+        self.set_max_keyframes(1000)   # SDVL.max_keyframes of the reference's cfg files, what tracker.configure() sets on the product side
 
     def handle_frame(self, img):
         img = np.ascontiguousarray(img, np.uint8)
