@@ -44,7 +44,7 @@ WORKLOADS = {
     # SURVEY §8(d) S-B / BASELINE config 4: EuRoC MH_01's geometry (config/config_euroc.cfg:9-14,42: 752x480, its intrinsics,
     # min_matches 5), four independent 300-frame chunks with seeds 20260010..13.  On one GPU the sequences follow the chunks round-robin
     # (sequence g: chunk g mod 4); with `--gpus 4` every rank tracks ONE chunk (shard.chunk_for_sequence)
-    "S-B": dict(w=752, h=480, cam=[458.654, 457.296, 367.215, 248.375], seqs=[3072, 2048, 1024], over={"SDVL.min_matches": 5}, label="~200 feats",
+    "S-B": dict(w=752, h=480, cam=[458.654, 457.296, 367.215, 248.375], seqs=[4096, 3072, 2048], over={"SDVL.min_matches": 5}, label="~200 feats",
                 cpu_frames=300, chunks=4, seed0=20260010),
     "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=[64], label="~1000 feats", cpu_frames=60,
                 over={"SDVL.num_features": 4000, "SDVL.max_matches": 1000}),
