@@ -385,7 +385,7 @@ def latency_legs(wl, texture, n_frames, mapper=False):
     if mapper:
         base.append("--mapper")
     out = {}
-    for name, n, extra in (("b1", 1, []), ("b16", 16, []), ("b16_batched", 16, ["--batch"])):
+    for name, n, extra in (("b1", 1, []), ("b1_lookahead", 1, ["--lookahead"]), ("b16", 16, []), ("b16_batched", 16, ["--batch"])):
         try:
             r = subprocess.run(base + ["--trackers", str(n)] + extra, capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -403,6 +403,10 @@ def latency_legs(wl, texture, n_frames, mapper=False):
     if "b1" in out:
         blk.update({"b1_frames_per_s": out["b1"]["frames_per_s"], "b1_ms_per_frame_p50": out["b1"]["ms_per_frame_p50"],
                     "b1_ms_per_frame_p95": out["b1"]["ms_per_frame_p95"], "b1_tracked": out["b1"]["tracked"]})
+    if "b1_lookahead" in out:
+        blk.update({"b1_lookahead_frames_per_s": out["b1_lookahead"]["frames_per_s"], "b1_lookahead_ms_per_frame_p50": out["b1_lookahead"]["ms_per_frame_p50"],
+                    "b1_lookahead_note": "the same camera when the caller reads a sequence (main.cc's Video.type 1) and names the next frame one call ahead "
+                                         "(SDVL::SetNextImage, an addition to the reference's API): its pyramid and corners are built behind the current chain"})
     if "b16" in out:
         blk.update({"b16_frames_per_s": out["b16"]["frames_per_s"], "b16_frames_per_s_per_camera": out["b16"]["frames_per_s_per_camera"],
                     "b16_ms_per_frame_p50": out["b16"]["ms_per_frame_p50"], "b16_ms_per_frame_p95": out["b16"]["ms_per_frame_p95"],
@@ -1032,7 +1036,7 @@ def main():
                "checker_build": {"flags": "-O3 -march=x86-64-v3 -ffp-contract=off", "value": round(fps_chk, 2), "one_core": round(fps1, 2)}}
 
     if latency and cpu:
-        for b in ("b1", "b16", "b16_batched"):
+        for b in ("b1", "b1_lookahead", "b16", "b16_batched"):
             if b + "_frames_per_s" in latency:
                 latency[b + "_vs_cpu_one_core"] = round(latency[b + "_frames_per_s"] / cpu["one_core"], 2)
         latency["target"] = "north_star: >= 30 x the CPU reference path for one camera = %.0f frames/s here" % (30 * cpu["one_core"])

@@ -153,6 +153,11 @@ class SDVL {
   void Stop() { map_->Stop(); }
   void Mapping();
   bool HandleFrame(const Image &img);
+  // Round 5, an addition for callers that READ a sequence (main.cc's Video.type 1: images from disk are there before they are needed):
+  // name the image the NEXT HandleFrame call will be given (a device image, e.g. what Camera::UndistortImage returns, kept alive and
+  // unchanged until that call).  Its pyramid and corner detection are queued behind the coming call's chain and run while the host
+  // finishes that call.  Same results; an unused or mismatching look-ahead is dropped.
+  void SetNextImage(const Image &next);
   SE3 GetPose() const;
   TrackingQuality GetTrackingQuality() const { return tracking_quality_; }
   bool HasMap() { return state_ == STATE_RUNNING; }
@@ -184,6 +189,7 @@ class SDVL {
   // tracking tables too — a tracked frame is one submission and one wait instead of the host-driven stage-by-stage form
   // (SDVL_HANDLEFRAME_ONE_SHOT=1: a fresh batch per call, rounds 1-4)
   std::unique_ptr<SDVLBatch> self_batch_;
+  std::vector<Image> next_image_;  // SetNextImage: handed to the batch by the HandleFrame call it belongs to
   void SyncSelfBatch();
   // device-resident tracking table of this tracker (SDVLBatch owns the set): valid = the table holds last_frame_'s features
   struct TrackState {

@@ -398,11 +398,16 @@ void SDVL::CalcTrackingQuality(int matches, int attempts) {
   tracking_quality_ = TRACKING_INSUFFICIENT;
 }
 
+void SDVL::SetNextImage(const Image &next) {
+  next_image_.assign(1, next);
+}
+
 bool SDVL::HandleFrame(const Image &img) {
   std::unique_lock<std::mutex> lock(map_->GetMutex());  // the mapper thread of threaded mode stays out meanwhile
   static const bool one_shot = std::getenv("SDVL_HANDLEFRAME_ONE_SHOT") != nullptr;
   FrameStats st;
   if (one_shot) {  // rounds 1-4: a one-call batch, no device-resident tables, every stage driven from the host
+    next_image_.clear();
     SDVLBatch one(Device::Current(), {this}, 1);
     one.persistent_ = false;
     one.HandleFrames({img}, &st);
@@ -415,6 +420,10 @@ bool SDVL::HandleFrame(const Image &img) {
     track_.valid = false;
   }
   track_.slot = 0;  // (a farm batch that also steps this tracker would have renumbered it)
+  if (!next_image_.empty()) {
+    self_batch_->SetNextImages(next_image_);
+    next_image_.clear();
+  }
   try {
     self_batch_->HandleFrames({img}, &st);
   } catch (...) {

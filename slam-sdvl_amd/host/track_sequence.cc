@@ -10,6 +10,8 @@
 //            ONE sdvl::SDVLBatch::HandleFrames call per frame on one thread and one stream (the batched form of the same call);  [--prerender]  the synthetic frames are rendered on the GPU
 //            into page-locked host memory before the loop (the window of main.cc:136-138 never contained the rendering anyway; this keeps
 //            a 300-frame run short);  [--pageable]  with --prerender: plain malloc'ed frames, what an unregistered cv::Mat is;
+//            [--lookahead]  the loop undistorts frame k + 1 before it tracks frame k and names it with SDVL::SetNextImage (a sequence from
+//            disk is there before it is needed): its pyramid and corners are built while the host finishes frame k;
 //            [--set SDVL.key value]  a configuration value (after --config);  [--quiet]  no per-frame lines;  [--json]  one JSON line with the rates;  [--profile]  per-kernel dispatch time and host stages
 //
 // The two-frame homography bootstrap is out of scope: the first frame becomes a keyframe whose points are
@@ -67,7 +69,7 @@ int main(int argc, char **argv) {
   double cam4[4] = {517.3, 516.5, 318.6, 255.3}, dist[5] = {0, 0, 0, 0, 0}, plane[4] = {0, 0, 1, 2.0};
   std::string list, cfg;
   bool mapper = false, size_given = false, cam_given = false, dist_given = false;
-  bool prerender = false, pageable = false, quiet = false, json = false, profile = false, batch = false;
+  bool prerender = false, pageable = false, quiet = false, json = false, profile = false, batch = false, lookahead = false;
   int n_trackers = 1;
   std::vector<std::pair<std::string, double>> sets;  // --set SDVL.key value, applied after the configuration file
   unsigned texture = SDVL_TEXTURE_PLANE_NOISE;
@@ -86,6 +88,7 @@ int main(int argc, char **argv) {
     else if (a == "--texture") { need(1); const std::string t = argv[++i]; if (t == "camera") texture = SDVL_TEXTURE_CAMERA; else if (t != "plane") { std::cerr << "unknown texture " << t << std::endl; return 2; } }
     else if (a == "--trackers") { need(1); n_trackers = std::max(1, std::atoi(argv[++i])); }
     else if (a == "--batch") batch = true;
+    else if (a == "--lookahead") lookahead = true;
     else if (a == "--prerender") prerender = true;
     else if (a == "--pageable") pageable = true;
     else if (a == "--quiet") quiet = true;
@@ -190,6 +193,8 @@ int main(int argc, char **argv) {
         SDVL sdvl(&camera, map.get());
         std::vector<uint8_t> px(pool ? 0 : frame_bytes);
         me.ms.reserve(n_frames);
+        Image ahead;
+        bool ahead_valid = false;
         if (n_trackers > 1) {  // all cameras start together
           ready.fetch_add(1);
           while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
@@ -212,7 +217,19 @@ int main(int argc, char **argv) {
           Image img;
           img.data = data; img.cols = W; img.rows = H; img.step = W;
           Image imgu;
-          camera.UndistortImage(img, &imgu);                      // main.cc:133
+          if (lookahead && pool && ahead_valid) {
+            imgu = ahead;                                          // undistorted one iteration ago
+          } else {
+            camera.UndistortImage(img, &imgu);                      // main.cc:133
+          }
+          ahead_valid = false;
+          if (lookahead && pool && k + 1 < n_frames) {              // the next frame is there already: undistort it now, name it
+            Image nxt;
+            nxt.data = pool + frame_bytes * (k + 1); nxt.cols = W; nxt.rows = H; nxt.step = W;
+            camera.UndistortImage(nxt, &ahead);
+            ahead_valid = true;
+            if (k > 0) sdvl.SetNextImage(ahead);                   // (frame 0 is the bootstrap: no tracked step to queue behind)
+          }
           if (k == 1 && profile) dev.Check(sdvl_ctx_timing_enable(dev.ctx(), 1), "sdvl_ctx_timing_enable");
           const auto t0 = std::chrono::steady_clock::now();
           sdvl.HandleFrame(imgu);                                 // main.cc:136-138
@@ -352,6 +369,7 @@ int main(int argc, char **argv) {
                   pool ? (pool_pinned ? "page-locked host memory" : "pageable host memory") : "host memory of the loop (pageable)",
                   texture == SDVL_TEXTURE_CAMERA ? "camera" : "plane", W, H, mapper ? "true" : "false",
                   batch ? "sdvl::SDVLBatch::HandleFrames, one call per frame for all cameras (one thread, one stream)"
+                  : lookahead ? "SDVL::SetNextImage + SDVL::HandleFrame per frame (the next frame of the sequence named one call ahead)"
                         : "SDVL::HandleFrame per frame and camera (host/track_sequence.cc, the loop of main.cc:126-159; one thread and stream per camera)");
   } catch (const std::exception &e) {
     std::cerr << "track_sequence: " << e.what() << std::endl;

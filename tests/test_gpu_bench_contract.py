@@ -69,6 +69,7 @@ def check(d, steps=4, warmup=1, mapper=False):
     if not mapper:
         assert lat is not None and lat["b1_tracked"] == 11 and lat["b1_frames_per_s"] > 200 and lat["b16_tracked"] == 16 * 11
         assert lat["b16_batched_frames_per_s"] > lat["b1_frames_per_s"]          # 16 cameras in one call outrun one camera
+        assert lat["b1_lookahead_frames_per_s"] > 200                            # the sequence-from-disk form (SDVL::SetNextImage), reported apart
         assert abs(lat["b1_vs_cpu_one_core"] - lat["b1_frames_per_s"] / d["cpu_baseline"]["one_core"]) < 0.02
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "tracked frames/s" and "sample" in c
