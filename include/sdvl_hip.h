@@ -408,6 +408,9 @@ int sdvl_align_patches(sdvl_ctx *ctx, int n, const sdvl_frame *const *frames, co
  * host thread that drives several contexts (one per group of sequences) switches to another context's host work there
  * and comes back when sdvl_ctx_wait_done(ctx) says 1; when nothing else is runnable it sleeps in sdvl_ctx_wait_block. */
 int sdvl_ctx_set_wait_hook(sdvl_ctx *ctx, void (*hook)(void *user, sdvl_ctx *ctx), void *user);
+/* Round 5: waits of this context poll WITHOUT sleeping for the first `microseconds` (then fall back to the sleeping polls).  For a
+ * context whose waits are a lone camera's 0.2-ms chains (SDVL::HandleFrame sets 500): a sleeping poll wakes ~15 us late on average. */
+int sdvl_ctx_set_wait_spin(sdvl_ctx *ctx, int microseconds);
 int sdvl_ctx_wait_done(sdvl_ctx *ctx);
 int sdvl_ctx_wait_block(sdvl_ctx *ctx);
 /* 0 while the stream is healthy (idle or busy), SDVL_ERR_HIP after a device fault: for schedulers that poll _wait_done */

@@ -130,7 +130,7 @@ ABI_SYMBOLS = [
     "sdvl_track_collect", "sdvl_track_features", "sdvl_track_stats",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",
     "sdvl_frames_own_images", "sdvl_feed_create", "sdvl_feed_destroy", "sdvl_feed_last_error", "sdvl_feed_slot_arrived", "sdvl_feed_images", "sdvl_ctx_feed_acquire", "sdvl_ctx_feed_release", "sdvl_frame_footprint_cap", "sdvl_ctx_set_corner_capacity", "sdvl_frame_corner_capacity", "sdvl_detect_scratch_bytes",
-    "sdvl_ctx_fork_mark", "sdvl_ctx_fork_begin", "sdvl_ctx_fork_end", "sdvl_host_alloc_pinned", "sdvl_host_free_pinned", "sdvl_host_register", "sdvl_host_unregister",
+    "sdvl_ctx_set_wait_spin", "sdvl_ctx_fork_mark", "sdvl_ctx_fork_begin", "sdvl_ctx_fork_end", "sdvl_host_alloc_pinned", "sdvl_host_free_pinned", "sdvl_host_register", "sdvl_host_unregister",
 ]
 
 _lib = None

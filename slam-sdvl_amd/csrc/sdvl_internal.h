@@ -110,6 +110,7 @@ struct sdvl_ctx {
   // pinned host memory, polled by the waiting thread with plain loads (SDVL_WAIT_EVENTS=1: HIP events + hipEventQuery)
   volatile uint32_t *h_flag = nullptr;
   uint32_t flag_seq = 0;
+  int wait_spin_us = 0;  // sdvl_ctx_set_wait_spin: poll without sleeping for this long before the sleeping polls (a lone camera's 0.2-ms waits)
   hipEvent_t mark_events[4] = {nullptr, nullptr, nullptr, nullptr};  // event mode: one per kind of mark
   uint32_t mark_event_ticket[4] = {0, 0, 0, 0};
   // cooperative waits: when set, sdvl_stream_wait polls the event and calls the hook while the stream is still busy, so a

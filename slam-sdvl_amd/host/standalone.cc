@@ -540,6 +540,13 @@ static Pool *g_pool_of(void *&slot, int threads) {
 
 SDVLBatch::SDVLBatch(Device *dev, const vector<SDVL *> &trackers, int host_threads) : dev_(dev), trk_(trackers), threads_(host_threads) {
   for (size_t i = 0; i < trk_.size(); i++) trk_[i]->track_.slot = static_cast<int>(i);
+  // Round 5: a lone camera (a batch of up to four) waits for chains of 0.2 ms: its context polls without sleeping for the first 500 us of a
+  // wait (a sleeping poll wakes ~15 us late: 3.51 -> 3.83 k frames/s).  Larger batches keep the sleeping polls: 16 cameras in one batch gain
+  // nothing, configuration C's groups of 16 lose (46.8 -> 43.3 k: their host threads need the CPU), a farm waits ~9 ms with the CPUs short.
+  // SDVL_WAIT_SPIN_US=n overrides for every batch size (0: never spin).
+  static const int spin_env = std::getenv("SDVL_WAIT_SPIN_US") ? std::atoi(std::getenv("SDVL_WAIT_SPIN_US")) : -1;
+  const int spin_us = spin_env >= 0 ? spin_env : (trk_.size() <= 4 ? 500 : 0);
+  if (dev_ && dev_->ctx()) (void)sdvl_ctx_set_wait_spin(dev_->ctx(), spin_us);
 }
 SDVLBatch::~SDVLBatch() {
   if (track_) {
