@@ -51,6 +51,7 @@ struct sdvlh_frame_stats {
   int state, quality, matches, attempts, inliers, outliers, n_corners, align_meas, keyframe, relocalized;
   double pose[7];
   int align_features, align_iters, search_requests, lk_iters;
+  int host_path;
 };
 
 const char *sdvlh_last_error() { return g_err.c_str(); }
@@ -141,6 +142,7 @@ static int step(Batch *b, const std::vector<Image> &imgs, sdvlh_frame_stats *out
       o.relocalized = s.relocalized;
       std::memcpy(o.pose, s.pose, sizeof(o.pose));
       o.align_features = s.align_features; o.align_iters = s.align_iters; o.search_requests = s.search_requests; o.lk_iters = s.lk_iters;
+      o.host_path = s.host_path;
     }
     return 0;
   } catch (const std::exception &e) {

@@ -548,7 +548,7 @@ class FeatureAlign {
 
 // wall-clock per stage of SDVLBatch::HandleFrames, accumulated (seconds); index = StageId
 enum StageId { ST_UPLOAD_PYR = 0, ST_FAST, ST_SELECT, ST_CORNERS_ORB, ST_PRELUDE, ST_IMAGE_ALIGN, ST_PREPARE, ST_SEARCH, ST_FINISH, ST_POSE, ST_MAPPING,
-               ST_EPILOGUE, ST_MAPPER, ST_TOTAL, ST_MAP_CANDIDATES, ST_MAP_CONNECTIONS, ST_MAP_INIT, ST_MAP_FINISH, ST_MAP_BEGIN, ST_MAP_EMIT, ST_MAP_SEARCH, ST_MAP_APPLY, ST_COUNT };
+               ST_EPILOGUE, ST_MAPPER, ST_TOTAL, ST_MAP_CANDIDATES, ST_MAP_CONNECTIONS, ST_MAP_INIT, ST_MAP_FINISH, ST_MAP_BEGIN, ST_MAP_EMIT, ST_MAP_SEARCH, ST_MAP_APPLY, ST_RELOCALIZE, ST_COUNT };
 struct StageTimes {
   double t[ST_COUNT] = {0};
   long steps = 0;
@@ -561,6 +561,9 @@ struct FrameStats {
   double pose[7] = {1, 0, 0, 0, 0, 0, 0};
   // traffic accounting: features / GN evaluations of the alignment job, SearchPoint requests / LK iterations
   int align_features = 0, align_iters = 0, search_requests = 0, lk_iters = 0;
+  // which form of the step carried this tracker: 0 = the device-resident tables (one submission), 1 = the whole batch went through the
+  // host-driven form (HandleFramesGeneric), 2 = this tracker alone was tracked through the per-object calls inside a tabled step
+  int host_path = 0;
 };
 
 }  // namespace sdvl

@@ -255,6 +255,9 @@ class SDVLBatch {
   std::vector<const void *> ahead_src_;                 // the images they were made from
   void HandleFramesGeneric(const std::vector<Image> &imgs, FrameStats *stats);
   bool BuildTable(SDVL &t);
+  bool UploadTables(const std::vector<int> &need, std::vector<char> *built);
+  void RelocalizeLost(const std::vector<int> &lost, FrameStats *stats, std::vector<char> *found);
+  int TrackOnHost(SDVL &t, FrameStats *st);
   bool AppendSeeds(SDVL &t, const std::shared_ptr<Frame> &kf);  // rows of the points seeded on kf -> track_.up_points / up_feats
   void SyncStats(SDVL &t);
   void FetchCornerCounts(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats);

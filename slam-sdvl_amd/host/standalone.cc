@@ -750,6 +750,182 @@ bool SDVLBatch::AppendSeeds(SDVL &t, const shared_ptr<Frame> &kf) {
   return true;
 }
 
+// Tables of the trackers `need` rebuilt from their last_frame's host objects and sent to the device in ONE submission.
+// built == nullptr: all or nothing (false, nothing uploaded, if one of them cannot be expressed as a table);
+// otherwise the expressible ones are uploaded and (*built)[q] says which.
+bool SDVLBatch::UploadTables(const vector<int> &need, vector<char> *built) {
+  vector<char> ok(need.size(), 0);
+  ParallelFor(static_cast<int>(need.size()), [&](int q) { ok[q] = BuildTable(*trk_[need[q]]) ? 1 : 0; });
+  if (!built)
+    for (char o : ok)
+      if (!o) return false;
+  vector<int32_t> up_trk, up_buf, up_np, up_nf;
+  tr_up_points_.clear();
+  tr_up_feats_.clear();
+  vector<const sdvl_frame *> reg_frames;   // every reference frame the rebuilt tables name for the first time: ONE submission
+  vector<double> reg_poses;
+  for (size_t q = 0; q < need.size(); q++) {
+    if (!ok[q]) continue;
+    const int i = need[q];
+    SDVL::TrackState &ts = trk_[i]->track_;
+    for (Frame *ref : ts.up_register)
+      if (!ref->IsRegistered()) {
+        double pose[7];
+        ref->GetPose().ToArray(pose);
+        reg_frames.push_back(ref->device());
+        reg_poses.insert(reg_poses.end(), pose, pose + 7);
+        ref->SetRegistered();
+      }
+    up_trk.push_back(i);
+    up_buf.push_back(0);
+    up_np.push_back(static_cast<int32_t>(ts.up_points.size()));
+    up_nf.push_back(static_cast<int32_t>(ts.up_feats.size()));
+    tr_up_points_.insert(tr_up_points_.end(), ts.up_points.begin(), ts.up_points.end());
+    tr_up_feats_.insert(tr_up_feats_.end(), ts.up_feats.begin(), ts.up_feats.end());
+  }
+  if (!reg_frames.empty())
+    dev_->Check(sdvl_frames_register(dev_->ctx(), static_cast<int>(reg_frames.size()), reg_frames.data(), reg_poses.data()), "sdvl_frames_register");
+  if (!up_trk.empty())
+    dev_->Check(sdvl_track_upload(dev_->ctx(), track_, static_cast<int>(up_trk.size()), up_trk.data(), up_buf.data(), up_np.data(), tr_up_points_.data(),
+                                  up_nf.data(), tr_up_feats_.data()), "sdvl_track_upload");
+  for (size_t q = 0; q < need.size(); q++)
+    if (ok[q]) {
+      trk_[need[q]]->track_.feat_buf = 0;
+      trk_[need[q]]->track_.valid = true;
+    }
+  if (built) *built = ok;
+  return true;
+}
+
+// SDVL::Relocalize (sdvl.cc:73-89,205-238) for the trackers `lost` of a batch, inside the tabled step: the other trackers of the batch
+// are not touched.  The alignment of a tracker's current frame against EVERY keyframe of its map (each started from that keyframe's
+// pose, fast mode) is independent of the others: ONE launch for all (tracker, keyframe) pairs of all lost trackers.  The keyframe
+// loop then runs in the reference's order (newest first) over the results; Reproject(reloc = true) draws from rand() and stops at the
+// first keyframe that gathers MinMatches, so it stays sequential per tracker — but the trackers advance together: one search launch
+// per ROUND (a round = every unresolved tracker's next keyframe with error < 0.001; almost always there is one round).
+// (*found)[q]: tracker lost[q] has relocalised — last_frame_ = last_kf_ = the keyframe it landed on (sdvl.cc:84-86).
+void SDVLBatch::RelocalizeLost(const vector<int> &lost, FrameStats *stats, vector<char> *found) {
+  const int L = static_cast<int>(lost.size());
+  found->assign(L, 0);
+  vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> pairs;
+  vector<SE3> start, aligned;
+  vector<int> first(L + 1, 0);
+  for (int q = 0; q < L; q++) {
+    SDVL &t = *trk_[lost[q]];
+    SyncStats(t);                   // the Point objects Reproject reads catch up with the device's counters
+    t.map_->SetRelocalizing(true);  // sdvl.cc:80
+    for (int k = 0; k < 6; k++) t.vel_[k] = 0.0;
+    vector<shared_ptr<Frame>> &kfs = t.map_->GetKeyframes();
+    first[q] = static_cast<int>(pairs.size());
+    for (auto it = kfs.rbegin(); it != kfs.rend(); it++) {
+      pairs.push_back({*it, t.current_frame_});
+      start.push_back((*it)->GetPose());
+    }
+  }
+  first[L] = static_cast<int>(pairs.size());
+  vector<int> n_meas;
+  vector<double> errors;
+  {  // launches of bounded size: a farm whose trackers are all lost asks for B x |keyframes| alignments
+    const size_t n = pairs.size();
+    n_meas.assign(n, 0);
+    errors.assign(n, 1e10);
+    aligned.resize(n);
+    const size_t kChunk = 2048;
+    for (size_t b = 0; b < n; b += kChunk) {
+      const size_t e = std::min(n, b + kChunk);
+      vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> part(pairs.begin() + b, pairs.begin() + e);
+      vector<SE3> part_start(start.begin() + b, start.begin() + e), part_aligned;
+      vector<int> part_meas;
+      vector<double> part_err;
+      ImageAlign::ComputePoseBatch(part, true, &part_meas, &part_err, nullptr, &part_start, &part_aligned);
+      for (size_t j = b; j < e; j++) {
+        n_meas[j] = part_meas[j - b];
+        errors[j] = part_err[j - b];
+        aligned[j] = part_aligned[j - b];
+      }
+    }
+  }
+  vector<int> cursor(first.begin(), first.end() - 1);
+  vector<char> open_(L, 1);
+  vector<vector<sdvl_search_req>> per(L);
+  vector<sdvl_search_req> reqs;
+  vector<sdvl_search_res> res;
+  vector<size_t> begin(L + 1, 0);
+  for (;;) {
+    bool any = false;
+    reqs.clear();
+    for (int q = 0; q < L; q++) {
+      per[q].clear();
+      if (!open_[q]) continue;
+      SDVL &t = *trk_[lost[q]];
+      // sdvl.cc:209-222: every keyframe visited leaves its aligned pose on the frame; those with error >= 0.001 are passed over
+      while (cursor[q] < first[q + 1]) {
+        t.current_frame_->SetPose(aligned[cursor[q]]);
+        if (errors[cursor[q]] < 0.001) break;
+        cursor[q]++;
+      }
+      if (cursor[q] >= first[q + 1]) {
+        open_[q] = 0;
+        continue;
+      }
+      const shared_ptr<Frame> &cframe = pairs[cursor[q]].first;
+      t.feature_align_.PrepareReproject(t.current_frame_, cframe, true, &per[q]);
+      any = true;
+    }
+    if (!any) break;
+    for (int q = 0; q < L; q++) {
+      begin[q] = reqs.size();
+      reqs.insert(reqs.end(), per[q].begin(), per[q].end());
+    }
+    begin[L] = reqs.size();
+    Matcher::SearchPoints(dev_, reqs, *trk_[lost[0]]->camera_, &res);
+    for (int q = 0; q < L; q++) {
+      if (!open_[q] || cursor[q] >= first[q + 1]) continue;
+      SDVL &t = *trk_[lost[q]];
+      t.feature_align_.FinishReproject(t.current_frame_, res.data() + begin[q]);
+      t.matches_ = t.feature_align_.GetMatches();
+      t.attempts_ = t.feature_align_.GetAttempts();
+      if (t.matches_ >= Config::MinMatches()) {
+        const shared_ptr<Frame> cframe = pairs[cursor[q]].first;
+        t.map_->SetRelocalizing(false);  // sdvl.cc:84
+        t.last_kf_ = cframe;
+        t.last_frame_ = cframe;
+        t.track_.valid = false;  // the table follows last_frame_
+        stats[lost[q]].relocalized = 1;
+        (*found)[q] = 1;
+        open_[q] = 0;
+      } else {
+        cursor[q]++;
+      }
+    }
+  }
+}
+
+// ProcessFrame (sdvl.cc:179-203) of ONE tracker through the per-object calls (ImageAlign::ComputePose, FeatureAlign::Reproject /
+// OptimizePose), inside a tabled step: for the tracker whose last_frame no table can express (a keyframe with more features than the
+// alignment kernels take) while everybody else stays on the tables.  Returns the decision (0 lost, 1 frame, 2 keyframe).
+int SDVLBatch::TrackOnHost(SDVL &t, FrameStats *st) {
+  st->host_path = 2;
+  ImageAlign image_align;
+  st->align_meas = image_align.ComputePose(t.last_frame_, t.current_frame_);
+  st->align_features = static_cast<int>(t.last_frame_->GetFeatures().size());
+  t.feature_align_.Reproject(t.current_frame_, t.last_frame_, t.last_kf_);
+  t.matches_ = t.feature_align_.GetMatches();
+  t.attempts_ = t.feature_align_.GetAttempts();
+  t.feature_align_.OptimizePose(t.current_frame_);
+  st->inliers = t.feature_align_.GetInliers();
+  st->outliers = t.feature_align_.GetOutliers();
+  {  // GetMotionModel, sdvl.cc:266-276
+    const SE3 mov = t.current_frame_->GetPose() * t.last_frame_->GetPose().Inverse();
+    const Vector6d vel = SE3::Log(mov);
+    for (int c = 0; c < 6; c++) t.vel_[c] = 0.9 * (0.5 * vel[c] + 0.5 * t.vel_[c]);
+  }
+  t.CalcTrackingQuality(t.matches_, t.attempts_);
+  t.track_.valid = false;  // this frame's features live on the host
+  if (t.tracking_quality_ == SDVL::TRACKING_BAD) return 0;
+  return (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) ? 2 : 1;
+}
+
 // One step of B trackers on the device-resident tables: ONE submission (alignment, detection, reprojection, search, match
 // selection, pose, table update) and ONE wait.  The host keeps what only it can do: rand() (cell shuffle, RANSAC draws), the
 // motion model, tracking quality, the keyframe decision and everything a keyframe sets off.
@@ -760,7 +936,6 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
   for (int i = 0; i < B; i++) {
     SDVL &t = *trk_[i];
     if (t.feature_align_.MaxMatches() > FeatureAlign::kMaxDevicePoseObs || t.feature_align_.MaxMatches() < 1) return false;
-    if (t.state_ == SDVL::STATE_RUNNING && t.lost_frames_ >= 3) return false;  // Relocalize (sdvl.cc:205-238) runs on the host path
     if (t.camera_ != trk_[0]->camera_) return false;
   }
   Camera &camera = *trk_[0]->camera_;
@@ -779,47 +954,13 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
 
   // ---- tables of the trackers whose last_frame changed behind the device's back (keyframes: seeded / mapped features).
   // First of all: a frame that cannot be expressed as a table sends the whole step to the host path, untouched.
+  // (A tracker that has to relocalise — lost_frames_ >= 3, sdvl.cc:73 — gets its table further down, from the keyframe it lands on.)
   std::unique_ptr<StageClock> clk(new StageClock(ST_PREPARE));
   {
     vector<int> need;
     for (int i = 0; i < B; i++)
-      if (trk_[i]->state_ == SDVL::STATE_RUNNING && !trk_[i]->track_.valid) need.push_back(i);
-    if (!need.empty()) {
-      vector<char> ok(need.size(), 0);
-      ParallelFor(static_cast<int>(need.size()), [&](int q) { ok[q] = BuildTable(*trk_[need[q]]) ? 1 : 0; });
-      for (char o : ok)
-        if (!o) return false;
-      vector<int32_t> up_trk, up_buf, up_np, up_nf;
-      tr_up_points_.clear();
-      tr_up_feats_.clear();
-      vector<const sdvl_frame *> reg_frames;   // every reference frame the rebuilt tables name for the first time: ONE submission
-      vector<double> reg_poses;
-      for (int i : need) {
-        SDVL::TrackState &ts = trk_[i]->track_;
-        for (Frame *ref : ts.up_register)
-          if (!ref->IsRegistered()) {
-            double pose[7];
-            ref->GetPose().ToArray(pose);
-            reg_frames.push_back(ref->device());
-            reg_poses.insert(reg_poses.end(), pose, pose + 7);
-            ref->SetRegistered();
-          }
-        up_trk.push_back(i);
-        up_buf.push_back(0);
-        up_np.push_back(static_cast<int32_t>(ts.up_points.size()));
-        up_nf.push_back(static_cast<int32_t>(ts.up_feats.size()));
-        tr_up_points_.insert(tr_up_points_.end(), ts.up_points.begin(), ts.up_points.end());
-        tr_up_feats_.insert(tr_up_feats_.end(), ts.up_feats.begin(), ts.up_feats.end());
-      }
-      if (!reg_frames.empty())
-        dev_->Check(sdvl_frames_register(dev_->ctx(), static_cast<int>(reg_frames.size()), reg_frames.data(), reg_poses.data()), "sdvl_frames_register");
-      dev_->Check(sdvl_track_upload(dev_->ctx(), track_, static_cast<int>(up_trk.size()), up_trk.data(), up_buf.data(), up_np.data(), tr_up_points_.data(),
-                                    up_nf.data(), tr_up_feats_.data()), "sdvl_track_upload");
-      for (int i : need) {
-        trk_[i]->track_.feat_buf = 0;
-        trk_[i]->track_.valid = true;
-      }
-    }
+      if (trk_[i]->state_ == SDVL::STATE_RUNNING && !trk_[i]->track_.valid && trk_[i]->lost_frames_ < 3) need.push_back(i);
+    if (!need.empty() && !UploadTables(need, nullptr)) return false;
   }
 
   // ---- stage 0: Frame construction, sdvl.cc:59 (pyramids now, detection behind the alignment)
@@ -838,7 +979,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     ahead_src_.clear();
   }
   if (!detected_ahead) Frame::CreateBatch(&camera, &trk_[0]->orb_detector_, imgs, false, Config::NumFeatures(), &frames, &pfor);
-  vector<int> run;
+  vector<int> run, lost;
   clk.reset(new StageClock(ST_PRELUDE));
   for (int i = 0; i < B; i++) {
     SDVL &t = *trk_[i];
@@ -858,15 +999,47 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
       t.track_.valid = false;
       st.state = 0;
       st.keyframe = 1;
+    } else if (t.lost_frames_ >= 3) {
+      st.state = 2;
+      lost.push_back(i);  // relocalize = lost_frames_ >= 3, sdvl.cc:73
     } else {
       st.state = 2;
       t.current_frame_->SetPose(SE3::Exp(t.vel_) * t.last_frame_->GetPose());  // SetMotionModel, sdvl.cc:278-281
       run.push_back(i);
     }
   }
+  // ---- Relocalize (sdvl.cc:73-89,205-238) for the trackers that lost their map, in THIS step: their alignments against their
+  // keyframes and their searches are extra launches of the same submission queue; the trackers that found a keyframe join the
+  // tracked step below with a table built from that keyframe (ProcessFrame(last_frame_ = last_kf_ = the keyframe), sdvl.cc:86-93),
+  // the others sit this frame out (sdvl.cc:91: !relocalize).  Nobody else's tables are touched.
+  bool detected_now = false;
+  vector<int> host_run;  // relocalised onto a keyframe no table can express: tracked through the per-object calls, alone
+  if (!lost.empty()) {
+    clk.reset(new StageClock(ST_RELOCALIZE));
+    if (!detected_ahead) {  // Reproject searches the new frame's corners
+      Frame::DetectBatch(frames, Config::NumFeatures());
+      detected_now = true;
+    }
+    vector<char> found;
+    RelocalizeLost(lost, stats, &found);
+    vector<int> again;
+    for (size_t q = 0; q < lost.size(); q++)
+      if (found[q]) again.push_back(lost[q]);
+    if (!again.empty()) {
+      vector<char> built;
+      UploadTables(again, &built);
+      for (size_t q = 0; q < again.size(); q++) {
+        SDVL &t = *trk_[again[q]];
+        t.current_frame_->SetPose(SE3::Exp(t.vel_) * t.last_frame_->GetPose());  // SetMotionModel, sdvl.cc:278-281 (vel_ = 0)
+        (built[q] ? run : host_run).push_back(again[q]);
+      }
+      std::sort(run.begin(), run.end());
+    }
+    clk.reset(new StageClock(ST_PRELUDE));
+  }
   const int R = static_cast<int>(run.size());
 
-  vector<char> decision(R, 0);  // 0 = tracking lost, 1 = ordinary frame, 2 = new keyframe
+  vector<char> decision(B, 0);  // per tracker: 0 = tracking lost / not tracked, 1 = ordinary frame, 2 = new keyframe
   vector<shared_ptr<Frame>> kfs;
   vector<int> kf_owner;
   bool filter_begun = false;
@@ -906,7 +1079,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     // (sdvl_ctx_fork_*); a farm's large batches keep one stream per group — there the other groups are the company.
     // SDVL_DETECT_FORK=0 / 1 forces it off / on.
     static const int fork_env = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
-    const bool fork_detect = !detected_ahead && (fork_env >= 0 ? fork_env != 0 : B <= 32);
+    const bool fork_detect = !detected_ahead && !detected_now && (fork_env >= 0 ? fork_env != 0 : B <= 32);
     if (fork_detect) dev_->Check(sdvl_ctx_fork_mark(dev_->ctx()), "sdvl_ctx_fork_mark");  // the pyramids are queued: the side chain starts here
     dev_->Check(sdvl_track_align(dev_->ctx(), track_, R, tr_jobs_.data(), tr_rank_.data(), tr_rand_.data(), &cam, &prm), "sdvl_track_align");
     if (fork_detect) {
@@ -918,7 +1091,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         throw;
       }
       dev_->Check(sdvl_ctx_fork_end(dev_->ctx()), "sdvl_ctx_fork_end");
-    } else if (!detected_ahead) {
+    } else if (!detected_ahead && !detected_now) {
       Frame::DetectBatch(frames, Config::NumFeatures());  // FAST + selection run behind the alignment
     }
     clk.reset(new StageClock(ST_SEARCH));
@@ -980,35 +1153,41 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
       }
       t.CalcTrackingQuality(t.matches_, t.attempts_);
       if (t.tracking_quality_ != SDVL::TRACKING_BAD)
-        decision[k] = (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) ? 2 : 1;
+        decision[i] = (t.tracking_quality_ == SDVL::TRACKING_GOOD && t.map_->NeedKeyframe(t.current_frame_, t.matches_)) ? 2 : 1;
     });
+  }
+  // (a relocalised tracker whose keyframe no table can hold: the per-object calls, behind the batch's chain on the same stream)
+  for (int i : host_run) decision[i] = static_cast<char>(TrackOnHost(*trk_[i], &stats[i]));
+  vector<int> act(run);  // every tracker that executed ProcessFrame this step
+  act.insert(act.end(), host_run.begin(), host_run.end());
+  if (!act.empty()) {
     // the keyframes are known: queue their FilterCorners inputs now; the bookkeeping below runs meanwhile
     clk.reset(new StageClock(ST_POSE));
     {
       vector<char> fresh(B, 0);
-      for (int k = 0; k < R; k++)
-        if (decision[k] == 2 && !dynamic_cast<MapperMap *>(trk_[run[k]]->map_)) fresh[run[k]] = 1;
+      for (int i : act)
+        if (decision[i] == 2 && !dynamic_cast<MapperMap *>(trk_[i]->map_)) fresh[i] = 1;
       for (int i = 0; i < B; i++) {
         if (trk_[i]->pending_kf_) { kfs.push_back(trk_[i]->pending_kf_); kf_owner.push_back(i); }
         else if (fresh[i]) { kfs.push_back(trk_[i]->current_frame_); kf_owner.push_back(i); }
       }
       if (!kfs.empty()) {
         StageClock fclk(ST_MAPPING);
-        for (int i = 0; i < B; i++)
-          if (stats[i].state == 0) { FetchCornerCounts(frames, stats); break; }  // bootstrap frames: their counts did not ride along
+        // bootstrap frames and the frames of trackers that sat the step out or were tracked by hand: their counts did not ride along
+        if (static_cast<int>(run.size()) < B) FetchCornerCounts(frames, stats);
         Frame::FilterCornersBegin(kfs);
         filter_begun = true;
       }
     }
     static const bool flat_keyframes = std::getenv("SDVL_KEYFRAME_OBJECTS") == nullptr;  // =1: round 3's path (A/B)
-    vector<int> r_matches(R);
-    for (int k = 0; k < R; k++) r_matches[k] = tr_res_[k].matches;
-    ParallelFor(R, [&](int k) {
-      const int i = run[k];
+    vector<int> r_matches(B, 0);
+    for (int k = 0; k < R; k++) r_matches[run[k]] = tr_res_[k].matches;
+    ParallelFor(static_cast<int>(act.size()), [&](int a) {
+      const int i = act[a];
       SDVL &t = *trk_[i];
       FrameStats &st = stats[i];
-      if (decision[k] == 0) return;  // tracking lost: last_frame and its table stay
-      if (decision[k] == 2) {
+      if (decision[i] == 0) return;  // tracking lost: last_frame and its table stay
+      if (decision[i] == 2) {
         // Round 4, plane-map trackers: the keyframe's ~190 matched features STAY flat records and its table stays the one the step has
         // just left on the device — what the keyframe adds (the points the map seeds in its empty cells, ~60) is appended to both
         // sides after the seeding (EpilogueAndMapper -> AppendSeeds -> sdvl_track_append).  Until round 3 every keyframe turned its
@@ -1018,7 +1197,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         // the host-driven path, a table rebuild when the rows run out), the points learn of their observations then.
         const bool plane = !dynamic_cast<MapperMap *>(t.map_);
         const size_t rows = t.track_.points ? t.track_.points->size() : static_cast<size_t>(track_cap_);
-        const bool room = static_cast<int>(rows) + track_cells_ <= track_cap_ && r_matches[k] + track_cells_ <= track_cap_;
+        const bool room = static_cast<int>(rows) + track_cells_ <= track_cap_ && r_matches[i] + track_cells_ <= track_cap_;
         if (flat_keyframes && plane && room && t.current_frame_->HasFlatFeatures()) {
           t.current_frame_->LinkPointsOnMaterialize();
           t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
@@ -1041,14 +1220,14 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         st.keyframe = 1;
       } else {
         t.map_->AddFrame(t.current_frame_);
-        t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
+        if (t.current_frame_->HasFlatFeatures()) t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
       }
       t.last_frame_ = t.current_frame_;
     });
   }
   clk.reset();
   next_imgs_.clear();  // a look-ahead belongs to ONE step, whether that step could use it (R == B tracked frames) or not (bootstrap)
-  if (R == 0 && !detected_ahead) {  // bootstrap-only step: the new keyframes still need their corners
+  if (R == 0 && !detected_ahead && !detected_now) {  // bootstrap-only step: the new keyframes still need their corners
     // (a small batch detects on the side stream here too: the stream and its queue exist by the time a tracked frame forks)
     static const int fork_env0 = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
     const bool fork0 = fork_env0 >= 0 ? fork_env0 != 0 : B <= 32;
@@ -1160,6 +1339,7 @@ void SDVLBatch::HandleFramesGeneric(const vector<Image> &imgs, FrameStats *stats
     SDVL &t = *trk_[i];
     FrameStats &st = stats[i];
     st = FrameStats();
+    st.host_path = 1;
     t.current_frame_ = frames[i];
     t.current_frame_->SetID(t.frame_counter_++);
     if (t.state_ != SDVL::STATE_RUNNING) {

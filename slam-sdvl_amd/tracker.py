@@ -12,7 +12,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "host", "libsdvl_host.so")
 class FrameStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("state", "quality", "matches", "attempts", "inliers", "outliers", "n_corners",
                                        "align_meas", "keyframe", "relocalized")] + [("pose", C.c_double * 7)] + [
-        (n, C.c_int) for n in ("align_features", "align_iters", "search_requests", "lk_iters")]
+        (n, C.c_int) for n in ("align_features", "align_iters", "search_requests", "lk_iters", "host_path")]
 
 
 _lib = None
@@ -166,7 +166,7 @@ class TrackerBatch:
 
     STAGES = ["upload_pyr", "fast", "select", "corners_orb", "prelude", "image_align", "prepare", "search", "finish", "pose", "mapping",
               "epilogue", "mapper", "total", "map_candidates", "map_connections", "map_init", "map_finish",
-              "map_begin", "map_emit", "map_search", "map_apply"]
+              "map_begin", "map_emit", "map_search", "map_apply", "relocalize"]
 
     def map_stats(self, i):
         """mapper mode only: candidates, converged, initialized, linked, connected, keyframes of tracker i"""
