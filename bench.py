@@ -607,6 +607,11 @@ def main():
                          "0 = skip; default 600 for S-A on one GPU")
     ap.add_argument("--sustained-max-keyframes", type=int, default=48,
                     help="SDVL.max_keyframes of the sustained leg (the reference's cfg files say 1000, its default is 100: config.cc:63); 0 = the workload's")
+    ap.add_argument("--lost-mix-steps", type=int, default=-1,
+                    help="steps of the LOST-MIX leg (VERDICT r05 #1): a fresh farm on a pool of distinct sequences resident in HBM runs 40 undisturbed steps "
+                         "(its own baseline), then this many steps in which 5 %% of the trackers are blinded (a featureless frame) for 5 frames every 50 "
+                         "frames: they go TRACKING_BAD x3, relocalise over their keyframes inside the tabled step and rejoin; reported as value_lost_mix "
+                         "and lost_mix; 0 = skip; default 100 for S-A / S-B on one GPU")
     ap.add_argument("--host-steps", type=int, default=-1,
                     help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
@@ -644,6 +649,8 @@ def main():
         args.host_steps = 16 if world == 1 else 8
     if args.sustained_frames < 0:
         args.sustained_frames = 600 if (world == 1 and args.workload == "S-A" and not args.mapper and not dry) else 0
+    if args.lost_mix_steps < 0:
+        args.lost_mix_steps = 100 if (world == 1 and args.workload in ("S-A", "S-B") and not args.mapper and not dry) else 0
     dist = None
     if dry:
         return dry_rank(args, rank, world)
@@ -931,13 +938,81 @@ def main():
     # through the farm's input ring like the host-fed leg — every tracker's frames cross the link, nothing is shared on the device.
     sustained = None
     NF = args.sustained_frames
-    if NF > Wm + 2:
-        import resource as _res
+    lost_mix = None
+    if NF > Wm + 2 or args.lost_mix_steps > 0:
         lib_hip = pkg.load_library()
         ctx.check(lib_hip.sdvl_device_free(ctx.h, C.c_void_p(buf)))
         farm.close()                        # the first legs' trackers, keyframes and rings go
         farm = None
         torch.cuda.synchronize()
+    # ---- LOST-MIX leg: what a farm of real cameras sees — now and then a camera is covered or looks at a blank wall.  Until round 5 one
+    # tracker with lost_frames >= 3 sent its whole batch of 256 to the host-driven path (14 k frame-steps/s); now its Relocalize
+    # (sdvl.cc:73-89,205-238) runs inside the tabled step.  Input: D distinct sequences resident in HBM (tracker i follows i mod D) and ONE
+    # featureless frame; a blinded tracker resumes, five steps later, with the frame it would have seen when it was blinded.
+    if args.lost_mix_steps > 0:
+        M, base_steps, blind_len, period, D = args.lost_mix_steps, 40, 5, 50, min(B, 32)
+        NFp = 1 + Wm + base_steps + M
+        farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
+        farm.set_fibers(fibers)
+        ctx3 = CtxView(pkg, farm.ctx_handle(0))
+        pool = ctx3.malloc(D * NFp * frame_bytes)
+        for k in range(NFp):
+            views = [make_view(pkg, se3_exp(shard.sequence_twist(d) * k), SEQ_SEED(d), k) for d in range(D)]
+            ctx3.render(views, pool + k * D * frame_bytes)
+        grey_t = torch.full((frame_bytes,), 127, dtype=torch.uint8, device="cuda")   # (device memory for one frame; torch is the plumbing here)
+        torch.cuda.synchronize()
+        grey = grey_t.data_ptr()
+        lp = np.zeros((NFp, B), np.uint64)
+        first_mixed = 1 + Wm + base_steps
+        n_blinded = 0
+        for i in range(B):
+            kk = 0
+            for k in range(NFp):
+                s_mix = k - first_mixed
+                e = s_mix // period if s_mix >= 0 else -1
+                blind = e >= 0 and (i % 20) == (10 * e) % 20 and (s_mix - e * period) < blind_len
+                if blind:
+                    lp[k, i] = grey
+                    n_blinded += 1
+                else:
+                    lp[k, i] = pool + (kk * D + i % D) * frame_bytes
+                    kk += 1
+        farm.reserve(Bg * (NFp // 4 + 8))
+        farm.run(lp[:1 + Wm], workers)                           # bootstrap keyframe + warm-up, untimed
+        lbuf = farm.alloc_stats(max(base_steps, M))
+        barrier()
+        t0 = time.perf_counter()
+        st_a = farm.run(lp[1 + Wm:first_mixed], workers, lbuf)
+        barrier()
+        el_a = time.perf_counter() - t0
+        tracked_a = sum(int(st.quality != 2) for st in st_a[:base_steps * B])
+        farm.stage_times(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        st_m = farm.run(lp[first_mixed:], workers, lbuf)
+        barrier()
+        el_m = time.perf_counter() - t0
+        mix = st_m[:M * B]
+        tracked_m = sum(int(st.quality != 2) for st in mix)
+        lm_stage_s, lm_stage_n = farm.stage_times()
+        lost_mix = {"value": round(tracked_m / el_m, 2), "unit": "tracked frames/s", "steps": M, "ms_per_step": round(el_m / M * 1e3, 3),
+                    "undisturbed_value": round(tracked_a / el_a, 2), "undisturbed_steps": base_steps,
+                    "ratio_to_undisturbed": round((tracked_m / el_m) / max(1e-9, tracked_a / el_a), 4),
+                    "frame_steps_per_s": round(M * B / el_m, 2),
+                    "blinded_tracker_frames": n_blinded, "lost_frames": M * B - tracked_m,
+                    "relocalized": sum(int(st.relocalized) for st in mix),
+                    "frames_on_the_host_driven_path": sum(int(st.host_path != 0) for st in mix),
+                    "relocalize_host_ms_per_group_step": round(lm_stage_s.get("relocalize", 0.0) / max(1, lm_stage_n) * 1e3, 3),
+                    "schedule": "every %d steps 1 tracker in 20 sees %d featureless frames: TRACKING_BAD x3, two steps of Relocalize over its keyframes that fail, "
+                                "one that succeeds" % (period, blind_len),
+                    "input": "%d distinct sequences x %d frames resident in HBM (tracker i follows sequence i mod %d), one shared featureless frame" % (D, NFp, D)}
+        ctx3.check(lib_hip.sdvl_device_free(ctx3.h, C.c_void_p(pool)))
+        farm.close()
+        farm = None
+        del grey_t
+        torch.cuda.synchronize()
+    if NF > Wm + 2:
+        import resource as _res
         free0, total0 = torch.cuda.mem_get_info()
         D = min(B, int(os.environ.get("SDVL_BENCH_SUSTAINED_DISTINCT", "32")))
         max_kf = args.sustained_max_keyframes
@@ -973,8 +1048,13 @@ def main():
             farm.reserve(Bg * kf_budget)
             farm.run(sptrs[:1 + Wm], workers)                      # bootstrap keyframe + warm-up, untimed
             Ks = NF - 1 - Wm
-            half = Ks // 2                                         # the timed region in two halves: memory is read in between
-            sbuf = farm.alloc_stats(Ks - half)
+            half = Ks // 2                                         # memory is read at the middle of the timed region and at its end
+            # the timed region in chunks of ~100 steps: frame-steps/s and the tracked share of each — a long sequence may lose its scene
+            # (S-A's plane leaves the view after ~900 frames: from then on every tracker relocalises at every frame)
+            n_chunks = max(2, min(16, Ks // 100))
+            n_chunks += n_chunks % 2                               # (even: the middle of the region is a chunk boundary)
+            bounds = [half * c // (n_chunks // 2) for c in range(n_chunks // 2)] + [half + (Ks - half) * c // (n_chunks // 2) for c in range(n_chunks // 2 + 1)]
+            sbuf = farm.alloc_stats(max(bounds[c + 1] - bounds[c] for c in range(n_chunks)))
 
             def mem_now():
                 torch.cuda.synchronize()
@@ -987,21 +1067,23 @@ def main():
                 except (OSError, ValueError):
                     pass
                 return round((total0 - fr) / 1e9, 1), round(rss, 1)
-            barrier()
-            t0 = time.perf_counter()
-            sstats_a = farm.run(sptrs[1 + Wm:1 + Wm + half], workers, sbuf)
-            barrier()
-            elapsed_a = time.perf_counter() - t0
-            tracked_s = sum(int(st.quality != 2) for st in sstats_a[:half * B])
-            kf_s = sum(int(st.keyframe) for st in sstats_a[:half * B])
-            mem_mid = mem_now()
-            barrier()
-            t0 = time.perf_counter()
-            sstats_b = farm.run(sptrs[1 + Wm + half:], workers, sbuf)
-            barrier()
-            elapsed_s = elapsed_a + (time.perf_counter() - t0)
-            tracked_s += sum(int(st.quality != 2) for st in sstats_b[:(Ks - half) * B])
-            kf_s += sum(int(st.keyframe) for st in sstats_b[:(Ks - half) * B])
+            elapsed_s, tracked_s, kf_s, phases, mem_mid = 0.0, 0, 0, [], None
+            for c in range(n_chunks):
+                a, b = bounds[c], bounds[c + 1]
+                barrier()
+                t0 = time.perf_counter()
+                sst = farm.run(sptrs[1 + Wm + a:1 + Wm + b], workers, sbuf)
+                barrier()
+                el = time.perf_counter() - t0
+                trk_c = sum(int(st.quality != 2) for st in sst[:(b - a) * B])
+                kf_s += sum(int(st.keyframe) for st in sst[:(b - a) * B])
+                hp_c = sum(int(st.host_path != 0) for st in sst[:(b - a) * B])
+                elapsed_s += el
+                tracked_s += trk_c
+                phases.append({"first_frame": 1 + Wm + a, "steps": b - a, "tracked_fraction": round(trk_c / ((b - a) * B), 4),
+                               "frame_steps_per_s": round((b - a) * B / el, 1), "frames_on_the_host_driven_path": hp_c})
+                if b == half:
+                    mem_mid = mem_now()
             mem_end = mem_now()
             sustained = {"value": round(tracked_s / elapsed_s, 2), "unit": "frames/s", "frames_per_sequence": NF, "timed_steps": Ks, "ms_per_step": round(elapsed_s / Ks * 1e3, 3),
                          "sequences_per_gpu": B, "tracked_fraction": round(tracked_s / (B * Ks), 5),
@@ -1011,6 +1093,11 @@ def main():
                          "host_rss_gb_at_frame_%d" % (1 + Wm + half): mem_mid[1], "host_rss_gb_at_end": mem_end[1],
                          "host_max_rss_gb": round(_res.getrusage(_res.RUSAGE_SELF).ru_maxrss / 1e6, 1),
                          "pcie_h2d_gb_per_s": round(B * Ks * frame_bytes / elapsed_s / 1e9, 2),
+                         "phases": phases,
+                         "lost_phase_frame_steps_per_s": (lambda lp: round(sum(p_["steps"] for p_ in lp) * B / sum(p_["steps"] * B / p_["frame_steps_per_s"] for p_ in lp), 1) if lp else None)(
+                             [p_ for p_ in phases if p_["tracked_fraction"] < 0.02]),
+                         "lost_phase_note": "chunks of the timed region in which under 2 % of the frames were tracked: every tracker runs Relocalize (sdvl.cc:205-238) "
+                                            "over all its keyframes at every frame, inside the tabled step",
                          "input": "host-fed through the input ring from %d distinct sequences x %d frames in pinned host memory (tracker i follows sequence i mod %d)" % (D, NF, D)}
             farm.set_host_input(False)
             del spool
@@ -1144,6 +1231,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
             "value_host_fed": host_fed["value"] if host_fed else None, "host_fed": host_fed,
             "value_sustained": sustained["value"] if sustained else None, "sustained": sustained,
+            "value_lost_mix": lost_mix["value"] if lost_mix else None, "lost_mix": lost_mix,
             "config": {"workload": "%s: synthetic %s %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step%s" % (args.workload, {"S-A": "TUM fr1-like", "S-B": "EuRoC MH_01-like (config_euroc.cfg)", "S-C": "roofline case"}[args.workload], W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",

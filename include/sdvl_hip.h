@@ -310,6 +310,17 @@ int sdvl_image_align(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int 
 int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, int n_features,
                            const sdvl_align_feature *features, const sdvl_camera *cam, const sdvl_align_params *p);
 int sdvl_image_align_end(sdvl_ctx *ctx, int n_jobs, sdvl_align_result *out);
+/* SDVL::Relocalize (sdvl.cc:205-238) calls ImageAlign::ComputePose(keyframe, current, fast) for EVERY keyframe of the map at every
+ * frame a tracker stays lost: frame1's feature records are the same from one frame to the next.  A store keeps them in HBM:
+ * _create reserves `capacity` records, _write fills records [offset, offset + n) (ordered behind the context's queued work, complete
+ * on return), and sdvl_image_align_begin_stored is sdvl_image_align_begin with the jobs' feat_begin / feat_end naming records of the
+ * store - per frame only the job records cross the link.  Results through sdvl_image_align_end as usual. */
+typedef struct sdvl_align_store sdvl_align_store;
+int sdvl_align_store_create(sdvl_ctx *ctx, int capacity, sdvl_align_store **out);
+int sdvl_align_store_destroy(sdvl_ctx *ctx, sdvl_align_store *store);
+int sdvl_align_store_write(sdvl_ctx *ctx, sdvl_align_store *store, int offset, int n, const sdvl_align_feature *features);
+int sdvl_image_align_begin_stored(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, const sdvl_align_store *store,
+                                  const sdvl_camera *cam, const sdvl_align_params *p);
 
 /* ---- Matcher::SearchPoint, matcher.cc:45-121 (WarpMatrixAffine :293-312, GetSearchLevel :314-323,
  * CreatePatch :325-357, GetCornersInRange :123-230, SearchFeatures :232-291, AlignPatch :359-445).

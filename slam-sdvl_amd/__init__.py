@@ -125,7 +125,7 @@ ABI_SYMBOLS = [
     "sdvl_pyramid_build", "sdvl_frame_download_level", "sdvl_fast_num_cells", "sdvl_fast_cells",
     "sdvl_detect_corners", "sdvl_frames_corner_counts", "sdvl_frame_download_corners", "sdvl_retain_best",
     "sdvl_frame_set_corners", "sdvl_frames_set_corners", "sdvl_frame_num_corners", "sdvl_shi_tomasi", "sdvl_orb_describe",
-    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_filter_inputs_begin", "sdvl_filter_inputs_end", "sdvl_filter_corners_begin", "sdvl_filter_corners_end", "sdvl_orb_describe_points", "sdvl_hamming_argmin", "sdvl_image_align", "sdvl_image_align_begin", "sdvl_image_align_end", "sdvl_search_points", "sdvl_search_begin", "sdvl_search_slot", "sdvl_search_run", "sdvl_align_patches", "sdvl_pose_from_matches", "sdvl_search_points_filter", "sdvl_search_run_filter", "sdvl_search_run_chain", "sdvl_search_chain_end", "sdvl_frame_footprint", "sdvl_undistort", "sdvl_frames_upload_undistorted", "sdvl_ctx_set_wait_hook", "sdvl_ctx_wait_done", "sdvl_ctx_wait_block", "sdvl_ctx_health", "sdvl_ctx_counters",
+    "sdvl_frame_download_descriptors", "sdvl_filter_inputs", "sdvl_filter_inputs_begin", "sdvl_filter_inputs_end", "sdvl_filter_corners_begin", "sdvl_filter_corners_end", "sdvl_orb_describe_points", "sdvl_hamming_argmin", "sdvl_image_align", "sdvl_image_align_begin", "sdvl_image_align_end", "sdvl_align_store_create", "sdvl_align_store_destroy", "sdvl_align_store_write", "sdvl_image_align_begin_stored", "sdvl_search_points", "sdvl_search_begin", "sdvl_search_slot", "sdvl_search_run", "sdvl_align_patches", "sdvl_pose_from_matches", "sdvl_search_points_filter", "sdvl_search_run_filter", "sdvl_search_run_chain", "sdvl_search_chain_end", "sdvl_frame_footprint", "sdvl_undistort", "sdvl_frames_upload_undistorted", "sdvl_ctx_set_wait_hook", "sdvl_ctx_wait_done", "sdvl_ctx_wait_block", "sdvl_ctx_health", "sdvl_ctx_counters",
     "sdvl_track_create", "sdvl_track_destroy", "sdvl_frame_register", "sdvl_frames_register", "sdvl_track_upload", "sdvl_track_append", "sdvl_track_align", "sdvl_track_search",
     "sdvl_track_collect", "sdvl_track_features", "sdvl_track_stats",
     "sdvl_synth_render", "sdvl_device_malloc", "sdvl_device_free", "sdvl_device_download",

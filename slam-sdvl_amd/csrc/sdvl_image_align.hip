@@ -1712,6 +1712,53 @@ extern "C" int sdvl_image_align_begin(sdvl_ctx *ctx, int n_jobs, const sdvl_alig
   return SDVL_OK;
 }
 
+// ---- feature records that stay in HBM (Relocalize, sdvl.cc:205-238: every new frame is aligned against the SAME keyframes)
+struct sdvl_align_store {
+  sdvl_align_feature *d;
+  int cap;
+};
+
+extern "C" int sdvl_align_store_create(sdvl_ctx *ctx, int capacity, sdvl_align_store **out) {
+  if (!ctx || !out || capacity <= 0) return SDVL_ERR_INVALID;
+  SDVL_HIP_CHECK(ctx, sdvl_bind_device(ctx));
+  void *d = nullptr;
+  SDVL_HIP_CHECK(ctx, hipMalloc(&d, sizeof(sdvl_align_feature) * static_cast<size_t>(capacity)));
+  *out = new sdvl_align_store{static_cast<sdvl_align_feature *>(d), capacity};
+  return SDVL_OK;
+}
+
+extern "C" int sdvl_align_store_destroy(sdvl_ctx *ctx, sdvl_align_store *store) {
+  if (!ctx) return SDVL_ERR_INVALID;
+  if (!store) return SDVL_OK;
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));  // alignments that read it may still be queued
+  SDVL_HIP_CHECK(ctx, hipFree(store->d));
+  delete store;
+  return SDVL_OK;
+}
+
+// records [offset, offset + n) of the store <- features; ordered behind the context's queued work, complete on return
+extern "C" int sdvl_align_store_write(sdvl_ctx *ctx, sdvl_align_store *store, int offset, int n, const sdvl_align_feature *features) {
+  if (!ctx || !store || offset < 0 || n < 0 || (n > 0 && !features)) return SDVL_ERR_INVALID;
+  SDVL_REQUIRE(ctx, offset + n <= store->cap, "sdvl_align_store_write beyond the store's capacity");
+  if (n == 0) return SDVL_OK;
+  SDVL_HIP_CHECK(ctx, hipMemcpyAsync(store->d + offset, features, sizeof(sdvl_align_feature) * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
+  SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
+  return SDVL_OK;
+}
+
+// sdvl_image_align_begin with the jobs' feat_begin / feat_end naming records of `store`: nothing but the job records crosses the link
+extern "C" int sdvl_image_align_begin_stored(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jobs, const sdvl_align_store *store, const sdvl_camera *cam,
+                                             const sdvl_align_params *p) {
+  if (!ctx || !cam || !p || !store || n_jobs < 0 || (n_jobs > 0 && !jobs)) return SDVL_ERR_INVALID;
+  ctx->align_pending = 0;
+  if (n_jobs == 0) return SDVL_OK;
+  const int rc = sdvl_image_align_enqueue(ctx, n_jobs, jobs, store->cap, nullptr, store->d, cam, p, nullptr);
+  if (rc) return rc;
+  SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_ALIGN, &ctx->align_ticket));
+  ctx->align_pending = n_jobs;
+  return SDVL_OK;
+}
+
 // waits for the results of the matching sdvl_image_align_begin only — not for work queued after it
 extern "C" int sdvl_image_align_end(sdvl_ctx *ctx, int n_jobs, sdvl_align_result *out) {
   if (!ctx || n_jobs < 0 || (n_jobs > 0 && !out)) return SDVL_ERR_INVALID;

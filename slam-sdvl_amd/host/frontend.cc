@@ -743,6 +743,26 @@ sdvl_align_params AlignParams(bool fast) {
   return ap;
 }
 
+// what ComputePose reads of frame1's features (image_align.cc:147-160,219-236), appended to `feats`
+void ImageAlign::PackFeatures(Frame &f1, vector<sdvl_align_feature> *feats) {
+  const Vector3d first_pos = f1.GetWorldPosition();
+  for (auto &ft : f1.GetFeatures()) {
+    sdvl_align_feature a;
+    a.px = ft->GetPosition()(0); a.py = ft->GetPosition()(1);
+    a.fx = ft->GetVector()(0); a.fy = ft->GetVector()(1); a.fz = ft->GetVector()(2);
+    Point *pt = ft->GetPointRaw();
+    a.valid = (pt && !pt->ToDelete()) ? 1 : 0;
+    a.depth = 0.0;
+    if (a.valid) {
+      const Vector3d p = pt->GetPosition();
+      const double dx = p(0) - first_pos(0), dy = p(1) - first_pos(1), dz = p(2) - first_pos(2);
+      a.depth = std::sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    a.pad_ = 0;
+    feats->push_back(a);
+  }
+}
+
 // image_align.cc:46-84 for n pairs with one launch
 void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> &pairs, bool fast, vector<int> *n_meas,
                                   vector<double> *errors, vector<int> *iters, const vector<SE3> *start_poses, vector<SE3> *out_poses,
@@ -772,26 +792,11 @@ void ImageAlign::ComputePoseBatch(const vector<std::pair<shared_ptr<Frame>, shar
       std::cerr << "[ERROR] No points to track!" << std::endl;  // image_align.cc:55-58
       continue;
     }
-    const Vector3d first_pos = f1.GetWorldPosition();
     sdvl_align_job job;
     job.ref = f1.device();
     job.cur = f2.device();
     job.feat_begin = static_cast<int32_t>(feats.size());
-    for (auto &ft : features) {
-      sdvl_align_feature a;
-      a.px = ft->GetPosition()(0); a.py = ft->GetPosition()(1);
-      a.fx = ft->GetVector()(0); a.fy = ft->GetVector()(1); a.fz = ft->GetVector()(2);
-      Point *pt = ft->GetPointRaw();
-      a.valid = (pt && !pt->ToDelete()) ? 1 : 0;
-      a.depth = 0.0;
-      if (a.valid) {
-        const Vector3d p = pt->GetPosition();
-        const double dx = p(0) - first_pos(0), dy = p(1) - first_pos(1), dz = p(2) - first_pos(2);
-        a.depth = std::sqrt(dx * dx + dy * dy + dz * dz);
-      }
-      a.pad_ = 0;
-      feats.push_back(a);
-    }
+    PackFeatures(f1, &feats);
     job.feat_end = static_cast<int32_t>(feats.size());
     const SE3 T = (start_poses ? (*start_poses)[i] : f2.GetPose()) * f1.GetPose().Inverse();  // image_align.cc:66
     T.ToArray(job.T);

@@ -424,6 +424,8 @@ class ImageAlign {
   // (corner detection of the new frames) runs behind the alignment while the host already continues with the poses
   // start_poses[i]: pose of pairs[i].second to start from (default: its current pose); out_poses: where the aligned
   // poses go instead of into the frames — together they let ONE frame be aligned against many references at once
+  // what ComputePose reads of frame1's features, as the device's records, appended to `feats`
+  static void PackFeatures(Frame &frame1, std::vector<sdvl_align_feature> *feats);
 
  private:
   double error_ = 1e10;

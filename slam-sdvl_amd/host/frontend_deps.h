@@ -155,7 +155,7 @@ class Map {
   virtual void UpdateMap() {}
   virtual void Start() {}
   virtual void Stop() {}
-  void DeletePoint(const std::shared_ptr<Point> &p) { points_trash_.push_back(p); }
+  void DeletePoint(const std::shared_ptr<Point> &p) { points_trash_.push_back(p); version_++; }
   bool NeedKeyframe(const std::shared_ptr<Frame> &frame, int matches);  // map.cc:170-188
   virtual void AddKeyframe(const std::shared_ptr<Frame> &frame, bool search = true);
   virtual void AddFrame(const std::shared_ptr<Frame> &) {}
@@ -166,6 +166,10 @@ class Map {
   // tracker's table must be rebuilt before the next step
   bool TakeTablesDirty() { const bool d = tables_dirty_; tables_dirty_ = false; return d; }
   std::vector<std::shared_ptr<Frame>> &GetKeyframes() { return keyframes_; }
+  // (an addition) changes whenever the keyframe list or a point behind a keyframe's feature changed (added / culled keyframe, deleted
+  // point, a mapper update): what SDVLBatch's relocalisation cache of keyframe feature records is checked against
+  unsigned long long Version() const { return version_; }
+  void Touch() { version_++; }
   // mapper work for a fresh keyframe (Map::InitCandidates stand-in); called outside the tracking stages
   virtual void InitCandidates(const std::shared_ptr<Frame> &) {}
 
@@ -173,6 +177,7 @@ class Map {
   std::vector<std::shared_ptr<Frame>> keyframes_;
   std::vector<std::shared_ptr<Point>> points_trash_;
   bool tables_dirty_ = false;
+  unsigned long long version_ = 0;
   std::shared_ptr<Frame> last_kf_;
   int last_matches_ = 0;
   std::mutex mutex_map_;

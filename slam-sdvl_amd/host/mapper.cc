@@ -217,6 +217,7 @@ void MapperMap::AddKeyframe(const shared_ptr<Frame> &frame, bool search) {
   if (search) keyframe_queue_.push_back(frame);
   else initial_kf_id_ = std::max(initial_kf_id_, frame->GetID());
   num_kfs_++;
+  version_++;
   frame->SetKeyframeID(num_kfs_);
   keyframes_.push_back(frame);
   retired_.push_back(frame);
@@ -244,6 +245,7 @@ void MapperMap::LimitKeyframes(const shared_ptr<Frame> &frame) {
 
 // map.cc:207-259
 void MapperMap::EmptyTrash() {
+  if (!frame_trash_.empty()) version_++;
   for (auto fit = frame_trash_.begin(); fit != frame_trash_.end(); fit++) {
     if ((*fit)->IsKeyframe())
       for (auto it = keyframes_.begin(); it != keyframes_.end(); it++)
@@ -282,6 +284,7 @@ bool MapperMap::BeginUpdate() {
     frame_queue_.pop_front();
   }
   updates_++;
+  version_++;  // the depth filter moves candidates, connections add features to keyframes
   depth_mean_ = cur_->GetSceneDepth();
   pass_ = 0;
   occurrence_.assign(candidates_.size(), 0);

@@ -209,6 +209,16 @@ class SDVL {
     bool append_pending = false;
     size_t first_seed = 0;
   } track_;
+  // Relocalize (sdvl.cc:205-238) aligns every new frame against the same keyframes: their feature records live in the batch's
+  // sdvl_align_store from the first lost frame until the map changes (Map::Version)
+  struct RelocCache {
+    const void *owner = nullptr;               // the SDVLBatch whose store holds the records
+    unsigned long long version = ~0ull;        // Map::Version() the records were packed at
+    unsigned long long epoch = 0;              // the store's epoch (a store that was reset has lost them)
+    std::vector<std::shared_ptr<Frame>> kfs;   // newest first, the order Relocalize visits them in
+    std::vector<int32_t> begin;                // kfs.size() + 1 record offsets in the store
+    std::vector<double> T;                     // 7 per keyframe: start pose * keyframe pose^-1 (image_align.cc:66 with frame2 at the keyframe's pose)
+  } reloc_;
 };
 
 // B independent trackers stepping together, one launch per kernel per stage (MI355X-first driver)
@@ -264,6 +274,11 @@ class SDVLBatch {
   void EpilogueAndMapper(const std::vector<std::shared_ptr<Frame>> &frames, FrameStats *stats, std::vector<std::shared_ptr<Frame>> *kfs,
                          std::vector<int> *kf_owner, bool filter_begun);
   sdvl_track_set *track_ = nullptr;
+  // keyframe feature records of the trackers that are relocalising (SDVL::RelocCache): one bump-allocated store per batch
+  sdvl_align_store *reloc_store_ = nullptr;
+  int reloc_cap_ = 0, reloc_used_ = 0;
+  unsigned long long reloc_epoch_ = 0;  // 0: no store yet
+  void RelocAlign(const std::vector<sdvl_align_job> &jobs, const sdvl_align_params &ap, std::vector<sdvl_align_result> *res);
   int track_cells_ = 0, track_cap_ = 0;
   bool persistent_ = true;  // SDVL::HandleFrame's one-shot batches never build tables
   friend class SDVL;

@@ -185,12 +185,14 @@ bool Map::NeedKeyframe(const shared_ptr<Frame> &frame, int) {
 
 // map.cc:145-159
 void Map::AddKeyframe(const shared_ptr<Frame> &frame, bool) {
+  version_++;
   keyframes_.push_back(frame);
   last_kf_ = frame;
 }
 
 // map.cc:207-259 (points)
 void Map::EmptyTrash() {
+  if (!points_trash_.empty()) version_++;
   for (auto &p : points_trash_) {
     if (!p->ToDelete() && p->TrackRow() >= 0 && !p->DeviceTrashed()) tables_dirty_ = true;
     std::list<shared_ptr<Feature>> &features = p->GetFeatures();
@@ -221,6 +223,7 @@ void PlaneMap::LimitKeyframes(const shared_ptr<Frame> &frame) {
 }
 
 void PlaneMap::EmptyTrash() {
+  if (!culled_.empty()) version_++;
   for (const shared_ptr<Frame> &kf : culled_) {
     // the points this keyframe seeded (their first observation is one of its features) go with it
     vector<shared_ptr<Feature>> &features = kf->GetFeatures();
@@ -264,6 +267,7 @@ void PlaneMap::SeedFromFiltered(const shared_ptr<Frame> &kf) {
     shared_ptr<Point> pt = kf->NewPoint();
     const double rho = 1.0 / s;
     pt->InitFixed(feature, s, (0.05 * rho) * (0.05 * rho), world * Vector3d(s * v(0), s * v(1), s * v(2)));
+    version_++;
     feature->SetPoint(pt);
     kf->AddFeature(feature);
     pt->AddFeature(feature);
@@ -553,6 +557,10 @@ SDVLBatch::~SDVLBatch() {
     Device::SetCurrent(dev_);
     sdvl_track_destroy(dev_->ctx(), track_);
   }
+  if (reloc_store_) {
+    Device::SetCurrent(dev_);
+    (void)sdvl_align_store_destroy(dev_->ctx(), reloc_store_);
+  }
 }
 
 static thread_local void *g_pool_slot = nullptr;
@@ -797,59 +805,162 @@ bool SDVLBatch::UploadTables(const vector<int> &need, vector<char> *built) {
   return true;
 }
 
+static std::atomic<unsigned long long> g_reloc_epoch{1};  // process-wide: a cache never mistakes another batch's store for its own
+
+// The alignments of RelocalizeLost: jobs whose feature ranges name records of the batch's store, in launches of bounded size
+// (a farm whose trackers are all lost asks for B x |keyframes| alignments per step).
+void SDVLBatch::RelocAlign(const vector<sdvl_align_job> &jobs, const sdvl_align_params &ap, vector<sdvl_align_result> *res) {
+  res->resize(jobs.size());
+  const sdvl_camera cam = trk_[0]->camera_->abi();
+  const size_t kChunk = 4096;
+  for (size_t b = 0; b < jobs.size(); b += kChunk) {
+    const int n = static_cast<int>(std::min(jobs.size(), b + kChunk) - b);
+    dev_->Check(sdvl_image_align_begin_stored(dev_->ctx(), n, jobs.data() + b, reloc_store_, &cam, &ap), "sdvl_image_align_begin_stored");
+    dev_->Check(sdvl_image_align_end(dev_->ctx(), n, res->data() + b), "sdvl_image_align_end");
+  }
+}
+
 // SDVL::Relocalize (sdvl.cc:73-89,205-238) for the trackers `lost` of a batch, inside the tabled step: the other trackers of the batch
 // are not touched.  The alignment of a tracker's current frame against EVERY keyframe of its map (each started from that keyframe's
-// pose, fast mode) is independent of the others: ONE launch for all (tracker, keyframe) pairs of all lost trackers.  The keyframe
-// loop then runs in the reference's order (newest first) over the results; Reproject(reloc = true) draws from rand() and stops at the
-// first keyframe that gathers MinMatches, so it stays sequential per tracker — but the trackers advance together: one search launch
-// per ROUND (a round = every unresolved tracker's next keyframe with error < 0.001; almost always there is one round).
+// pose, fast mode) is independent of the others: one launch for all (tracker, keyframe) pairs of all lost trackers.
+//  * The keyframes' feature records do not change while a tracker is lost (no tracked step, the mapper stands still): they are packed
+//    once and stay in HBM (sdvl_align_store; SDVL::RelocCache remembers where) — per frame only the job records cross the link.
+//  * Fast mode gives up behind the coarsest level when the update there is still > 0.01 (image_align.cc:73-76), and on a frame that
+//    shows something else nearly every keyframe does: the launch runs that level ONLY (a third of PrecomputePatches); the few jobs
+//    that pass it are run again in full — same start, same arithmetic, so both passes leave what one full pass would.
+// The keyframe loop then runs in the reference's order (newest first) over the results; Reproject(reloc = true) draws from rand() and
+// stops at the first keyframe that gathers MinMatches, so it stays sequential per tracker — but the trackers advance together: one
+// search launch per ROUND (a round = every unresolved tracker's next keyframe with error < 0.001; almost always there is one round).
 // (*found)[q]: tracker lost[q] has relocalised — last_frame_ = last_kf_ = the keyframe it landed on (sdvl.cc:84-86).
 void SDVLBatch::RelocalizeLost(const vector<int> &lost, FrameStats *stats, vector<char> *found) {
   const int L = static_cast<int>(lost.size());
   found->assign(L, 0);
-  vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> pairs;
-  vector<SE3> start, aligned;
-  vector<int> first(L + 1, 0);
+  // ---- the keyframes' records: packed for the trackers whose map changed since (or that were not lost before)
+  vector<vector<sdvl_align_feature>> fresh(L);
+  vector<char> stale(L, 0);
   for (int q = 0; q < L; q++) {
     SDVL &t = *trk_[lost[q]];
     SyncStats(t);                   // the Point objects Reproject reads catch up with the device's counters
     t.map_->SetRelocalizing(true);  // sdvl.cc:80
     for (int k = 0; k < 6; k++) t.vel_[k] = 0.0;
+    SDVL::RelocCache &rc = t.reloc_;
+    stale[q] = (!reloc_store_ || rc.owner != this || rc.epoch != reloc_epoch_ || rc.version != t.map_->Version()) ? 1 : 0;
+  }
+  ParallelFor(L, [&](int q) {
+    if (!stale[q]) return;
+    SDVL &t = *trk_[lost[q]];
+    SDVL::RelocCache &rc = t.reloc_;
+    rc.kfs.clear();
+    rc.begin.assign(1, 0);
+    rc.T.clear();
     vector<shared_ptr<Frame>> &kfs = t.map_->GetKeyframes();
-    first[q] = static_cast<int>(pairs.size());
     for (auto it = kfs.rbegin(); it != kfs.rend(); it++) {
-      pairs.push_back({*it, t.current_frame_});
-      start.push_back((*it)->GetPose());
+      rc.kfs.push_back(*it);
+      ImageAlign::PackFeatures(**it, &fresh[q]);
+      rc.begin.push_back(static_cast<int32_t>(fresh[q].size()));
+      double T7[7];
+      ((*it)->GetPose() * (*it)->GetPose().Inverse()).ToArray(T7);  // current_frame_->SetPose(cframe->GetPose()), then image_align.cc:66
+      rc.T.insert(rc.T.end(), T7, T7 + 7);
+    }
+  });
+  {
+    size_t need = 0;
+    for (int q = 0; q < L; q++)
+      if (stale[q]) need += fresh[q].size();
+    if (need > 0 && (!reloc_store_ || reloc_used_ + need > static_cast<size_t>(reloc_cap_))) {
+      // no room behind the records in use: a new store for what is live now (the other trackers' caches are void: epoch)
+      size_t live = need;
+      for (int q = 0; q < L; q++)
+        if (!stale[q]) {
+          stale[q] = 1;  // repack: its records die with the old store
+          SDVL &t = *trk_[lost[q]];
+          SDVL::RelocCache &rc = t.reloc_;
+          rc.kfs.clear(); rc.begin.assign(1, 0); rc.T.clear();
+          vector<shared_ptr<Frame>> &kfs = t.map_->GetKeyframes();
+          for (auto it = kfs.rbegin(); it != kfs.rend(); it++) {
+            rc.kfs.push_back(*it);
+            ImageAlign::PackFeatures(**it, &fresh[q]);
+            rc.begin.push_back(static_cast<int32_t>(fresh[q].size()));
+            double T7[7];
+            ((*it)->GetPose() * (*it)->GetPose().Inverse()).ToArray(T7);
+            rc.T.insert(rc.T.end(), T7, T7 + 7);
+          }
+          live += fresh[q].size();
+        }
+      if (reloc_store_) dev_->Check(sdvl_align_store_destroy(dev_->ctx(), reloc_store_), "sdvl_align_store_destroy");
+      reloc_store_ = nullptr;
+      reloc_epoch_ = g_reloc_epoch++;
+      reloc_used_ = 0;
+      const size_t cap = std::max<size_t>(2 * live, 65536);
+      if (cap > 0x7fffffffu) throw std::runtime_error("SDVLBatch: relocalisation store too large");
+      dev_->Check(sdvl_align_store_create(dev_->ctx(), static_cast<int>(cap), &reloc_store_), "sdvl_align_store_create");
+      reloc_cap_ = static_cast<int>(cap);
+    }
+    if (need > 0) {
+      vector<sdvl_align_feature> all;
+      const int base = reloc_used_;
+      for (int q = 0; q < L; q++) {
+        if (!stale[q]) continue;
+        SDVL &t = *trk_[lost[q]];
+        SDVL::RelocCache &rc = t.reloc_;
+        const int32_t off = base + static_cast<int32_t>(all.size());
+        for (int32_t &b : rc.begin) b += off;
+        all.insert(all.end(), fresh[q].begin(), fresh[q].end());
+        rc.owner = this;
+        rc.epoch = reloc_epoch_;
+        rc.version = t.map_->Version();
+      }
+      dev_->Check(sdvl_align_store_write(dev_->ctx(), reloc_store_, base, static_cast<int>(all.size()), all.data()), "sdvl_align_store_write");
+      reloc_used_ = base + static_cast<int>(all.size());
     }
   }
-  first[L] = static_cast<int>(pairs.size());
-  vector<int> n_meas;
-  vector<double> errors;
-  {  // launches of bounded size: a farm whose trackers are all lost asks for B x |keyframes| alignments
-    const size_t n = pairs.size();
-    n_meas.assign(n, 0);
-    errors.assign(n, 1e10);
-    aligned.resize(n);
-    const size_t kChunk = 2048;
-    for (size_t b = 0; b < n; b += kChunk) {
-      const size_t e = std::min(n, b + kChunk);
-      vector<std::pair<shared_ptr<Frame>, shared_ptr<Frame>>> part(pairs.begin() + b, pairs.begin() + e);
-      vector<SE3> part_start(start.begin() + b, start.begin() + e), part_aligned;
-      vector<int> part_meas;
-      vector<double> part_err;
-      ImageAlign::ComputePoseBatch(part, true, &part_meas, &part_err, nullptr, &part_start, &part_aligned);
-      for (size_t j = b; j < e; j++) {
-        n_meas[j] = part_meas[j - b];
-        errors[j] = part_err[j - b];
-        aligned[j] = part_aligned[j - b];
+  // ---- the alignments
+  vector<sdvl_align_job> jobs;
+  vector<int> first(L + 1, 0);
+  for (int q = 0; q < L; q++) {
+    SDVL &t = *trk_[lost[q]];
+    const SDVL::RelocCache &rc = t.reloc_;
+    first[q] = static_cast<int>(jobs.size());
+    for (size_t j = 0; j < rc.kfs.size(); j++) {
+      if (rc.begin[j + 1] == rc.begin[j]) {
+        std::cerr << "[ERROR] No points to track!" << std::endl;  // image_align.cc:55-58
+      }
+      sdvl_align_job jb;
+      jb.ref = rc.kfs[j]->device();
+      jb.cur = t.current_frame_->device();
+      jb.feat_begin = rc.begin[j];
+      jb.feat_end = rc.begin[j + 1];
+      std::memcpy(jb.T, rc.T.data() + 7 * j, sizeof(jb.T));
+      jobs.push_back(jb);
+    }
+  }
+  first[L] = static_cast<int>(jobs.size());
+  vector<sdvl_align_result> res;
+  if (!jobs.empty()) {
+    sdvl_align_params ap = AlignParams(true);
+    const int min_level = ap.min_level;
+    ap.min_level = ap.max_level;  // the coarsest level alone
+    RelocAlign(jobs, ap, &res);
+    if (min_level < ap.max_level) {
+      vector<int> pass;
+      for (size_t j = 0; j < jobs.size(); j++)
+        if (res[j].error <= 0.01) pass.push_back(static_cast<int>(j));  // image_align.cc:73-76 did not give up: the finer levels follow
+      if (!pass.empty()) {
+        vector<sdvl_align_job> again;
+        for (int j : pass) again.push_back(jobs[j]);
+        vector<sdvl_align_result> full;
+        ap.min_level = min_level;
+        RelocAlign(again, ap, &full);
+        for (size_t k = 0; k < pass.size(); k++) res[pass[k]] = full[k];
       }
     }
   }
+  // ---- the keyframe loop, sdvl.cc:209-235
   vector<int> cursor(first.begin(), first.end() - 1);
   vector<char> open_(L, 1);
   vector<vector<sdvl_search_req>> per(L);
   vector<sdvl_search_req> reqs;
-  vector<sdvl_search_res> res;
+  vector<sdvl_search_res> sres;
   vector<size_t> begin(L + 1, 0);
   for (;;) {
     bool any = false;
@@ -858,17 +969,23 @@ void SDVLBatch::RelocalizeLost(const vector<int> &lost, FrameStats *stats, vecto
       per[q].clear();
       if (!open_[q]) continue;
       SDVL &t = *trk_[lost[q]];
-      // sdvl.cc:209-222: every keyframe visited leaves its aligned pose on the frame; those with error >= 0.001 are passed over
+      const SDVL::RelocCache &rc = t.reloc_;
+      // every keyframe visited leaves its aligned pose on the frame (image_align.cc:79); those with error >= 0.001 are passed over
       while (cursor[q] < first[q + 1]) {
-        t.current_frame_->SetPose(aligned[cursor[q]]);
-        if (errors[cursor[q]] < 0.001) break;
+        const int j = cursor[q] - first[q];
+        if (rc.begin[j + 1] > rc.begin[j])  // (ComputePose returns before touching the pose when frame1 has no features)
+          t.current_frame_->SetPose(SE3::FromArray(res[cursor[q]].T) * rc.kfs[j]->GetPose());
+        else
+          t.current_frame_->SetPose(rc.kfs[j]->GetPose());
+        const double err = rc.begin[j + 1] > rc.begin[j] ? res[cursor[q]].error : 1e10;
+        if (err < 0.001) break;
         cursor[q]++;
       }
       if (cursor[q] >= first[q + 1]) {
         open_[q] = 0;
         continue;
       }
-      const shared_ptr<Frame> &cframe = pairs[cursor[q]].first;
+      const shared_ptr<Frame> &cframe = rc.kfs[cursor[q] - first[q]];
       t.feature_align_.PrepareReproject(t.current_frame_, cframe, true, &per[q]);
       any = true;
     }
@@ -878,15 +995,15 @@ void SDVLBatch::RelocalizeLost(const vector<int> &lost, FrameStats *stats, vecto
       reqs.insert(reqs.end(), per[q].begin(), per[q].end());
     }
     begin[L] = reqs.size();
-    Matcher::SearchPoints(dev_, reqs, *trk_[lost[0]]->camera_, &res);
+    Matcher::SearchPoints(dev_, reqs, *trk_[lost[0]]->camera_, &sres);
     for (int q = 0; q < L; q++) {
       if (!open_[q] || cursor[q] >= first[q + 1]) continue;
       SDVL &t = *trk_[lost[q]];
-      t.feature_align_.FinishReproject(t.current_frame_, res.data() + begin[q]);
+      t.feature_align_.FinishReproject(t.current_frame_, sres.data() + begin[q]);
       t.matches_ = t.feature_align_.GetMatches();
       t.attempts_ = t.feature_align_.GetAttempts();
       if (t.matches_ >= Config::MinMatches()) {
-        const shared_ptr<Frame> cframe = pairs[cursor[q]].first;
+        const shared_ptr<Frame> cframe = t.reloc_.kfs[cursor[q] - first[q]];
         t.map_->SetRelocalizing(false);  // sdvl.cc:84
         t.last_kf_ = cframe;
         t.last_frame_ = cframe;
