@@ -428,7 +428,8 @@ int sdvl_ctx_wait_block(sdvl_ctx *ctx);
 int sdvl_ctx_health(sdvl_ctx *ctx);
 /* Which path the work of this context took, counted on the host (a fast path must be SEEN to run: the tracked step scanned whole
  * corner lists for a round and a half without failing anything).  out4[0] = tracked jobs (sdvl_track_search) whose search reads the
- * corner bins, out4[1] = tracked jobs whose search scans the frame's whole corner list, out4[2..3] reserved (0). */
+ * corner bins, out4[1] = tracked jobs whose search scans the frame's whole corner list, out4[2] = undistortion maps built
+ * (sdvl_undistort / sdvl_frames_upload_undistorted build one per camera, not per call), out4[3] reserved (0). */
 int sdvl_ctx_counters(sdvl_ctx *ctx, int64_t *out4);
 
 /* ---- input stage: Camera::UndistortImage = cv::undistort(in, out, K, D) (camera.cc:39-67,100-105, main.cc:133) ----

@@ -238,6 +238,7 @@ extern "C" int sdvl_ctx_health(sdvl_ctx *ctx) {
 extern "C" int sdvl_ctx_counters(sdvl_ctx *ctx, int64_t *out4) {
   if (!ctx || !out4) return SDVL_ERR_INVALID;
   for (int i = 0; i < 4; i++) out4[i] = ctx->counters[i];
+  out4[2] = ctx->undist_maps_built;
   return SDVL_OK;
 }
 
@@ -392,6 +393,7 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   if (ctx->d_nits) (void)hipFree(ctx->d_nits);
   if (ctx->d_registry) (void)hipFree(ctx->d_registry);
   if (ctx->d_fast_table) (void)hipFree(ctx->d_fast_table);
+  if (ctx->d_undist_map) (void)hipFree(ctx->d_undist_map);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_search) (void)hipHostFree(ctx->h_search);
   if (ctx->d_search) (void)hipFree(ctx->d_search);

@@ -61,6 +61,12 @@ struct sdvl_ctx {
   void *d_fast_table = nullptr;
   long long fast_table_key = -1;
   int fast_table_cells = 0;
+  // Camera::UndistortImage's map (sdvl_undistort.hip): one 32-bit word per pixel for the last (size, intrinsics, distortion) seen
+  void *d_undist_map = nullptr;
+  size_t undist_map_bytes = 0;
+  double undist_key[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  void *undist_quads = nullptr;  // the per-quad records behind the per-pixel words, same allocation
+  long long undist_maps_built = 0;
   // input ring (sdvl_ctx_prefetch_images / _fence): a second stream that carries the NEXT step's images while this one computes
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};  // one per prefetch in flight (ticket & 3)
