@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t f) {  // four 3-bit fields 
 // one workgroup = a tile of 128 x 8 output pixels (a lane: one quad) of kRemapFrames consecutive frames; the loads of all frames of the
 // lane are in flight before the first result is needed.  kFull: all kRemapFrames frames exist (every workgroup but the last frame group's);
 // kWide: every destination row start is 4-byte aligned and a multiple of four pixels wide (the frames' own level 0 always is)
-constexpr int kRemapFrames = 8;
+constexpr int kRemapFrames = 4;
 template <bool kFull, bool kWide>
 __device__ __forceinline__ void remap_compact(const UndistJob *__restrict__ jobs, const QuadRec q, int nf, int ss, uint32_t drow, int npx) {
   // (the frame pointers are uniform and name global memory: address space 1 lets the loads take a scalar base + 32-bit lane offset
