@@ -52,6 +52,13 @@ WORKLOADS = {
 XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])
 TEXTURES = {"plane": 0, "camera": 1}   # csrc/sdvl_synth.h: SDVL_TEXTURE_PLANE_NOISE (rounds 1-4: a FAST corner on every second pixel) / SDVL_TEXTURE_CAMERA
 TEXTURE = 0
+# the lenses of the reference's configuration files (Camera.d1..d5): with --distortion every leg's frames are what a camera with that lens
+# records and Camera::UndistortImage (camera.cc:100-105, main.cc:133) runs on every frame, fused into the upload of the tracked step
+DISTORTIONS = {"none": None,
+               "tum_f1": [0.2624, -0.9531, -0.0054, 0.0026, 1.1633],       # config/config_tum_f1.cfg:15-19
+               "tum_f2": [0.2312, -0.7849, -0.0033, -0.0001, 0.9172],      # config/config_tum_f2.cfg:15-19
+               "euroc": [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]}   # config/config_euroc.cfg:15-19
+DISTORTION = None
 SEQ_SEED = None     # global sequence index -> texture seed (main() sets it from the workload)
 
 
@@ -86,6 +93,8 @@ def make_view(pkg, T, seed, frame_id):
         v.t[i] = float(T[4 + i])
     v.plane[0], v.plane[1], v.plane[2], v.plane[3] = 0.0, 0.0, 1.0, 2.0
     v.seed, v.frame_id, v.texture = seed, frame_id, TEXTURE
+    for i in range(5):
+        v.dist[i] = float(DISTORTION[i]) if DISTORTION is not None else 0.0
     return v
 
 
@@ -367,7 +376,7 @@ def cpu_baseline(frames, mapper=False, threads=1, ref_flags=False):
     return tracked / wall, tracked, wall
 
 
-def latency_legs(wl, texture, n_frames, mapper=False):
+def latency_legs(wl, texture, n_frames, mapper=False, dist=None):
     """The reference's own shape of use (main.cc:126-159): ONE camera through SDVL::HandleFrame, frame after frame — and 16 cameras,
     one host thread + one HIP stream each — measured by host/track_sequence, the C++ loop against the reference's API, as child
     processes BEFORE this process touches the GPU (they have the chip to themselves).  The window is main.cc:136-138: the
@@ -384,6 +393,8 @@ def latency_legs(wl, texture, n_frames, mapper=False):
         base += ["--set", k, repr(float(v))]
     if mapper:
         base.append("--mapper")
+    if dist is not None:   # frames rendered through the lens; track_sequence calls camera.UndistortImage before every HandleFrame (outside the window, main.cc:133)
+        base += ["--dist"] + [repr(float(d)) for d in dist]
     out = {}
     for name, n, extra in (("b1", 1, []), ("b1_lookahead", 1, ["--lookahead"]), ("b16", 16, []), ("b16_batched", 16, ["--batch"])):
         try:
@@ -588,6 +599,9 @@ def main():
     ap.add_argument("--texture", choices=sorted(TEXTURES), default="plane",
                     help="plane: value noise, a FAST corner on every second tested pixel (rounds 1-4); camera: piecewise-smooth shading + soft-edged "
                          "shapes, 2-5 k FAST keypoints per 640x480 frame (a few % of the pixels, like a camera frame)")
+    ap.add_argument("--distortion", choices=sorted(DISTORTIONS), default="none",
+                    help="the camera's lens (the cfg file's Camera.d1..d5): the synthetic frames are rendered THROUGH that lens and every leg undistorts "
+                         "them first, as main.cc:133 does (Camera::UndistortImage: a remap from a per-camera map cached on the device)")
     ap.add_argument("--latency-frames", type=int, default=-1,
                     help="frames of the LATENCY legs (one sequence alone and 16 sequences through the C++ SDVL::HandleFrame loop, host/track_sequence): "
                          "0 = skip; default 300 for S-A / S-B on one GPU")
@@ -617,7 +631,8 @@ def main():
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
                          "default 16 on one GPU, 8 per rank on several (10 GB of pinned host memory per rank, NUMA-local to its GPU)")
     args = ap.parse_args()
-    global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS, TEXTURE, SEQ_SEED
+    global W_IMG, H_IMG, TUM_CAM, FEATS_LABEL, ORACLE_PARAMS, TEXTURE, SEQ_SEED, DISTORTION
+    DISTORTION = DISTORTIONS[args.distortion]
     wl = WORKLOADS[args.workload]
     W_IMG, H_IMG, TUM_CAM, FEATS_LABEL = wl["w"], wl["h"], np.array(wl["cam"]), wl["label"]
     ORACLE_PARAMS = {k.split(".")[1]: v for k, v in wl["over"].items()}
@@ -658,7 +673,7 @@ def main():
         args.latency_frames = 300 if (world == 1 and args.workload in ("S-A", "S-B")) else 0
     latency = None
     if world == 1 and args.latency_frames > 2:
-        latency = latency_legs(wl, args.texture, args.latency_frames, args.mapper)   # child processes, before this one touches the GPU
+        latency = latency_legs(wl, args.texture, args.latency_frames, args.mapper, DISTORTION)   # child processes, before this one touches the GPU
     # (GPU_MAX_HW_QUEUES: the farm's 16 groups are 16 HIP streams and the runtime multiplexes a process's streams onto 4 hardware queues by
     #  default.  16 queues gave +5 % over three alternating pairs on one box (profiles/r05/ab_round5.txt) and nothing on the next
     #  (ab_queues_by_steps.txt: within the run-to-run spread at 10 / 20 / 40 / 80 steps), while every dispatch gets 2-10 x longer because
@@ -727,6 +742,8 @@ def main():
     trk.set_mapper(args.mapper)
     farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
     farm.set_fibers(fibers)
+    if DISTORTION is not None:
+        farm.set_distortion(DISTORTION)
     ctxs = [CtxView(pkg, farm.ctx_handle(g)) for g in range(G)]
     ctx = ctxs[0]
 
@@ -758,6 +775,10 @@ def main():
         ctx.render(views, cbuf)
         host = ctx.download(cbuf, n_cpu * frame_bytes).reshape(n_cpu, H_IMG, W_IMG)
         cpu_sample = [host[k].copy() for k in range(n_cpu)]
+        if DISTORTION is not None:   # main.cc:133: the reference undistorts before the window it times (the oracle's cv::undistort restatement)
+            import oraclelib as _ol
+            _orc = _ol.Oracle()
+            cpu_sample = [_orc.undistort(im, TUM_CAM, np.array(DISTORTION)) for im in cpu_sample]
         cpu_one = cpu_baseline(cpu_sample, args.mapper, 1)
         del host
         if os.environ.get("SDVL_BENCH_CPU_ORDER", "after") == "before":
@@ -954,6 +975,8 @@ def main():
         NFp = 1 + Wm + base_steps + M
         farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
         farm.set_fibers(fibers)
+        if DISTORTION is not None:
+            farm.set_distortion(DISTORTION)
         ctx3 = CtxView(pkg, farm.ctx_handle(0))
         pool = ctx3.malloc(D * NFp * frame_bytes)
         for k in range(NFp):
@@ -1034,6 +1057,8 @@ def main():
                 trk.configure(dict(trk.TUM_OVERRIDES, **dict(wl["over"], **{"SDVL.max_keyframes": max_kf})))
             farm = trk.TrackerFarm(local_rank, G, Bg, W_IMG, H_IMG, TUM_CAM, host_threads_per_group=threads)
             farm.set_fibers(fibers)
+            if DISTORTION is not None:
+                farm.set_distortion(DISTORTION)
             ctx2 = CtxView(pkg, farm.ctx_handle(0))
             spool = torch.empty(D * NF * frame_bytes, dtype=torch.uint8, pin_memory=True)
             tmp = ctx2.malloc(D * frame_bytes)
@@ -1235,6 +1260,8 @@ def main():
             "config": {"workload": "%s: synthetic %s %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step%s" % (args.workload, {"S-A": "TUM fr1-like", "S-B": "EuRoC MH_01-like (config_euroc.cfg)", "S-C": "roofline case"}[args.workload], W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",
+                       "distortion": ("%s: %s; frames rendered through the lens, Camera::UndistortImage inside every step (cached map, fused into the upload)" %
+                                      (args.distortion, DISTORTION)) if DISTORTION is not None else "none (pinhole frames: config/*.cfg's d1 = 0 case, camera.cc:46)",
                        "texture": args.texture + (": piecewise-smooth shading + soft-edged shapes at three scales (csrc/sdvl_synth.h SDVL_TEXTURE_CAMERA)" if TEXTURE else
                                                   ": five octaves of value noise, a FAST corner on every second tested pixel (rounds 1-4)"),
                        "look_ahead": not os.environ.get("SDVL_NO_LOOKAHEAD"), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),

@@ -113,7 +113,8 @@ class DepthOut(C.Structure):
 class SynthView(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
                 ("R", C.c_double * 9), ("t", C.c_double * 3), ("plane", C.c_double * 4),
-                ("seed", C.c_uint32), ("frame_id", C.c_uint32), ("texture", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("seed", C.c_uint32), ("frame_id", C.c_uint32), ("texture", C.c_uint32), ("reserved_", C.c_uint32),
+                ("dist", C.c_double * 5)]
 
 
 # every symbol include/sdvl_hip.h declares

@@ -27,6 +27,10 @@ struct sdvl_synth_view {
   uint32_t frame_id; // sensor-noise seed
   uint32_t texture;  // SDVL_TEXTURE_PLANE_NOISE (rounds 1-4) or SDVL_TEXTURE_CAMERA
   uint32_t reserved_;
+  // Round 6: the lens.  dist = (k1, k2, p1, p2, k3) of the radial-tangential model (Camera.d1..d5 of the reference's cfg files); with
+  // dist[0] != 0 the view is what a camera with that lens records — the image Camera::UndistortImage (camera.cc:100-105) turns back into
+  // the pinhole view.  dist[0] == 0 (as the reference tests it, camera.cc:46): pinhole, the bytes of rounds 1-5.
+  double dist[5];
 };
 #define SDVL_TEXTURE_PLANE_NOISE 0u
 #define SDVL_TEXTURE_CAMERA 1u
@@ -117,7 +121,20 @@ SDVL_HD inline double sdvl_camera_texture(double X, double Y, double pix, uint32
 
 SDVL_HD inline uint8_t sdvl_synth_pixel(const sdvl_synth_view *s, int u, int v) {
   // ray in camera coords, rotate to world: R^T * r ; camera centre C = -R^T t
-  const double rx = (u - s->u0) / s->fx, ry = (v - s->v0) / s->fy, rz = 1.0;
+  double rx = (u - s->u0) / s->fx, ry = (v - s->v0) / s->fy;
+  const double rz = 1.0;
+  if (s->dist[0] != 0.0) {
+    // (rx, ry) is where the LENS put the ray: invert x_d = x kr + 2 p1 x y + p2 (r2 + 2 x2), y_d = y kr + p1 (r2 + 2 y2) + 2 p2 x y by the
+    // usual fixed-point iteration (eight rounds; + - * / only)
+    const double xd = rx, yd = ry;
+    for (int it = 0; it < 8; it++) {
+      const double x2 = rx * rx, y2 = ry * ry, r2 = x2 + y2, xy2 = 2.0 * rx * ry;
+      const double kr = 1.0 + ((s->dist[4] * r2 + s->dist[1]) * r2 + s->dist[0]) * r2;
+      const double dx = s->dist[2] * xy2 + s->dist[3] * (r2 + 2.0 * x2), dy = s->dist[2] * (r2 + 2.0 * y2) + s->dist[3] * xy2;
+      rx = (xd - dx) / kr;
+      ry = (yd - dy) / kr;
+    }
+  }
   const double wx = s->R[0] * rx + s->R[3] * ry + s->R[6] * rz;
   const double wy = s->R[1] * rx + s->R[4] * ry + s->R[7] * rz;
   const double wz = s->R[2] * rx + s->R[5] * ry + s->R[8] * rz;

@@ -38,6 +38,7 @@ struct Batch {
   std::vector<std::unique_ptr<PlaneMap>> maps;
   std::vector<std::unique_ptr<SDVL>> trackers;
   std::unique_ptr<SDVLBatch> batch;
+  bool raw_input = false;  // sdvlh_batch_set_distortion: the images of a step are RAW camera frames (Image::raw)
   int w, h;
   std::string err;
 };
@@ -108,6 +109,17 @@ void *sdvlh_batch_create(void *device, int B, int w, int h, const double *cam4, 
   }
 }
 
+// The camera of the batch gets a lens (Camera::SetDistortions, camera.cc:39-67; dist5 = Camera.d1..d5 of the cfg files) and the images of
+// every later step are taken as RAW camera frames: Camera::UndistortImage (main.cc:133) runs inside the step, fused into the frames'
+// upload.  dist5[0] == 0 (the reference's test, camera.cc:46) turns it off again.
+int sdvlh_batch_set_distortion(void *bp, const double *dist5) {
+  Batch *b = static_cast<Batch *>(bp);
+  if (!b || !dist5) return -1;
+  b->cam->SetDistortions(dist5[0], dist5[1], dist5[2], dist5[3], dist5[4]);
+  b->raw_input = b->cam->HasDistortion();
+  return 0;
+}
+
 // map mode of the batches created AFTER the call: 0 = plane map stub (every keyframe seeded from the scene plane),
 // 1 = the reference's mapper in sequential mode (map.cc; the first keyframe is still bootstrapped from the plane)
 void sdvlh_set_mapper(int on) { g_use_mapper = on != 0; }
@@ -130,9 +142,11 @@ void sdvlh_batch_destroy(void *bp) {
   delete b;
 }
 
-static int step(Batch *b, const std::vector<Image> &imgs, sdvlh_frame_stats *out) {
+static int step(Batch *b, std::vector<Image> &imgs, sdvlh_frame_stats *out) {
   try {
     std::vector<FrameStats> st(imgs.size());
+    if (b->raw_input)
+      for (Image &im : imgs) im.raw = true;
     b->batch->HandleFrames(imgs, st.data());
     for (size_t i = 0; i < imgs.size(); i++) {
       const FrameStats &s = st[i];
@@ -239,6 +253,8 @@ int sdvlh_batch_set_next_device(void *bp, const void *const *dev_imgs, int strid
     std::vector<Image> v;
     if (dev_imgs)
       for (size_t i = 0; i < b->trackers.size(); i++) v.push_back(Image::WrapDevice(dev_imgs[i], b->w, b->h, stride, true));
+    if (b->raw_input)
+      for (Image &im : v) im.raw = true;
     b->batch->SetNextImages(v);
     return 0;
   } catch (const std::exception &e) {

@@ -428,8 +428,30 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
     up_f.clear();
     up_i.clear();
   };
+  // RAW camera images (Image::raw) of a camera with a lens: level 0 = Camera::UndistortImage(image), one remap launch per source kind
+  vector<sdvl_frame *> un_f[2];
+  vector<const void *> un_i[2];
+  int un_step[2] = {0, 0};
+  auto flush_raw = [&](int kind) {
+    if (un_f[kind].empty()) return;
+    const Camera *cam = frames[0]->GetCamera();
+    const sdvl_camera c = cam->abi();
+    const sdvl_distortion d = cam->distortion();
+    dev->Check(sdvl_frames_upload_undistorted(dev->ctx(), static_cast<int>(un_f[kind].size()), un_f[kind].data(), un_i[kind].data(), un_step[kind], kind, &c, &d),
+               "sdvl_frames_upload_undistorted");
+    un_f[kind].clear();
+    un_i[kind].clear();
+  };
   for (int i = 0; i < n; i++) {
     frames[i]->SetImageTransient(false);
+    if (imgs[i].raw && frames[i]->GetCamera()->HasDistortion()) {
+      const int kind = imgs[i].dev_src ? 1 : 0;
+      if (!un_f[kind].empty() && (imgs[i].step != un_step[kind] || frames[i]->GetCamera() != frames[0]->GetCamera())) flush_raw(kind);
+      un_step[kind] = imgs[i].step;
+      un_f[kind].push_back(devs[i]);
+      un_i[kind].push_back(imgs[i].dev_src ? imgs[i].dev_src : static_cast<const void *>(imgs[i].data));
+      continue;
+    }
     if (imgs[i].dev_src && imgs[i].step == imgs[i].cols && imgs[i].borrow) {
       dev->Check(sdvl_frame_borrow_image_device(dev->ctx(), devs[i], imgs[i].dev_src), "sdvl_frame_borrow_image_device");
       frames[i]->SetImageTransient(imgs[i].transient);
@@ -442,6 +464,8 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
     }
   }
   flush();
+  flush_raw(0);
+  flush_raw(1);
   dev->Check(sdvl_pyramid_build(dev->ctx(), n, devs.data()), "sdvl_pyramid_build");
   if (!corners) return;
   // FastDetector::DetectPyramid on the device (FAST + quota + retainBest in libstdc++ order); nothing returns to the host

@@ -140,6 +140,7 @@ int main(int argc, char **argv) {
     v.seed = seed;
     v.frame_id = static_cast<uint32_t>(k);
     v.texture = texture;
+    for (int q = 0; q < 5; q++) v.dist[q] = dist[q];  // --dist: the frames are what a camera with that lens records (camera.UndistortImage undoes it)
     return v;
   };
 

@@ -116,6 +116,9 @@ struct Image {
   // borrow + transient: the HBM image stays valid for the step that tracks it only (a slot of an input ring): the Frame aliases it
   // and takes a copy if it becomes a keyframe (Frame::OwnImages) — one frame in five in S-A, the other four never copy
   bool transient = false;
+  // (an addition) a RAW camera image: the Frame built from it takes Camera::UndistortImage(image) (camera.cc:100-105, main.cc:133) as its
+  // level 0 — the undistortion fused into the frame's upload, for callers that hand whole batches of camera frames to SDVLBatch
+  bool raw = false;
   static Image WrapDevice(const void *dev_ptr, int w, int h, int stride, bool borrow_storage = false, bool transient_storage = false) {
     Image r;
     r.dev_src = dev_ptr; r.cols = w; r.rows = h; r.step = stride; r.borrow = borrow_storage; r.transient = borrow_storage && transient_storage;

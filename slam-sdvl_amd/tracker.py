@@ -156,6 +156,14 @@ class TrackerBatch:
         if self.lib.sdvlh_batch_set_next_device(self.h, ptrs, self.w) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
 
+    def set_distortion(self, dist5):
+        """the batch's camera gets a lens (Camera.d1..d5 of the reference's cfg files) and the images of every later step are RAW camera
+        frames: Camera::UndistortImage (main.cc:133) runs inside the step, fused into the frames' upload"""
+        d = np.ascontiguousarray(dist5, np.float64)
+        self.lib.sdvlh_batch_set_distortion.argtypes = [C.c_void_p, C.c_void_p]
+        if self.lib.sdvlh_batch_set_distortion(self.h, d.ctypes.data) != 0:
+            raise RuntimeError("sdvlh_batch_set_distortion")
+
     def step_device_transient(self, dev_ptrs):
         """frames in HBM that stay valid for THIS step only (a slot of an input ring): aliased while tracked, frames that become
         keyframes take a copy at the end of the step"""
@@ -223,6 +231,14 @@ class TrackerFarm:
         """pool HBM frames up front (keyframes keep theirs): no hipMalloc on the tracking path for that many frames"""
         if self.lib.sdvlh_farm_reserve(self.h, int(frames_per_group)) != 0:
             raise RuntimeError(self.lib.sdvlh_last_error().decode())
+
+    def set_distortion(self, dist5):
+        """every group's camera gets the lens; the frames of run() are RAW camera frames from then on (TrackerBatch.set_distortion)"""
+        d = np.ascontiguousarray(dist5, np.float64)
+        self.lib.sdvlh_batch_set_distortion.argtypes = [C.c_void_p, C.c_void_p]
+        for g in range(self.G):
+            if self.lib.sdvlh_batch_set_distortion(self.lib.sdvlh_farm_batch(self.h, g), d.ctypes.data) != 0:
+                raise RuntimeError("sdvlh_batch_set_distortion")
 
     def set_fibers(self, n):
         """n > 1: every worker thread interleaves n group-steps, switching at GPU waits (use G = n * workers groups)"""

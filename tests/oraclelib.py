@@ -35,7 +35,8 @@ class FrameStats(C.Structure):
 class SynthView(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
                 ("R", C.c_double * 9), ("t", C.c_double * 3), ("plane", C.c_double * 4),
-                ("seed", C.c_uint32), ("frame_id", C.c_uint32), ("texture", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("seed", C.c_uint32), ("frame_id", C.c_uint32), ("texture", C.c_uint32), ("reserved_", C.c_uint32),
+                ("dist", C.c_double * 5)]
 
 
 def _ensure(path, cmd, cwd):
@@ -305,8 +306,11 @@ class Synth:
     def __init__(self):
         self.lib = load_synth()
 
-    def render(self, T_cw, cam, w, h, seed=20260001, frame_id=0, plane=(0, 0, 1, 2.0), texture=0):
+    def render(self, T_cw, cam, w, h, seed=20260001, frame_id=0, plane=(0, 0, 1, 2.0), texture=0, dist=None):
+        """dist = (k1, k2, p1, p2, k3): the view through that lens (what Camera::UndistortImage undoes); None: pinhole"""
         v = SynthView()
+        for i in range(5):
+            v.dist[i] = float(dist[i]) if dist is not None else 0.0
         v.fx, v.fy, v.u0, v.v0 = [float(c) for c in cam]
         R = quat_to_R(T_cw[:4])
         for i in range(9):

@@ -156,6 +156,41 @@ def test_mixed_batch_lost_trackers_relocalize_inside_the_tabled_step(trk, orc, s
     dev.close()
 
 
+def test_raw_camera_frames_through_the_lens_undistorted_inside_the_step(trk, orc, synth):
+    """frames rendered THROUGH config_tum_f1.cfg's lens are handed to the batch as they come from the camera
+    (TrackerBatch.set_distortion: Image::raw); Camera::UndistortImage (camera.cc:100-105, main.cc:133) runs inside the step, fused into the
+    frames' upload, from a map that is built ONCE.  The oracle is fed its own cv::undistort of the same bytes: identical decisions."""
+    from oraclelib import TUM_DIST
+    trk.configure()
+    B, n_frames = 3, 9
+    dev = trk.HostDevice(0)
+    xis = [XI * (1.0 + 0.15 * i) * (1 if i % 2 == 0 else -1) for i in range(B)]
+    seeds = [20260001 + i for i in range(B)]
+    batch = trk.TrackerBatch(dev, B, 640, 480, TUM_CAM)
+    batch.set_distortion(TUM_DIST)
+    oracles = [orc.tracker(640, 480, TUM_CAM) for _ in range(B)]
+    pkg = importlib.import_module("slam-sdvl_amd")
+    lib = pkg.load_library()
+    for k in range(n_frames):
+        raw = [synth.render(trajectory_pose(orc, k, xis[i]), TUM_CAM, 640, 480, seed=seeds[i], frame_id=k, dist=TUM_DIST) for i in range(B)]
+        got = batch.step_host(raw)
+        for i in range(B):
+            w, g = oracles[i].handle_frame(orc.undistort(raw[i], TUM_CAM, TUM_DIST)), got[i]
+            assert (g.state, g.quality, g.keyframe, g.n_corners, g.matches, g.attempts, g.inliers, g.outliers, g.align_meas, g.host_path) == \
+                   (w.state, w.quality, w.keyframe, w.n_corners, w.matches, w.attempts, w.inliers, w.outliers, w.align_meas, 0), (k, i)
+            assert np.abs(np.array(g.pose[:]) - np.array(w.pose[:])).max() <= POSE_TOL, (k, i)
+            if k > 0:
+                assert g.quality == 0 and g.matches >= 100       # the undistorted view is the pinhole view again: tracked as usual
+    counters = (C.c_int64 * 4)()
+    lib.sdvl_ctx_counters.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.sdvl_ctx_counters(dev.ctx_handle(), counters) == 0
+    assert counters[2] == 1, counters[2]                          # one map for the camera, not one per call
+    batch.close()
+    for o in oracles:
+        o.close()
+    dev.close()
+
+
 def run_mapper_case(trk, orc, synth, B, n_frames, threads):
     """closed loop with the reference's mapper (map.cc, sequential mode) on both sides: the tracker's per-frame decisions,
     the poses AND the map bookkeeping (candidates alive / converged / initialised / linked, connections, keyframes after
