@@ -46,7 +46,8 @@ WORKLOADS = {
     # (sequence g: chunk g mod 4); with `--gpus 4` every rank tracks ONE chunk (shard.chunk_for_sequence)
     "S-B": dict(w=752, h=480, cam=[458.654, 457.296, 367.215, 248.375], seqs=[4096, 3072, 2048], over={"SDVL.min_matches": 5}, label="~200 feats",
                 cpu_frames=300, chunks=4, seed0=20260010),
-    "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=[64], label="~1000 feats", cpu_frames=60,
+    # (seeds 20260100 + rank*64 + i, SURVEY §8d: with 64 sequences per GPU that is 20260100 + the global sequence index)
+    "S-C": dict(w=1280, h=960, cam=[1034.6, 1033.0, 637.2, 510.6], seqs=[64], label="~1000 feats", cpu_frames=60, seed0=20260100,
                 over={"SDVL.num_features": 4000, "SDVL.max_matches": 1000}),
 }
 XI = np.array([0.004, 0.002, 0.001, 0.0008, -0.0012, 0.0005])
@@ -270,7 +271,7 @@ def _frames_per_dispatch(row):
 
 def pmc_traffic_bytes(kernel, frames_per_launch):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN/pmc_hbm_traffic.csv, newest round), scaled to
-    this run's frames per launch.  The counters need their own rocprofv3 passes (tools/profile_round.sh), so they cannot be
+    this run's frames per launch.  The counters need their own rocprofv3 passes (tools/profile_bench.sh), so they cannot be
     sampled inside the timed region.  FETCH_SIZE on gfx950 tallies a 128-B request as 64 B (MI355X_MICROARCH.md, HBM): the guide
     calibrates the x2 for 16-B-per-lane streams; summarize_profiles.py marks per row whether the kernel's loads are of that kind
     (column fetch_x2) and the figure here applies it.  Returns (bytes or None, where the figure came from)."""
@@ -383,6 +384,12 @@ def latency_legs(wl, texture, n_frames, mapper=False, dist=None):
     HandleFrame call alone; the image is on the device by then (Camera::UndistortImage, main.cc:133, is outside, as in the
     reference).  Returns the `latency` block or None."""
     import subprocess
+    # Under a profiler the preloaded tool library has initialised the GPU in THIS process already: starting children from it is the
+    # forbidden exec-after-GPU-init, and their lone-camera kernels would land in the farm's per-kernel averages (ADVICE r05)
+    preload = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB"))
+    if "rocprof" in preload.lower():
+        sys.stderr.write("bench.py: a rocprofiler library is preloaded; the latency legs (child processes) are skipped\n")
+        return None
     exe = os.path.join(ROOT, "slam-sdvl_amd", "host", "track_sequence")
     if not os.path.exists(exe):
         sys.stderr.write("bench.py: %s is not built; latency legs skipped\n" % exe)
@@ -540,6 +547,23 @@ def launch_ranks(n, dry=False):
     return rc
 
 
+def seq_seed_fn(shard, wl, per_gpu, world):
+    """global sequence index -> texture seed.  S-B: the seed names the chunk (20260010..13; shard.chunk_for_sequence: rank r tracks the
+    chunks {c : c mod G = r}, chunk r mod 4 with more ranks than chunks), a rank's sequences differ by their twists; S-C: 20260100 + the
+    global index (= 20260100 + rank*64 + i at SURVEY's 64 sequences per GPU); S-A: 20260001 + the global index."""
+    if "chunks" in wl:
+        return lambda g: wl["seed0"] + shard.chunk_for_sequence(g, per_gpu, world, wl["chunks"])
+    if "seed0" in wl:
+        return lambda g: wl["seed0"] + g
+    return shard.sequence_seed
+
+
+def host_budget_per_rank(world):
+    """host memory ONE rank may plan with (pinned pools, keyframe objects): what the node has free, divided by the ranks that share it"""
+    free = host_memory_available()
+    return None if free is None else free / max(1, world)
+
+
 def dry_rank(args, rank, world):
     """SDVL_BENCH_DRY=1: the N > 1 plumbing of this file without a GPU - sharding, gloo rendezvous, barrier, the one
     reduction (shard.reduce_throughput) and rank 0's JSON line - so that the launcher is testable on CPU."""
@@ -550,7 +574,14 @@ def dry_rank(args, rank, world):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     B, K = args.seqs, args.steps
     my = shard.sequences_for_rank(rank, world, B)
+    # what this rank would render: the texture seeds of its sequences (workload-dependent) and the host memory it may plan with
+    seed_of = seq_seed_fn(shard, WORKLOADS[args.workload], B, world)
+    mine = {"rank": rank, "first_sequence": my[0], "seeds": sorted(set(seed_of(g) for g in my)), "seed_of_first": seed_of(my[0]), "seed_of_last": seed_of(my[-1]),
+            "host_budget_bytes": host_budget_per_rank(world)}
+    per_rank = [mine]
     if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.02 * (1 + rank))                      # ranks finish at different times: the job's time is the slowest rank's
@@ -583,7 +614,8 @@ def dry_rank(args, rank, world):
         print(json.dumps({"metric": "tracked frames/sec (dry run, no GPU)", "value": round(tracked_all / elapsed_max, 2), "unit": "frames/s",
                           "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed_max / K * 1e3, 3), "dry": True,
                           "tracked": tracked_all, "cpu_share": int(os.environ.get("SDVL_BENCH_CPU_SHARE", "0")),
-                          "sequences": [my[0], my[-1]], "scaling": "weak",
+                          "sequences": [my[0], my[-1]], "scaling": "weak", "workload": args.workload, "per_rank": per_rank,
+                          "host_memory_available_bytes": host_memory_available(),
                           "value_host_fed": host_fed["value"] if host_fed else None, "host_fed": host_fed, "roofline": {"link": link}}))
     if world > 1:
         dist.destroy_process_group()
@@ -748,10 +780,7 @@ def main():
     ctx = ctxs[0]
 
     my_seqs = shard.sequences_for_rank(rank, world, B)   # independent sequences: no data-path collective
-    if "chunks" in wl:   # S-B: the texture seed names the chunk (20260010..13); a rank's sequences differ by their twists
-        SEQ_SEED = lambda g: wl["seed0"] + shard.chunk_for_sequence(g, B, world, wl["chunks"])
-    else:
-        SEQ_SEED = shard.sequence_seed
+    SEQ_SEED = seq_seed_fn(shard, wl, B, world)
     buf = ctx.malloc(B * n_frames * frame_bytes)
     for k in range(n_frames):                 # frame-major layout: step k reads B consecutive frames
         views = [make_view(pkg, se3_exp(shard.sequence_twist(g) * k), SEQ_SEED(g), k) for g in my_seqs]
@@ -885,9 +914,7 @@ def main():
     host_fed = None
     Kh = max(0, args.host_steps)
     if Kh > 0:
-        host_free = host_memory_available()
-        if host_free is not None:
-            host_free /= world                        # every rank of the node pins its own pool out of the same memory
+        host_free = host_budget_per_rank(world)        # every rank of the node pins its own pool out of the same memory
         while Kh > 4 and host_free is not None and B * Kh * frame_bytes + 12e9 > 0.85 * host_free:
             Kh //= 2                                  # fewer host-fed steps rather than an out-of-memory kill
         if distributed:                               # all ranks run the same number of steps (the smallest any of them can afford)
@@ -1113,6 +1140,8 @@ def main():
             sustained = {"value": round(tracked_s / elapsed_s, 2), "unit": "frames/s", "frames_per_sequence": NF, "timed_steps": Ks, "ms_per_step": round(elapsed_s / Ks * 1e3, 3),
                          "sequences_per_gpu": B, "tracked_fraction": round(tracked_s / (B * Ks), 5),
                          "max_keyframes": max_kf if max_kf > 0 else "the workload's (never reached)",
+                         "map": "BOUNDED-MAP variant: SDVL.max_keyframes = %s (the reference's cfg files say 1000, config.cc:63 defaults to 100) and the plane-map stub deletes a culled "
+                                "keyframe's points with it, which Map::LimitKeyframes / EmptyTrash do not; cpu_baseline runs the oracle at the cfg's 1000" % (max_kf if max_kf > 0 else "the workload's"),
                          "keyframes_made_per_sequence": round(1 + kf_s / B * (NF - 1) / Ks, 1), "hbm_bytes_per_keyframe": int(footprint), "corner_capacity": corner_cap,
                          "hbm_used_gb_at_frame_%d" % (1 + Wm + half): mem_mid[0], "hbm_used_gb_at_end": mem_end[0], "hbm_total_gb": round(total0 / 1e9, 1),
                          "host_rss_gb_at_frame_%d" % (1 + Wm + half): mem_mid[1], "host_rss_gb_at_end": mem_end[1],
@@ -1179,7 +1208,7 @@ def main():
             roofline = {"bound": "hbm", "kernel": name, "selection_rule": "argmax of kernel_ms_per_step (dispatch time, HIP events on the kernel's own stream)",
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_us": round(avg_s * 1e6, 2), "frames_per_launch": round(frames_per_launch, 1),
                         "achieved": None, "frac": None, "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": None}
-            # the counters need rocprofv3 passes of their own (tools/profile_round.sh): the line quotes the committed ones when they were taken
+            # the counters need rocprofv3 passes of their own (tools/profile_bench.sh): the line quotes the committed ones when they were taken
             # on this workload and texture, and says whether the kernels have changed since (traffic_stale)
             stale, stale_detail = profile_staleness()
             same_input = True     # _pmc_rows only finds passes of this workload and texture (profiles/rNN/<tag>/)

@@ -283,7 +283,13 @@ __device__ __forceinline__ int fast_corner_best(const uint8_t *tile, int pitch_b
 // as halves (kPitchHW words per row, pixel x at half 4 + x), the pair (x, x+1) with x odd reads its ring as 20 aligned words
 // — position (dx, dy) of both pixels is the word at half x + dx for odd dx, and two neighbouring words funnel-shifted by 16
 // bits for even dx — and every min3 / max3 serves two pixels: 32 + 32 + 16 packed operations instead of 2 x 88 scalar ones.
-constexpr int kPitchHW = 20;  // LDS row pitch of the half tile in 32-bit words: 4 + 32 + 4 halves
+#ifndef SDVL_FC_PITCH
+#define SDVL_FC_PITCH 20
+#endif
+#ifndef SDVL_FC_ALL64
+#define SDVL_FC_ALL64 0
+#endif
+constexpr int kPitchHW = SDVL_FC_PITCH;  // LDS row pitch of the half tile in 32-bit words: 4 + 32 + 4 halves (= 20) or more
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2 pk_min3(h2 a, h2 b, h2 c) {
@@ -346,10 +352,33 @@ __device__ __forceinline__ h2 fast_pair_best(const uint32_t *w, h2 t2) {
 __device__ __forceinline__ void fast_quad_best(const uint32_t *w, h2 t2, h2 *best_a, h2 *best_b) {
   const auto w2 = [w](int dy, int k) { return *reinterpret_cast<const uint2 *>(&w[(dy + 3) * kPitchHW + k]); };  // k even
   const auto w1 = [w](int dy, int k) { return w[(dy + 3) * kPitchHW + k]; };
+#if SDVL_FC_ALL64
+  // every read a 64-bit one (banks mod 64, both word parities; a lane's unused second word stays inside its row: word <= 19)
+  const uint32_t a1 = w2(3, 0).y, b1 = w2(-3, 0).y;
+  const uint2 a23 = w2(3, 2), b23 = w2(-3, 2);
+  const uint2 c01 = w2(2, 0), c23 = w2(2, 2), d01 = w2(-2, 0), d23 = w2(-2, 2), z01 = w2(0, 0), z23 = w2(0, 2), u01 = w2(1, 0), l01 = w2(-1, 0);
+  const uint32_t c4 = w2(2, 4).x, d4 = w2(-2, 4).x, z4 = w2(0, 4).x, u3 = w2(1, 2).y, u4 = w2(1, 4).x, l3 = w2(-1, 2).y, l4 = w2(-1, 4).x;
+  (void)w1;
+#else
   const uint32_t a1 = w1(3, 1), b1 = w1(-3, 1);
   const uint2 a23 = w2(3, 2), b23 = w2(-3, 2);
   const uint2 c01 = w2(2, 0), c23 = w2(2, 2), d01 = w2(-2, 0), d23 = w2(-2, 2), z01 = w2(0, 0), z23 = w2(0, 2), u01 = w2(1, 0), l01 = w2(-1, 0);
   const uint32_t c4 = w1(2, 4), d4 = w1(-2, 4), z4 = w1(0, 4), u3 = w1(1, 3), u4 = w1(1, 4), l3 = w1(-1, 3), l4 = w1(-1, 4);
+#endif
+#ifdef SDVL_FC_LDS_TWICE
+  // A/B (tools/fc_lds_ab.sh): the ring's 19 reads issued a second time (volatile: the compiler keeps them) — does the kernel's time
+  // follow its LDS traffic at all?
+  {
+    const volatile uint32_t *vw = w;
+    uint32_t sink = 0;
+    for (int dy = -3; dy <= 3; dy++) {
+      if (dy == 3 || dy == -3) { sink ^= vw[(dy + 3) * kPitchHW + 1]; sink ^= vw[(dy + 3) * kPitchHW + 2]; sink ^= vw[(dy + 3) * kPitchHW + 3]; }
+      else if (dy == 2 || dy == -2 || dy == 0) { for (int k = 0; k < 5; k++) sink ^= vw[(dy + 3) * kPitchHW + k]; }
+      else { sink ^= vw[(dy + 3) * kPitchHW + 0]; sink ^= vw[(dy + 3) * kPitchHW + 1]; sink ^= vw[(dy + 3) * kPitchHW + 3]; sink ^= vw[(dy + 3) * kPitchHW + 4]; }
+    }
+    asm volatile("" ::"v"(sink));
+  }
+#endif
   const PairRing qa = {a1, a23.x, b1, b23.x, c01.x, c01.y, c23.x, c23.y, d01.x, d01.y, d23.x, d23.y, z01.x, z01.y, z23.x, z23.y, u01.x, u3, l01.x, l3};
   const PairRing qb = {a23.x, a23.y, b23.x, b23.y, c01.y, c23.x, c23.y, c4, d01.y, d23.x, d23.y, d4, z01.y, z23.x, z23.y, z4, u01.y, u4, l01.y, l4};
   *best_a = fast_pair_best_ring(qa, t2);

@@ -1626,7 +1626,7 @@ int sdvl_image_align_enqueue(sdvl_ctx *ctx, int n_jobs, const sdvl_align_job *jo
 // out of the tracking tables inside the kernel.  max_nf = the largest feature count among the jobs.
 int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev *d_jobs, const TrackPoint *d_points, const TrackFeat *d_feats0,
                                    const TrackFeat *d_feats1, int np, int nfeat_cap, int max_nf, int levels, const sdvl_camera *cam,
-                                   const sdvl_align_params *p, sdvl_align_result *d_results) {
+                                   const sdvl_align_params *p, sdvl_align_result *d_results, int batch_size) {
   SDVL_REQUIRE(ctx, p->patch_size == 4, "only align_patch_size 4 is supported");
   SDVL_REQUIRE(ctx, p->min_level >= 0 && p->max_level >= p->min_level && p->max_level < SDVL_MAX_LEVELS, "bad align levels");
   SDVL_REQUIRE(ctx, p->max_level < levels, "max_align_level exceeds the pyramid depth");
@@ -1639,7 +1639,7 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
   // HandleFrame): one feature per lane instead of three rounds per lane shortens every Gauss-Newton evaluation of a chain that has the
   // chip to itself; a farm's launches of hundreds of jobs keep one wave per job (fewer instructions in total).  SDVL_IA_SMALL_WAVES=1|4
   static const int small_kw = getenv("SDVL_IA_SMALL_WAVES") ? atoi(getenv("SDVL_IA_SMALL_WAVES")) : 4;
-  const int kw = (max_nf > kLdsMaxF || (n_jobs <= 32 && small_kw == 4)) ? 4 : 1;
+  const int kw = (max_nf > kLdsMaxF || (batch_size <= 32 && small_kw == 4)) ? 4 : 1;
   const int max_f = max_nf <= 0 ? 64 * kw : (max_nf + 64 * kw - 1) / (64 * kw) * (64 * kw);
   // PrecomputePatches of all levels as a wide launch in front of the Gauss-Newton chains (SDVL_IA_PRE=0: inside the chain, A/B)
   // SDVL_IA_TRACK_FUSED=1 (round 5, measured): no precompute launch and the items of the level at hand in LDS — jobs of up to

@@ -162,7 +162,8 @@ struct PoseJobDev {
 size_t sdvl_pose_hyp_bytes();
 // max_obs: the most observations any of the jobs can hold (the device knows the actual counts; the supporter kernel's grid covers this many)
 int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
-                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists, int max_obs);
+                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists, int max_obs,
+                             int batch_size);  // batch_size: see sdvl_image_align_track_enqueue
 
 // sdvl_image_align.hip: queue the alignment of n_jobs pairs; features from the host (`features`) or resident (`d_features`);
 // results to `d_results` (device) or, when null, to the context's result buffers (see sdvl_image_align_begin)

@@ -499,7 +499,8 @@ __global__ __launch_bounds__(64 * kRefWaves) void pose_refine_kernel(const PoseJ
 size_t sdvl_pose_hyp_bytes() { return sizeof(HypResult); }
 
 int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs, const sdvl_pose_obs *d_obs, const int32_t *d_rand,
-                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists, int max_obs) {
+                             const int32_t *d_nits, const sdvl_pose_params *p, void *d_hyp, sdvl_pose_result *d_res, int32_t *d_lists, int max_obs,
+                             int batch_size) {
   if (max_obs < 1) max_obs = 1;
   if (max_obs > kMaxObs) max_obs = kMaxObs;
   SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), d_jobs, d_obs, d_rand, *p,
@@ -510,7 +511,7 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
   // other streams' kernels than they save: 2.4 -> 3.9 ms of dispatch time per step); configuration C's ~850: wave 0 + two helpers
   // Round 5: a small batch (a lone camera) takes the helper waves too — nobody else wants the CU (SDVL_POSE_SMALL_HELPERS=0: off)
   static const bool small_helpers = !(getenv("SDVL_POSE_SMALL_HELPERS") && atoi(getenv("SDVL_POSE_SMALL_HELPERS")) == 0);
-  if (max_obs > 256 || (n_jobs <= 32 && small_helpers))
+  if (max_obs > 256 || (batch_size <= 32 && small_helpers))
     SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel<3>, dim3(n_jobs), dim3(192), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
                 d_lists);
   else
@@ -575,7 +576,7 @@ extern "C" int sdvl_pose_from_matches(sdvl_ctx *ctx, int n_jobs, const sdvl_pose
   prm.pad_ = 0;  // rand_idx holds indices already reduced modulo the match count
   int max_obs = 0;
   for (int j = 0; j < n_jobs; j++) max_obs = std::max(max_obs, jobs[j].obs_end - jobs[j].obs_begin);
-  rc = sdvl_pose_enqueue_device(ctx, n_jobs, dj, dobs, drand, dnits, &prm, dhyp, dres, dlists, max_obs);
+  rc = sdvl_pose_enqueue_device(ctx, n_jobs, dj, dobs, drand, dnits, &prm, dhyp, dres, dlists, max_obs, n_jobs);
   if (rc) return rc;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, res_bytes + list_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));

@@ -1289,7 +1289,7 @@ int sdvl_search_run_chain(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
   sdvl_pose_params prm = *pp;
   prm.pad_ = 1;  // raw rand() values: the kernel reduces them modulo the match count it finds in the job
   rc = sdvl_pose_enqueue_device(ctx, n_frames, d_jobs, d_obs, reinterpret_cast<const int32_t *>(d8 + fb + 2 * cb + pb),
-                                static_cast<const int32_t *>(ctx->d_nits), &prm, d_hyp, d_res, d_lists, max_size);
+                                static_cast<const int32_t *>(ctx->d_nits), &prm, d_hyp, d_res, d_lists, max_size, n_frames);
   if (rc) return rc;
   SDVL_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->h_out) + h_off, dx + jb + ob + hb, rb + nb + lb, hipMemcpyDeviceToHost, ctx->stream));
   ctx->chain_pending = n_frames;

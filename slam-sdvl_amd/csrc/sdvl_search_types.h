@@ -134,7 +134,9 @@ int sdvl_select_matches_launch(sdvl_ctx *ctx, int n_frames, const ChainFrameDev 
 // sdvl_image_align.hip: the image alignment of a tracked step, features straight from the tracking tables (no records, no wait)
 int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev *d_jobs, const TrackPoint *d_points, const TrackFeat *d_feats0,
                                    const TrackFeat *d_feats1, int np, int nfeat_cap, int max_nf, int levels, const sdvl_camera *cam,
-                                   const sdvl_align_params *p, sdvl_align_result *d_results);
+                                   const sdvl_align_params *p, sdvl_align_result *d_results, int batch_size);
+// batch_size: the capacity of the set the jobs come from (NOT the jobs of this step): it picks the one-wave or four-wave form for the
+// set's life, so that a sequence's sums do not change order when a neighbour bootstraps or is lost
 // the iteration-budget table of SelectInliers for all match counts up to max_size, resident in HBM (ctx->d_nits)
 extern "C" int sdvl_ensure_nits_table(sdvl_ctx *ctx, int npoints_cfg, int max_its, int max_size);
 

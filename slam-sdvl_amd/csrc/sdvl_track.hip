@@ -775,7 +775,7 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
   } else {
     rc = sdvl_image_align_track_enqueue(ctx, n_jobs, static_cast<const TrackJobDev *>(s->d_jobs), static_cast<const TrackPoint *>(s->d_points),
                                         static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, max_nf,
-                                        jobs[0].cur->v.levels, cam, &p->align, s->d_ares);
+                                        jobs[0].cur->v.levels, cam, &p->align, s->d_ares, s->n);
   }
   if (rc) return rc;
   s->phase = 1;
@@ -879,7 +879,7 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
   sdvl_pose_params pp = s->prm.pose;
   pp.pad_ = 1;  // raw rand() values: the kernel reduces them modulo the match count it finds in the job
   rc = sdvl_pose_enqueue_device(ctx, n_jobs, s->d_pjobs, s->d_obs, s->d_rand, static_cast<const int32_t *>(ctx->d_nits), &pp, s->d_hyp, s->d_pres,
-                                s->d_lists, s->mm);
+                                s->d_lists, s->mm, s->n);
   if (rc) { (void)end_capture(); return rc; }
   {
     // s_before | s_found | (8-byte aligned) depths of the new frame's points, at most mm of them

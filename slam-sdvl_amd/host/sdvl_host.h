@@ -196,6 +196,7 @@ class SDVL {
     bool valid = false;
     int feat_buf = 0;
     int slot = 0;                                     // the tracker's index in its batch = which table of the set is its own
+    const void *owner = nullptr;                      // the SDVLBatch whose set holds that table (a tracker may be stepped by a farm batch AND through HandleFrame)
     std::shared_ptr<Frame::PointTable> points;        // table index -> Point
     std::vector<sdvl_track_point_stat> stats;         // newest counters of `points`; the Point objects lag behind
     bool stats_dirty = false;

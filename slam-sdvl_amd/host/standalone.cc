@@ -423,7 +423,6 @@ bool SDVL::HandleFrame(const Image &img) {
     self_batch_.reset(new SDVLBatch(dev, {this}, 1));
     track_.valid = false;
   }
-  track_.slot = 0;  // (a farm batch that also steps this tracker would have renumbered it)
   if (!next_image_.empty()) {
     self_batch_->SetNextImages(next_image_);
     next_image_.clear();
@@ -1055,6 +1054,18 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     if (t.feature_align_.MaxMatches() > FeatureAlign::kMaxDevicePoseObs || t.feature_align_.MaxMatches() < 1) return false;
     if (t.camera_ != trk_[0]->camera_) return false;
   }
+  // The rows of a tracker's table live in the set of ONE batch: a tracker that was last stepped by another batch (a farm batch and its own
+  // SDVL::HandleFrame batch, say) brings its counters up to date and gets its table rebuilt here, under this batch's slot
+  for (int i = 0; i < B; i++) {
+    SDVL::TrackState &ts = trk_[i]->track_;
+    if (ts.owner != this) {
+      SyncStats(*trk_[i]);
+      ts.valid = false;
+      ts.append_pending = false;
+      ts.owner = this;
+    }
+    ts.slot = i;
+  }
   Camera &camera = *trk_[0]->camera_;
   const int cells = trk_[0]->feature_align_.GridCells();
   if (cells > 65535) return false;
@@ -1193,10 +1204,11 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     const sdvl_camera cam = camera.abi();
     // Round 5: a SMALL batch (a lone camera's HandleFrame above all) is a chain of launches that each fill a sliver of the chip: its
     // detection (FAST, selection: needs the pyramid only) runs on the context's side stream BESIDE the alignment instead of behind it
-    // (sdvl_ctx_fork_*); a farm's large batches keep one stream per group — there the other groups are the company.
+    // (sdvl_ctx_fork_*); a farm's batches keep one stream per group — there the other groups are the company, and a whole-context wait
+    // inside a fork would block the worker's other groups (B <= 4: the batches that also spin on their waits).
     // SDVL_DETECT_FORK=0 / 1 forces it off / on.
     static const int fork_env = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
-    const bool fork_detect = !detected_ahead && !detected_now && (fork_env >= 0 ? fork_env != 0 : B <= 32);
+    const bool fork_detect = !detected_ahead && !detected_now && (fork_env >= 0 ? fork_env != 0 : B <= 4);
     if (fork_detect) dev_->Check(sdvl_ctx_fork_mark(dev_->ctx()), "sdvl_ctx_fork_mark");  // the pyramids are queued: the side chain starts here
     dev_->Check(sdvl_track_align(dev_->ctx(), track_, R, tr_jobs_.data(), tr_rank_.data(), tr_rand_.data(), &cam, &prm), "sdvl_track_align");
     if (fork_detect) {
@@ -1347,7 +1359,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
   if (R == 0 && !detected_ahead && !detected_now) {  // bootstrap-only step: the new keyframes still need their corners
     // (a small batch detects on the side stream here too: the stream and its queue exist by the time a tracked frame forks)
     static const int fork_env0 = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
-    const bool fork0 = fork_env0 >= 0 ? fork_env0 != 0 : B <= 32;
+    const bool fork0 = fork_env0 >= 0 ? fork_env0 != 0 : B <= 4;
     if (fork0) {
       dev_->Check(sdvl_ctx_fork_mark(dev_->ctx()), "sdvl_ctx_fork_mark");
       dev_->Check(sdvl_ctx_fork_begin(dev_->ctx()), "sdvl_ctx_fork_begin");

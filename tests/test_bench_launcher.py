@@ -75,3 +75,28 @@ def test_a_failing_rank_fails_the_launch():
                          capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode != 0                               # steps = 0: every rank divides by zero -> the launcher reports it
     assert "exited with" in out.stderr
+
+
+def _dry(*args):
+    out = subprocess.run([sys.executable, BENCH, *args], env=_env(SDVL_BENCH_DRY="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+
+
+def test_eight_ranks_s_b_every_rank_tracks_chunk_rank_mod_4():
+    """the shape the driver's 8-GPU node runs, dry.  S-B (BASELINE config 4): four chunks, seeds 20260010..13; with more
+    ranks than chunks rank r tracks chunk r mod 4.  Every rank plans with an eighth of the node's free host memory."""
+    d = _dry("--gpus", "8", "--workload", "S-B", "--steps", "2", "--warmup", "1", "--seqs", "8", "--host-steps", "0")
+    assert d["n_gpus"] == 8 and d["tracked"] == 8 * 8 * 2 and len(d["per_rank"]) == 8
+    for r, pr in enumerate(d["per_rank"]):
+        assert pr["rank"] == r and pr["first_sequence"] == 8 * r
+        assert pr["seeds"] == [20260010 + r % 4], (r, pr["seeds"])
+        assert pr["host_budget_bytes"] is None or pr["host_budget_bytes"] <= d["host_memory_available_bytes"] * 1.25 / 8   # (free memory moves a little between the ranks' readings)
+
+
+def test_eight_ranks_s_c_seeds_follow_the_survey():
+    """S-C (BASELINE config 5): 64 sequences per GPU x 8 GPUs, seeds 20260100 + rank*64 + i"""
+    d = _dry("--gpus", "8", "--workload", "S-C", "--steps", "1", "--warmup", "1", "--seqs", "64", "--host-steps", "0")
+    assert d["n_gpus"] == 8 and d["tracked"] == 8 * 64
+    for r, pr in enumerate(d["per_rank"]):
+        assert pr["seed_of_first"] == 20260100 + r * 64 and pr["seed_of_last"] == 20260100 + r * 64 + 63 and len(pr["seeds"]) == 64

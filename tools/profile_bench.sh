@@ -1,8 +1,8 @@
 #!/bin/bash
-# Run on the GPU box from the repo root:  bash tools/profile_r05.sh TAG [bench.py arguments, e.g. --texture camera | --workload S-B --texture camera]
+# Run on the GPU box from the repo root:  bash tools/profile_bench.sh TAG [bench.py arguments, e.g. --texture camera | --workload S-B --texture camera]
 # One workload / texture per call: the full bench line, then rocprofv3 passes of a short run of the same command (the program itself
 # follows `--`; counters in passes of their own, never with a trace domain beyond the kernel trace), condensed by
-# tools/summarize_profiles.py into gpurun_out/TAG/summary (copy what should be judged into profiles/r05/TAG/).
+# tools/summarize_profiles.py into gpurun_out/TAG/summary (copy what should be judged into profiles/rNN/TAG/).
 #   SKIP_FULL=1: no full bench line (only the profiler passes);  SKIP_PMC=1: kernel trace only
 set -u
 TAG=$1; shift
@@ -10,7 +10,8 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out/$TAG
 mkdir -p $O
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/prof_sq $O/summary
-SHORT="--cpu-frames 0 --host-steps 0 --sustained-frames 0 --latency-frames 0"
+# every profiled run: no child processes (the latency legs exec track_sequence: under rocprofv3 the GPU is already initialised), no extra farms
+SHORT="--cpu-frames 0 --host-steps 0 --sustained-frames 0 --latency-frames 0 --lost-mix-steps 0"
 if [ -z "${SKIP_FULL:-}" ]; then
   python3 bench.py "$@" > $O/bench_default.json 2> $O/bench_default.err || { echo "bench.py failed"; tail -5 $O/bench_default.err; exit 1; }
 fi

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 output of tools/profile_round.sh into the small CSV / JSON files kept under profiles/.
+"""Condense the rocprofv3 output of tools/profile_bench.sh into the small CSV / JSON files kept under profiles/.
     python tools/summarize_profiles.py <gpurun_out> <dest_dir>"""
 import csv
 import glob
