@@ -1,3 +1,4 @@
+# (historical: the -D switches it sets existed during round 6's experiment only; kept as the record of how profiles/r06/fast_cells_lds_experiment/ was produced)
 # bash tools/fc_lds_ab.sh: fast_cells with different LDS row pitches / read widths — time alone (kernel_bench) and the SQ LDS counters
 # (are the bank conflicts hidden behind VALU issue?).  Rebuilds csrc/libsdvl_hip.so per variant ON THE BOX; restores the default at the end.
 set -u

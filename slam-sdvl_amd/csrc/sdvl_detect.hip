@@ -15,8 +15,7 @@ namespace {
 
 // Output tile of one workgroup: 32 x 8 outputs for ONE WAVE (the form the launches use: no s_barrier — the lanes hand the
 // source tile and the horizontal sums over through LDS behind a wave fence; among the other streams' kernels the 64 x 16 tile
-// of a four-wave workgroup with its three barriers ran 3.5x longer than alone, a wave that never waits for another wave does not),
-// 64 x 16 for 256 threads (kept for A/B: SDVL_PYR_WG4=1).
+// of a four-wave workgroup with its three barriers ran 3.5x longer than alone, a wave that never waits for another wave does not).
 constexpr int kPyrTW = 32, kPyrTH = 8;
 
 __device__ __forceinline__ void pyr_wave_sync() {
@@ -56,17 +55,13 @@ __global__ __launch_bounds__(kPyrTW * kPyrTH / 4) void pyr_down_kernel(const Pyr
   // Round 4: a 1-D grid dealt so that ALL tiles of a frame run on one XCD (workgroups go round-robin over the 8 XCDs: id & 7), in
   // row-major tile order.  With the plain (x, y, frame) grid the x-neighbours of a 32-px tile row landed on eight different XCDs and
   // each of their L2s fetched the same 128-B source lines, as did the vertical halo rows: 106 MB of HBM traffic per dispatch
-  // against 32.6 MB algorithmic (profiles/r03/pmc_hbm_traffic.csv).  gx == 0: the old 3-D grid (SDVL_PYR_GRID3D=1, A/B).
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (gx > 0) {
-    const int id = blockIdx.x, per_frame = gx * gy;
-    const int slot = id >> 3;
-    bz = (slot / per_frame) * 8 + (id & 7);
-    if (bz >= n_jobs) return;
-    const int t = slot % per_frame;
-    by = t / gx;
-    bx = t - by * gx;
-  }
+  // against 32.6 MB algorithmic (profiles/r03/pmc_hbm_traffic.csv).
+  const int id = blockIdx.x, per_frame = gx * gy;
+  const int slot = id >> 3;
+  const int bz = (slot / per_frame) * 8 + (id & 7);
+  if (bz >= n_jobs) return;
+  const int tq = slot % per_frame;
+  const int by = tq / gx, bx = tq - by * gx;
   const PyrJob job = jobs[bz];
   const int tx0 = bx * kPyrTW, ty0 = by * kPyrTH;
   if (tx0 >= job.dw || ty0 >= job.dh) return;
@@ -283,13 +278,7 @@ __device__ __forceinline__ int fast_corner_best(const uint8_t *tile, int pitch_b
 // as halves (kPitchHW words per row, pixel x at half 4 + x), the pair (x, x+1) with x odd reads its ring as 20 aligned words
 // — position (dx, dy) of both pixels is the word at half x + dx for odd dx, and two neighbouring words funnel-shifted by 16
 // bits for even dx — and every min3 / max3 serves two pixels: 32 + 32 + 16 packed operations instead of 2 x 88 scalar ones.
-#ifndef SDVL_FC_PITCH
-#define SDVL_FC_PITCH 20
-#endif
-#ifndef SDVL_FC_ALL64
-#define SDVL_FC_ALL64 0
-#endif
-constexpr int kPitchHW = SDVL_FC_PITCH;  // LDS row pitch of the half tile in 32-bit words: 4 + 32 + 4 halves (= 20) or more
+constexpr int kPitchHW = 20;  // LDS row pitch of the half tile in 32-bit words: 4 + 32 + 4 halves
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2 pk_min3(h2 a, h2 b, h2 c) {
@@ -336,49 +325,16 @@ __device__ __forceinline__ h2 fast_pair_best_ring(const PairRing &q, h2 t2) {
   return pk_max3(t2, v - min_x, max_n - v);
 }
 
-// w = word of the half tile at (tile row of ring row -3, halves x-3 | x-2) for the pair (x, x+1), x odd
-__device__ __forceinline__ h2 fast_pair_best(const uint32_t *w, h2 t2) {
-#define SDVL_HW(DY, K) w[((DY) + 3) * kPitchHW + (K)]  // K = (dx + 3) / 2 for odd dx: halves (x + dx, x + dx + 1)
-  const PairRing q = {SDVL_HW(3, 1), SDVL_HW(3, 2), SDVL_HW(-3, 1), SDVL_HW(-3, 2), SDVL_HW(2, 0), SDVL_HW(2, 1), SDVL_HW(2, 2), SDVL_HW(2, 3),
-                      SDVL_HW(-2, 0), SDVL_HW(-2, 1), SDVL_HW(-2, 2), SDVL_HW(-2, 3), SDVL_HW(0, 0), SDVL_HW(0, 1), SDVL_HW(0, 2), SDVL_HW(0, 3),
-                      SDVL_HW(1, 0), SDVL_HW(1, 3), SDVL_HW(-1, 0), SDVL_HW(-1, 3)};
-#undef SDVL_HW
-  return fast_pair_best_ring(q, t2);
-}
-
 // Two horizontally adjacent pairs (x .. x+3, x = 3 mod 4) at once: w as for the first pair and EVEN (8-byte aligned).  The second
 // pair's ring is the first one's moved by one word, so the two share 11 of their 2 x 20 words: 29 loads, the even-odd word pairs
 // as 64-bit loads (which the LDS serves at twice the rate of two 32-bit ones).
 __device__ __forceinline__ void fast_quad_best(const uint32_t *w, h2 t2, h2 *best_a, h2 *best_b) {
   const auto w2 = [w](int dy, int k) { return *reinterpret_cast<const uint2 *>(&w[(dy + 3) * kPitchHW + k]); };  // k even
   const auto w1 = [w](int dy, int k) { return w[(dy + 3) * kPitchHW + k]; };
-#if SDVL_FC_ALL64
-  // every read a 64-bit one (banks mod 64, both word parities; a lane's unused second word stays inside its row: word <= 19)
-  const uint32_t a1 = w2(3, 0).y, b1 = w2(-3, 0).y;
-  const uint2 a23 = w2(3, 2), b23 = w2(-3, 2);
-  const uint2 c01 = w2(2, 0), c23 = w2(2, 2), d01 = w2(-2, 0), d23 = w2(-2, 2), z01 = w2(0, 0), z23 = w2(0, 2), u01 = w2(1, 0), l01 = w2(-1, 0);
-  const uint32_t c4 = w2(2, 4).x, d4 = w2(-2, 4).x, z4 = w2(0, 4).x, u3 = w2(1, 2).y, u4 = w2(1, 4).x, l3 = w2(-1, 2).y, l4 = w2(-1, 4).x;
-  (void)w1;
-#else
   const uint32_t a1 = w1(3, 1), b1 = w1(-3, 1);
   const uint2 a23 = w2(3, 2), b23 = w2(-3, 2);
   const uint2 c01 = w2(2, 0), c23 = w2(2, 2), d01 = w2(-2, 0), d23 = w2(-2, 2), z01 = w2(0, 0), z23 = w2(0, 2), u01 = w2(1, 0), l01 = w2(-1, 0);
   const uint32_t c4 = w1(2, 4), d4 = w1(-2, 4), z4 = w1(0, 4), u3 = w1(1, 3), u4 = w1(1, 4), l3 = w1(-1, 3), l4 = w1(-1, 4);
-#endif
-#ifdef SDVL_FC_LDS_TWICE
-  // A/B (tools/fc_lds_ab.sh): the ring's 19 reads issued a second time (volatile: the compiler keeps them) — does the kernel's time
-  // follow its LDS traffic at all?
-  {
-    const volatile uint32_t *vw = w;
-    uint32_t sink = 0;
-    for (int dy = -3; dy <= 3; dy++) {
-      if (dy == 3 || dy == -3) { sink ^= vw[(dy + 3) * kPitchHW + 1]; sink ^= vw[(dy + 3) * kPitchHW + 2]; sink ^= vw[(dy + 3) * kPitchHW + 3]; }
-      else if (dy == 2 || dy == -2 || dy == 0) { for (int k = 0; k < 5; k++) sink ^= vw[(dy + 3) * kPitchHW + k]; }
-      else { sink ^= vw[(dy + 3) * kPitchHW + 0]; sink ^= vw[(dy + 3) * kPitchHW + 1]; sink ^= vw[(dy + 3) * kPitchHW + 3]; sink ^= vw[(dy + 3) * kPitchHW + 4]; }
-    }
-    asm volatile("" ::"v"(sink));
-  }
-#endif
   const PairRing qa = {a1, a23.x, b1, b23.x, c01.x, c01.y, c23.x, c23.y, d01.x, d01.y, d23.x, d23.y, z01.x, z01.y, z23.x, z23.y, u01.x, u3, l01.x, l3};
   const PairRing qb = {a23.x, a23.y, b23.x, b23.y, c01.y, c23.x, c23.y, c4, d01.y, d23.x, d23.y, d4, z01.y, z23.x, z23.y, z4, u01.y, u4, l01.y, l4};
   *best_a = fast_pair_best_ring(qa, t2);
@@ -398,237 +354,6 @@ __device__ __forceinline__ int wave_rank4(uint32_t flags, int *wave_total) {
   return below;
 }
 
-__global__ __launch_bounds__(256) void fast_cells_kernel(const FastJob *__restrict__ jobs, FastLevels lv, const CellGeo *__restrict__ cells) {
-  // ROI tile with room for a 3-row / 4-byte halo.  The halo is never initialised: every value that decides something
-  // is read within 3 px of a tested pixel, i.e. inside the ROI; halo bytes only flow into results that are masked out.
-  __shared__ uint32_t s_img[(kTile + 2 * kPadRows) * kPitchW];
-  __shared__ uint32_t s_imgh[(kTile + 2 * kPadRows) * kPitchHW];  // the same tile as halves, for the pair path
-  __shared__ uint32_t s_score[(kTile + 2) * kPitchW];  // scores of the corners, 0 elsewhere inside the ROI
-  __shared__ __attribute__((aligned(16))) uint32_t s_scoreh[(kTile + 2) * kPitchHW];  // the same as halves (pair path: the 3x3 suppression runs on pairs too)
-  __shared__ uint16_t s_list[kTile * kTile];           // (row << 5 | x) of the pixels that pass the compass pre-test
-  __shared__ int s_wave_tot[4], s_probe[4];
-  __shared__ int s_keep_tot[3][4];
-  const FastJob &job = jobs[blockIdx.y];  // by reference: a by-value copy indexed with the runtime level lands in scratch
-  // Workgroups go to the 8 XCDs round-robin by linear id; gridDim.x is a multiple of 32, so XCD = blockIdx.x % 8.  Within
-  // every run of 32 cells an XCD gets 4 horizontally adjacent ones: a cell row is 32 bytes, so the 4 cells share their
-  // 128-byte lines and find them in ONE L2 instead of fetching them once per XCD — and every XCD still sees the same mix
-  // of full and margin-clipped cells.  (One workgroup looping over its 4 cells was measured, also with the next cell's tile
-  // prefetched into registers: 385-392 µs against 318 per 256 frames — the cells of a workgroup then run one after the other
-  // with barriers in between, and independent workgroups fill those gaps better than a loop does.)
-  const int total_cells = lv.cell_begin[lv.n_levels];
-  const int gcell = static_cast<int>(blockIdx.x & ~31u) + static_cast<int>(blockIdx.x & 7u) * 4 + static_cast<int>((blockIdx.x >> 3) & 3u);
-  if (gcell >= total_cells) return;
-  // level and clipped ROI of the cell come from a table computed once per frame shape on the host: the level search, the
-  // division by the grid width and the margin clipping were ~100 dependent scalar instructions at the head of every workgroup
-  const CellGeo geo = cells[gcell];
-  const int tid = threadIdx.x;
-  if ((geo.wh & 0xFFFFu) == 0u) {  // cell swallowed by the margin: cv::FAST is not called (fast_detector.cc:84-92)
-    if (tid == 0) job.cell_counts[gcell] = 0;
-    return;
-  }
-  const int l = geo.level & 0xFF;
-  const int W = job.lw[l];
-  const int x0 = static_cast<int>(geo.xy & 0xFFFFu), y0 = static_cast<int>(geo.xy >> 16);
-  const int rw = static_cast<int>(geo.wh & 0xFFFFu), rh = static_cast<int>(geo.wh >> 16);  // <= 32
-  const uint8_t *img = job.level[l];
-  const int row = tid >> 3, wq = tid & 7, cg = wq * 4;
-  {
-    uint32_t pack = 0;
-    if (row < rh) {
-      const uint8_t *src = img + static_cast<size_t>(y0 + row) * W + x0 + cg;
-      if (cg + 4 <= rw && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {  // every cell column but the margin-clipped ones
-        pack = *reinterpret_cast<const uint32_t *>(src);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (cg + k < rw) pack |= static_cast<uint32_t>(src[k]) << (8 * k);
-      }
-    }
-    s_img[(row + kPadRows) * kPitchW + 1 + wq] = pack;
-    static_assert(((kTile + 2) * kPitchHW) % 4 == 0 && (kTile + 2) * kPitchHW / 4 <= 256, "one 16-byte store per thread clears the plane");
-    if (tid < (kTile + 2) * kPitchHW / 4) reinterpret_cast<uint4 *>(s_scoreh)[tid] = make_uint4(0u, 0u, 0u, 0u);
-    {  // pixels cg .. cg+3 as halves 4 + cg .. : words 2 + 2 wq and the next (round-toward-zero is exact for 0..255)
-      const auto lo = __builtin_amdgcn_cvt_pkrtz(static_cast<float>(pack & 0xFFu), static_cast<float>((pack >> 8) & 0xFFu));
-      const auto hi = __builtin_amdgcn_cvt_pkrtz(static_cast<float>((pack >> 16) & 0xFFu), static_cast<float>(pack >> 24));
-      uint2 hw;
-      hw.x = __builtin_bit_cast(uint32_t, lo);
-      hw.y = __builtin_bit_cast(uint32_t, hi);
-      *reinterpret_cast<uint2 *>(&s_imgh[(row + kPadRows) * kPitchHW + 2 + 2 * wq]) = hw;
-    }
-  }
-  const int t = lv.threshold;
-  const int lane = tid & 63, wave = tid >> 6;
-  if (wave == 0) {
-    const int tw = rw - 6, th = rh - 6;
-    bool probed = false, passed = false;
-    if (tw > 0 && th > 0) {
-      const int pr = 3 + ((lane >> 3) * th >> 3), px = 3 + ((lane & 7) * tw >> 3);
-      const uint8_t *q = img + static_cast<size_t>(y0 + pr) * W + x0 + px;
-      probed = true;
-      passed = fast_compass_pass(q[0], q[3 * W], q[3], q[-3 * W], q[-3], t);
-    }
-    const unsigned long long mp = __ballot(probed), mq = __ballot(passed);
-    if (lane == 0) s_probe[0] = 2 * __popcll(mq) > __popcll(mp) ? 1 : 0;
-  }
-  __syncthreads();
-  // ---- density probe (wave 0, before the barrier above): the compass pre-test on an 8 x 8 sample of the tested pixels, read
-  // straight from the image while the tile is on its way, so the vote rides on the tile's barrier instead of costing one.
-  // Where most pixels pass it — dense texture: on the synthetic plane 83 % of the tested pixels pass and 48 % are corners —
-  // listing the survivors buys nothing, and the tile is scored densely instead (phases A and B skipped).  Both paths yield the
-  // same corners and scores; the probe only chooses the cheaper one.
-  const bool dense = s_probe[0] != 0;
-  int ncand;                 // candidates of phase C: pixels (sparse path) or pixel pairs (dense path)
-  int dense_npr = 1, dense_inv = 0;
-  if (dense) {
-    // every tested pixel (rows 3 .. rh-4, columns 3 .. rw-4) is a candidate, two per lane: pair q = (row q / npr, columns
-    // 3 + 2 (q % npr) and the next), in scan order
-    const int tw = rw - 6;
-    dense_npr = tw > 0 ? (tw + 1) >> 1 : 1;
-    ncand = tw > 0 && rh > 6 ? dense_npr * (rh - 6) : 0;
-    dense_inv = (65536 + dense_npr - 1) / dense_npr;  // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13
-  } else {
-    s_score[(row + 1) * kPitchW + 1 + wq] = 0;  // the byte score plane of this path; two barriers lie between here and its first use
-    // ---- phase A: compass pre-test of the thread's 4 pixels
-    uint32_t cflags = 0;
-    if (row >= 3 && row < rh - 3) {
-      const uint32_t *qz = &s_img[(row + kPadRows) * kPitchW + wq];
-      const uint32_t rz0 = qz[0], rz1 = qz[1], rz2 = qz[2];
-      const uint32_t up = s_img[(row + kPadRows - 3) * kPitchW + wq + 1], dn = s_img[(row + kPadRows + 3) * kPitchW + wq + 1];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int x = cg + k;
-        if (x < 3 || x >= rw - 3) continue;
-        const int v = static_cast<int>((rz1 >> (8 * k)) & 0xFFu);
-        if (fast_compass_pass(v, static_cast<int>((dn >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 7 + k),
-                              static_cast<int>((up >> (8 * k)) & 0xFFu), byte_of(rz0, rz1, rz2, 1 + k), t))
-          cflags |= 1u << k;
-      }
-    }
-    // ---- phase B: candidates listed densely in scan order (thread order == row-major pixel order)
-    int wtot;
-    const int wrank = wave_rank4(cflags, &wtot);
-    if (lane == 0) s_wave_tot[wave] = wtot;
-    __syncthreads();
-    int cbase = 0;
-    for (int w = 0; w < wave; w++) cbase += s_wave_tot[w];
-    ncand = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-    {
-      int cpos = cbase + wrank;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (cflags & (1u << k)) s_list[cpos++] = static_cast<uint16_t>((row << 5) | (cg + k));
-    }
-    __syncthreads();
-  }
-  // ---- phase C: the 16-pixel arithmetic, which yields the segment test AND the score — one candidate pixel per lane and
-  // pass (sparse), or one pixel PAIR per lane and pass on packed halves (dense).  Slot (ps, k): pass ps, pixel k of the pair.
-  uint8_t *score_bytes = reinterpret_cast<uint8_t *>(s_score);
-  const uint8_t *img_bytes = reinterpret_cast<const uint8_t *>(s_img);
-  const int npass = (ncand + 255) >> 8;  // <= 3 (sparse: 26 x 26 tested pixels; dense: 13 x 26 pairs -> 2)
-  int rc_of[3][2], sc_of[3][2];
-#pragma unroll
-  for (int ps = 0; ps < 3; ps++) {
-    rc_of[ps][0] = rc_of[ps][1] = 0;
-    sc_of[ps][0] = sc_of[ps][1] = 0;
-    if (ps < npass) {
-      const int i = ps * 256 + tid;
-      if (i < ncand) {
-        if (dense) {
-          const int qr = (i * dense_inv) >> 16, j = i - qr * dense_npr;
-          const int r = qr + 3, x = 3 + 2 * j;
-          const _Float16 th = static_cast<_Float16>(t);
-          const h2 best2 = fast_pair_best(&s_imgh[r * kPitchHW + 2 + j], h2{th, th});  // tile row r = ring row -3 of image row r
-          const int b0 = static_cast<int>(static_cast<float>(best2.x)), b1 = static_cast<int>(static_cast<float>(best2.y));
-          _Float16 *score_halves = reinterpret_cast<_Float16 *>(s_scoreh) + (r + 1) * (kPitchHW * 2) + 4 + x;
-          if (b0 > t) {
-            const int sc = (b0 - 1) & 0xFF;  // uchar like OpenCV's score buffer
-            score_halves[0] = static_cast<_Float16>(sc);
-            rc_of[ps][0] = (r << 5) | x;
-            sc_of[ps][0] = sc;
-          }
-          if (b1 > t && x + 1 < rw - 3) {
-            const int sc = (b1 - 1) & 0xFF;
-            score_halves[1] = static_cast<_Float16>(sc);
-            rc_of[ps][1] = (r << 5) | (x + 1);
-            sc_of[ps][1] = sc;
-          }
-        } else {
-          const int rc = s_list[i];
-          const int r = rc >> 5, x = rc & 31;
-          const int best = fast_corner_best(img_bytes + (r + kPadRows) * (kPitchW * 4) + 4 + x, kPitchW * 4, t);
-          if (best > t) {
-            const int sc = (best - 1) & 0xFF;
-            score_bytes[(r + 1) * (kPitchW * 4) + 4 + x] = static_cast<uint8_t>(sc);
-            rc_of[ps][0] = rc;
-            sc_of[ps][0] = sc;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- 3x3 strict non-max suppression of the corners (a score of 0 never survives, as in the per-pixel formulation)
-  uint32_t keep = 0;
-#pragma unroll
-  for (int ps = 0; ps < 3; ps++) {
-    if (ps < npass) {
-      bool ok0 = false, ok1 = false;
-      if (dense) {
-        // both pixels of the pair at once: the maximum over the 8 neighbours of each, three packed max3 per row of neighbours
-        const int sc0 = sc_of[ps][0], sc1 = sc_of[ps][1];
-        if (sc0 | sc1) {
-          const int rc = sc0 ? rc_of[ps][0] : rc_of[ps][1] - 1;  // (row, x of the pair's first pixel)
-          const int r = rc >> 5, x = rc & 31;
-          const uint32_t *sw = &s_scoreh[(r + 1) * kPitchHW + ((x + 3) >> 1)];  // halves (x-1 | x); the next word (x+1 | x+2)
-          const uint32_t u0 = sw[-kPitchHW], u1 = sw[-kPitchHW + 1], c0 = sw[0], c1 = sw[1], d0 = sw[kPitchHW], d1 = sw[kPitchHW + 1];
-          const h2 up = pk_max3(as_h2(u0), mid_h2(u1, u0), as_h2(u1)), dn = pk_max3(as_h2(d0), mid_h2(d1, d0), as_h2(d1));
-          const h2 m = pk_max3(up, dn, pk_max3(as_h2(c0), as_h2(c1), as_h2(c1)));  // same row: left neighbours (x-1 | x), right (x+1 | x+2)
-          ok0 = sc0 > static_cast<int>(static_cast<float>(m.x));
-          ok1 = sc1 > static_cast<int>(static_cast<float>(m.y));
-        }
-      } else {
-        const int sc = sc_of[ps][0];
-        if (sc) {
-          const int r = rc_of[ps][0] >> 5, x = rc_of[ps][0] & 31;
-          const uint8_t *q = score_bytes + (r + 1) * (kPitchW * 4) + 4 + x;
-          const int pb = kPitchW * 4;
-          ok0 = sc > q[-1] && sc > q[1] && sc > q[-pb - 1] && sc > q[-pb] && sc > q[-pb + 1] && sc > q[pb - 1] && sc > q[pb] && sc > q[pb + 1];
-        }
-      }
-      if (ok0) keep |= 1u << (2 * ps);
-      if (ok1) keep |= 1u << (2 * ps + 1);
-      const int cnt = __popcll(__ballot(ok0)) + __popcll(__ballot(ok1));
-      if (lane == 0) s_keep_tot[ps][wave] = cnt;
-    }
-  }
-  __syncthreads();
-  // survivors in candidate order (pass, lane, pixel of the pair) = row-major order = cv::FAST's output order
-  uint32_t *out = job.cell_kps + static_cast<size_t>(gcell) * SDVL_CELL_KP_CAP;
-  int base = 0;
-#pragma unroll
-  for (int ps = 0; ps < 3; ps++) {
-    if (ps < npass) {
-      const bool ok0 = (keep >> (2 * ps)) & 1u, ok1 = (keep >> (2 * ps + 1)) & 1u;
-      const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
-      int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m0 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m0), 0)) +
-                __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m1 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m1), 0));
-      for (int w = 0; w < wave; w++) pos += s_keep_tot[ps][w];
-      if (ok0 && pos < SDVL_CELL_KP_CAP) {
-        const int r = rc_of[ps][0] >> 5, x = rc_of[ps][0] & 31;
-        out[pos] = static_cast<uint32_t>(x0 + x) | (static_cast<uint32_t>(y0 + r) << 12) | (static_cast<uint32_t>(sc_of[ps][0]) << 24);
-      }
-      pos += ok0 ? 1 : 0;
-      if (ok1 && pos < SDVL_CELL_KP_CAP) {
-        const int r = rc_of[ps][1] >> 5, x = rc_of[ps][1] & 31;
-        out[pos] = static_cast<uint32_t>(x0 + x) | (static_cast<uint32_t>(y0 + r) << 12) | (static_cast<uint32_t>(sc_of[ps][1]) << 24);
-      }
-      base += s_keep_tot[ps][0] + s_keep_tot[ps][1] + s_keep_tot[ps][2] + s_keep_tot[ps][3];
-    }
-  }
-  if (tid == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
-}
-
-// ---- one WAVE per cell ---------------------------------------------------------------------------------------------------
 // The same work as fast_cells_kernel with a 64-lane workgroup: no s_barrier anywhere (the lanes of one wave hand data over
 // through LDS behind a wave fence), no cross-wave prefix sums (ranks come from ballots and a running base), the probe's vote
 // is a ballot, and only the tile / score planes of the chosen path are written: 7.5 KB of LDS per cell instead of 13 KB and
@@ -651,16 +376,16 @@ constexpr int kFcSparseWords = (kTile + 2 * kPadRows) * kPitchW + (kTile + 2) * 
 static_assert(kFcSparseWords <= kFcDenseWords, "the sparse layout lives inside the dense one");
 static_assert(((kTile + 2 * kPadRows) * kPitchHW * 4) % 16 == 0, "the half score plane is cleared with 16-byte stores");
 
-// kHalfScores (the default; SDVL_FAST_INT_SCORES=1 for the other form): the dense path's scores never leave the packed halves.
-// best >= t always, so "corner" is best - 1 >= t, a non-corner's best - 1 is t - 1, and a corner's score beats every non-corner's
-// whether the plane holds 0 or t - 1 for those: phase C stores best2 - 1 as it comes (two 16-bit stores, no conversion, no
-// compare) and keeps it in a register; the suppression folds max(t - 1, 0) into the neighbours' maximum m, and then
-// "is a corner AND beats its 8 neighbours" is the SIGN of m - score per half (integers in f16: exact, m == score gives +0).
+// The dense path's scores never leave the packed halves.  best >= t always, so "corner" is best - 1 >= t, a non-corner's best - 1 is
+// t - 1, and a corner's score beats every non-corner's whether the plane holds 0 or t - 1 for those: the ring phase stores best2 - 1 as
+// it comes (no conversion, no compare) and keeps it in a register; the suppression folds max(t - 1, 0) into the neighbours' maximum m,
+// and then "is a corner AND beats its 8 neighbours" is the SIGN of m - score per half (integers in f16: exact, m == score gives +0).
 // The second pixel of a row's last pair in an odd-width ROI is not a tested pixel: it is given t - 1, a non-corner.
-// kQuads (the default; SDVL_FAST_PAIRS=1 for one pair per lane and pass): a lane takes FOUR adjacent pixels, two pairs, per pass —
-// the rings of the two pairs share loads (fast_quad_best), and the index arithmetic, the suppression's neighbour loads and the ordered
-// compaction are paid once per four pixels: 3 passes of 182 lane tasks instead of 6 of 338.
-template <bool kHalfScores, bool kQuads = false>
+// A lane takes FOUR adjacent pixels, two pairs, per pass — the rings of the two pairs share loads (fast_quad_best), and the index
+// arithmetic, the suppression's neighbour loads and the ordered compaction are paid once per four pixels: 3 passes of 182 lane tasks.
+// (Round 6: the kernel's LDS bank conflicts — 57 % of its LDS cycles — are hidden behind its vector issue: a conflict-free layout
+//  halved the LDS cycles and changed nothing, profiles/r06/fast_cells_lds_experiment/.  The four-wave, pair-per-lane and integer-score
+//  forms of rounds 2-4 are gone.)
 __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__restrict__ jobs, FastLevels lv, const CellGeo *__restrict__ cells) {
   __shared__ __attribute__((aligned(16))) uint32_t s_mem[kFcDenseWords];
   const FastJob &job = jobs[blockIdx.y];
@@ -746,28 +471,17 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
     for (int k = 0; k < 4; k++) {  // pixels as halves: pixel x at half 4 + x
       const uint32_t pack = pk[k];
       uint2 hw;
-      if (kHalfScores) {
-        // the half 0x6400 | b IS 1024 + b (ulp 1 on [1024, 2048)): one byte shuffle per pixel pair instead of two conversions and
-        // a pack.  Every use of a pixel is a min / max or a difference of two pixels: the offset never shows.
-        hw.x = __builtin_amdgcn_perm(0x64646464u, pack, 0x04010400u);  // selector bytes 0-3: bytes of `pack`, 4-7: of the constant
-        hw.y = __builtin_amdgcn_perm(0x64646464u, pack, 0x04030402u);
-      } else {
-        const auto lo = __builtin_amdgcn_cvt_pkrtz(static_cast<float>(pack & 0xFFu), static_cast<float>((pack >> 8) & 0xFFu));
-        const auto hi = __builtin_amdgcn_cvt_pkrtz(static_cast<float>((pack >> 16) & 0xFFu), static_cast<float>(pack >> 24));
-        hw.x = __builtin_bit_cast(uint32_t, lo);
-        hw.y = __builtin_bit_cast(uint32_t, hi);
-      }
+      // the half 0x6400 | b IS 1024 + b (ulp 1 on [1024, 2048)): one byte shuffle per pixel pair instead of two conversions and
+      // a pack.  Every use of a pixel is a min / max or a difference of two pixels: the offset never shows.
+      hw.x = __builtin_amdgcn_perm(0x64646464u, pack, 0x04010400u);  // selector bytes 0-3: bytes of `pack`, 4-7: of the constant
+      hw.y = __builtin_amdgcn_perm(0x64646464u, pack, 0x04030402u);
       *reinterpret_cast<uint2 *>(&s_imgh[(row + kPadRows) * kPitchHW + 2 + 2 * (wbase + k)]) = hw;
     }
     fc_wave_sync();
     const int tw = rw - 6;
     const int npr = tw > 0 ? (tw + 1) >> 1 : 1;
-    const int ncand = tw > 0 && rh > 6 ? npr * (rh - 6) : 0;   // pixel pairs, <= 13 x 26 = 338
-    const int inv = geo.pair_inv;                              // q / npr == (q * inv) >> 16 for q < 1024, npr <= 13 (from the table: a division here is ten vector instructions)
-    const int npass = (ncand + 63) >> 6;                       // <= 6
     const _Float16 th = static_cast<_Float16>(t);
-    if constexpr (kQuads) {
-      static_assert(kHalfScores, "the quad path keeps its scores as halves");
+    {
       const h2 t2 = h2{th, th}, one2 = h2{static_cast<_Float16>(1), static_cast<_Float16>(1)};
       const h2 below2 = t2 - one2;  // best - 1 of a pixel that is no corner
       const _Float16 tf = static_cast<_Float16>(t > 1 ? t - 1 : 0);
@@ -859,122 +573,6 @@ __global__ __launch_bounds__(64) void fast_cells_wave_kernel(const FastJob *__re
       }
       if (lane == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
       return;
-    }
-    if constexpr (kHalfScores) {
-      const h2 t2 = h2{th, th}, one2 = h2{static_cast<_Float16>(1), static_cast<_Float16>(1)};
-      const _Float16 tf = static_cast<_Float16>(t > 1 ? t - 1 : 0);
-      const h2 floor2 = h2{tf, tf};
-      const bool odd = (tw & 1) != 0;
-      _Float16 *score_halves = reinterpret_cast<_Float16 *>(s_scoreh);
-      const FcGlobalWords gout = (FcGlobalWords)out;  // global, not flat, stores
-      uint32_t sc2[6], wofs[6], xy[6];  // per pass: the pair's scores (halves), its word in the half tile, (x | y << 12) of its first pixel
-#pragma unroll
-      for (int ps = 0; ps < 6; ps++) {
-        sc2[ps] = wofs[ps] = xy[ps] = 0u;
-        if (ps < npass) {
-          const int i = ps * 64 + lane;
-          if (i < ncand) {
-            const int qr = (i * inv) >> 16, j = i - qr * npr;
-            const int w = (qr + 3) * kPitchHW + 2 + j;  // tile row r = qr + 3 is ring row -3 of image row r
-            h2 s2 = fast_pair_best(&s_imgh[w], t2) - one2;
-            if (odd) {  // (a real branch on the wave-uniform flag: even widths, the common case, pay nothing)
-              asm volatile("");
-              if (j == npr - 1) s2.y = t2.y - one2.y;  // x + 1 == rw - 3: not a tested pixel
-            }
-            _Float16 *sh = score_halves + 2 * w + 2 * kPitchHW + 3;  // half 4 + x of plane row r + 1 (x = 3 + 2 j)
-            // two 16-bit stores, kept apart: the pair starts on an odd half, and merged into one UNALIGNED 32-bit LDS store (what
-            // the compiler makes of two plain stores) the kernel takes 227 us per 256 frames instead of 184
-            // (volatile through an LDS-address-space pointer: through a generic one they become flat stores with a wait each)
-            typedef __attribute__((address_space(3))) volatile _Float16 *LdsHalves;
-            const LdsHalves vsh = (LdsHalves)sh;
-            vsh[0] = s2.x;
-            vsh[1] = s2.y;
-            sc2[ps] = __builtin_bit_cast(uint32_t, s2);
-            wofs[ps] = static_cast<uint32_t>(w);
-            xy[ps] = static_cast<uint32_t>(x0 + 3 + 2 * j) | (static_cast<uint32_t>(y0 + 3 + qr) << 12);
-          }
-        }
-      }
-      fc_wave_sync();
-#pragma unroll
-      for (int ps = 0; ps < 6; ps++) {
-        if (ps < npass) {
-          const uint32_t own = sc2[ps];
-          uint32_t diff = 0u;  // sign per half: corner that beats its 8 neighbours
-          if (ps * 64 + lane < ncand) {
-            const uint32_t *sw = &s_scoreh[wofs[ps] + kPitchHW + 1];  // halves (x-1 | x) of plane row r + 1; the next word (x+1 | x+2)
-            const uint32_t u0 = sw[-kPitchHW], u1 = sw[-kPitchHW + 1], c0 = sw[0], c1 = sw[1], d0 = sw[kPitchHW], d1 = sw[kPitchHW + 1];
-            const h2 up = pk_max3(as_h2(u0), mid_h2(u1, u0), as_h2(u1)), dn = pk_max3(as_h2(d0), mid_h2(d1, d0), as_h2(d1));
-            const h2 m = pk_max3(up, dn, pk_max3(as_h2(c0), as_h2(c1), floor2));
-            diff = __builtin_bit_cast(uint32_t, m - as_h2(own));
-          }
-          const uint32_t lo_sign = (diff >> 15) & 1u;
-          const bool ok0 = lo_sign != 0u, ok1 = static_cast<int32_t>(diff) < 0;
-          const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
-          int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m0 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m0), 0)) +
-                    __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m1 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m1), 0));
-          const h2 s2 = as_h2(own);
-          if (ok0 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = xy[ps] | (static_cast<uint32_t>(static_cast<uint16_t>(s2.x)) << 24);
-          pos += static_cast<int>(lo_sign);
-          if (ok1 && pos < SDVL_CELL_KP_CAP) *fc_slot(gout, pos) = (xy[ps] + 1u) | (static_cast<uint32_t>(static_cast<uint16_t>(s2.y)) << 24);
-          base += __popcll(m0) + __popcll(m1);
-        }
-      }
-      if (lane == 0) job.cell_counts[gcell] = min(base, SDVL_CELL_KP_CAP);
-      return;
-    }
-    uint32_t found[6][2];  // corner of slot (pass, pixel of the pair): score << 10 | row << 5 | x, 0 = none
-#pragma unroll
-    for (int ps = 0; ps < 6; ps++) {
-      found[ps][0] = found[ps][1] = 0u;
-      if (ps < npass) {
-        const int i = ps * 64 + lane;
-        if (i < ncand) {
-          const int qr = (i * inv) >> 16, j = i - qr * npr;
-          const int r = qr + 3, x = 3 + 2 * j;
-          const h2 best2 = fast_pair_best(&s_imgh[r * kPitchHW + 2 + j], h2{th, th});
-          const int b0 = static_cast<int>(static_cast<float>(best2.x)), b1 = static_cast<int>(static_cast<float>(best2.y));
-          _Float16 *score_halves = reinterpret_cast<_Float16 *>(s_scoreh) + (r + 1) * (kPitchHW * 2) + 4 + x;
-          if (b0 > t) {
-            const int sc = (b0 - 1) & 0xFF;  // uchar like OpenCV's score buffer
-            score_halves[0] = static_cast<_Float16>(sc);
-            found[ps][0] = static_cast<uint32_t>((sc << 10) | (r << 5) | x);
-          }
-          if (b1 > t && x + 1 < rw - 3) {
-            const int sc = (b1 - 1) & 0xFF;
-            score_halves[1] = static_cast<_Float16>(sc);
-            found[ps][1] = static_cast<uint32_t>((sc << 10) | (r << 5) | (x + 1));
-          }
-        }
-      }
-    }
-    fc_wave_sync();
-    // 3x3 strict non-max suppression on the pairs and ordered output, pass by pass
-#pragma unroll
-    for (int ps = 0; ps < 6; ps++) {
-      if (ps < npass) {
-        const uint32_t f0 = found[ps][0], f1 = found[ps][1];
-        bool ok0 = false, ok1 = false;
-        if (f0 | f1) {
-          const int rc = f0 ? static_cast<int>(f0 & 1023u) : static_cast<int>(f1 & 1023u) - 1;  // (row, x of the pair's first pixel)
-          const int r = rc >> 5, x = rc & 31;
-          const uint32_t *sw = &s_scoreh[(r + 1) * kPitchHW + ((x + 3) >> 1)];  // halves (x-1 | x); the next word (x+1 | x+2)
-          const uint32_t u0 = sw[-kPitchHW], u1 = sw[-kPitchHW + 1], c0 = sw[0], c1 = sw[1], d0 = sw[kPitchHW], d1 = sw[kPitchHW + 1];
-          const h2 up = pk_max3(as_h2(u0), mid_h2(u1, u0), as_h2(u1)), dn = pk_max3(as_h2(d0), mid_h2(d1, d0), as_h2(d1));
-          const h2 m = pk_max3(up, dn, pk_max3(as_h2(c0), as_h2(c1), as_h2(c1)));
-          ok0 = static_cast<int>(f0 >> 10) > static_cast<int>(static_cast<float>(m.x));
-          ok1 = static_cast<int>(f1 >> 10) > static_cast<int>(static_cast<float>(m.y));
-        }
-        const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
-        int pos = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m0 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m0), 0)) +
-                  __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m1 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m1), 0));
-        if (ok0 && pos < SDVL_CELL_KP_CAP)
-          out[pos] = static_cast<uint32_t>(x0 + static_cast<int>(f0 & 31u)) | (static_cast<uint32_t>(y0 + static_cast<int>((f0 >> 5) & 31u)) << 12) | ((f0 >> 10) << 24);
-        pos += ok0 ? 1 : 0;
-        if (ok1 && pos < SDVL_CELL_KP_CAP)
-          out[pos] = static_cast<uint32_t>(x0 + static_cast<int>(f1 & 31u)) | (static_cast<uint32_t>(y0 + static_cast<int>((f1 >> 5) & 31u)) << 12) | ((f1 >> 10) << 24);
-        base += __popcll(m0) + __popcll(m1);
-      }
     }
   } else {
     uint32_t *s_img = s_mem;
@@ -1877,16 +1475,9 @@ int sdvl_pyramid_build(sdvl_ctx *ctx, int n, sdvl_frame *const *frames) {
   SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hj, bytes));
   for (int l = 1; l < levels; l++) {
     const FrameView &v = frames[0]->v;
-    static const bool four_waves = getenv("SDVL_PYR_WG4") != nullptr;
-    static const bool grid3d = getenv("SDVL_PYR_GRID3D") != nullptr;
-    const int tw = four_waves ? 64 : kPyrTW, th = four_waves ? 16 : kPyrTH;
-    const int gx = (v.lw[l] + tw - 1) / tw, gy = (v.lh[l] + th - 1) / th;
-    const dim3 grid = grid3d ? dim3(gx, gy, n) : dim3(static_cast<unsigned>(gx) * gy * ((n + 7) / 8 * 8), 1, 1);
-    const int kgx = grid3d ? 0 : gx;
-    if (four_waves)
-      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<64, 16>), grid, dim3(256), static_cast<const PyrJob *>(dsx) + (l - 1) * n, n, kgx, gy);
-    else
-      SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<kPyrTW, kPyrTH>), grid, dim3(64), static_cast<const PyrJob *>(dsx) + (l - 1) * n, n, kgx, gy);
+    const int gx = (v.lw[l] + kPyrTW - 1) / kPyrTW, gy = (v.lh[l] + kPyrTH - 1) / kPyrTH;
+    const dim3 grid = dim3(static_cast<unsigned>(gx) * gy * ((n + 7) / 8 * 8), 1, 1);
+    SDVL_LAUNCH(ctx, "pyr_down", (pyr_down_kernel<kPyrTW, kPyrTH>), grid, dim3(64), static_cast<const PyrJob *>(dsx) + (l - 1) * n, n, gx, gy);
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
@@ -1947,21 +1538,6 @@ static int fast_cells_dense_num() {
     const int n = e ? atoi(e) : 16;
     return n < 0 ? 0 : (n > 64 ? 64 : n);
   }();
-  return v;
-}
-
-static bool fast_cells_int_scores() {
-  static const bool v = getenv("SDVL_FAST_INT_SCORES") != nullptr;
-  return v;
-}
-// SDVL_FAST_PAIRS=1: the dense path with one pixel pair per lane and pass (A/B measurements, tests)
-static bool fast_cells_pairs() {
-  static const bool v = getenv("SDVL_FAST_PAIRS") != nullptr;
-  return v;
-}
-// SDVL_FAST_WG4=1: the four-wave workgroup per cell (fast_cells_kernel) instead of one wave per cell (A/B measurements, tests)
-static bool fast_cells_four_waves() {
-  static const bool v = getenv("SDVL_FAST_WG4") != nullptr;
   return v;
 }
 
@@ -2072,13 +1648,7 @@ int sdvl_fast_cells(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const sdvl_
     const int rc_t = fast_cell_table(ctx, lv, frames[0], &d_cells);
     if (rc_t) return rc_t;
   }
-  if (fast_cells_four_waves()) {
-    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), static_cast<const FastJob *>(dsx), lv, d_cells);
-  } else {
-    if (fast_cells_int_scores()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<false>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
-    else if (fast_cells_pairs()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
-    else SDVL_LAUNCH(ctx, "fast_cells", (fast_cells_wave_kernel<true, true>), dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
-  }
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(64), static_cast<const FastJob *>(dsx), lv, d_cells);
   SDVL_LAUNCH(ctx, "compact_cells", compact_cells_kernel, dim3(n), dim3(256), static_cast<const FastJob *>(dsx), total_cells, cap, d_kps, d_offs);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   int32_t *h_offs = static_cast<int32_t *>(ctx->h_out);
@@ -2225,13 +1795,7 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
     const int rc_t = fast_cell_table(ctx, lv, frames[0], &d_cells);
     if (rc_t) return rc_t;
   }
-  if (fast_cells_four_waves()) {
-    SDVL_LAUNCH(ctx, "fast_cells", fast_cells_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(256), df, lv, d_cells);
-  } else {
-    if (fast_cells_int_scores()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<false>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
-    else if (fast_cells_pairs()) SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel<true>, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
-    else SDVL_LAUNCH(ctx, "fast_cells", (fast_cells_wave_kernel<true, true>), dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
-  }
+  SDVL_LAUNCH(ctx, "fast_cells", fast_cells_wave_kernel, dim3((total_cells + 31) / 32 * 32, n), dim3(64), df, lv, d_cells);
   SDVL_LAUNCH(ctx, "select_cells", select_cells_kernel, dim3(static_cast<unsigned>((n + 7) / 8 * 8 * n_slices)), dim3(64), ds, sl, n);
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
   // writes them into device memory and, when results go direct, into the pinned host array as well

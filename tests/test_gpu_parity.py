@@ -1026,21 +1026,3 @@ def test_host_layer_camera_undistort(orc):
     assert f(dev.h, 640, 480, cam.ctypes.data, dist.ctypes.data, img.ctypes.data, 640, out.ctypes.data) == 1
     assert np.array_equal(out, orc.undistort(img, TUM_CAM, TUM_DIST))
     dev.close()
-
-
-@pytest.mark.parametrize("switch", ["SDVL_FAST_PAIRS", "SDVL_FAST_INT_SCORES", "SDVL_FAST_WG4"])
-def test_fast_cells_other_forms_of_the_dense_path(switch):
-    """the forms of fast_cells kept behind environment switches for A/B measurements (one pixel pair per lane and pass; integer scores;
-    the four-wave workgroup) yield the same corners as the default — the switches are read once per process, so each runs the FAST
-    parity tests in a process of its own"""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get(switch):
-        pytest.skip("already inside a run with the switch set")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "fast_cells and not other_forms", "-p", "no:cacheprovider"],
-                       capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **{switch: "1"}))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
