@@ -57,11 +57,10 @@ __global__ __launch_bounds__(256) void stage_push_kernel(const push_u32x4 *__res
 
 hipError_t sdvl_push(sdvl_ctx *ctx, void *dst_dev, const void *src_staged, size_t bytes) {
   if (bytes == 0) return hipSuccess;
-  static const bool dma = getenv("SDVL_STAGE_DMA") != nullptr;
   const uint8_t *s8 = static_cast<const uint8_t *>(src_staged), *ring = static_cast<const uint8_t *>(ctx->h_stage);
   // inside the ring allocations are 256-byte granules on both sides: copying whole 16-byte units never leaves them
   const bool staged = ring && s8 >= ring && s8 + bytes <= ring + ctx->h_stage_bytes && ((reinterpret_cast<uintptr_t>(s8) | reinterpret_cast<uintptr_t>(dst_dev)) & 15u) == 0;
-  if (dma || !staged || bytes > (static_cast<size_t>(64) << 20)) return hipMemcpyAsync(dst_dev, src_staged, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (!staged || bytes > (static_cast<size_t>(64) << 20)) return hipMemcpyAsync(dst_dev, src_staged, bytes, hipMemcpyHostToDevice, ctx->stream);
   const int n16 = static_cast<int>((bytes + 15) >> 4);
   const int blocks = n16 <= 256 ? 1 : (n16 >= 256 * 64 ? 64 : (n16 + 255) / 256);
   hipLaunchKernelGGL(stage_push_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const push_u32x4 *>(s8), static_cast<push_u32x4 *>(dst_dev), n16);
@@ -70,8 +69,7 @@ hipError_t sdvl_push(sdvl_ctx *ctx, void *dst_dev, const void *src_staged, size_
 
 // The other direction: results that a kernel left in device memory go to a pinned host buffer through a kernel's stores (posted PCIe
 // writes) instead of a DMA command — the tracked step's last sizeable DMA copy (the FilterCorners records, ~1 MB per group-step) was
-// what waited behind parked image transfers.  Both pointers 16-byte aligned, whole 16-byte units are copied;
-// SDVL_STAGE_DMA=1 (or SDVL_RESULT_COPIES=1) keeps hipMemcpyAsync.
+// what waited behind parked image transfers.  Both pointers 16-byte aligned, whole 16-byte units are copied.
 namespace {
 __global__ __launch_bounds__(256) void stage_pull_kernel(const push_u32x4 *__restrict__ src, push_u32x4 *__restrict__ dst_host, int n16) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) __builtin_nontemporal_store(src[i], dst_host + i);
@@ -80,9 +78,8 @@ __global__ __launch_bounds__(256) void stage_pull_kernel(const push_u32x4 *__res
 
 hipError_t sdvl_pull(sdvl_ctx *ctx, void *dst_host_pinned, const void *src_dev, size_t bytes) {
   if (bytes == 0) return hipSuccess;
-  static const bool dma = getenv("SDVL_STAGE_DMA") != nullptr || !sdvl_direct_results();
   const bool ok = ((reinterpret_cast<uintptr_t>(dst_host_pinned) | reinterpret_cast<uintptr_t>(src_dev)) & 15u) == 0;
-  if (dma || !ok || bytes > (static_cast<size_t>(64) << 20)) return hipMemcpyAsync(dst_host_pinned, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (!ok || bytes > (static_cast<size_t>(64) << 20)) return hipMemcpyAsync(dst_host_pinned, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
   const int n16 = static_cast<int>((bytes + 15) >> 4);
   const int blocks = n16 <= 256 ? 1 : (n16 >= 256 * 64 ? 64 : (n16 + 255) / 256);
   hipLaunchKernelGGL(stage_pull_kernel, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const push_u32x4 *>(src_dev), static_cast<push_u32x4 *>(dst_host_pinned), n16);
@@ -107,22 +104,10 @@ int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d) {
   return SDVL_OK;
 }
 
-static bool marks_use_events() {
-  static const bool ev = getenv("SDVL_WAIT_EVENTS") != nullptr;
-  return ev;
-}
-
 hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket) {
   const uint32_t seq = ++ctx->flag_seq;
   *ticket = seq;
-  if (marks_use_events()) {
-    if (!ctx->mark_events[kind]) {
-      hipError_t e = hipEventCreateWithFlags(&ctx->mark_events[kind], hipEventBlockingSync | hipEventDisableTiming);
-      if (e != hipSuccess) return e;
-    }
-    ctx->mark_event_ticket[kind] = seq;
-    return hipEventRecord(ctx->mark_events[kind], ctx->stream);
-  }
+  (void)kind;
   if (!ctx->h_flag) {
     void *p = nullptr;
     hipError_t e = sdvl_bind_device(ctx);
@@ -140,13 +125,7 @@ hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket) {
 // 1 = the mark has been reached, 0 = not yet, < 0 = the stream reported an error
 static int mark_reached(sdvl_ctx *ctx, int kind, uint32_t ticket, hipError_t *err) {
   *err = hipSuccess;
-  if (marks_use_events()) {
-    if (ctx->mark_event_ticket[kind] != ticket) return 1;  // a later mark of this kind has been recorded and waited for
-    const hipError_t e = hipEventQuery(ctx->mark_events[kind]);
-    if (e == hipErrorNotReady) return 0;
-    *err = e;
-    return e == hipSuccess ? 1 : -1;
-  }
+  (void)kind;
   const uint32_t seen = __atomic_load_n(const_cast<const uint32_t *>(ctx->h_flag), __ATOMIC_ACQUIRE);
   return static_cast<int32_t>(seen - ticket) >= 0 ? 1 : 0;
 }
@@ -156,7 +135,7 @@ static int mark_reached(sdvl_ctx *ctx, int kind, uint32_t ticket, hipError_t *er
 // of the thread at 1 us a 25 us nanosleep costs ~30 us.  Every ~100 ms the stream is asked whether it is still healthy,
 // so that a faulted kernel surfaces as an error instead of a hang.
 hipError_t sdvl_mark_wait(sdvl_ctx *ctx, int kind, uint32_t ticket) {
-  static const int poll_ns = getenv("SDVL_WAIT_POLL_NS") ? atoi(getenv("SDVL_WAIT_POLL_NS")) : 25000;
+  constexpr int poll_ns = 25000;
   static thread_local bool slack_set = false;
   if (!slack_set) {
     prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
@@ -180,7 +159,7 @@ hipError_t sdvl_mark_wait(sdvl_ctx *ctx, int kind, uint32_t ticket) {
     if (ctx->wait_hook) ctx->wait_hook(ctx->wait_user, ctx);
     else if (spin && std::chrono::steady_clock::now() < spin_until) __builtin_ia32_pause();
     else nanosleep(&ts, nullptr);
-    if (++polls % 4096 == 0 && !marks_use_events()) {
+    if (++polls % 4096 == 0) {
       const hipError_t q = hipStreamQuery(ctx->stream);
       if (q != hipSuccess && q != hipErrorNotReady) { err = q; break; }
     }
@@ -387,8 +366,6 @@ int sdvl_ctx_destroy(sdvl_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   sdvl_timer_collect(ctx);
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
-  for (hipEvent_t e : ctx->mark_events)
-    if (e) (void)hipEventDestroy(e);
   if (ctx->h_flag) (void)hipHostFree(const_cast<uint32_t *>(ctx->h_flag));
   if (ctx->d_nits) (void)hipFree(ctx->d_nits);
   if (ctx->d_registry) (void)hipFree(ctx->d_registry);
@@ -812,14 +789,9 @@ int sdvl_feed_create(int device, int n_slots, sdvl_feed **out) {
   f->device = device;
   // A stream of another priority class gets a hardware queue of its own: the markers that follow every transfer (hipEventRecord
   // behind an SDMA copy is a barrier packet that waits for the copy's signal) would otherwise sit in a queue shared with compute
-  // streams and stall them for the duration of every transfer.  SDVL_FEED_NORMAL_PRIORITY=1: a stream like any other (A/B).
-  bool ok;
-  if (getenv("SDVL_FEED_NORMAL_PRIORITY")) {
-    ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
-  } else {
-    int lo = 0, hi = 0;
-    ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi) == hipSuccess;
-  }
+  // streams and stall them for the duration of every transfer.
+  int lo = 0, hi = 0;
+  bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, hi) == hipSuccess;
   f->ready.assign(n_slots, nullptr);
   f->released.assign(n_slots, nullptr);
   for (int i = 0; i < n_slots && ok; i++)

@@ -1799,7 +1799,7 @@ int sdvl_detect_corners(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, const s
   SDVL_LAUNCH(ctx, "select_cells", select_cells_kernel, dim3(static_cast<unsigned>((n + 7) / 8 * 8 * n_slices)), dim3(64), ds, sl, n);
   // the counts follow the kernels to the host without anyone waiting for them (see sdvl_frames_corner_counts): the pack kernel
   // writes them into device memory and, when results go direct, into the pinned host array as well
-  const bool direct = sdvl_direct_results() && sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK;
+  const bool direct = sdvl_ensure(ctx, &ctx->h_counts, &ctx->h_counts_bytes, sizeof(int32_t) * n, true) == SDVL_OK;
   if (pack_lds > (48u << 10)) {
     // beyond the default dynamic-LDS limit.  The attribute belongs to the kernel object of a DEVICE, not to a context: it is raised
     // once per device to the most any configuration can ask for (the CU's 160 KB less the kernel's static LDS), whichever thread

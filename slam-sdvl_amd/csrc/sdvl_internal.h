@@ -113,12 +113,10 @@ struct sdvl_ctx {
   long long counters[4] = {0, 0, 0, 0};
   std::vector<void *> slabs;  // bulk frame storage, released with the context
   // Waiting for a point of the stream: a 32-bit sequence number written by the stream itself (hipStreamWriteValue32) into
-  // pinned host memory, polled by the waiting thread with plain loads (SDVL_WAIT_EVENTS=1: HIP events + hipEventQuery)
+  // pinned host memory, polled by the waiting thread with plain loads
   volatile uint32_t *h_flag = nullptr;
   uint32_t flag_seq = 0;
   int wait_spin_us = 0;  // sdvl_ctx_set_wait_spin: poll without sleeping for this long before the sleeping polls (a lone camera's 0.2-ms waits)
-  hipEvent_t mark_events[4] = {nullptr, nullptr, nullptr, nullptr};  // event mode: one per kind of mark
-  uint32_t mark_event_ticket[4] = {0, 0, 0, 0};
   // cooperative waits: when set, sdvl_stream_wait polls the event and calls the hook while the stream is still busy, so a
   // host thread that drives several contexts can run another one's host stage instead of sleeping
   uint32_t align_ticket = 0;  // marks the result copy of sdvl_image_align_begin
@@ -222,14 +220,9 @@ int sdvl_frame_fix_header(sdvl_ctx *ctx, sdvl_frame *f);
 // own AQL packet, so the measured span is the dispatch itself (what rocprofv3 --kernel-trace reports), not the queueing
 // behind other streams that share a hardware queue.
 bool sdvl_timer_events(sdvl_ctx *ctx, const char *name, hipEvent_t *a, hipEvent_t *b);
-// Small results go from the kernels straight into the context's pinned host buffers (host-coherent memory is mapped into
-// the device's address space; the stores are posted PCIe writes, visible to the host once the kernel has completed, i.e.
-// before the sequence number the stream writes behind it) instead of through a device buffer and a D2H copy packet.
-// SDVL_RESULT_COPIES=1 restores the copies (A/B measurements).
-inline bool sdvl_direct_results() {
-  static const bool off = getenv("SDVL_RESULT_COPIES") != nullptr;
-  return !off;
-}
+// (Small results go from the kernels straight into the context's pinned host buffers: host-coherent memory is mapped into the
+// device's address space; the stores are posted PCIe writes, visible to the host once the kernel has completed, i.e. before the
+// sequence number the stream writes behind it — no device buffer + D2H copy packet.)
 
 #define SDVL_LAUNCH(ctx, name, kernel, grid, block, ...)                                                   \
   do {                                                                                                     \

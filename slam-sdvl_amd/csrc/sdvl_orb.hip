@@ -647,8 +647,7 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   }
   memcpy(static_cast<uint8_t *>(hs) + jb, locked_cells, mb);
   SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, jb + mb));
-  static const bool scan_only = getenv("SDVL_FILTER_SCAN") != nullptr;  // A/B: the cells x corners scan for every grid
-  if (n_cells <= kBinCells && !scan_only)
+  if (n_cells <= kBinCells)
     SDVL_LAUNCH(ctx, "filter_select", filter_select_binned_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells,
                 margin, min_feature_score, max_out);
   else

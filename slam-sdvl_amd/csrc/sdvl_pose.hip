@@ -509,9 +509,8 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
               static_cast<HypResult *>(d_hyp));
   // a frame of the metric configuration has <= 200 observations: one wave (three waves with 59 KB of LDS wait longer for a CU among the
   // other streams' kernels than they save: 2.4 -> 3.9 ms of dispatch time per step); configuration C's ~850: wave 0 + two helpers
-  // Round 5: a small batch (a lone camera) takes the helper waves too — nobody else wants the CU (SDVL_POSE_SMALL_HELPERS=0: off)
-  static const bool small_helpers = !(getenv("SDVL_POSE_SMALL_HELPERS") && atoi(getenv("SDVL_POSE_SMALL_HELPERS")) == 0);
-  if (max_obs > 256 || (batch_size <= 32 && small_helpers))
+  // Round 5: a small batch (a lone camera) takes the helper waves too — nobody else wants the CU
+  if (max_obs > 256 || batch_size <= 32)
     SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel<3>, dim3(n_jobs), dim3(192), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
                 d_lists);
   else

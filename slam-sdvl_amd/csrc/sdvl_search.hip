@@ -1149,15 +1149,14 @@ static int search_enqueue(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const sd
     SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<false, 1>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8 * kWavesPerBlock)), dim3(64),
                 static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
                 static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
-                sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
+                static_cast<sdvl_search_res *>(ctx->h_out));
   } else {
     SDVL_LAUNCH(ctx, "search_points", (search_points_kernel<true, kWavesPerBlock>), dim3(static_cast<unsigned>((n_blocks + 7) / 8 * 8)), dim3(64 * kWavesPerBlock),
                 static_cast<const SearchReqDev *>(dsx), d_table, reinterpret_cast<const SearchBlock *>(static_cast<uint8_t *>(dsx) + in_bytes),
                 static_cast<const SearchPrep *>(d_prep), c, *p, n_blocks, static_cast<sdvl_search_res *>(ctx->d_out),
-                sdvl_direct_results() ? static_cast<sdvl_search_res *>(ctx->h_out) : nullptr);
+                static_cast<sdvl_search_res *>(ctx->h_out));
   }
   SDVL_HIP_CHECK(ctx, hipGetLastError());
-  if (!sdvl_direct_results()) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   return SDVL_OK;
 }
 
@@ -1377,9 +1376,8 @@ int sdvl_search_run_filter(sdvl_ctx *ctx, int n, const sdvl_camera *cam, const s
   sdvl_depth_out *h_fout = reinterpret_cast<sdvl_depth_out *>(static_cast<uint8_t *>(ctx->h_out) + h_off);
   SDVL_LAUNCH(ctx, "depth_filter", depth_filter_kernel, dim3((n + 127) / 128), dim3(128), d_reqs, d_table,
               static_cast<const sdvl_search_res *>(ctx->d_out), static_cast<const sdvl_depth_state *>(dsx), n, c, *fp, rows, n_rows, d_fout,
-              sdvl_direct_results() ? h_fout : nullptr);
+              h_fout);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
-  if (!sdvl_direct_results()) SDVL_HIP_CHECK(ctx, hipMemcpyAsync(h_fout, d_fout, sizeof(sdvl_depth_out) * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
   SDVL_HIP_CHECK(ctx, sdvl_stream_wait(ctx));
   memcpy(out, ctx->h_out, sizeof(sdvl_search_res) * static_cast<size_t>(n));
   memcpy(fout, h_fout, sizeof(sdvl_depth_out) * static_cast<size_t>(n));

@@ -4,7 +4,6 @@
 // SelectPoints' bookkeeping (Promote / Unpromote / MaxFailed), RemoveOutliers (:245-256) and the new frame's feature list —
 // runs in three small kernels around the existing ones:
 //
-//   track_align_prep   features of last_frame -> sdvl_align_feature records (image_align.cc:147-160,219-236)
 //   [image_align]      sdvl_image_align.hip, results stay in HBM
 //   track_project      pose = T * last_pose; ProjectPoints; candidates ordered as SelectPoints visits them (cell by cell in
 //                      the caller's shuffled order, inside a cell by score, stable) -> request records, cell starts, block
@@ -94,32 +93,6 @@ __global__ __launch_bounds__(256) void track_upload_kernel(const UploadRec *__re
   uint4 *df = reinterpret_cast<uint4 *>((r.feat_buf ? feats1 : feats0) + static_cast<size_t>(r.tracker) * nf + r.feat_dst);
   const int fw = r.n_feat * static_cast<int>(sizeof(TrackFeat) / 16);
   for (int i = threadIdx.x; i < fw; i += 256) df[i] = sf[i];
-}
-
-// image_align.cc:147-160,219-236 as ImageAlign::ComputePoseBatch prepares them on the host: position, bearing, validity,
-// depth = |point - frame1 position|
-__global__ __launch_bounds__(256) void track_align_prep_kernel(const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points,
-                                                               const TrackFeat *__restrict__ feats0, const TrackFeat *__restrict__ feats1, int np,
-                                                               int nf, int stride, sdvl_align_feature *__restrict__ out) {
-  const TrackJobDev &jb = jobs[blockIdx.x];
-  const TrackFeat *F = (jb.feat_buf ? feats1 : feats0) + static_cast<size_t>(jb.tracker) * nf;
-  const TrackPoint *P = points + static_cast<size_t>(jb.tracker) * np;
-  const V3 first_pos = se3_inverse(se3_from7(jb.last_pose)).t;  // Frame::GetWorldPosition()
-  for (int f = threadIdx.x; f < jb.n_feat; f += 256) {
-    const TrackFeat ft = F[f];
-    sdvl_align_feature a;
-    a.px = ft.px[0]; a.py = ft.px[1];
-    a.fx = ft.bearing[0]; a.fy = ft.bearing[1]; a.fz = ft.bearing[2];
-    const int pt = ft.point < 0 ? -1 : (ft.point & kPointMask);
-    a.valid = (pt >= 0 && !(P[pt].status & kDeleted)) ? 1 : 0;
-    a.depth = 0.0;
-    if (a.valid) {
-      const double dx = P[pt].P[0] - first_pos.x, dy = P[pt].P[1] - first_pos.y, dz = P[pt].P[2] - first_pos.z;
-      a.depth = sqrt(dx * dx + dy * dy + dz * dz);
-    }
-    a.pad_ = 0;
-    out[static_cast<size_t>(blockIdx.x) * stride + f] = a;
-  }
 }
 
 constexpr int kProjThreads = 512;
@@ -448,7 +421,6 @@ struct sdvl_track_set {
   TrackJobDev *d_jobs;
   uint16_t *d_cell_rank;
   int32_t *d_rand;
-  sdvl_align_feature *d_afeat;
   sdvl_align_result *d_ares;
   SearchReqDev *d_reqs;
   SearchPrep *d_prep;
@@ -478,9 +450,6 @@ struct sdvl_track_set {
   // SDVL_STEP_GRAPH=1 (A/B): the search -> pose -> commit chain of a step as a HIP graph.  The chain is captured
   // every step (its scalars and launch geometry follow the step's feature counts), the instantiated graph is UPDATED in place with
   // the new capture (same topology) and launched as one submission.
-  hipGraphExec_t graph_exec = nullptr;
-  double chain_submit_s = 0.0;  // host time inside the chain's submission (either form), for the A/B
-  long chain_submits = 0;
   sdvl_camera cam;
   sdvl_track_params prm;
 };
@@ -524,7 +493,6 @@ int sdvl_track_create(sdvl_ctx *ctx, int n, int max_points, int max_features, in
     s->d_jobs = carve<TrackJobDev>(p, N);
     s->d_cell_rank = carve<uint16_t>(p, N * s->cells);
     s->d_rand = carve<int32_t>(p, N * s->max_its);
-    s->d_afeat = carve<sdvl_align_feature>(p, NF);
     s->d_ares = carve<sdvl_align_result>(p, N);
     s->d_reqs = carve<SearchReqDev>(p, NF);
     s->d_prep = carve<SearchPrep>(p, NF);
@@ -583,10 +551,6 @@ int sdvl_track_destroy(sdvl_ctx *ctx, sdvl_track_set *s) {
   if (s->d_feats[1]) (void)hipFree(s->d_feats[1]);
   if (s->d_scratch) (void)hipFree(s->d_scratch);
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
-  if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-  if (getenv("SDVL_STEP_GRAPH_STATS") && s->chain_submits > 0)
-    fprintf(stderr, "sdvl_track: chain submission (%s): %.1f us per group-step over %ld steps\n", getenv("SDVL_STEP_GRAPH") ? "HIP graph" : "eager launches",
-            s->chain_submit_s / s->chain_submits * 1e6, s->chain_submits);
   delete s;
   return SDVL_OK;
 }
@@ -733,7 +697,6 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
   if (rc) return rc;
   uint8_t *h8 = static_cast<uint8_t *>(hs), *d8 = static_cast<uint8_t *>(dsx);
   TrackJobDev *hj = reinterpret_cast<TrackJobDev *>(h8);
-  std::vector<sdvl_align_job> aj(n_jobs);
   for (int j = 0; j < n_jobs; j++) {
     const sdvl_track_job &a = jobs[j];
     TrackJobDev &d = hj[j];
@@ -753,30 +716,15 @@ int sdvl_track_align(sdvl_ctx *ctx, sdvl_track_set *s, int n_jobs, const sdvl_tr
     for (int l = 0; l < SDVL_MAX_LEVELS; l++) d.last_level[l] = l < a.last->v.levels ? a.last->v.level[l] : nullptr;
     memcpy(d.T0, a.T, sizeof(double) * 7);
     d.pad2_ = 0.0;
-    aj[j].ref = a.last;
-    aj[j].cur = a.cur;
-    aj[j].feat_begin = j * s->stride;
-    aj[j].feat_end = j * s->stride + d.n_feat;
-    memcpy(aj[j].T, a.T, sizeof(double) * 7);
   }
   memcpy(h8 + jb, cell_rank, sizeof(uint16_t) * static_cast<size_t>(n_jobs) * s->cells);
   memcpy(h8 + jb + cb, rand_raw, rb);
   SDVL_HIP_CHECK(ctx, sdvl_push(ctx, s->d_jobs, h8, jb + cb + rb));
   (void)d8;
-  // Round 4: the alignment reads the tables itself (image_align_track_kernel): one launch instead of track_align_prep + a push of
-  // IaJob records + image_align.  SDVL_TRACK_ALIGN_RECORDS=1: the round-3 chain through sdvl_align_feature records (A/B).
-  static const bool via_records = getenv("SDVL_TRACK_ALIGN_RECORDS") != nullptr || (getenv("SDVL_IA_WAVE") && atoi(getenv("SDVL_IA_WAVE")) == 0);
-  if (via_records) {
-    SDVL_LAUNCH(ctx, "track_align_prep", track_align_prep_kernel, dim3(n_jobs), dim3(256), static_cast<const TrackJobDev *>(s->d_jobs),
-                static_cast<const TrackPoint *>(s->d_points), static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]),
-                s->np, s->nf, s->stride, s->d_afeat);
-    SDVL_HIP_CHECK(ctx, hipGetLastError());
-    rc = sdvl_image_align_enqueue(ctx, n_jobs, aj.data(), n_jobs * s->stride, nullptr, s->d_afeat, cam, &p->align, s->d_ares);
-  } else {
-    rc = sdvl_image_align_track_enqueue(ctx, n_jobs, static_cast<const TrackJobDev *>(s->d_jobs), static_cast<const TrackPoint *>(s->d_points),
-                                        static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, max_nf,
-                                        jobs[0].cur->v.levels, cam, &p->align, s->d_ares, s->n);
-  }
+  // the alignment reads the tables itself (image_align_track_*): no feature records, no launch in between
+  rc = sdvl_image_align_track_enqueue(ctx, n_jobs, static_cast<const TrackJobDev *>(s->d_jobs), static_cast<const TrackPoint *>(s->d_points),
+                                      static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, max_nf,
+                                      jobs[0].cur->v.levels, cam, &p->align, s->d_ares, s->n);
   if (rc) return rc;
   s->phase = 1;
   return SDVL_OK;
@@ -811,12 +759,9 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
       SDVL_HIP_CHECK(ctx, hipGetLastError());
     }
   }
-  // Round 4: track_project's lanes run SearchPoint's scalar phase for the requests they assemble: no search_prepare launch in a tracked
-  // step.  SDVL_TRACK_SEPARATE_PREPARE=1: the round-3 chain (A/B).
-  static const bool fused_prepare = getenv("SDVL_TRACK_SEPARATE_PREPARE") == nullptr;
-  static const bool use_graph = getenv("SDVL_STEP_GRAPH") != nullptr;
-  const auto t_submit = std::chrono::steady_clock::now();
-  const bool timing_was = ctx->timing;
+  // track_project's lanes run SearchPoint's scalar phase for the requests they assemble: no search_prepare launch in a tracked step.
+  // (The chain as a HIP graph was measured in rounds 4 and 5 — 2.69 k against 2.96 k frames/s for a lone camera, nothing for a farm:
+  //  launches are not the cost — and removed in round 6.)
   // (one-time set-up calls stay outside a capture)
   if (static_cast<size_t>(stride) * (8 + 16 + 2) + 64 > 60 * 1024) {  // track_project beyond the default dynamic LDS limit: raise it once per device
     static std::atomic<unsigned long long> attr_devices{0};
@@ -828,30 +773,6 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
       attr_devices.fetch_or(bit, std::memory_order_release);
     }
   }
-  if (use_graph) {
-    ctx->timing = false;  // start / stop events of a dispatch cannot be recorded into a capture
-    SDVL_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  }
-  const auto end_capture = [&]() -> hipError_t {  // leaves the stream out of capture mode whatever happened inside
-    if (!use_graph) return hipSuccess;
-    ctx->timing = timing_was;
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-    if (e != hipSuccess) return e;
-    if (s->graph_exec) {
-      hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
-      hipGraphNode_t bad = nullptr;
-      if (hipGraphExecUpdate(s->graph_exec, g, &bad, &res) != hipSuccess || res != hipGraphExecUpdateSuccess) {
-        (void)hipGetLastError();
-        (void)hipGraphExecDestroy(s->graph_exec);
-        s->graph_exec = nullptr;
-      }
-    }
-    if (!s->graph_exec) e = hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) return e;
-    return hipGraphLaunch(s->graph_exec, ctx->stream);
-  };
   {
     const size_t lds = static_cast<size_t>(stride) * (8 + 16 + 2) + 64;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -863,24 +784,21 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
                           static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, stride, s->mm, s->max_its,
                           static_cast<const sdvl_align_result *>(s->d_ares), static_cast<const uint16_t *>(s->d_cell_rank), s->cells, c,
                           s->prm.cell_size, s->prm.patch_size, registry, s->d_reqs, s->d_reqpt, s->d_cfirst, s->d_cfeat, s->d_blocks, s->d_chain,
-                          s->prm.search, fused_prepare ? s->d_prep : nullptr);
-    if (hipError_t le = hipGetLastError(); le != hipSuccess) {  // never leave the stream in capture mode
-      (void)end_capture();
-      SDVL_HIP_CHECK(ctx, le);
-    }
+                          s->prm.search, s->d_prep);
+    SDVL_HIP_CHECK(ctx, hipGetLastError());
   }
   int rc = sdvl_search_launch_device(ctx, n_jobs * stride, s->d_reqs, registry, s->d_blocks, n_jobs * (stride / kWavesPerBlock), &s->cam,
-                                     &s->prm.search, s->d_prep, s->d_res, nullptr, /*prepared*/ fused_prepare);
-  if (rc) { (void)end_capture(); return rc; }
+                                     &s->prm.search, s->d_prep, s->d_res, nullptr, /*prepared*/ true);
+  if (rc) return rc;
   // match ranks are not needed separately: track_commit derives them again from the same flags
   rc = sdvl_select_matches_launch(ctx, n_jobs, s->d_chain, nullptr, s->d_cfirst, s->d_res, s->d_reqpt, &s->cam, s->d_pjobs, s->d_obs, s->d_nobs,
                                   nullptr);
-  if (rc) { (void)end_capture(); return rc; }
+  if (rc) return rc;
   sdvl_pose_params pp = s->prm.pose;
   pp.pad_ = 1;  // raw rand() values: the kernel reduces them modulo the match count it finds in the job
   rc = sdvl_pose_enqueue_device(ctx, n_jobs, s->d_pjobs, s->d_obs, s->d_rand, static_cast<const int32_t *>(ctx->d_nits), &pp, s->d_hyp, s->d_pres,
                                 s->d_lists, s->mm, s->n);
-  if (rc) { (void)end_capture(); return rc; }
+  if (rc) return rc;
   {
     // s_before | s_found | (8-byte aligned) depths of the new frame's points, at most mm of them
     const size_t lds = (static_cast<size_t>(stride + 1) * 2 + stride + 64 + 7) / 8 * 8 + static_cast<size_t>(s->mm) * 8;
@@ -893,14 +811,8 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
                           static_cast<const sdvl_search_res *>(s->d_res), static_cast<const sdvl_pose_result *>(s->d_pres),
                           static_cast<const int32_t *>(s->d_lists), static_cast<const sdvl_align_result *>(s->d_ares), c, s->prm.max_failed, registry,
                           s->h_results, s->h_feats, s->h_stats);
-    if (hipError_t le = hipGetLastError(); le != hipSuccess) {
-      (void)end_capture();
-      SDVL_HIP_CHECK(ctx, le);
-    }
+    SDVL_HIP_CHECK(ctx, hipGetLastError());
   }
-  SDVL_HIP_CHECK(ctx, end_capture());
-  s->chain_submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_submit).count();
-  s->chain_submits++;
   SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_CHAIN, &s->ticket));
   s->phase = 2;
   return SDVL_OK;

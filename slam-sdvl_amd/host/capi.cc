@@ -313,8 +313,6 @@ struct Farm {
   // transfers ran side by side and shared the link, so the one a group was waiting for was slowed by the ones nobody needed yet
   // (38-47 GB/s of the 57 the link gives; a ring of three was slower still).  The feeder issues the transfers one after the
   // other, the group that is furthest behind first; the workers only exchange events with it.
-  // SDVL_RING_PRIVATE_STREAMS=1: round 2's form (the worker prefetches on its context's copy stream, two slots).
-  bool use_feeder = true;
   int kRingSlots = 3;
   sdvl_feed *feed = nullptr;
   double feed_call_s = 0.0, feed_wait_s = 0.0;  // the feeder's time inside sdvl_feed_images / waiting for a free slot, last run
@@ -356,17 +354,10 @@ struct Farm {
   }
 
   int StepGroup(int g) {
-    // diagnostic: extra host latency per group-step.  If throughput falls by as much, the groups' chains are latency-bound;
-    // if it does not, the GPU is the limiter and the host's share of a step is hidden behind the other groups' kernels.
-    static const int extra_us = getenv("SDVL_FARM_EXTRA_HOST_US") ? atoi(getenv("SDVL_FARM_EXTRA_HOST_US")) : 0;
-    if (extra_us > 0) {
-      timespec ts{extra_us / 1000000, (extra_us % 1000000) * 1000L};
-      nanosleep(&ts, nullptr);
-    }
     const int total = G * Bg;
     const int s = done[g];  // only the owner of a busy group reads or writes its counter
     const size_t off = static_cast<size_t>(s) * total + static_cast<size_t>(g) * Bg;
-    if (host_input && input_ring && use_feeder && feed) {
+    if (host_input && input_ring && feed) {
       sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(devices[g]));
       {
         std::unique_lock<std::mutex> lk(m);
@@ -384,9 +375,8 @@ struct Farm {
       }
       // The step is submitted only once its images are in HBM: a stream that waits for a transfer ON THE DEVICE holds a barrier
       // packet in its hardware queue, and the streams that share the queue (4 queues for 16 groups) stall behind it although their
-      // own images arrived long ago.  SDVL_RING_DEVICE_WAIT=1: round 3's first form (hipStreamWaitEvent only).
-      static const bool device_wait = getenv("SDVL_RING_DEVICE_WAIT") != nullptr;
-      if (late && !device_wait) {
+      // own images arrived long ago.
+      if (late) {
         const auto tw = std::chrono::steady_clock::now();
         for (;;) {
           const int a = sdvl_feed_slot_arrived(feed, slot);
@@ -428,41 +418,6 @@ struct Farm {
       }
       return rc;
     }
-    if (host_input && input_ring && stride == w) {
-      // a ring of kRingSlots steps: while step s computes, the images of the following kRingSlots - 1 steps are under way
-      sdvl_ctx *ctx = static_cast<sdvl_ctx *>(sdvlh_device_ctx(devices[g]));
-      const size_t fb = static_cast<size_t>(w) * h;
-      if (!ring[g] && sdvl_device_malloc(ctx, static_cast<int64_t>(kRingSlots * fb * Bg), &ring[g]) != SDVL_OK) {
-        g_err = std::string("input ring: ") + sdvl_last_error(ctx);
-        return -1;
-      }
-      std::vector<void *> dst(Bg);
-      auto slot_ptrs = [&](int step) {
-        uint8_t *base = static_cast<uint8_t *>(ring[g]) + static_cast<size_t>(step % kRingSlots) * Bg * fb;
-        for (int i = 0; i < Bg; i++) dst[i] = base + static_cast<size_t>(i) * fb;
-      };
-      auto prefetch = [&](int step) {  // -> ticket, or a negative status
-        slot_ptrs(step);
-        const size_t o = static_cast<size_t>(step) * total + static_cast<size_t>(g) * Bg;
-        const int t = sdvl_ctx_prefetch_images(ctx, Bg, reinterpret_cast<const uint8_t *const *>(dev_frames + o), stride, w, h, dst.data());
-        if (t >= 0) ring_ticket[static_cast<size_t>(g) * kRingSlots + step % kRingSlots] = t;
-        return t;
-      };
-      int rc = SDVL_OK;
-      if (s == 0)  // nothing is under way yet
-        for (int a = 0; a < kRingSlots - 1 && a < n_steps && rc >= 0; a++) rc = prefetch(a);
-      // the slot that step s - 1 read is free (that step is complete): the images of step s + kRingSlots - 1 go there
-      if (rc >= 0 && s + kRingSlots - 1 < n_steps) rc = prefetch(s + kRingSlots - 1);
-      if (rc >= 0) rc = sdvl_ctx_prefetch_fence(ctx, ring_ticket[static_cast<size_t>(g) * kRingSlots + s % kRingSlots]);  // this step's kernels start behind its images
-      if (rc < 0) {
-        g_err = std::string("input ring: ") + sdvl_last_error(ctx);
-        return -1;
-      }
-      slot_ptrs(s);
-      static const bool copy_all = getenv("SDVL_RING_COPY_ALL") != nullptr;  // round 2's behaviour: every frame copies its image out of the ring (A/B)
-      return copy_all ? sdvlh_batch_step_device_copy(batches[g], dst.data(), stride, out + off)
-                      : sdvlh_batch_step_device_transient(batches[g], dst.data(), stride, out + off);
-    }
     if (host_input) return sdvlh_batch_step_host(batches[g], reinterpret_cast<const uint8_t *const *>(dev_frames + off), stride, out + off);
     // frames resident in HBM: the group knows its next images — their pyramids and detection are queued a step ahead (SDVL_NO_LOOKAHEAD=1: A/B)
     static const bool lookahead = getenv("SDVL_NO_LOOKAHEAD") == nullptr;
@@ -491,7 +446,7 @@ struct Farm {
     const int total = G * Bg;
     std::vector<void *> dst(Bg);
     std::deque<int> in_flight;  // slots whose transfer has been queued and not yet seen complete, oldest first
-    static const int feed_in_flight = getenv("SDVL_FEED_IN_FLIGHT") ? std::max(1, atoi(getenv("SDVL_FEED_IN_FLIGHT"))) : 2;
+    constexpr int feed_in_flight = 2;  // at most two transfers queued on the device (one: the link idles between them; more: no gain)
     for (;;) {
       int g = -1, s = 0;
       {
@@ -564,7 +519,7 @@ struct Farm {
           std::lock_guard<std::mutex> lk(m);
           if (failed) return;
         }
-        const bool marks_here = !step_marks.empty() && !(host_input && input_ring && use_feeder && feed);
+        const bool marks_here = !step_marks.empty() && !(host_input && input_ring && feed);
         const double tb = marks_here ? Since() : 0.0;
         const int rc = StepGroup(worker);
         if (marks_here) step_marks[worker].push_back(StepMark{worker, s, tb, tb, Since(), 0, {0}, 0});
@@ -758,7 +713,6 @@ void *sdvlh_farm_create(int gpu, int G, int Bg, int w, int h, const double *cam4
   Farm *f = new Farm();
   f->gpu = gpu; f->G = G; f->Bg = Bg; f->w = w; f->h = h;
   f->ring.assign(G, nullptr);
-  if (getenv("SDVL_RING_PRIVATE_STREAMS")) { f->use_feeder = false; f->kRingSlots = 2; }
   f->ring_ticket.assign(static_cast<size_t>(G) * f->kRingSlots, -1);
   for (int g = 0; g < G; g++) {
     void *d = sdvlh_device_create(gpu);
@@ -949,7 +903,7 @@ int sdvlh_farm_run(void *fp, int n_steps, const void *const *dev_frames, int str
     f->run_t0 = std::chrono::steady_clock::now();
   }
   std::thread feeder;
-  if (f->host_input && f->input_ring && f->use_feeder) {
+  if (f->host_input && f->input_ring) {
     bool rings = true;
     for (int g = 0; g < f->G; g++) rings = rings && f->ring[g] != nullptr;
     if (!rings) { g_err = "input ring: the rings were not allocated (sdvlh_farm_set_host_input)"; return -1; }

@@ -30,14 +30,6 @@ static thread_local Device *g_current_device = nullptr;
 
 // Descriptors are lazy, as in the reference (matcher.cc:266-269, frame.cc:148-161): a new frame gets corners only; the
 // search kernel computes the descriptors of the corners it compares and FilterCorners asks for a keyframe's full set.
-// SDVL_EAGER_ORB=1 restores "every corner of every frame right after detection" (same results, ~4x the ORB work).
-static bool EagerOrb() {
-  static const bool eager = [] {
-    const char *e = std::getenv("SDVL_EAGER_ORB");
-    return e && e[0] == '1';
-  }();
-  return eager;
-}
 static thread_local StageTimes *g_stage_times = nullptr;
 StageTimes *&StageTimes::Active() { return g_stage_times; }
 
@@ -61,8 +53,7 @@ void ChunkPool::Map(size_t bytes) {
   bytes = (bytes + kChunk - 1) / kChunk * kChunk;
   // Round 4: the region starts on a 2-MB boundary and asks for transparent huge pages (the boxes run THP in `madvise` mode): the
   // arenas of the keyframes are memory that is written once and kept, i.e. first-touch faults — one per 2 MB instead of one per 4 KB.
-  // SDVL_NO_HUGEPAGE=1: plain pages (A/B).
-  static const bool huge = std::getenv("SDVL_NO_HUGEPAGE") == nullptr;
+  constexpr bool huge = true;
   constexpr size_t kHuge = 2u << 20;
   const size_t span = huge ? bytes + kHuge : bytes;
   void *raw = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
@@ -473,7 +464,6 @@ void BuildFrames(const vector<Frame *> &frames, const vector<sdvl_frame *> &devs
   clk.reset(new StageClock(ST_FAST));
   dev->Check(sdvl_detect_corners(dev->ctx(), n, devs.data(), &dp, nfeatures), "sdvl_detect_corners");
   clk.reset(new StageClock(ST_CORNERS_ORB));
-  if (Config::UseORB() && EagerOrb()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
 }
 }  // namespace
 
@@ -562,7 +552,6 @@ void Frame::DetectBatch(const vector<shared_ptr<Frame>> &frames, int nfeatures) 
     dev->Check(sdvl_detect_corners(dev->ctx(), n, devs.data(), &dp, nfeatures), "sdvl_detect_corners");
   }
   StageClock clk(ST_CORNERS_ORB);
-  if (Config::UseORB() && EagerOrb()) dev->Check(sdvl_orb_describe(dev->ctx(), n, devs.data(), SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
 }
 
 // frame.cc:122-131
@@ -575,7 +564,6 @@ void Frame::CreateCorners(int, int nfeatures) {
   descriptors_on_host_ = false;
   dev->Check(sdvl_detect_corners(dev->ctx(), 1, &dev_, &dp, nfeatures), "sdvl_detect_corners");
   corners_on_host_ = false;
-  if (Config::UseORB() && EagerOrb()) dev->Check(sdvl_orb_describe(dev->ctx(), 1, &dev_, SDVL_MAX_CORNERS, nullptr), "sdvl_orb_describe");
 }
 
 vector<Vector3i> &Frame::GetCorners() {
@@ -867,8 +855,7 @@ sdvl_search_params SearchParams() {
   sp.max_fast_levels = Config::MaxFastLevels();
   sp.margin = DetectMargin();
   sp.use_orb = Config::UseORB() ? 1 : 0;
-  static const bool tree = std::getenv("SDVL_LK_TREE_SUMS") != nullptr;  // A/B: tolerance-class LK sums (include/sdvl_hip.h)
-  sp.lk_tree_sums = tree ? 1 : 0;
+  sp.lk_tree_sums = 0;  // sequential-order LK sums: offsets bit-identical to the reference's loop (1: tolerance-class tree sums, include/sdvl_hip.h)
   sp.pad_ = 0;
   return sp;
 }

@@ -546,9 +546,7 @@ SDVLBatch::SDVLBatch(Device *dev, const vector<SDVL *> &trackers, int host_threa
   // Round 5: a lone camera (a batch of up to four) waits for chains of 0.2 ms: its context polls without sleeping for the first 500 us of a
   // wait (a sleeping poll wakes ~15 us late: 3.51 -> 3.83 k frames/s).  Larger batches keep the sleeping polls: 16 cameras in one batch gain
   // nothing, configuration C's groups of 16 lose (46.8 -> 43.3 k: their host threads need the CPU), a farm waits ~9 ms with the CPUs short.
-  // SDVL_WAIT_SPIN_US=n overrides for every batch size (0: never spin).
-  static const int spin_env = std::getenv("SDVL_WAIT_SPIN_US") ? std::atoi(std::getenv("SDVL_WAIT_SPIN_US")) : -1;
-  const int spin_us = spin_env >= 0 ? spin_env : (trk_.size() <= 4 ? 500 : 0);
+  const int spin_us = trk_.size() <= 4 ? 500 : 0;
   if (dev_ && dev_->ctx()) (void)sdvl_ctx_set_wait_spin(dev_->ctx(), spin_us);
 }
 SDVLBatch::~SDVLBatch() {
@@ -1046,8 +1044,7 @@ int SDVLBatch::TrackOnHost(SDVL &t, FrameStats *st) {
 // selection, pose, table update) and ONE wait.  The host keeps what only it can do: rand() (cell shuffle, RANSAC draws), the
 // motion model, tracking quality, the keyframe decision and everything a keyframe sets off.
 bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats) {
-  static const bool chain_enabled = std::getenv("SDVL_NO_CHAIN") == nullptr;
-  if (!persistent_ || !TrackTables() || !chain_enabled || !DevicePose() || Config::MaxRansacPoints() > 8) return false;
+  if (!persistent_ || !TrackTables() || !DevicePose() || Config::MaxRansacPoints() > 8) return false;
   const int B = static_cast<int>(trk_.size());
   for (int i = 0; i < B; i++) {
     SDVL &t = *trk_[i];
@@ -1206,9 +1203,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
     // detection (FAST, selection: needs the pyramid only) runs on the context's side stream BESIDE the alignment instead of behind it
     // (sdvl_ctx_fork_*); a farm's batches keep one stream per group — there the other groups are the company, and a whole-context wait
     // inside a fork would block the worker's other groups (B <= 4: the batches that also spin on their waits).
-    // SDVL_DETECT_FORK=0 / 1 forces it off / on.
-    static const int fork_env = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
-    const bool fork_detect = !detected_ahead && !detected_now && (fork_env >= 0 ? fork_env != 0 : B <= 4);
+    const bool fork_detect = !detected_ahead && !detected_now && B <= 4;
     if (fork_detect) dev_->Check(sdvl_ctx_fork_mark(dev_->ctx()), "sdvl_ctx_fork_mark");  // the pyramids are queued: the side chain starts here
     dev_->Check(sdvl_track_align(dev_->ctx(), track_, R, tr_jobs_.data(), tr_rank_.data(), tr_rand_.data(), &cam, &prm), "sdvl_track_align");
     if (fork_detect) {
@@ -1308,7 +1303,6 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         filter_begun = true;
       }
     }
-    static const bool flat_keyframes = std::getenv("SDVL_KEYFRAME_OBJECTS") == nullptr;  // =1: round 3's path (A/B)
     vector<int> r_matches(B, 0);
     for (int k = 0; k < R; k++) r_matches[run[k]] = tr_res_[k].matches;
     ParallelFor(static_cast<int>(act.size()), [&](int a) {
@@ -1327,7 +1321,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
         const bool plane = !dynamic_cast<MapperMap *>(t.map_);
         const size_t rows = t.track_.points ? t.track_.points->size() : static_cast<size_t>(track_cap_);
         const bool room = static_cast<int>(rows) + track_cells_ <= track_cap_ && r_matches[i] + track_cells_ <= track_cap_;
-        if (flat_keyframes && plane && room && t.current_frame_->HasFlatFeatures()) {
+        if (plane && room && t.current_frame_->HasFlatFeatures()) {
           t.current_frame_->LinkPointsOnMaterialize();
           t.track_.feat_buf ^= 1;  // the matches the step left in the other buffer are last_frame's features now
           t.track_.append_pending = true;
@@ -1358,8 +1352,7 @@ bool SDVLBatch::HandleFramesTracked(const vector<Image> &imgs, FrameStats *stats
   next_imgs_.clear();  // a look-ahead belongs to ONE step, whether that step could use it (R == B tracked frames) or not (bootstrap)
   if (R == 0 && !detected_ahead && !detected_now) {  // bootstrap-only step: the new keyframes still need their corners
     // (a small batch detects on the side stream here too: the stream and its queue exist by the time a tracked frame forks)
-    static const int fork_env0 = std::getenv("SDVL_DETECT_FORK") ? std::atoi(std::getenv("SDVL_DETECT_FORK")) : -1;
-    const bool fork0 = fork_env0 >= 0 ? fork_env0 != 0 : B <= 4;
+    const bool fork0 = B <= 4;
     if (fork0) {
       dev_->Check(sdvl_ctx_fork_mark(dev_->ctx()), "sdvl_ctx_fork_mark");
       dev_->Check(sdvl_ctx_fork_begin(dev_->ctx()), "sdvl_ctx_fork_begin");
@@ -1571,8 +1564,7 @@ void SDVLBatch::HandleFramesGeneric(const vector<Image> &imgs, FrameStats *stats
       // search -> match selection -> RANSAC + pose refinement as ONE submission (sdvl_search_run_chain): the device replays
       // the second half of SelectPoints itself, so the pose kernels run while this thread does the same replay for its
       // own bookkeeping (features, point statistics) instead of starting after it
-      static const bool chain_enabled = std::getenv("SDVL_NO_CHAIN") == nullptr;
-      chain = chain_enabled && device_pose && Config::MaxRansacPoints() <= 8;
+      chain = device_pose && Config::MaxRansacPoints() <= 8;
       for (int k = 0; k < R && chain; k++)
         if (trk_[run[k]]->feature_align_.MaxMatches() > FeatureAlign::kMaxDevicePoseObs) chain = false;
       if (chain) {

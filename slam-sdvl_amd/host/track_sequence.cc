@@ -231,8 +231,7 @@ int main(int argc, char **argv) {
             ahead_valid = true;
             if (k > 0) sdvl.SetNextImage(ahead);                   // (frame 0 is the bootstrap: no tracked step to queue behind)
           }
-          // (--profile with SDVL_TS_STAGES_ONLY=1: host stage times only — dispatch events cost the host ~8 us per launch)
-          if (k == 1 && profile && !std::getenv("SDVL_TS_STAGES_ONLY")) dev.Check(sdvl_ctx_timing_enable(dev.ctx(), 1), "sdvl_ctx_timing_enable");
+          if (k == 1 && profile) dev.Check(sdvl_ctx_timing_enable(dev.ctx(), 1), "sdvl_ctx_timing_enable");
           const auto t0 = std::chrono::steady_clock::now();
           sdvl.HandleFrame(imgu);                                 // main.cc:136-138
           if (mapper) sdvl.Mapping();                             // sequential mode, main.cc:148-149
