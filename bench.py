@@ -670,7 +670,7 @@ def main():
     ORACLE_PARAMS = {k.split(".")[1]: v for k, v in wl["over"].items()}
     TEXTURE = TEXTURES[args.texture]
     global PROFILE_TAG
-    PROFILE_TAG = "%s_%s" % (args.workload.lower().replace("-", ""), args.texture)
+    PROFILE_TAG = "%s_%s" % (args.workload.lower().replace("-", ""), args.texture) + ("_" + args.distortion if args.distortion != "none" else "")
     seq_choices = [args.seqs] if args.seqs > 0 else list(wl["seqs"])
     args.seqs = seq_choices[0]
     if args.cpu_frames < 0:

@@ -10,10 +10,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra):
+def run_bench(*extra, env=None, want_stderr=False):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--seqs", "32", "--cpu-frames", "12", "--sustained-frames", "40", "--latency-frames", "12",
-                          "--lost-mix-steps", "20", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--lost-mix-steps", "20", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
+    if want_stderr:
+        lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+        return json.loads(lines[0]), out.stderr
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout
     return json.loads(lines[0])
@@ -96,6 +99,17 @@ def test_bench_line_contract_with_the_drivers_warmup():
 
 def test_bench_line_contract_mapper_and_fibers():
     check(run_bench("--mapper", "--groups", "4", "--workers", "2", "--fibers", "2", "--latency-frames", "0"), mapper=True)
+
+
+def test_bench_diagnostic_switches(tmp_path):
+    """the farm's three diagnostic switches (README): SDVL_NO_LOOKAHEAD (the resident leg does not queue the next step's pyramids ahead),
+    SDVL_FARM_TIMELINE (one line per group-step), SDVL_PROFILE (sampling profile of the worker threads on stderr)"""
+    tl = tmp_path / "timeline.txt"
+    d, err = run_bench("--sustained-frames", "0", "--latency-frames", "0", "--lost-mix-steps", "0",
+                       env={"SDVL_NO_LOOKAHEAD": "1", "SDVL_FARM_TIMELINE": str(tl), "SDVL_PROFILE": "1"}, want_stderr=True)
+    assert d["config"]["look_ahead"] is False and d["value"] > 0
+    assert tl.exists() and tl.stat().st_size > 0
+    assert "samples of 1 ms CPU" in err
 
 
 def test_bench_line_contract_s_b_on_the_camera_texture():

@@ -1026,3 +1026,21 @@ def test_host_layer_camera_undistort(orc):
     assert f(dev.h, 640, 480, cam.ctypes.data, dist.ctypes.data, img.ctypes.data, 640, out.ctypes.data) == 1
     assert np.array_equal(out, orc.undistort(img, TUM_CAM, TUM_DIST))
     dev.close()
+
+
+@pytest.mark.parametrize("dense_num", ["0", "64"])
+def test_fast_cells_with_every_cell_on_one_path(dense_num):
+    """SDVL_FAST_DENSE_NUM (of 64 probed pixels that send a cell down the dense path; default 16): 0 = every cell dense, 64 = every cell
+    through the candidate list.  Both yield the default's corners, order included — the switch is read once per process, so each value runs
+    the FAST / detection parity tests in a process of its own"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("SDVL_FAST_DENSE_NUM"):
+        pytest.skip("already inside a run with the switch set")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "(fast_cells or detect_corners) and not every_cell", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, SDVL_FAST_DENSE_NUM=dense_num))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

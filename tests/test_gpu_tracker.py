@@ -645,7 +645,11 @@ def test_cpp_example_track_sequence_matches_the_oracle(orc, synth, tmp_path):
     ref.close()
     # third run: the tracked step's search without the corner bins (SDVL_TRACK_NO_BINS=1: the views of the current frames lose the
     # bins sdvl_track_align named ahead of the detection, as for frames whose corners were set by hand) — same answers
-    for args, env in ((["--synthetic", str(n)], {}), (["--list", str(lst)], {}), (["--synthetic", str(n)], {"SDVL_TRACK_NO_BINS": "1"})):
+    # further runs, one per environment switch of the tracking step (README): the host-driven form (round 1's path), the pose stage on
+    # the host, the one-shot batch per HandleFrame call — same answers each time
+    for args, env in ((["--synthetic", str(n)], {}), (["--list", str(lst)], {}), (["--synthetic", str(n)], {"SDVL_TRACK_NO_BINS": "1"}),
+                      (["--synthetic", str(n)], {"SDVL_NO_TRACK_TABLES": "1"}), (["--synthetic", str(n)], {"SDVL_POSE_HOST": "1"}),
+                      (["--synthetic", str(n)], {"SDVL_HANDLEFRAME_ONE_SHOT": "1"})):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr
         rows = [l.split() for l in r.stdout.strip().splitlines()]
@@ -663,7 +667,8 @@ def test_cpp_single_call_api_surface():
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam-sdvl_amd", "host", "api_surface_check")
     assert os.path.exists(exe), "build() makes it (make -C slam-sdvl_amd/host)"
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    # (SDVL_GPU: the GPU a SDVL(Camera*) built on a thread without a Device opens for itself)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, SDVL_GPU="0"))
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
     assert len(lines) >= 16 and all(l.startswith("ok") for l in lines[:-1]) and lines[-1] == "0 check(s) failed"
