@@ -163,6 +163,158 @@ __global__ __launch_bounds__(kHypDraws) void pose_hypotheses_kernel(const PoseJo
   dst.supporters = 0;  // pose_supporters_kernel adds to it
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Round 6: ONE WAVE per draw, for the sets whose launches leave the chip empty (a lone camera, configuration C's groups of 16).  The lane
+// form above makes a draw a chain of ~27 k dependent vector instructions (five points one after the other, the pivoted LDLT with every
+// swap predicated, and a wave runs until its SLOWEST draw has converged); here lanes 0..npts-1 take one point each, lanes 0..27 add the
+// points' normal-equation terms IN POINT ORDER (the rounding of the sequential loop, feature_align.cc:370-400), the solve and the SE3
+// update run uniformly (scalar pivot branches), the wave leaves as soon as ITS draw has converged — and counts the draw's supporters
+// over all matches itself (feature_align.cc:190, 245-283: an integer sum), so pose_supporters_kernel is not launched behind this form.
+// Same operations on the same operands in the same order as converge_pose_small: the draws' results are bit-identical.
+struct HypWaveLds {
+  double terms[8][29];
+  double sums[28];
+  double errs[8];
+};
+
+__device__ __forceinline__ void hyp_terms(const sdvl_pose_obs &o, const M3 &R, const V3 &t, double scale, double *row) {
+  double ex, ey;
+  V3 pos;
+  reproj_error(o, R, t, &ex, &ey, &pos);
+  double J[12];
+  jacobian_3d_to_plane(pos, J);
+#pragma unroll
+  for (int c = 0; c < 12; c++) J[c] *= o.inv_cov;
+  const double weight = tukey(sqrt(ex * ex + ey * ey) / scale);
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = r; c < 6; c++) row[k++] = (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+#pragma unroll
+  for (int r = 0; r < 6; r++) row[21 + r] = (J[r] * ex + J[6 + r] * ey) * weight;
+  row[27] = (ex * ex + ey * ey) * weight;
+}
+
+__global__ __launch_bounds__(64) void pose_hypotheses_wave_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
+                                                                  const int32_t *__restrict__ rand_idx, sdvl_pose_params prm,
+                                                                  HypResult *__restrict__ hyp) {
+  __shared__ HypWaveLds L;
+  const PoseJobDev &job = jobs[blockIdx.y];
+  const int h = blockIdx.x, lane = threadIdx.x;
+  const int size = job.n_obs;
+  const sdvl_pose_obs *obs = obs_all + job.obs_begin;
+  HypResult &dst = hyp[static_cast<size_t>(blockIdx.y) * prm.max_ransac_its + h];
+  Rigid se3 = se3_from7(job.pose);
+  int ok = 0, supporters = 0;
+  if (size > 0) {
+    const int npts = min(prm.max_ransac_points, size);
+    int index = rand_idx[job.rand_begin + h];  // rand() % size, drawn on the host (feature_align.cc:180) ...
+    if (prm.pad_ & 1) index %= size;           // ... or the raw rand() value when the host could not know `size` yet
+    const bool mine = lane < npts;
+    const sdvl_pose_obs o = obs[(index + (mine ? lane : 0)) % size];
+    Rigid last = se3;
+    double chi2 = 0.0;
+    {
+      const M3 R = se3_rot(se3);
+      if (mine) {
+        double ex, ey;
+        V3 pos;
+        reproj_error(o, R, se3.t, &ex, &ey, &pos);
+        L.errs[lane] = sqrt(ex * ex + ey * ey);
+      }
+    }
+    wave_lds_sync();
+    // GetMedianVector: element floor(n/2) of the sorted order (extra/utils.cc:215-220) — the insertion sort of converge_pose_small
+    // with every index a compile-time constant (the moves predicated), uniform across the wave
+    double errs[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) errs[q] = q < npts ? L.errs[q] : 0.0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      if (i < npts) {
+        const double v = errs[i];
+        bool moving = true;
+#pragma unroll
+        for (int j = i - 1; j >= 0; j--) {
+          const bool shift = moving && errs[j] > v;
+          errs[j + 1] = shift ? errs[j] : (moving ? v : errs[j + 1]);
+          moving = shift;
+        }
+        if (moving) errs[0] = v;
+      }
+    }
+    double med = errs[0];
+#pragma unroll
+    for (int q = 1; q < 8; q++)
+      if (q == npts / 2) med = errs[q];
+    double scale = kMADNorm * med;
+    for (int i = 0; i < prm.max_optim_pose_its; i++) {
+      if (i == 5) scale = 0.85 / prm.fx;
+      const M3 R = se3_rot(se3);
+      if (mine) hyp_terms(o, R, se3.t, scale, L.terms[lane]);
+      wave_lds_sync();
+      if (lane < 28) {
+        const bool neg = lane >= 21 && lane < 27;  // b accumulates with -= in the reference, and x - t == x + (-t) exactly
+        double acc = 0.0;
+        for (int q = 0; q < npts; q++) acc += neg ? -L.terms[q][lane] : L.terms[q][lane];
+        L.sums[lane] = acc;
+      }
+      wave_lds_sync();
+      double A[36], b[6], dT[6];
+      {
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = r; c < 6; c++) {
+            A[6 * r + c] = L.sums[t];
+            A[6 * c + r] = L.sums[t];
+            t++;
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < 6; r++) b[r] = L.sums[21 + r];
+      const double new_chi2 = L.sums[27];
+      wave_lds_sync();
+      ldlt_solve6_reg<true>(A, b, dT);
+      if ((i > 0 && new_chi2 > chi2) || dT[0] != dT[0]) {
+        se3 = last;
+        break;
+      }
+      const Rigid T_new = se3_mul(se3_exp(dT), se3);
+      last = se3;
+      se3 = T_new;
+      chi2 = new_chi2;
+      if (abs_max6(dT) <= 1e-10) break;
+    }
+    ok = 1;
+    // CheckReprojectionError of this draw over every match
+    const M3 R = se3_rot(se3);
+    for (int q0 = 0; q0 < size; q0 += 64) {
+      const int q = q0 + lane;
+      bool in = false;
+      if (q < size) {
+        double ex, ey;
+        V3 pos;
+        reproj_error(obs[q], R, se3.t, &ex, &ey, &pos);
+        in = sqrt(ex * ex + ey * ey) <= prm.inlier_threshold;
+      }
+      supporters += __popcll(__ballot(in));
+    }
+  }
+  if (lane == 0) {
+    se3_to7(se3, dst.se3);
+    dst.ok = ok;
+    dst.supporters = supporters;
+  }
+}
+
 // CheckReprojectionError of every draw over every match (feature_align.cc:190, 245-283).  blockIdx.x = draw, blockIdx.y = chunk of
 // kSupChunk matches, blockIdx.z = frame; a supporter count is an integer sum, so its order is free: one add per wave.
 __global__ __launch_bounds__(64) void pose_supporters_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
@@ -239,12 +391,6 @@ __device__ void check_list(const sdvl_pose_obs *obs, const uint16_t *list, int n
   }
   *n_in = ni;
   *n_out = no;
-}
-
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // k-th smallest (0-based) of the n non-negative doubles vals[0..n), n <= 64 * kSlots, by one wave; uniform result.
@@ -503,10 +649,16 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
                              int batch_size) {
   if (max_obs < 1) max_obs = 1;
   if (max_obs > kMaxObs) max_obs = kMaxObs;
-  SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), d_jobs, d_obs, d_rand, *p,
-              static_cast<HypResult *>(d_hyp));
-  SDVL_LAUNCH(ctx, "pose_supporters", pose_supporters_kernel, dim3(p->max_ransac_its, (max_obs + kSupChunk - 1) / kSupChunk, n_jobs), dim3(64), d_jobs, d_obs, *p,
-              static_cast<HypResult *>(d_hyp));
+  if (batch_size <= 32) {
+    // a small set: one wave per draw, the supporters counted by the same wave (see pose_hypotheses_wave_kernel)
+    SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_wave_kernel, dim3(p->max_ransac_its, n_jobs), dim3(64), d_jobs, d_obs, d_rand, *p,
+                static_cast<HypResult *>(d_hyp));
+  } else {
+    SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), d_jobs, d_obs, d_rand, *p,
+                static_cast<HypResult *>(d_hyp));
+    SDVL_LAUNCH(ctx, "pose_supporters", pose_supporters_kernel, dim3(p->max_ransac_its, (max_obs + kSupChunk - 1) / kSupChunk, n_jobs), dim3(64), d_jobs, d_obs, *p,
+                static_cast<HypResult *>(d_hyp));
+  }
   // a frame of the metric configuration has <= 200 observations: one wave (three waves with 59 KB of LDS wait longer for a CU among the
   // other streams' kernels than they save: 2.4 -> 3.9 ms of dispatch time per step); configuration C's ~850: wave 0 + two helpers
   // Round 5: a small batch (a lone camera) takes the helper waves too — nobody else wants the CU
