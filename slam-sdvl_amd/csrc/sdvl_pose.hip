@@ -550,7 +550,8 @@ template <int kRefWaves>
 __global__ __launch_bounds__(64 * kRefWaves) void pose_refine_kernel(const PoseJobDev *__restrict__ jobs, const sdvl_pose_obs *__restrict__ obs_all,
                                                          const int32_t *__restrict__ nits_table, const HypResult *__restrict__ hyp,
                                                          sdvl_pose_params prm, sdvl_pose_result *__restrict__ results,
-                                                         int32_t *__restrict__ out_lists) {
+                                                         int32_t *__restrict__ out_lists, int lazy_supporters, const int32_t *__restrict__ rand_idx,
+                                                         int hyp_ready) {
   __shared__ RefineLds<kRefWaves> L;
   const PoseJobDev &job = jobs[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -577,6 +578,71 @@ __global__ __launch_bounds__(64 * kRefWaves) void pose_refine_kernel(const PoseJ
   const int32_t *nits_of = nits_table + job.nits_begin;  // iteration budget after an improvement to s supporters
   int best_it = -1;
   int nits = prm.max_ransac_its, best_sup = 0, it = 0;
+  double best7[7] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (lazy_supporters) {
+    // Round 6: the supporters of a draw are counted HERE, when the replay reaches the draw — the reference stops drawing once the budget is
+    // met (typically after 5-10 of the 100 draws when nine matches in ten are inliers), and so does this loop: pose_supporters_kernel
+    // tested every draw against every match (24 k of a tracked frame's 694 k instructions) for counts nobody read.  Lane h holds draw
+    // base + h; the loop takes a draw's pose out of it with readlane and counts over the matches in rounds of 64 (an integer sum).
+    for (int base = 0; base < prm.max_ransac_its && it < nits; base += 64) {
+      const int h = base + lane;
+      int ok_h = 0;
+      double p7[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (h < prm.max_ransac_its) {
+        if (h < hyp_ready) {
+          ok_h = hy[h].ok;
+#pragma unroll
+          for (int k = 0; k < 7; k++) p7[k] = hy[h].se3[k];
+        } else {
+          // a draw beyond those pose_hypotheses_kernel converged (it is launched for the first 64 only: a budget that 64 draws do not
+          // meet is the exception — fewer than ~6 matches in 10 are inliers): its lane converges it here, exactly as that kernel would
+          const int npoints = min(prm.max_ransac_points, size);
+          int index = rand_idx[job.rand_begin + h];
+          if (prm.pad_ & 1) index %= size;
+          int sel[8];
+          for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
+          Rigid se3;
+          if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
+            ok_h = 1;
+            se3_to7(se3, p7);
+          }
+        }
+      }
+      const int end = min(base + 64, prm.max_ransac_its);
+      while (it < nits && it < end) {
+        const int src = it - base;
+        int s_it = -1;
+        double u7[7] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (__builtin_amdgcn_readlane(ok_h, src)) {
+#pragma unroll
+          for (int k = 0; k < 7; k++)
+            u7[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p7[k]), src), __builtin_amdgcn_readlane(__double2loint(p7[k]), src));
+          const Rigid se3 = se3_from7(u7);
+          const M3 R = se3_rot(se3);
+          s_it = 0;
+          for (int q0 = 0; q0 < size; q0 += 64) {
+            const int q = q0 + lane;
+            bool in = false;
+            if (q < size) {
+              double ex, ey;
+              V3 pos;
+              reproj_error(obs[q], R, se3.t, &ex, &ey, &pos);
+              in = sqrt(ex * ex + ey * ey) <= prm.inlier_threshold;
+            }
+            s_it += __popcll(__ballot(in));
+          }
+        }
+        if (s_it > best_sup) {
+          best_sup = s_it;
+          best_it = it;
+          nits = nits_of[best_sup];
+#pragma unroll
+          for (int k = 0; k < 7; k++) best7[k] = u7[k];  // (a draw converged on demand exists in registers only)
+        }
+        it++;
+      }
+    }
+  } else
   for (int base = 0; base < prm.max_ransac_its && it < nits; base += 64) {
     const int h = base + lane;
     int sup = -1;
@@ -593,7 +659,7 @@ __global__ __launch_bounds__(64 * kRefWaves) void pose_refine_kernel(const PoseJ
     }
   }
   Rigid best = se3_identity();  // SE3 best_se3 default-constructed
-  if (best_it >= 0) best = se3_from7(hy[best_it].se3);
+  if (best_it >= 0) best = lazy_supporters ? se3_from7(best7) : se3_from7(hy[best_it].se3);
   res.n_draws = it;
   // ---- final CheckReprojectionError with the best hypothesis -> inliers / outliers (feature_align.cc:215)
   for (int q = lane; q < size; q += 64) L.tmp[q] = static_cast<uint16_t>(q);
@@ -649,25 +715,32 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
                              int batch_size) {
   if (max_obs < 1) max_obs = 1;
   if (max_obs > kMaxObs) max_obs = kMaxObs;
+  const bool all_supporters = getenv("SDVL_POSE_ALL_SUPPORTERS") != nullptr;  // (read per call: the test flips it inside one process)
+  int hyp_ready = p->max_ransac_its;
   if (batch_size <= 32) {
     // a small set: one wave per draw, the supporters counted by the same wave (see pose_hypotheses_wave_kernel)
     SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_wave_kernel, dim3(p->max_ransac_its, n_jobs), dim3(64), d_jobs, d_obs, d_rand, *p,
                 static_cast<HypResult *>(d_hyp));
   } else {
-    SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((p->max_ransac_its + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), d_jobs, d_obs, d_rand, *p,
+    hyp_ready = all_supporters ? p->max_ransac_its : std::min(p->max_ransac_its, kHypDraws);  // the first wave of draws; the rest on demand (pose_refine)
+    SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((hyp_ready + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), d_jobs, d_obs, d_rand, *p,
                 static_cast<HypResult *>(d_hyp));
-    SDVL_LAUNCH(ctx, "pose_supporters", pose_supporters_kernel, dim3(p->max_ransac_its, (max_obs + kSupChunk - 1) / kSupChunk, n_jobs), dim3(64), d_jobs, d_obs, *p,
-                static_cast<HypResult *>(d_hyp));
+    // the supporters: counted by pose_refine as its replay of the RANSAC loop reaches a draw; SDVL_POSE_ALL_SUPPORTERS=1 (A/B and test):
+    // every draw against every match in a launch of its own, as in rounds 3-5
+    if (all_supporters)
+      SDVL_LAUNCH(ctx, "pose_supporters", pose_supporters_kernel, dim3(p->max_ransac_its, (max_obs + kSupChunk - 1) / kSupChunk, n_jobs), dim3(64), d_jobs, d_obs, *p,
+                  static_cast<HypResult *>(d_hyp));
   }
+  const int lazy = (batch_size > 32 && !all_supporters) ? 1 : 0;
   // a frame of the metric configuration has <= 200 observations: one wave (three waves with 59 KB of LDS wait longer for a CU among the
   // other streams' kernels than they save: 2.4 -> 3.9 ms of dispatch time per step); configuration C's ~850: wave 0 + two helpers
   // Round 5: a small batch (a lone camera) takes the helper waves too — nobody else wants the CU
   if (max_obs > 256 || batch_size <= 32)
     SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel<3>, dim3(n_jobs), dim3(192), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
-                d_lists);
+                d_lists, lazy, d_rand, hyp_ready);
   else
   SDVL_LAUNCH(ctx, "pose_refine", pose_refine_kernel<1>, dim3(n_jobs), dim3(64), d_jobs, d_obs, d_nits, static_cast<const HypResult *>(d_hyp), *p, d_res,
-              d_lists);
+              d_lists, lazy, d_rand, hyp_ready);
   SDVL_HIP_CHECK(ctx, hipGetLastError());
   return SDVL_OK;
 }

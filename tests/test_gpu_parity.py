@@ -958,6 +958,33 @@ def test_pose_from_matches_many_draws(ctx, orc):
     assert max(w["n_draws"] for w in wants) > 128   # the later workgroups' draws are really consumed
 
 
+@pytest.mark.parametrize("env", [None, "SDVL_POSE_ALL_SUPPORTERS"])
+def test_pose_from_matches_batch_of_40_on_the_farm_forms(ctx, orc, env, monkeypatch):
+    """More than 32 jobs in one call: the farm's forms of the pose stage — one LANE per draw, the first 64 draws converged by
+    pose_hypotheses, the supporters counted by pose_refine as its replay reaches a draw, draws beyond 64 converged there on demand
+    (round 6).  Jobs with few inliers keep drawing past 64; the oracle's n_draws, lists and poses are demanded of every job.
+    SDVL_POSE_ALL_SUPPORTERS=1: rounds 3-5's form (every draw against every match in pose_supporters)."""
+    if env:
+        monkeypatch.setenv(env, "1")
+    cam = TUM_CAM
+    jobs, wants = [], []
+    for j in range(40):
+        n = [160, 60, 200, 25][j % 4]
+        frac = [0.1, 0.5, 0.62, 0.3][j % 4] if j % 8 < 6 else 0.7
+        obs, guess = make_matches(orc, n, seed=300 + j, outlier_frac=frac)
+        skip = 11 * j
+        draws = orc.rand_stream(skip + 100, seed=7)[skip:]
+        jobs.append((obs, guess, draws))
+        wants.append(orc.pose_from_matches(cam, obs, guess, rand_seed=7, rand_skip=skip))
+    got = ctx.pose_from_matches(jobs, fx=cam[0])
+    for j, (g, w) in enumerate(zip(got, wants)):
+        assert g["n_draws"] == w["n_draws"], j
+        assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["outliers"], w["outliers"]), j
+        assert np.abs(g["pose"] - w["pose"]).max() <= 1e-9, j
+    n_draws = [w["n_draws"] for w in wants]
+    assert max(n_draws) > 64 and min(n_draws) < 20, n_draws   # both the on-demand draws and the early stop are exercised
+
+
 def test_pose_from_matches_degenerate_inputs(ctx, orc):
     """all matches identical / all outliers / more matches than the device path takes"""
     cam = TUM_CAM
