@@ -717,7 +717,10 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
   if (max_obs > kMaxObs) max_obs = kMaxObs;
   const bool all_supporters = getenv("SDVL_POSE_ALL_SUPPORTERS") != nullptr;  // (read per call: the test flips it inside one process)
   int hyp_ready = p->max_ransac_its;
-  if (batch_size <= 32) {
+  // one wave per draw pays while every wave finds a SIMD of its own: a lone camera (100 waves), not configuration C's groups of 16
+  // (1600 waves per launch, four groups at a time: 46.3 k tracked frames/s with the lane form against 41.3 k, two alternating pairs)
+  const bool wave_form = batch_size <= 4;
+  if (wave_form) {
     // a small set: one wave per draw, the supporters counted by the same wave (see pose_hypotheses_wave_kernel)
     SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_wave_kernel, dim3(p->max_ransac_its, n_jobs), dim3(64), d_jobs, d_obs, d_rand, *p,
                 static_cast<HypResult *>(d_hyp));
@@ -731,7 +734,7 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
       SDVL_LAUNCH(ctx, "pose_supporters", pose_supporters_kernel, dim3(p->max_ransac_its, (max_obs + kSupChunk - 1) / kSupChunk, n_jobs), dim3(64), d_jobs, d_obs, *p,
                   static_cast<HypResult *>(d_hyp));
   }
-  const int lazy = (batch_size > 32 && !all_supporters) ? 1 : 0;
+  const int lazy = (!wave_form && !all_supporters) ? 1 : 0;
   // a frame of the metric configuration has <= 200 observations: one wave (three waves with 59 KB of LDS wait longer for a CU among the
   // other streams' kernels than they save: 2.4 -> 3.9 ms of dispatch time per step); configuration C's ~850: wave 0 + two helpers
   // Round 5: a small batch (a lone camera) takes the helper waves too — nobody else wants the CU
