@@ -104,7 +104,10 @@ int sdvl_stage_alloc(sdvl_ctx *ctx, size_t bytes, void **h, void **d) {
   return SDVL_OK;
 }
 
-static hipError_t mark_flag(sdvl_ctx *ctx) {
+hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket) {
+  const uint32_t seq = ++ctx->flag_seq;
+  *ticket = seq;
+  (void)kind;
   if (!ctx->h_flag) {
     void *p = nullptr;
     hipError_t e = sdvl_bind_device(ctx);
@@ -114,26 +117,6 @@ static hipError_t mark_flag(sdvl_ctx *ctx) {
     memset(p, 0, 64);
     ctx->h_flag = static_cast<volatile uint32_t *>(p);
   }
-  return hipSuccess;
-}
-
-// Round 6: a mark that the LAST KERNEL in front of it writes itself (its last workgroup, behind a system-scope fence) instead of a
-// stream write command behind the kernel: the command processor takes ~8 us to notice the kernel's end and execute the write — for a lone
-// camera that is 3 % of the frame.  The caller passes (*flag, *ticket) to that kernel and queues nothing else for the mark.
-hipError_t sdvl_mark_reserve(sdvl_ctx *ctx, uint32_t *ticket, uint32_t **flag) {
-  const hipError_t e = mark_flag(ctx);
-  if (e != hipSuccess) return e;
-  *ticket = ++ctx->flag_seq;
-  *flag = const_cast<uint32_t *>(ctx->h_flag);
-  return hipSuccess;
-}
-
-hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket) {
-  (void)kind;
-  const hipError_t e0 = mark_flag(ctx);
-  if (e0 != hipSuccess) return e0;
-  const uint32_t seq = ++ctx->flag_seq;
-  *ticket = seq;
   // the stream itself writes the sequence number once everything before it has completed: no event object, and the
   // waiting thread polls a cache line instead of calling into the runtime
   return hipStreamWriteValue32(ctx->stream, const_cast<uint32_t *>(ctx->h_flag), seq, 0);

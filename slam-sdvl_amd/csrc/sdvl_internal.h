@@ -210,9 +210,6 @@ hipError_t sdvl_stream_wait(sdvl_ctx *ctx);
 // 3 = keyframe filter inputs
 enum { SDVL_MARK_STREAM = 0, SDVL_MARK_ALIGN = 1, SDVL_MARK_CHAIN = 2, SDVL_MARK_FILTER = 3 };
 hipError_t sdvl_mark_record(sdvl_ctx *ctx, int kind, uint32_t *ticket);
-// the same mark written by the last kernel in front of it (see sdvl_ctx.hip): (*flag, *ticket) go to that kernel, whose last workgroup
-// stores the ticket into the flag behind a system-scope fence; wait for it with sdvl_mark_wait as usual
-hipError_t sdvl_mark_reserve(sdvl_ctx *ctx, uint32_t *ticket, uint32_t **flag);
 hipError_t sdvl_mark_wait(sdvl_ctx *ctx, int kind, uint32_t ticket);
 // host copy of a frame's corner count; fetches it (blocking) when only the device knows it
 int sdvl_frame_count_host(sdvl_ctx *ctx, sdvl_frame *f, int *n);

@@ -242,8 +242,7 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
                                                            const sdvl_pose_result *__restrict__ pres, const int32_t *__restrict__ lists,
                                                            const sdvl_align_result *__restrict__ ares, Cam cam, int max_failed,
                                                            SearchFramePose *__restrict__ registry, sdvl_track_result *__restrict__ h_results,
-                                                           sdvl_track_feature_out *__restrict__ h_feats, sdvl_track_point_stat *__restrict__ h_stats,
-                                                           unsigned int *__restrict__ done, uint32_t *__restrict__ h_flag, uint32_t ticket) {
+                                                           sdvl_track_feature_out *__restrict__ h_feats, sdvl_track_point_stat *__restrict__ h_stats) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   uint16_t *s_before = reinterpret_cast<uint16_t *>(s_dyn);  // [stride + 1] matches selected among the candidates before k
   uint8_t *s_found = reinterpret_cast<uint8_t *>(s_before + stride + 1);  // [stride]
@@ -406,18 +405,6 @@ __global__ __launch_bounds__(256) void track_commit_kernel(const TrackJobDev *__
 #pragma unroll
     for (int q = 0; q < 7; q++) registry[jb.cur_id].pose[q] = pr.pose[q];  // the frame's final pose, for when it becomes a reference
   }
-  // the step's mark (sdvl_mark_reserve): every lane's stores into the pinned host buffers are ordered in front of its workgroup's count,
-  // the last workgroup to count stores the ticket the host polls for
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned int before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (before == gridDim.x - 1) {
-      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next step's launch comes behind this one in the stream
-      __threadfence_system();
-      __hip_atomic_store(h_flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
 }
 
 }  // namespace
@@ -447,7 +434,6 @@ struct sdvl_track_set {
   void *d_hyp;
   sdvl_pose_result *d_pres;
   int32_t *d_lists, *d_nobs;
-  unsigned int *d_done = nullptr;  // workgroups of track_commit that have finished (the last one writes the step's mark and resets it)
   // pinned host mirrors, written by track_commit
   uint8_t *h_pinned = nullptr;
   sdvl_track_result *h_results;
@@ -527,8 +513,6 @@ int sdvl_track_create(sdvl_ctx *ctx, int n, int max_points, int max_features, in
       e = hipMalloc(reinterpret_cast<void **>(&s->d_scratch), s->scratch_bytes);
     }
   }
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_done), 256);
-  if (e == hipSuccess) e = hipMemset(s->d_done, 0, 256);
   if (e == hipSuccess) {
     const size_t hb = (sizeof(sdvl_track_result) * N + 255) / 256 * 256, fb = (sizeof(sdvl_track_feature_out) * NF + 255) / 256 * 256;
     const size_t sb = sizeof(sdvl_track_point_stat) * N * s->np;
@@ -566,7 +550,6 @@ int sdvl_track_destroy(sdvl_ctx *ctx, sdvl_track_set *s) {
   if (s->d_feats[0]) (void)hipFree(s->d_feats[0]);
   if (s->d_feats[1]) (void)hipFree(s->d_feats[1]);
   if (s->d_scratch) (void)hipFree(s->d_scratch);
-  if (s->d_done) (void)hipFree(s->d_done);
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   delete s;
   return SDVL_OK;
@@ -821,17 +804,16 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
     const size_t lds = (static_cast<size_t>(stride + 1) * 2 + stride + 64 + 7) / 8 * 8 + static_cast<size_t>(s->mm) * 8;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "track_commit", &ev_a, &ev_b);
-    uint32_t *flag = nullptr;  // the step's mark is written by track_commit's last workgroup: no stream write command behind the kernel
-    SDVL_HIP_CHECK(ctx, sdvl_mark_reserve(ctx, &s->ticket, &flag));
     hipExtLaunchKernelGGL(track_commit_kernel, dim3(n_jobs), dim3(256), lds, ctx->stream, ev_a, ev_b, 0, static_cast<const TrackJobDev *>(s->d_jobs),
                           s->d_points, static_cast<const TrackFeat *>(s->d_feats[0]), static_cast<const TrackFeat *>(s->d_feats[1]), s->d_feats[0],
                           s->d_feats[1], s->np, s->nf, stride, s->mm, static_cast<const ChainFrameDev *>(s->d_chain),
                           static_cast<const int32_t *>(s->d_cfirst), static_cast<const int32_t *>(s->d_cfeat),
                           static_cast<const sdvl_search_res *>(s->d_res), static_cast<const sdvl_pose_result *>(s->d_pres),
                           static_cast<const int32_t *>(s->d_lists), static_cast<const sdvl_align_result *>(s->d_ares), c, s->prm.max_failed, registry,
-                          s->h_results, s->h_feats, s->h_stats, s->d_done, flag, s->ticket);
+                          s->h_results, s->h_feats, s->h_stats);
     SDVL_HIP_CHECK(ctx, hipGetLastError());
   }
+  SDVL_HIP_CHECK(ctx, sdvl_mark_record(ctx, SDVL_MARK_CHAIN, &s->ticket));
   s->phase = 2;
   return SDVL_OK;
 }
