@@ -228,17 +228,22 @@ __global__ __launch_bounds__(256) void filter_select_kernel(const FilterJob *__r
 // short list (LDS atomics, arrival order), the cell's thread puts the handful of entries back into list order and runs the
 // reference's sequential comparison over them.  Work ~ corners instead of cells x corners (configuration C: 1200 cells x
 // 4050 corners).  A cell with more than kBinSlots corners falls back to the scan over all corners.
+// Round 6: two sizes.  The arrays are static LDS: 60 KB when they are cut for configuration C's 1200 cells and 6144 corners — a
+// workgroup that has to find 60 KB free on one compute unit among the other streams' kernels (fast_cells alone fills 150 of a CU's
+// 160 KB) waits: 132 us per dispatch in the farm against 15 alone.  The metric configuration's 300 cells and ~1000 corners take 16 KB.
 constexpr int kBinCells = 2048, kBinSlots = 10;
+constexpr int kBinCellsSmall = 512, kBinCornersSmall = 2048;
 
+template <int kCells, int kCorners>
 __global__ __launch_bounds__(256) void filter_select_binned_kernel(const FilterJob *__restrict__ jobs, int cell_size, int grid_w, int n_cells,
                                                                    int margin, int min_score, int max_out) {
-  __shared__ uint16_t s_cell[kFilterMaxCorners];
-  __shared__ uint16_t s_list[kBinCells * kBinSlots];
-  __shared__ int s_cnt[kBinCells];  // corners of the cell; afterwards the chosen corner or -1
+  __shared__ uint16_t s_cell[kCorners];
+  __shared__ uint16_t s_list[kCells * kBinSlots];
+  __shared__ int s_cnt[kCells];  // corners of the cell; afterwards the chosen corner or -1
   __shared__ int s_wave[4];
   const FilterJob &job = jobs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = min(min(job.n_ptr[0], job.ccap), kFilterMaxCorners);
+  const int n = min(min(job.n_ptr[0], job.ccap), kCorners);
   for (int c = tid; c < n_cells; c += 256) s_cnt[c] = 0;
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
@@ -647,9 +652,12 @@ int sdvl_filter_corners_begin(sdvl_ctx *ctx, int n, sdvl_frame *const *frames, c
   }
   memcpy(static_cast<uint8_t *>(hs) + jb, locked_cells, mb);
   SDVL_HIP_CHECK(ctx, sdvl_push(ctx, dsx, hs, jb + mb));
-  if (n_cells <= kBinCells)
-    SDVL_LAUNCH(ctx, "filter_select", filter_select_binned_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells,
-                margin, min_feature_score, max_out);
+  if (n_cells <= kBinCellsSmall && ccap <= kBinCornersSmall)
+    SDVL_LAUNCH(ctx, "filter_select", (filter_select_binned_kernel<kBinCellsSmall, kBinCornersSmall>), dim3(n), dim3(256), static_cast<const FilterJob *>(dsx),
+                cell_size, grid_w, n_cells, margin, min_feature_score, max_out);
+  else if (n_cells <= kBinCells)
+    SDVL_LAUNCH(ctx, "filter_select", (filter_select_binned_kernel<kBinCells, kFilterMaxCorners>), dim3(n), dim3(256), static_cast<const FilterJob *>(dsx),
+                cell_size, grid_w, n_cells, margin, min_feature_score, max_out);
   else
     SDVL_LAUNCH(ctx, "filter_select", filter_select_kernel, dim3(n), dim3(256), static_cast<const FilterJob *>(dsx), cell_size, grid_w, n_cells, margin,
                 min_feature_score, max_out);

@@ -361,8 +361,11 @@ struct RefineLds {
   double terms[64 * kRefWaves][29];  // 28 normal-equation terms per observation of a round (+1 pad: no 2-way bank conflict pattern)
   RefineCtl ctl;
   double sums[28];
-  double errs[kMaxObs];
-  uint16_t inl[kMaxObs], outl[kMaxObs], tmp[kMaxObs];
+  // the one-wave form is launched for jobs of at most 256 observations only (sdvl_pose_enqueue_device): a quarter of the lists — 19 KB
+  // of LDS per workgroup instead of 29.5, which is what a workgroup waits for among the other streams' kernels
+  static constexpr int kObs = kRefWaves == 1 ? 256 : kMaxObs;
+  double errs[kObs];
+  uint16_t inl[kObs], outl[kObs], tmp[kObs];
 };
 
 // CheckReprojectionError over list[0..n) in order; appends to inl (at *n_in) and outl (at *n_out)
@@ -475,7 +478,7 @@ __device__ bool converge_pose_wave(RefineLds<kRefWaves> &L, const sdvl_pose_obs 
   }
   wave_lds_sync();
   // median = element floor(n/2) of the sorted order (what nth_element leaves there)
-  const double median = n <= 256 ? wave_kth_smallest<4>(L.errs, n, n / 2, lane) : wave_kth_smallest<kMaxObs / 64>(L.errs, n, n / 2, lane);
+  const double median = n <= 256 ? wave_kth_smallest<4>(L.errs, n, n / 2, lane) : wave_kth_smallest<RefineLds<kRefWaves>::kObs / 64>(L.errs, n, n / 2, lane);
   double scale = kMADNorm * median;
   for (int i = 0; i < max_its; i++) {
     if (i == 5) scale = 0.85 / fx;
