@@ -180,6 +180,16 @@ struct IaRecordFeats {
     return ft.valid != 0;
   }
   __device__ __forceinline__ void pos(int f, double *px, double *py) const { *px = F[f].px; *py = F[f].py; }
+  // the same in two steps for the precompute kernel (see IaTableFeats::fetch)
+  struct Raw { double fx, fy, fz, depth; int valid; };
+  __device__ __forceinline__ void fetch(int f, Raw *r, double *px, double *py) const {
+    const sdvl_align_feature ft = F[f];
+    *px = ft.px;
+    *py = ft.py;
+    *r = Raw{ft.fx, ft.fy, ft.fz, ft.depth, ft.valid};
+  }
+  __device__ __forceinline__ bool valid(const Raw &r) const { return r.valid != 0; }
+  __device__ __forceinline__ V3 point(const Raw &r) const { return vscale({r.fx, r.fy, r.fz}, r.depth); }
 };
 
 // feature source B: the rows of the device-resident tracking tables — what track_align_prep_kernel wrote into records until
@@ -191,27 +201,53 @@ struct IaTableFeats {
   __device__ __forceinline__ bool load(int f, V3 *xyz) const {
     const TrackFeat ft = F[f];
     const int pt = ft.point < 0 ? -1 : (ft.point & kPointMask);
-    const bool valid = pt >= 0 && !(P[pt].status & kDeleted);
+    // status and position of the point's row in one round trip (row 0 when there is no point: read and ignored)
+    const TrackPoint &row = P[pt < 0 ? 0 : pt];
+    const int status = row.status;
+    const double p0 = row.P[0], p1 = row.P[1], p2 = row.P[2];
+    const bool valid = pt >= 0 && !(status & kDeleted);
     double depth = 0.0;
     if (valid) {
-      const double dx = P[pt].P[0] - first_pos.x, dy = P[pt].P[1] - first_pos.y, dz = P[pt].P[2] - first_pos.z;
+      const double dx = p0 - first_pos.x, dy = p1 - first_pos.y, dz = p2 - first_pos.z;
       depth = sqrt(dx * dx + dy * dy + dz * dz);
     }
     *xyz = vscale({ft.bearing[0], ft.bearing[1], ft.bearing[2]}, depth);
     return valid;
   }
   __device__ __forceinline__ void pos(int f, double *px, double *py) const { *px = F[f].px[0]; *py = F[f].px[1]; }
+  // the row, and behind it the point's status AND position in one go (row 0 when the feature has no point: read and ignored) — the
+  // chain row -> status -> position -> pixel was four dependent memory round trips in front of the window's loads, this is two
+  // Round 6, for the precompute kernel: the row, and behind it the point's status AND position ASKED FOR (row 0 when the feature has no
+  // point: read and ignored) but not looked at — the caller issues the reference window's loads (which need the row's pixel only) before
+  // valid() / point() wait for the point's row.  Row -> status -> position -> pixel -> window rows one by one were eight dependent
+  // memory round trips per feature in a kernel that does little else; this way there are two.
+  struct Raw { double b0, b1, b2, p0, p1, p2; int pt, status; };
+  __device__ __forceinline__ void fetch(int f, Raw *r, double *px, double *py) const {
+    const TrackFeat ft = F[f];
+    *px = ft.px[0];
+    *py = ft.px[1];
+    const int pt = ft.point < 0 ? -1 : (ft.point & kPointMask);
+    const TrackPoint &row = P[pt < 0 ? 0 : pt];
+    *r = Raw{ft.bearing[0], ft.bearing[1], ft.bearing[2], row.P[0], row.P[1], row.P[2], pt, row.status};
+    asm volatile("" ::: "memory");  // the point's loads are issued here, not sunk to where valid() / point() look at them
+  }
+  __device__ __forceinline__ bool valid(const Raw &r) const { return r.pt >= 0 && !(r.status & kDeleted); }
+  __device__ __forceinline__ V3 point(const Raw &r) const {  // (of a valid feature)
+    const double dx = r.p0 - first_pos.x, dy = r.p1 - first_pos.y, dz = r.p2 - first_pos.z;
+    return vscale({r.b0, r.b1, r.b2}, sqrt(dx * dx + dy * dy + dz * dz));
+  }
 };
 
 // PrecomputePatches of ONE feature at one level (image_align.cc:208-267): border test, the 16 reference items {patch, dx, dy} and
 // the gradient sums Sxx, Sxy, Syy.  Returns whether the feature is visible at the level; writes nothing otherwise.
-__device__ __forceinline__ bool ia_precompute_feature(const uint8_t *ref_img, int W, int H, float scale, double fpx, double fpy, bool valid, int f,
+template <class Valid>
+__device__ __forceinline__ bool ia_precompute_feature(const uint8_t *ref_img, int W, int H, float scale, double fpx, double fpy, const Valid valid, int f,
                                                       int pitch, float2 *it_pd, float *it_dy, double *sums3) {
   const float u_ref = static_cast<float>(fpx * scale);
   const float v_ref = static_cast<float>(fpy * scale);
   const int ui = static_cast<int>(floorf(u_ref)), vi = static_cast<int>(floorf(v_ref));
   const int border = 3;
-  if (!valid || ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) return false;
+  if (ui - border < 0 || vi - border < 0 || ui + border >= W || vi + border >= H) return false;  // (`valid`: below, behind the window's loads)
   const float su = u_ref - ui, sv = v_ref - vi;
   const float w_tl = static_cast<float>((1.0 - su) * (1.0 - sv));
   const float w_tr = static_cast<float>(su * (1.0 - sv));
@@ -222,19 +258,25 @@ __device__ __forceinline__ bool ia_precompute_feature(const uint8_t *ref_img, in
   const uint8_t *wp = ref_img + static_cast<size_t>(vi - 3) * W + (ui - 3);
   float g[3][6];  // rolling: rows y-2, y-1, y of the grid
   float ra[7], rb[7];
+  // all seven rows of the window are asked for before the first is used (round 6: row by row, every row's wait also waited for the
+  // item stores queued in front of it — a memory round trip per row on a chain that is nothing but round trips)
+  uint32_t wlo[7], whi[7];
+#pragma unroll
+  for (int y = 0; y < 7; y++) ia_load_row8(wp + static_cast<size_t>(y) * W, 7, &wlo[y], &whi[y]);
+  // a feature without a live point is not visible either (image_align.cc:219-221); the test sits here so that the window's loads do not
+  // wait for the point's row, on which `valid` depends (the window of such a feature is read and dropped)
+  asm volatile("" ::: "memory");  // (the loads above stay above: the compiler otherwise tests `valid` first and the window waits for the point's row)
+  if (!valid()) return false;
   {
-    uint32_t lo, hi;
-    ia_load_row8(wp, 7, &lo, &hi);
 #pragma unroll
-    for (int k = 0; k < 4; k++) ra[k] = ia_byte(lo, k);
+    for (int k = 0; k < 4; k++) ra[k] = ia_byte(wlo[0], k);
 #pragma unroll
-    for (int k = 4; k < 7; k++) ra[k] = ia_byte(hi, k - 4);
+    for (int k = 4; k < 7; k++) ra[k] = ia_byte(whi[0], k - 4);
   }
   double sxx = 0.0, sxy = 0.0, syy = 0.0;
 #pragma unroll
   for (int y = 0; y < 6; y++) {
-    uint32_t lo, hi;
-    ia_load_row8(wp + static_cast<size_t>(y + 1) * W, 7, &lo, &hi);
+    const uint32_t lo = wlo[y + 1], hi = whi[y + 1];
 #pragma unroll
     for (int k = 0; k < 4; k++) rb[k] = ia_byte(lo, k);
 #pragma unroll
@@ -391,6 +433,16 @@ __device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, cons
         if (f >= nf) continue;
         const int flag = s_flag[f];
         if (!(flag & kIaVis)) continue;
+        // the feature's 48 reference items do not depend on the pose: their loads go out first and are in flight under the projection
+        // and the window's loads (round 6: the compiler had split them into three batches around the window's rows — three memory
+        // round trips per round of a wave that has nothing else to do meanwhile)
+        float2 pdv[16];
+        float dyv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          pdv[k] = it_pd[k * pitch + f];
+          dyv[k] = it_dy[k * pitch + f];
+        }
         const double X = s_x[f], Y = s_x[max_f + f], Z = s_x[2 * max_f + f];
         const V3 xc = {R.m[0] * X + R.m[1] * Y + R.m[2] * Z + Tt.x, R.m[3] * X + R.m[4] * Y + R.m[5] * Z + Tt.y,
                        R.m[6] * X + R.m[7] * Y + R.m[8] * Z + Tt.z};
@@ -413,26 +465,26 @@ __device__ __forceinline__ void ia_wave_body(const IaIn job, const Feats F, cons
         const float w3 = su * sv;
         const uint8_t *wp = cur_img + static_cast<size_t>(vi - 2) * W + (ui - 2);
         float ra[5], rb[5];
-        {
-          uint32_t lo, hi;
-          ia_load_row8(wp, 5, &lo, &hi);
+        uint32_t wlo[5], whi[5];
 #pragma unroll
-          for (int k = 0; k < 4; k++) ra[k] = ia_byte(lo, k);
-          ra[4] = ia_byte(hi, 0);
+        for (int y = 0; y < 5; y++) ia_load_row8(wp + static_cast<size_t>(y) * W, 5, &wlo[y], &whi[y]);
+        {
+#pragma unroll
+          for (int k = 0; k < 4; k++) ra[k] = ia_byte(wlo[0], k);
+          ra[4] = ia_byte(whi[0], 0);
         }
         double A = 0.0, B = 0.0, c2 = 0.0;
 #pragma unroll
         for (int y = 0; y < 4; y++) {
-          uint32_t lo, hi;
-          ia_load_row8(wp + static_cast<size_t>(y + 1) * W, 5, &lo, &hi);
+          const uint32_t lo = wlo[y + 1], hi = whi[y + 1];
 #pragma unroll
           for (int k = 0; k < 4; k++) rb[k] = ia_byte(lo, k);
           rb[4] = ia_byte(hi, 0);
 #pragma unroll
           for (int x = 0; x < 4; x++) {
             const float intensity = w0 * ra[x] + w1 * ra[x + 1] + w2 * rb[x] + w3 * rb[x + 1];
-            const float2 pd = it_pd[(y * 4 + x) * pitch + f];
-            const float dy = it_dy[(y * 4 + x) * pitch + f];
+            const float2 pd = pdv[y * 4 + x];
+            const float dy = dyv[y * 4 + x];
             const float res = intensity - pd.x;
             const double dres = res;
             A += static_cast<double>(pd.y) * dres;
@@ -642,6 +694,9 @@ template <class Feats>
 __device__ __forceinline__ void ia_pre_body(const uint8_t *ref_img, int W, int H, int level, int nf, const Feats F, double fx, int pitch, IaPreOut o) {
   __shared__ double s_redH[4][24];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the level's image pointer and size come out of the job record by a run-time index: have them in scalar registers NOW — loaded where
+  // they are first used, in front of the window's loads, they made those loads wait for everything issued before them
+  asm volatile("" : "+s"(ref_img), "+s"(W), "+s"(H));
   const float scale = 1.0f / (1 << level);
   const double fl = fx / (1 << level);
   float2 *it_pd = reinterpret_cast<float2 *>(o.items);
@@ -655,14 +710,13 @@ __device__ __forceinline__ void ia_pre_body(const uint8_t *ref_img, int W, int H
     bool vis = false;
     double sums[3] = {0.0, 0.0, 0.0};
     if (f < nf) {
-      V3 xyz;
-      const bool valid = F.load(f, &xyz);
+      typename Feats::Raw raw;
       double fpx, fpy;
-      F.pos(f, &fpx, &fpy);
-      vis = ia_precompute_feature(ref_img, W, H, scale, fpx, fpy, valid, f, pitch, it_pd, it_dy, sums);
+      F.fetch(f, &raw, &fpx, &fpy);
+      vis = ia_precompute_feature(ref_img, W, H, scale, fpx, fpy, [&]() { return F.valid(raw); }, f, pitch, it_pd, it_dy, sums);
       if (vis) {
+        const V3 xyz = F.point(raw);
         ia_feature_h(xyz.x, xyz.y, 1. / xyz.z, fl, sums[0], sums[1], sums[2], h16, h8);
-
       }
     }
     o.S[f] = sums[0];
@@ -714,7 +768,7 @@ __global__ __launch_bounds__(256) void image_align_pre_kernel(const IaJob *__res
 }
 
 template <int kWaves>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_wave_pre_kernel(
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 8))) void image_align_wave_pre_kernel(
     const IaJob *__restrict__ jobs, const sdvl_align_feature *__restrict__ feats_all, Cam cam, sdvl_align_params prm, int n_jobs, int max_f, void *pre,
     sdvl_align_result *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -745,7 +799,7 @@ __global__ __launch_bounds__(256) void image_align_track_pre_kernel(const TrackJ
 }
 
 template <int kWaves>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void image_align_track_wave_pre_kernel(
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 8))) void image_align_track_wave_pre_kernel(
     const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points, const TrackFeat *__restrict__ feats0, const TrackFeat *__restrict__ feats1,
     int np, int nfeat_cap, Cam cam, sdvl_align_params prm, int n_jobs, int max_f, void *pre, sdvl_align_result *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];

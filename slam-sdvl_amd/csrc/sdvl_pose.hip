@@ -54,8 +54,28 @@ __device__ __forceinline__ void reproj_error(const sdvl_pose_obs &o, const M3 &R
 
 // ---------------------------------------------------------------------------------------------- hypotheses (lane each)
 // ConvergePose over `npts` observations idx[0..npts) (npts <= 8), all in registers / small local arrays
+// kCache (round 6): the draw's observations are copied ONCE into the lane's column of an LDS block [npts][6][64] and read from there —
+// from global memory they were a dependent load per point and iteration (the loops over a run-time point count are not unrolled):
+// 5 x 10 memory round trips on a chain that has one wave per SIMD to hide them behind, half of the kernel's time.
+template <bool kCache>
 __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, int npts, const Rigid &frame_pose, double fx, int max_its,
-                                    Rigid *se3) {
+                                    Rigid *se3, double *cache = nullptr, int lane = 0) {
+  if (kCache) {
+    for (int q = 0; q < npts; q++) {
+      const sdvl_pose_obs o = obs[idx[q]];
+      double *c = cache + (q * 6) * 64 + lane;
+      c[0] = o.px; c[64] = o.py; c[128] = o.pz; c[192] = o.ax; c[256] = o.ay; c[320] = o.inv_cov;
+    }
+  }
+  const auto ob = [&](int q) {
+    if (kCache) {
+      const double *c = cache + (q * 6) * 64 + lane;
+      sdvl_pose_obs o;
+      o.px = c[0]; o.py = c[64]; o.pz = c[128]; o.ax = c[192]; o.ay = c[256]; o.inv_cov = c[320];
+      return o;
+    }
+    return obs[idx[q]];
+  };
   Rigid last = frame_pose;
   *se3 = last;
   double chi2 = 0.0;
@@ -65,7 +85,7 @@ __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, in
     for (int q = 0; q < npts; q++) {
       double ex, ey;
       V3 pos;
-      reproj_error(obs[idx[q]], R, se3->t, &ex, &ey, &pos);
+      reproj_error(ob(q), R, se3->t, &ex, &ey, &pos);
       errs[q] = sqrt(ex * ex + ey * ey);
     }
   }
@@ -90,10 +110,11 @@ __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, in
     for (int q = 0; q < npts; q++) {
       double ex, ey;
       V3 pos;
-      reproj_error(obs[idx[q]], R, se3->t, &ex, &ey, &pos);
+      const sdvl_pose_obs o = ob(q);
+      reproj_error(o, R, se3->t, &ex, &ey, &pos);
       double J[12];
       jacobian_3d_to_plane(pos, J);
-      const double ic = obs[idx[q]].inv_cov;
+      const double ic = o.inv_cov;
 #pragma unroll
       for (int c = 0; c < 12; c++) J[c] *= ic;
       const double weight = tukey(sqrt(ex * ex + ey * ey) / scale);
@@ -152,7 +173,8 @@ __global__ __launch_bounds__(kHypDraws) void pose_hypotheses_kernel(const PoseJo
     int sel[8];
     for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
     Rigid se3;
-    if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
+    extern __shared__ double s_hyp_cache[];  // [max_ransac_points][6][64]
+    if (converge_pose_small<true>(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3, s_hyp_cache, threadIdx.x)) {
       r.ok = 1;
       se3_to7(se3, r.se3);
     }
@@ -366,6 +388,9 @@ struct RefineLds {
   static constexpr int kObs = kRefWaves == 1 ? 256 : kMaxObs;
   double errs[kObs];
   uint16_t inl[kObs], outl[kObs], tmp[kObs];
+  // one-wave form: the observations of the list that ConvergePose iterates over, copied once per call ([field][position in the list]) —
+  // from global memory they were a dependent load per round and iteration (round 6)
+  double obs_c[kRefWaves == 1 ? 6 : 1][kRefWaves == 1 ? kObs : 1];
 };
 
 // CheckReprojectionError over list[0..n) in order; appends to inl (at *n_in) and outl (at *n_out)
@@ -420,9 +445,20 @@ __device__ __forceinline__ double wave_kth_smallest(const double *vals, int n, i
 
 // the 28 terms of observation list[q] under (R, t) -> L.terms[row] (feature_align.cc:370-400)
 template <int kRefWaves>
+__device__ __forceinline__ sdvl_pose_obs refine_obs(const RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, const uint16_t *list, int q) {
+  if constexpr (kRefWaves == 1) {
+    sdvl_pose_obs o;
+    o.px = L.obs_c[0][q]; o.py = L.obs_c[1][q]; o.pz = L.obs_c[2][q]; o.ax = L.obs_c[3][q]; o.ay = L.obs_c[4][q]; o.inv_cov = L.obs_c[5][q];
+    return o;
+  } else {
+    return obs[list[q]];
+  }
+}
+
+template <int kRefWaves>
 __device__ __forceinline__ void refine_terms(RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, const uint16_t *list, int q, int row, const M3 &R, const V3 &t,
                                              double scale) {
-  const sdvl_pose_obs o = obs[list[q]];
+  const sdvl_pose_obs o = refine_obs(L, obs, list, q);
   double ex, ey;
   V3 pos;
   reproj_error(o, R, t, &ex, &ey, &pos);
@@ -437,7 +473,7 @@ __device__ __forceinline__ void refine_terms(RefineLds<kRefWaves> &L, const sdvl
 #pragma unroll
     for (int c = r; c < 6; c++) L.terms[row][k++] = (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
 #pragma unroll
-  for (int r = 0; r < 6; r++) L.terms[row][21 + r] = (J[r] * ex + J[6 + r] * ey) * weight;
+  for (int r = 0; r < 6; r++) L.terms[row][21 + r] = -((J[r] * ex + J[6 + r] * ey) * weight);  // b accumulates with -= in the reference: x - t == x + (-t) exactly
   L.terms[row][27] = (ex * ex + ey * ey) * weight;
 }
 
@@ -467,12 +503,18 @@ __device__ bool converge_pose_wave(RefineLds<kRefWaves> &L, const sdvl_pose_obs 
   *se3 = last;
   double chi2 = 0.0;
   if (n == 0) return false;
+  if constexpr (kRefWaves == 1) {
+    for (int q = lane; q < n; q += 64) {
+      const sdvl_pose_obs o = obs[list[q]];
+      L.obs_c[0][q] = o.px; L.obs_c[1][q] = o.py; L.obs_c[2][q] = o.pz; L.obs_c[3][q] = o.ax; L.obs_c[4][q] = o.ay; L.obs_c[5][q] = o.inv_cov;
+    }
+  }
   {
     const M3 R = se3_rot(*se3);
     for (int q = lane; q < n; q += 64) {
       double ex, ey;
       V3 pos;
-      reproj_error(obs[list[q]], R, se3->t, &ex, &ey, &pos);
+      reproj_error(refine_obs(L, obs, list, q), R, se3->t, &ex, &ey, &pos);
       L.errs[q] = sqrt(ex * ex + ey * ey);
     }
   }
@@ -501,19 +543,30 @@ __device__ bool converge_pose_wave(RefineLds<kRefWaves> &L, const sdvl_pose_obs 
       if (q < n) refine_terms(L, obs, list, q, lane, R, se3->t, scale);
       __syncthreads();  // B
       if (lane < 28) {
-        // in observation order; b accumulates with -= in the reference, and x - t == x + (-t) exactly.  Loads are issued
-        // eight at a time so that the LDS latency is paid once per group, the adds stay a dependent chain.
+        // in observation order (the b terms were stored negated: refine_terms).  The adds are a dependent chain; the LDS reads of the
+        // next eight terms are in flight while the current eight are added (round 6: the loop used to wait for every group of eight —
+        // with configuration C's ~850 matches that wait was half of the kernel)
         const int m = min(64 * kRefWaves, n - q0);
-        const bool neg = lane >= 21 && lane < 27;
+        double cur[8], nxt[8];
         int j = 0;
-        for (; j + 8 <= m; j += 8) {
-          double t8[8];
+        if (m >= 8) {
 #pragma unroll
-          for (int u = 0; u < 8; u++) t8[u] = L.terms[j + u][lane];
-#pragma unroll
-          for (int u = 0; u < 8; u++) acc += neg ? -t8[u] : t8[u];
+          for (int u = 0; u < 8; u++) cur[u] = L.terms[u][lane];
         }
-        for (; j < m; j++) acc += neg ? -L.terms[j][lane] : L.terms[j][lane];
+        for (; j + 16 <= m; j += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; u++) nxt[u] = L.terms[j + 8 + u][lane];
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += cur[u];
+#pragma unroll
+          for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+        }
+        if (j + 8 <= m) {
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += cur[u];
+          j += 8;
+        }
+        for (; j < m; j++) acc += L.terms[j][lane];
       }
       wave_lds_sync();
     }
@@ -605,7 +658,7 @@ __global__ __launch_bounds__(64 * kRefWaves) void pose_refine_kernel(const PoseJ
           int sel[8];
           for (int i = 0; i < npoints; i++) sel[i] = (index + i) % size;
           Rigid se3;
-          if (converge_pose_small(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
+          if (converge_pose_small<false>(obs, sel, npoints, se3_from7(job.pose), prm.fx, prm.max_optim_pose_its, &se3)) {
             ok_h = 1;
             se3_to7(se3, p7);
           }
@@ -729,8 +782,13 @@ int sdvl_pose_enqueue_device(sdvl_ctx *ctx, int n_jobs, const PoseJobDev *d_jobs
                 static_cast<HypResult *>(d_hyp));
   } else {
     hyp_ready = all_supporters ? p->max_ransac_its : std::min(p->max_ransac_its, kHypDraws);  // the first wave of draws; the rest on demand (pose_refine)
-    SDVL_LAUNCH(ctx, "pose_hypotheses", pose_hypotheses_kernel, dim3((hyp_ready + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), d_jobs, d_obs, d_rand, *p,
-                static_cast<HypResult *>(d_hyp));
+    {
+      hipEvent_t ev_a = nullptr, ev_b = nullptr;
+      sdvl_timer_events(ctx, "pose_hypotheses", &ev_a, &ev_b);
+      const size_t cache_bytes = static_cast<size_t>(p->max_ransac_points) * 6 * 64 * sizeof(double);  // <= 24.5 KB (max_ransac_points <= 8)
+      hipExtLaunchKernelGGL(pose_hypotheses_kernel, dim3((hyp_ready + kHypDraws - 1) / kHypDraws, n_jobs), dim3(kHypDraws), cache_bytes, ctx->stream, ev_a, ev_b,
+                            0, d_jobs, d_obs, d_rand, *p, static_cast<HypResult *>(d_hyp));
+    }
     // the supporters: counted by pose_refine as its replay of the RANSAC loop reaches a draw; SDVL_POSE_ALL_SUPPORTERS=1 (A/B and test):
     // every draw against every match in a launch of its own, as in rounds 3-5
     if (all_supporters)
