@@ -377,6 +377,14 @@ struct RefineCtl {
   double R[9], t[3], scale;
   const uint16_t *list;
   int n, q0, cmd;  // cmd: 1 = compute the terms of round q0, 0 = leave
+  int gen;         // counts the ConvergePose calls: a lane's cached observation belongs to one call's list
+};
+// the observation a lane computed terms for last time: with a list that fits one round (<= 64 lanes x waves: the metric configuration's
+// ~165 inliers on three waves) a lane has the SAME observation in every iteration of a ConvergePose call — one global load per call
+// instead of one dependent load per iteration (round 6)
+struct RefineObsCache {
+  int q = -1, gen = -1;
+  sdvl_pose_obs o;
 };
 template <int kRefWaves>
 struct RefineLds {
@@ -457,8 +465,13 @@ __device__ __forceinline__ sdvl_pose_obs refine_obs(const RefineLds<kRefWaves> &
 
 template <int kRefWaves>
 __device__ __forceinline__ void refine_terms(RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, const uint16_t *list, int q, int row, const M3 &R, const V3 &t,
-                                             double scale) {
-  const sdvl_pose_obs o = refine_obs(L, obs, list, q);
+                                             double scale, RefineObsCache &cache, int gen) {
+  if (kRefWaves > 1 && (cache.q != q || cache.gen != gen)) {
+    cache.o = obs[list[q]];
+    cache.q = q;
+    cache.gen = gen;
+  }
+  const sdvl_pose_obs o = kRefWaves > 1 ? cache.o : refine_obs(L, obs, list, q);
   double ex, ey;
   V3 pos;
   reproj_error(o, R, t, &ex, &ey, &pos);
@@ -480,6 +493,7 @@ __device__ __forceinline__ void refine_terms(RefineLds<kRefWaves> &L, const sdvl
 // what a helper wave (1 .. kRefWaves - 1) does for the whole kernel: wait for wave 0's command, compute its 64 observations of the round
 template <int kRefWaves>
 __device__ void refine_helper_loop(RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, int wave, int lane) {
+  RefineObsCache cache;
   for (;;) {
     __syncthreads();  // A: the command is published
     if (L.ctl.cmd == 0) return;
@@ -489,7 +503,7 @@ __device__ void refine_helper_loop(RefineLds<kRefWaves> &L, const sdvl_pose_obs 
 #pragma unroll
       for (int k = 0; k < 9; k++) R.m[k] = L.ctl.R[k];
       const V3 t = {L.ctl.t[0], L.ctl.t[1], L.ctl.t[2]};
-      refine_terms(L, obs, L.ctl.list, q, 64 * wave + lane, R, t, L.ctl.scale);
+      refine_terms(L, obs, L.ctl.list, q, 64 * wave + lane, R, t, L.ctl.scale, cache, L.ctl.gen);
     }
     __syncthreads();  // B: the round's terms are complete
   }
@@ -498,11 +512,12 @@ __device__ void refine_helper_loop(RefineLds<kRefWaves> &L, const sdvl_pose_obs 
 // ConvergePose over list[0..n) (n <= kMaxObs) by wave 0 with the helpers; returns false when the list is empty
 template <int kRefWaves>
 __device__ bool converge_pose_wave(RefineLds<kRefWaves> &L, const sdvl_pose_obs *obs, const uint16_t *list, int n, const Rigid &frame_pose, double fx,
-                                   int max_its, Rigid *se3, int lane) {
+                                   int max_its, Rigid *se3, int lane, int gen) {
   Rigid last = frame_pose;
   *se3 = last;
   double chi2 = 0.0;
   if (n == 0) return false;
+  RefineObsCache cache;
   if constexpr (kRefWaves == 1) {
     for (int q = lane; q < n; q += 64) {
       const sdvl_pose_obs o = obs[list[q]];
@@ -536,11 +551,12 @@ __device__ bool converge_pose_wave(RefineLds<kRefWaves> &L, const sdvl_pose_obs 
         L.ctl.list = list;
         L.ctl.n = n;
         L.ctl.q0 = q0;
+        L.ctl.gen = gen;
         L.ctl.cmd = 1;
       }
       __syncthreads();  // A
       const int q = q0 + lane;
-      if (q < n) refine_terms(L, obs, list, q, lane, R, se3->t, scale);
+      if (q < n) refine_terms(L, obs, list, q, lane, R, se3->t, scale, cache, gen);
       __syncthreads();  // B
       if (lane < 28) {
         // in observation order (the b terms were stored negated: refine_terms).  The adds are a dependent chain; the LDS reads of the
@@ -728,7 +744,7 @@ __global__ __launch_bounds__(64 * kRefWaves) void pose_refine_kernel(const PoseJ
   for (int pass = 0; pass < 2; pass++) {
     // OptimizePose(frame, &inliers, &outliers), :218-230
     Rigid se3;
-    if (converge_pose_wave(L, obs, L.inl, n_in, pose, prm.fx, prm.max_optim_pose_its, &se3, lane)) {
+    if (converge_pose_wave(L, obs, L.inl, n_in, pose, prm.fx, prm.max_optim_pose_its, &se3, lane, pass)) {
       pose = se3;
       res.refined = 1;
       for (int q = lane; q < n_in; q += 64) L.tmp[q] = L.inl[q];
