@@ -215,8 +215,6 @@ struct IaTableFeats {
     return valid;
   }
   __device__ __forceinline__ void pos(int f, double *px, double *py) const { *px = F[f].px[0]; *py = F[f].px[1]; }
-  // the row, and behind it the point's status AND position in one go (row 0 when the feature has no point: read and ignored) — the
-  // chain row -> status -> position -> pixel was four dependent memory round trips in front of the window's loads, this is two
   // Round 6, for the precompute kernel: the row, and behind it the point's status AND position ASKED FOR (row 0 when the feature has no
   // point: read and ignored) but not looked at — the caller issues the reference window's loads (which need the row's pixel only) before
   // valid() / point() wait for the point's row.  Row -> status -> position -> pixel -> window rows one by one were eight dependent

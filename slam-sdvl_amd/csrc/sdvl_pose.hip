@@ -56,7 +56,7 @@ __device__ __forceinline__ void reproj_error(const sdvl_pose_obs &o, const M3 &R
 // ConvergePose over `npts` observations idx[0..npts) (npts <= 8), all in registers / small local arrays
 // kCache (round 6): the draw's observations are copied ONCE into the lane's column of an LDS block [npts][6][64] and read from there —
 // from global memory they were a dependent load per point and iteration (the loops over a run-time point count are not unrolled):
-// 5 x 10 memory round trips on a chain that has one wave per SIMD to hide them behind, half of the kernel's time.
+// up to 5 x 10 memory round trips on a chain that has one wave per SIMD to hide them behind.
 template <bool kCache>
 __device__ bool converge_pose_small(const sdvl_pose_obs *obs, const int *idx, int npts, const Rigid &frame_pose, double fx, int max_its,
                                     Rigid *se3, double *cache = nullptr, int lane = 0) {
@@ -191,7 +191,8 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Round 6: ONE WAVE per draw, for the sets whose launches leave the chip empty (a lone camera, configuration C's groups of 16).  The lane
+// Round 6: ONE WAVE per draw, for the sets whose launches leave the chip empty (a lone camera: sets of <= 4 trackers; configuration C's
+// groups of 16 — 1600 such waves per launch, four groups at a time — lose 10 % on it and keep the lane form).  The lane
 // form above makes a draw a chain of ~27 k dependent vector instructions (five points one after the other, the pivoted LDLT with every
 // swap predicated, and a wave runs until its SLOWEST draw has converged); here lanes 0..npts-1 take one point each, lanes 0..27 add the
 // points' normal-equation terms IN POINT ORDER (the rounding of the sequential loop, feature_align.cc:370-400), the solve and the SE3
