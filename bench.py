@@ -377,6 +377,36 @@ def cpu_baseline(frames, mapper=False, threads=1, ref_flags=False):
     return tracked / wall, tracked, wall
 
 
+def hw_queues_leg(args, n_queues):
+    """The resident leg once more in a CHILD process whose HIP runtime multiplexes the farm's streams onto `n_queues` hardware queues
+    (GPU_MAX_HW_QUEUES; the runtime's default is 4, the farm has 16 groups = 16 streams).  With 16 queues up to sixteen kernels share the chip:
+    the farm is 3-5 % faster on most boxes of the pool (profiles/r06/ab_round6.txt) and every dispatch lasts longer, so the per-kernel durations the
+    `roofline` block divides by stop describing a kernel — which is why `value` and `roofline` stay on the runtime's default and this figure is
+    reported beside them (value_hw_queues_16).  Started before this process touches the GPU, like the latency legs; skipped under a profiler."""
+    import subprocess
+    preload = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB"))
+    if "rocprof" in preload.lower():
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--texture", args.texture, "--distortion", args.distortion,
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--seqs", str(args.user_seqs), "--groups", str(args.groups), "--threads", str(args.threads),
+           "--workers", str(args.workers), "--fibers", str(args.fibers), "--cpu-frames", "0", "--host-steps", "0", "--sustained-frames", "0",
+           "--latency-frames", "0", "--lost-mix-steps", "0", "--hw-queues-leg", "0"]
+    try:
+        r = subprocess.run(cmd, env=dict(os.environ, GPU_MAX_HW_QUEUES=str(n_queues)), capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            sys.stderr.write("bench.py: hardware-queues leg failed (rc %d): %s\n" % (r.returncode, r.stderr[-400:]))
+            return None
+        d = json.loads(line[-1])
+    except (subprocess.SubprocessError, ValueError) as e:
+        sys.stderr.write("bench.py: hardware-queues leg failed: %s\n" % e)
+        return None
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "gpu_max_hw_queues": n_queues,
+            "note": "the same resident leg (same sequences, steps and farm shape) in a child process with GPU_MAX_HW_QUEUES=%d: the farm's 16 streams on "
+                    "16 hardware queues instead of the runtime's 4; not `value`: with sixteen kernels sharing the chip a dispatch's duration no longer "
+                    "describes its kernel, so the roofline block is measured on the runtime's default" % n_queues}
+
+
 def latency_legs(wl, texture, n_frames, mapper=False, dist=None):
     """The reference's own shape of use (main.cc:126-159): ONE camera through SDVL::HandleFrame, frame after frame — and 16 cameras,
     one host thread + one HIP stream each — measured by host/track_sequence, the C++ loop against the reference's API, as child
@@ -658,6 +688,9 @@ def main():
                          "(its own baseline), then this many steps in which 5 %% of the trackers are blinded (a featureless frame) for 5 frames every 50 "
                          "frames: they go TRACKING_BAD x3, relocalise over their keyframes inside the tabled step and rejoin; reported as value_lost_mix "
                          "and lost_mix; 0 = skip; default 100 for S-A / S-B on one GPU")
+    ap.add_argument("--hw-queues-leg", type=int, default=-1,
+                    help="hardware queues of the extra HW-QUEUES leg (the resident leg again in a child process with GPU_MAX_HW_QUEUES set to this; "
+                         "reported as value_hw_queues_16): 0 = skip; default 16 for S-A / S-B on one GPU when the caller has not set GPU_MAX_HW_QUEUES")
     ap.add_argument("--host-steps", type=int, default=-1,
                     help="steps of the second, HOST-FED leg (frames in pinned host memory, uploaded inside the step, as SDVL::HandleFrame(const cv::Mat&) "
                          "receives them): reported as value_host_fed next to the HBM-resident value; 0 = skip; "
@@ -671,6 +704,7 @@ def main():
     TEXTURE = TEXTURES[args.texture]
     global PROFILE_TAG
     PROFILE_TAG = "%s_%s" % (args.workload.lower().replace("-", ""), args.texture) + ("_" + args.distortion if args.distortion != "none" else "")
+    args.user_seqs = args.seqs   # what the caller asked for (0 = the workload's choices): handed on to the hardware-queues leg's child
     seq_choices = [args.seqs] if args.seqs > 0 else list(wl["seqs"])
     args.seqs = seq_choices[0]
     if args.cpu_frames < 0:
@@ -706,6 +740,9 @@ def main():
     latency = None
     if world == 1 and args.latency_frames > 2:
         latency = latency_legs(wl, args.texture, args.latency_frames, args.mapper, DISTORTION)   # child processes, before this one touches the GPU
+    if args.hw_queues_leg < 0:
+        args.hw_queues_leg = 16 if (world == 1 and args.workload in ("S-A", "S-B") and not args.mapper and "GPU_MAX_HW_QUEUES" not in os.environ) else 0
+    hw_queues = hw_queues_leg(args, args.hw_queues_leg) if (world == 1 and args.hw_queues_leg > 0) else None
     # (GPU_MAX_HW_QUEUES: the farm's 16 groups are 16 HIP streams and the runtime multiplexes a process's streams onto 4 hardware queues by
     #  default.  16 queues gave +5 % over three alternating pairs on one box (profiles/r05/ab_round5.txt) and nothing on the next
     #  (ab_queues_by_steps.txt: within the run-to-run spread at 10 / 20 / 40 / 80 steps), while every dispatch gets 2-10 x longer because
@@ -1286,6 +1323,7 @@ def main():
             "value_host_fed": host_fed["value"] if host_fed else None, "host_fed": host_fed,
             "value_sustained": sustained["value"] if sustained else None, "sustained": sustained,
             "value_lost_mix": lost_mix["value"] if lost_mix else None, "lost_mix": lost_mix,
+            "value_hw_queues_16": hw_queues["value"] if hw_queues else None, "hw_queues": hw_queues,
             "config": {"workload": "%s: synthetic %s %dx%d mono, textured plane z=2m, %d independent sequences per GPU, "
                                    "one tracked frame per sequence per step%s" % (args.workload, {"S-A": "TUM fr1-like", "S-B": "EuRoC MH_01-like (config_euroc.cfg)", "S-C": "roofline case"}[args.workload], W_IMG, H_IMG, B, "; map = reference mapper run inside the step (sequential mode)" if args.mapper else ""),
                        "input": "hbm_resident (frames rendered into HBM before the timed region; the host-fed rate is value_host_fed)",

@@ -80,6 +80,13 @@ def check(d, steps=4, warmup=1, mapper=False):
     if lm is not None:
         assert d["value_lost_mix"] == lm["value"] > 0 and lm["steps"] == 20 and lm["undisturbed_value"] > 0
         assert lm["frames_on_the_host_driven_path"] == 0 and lm["blinded_tracker_frames"] == 10 and lm["relocalized"] == 2, lm
+    # round 6: the resident leg again on 16 hardware queues (a child process with GPU_MAX_HW_QUEUES=16), reported beside `value`, never as it
+    hq = d["hw_queues"]
+    if not mapper:
+        assert hq is not None and d["value_hw_queues_16"] == hq["value"] > 0 and hq["gpu_max_hw_queues"] == 16 and hq["steps"] == steps
+        assert d["config"]["gpu_max_hw_queues"].startswith("runtime default")   # `value` itself was measured on the runtime's default
+    else:
+        assert hq is None and d["value_hw_queues_16"] is None
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "tracked frames/s" and "sample" in c
     assert 0 < c["one_core"] <= c["value"] * 1.05   # the all-core figure is at least the one-core figure
