@@ -688,9 +688,9 @@ inline size_t ia_pre_bytes(int n_jobs, int n_lv, int pitch) {
   return (nb * (48 * pitch * sizeof(float) + 3 * pitch * sizeof(double) + 32 * sizeof(double) + pitch) + 255) / 256 * 256;
 }
 
-template <class Feats>
+template <int kPreWaves, class Feats>
 __device__ __forceinline__ void ia_pre_body(const uint8_t *ref_img, int W, int H, int level, int nf, const Feats F, double fx, int pitch, IaPreOut o) {
-  __shared__ double s_redH[4][24];
+  __shared__ double s_redH[kPreWaves][24];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the level's image pointer and size come out of the job record by a run-time index: have them in scalar registers NOW — loaded where
   // they are first used, in front of the window's loads, they made those loads wait for everything issued before them
@@ -704,7 +704,7 @@ __device__ __forceinline__ void ia_pre_body(const uint8_t *ref_img, int W, int H
   for (int i = 0; i < 16; i++) h16[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 8; i++) h8[i] = 0.0;
-  for (int f = tid; f < pitch; f += 256) {
+  for (int f = tid; f < pitch; f += 64 * kPreWaves) {
     bool vis = false;
     double sums[3] = {0.0, 0.0, 0.0};
     if (f < nf) {
@@ -726,7 +726,7 @@ __device__ __forceinline__ void ia_pre_body(const uint8_t *ref_img, int W, int H
   const double t8 = wave_reduce_n<8>(h8, lane);
   if ((lane & 3) == 0) s_redH[wave][(lane >> 2) & 15] = t16;
   if ((lane & 7) == 0) s_redH[wave][16 + ((lane >> 3) & 7)] = t8;
-  __syncthreads();
+  if (kPreWaves > 1) __syncthreads(); else ia_wave_fence();
   if (wave == 0) {
     double Hm[36];
     int k = 0;
@@ -736,7 +736,7 @@ __device__ __forceinline__ void ia_pre_body(const uint8_t *ref_img, int W, int H
       for (int c = rr; c < 6; c++) {
         double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) sum += s_redH[w][k];
+        for (int w = 0; w < kPreWaves; w++) sum += s_redH[w][k];
         Hm[6 * rr + c] = sum;
         Hm[6 * c + rr] = sum;
         k++;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void image_align_pre_kernel(const IaJob *__res
   const int n_lv = prm.max_level - prm.min_level + 1;
   const int job = static_cast<int>(blockIdx.x) / n_lv, li = static_cast<int>(blockIdx.x) - job * n_lv, level = prm.max_level - li;
   const IaJob &jb = jobs[job];
-  ia_pre_body(jb.ref_level[level], jb.lw[level], jb.lh[level], level, jb.n_feat, IaRecordFeats{feats_all + jb.feat_begin}, cam.fx, pitch,
+  ia_pre_body<4>(jb.ref_level[level], jb.lw[level], jb.lh[level], level, jb.n_feat, IaRecordFeats{feats_all + jb.feat_begin}, cam.fx, pitch,
               ia_pre_block(pre, n_jobs, n_lv, pitch, job, li));
 }
 
@@ -786,13 +786,14 @@ __device__ __forceinline__ IaTableFeats ia_table_feats(const TrackJobDev &jb, co
                       se3_inverse(se3_from7(jb.last_pose)).t};
 }
 
-__global__ __launch_bounds__(256) void image_align_track_pre_kernel(const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points,
+template <int kPreWaves>
+__global__ __launch_bounds__(64 * kPreWaves) void image_align_track_pre_kernel(const TrackJobDev *__restrict__ jobs, const TrackPoint *__restrict__ points,
                                                                     const TrackFeat *__restrict__ feats0, const TrackFeat *__restrict__ feats1, int np,
                                                                     int nfeat_cap, Cam cam, sdvl_align_params prm, int n_jobs, int pitch, void *pre) {
   const int n_lv = prm.max_level - prm.min_level + 1;
   const int job = static_cast<int>(blockIdx.x) / n_lv, li = static_cast<int>(blockIdx.x) - job * n_lv, level = prm.max_level - li;
   const TrackJobDev &jb = jobs[job];
-  ia_pre_body(jb.last_level[level], jb.cur.lw[level], jb.cur.lh[level], level, jb.n_feat, ia_table_feats(jb, points, feats0, feats1, np, nfeat_cap), cam.fx,
+  ia_pre_body<kPreWaves>(jb.last_level[level], jb.cur.lw[level], jb.cur.lh[level], level, jb.n_feat, ia_table_feats(jb, points, feats0, feats1, np, nfeat_cap), cam.fx,
               pitch, ia_pre_block(pre, n_jobs, n_lv, pitch, job, li));
 }
 
@@ -955,7 +956,15 @@ int sdvl_image_align_track_enqueue(sdvl_ctx *ctx, int n_jobs, const TrackJobDev 
     if (rc_a) return rc_a;
   }
   const Cam c{cam->width, cam->height, cam->fx, cam->fy, cam->u0, cam->v0};
-  SDVL_LAUNCH(ctx, "image_align_pre", image_align_track_pre_kernel, dim3(static_cast<unsigned>(n_jobs) * n_lv), dim3(256), d_jobs, d_points, d_feats0, d_feats1,
+  // Round 6: beside the one-wave Gauss-Newton form (a farm's launches) the precompute runs ONE wave per (job, level) too, its lanes
+  // taking the level's features in rounds of 64: a four-wave workgroup is placed when four slots of one CU are free at the same moment,
+  // which among the other streams' one-wave workgroups happens far less often than its share — 2.4 -> 1.3 ms of dispatch time per step
+  // of 16 groups for the same instructions (+1.4 % tracked frames/s).  Small sets (a lone camera) keep four waves: nobody else wants the CU.
+  if (kw == 1)
+    SDVL_LAUNCH(ctx, "image_align_pre", image_align_track_pre_kernel<1>, dim3(static_cast<unsigned>(n_jobs) * n_lv), dim3(64), d_jobs, d_points, d_feats0, d_feats1,
+                np, nfeat_cap, c, *p, n_jobs, max_f, ctx->d_work);
+  else
+  SDVL_LAUNCH(ctx, "image_align_pre", image_align_track_pre_kernel<4>, dim3(static_cast<unsigned>(n_jobs) * n_lv), dim3(256), d_jobs, d_points, d_feats0, d_feats1,
               np, nfeat_cap, c, *p, n_jobs, max_f, ctx->d_work);
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   sdvl_timer_events(ctx, max_nf > kLdsMaxF ? "image_align_big" : "image_align", &ev_a, &ev_b);

@@ -777,8 +777,12 @@ int sdvl_track_search(sdvl_ctx *ctx, sdvl_track_set *s) {
     const size_t lds = static_cast<size_t>(stride) * (8 + 16 + 2) + 64;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     sdvl_timer_events(ctx, "track_project", &ev_a, &ev_b);
-    // a lane per feature of last_frame: 256 lanes cover the ~190 features of the metric configuration, configuration C's ~850 take 512
-    const int proj_threads = stride <= 256 ? 256 : kProjThreads;
+    // a lane per feature of last_frame: 256 lanes cover the ~190 features of the metric configuration, configuration C's ~850 take 512.
+    // Round 6: a farm's launches (sets of more than 32 trackers) take 128 — among the other streams' one-wave workgroups a workgroup
+    // is placed when ALL its waves find a slot on one CU at the same moment, and four are found far less often than two: the kernel's
+    // dispatch time in company is how long its workgroups wait to be placed (2.0 -> 1.5 ms per step of 16 groups, +3 % tracked frames/s;
+    // 64 threads: +1 % — the rank loop gets longer)
+    const int proj_threads = stride <= 256 ? (s->n > 32 ? 128 : 256) : kProjThreads;
     hipExtLaunchKernelGGL(track_project_kernel, dim3(n_jobs), dim3(proj_threads), lds, ctx->stream, ev_a, ev_b, 0,
                           static_cast<const TrackJobDev *>(s->d_jobs), s->d_points, static_cast<const TrackFeat *>(s->d_feats[0]),
                           static_cast<const TrackFeat *>(s->d_feats[1]), s->np, s->nf, stride, s->mm, s->max_its,
